@@ -1,0 +1,114 @@
+/*
+ * libmaskbev_hip.so — C ABI of the MI355X (gfx950) hot-path kernels of mask_bev_amd.
+ *
+ * Conventions (SURVEY.md §8b "Native (C-ABI) layer"):
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - the caller owns every buffer, including `workspace`; the library never allocates, frees or
+ *     retains pointers, keeps no mutable global state and is re-entrant;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no hidden device sync;
+ *   - return value: 0 = success, < 0 = mbv_status (bad argument), > 0 = hipError_t of a failed launch;
+ *   - no exceptions, no abort, no stdout.
+ *
+ * Each entry point cites the reference interface it replaces (file:line under the reference tree).
+ */
+#ifndef MASKBEV_HIP_H_
+#define MASKBEV_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MBV_OK = 0,
+  MBV_ERR_BAD_ARG = -1,
+  MBV_ERR_WORKSPACE = -2,
+  MBV_ERR_UNSUPPORTED = -3
+} mbv_status;
+
+/* Library/ABI version; bumped whenever a signature below changes. */
+int mbv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1 — range filter + hard voxelisation of a batch of scans.
+ * Replaces: MaskBevEncoder._filter_in_range (mask_bev/models/encoders/mask_bev_encoders.py:113-117)
+ *           + MaskBevEncoder.voxelize (:95-111) → mmcv.ops.Voxelization (:69,100; mmcv 2.0.0
+ *           hard_voxelize_forward, deterministic).
+ * Semantics (bit-exact with the CPU reference): per point c = floor((p - min) / vs) in f32 with IEEE
+ * division; pillar ids in order of FIRST APPEARANCE in the scan's point list; a pillar keeps its first
+ * `max_points` points in input order; pillars beyond `max_voxels` per scan are dropped.
+ *
+ * points        (total_points, point_dim) f32, scans concatenated
+ * scan_offsets  (batch + 1) i32, scan b owns points [scan_offsets[b], scan_offsets[b+1])
+ * range/vs/grid x,y,z bounds (already rounded to f32), voxel sizes, grid sizes
+ * prefilter     1 → apply the strict `min < p < max` test of :113-117 first
+ * pillar_capacity  rows available in the outputs (>= min(total_points, batch*max_voxels))
+ * coors         (pillar_capacity, 4) i32  (b, z, y, x)
+ * num_points    (pillar_capacity) i32
+ * pillar_points (pillar_capacity, max_points) i32: index into `points` of each kept point, -1 padded
+ * row_start     (pillar_capacity + 1) i32: exclusive prefix sum of num_points (compact row of slot 0)
+ * cell_to_pillar (batch, gz*gy*gx) i32: pillar id of every BEV cell, -1 if empty
+ * counts        (batch + 2) i32: pillars per scan, then total pillars V, then total kept points K
+ */
+size_t mbv_voxelize_workspace_bytes(int64_t total_points, int32_t batch, int64_t cells_per_scan);
+
+int mbv_voxelize(const float* points, int32_t point_dim, int64_t total_points,
+                 const int32_t* scan_offsets, int32_t batch,
+                 float x_min, float y_min, float z_min, float x_max, float y_max, float z_max,
+                 float vx, float vy, float vz, int32_t gx, int32_t gy, int32_t gz,
+                 int32_t prefilter, int32_t max_points, int32_t max_voxels, int64_t pillar_capacity,
+                 int32_t* coors, int32_t* num_points, int32_t* pillar_points, int32_t* row_start,
+                 int32_t* cell_to_pillar, int32_t* counts,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Dense (V, max_points, point_dim) zero-padded voxel tensor, i.e. the first return value of
+ * mmcv.ops.Voxelization as exposed by MaskBevEncoder.voxelize (mask_bev_encoders.py:95-111). */
+int mbv_gather_voxels(const float* points, int32_t point_dim, const int32_t* pillar_points,
+                      int64_t num_pillars, int32_t max_points, float* voxels, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2a — pillar decoration over REAL points only (no zero padding).
+ * Replaces the input stage of mmdet3d PillarFeatureNet.forward(legacy=True, with_distance=True)
+ * reached from MaskBevEncoder.encode (mask_bev_encoders.py:70-72,119-120).
+ * rows  (K, point_dim + 7) f32 : [fc_x, fc_y, fc_z, extra.., cl_x, cl_y, cl_z, fc_x, fc_y, fc_z, |fc|]
+ *        (fc = offset from the pillar centre — the legacy aliasing — cl = offset from the pillar mean)
+ * row_pillar (K) i64 : pillar of each compact row
+ */
+int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pillar_points,
+                     const int32_t* num_points, const int32_t* row_start, const int32_t* coors,
+                     int64_t num_pillars, int32_t max_points,
+                     float vx, float vy, float vz, float x_off, float y_off, float z_off,
+                     float* rows, int64_t* row_pillar, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3 — PointPillarsScatter fused with the (C, H, W) LayerNorm; the dense canvas is never built.
+ * Replaces: MaskBevEncoder.middle_encode (mask_bev_encoders.py:122-123 → mmdet3d PointPillarsScatter)
+ *           + nn.LayerNorm([C, ny, nx], eps) (:75, :92).
+ * feats (V, C) f32; pillar_batch_start (batch+1) i32 prefix of pillars per scan (scan b owns pillars
+ * [start[b], start[b+1])); cell_to_pillar (batch, cells) i32; weight/bias (C, cells) f32;
+ * out (batch, C, cells) f32; stats (batch, 2) f32 = (mean, rstd), saved for backward.
+ * workspace: mbv_scatter_layernorm_workspace_bytes(batch).
+ */
+size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch);
+
+int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
+                              const int32_t* cell_to_pillar, const float* weight, const float* bias,
+                              int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
+                              float* out, float* stats, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* Backward: grad_out (batch, C, cells) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
+ * `accumulate` != 0 adds into grad_weight / grad_bias instead of overwriting them. */
+int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats,
+                              const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
+                              const float* weight, const float* stats,
+                              int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
+                              float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKBEV_HIP_H_ */

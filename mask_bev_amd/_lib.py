@@ -1,0 +1,74 @@
+"""ctypes binding of ``libmaskbev_hip.so`` (declared in ``include/maskbev_hip.h``).
+
+The product path has no CPU fallback: if the library is missing or a kernel call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
+from typing import Dict, List, Tuple
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
+
+ABI_VERSION = 1
+
+
+class MaskBevHipError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_F = c_float
+_I = c_int32
+_L = c_int64
+
+# symbol -> (restype, argtypes); mirrors include/maskbev_hip.h one to one
+SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
+    'mbv_abi_version': (ctypes.c_int, []),
+    'mbv_voxelize_workspace_bytes': (c_size_t, [_L, _I, _L]),
+    'mbv_voxelize': (ctypes.c_int, [_P, _I, _L, _P, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _L,
+                                    _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'mbv_gather_voxels': (ctypes.c_int, [_P, _I, _P, _L, _I, _P, _P]),
+    'mbv_pfn_decorate': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    'mbv_scatter_layernorm_workspace_bytes': (c_size_t, [_I]),
+    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, c_size_t, _P]),
+    'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
+                                                 c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library, binding every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MaskBevHipError(
+            f'{LIB_PATH} is missing. Build it with `python -m mask_bev_amd.build` (needs hipcc). '
+            'mask_bev_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MaskBevHipError(f'{LIB_PATH} does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mbv_abi_version()
+    if v != ABI_VERSION:
+        raise MaskBevHipError(f'libmaskbev_hip.so ABI {v} != expected {ABI_VERSION}; rebuild it')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        names = {-1: 'MBV_ERR_BAD_ARG', -2: 'MBV_ERR_WORKSPACE', -3: 'MBV_ERR_UNSUPPORTED'}
+        raise MaskBevHipError(f'{what} failed: {names.get(rc, rc)}')
+    raise MaskBevHipError(f'{what} failed: hipError_t {rc}')

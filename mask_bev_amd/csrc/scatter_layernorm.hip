@@ -1,0 +1,379 @@
+// K3 — PointPillarsScatter fused with the (C, ny, nx) LayerNorm, forward and backward, gfx950.
+//
+// Replaces mask_bev/models/encoders/mask_bev_encoders.py:122-123 (mmdet3d PointPillarsScatter) and
+// :75,:92 (nn.LayerNorm([C, ny, nx], eps=1e-3)).
+//
+// HBM-bound.  The reference writes a dense zero canvas (134 MB / scan at 128x512x512), reads it back for
+// the statistics and again for the affine.  Here the canvas never exists:
+//   * mean / variance come from the V x C pillar features alone (every empty cell is exactly 0);
+//   * the apply kernel streams weight / bias once per BATCH (registers, reused for every scan) and
+//     writes the output once; pillar rows are gathered through an LDS tile that transposes
+//     (pillar, channel) rows into the x-contiguous NCHW layout so every global access is a full
+//     16 B / lane coalesced access.
+// Algorithmic bytes per batch: 2*C*G*4 (weight + bias) + B*C*G*4 (out) + V*C*4 (+ B*G*4 cell map).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kCT = 32;  // channels per block tile (4 waves x 8 channels)
+
+// ---------------------------------------------------------------------------------------------
+// statistics over the sparse features
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ln_stats(const float* __restrict__ feats,
+                                                  const int32_t* __restrict__ pillar_batch_start, int channels,
+                                                  double* __restrict__ sums /* [batch][2] */) {
+  const int b = blockIdx.y;
+  const int64_t begin = (int64_t)pillar_batch_start[b] * channels;
+  const int64_t end = (int64_t)pillar_batch_start[b + 1] * channels;
+  double s = 0.0, q = 0.0;
+  // channels % 4 == 0 is enforced by the launcher, so the range is float4 aligned
+  for (int64_t i = begin + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < end;
+       i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(feats + i);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  __shared__ double red[2][4];
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[b * 2 + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[b * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+__global__ void k_ln_finalize(const double* __restrict__ sums, int batch, double inv_count, float eps,
+                              float* __restrict__ stats) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double mean = sums[b * 2] * inv_count;
+  double var = sums[b * 2 + 1] * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[b * 2 + 0] = (float)mean;
+  stats[b * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile helpers.  A block owns one BEV row y, XT = 64*VEC consecutive cells and kCT channels.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+struct Tile {
+  static constexpr int XT = 64 * VEC;          // cells per tile
+  static constexpr int LD = XT + 4;            // padded row (keeps float4 reads 16 B aligned)
+  static constexpr int GROUPS = 256 / XT;      // threads sharing one cell in the gather phase
+  static constexpr int CH_PER_THREAD = kCT / GROUPS;
+};
+
+// gather feats[pid][c0 .. c0+kCT) of the tile's cells into lds[c][x] (zeros for empty cells)
+template <int VEC>
+__device__ __forceinline__ void gather_tile(const float* __restrict__ feats, int channels, int c0, int32_t pid,
+                                            float* __restrict__ lds) {
+  using T = Tile<VEC>;
+  const int cell = threadIdx.x % T::XT;
+  const int grp = threadIdx.x / T::XT;
+  const int cbeg = grp * T::CH_PER_THREAD;
+#pragma unroll
+  for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
+    const int c = c0 + cbeg + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pid >= 0 && c < channels) v = *reinterpret_cast<const float4*>(feats + (int64_t)pid * channels + c);
+    lds[(cbeg + k + 0) * T::LD + cell] = v.x;
+    lds[(cbeg + k + 1) * T::LD + cell] = v.y;
+    lds[(cbeg + k + 2) * T::LD + cell] = v.z;
+    lds[(cbeg + k + 3) * T::LD + cell] = v.w;
+  }
+}
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  using type = float4;
+};
+template <>
+struct VecT<1> {
+  using type = float;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+  } else {
+    r[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    *p = r[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward apply
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feats,
+                                                  const int32_t* __restrict__ cell_to_pillar,
+                                                  const float* __restrict__ weight, const float* __restrict__ bias,
+                                                  const float* __restrict__ stats, int batch, int channels, int ny,
+                                                  int nx, int xtiles, float* __restrict__ out) {
+  using T = Tile<VEC>;
+  __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
+  const int y = blockIdx.x / xtiles;
+  const int x0 = (blockIdx.x % xtiles) * T::XT;
+  const int c0 = blockIdx.y * kCT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t cells = (int64_t)ny * nx;
+  const int xv = x0 + lane * VEC;            // first x of this lane in the apply phase
+  const bool x_ok = xv < nx;                  // nx % VEC == 0 → the whole vector is in range
+  // affine parameters: read once, reused for every scan of the batch
+  float w[8][VEC], bz[8][VEC];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + wave * 8 + k;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; bz[k][e] = 0.f; }
+    if (x_ok && c < channels) {
+      const int64_t o = ((int64_t)c * ny + y) * nx + xv;
+      load_vec<VEC>(weight + o, w[k]);
+      load_vec<VEC>(bias + o, bz[k]);
+    }
+  }
+  const int gcell = threadIdx.x % T::XT;
+  for (int b = 0; b < batch; ++b) {
+    const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+    int32_t pid = -1;
+    if (x0 + gcell < nx) pid = cell_to_pillar[(int64_t)b * cells + (int64_t)y * nx + x0 + gcell];
+    gather_tile<VEC>(feats, channels, c0, pid, lds);
+    __syncthreads();
+    if (x_ok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int cl = wave * 8 + k;
+        const int c = c0 + cl;
+        if (c < channels) {
+          float f[VEC], r[VEC];
+          load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) r[e] = (f[e] - mean) * rstd * w[k][e] + bz[k][e];
+          store_vec<VEC>(out + (((int64_t)b * channels + c) * ny + y) * nx + xv, r);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, pass 1: grad_weight / grad_bias, per-scan sums of (g*w) and (g*w*xhat), and g*w at the
+// occupied cells scattered back into (pillar, channel) rows.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ grad_out,
+                                                      const float* __restrict__ feats,
+                                                      const int32_t* __restrict__ cell_to_pillar,
+                                                      const float* __restrict__ weight,
+                                                      const float* __restrict__ stats, int batch, int channels,
+                                                      int ny, int nx, int xtiles, float* __restrict__ grad_feats,
+                                                      float* __restrict__ grad_weight, float* __restrict__ grad_bias,
+                                                      int accumulate, double* __restrict__ sums /* [batch][2] */) {
+  using T = Tile<VEC>;
+  __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
+  __shared__ double red[2][4];
+  const int y = blockIdx.x / xtiles;
+  const int x0 = (blockIdx.x % xtiles) * T::XT;
+  const int c0 = blockIdx.y * kCT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t cells = (int64_t)ny * nx;
+  const int xv = x0 + lane * VEC;
+  const bool x_ok = xv < nx;
+  float w[8][VEC], dw[8][VEC], db[8][VEC];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + wave * 8 + k;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; dw[k][e] = 0.f; db[k][e] = 0.f; }
+    if (x_ok && c < channels) load_vec<VEC>(weight + ((int64_t)c * ny + y) * nx + xv, w[k]);
+  }
+  const int gcell = threadIdx.x % T::XT;
+  const int grp = threadIdx.x / T::XT;
+  for (int b = 0; b < batch; ++b) {
+    const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+    int32_t pid = -1;
+    if (x0 + gcell < nx) pid = cell_to_pillar[(int64_t)b * cells + (int64_t)y * nx + x0 + gcell];
+    gather_tile<VEC>(feats, channels, c0, pid, lds);
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    if (x_ok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int cl = wave * 8 + k;
+        const int c = c0 + cl;
+        if (c < channels) {
+          float f[VEC], g[VEC], gw[VEC];
+          load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
+          load_vec<VEC>(grad_out + (((int64_t)b * channels + c) * ny + y) * nx + xv, g);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float xhat = (f[e] - mean) * rstd;
+            dw[k][e] += g[e] * xhat;
+            db[k][e] += g[e];
+            gw[e] = g[e] * w[k][e];
+            s1 += (double)gw[e];
+            s2 += (double)gw[e] * (double)xhat;
+          }
+          store_vec<VEC>(&lds[cl * T::LD + lane * VEC], gw);
+        }
+      }
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&sums[b * 2 + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      atomicAdd(&sums[b * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+    // scatter g*w of the occupied cells back to (pillar, channel) rows
+    if (pid >= 0) {
+      const int cbeg = grp * T::CH_PER_THREAD;
+#pragma unroll
+      for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
+        const int c = c0 + cbeg + k;
+        if (c < channels) {
+          const float4 v = make_float4(lds[(cbeg + k + 0) * T::LD + gcell], lds[(cbeg + k + 1) * T::LD + gcell],
+                                       lds[(cbeg + k + 2) * T::LD + gcell], lds[(cbeg + k + 3) * T::LD + gcell]);
+          *reinterpret_cast<float4*>(grad_feats + (int64_t)pid * channels + c) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (x_ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + wave * 8 + k;
+      if (c < channels) {
+        const int64_t o = ((int64_t)c * ny + y) * nx + xv;
+        if (accumulate) {
+          float a[VEC], bb[VEC];
+          load_vec<VEC>(grad_weight + o, a);
+          load_vec<VEC>(grad_bias + o, bb);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { dw[k][e] += a[e]; db[k][e] += bb[e]; }
+        }
+        store_vec<VEC>(grad_weight + o, dw[k]);
+        store_vec<VEC>(grad_bias + o, db[k]);
+      }
+    }
+  }
+}
+
+// backward, pass 2: dfeat = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat)) on the (V, C) rows
+__global__ void __launch_bounds__(256) k_ln_bwd_rows(const float* __restrict__ feats,
+                                                     const int32_t* __restrict__ pillar_batch_start, int batch,
+                                                     int channels, int64_t num_pillars,
+                                                     const float* __restrict__ stats,
+                                                     const double* __restrict__ sums, double inv_count,
+                                                     float* __restrict__ grad_feats) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= num_pillars * channels) return;
+  const int64_t v = i4 / channels;
+  int b = 0;
+  while (b + 1 < batch && v >= pillar_batch_start[b + 1]) ++b;
+  const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+  const float m1 = (float)(sums[b * 2] * inv_count), m2 = (float)(sums[b * 2 + 1] * inv_count);
+  const float4 f = *reinterpret_cast<const float4*>(feats + i4);
+  float4 g = *reinterpret_cast<const float4*>(grad_feats + i4);
+  g.x = rstd * (g.x - m1 - (f.x - mean) * rstd * m2);
+  g.y = rstd * (g.y - m1 - (f.y - mean) * rstd * m2);
+  g.z = rstd * (g.z - m1 - (f.z - mean) * rstd * m2);
+  g.w = rstd * (g.w - m1 - (f.w - mean) * rstd * m2);
+  *reinterpret_cast<float4*>(grad_feats + i4) = g;
+}
+
+}  // namespace
+
+extern "C" size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch) {
+  if (batch <= 0) return 0;
+  return mbv_align_up(sizeof(double) * 2 * (size_t)batch, 256);
+}
+
+extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
+                                         const int32_t* cell_to_pillar, const float* weight, const float* bias,
+                                         int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps, float* out,
+                                         float* stats, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0) return MBV_ERR_BAD_ARG;
+  if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
+  if (!feats || !pillar_batch_start || !cell_to_pillar || !weight || !bias || !out || !stats) return MBV_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
+  double* sums = reinterpret_cast<double*>(workspace);
+  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * batch, stream));
+  hipLaunchKernelGGL(k_ln_stats, dim3(256, batch), dim3(256), 0, stream, feats, pillar_batch_start, channels, sums);
+  MBV_CHECK_LAUNCH();
+  const double inv_count = 1.0 / ((double)channels * ny * nx);
+  hipLaunchKernelGGL(k_ln_finalize, dim3((batch + 63) / 64), dim3(64), 0, stream, sums, batch, inv_count, eps, stats);
+  MBV_CHECK_LAUNCH();
+  const int ctiles = (channels + kCT - 1) / kCT;
+  if (nx % 4 == 0) {
+    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
+    hipLaunchKernelGGL(k_ln_apply<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar, weight,
+                       bias, stats, batch, channels, ny, nx, xtiles, out);
+  } else {
+    const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
+    hipLaunchKernelGGL(k_ln_apply<1>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar, weight,
+                       bias, stats, batch, channels, ny, nx, xtiles, out);
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats, const int32_t* pillar_batch_start,
+                                         const int32_t* cell_to_pillar, const float* weight, const float* stats,
+                                         int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
+                                         float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0) return MBV_ERR_BAD_ARG;
+  if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
+  if (!grad_out || !feats || !pillar_batch_start || !cell_to_pillar || !weight || !stats || !grad_feats ||
+      !grad_weight || !grad_bias)
+    return MBV_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
+  double* sums = reinterpret_cast<double*>(workspace);
+  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * batch, stream));
+  const int ctiles = (channels + kCT - 1) / kCT;
+  if (nx % 4 == 0) {
+    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
+    hipLaunchKernelGGL(k_ln_bwd_dense<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, grad_out, feats,
+                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
+                       grad_bias, accumulate, sums);
+  } else {
+    const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
+    hipLaunchKernelGGL(k_ln_bwd_dense<1>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, grad_out, feats,
+                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
+                       grad_bias, accumulate, sums);
+  }
+  MBV_CHECK_LAUNCH();
+  if (num_pillars > 0) {
+    const double inv_count = 1.0 / ((double)channels * ny * nx);
+    const int64_t n4 = num_pillars * channels / 4;
+    hipLaunchKernelGGL(k_ln_bwd_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, feats,
+                       pillar_batch_start, batch, channels, num_pillars, stats, sums, inv_count, grad_feats);
+    MBV_CHECK_LAUNCH();
+  }
+  return MBV_OK;
+}

@@ -1,0 +1,209 @@
+"""Building blocks shared by the backbone and the head.
+
+Parameter names follow the checkpoints of the reference stack (mmcv 2.0.0 / mmdet 3.0.0 leaf names, see
+SURVEY.md §8f-4) so that ``state_dict()`` keys are interchangeable; the implementations are our own and
+are organised around channels-last (B, H, W, C) token maps, which is what the gfx950 kernels consume.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def trunc_normal_(t: torch.Tensor, std: float = 0.02) -> torch.Tensor:
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std)
+
+
+class FFN(nn.Module):
+    """Two-layer MLP with residual; keys ``layers.0.0.*`` / ``layers.1.*`` (mmcv ``FFN`` layout, used at
+    mask_bev/models/networks/swin/swin.py:347-355 and mask_bev_panoptic_head.py:137-142,168-175)."""
+
+    def __init__(self, embed_dims: int, feedforward_channels: int, act: str = 'gelu'):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU() if act == 'gelu' else nn.ReLU()),
+            nn.Linear(feedforward_channels, embed_dims))
+
+    def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return (x if identity is None else identity) + self.layers(x)
+
+
+def corner_pad(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
+    """Pad bottom/right of an NCHW map so a (k, stride s) kernel tiles it ('corner' adaptive padding)."""
+    h, w = x.shape[-2:]
+    ph = max((math.ceil(h / s) - 1) * s + k - h, 0)
+    pw = max((math.ceil(w / s) - 1) * s + k - w, 0)
+    return F.pad(x, [0, pw, 0, ph]) if (ph or pw) else x
+
+
+class PatchEmbed(nn.Module):
+    """Non-overlapping patch projection + LayerNorm → channels-last tokens (B, H', W', E).
+    Keys ``projection.*`` / ``norm.*`` (mmdet ``PatchEmbed``, built at swin.py:579-586)."""
+
+    def __init__(self, in_channels: int, embed_dims: int, patch: int):
+        super().__init__()
+        self.patch = patch
+        self.projection = nn.Conv2d(in_channels, embed_dims, kernel_size=patch, stride=patch)
+        self.norm = nn.LayerNorm(embed_dims)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.projection(corner_pad(x, self.patch, self.patch))
+        return self.norm(x.permute(0, 2, 3, 1))
+
+
+class PatchMerging(nn.Module):
+    """2x2 neighbourhood concat (channel order c*4 + kh*2 + kw, as ``nn.Unfold``) → LN(4C) → Linear(4C→2C).
+    Keys ``norm.*`` / ``reduction.weight`` (mmdet ``PatchMerging``, built at swin.py:611-616)."""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
+        super().__init__()
+        self.stride = stride
+        self.norm = nn.LayerNorm(4 * in_channels)
+        self.reduction = nn.Linear(4 * in_channels, out_channels, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:          # (B, H, W, C) → (B, H', W', 2C)
+        b, h, w, c = x.shape
+        s = self.stride
+        ph = max((math.ceil(h / s) - 1) * s + 2 - h, 0)
+        pw = max((math.ceil(w / s) - 1) * s + 2 - w, 0)
+        if ph or pw:
+            x = F.pad(x, (0, 0, 0, pw, 0, ph))
+            h, w = h + ph, w + pw
+        oh, ow = (h - 2) // s + 1, (w - 2) // s + 1
+        if s == 2:
+            x = x[:, :oh * 2, :ow * 2].reshape(b, oh, 2, ow, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(b, oh, ow, 4 * c)
+        else:
+            x = F.unfold(x.permute(0, 3, 1, 2), kernel_size=2, stride=s).transpose(1, 2).reshape(b, oh, ow, 4 * c)
+        return self.reduction(self.norm(x))
+
+
+class ConvGN(nn.Module):
+    """conv → GroupNorm(32) [→ ReLU]; keys ``conv.*`` / ``gn.*`` (mmcv ``ConvModule`` layout used by the
+    pixel decoder configured at mask_bev_panoptic_head.py:119-123)."""
+
+    def __init__(self, cin: int, cout: int, k: int, bias: bool, relu: bool, groups: int = 32):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=k // 2, bias=bias)
+        self.gn = nn.GroupNorm(groups, cout)
+        self.relu = relu
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.gn(self.conv(x))
+        return F.relu(x) if self.relu else x
+
+
+_SINE_CACHE: Dict[Tuple, torch.Tensor] = {}
+
+
+def sine_positional_encoding(h: int, w: int, num_feats: int, device, temperature: float = 10000.0,
+                             scale: float = 2 * math.pi, eps: float = 1e-6) -> torch.Tensor:
+    """(1, 2*num_feats, H, W) normalised sine encoding of an un-padded map (mmdet ``SinePositionalEncoding``
+    with normalize=True; mask_bev_panoptic_head.py:144-149).  Constant per shape, so cached on device."""
+    key = (h, w, num_feats, str(device))
+    pe = _SINE_CACHE.get(key)
+    if pe is None:
+        y = torch.arange(1, h + 1, dtype=torch.float32, device=device).view(h, 1).expand(h, w)
+        x = torch.arange(1, w + 1, dtype=torch.float32, device=device).view(1, w).expand(h, w)
+        y = y / (h + eps) * scale
+        x = x / (w + eps) * scale
+        dim_t = torch.arange(num_feats, dtype=torch.float32, device=device)
+        dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode='floor') / num_feats)
+        px = x[:, :, None] / dim_t
+        py = y[:, :, None] / dim_t
+        px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).view(h, w, -1)
+        py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).view(h, w, -1)
+        pe = torch.cat((py, px), dim=2).permute(2, 0, 1).unsqueeze(0).contiguous()
+        _SINE_CACHE[key] = pe
+    return pe
+
+
+class _AttnParams(nn.Module):
+    """Parameter holder with ``nn.MultiheadAttention``'s names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, embed_dims: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dims, embed_dims))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dims))
+        self.out_proj = nn.Linear(embed_dims, embed_dims)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class MultiheadAttention(nn.Module):
+    """Residual multi-head attention with positional terms added to q / k only.
+    Keys ``attn.in_proj_weight`` …  (mmcv ``MultiheadAttention`` wrapping ``nn.MultiheadAttention``;
+    configured at mask_bev_panoptic_head.py:154-167, called from the decoder loop of
+    mask_bev/models/networks/mask2former_head/mask2former_head.py:542-553)."""
+
+    def __init__(self, embed_dims: int, num_heads: int):
+        super().__init__()
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.attn = _AttnParams(embed_dims)
+
+    def forward(self, query, key, value, query_pos=None, key_pos=None, blocked: Optional[torch.Tensor] = None):
+        """query (B, Q, E), key/value (B, L, E); ``blocked`` (B, 1|H, Q, L) bool, True = may NOT attend."""
+        e, h = self.embed_dims, self.num_heads
+        w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
+        q = query + query_pos if query_pos is not None else query
+        k = key + key_pos if key_pos is not None else key
+        b, nq, _ = q.shape
+        nl = k.shape[1]
+        q = F.linear(q, w[:e], bias[:e]).view(b, nq, h, e // h).transpose(1, 2)
+        k = F.linear(k, w[e:2 * e], bias[e:2 * e]).view(b, nl, h, e // h).transpose(1, 2)
+        v = F.linear(value, w[2 * e:], bias[2 * e:]).view(b, nl, h, e // h).transpose(1, 2)
+        mask = None if blocked is None else ~blocked
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        o = o.transpose(1, 2).reshape(b, nq, e)
+        return query + self.attn.out_proj(o)
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """Multi-scale deformable self-attention of the pixel decoder (mmcv ``MultiScaleDeformableAttention``;
+    configured at mask_bev_panoptic_head.py:127-136).  Keys ``sampling_offsets``, ``attention_weights``,
+    ``value_proj``, ``output_proj``."""
+
+    def __init__(self, embed_dims: int = 256, num_heads: int = 8, num_levels: int = 3, num_points: int = 4):
+        super().__init__()
+        self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.zeros_(self.sampling_offsets.weight)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2).repeat(
+            1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.zeros_(self.value_proj.bias)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.zeros_(self.output_proj.bias)
+
+    def forward(self, query: torch.Tensor, query_pos: torch.Tensor, reference_points: torch.Tensor,
+                spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor):
+        """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y)."""
+        b, n, e = query.shape
+        h, l, p = self.num_heads, self.num_levels, self.num_points
+        q = query + query_pos
+        value = self.value_proj(query).view(b, n, h, e // h)
+        off = self.sampling_offsets(q).view(b, n, h, l, p, 2)
+        aw = self.attention_weights(q).view(b, n, h, l * p).softmax(-1).view(b, n, h, l, p)
+        normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(off.dtype)          # (L, 2) = (w, h)
+        loc = reference_points.view(1, n, 1, 1, 1, 2) + off / normalizer.view(1, 1, 1, l, 1, 2)
+        out = ops.ms_deform_attn(value, spatial_shapes, shapes_t, level_start, loc, aw)
+        return self.output_proj(out) + query

@@ -1,0 +1,196 @@
+"""Torch-facing wrappers of the C-ABI kernels (``include/maskbev_hip.h``).
+
+PyTorch is plumbing here: it owns device memory, the stream and the autograd graph; every function
+below enqueues hand-written gfx950 kernels on ``torch.cuda.current_stream()`` through ctypes.
+There is no CPU fallback — tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MaskBevHipError, check
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MaskBevHipError('mask_bev_amd kernels need ROCm device tensors (no CPU fallback); got a '
+                                  f'{t.device} tensor')
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------
+# K1 voxelisation
+# --------------------------------------------------------------------------------------
+@dataclass
+class VoxelGeometry:
+    """Grid description; mirrors the arguments of mmcv ``Voxelization`` built at
+    mask_bev/models/encoders/mask_bev_encoders.py:67-69 (bounds are rounded to f32 by the kernel ABI)."""
+    pc_range: Sequence[float]      # x_min, y_min, z_min, x_max, y_max, z_max
+    voxel_size: Sequence[float]    # vx, vy, vz
+    grid: Sequence[int]            # gx, gy, gz
+
+    @staticmethod
+    def from_ranges(pc_range: Sequence[float], voxel_size: Sequence[float]) -> 'VoxelGeometry':
+        r = torch.tensor(list(pc_range), dtype=torch.float32)
+        v = torch.tensor(list(voxel_size), dtype=torch.float32)
+        grid = torch.round((r[3:] - r[:3]) / v).long().tolist()     # mmcv Voxelization.__init__ [upstream]
+        return VoxelGeometry(list(pc_range), list(voxel_size), grid)
+
+    @property
+    def cells(self) -> int:
+        return int(self.grid[0]) * int(self.grid[1]) * int(self.grid[2])
+
+
+@dataclass
+class Pillars:
+    """Output of :func:`voxelize` (all device tensors except the python ints)."""
+    points: torch.Tensor            # (N_total, D) f32, the concatenated scans
+    scan_offsets: torch.Tensor      # (B+1,) i32
+    coors: torch.Tensor             # (V, 4) i32 (b, z, y, x)
+    num_points: torch.Tensor        # (V,) i32
+    pillar_points: torch.Tensor     # (V, P) i32 index into points, -1 padded
+    row_start: torch.Tensor         # (V+1,) i32
+    cell_to_pillar: torch.Tensor    # (B, cells) i32
+    pillar_batch_start: torch.Tensor  # (B+1,) i32
+    pillars_per_scan: List[int]
+    num_pillars: int
+    num_rows: int
+    max_points: int
+
+
+def voxelize(point_clouds: Sequence[torch.Tensor], geom: VoxelGeometry, max_points: int, max_voxels: int,
+             prefilter: bool = True) -> Pillars:
+    """Range filter + hard voxelisation of a batch of scans (K1).  One host sync (reading V and K)."""
+    lib = _lib.load()
+    if len(point_clouds) == 0:
+        raise ValueError('empty batch')
+    _need_gpu(*point_clouds)
+    dev = point_clouds[0].device
+    dim = int(point_clouds[0].shape[1])
+    lens = [int(p.shape[0]) for p in point_clouds]
+    points = torch.cat([p.reshape(-1, dim) for p in point_clouds], 0).to(torch.float32).contiguous()
+    n = int(points.shape[0])
+    batch = len(point_clouds)
+    offs = [0]
+    for l in lens:
+        offs.append(offs[-1] + l)
+    scan_offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    cap = min(n, batch * max_voxels) if max_voxels >= 0 else n
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    ppts = torch.empty((cap, max_points), dtype=torch.int32, device=dev)
+    row_start = torch.empty((cap + 1,), dtype=torch.int32, device=dev)
+    c2p = torch.empty((batch, geom.cells), dtype=torch.int32, device=dev)
+    counts = torch.empty((batch + 2,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.mbv_voxelize_workspace_bytes(n, batch, geom.cells)
+    ws = _workspace(ws_bytes, dev)
+    r, v, g = geom.pc_range, geom.voxel_size, geom.grid
+    rc = lib.mbv_voxelize(_ptr(points), dim, n, _ptr(scan_offsets), batch,
+                          r[0], r[1], r[2], r[3], r[4], r[5], v[0], v[1], v[2], int(g[0]), int(g[1]), int(g[2]),
+                          1 if prefilter else 0, int(max_points), int(max_voxels), cap,
+                          _ptr(coors), _ptr(nump), _ptr(ppts), _ptr(row_start), _ptr(c2p), _ptr(counts),
+                          _ptr(ws), ws.numel(), _stream())
+    check(rc, 'mbv_voxelize')
+    counts_h = counts.cpu().tolist()                      # the one permitted sync
+    per_scan, nv, nk = counts_h[:batch], counts_h[batch], counts_h[batch + 1]
+    pbs = [0]
+    for c in per_scan:
+        pbs.append(pbs[-1] + c)
+    return Pillars(points=points, scan_offsets=scan_offsets, coors=coors[:nv], num_points=nump[:nv],
+                   pillar_points=ppts[:nv], row_start=row_start[:nv + 1], cell_to_pillar=c2p,
+                   pillar_batch_start=torch.tensor(pbs, dtype=torch.int32).to(dev, non_blocking=True),
+                   pillars_per_scan=per_scan, num_pillars=nv, num_rows=nk, max_points=int(max_points))
+
+
+def gather_voxels(p: Pillars) -> torch.Tensor:
+    """Dense zero-padded (V, P, D) voxel tensor — the first output of mmcv ``Voxelization``."""
+    lib = _lib.load()
+    dim = int(p.points.shape[1])
+    out = torch.empty((p.num_pillars, p.max_points, dim), dtype=torch.float32, device=p.points.device)
+    rc = lib.mbv_gather_voxels(_ptr(p.points), dim, _ptr(p.pillar_points), p.num_pillars, p.max_points, _ptr(out),
+                               _stream())
+    check(rc, 'mbv_gather_voxels')
+    return out
+
+
+def pfn_decorate(p: Pillars, voxel_size: Sequence[float], pc_range: Sequence[float]):
+    """Compact decorated rows (K, D+7) of the real points + the pillar of each row (K2a)."""
+    lib = _lib.load()
+    dim = int(p.points.shape[1])
+    dev = p.points.device
+    rows = torch.empty((p.num_rows, dim + 7), dtype=torch.float32, device=dev)
+    row_pillar = torch.empty((p.num_rows,), dtype=torch.int64, device=dev)
+    vx, vy, vz = [float(v) for v in voxel_size]
+    rc = lib.mbv_pfn_decorate(_ptr(p.points), dim, _ptr(p.pillar_points), _ptr(p.num_points), _ptr(p.row_start),
+                              _ptr(p.coors), p.num_pillars, p.max_points, vx, vy, vz,
+                              vx / 2 + pc_range[0], vy / 2 + pc_range[1], vz / 2 + pc_range[2],
+                              _ptr(rows), _ptr(row_pillar), _stream())
+    check(rc, 'mbv_pfn_decorate')
+    return rows, row_pillar
+
+
+# --------------------------------------------------------------------------------------
+# K3 scatter + (C, H, W) LayerNorm
+# --------------------------------------------------------------------------------------
+class _ScatterLayerNorm(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, feats, weight, bias, cell_to_pillar, pillar_batch_start, batch, ny, nx, eps):
+        lib = _lib.load()
+        _need_gpu(feats, weight, bias, cell_to_pillar, pillar_batch_start)
+        feats = feats.contiguous()
+        weight = weight.contiguous()
+        bias = bias.contiguous()
+        c = int(weight.shape[0])
+        dev = feats.device
+        out = torch.empty((batch, c, ny, nx), dtype=torch.float32, device=dev)
+        stats = torch.empty((batch, 2), dtype=torch.float32, device=dev)
+        ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
+        rc = lib.mbv_scatter_layernorm_fwd(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
+                                           _ptr(bias), batch, c, ny, nx, float(eps), _ptr(out), _ptr(stats), _ptr(ws),
+                                           ws.numel(), _stream())
+        check(rc, 'mbv_scatter_layernorm_fwd')
+        ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
+        ctx.dims = (batch, c, ny, nx)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        feats, weight, stats, cell_to_pillar, pillar_batch_start = ctx.saved_tensors
+        batch, c, ny, nx = ctx.dims
+        grad_out = grad_out.to(torch.float32).contiguous()
+        dev = feats.device
+        g_feats = torch.empty_like(feats)
+        g_w = torch.empty_like(weight)
+        g_b = torch.empty_like(weight)
+        ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
+        rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), _ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar),
+                                           _ptr(weight), _ptr(stats), batch, c, ny, nx, int(feats.shape[0]),
+                                           _ptr(g_feats), _ptr(g_w), _ptr(g_b), 0, _ptr(ws), ws.numel(), _stream())
+        check(rc, 'mbv_scatter_layernorm_bwd')
+        return g_feats, g_w, g_b, None, None, None, None, None, None
+
+
+def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, p: Pillars, batch: int, ny: int,
+                      nx: int, eps: float) -> torch.Tensor:
+    """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3)."""
+    return _ScatterLayerNorm.apply(feats, weight, bias, p.cell_to_pillar, p.pillar_batch_start, batch, ny, nx, eps)

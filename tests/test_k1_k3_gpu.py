@@ -1,0 +1,145 @@
+"""GPU parity of K1 (voxelise), K2a (decorate) and K3 (scatter + CHW LayerNorm) against the oracle.
+Integer outputs must be bit-exact; f32 outputs within the tolerances written below."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import maskbev_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(nx=64, ny=64, vs=0.25, P=8, C=32, pc_dim=4, max_voxels=250000):
+    return O.make_cfg(x_range=(-nx * vs / 2, nx * vs / 2), y_range=(-ny * vs / 2, ny * vs / 2), z_range=(-3, 1),
+                      voxel_size=vs, num_queries=8, max_num_points=P, encoder_feat_channels=[C, C, C],
+                      backbone_embed_dim=24, head_feat_channels=32, head_out_channels=32, pc_point_dim=pc_dim,
+                      max_voxels=max_voxels)
+
+
+def _geom(cfg):
+    from mask_bev_amd.ops import VoxelGeometry
+    return VoxelGeometry.from_ranges(cfg.pc_range, cfg.voxel_size3)
+
+
+def _scans(cfg, sizes, seed, dim=4, spread=1.2):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for n in sizes:
+        p = torch.rand(n, dim, generator=g)
+        lo = torch.tensor([cfg.x_range[0], cfg.y_range[0], cfg.z_range[0]])
+        hi = torch.tensor([cfg.x_range[1], cfg.y_range[1], cfg.z_range[1]])
+        mid, half = (lo + hi) / 2, (hi - lo) / 2 * spread
+        p[:, :3] = mid + (p[:, :3] * 2 - 1) * half
+        out.append(p)
+    return out
+
+
+def _check_voxelize(cfg, scans, device):
+    from mask_bev_amd import ops
+    pil = ops.voxelize([s.to(device) for s in scans], _geom(cfg), cfg.max_num_points, cfg.max_voxels)
+    voxels = ops.gather_voxels(pil)
+    torch.cuda.synchronize()
+    ref_v, ref_n, ref_c = O.voxelize(cfg, scans)
+    assert pil.num_pillars == ref_c.shape[0]
+    assert torch.equal(pil.coors.cpu(), ref_c.to(torch.int32))
+    assert torch.equal(pil.num_points.cpu(), ref_n.to(torch.int32))
+    assert torch.equal(voxels.cpu(), ref_v)                       # bit-exact copy of the kept points
+    assert pil.num_rows == int(ref_n.sum())
+    return pil, (ref_v, ref_n, ref_c)
+
+
+@pytest.mark.parametrize('sizes', [[3000], [5000, 1, 2500], [0, 700], [64, 64, 64, 64]])
+def test_voxelize_bit_exact_random(device, sizes):
+    cfg = _cfg()
+    _check_voxelize(cfg, _scans(cfg, sizes, seed=sum(sizes)), device)
+
+
+def test_voxelize_crowded_cells_and_order(device):
+    """> P points per cell, all points in one cell, and duplicate cells in different order."""
+    cfg = _cfg(nx=8, ny=8, vs=1.0, P=4)
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(4000, 4, generator=g) * torch.tensor([8.0, 8.0, 4.0, 1.0]) - torch.tensor([4.0, 4.0, 3.0, 0.0])
+    one = torch.rand(3000, 4, generator=g) * torch.tensor([0.5, 0.5, 1.0, 1.0])      # a single pillar
+    _check_voxelize(cfg, [a, one, a.flip(0)], device)
+
+
+def test_voxelize_borders(device):
+    """Points exactly on cell borders and on the range bounds (strict < pre-filter)."""
+    cfg = _cfg(nx=16, ny=16, vs=0.5, P=3)
+    xs = torch.arange(-4.0, 4.0001, 0.25)
+    pts = torch.stack(torch.meshgrid(xs, xs, torch.tensor([-3.0, -2.9999, 0.0, 0.9999, 1.0]), indexing='ij'), -1)
+    pts = torch.cat([pts.reshape(-1, 3), torch.zeros(pts.numel() // 3, 1)], 1)
+    pts = pts[torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(1))]
+    eps = torch.tensor([[np.nextafter(np.float32(4.0), np.float32(0.0)), 0.0, 0.0, 0.0],
+                        [np.nextafter(np.float32(-4.0), np.float32(0.0)), 0.0, 0.0, 0.0],
+                        [float('nan'), 0.0, 0.0, 0.0], [float('inf'), 0.0, 0.0, 0.0]])
+    _check_voxelize(cfg, [torch.cat([pts, eps])], device)
+
+
+def test_voxelize_max_voxels_cap(device):
+    cfg = _cfg(max_voxels=100)
+    _check_voxelize(cfg, _scans(cfg, [4000, 50, 3000], seed=3), device)
+
+
+def test_voxelize_lidar_sized(device):
+    """Full-size 120k-point scans on the 512x512 grid, against the C oracle."""
+    cfg = O.make_cfg(x_range=(-40, 40), y_range=(-40, 40), z_range=(-3, 1), voxel_size=0.15625, num_queries=100,
+                     max_num_points=32, encoder_feat_channels=[128, 128, 128], backbone_embed_dim=192,
+                     head_feat_channels=256, head_out_channels=256)
+    assert (cfg.nx, cfg.ny) == (512, 512)
+    g = torch.Generator().manual_seed(11)
+    scans = []
+    for _ in range(2):
+        r = torch.rand(120000, generator=g) ** 2 * 55
+        th = torch.rand(120000, generator=g) * 6.2831853
+        z = torch.rand(120000, generator=g) * 5 - 3.5
+        scans.append(torch.stack([r * th.cos(), r * th.sin(), z, torch.rand(120000, generator=g)], 1))
+    pil, _ = _check_voxelize(cfg, scans, device)
+    # size-independent properties
+    c2p = pil.cell_to_pillar.cpu()
+    coors = pil.coors.cpu().long()
+    assert torch.equal(c2p[coors[:, 0], coors[:, 2] * cfg.nx + coors[:, 3]], torch.arange(pil.num_pillars, dtype=torch.int32))
+    assert int((c2p >= 0).sum()) == pil.num_pillars
+    rs = pil.row_start.cpu()
+    assert torch.equal(rs[1:] - rs[:-1], pil.num_points.cpu())
+
+
+def test_decorate_matches_oracle(device):
+    from mask_bev_amd import ops
+    cfg = _cfg()
+    scans = _scans(cfg, [4000, 3000], seed=9)
+    pil, (rv, rn, rc) = _check_voxelize(cfg, scans, device)
+    rows, row_pillar = ops.pfn_decorate(pil, cfg.voxel_size3, cfg.pc_range)
+    dense = O.pfn_decorate(cfg, rv, rn, rc)                              # (V, P, 11), zero padded
+    mask = torch.arange(cfg.max_num_points).view(1, -1) < rn.view(-1, 1)
+    ref_rows = dense[mask]                                               # pillar-major, slot order == compact order
+    torch.testing.assert_close(rows.cpu(), ref_rows, rtol=1e-5, atol=1e-5)
+    ref_pillar = torch.arange(rv.shape[0]).view(-1, 1).expand(-1, cfg.max_num_points)[mask]
+    assert torch.equal(row_pillar.cpu(), ref_pillar)
+
+
+@pytest.mark.parametrize('nx,ny,C,sizes', [(64, 64, 32, [3000, 2000]), (52, 40, 16, [500]), (63, 32, 8, [900, 10, 0])])
+def test_scatter_layernorm_fwd_bwd(device, nx, ny, C, sizes):
+    """K3 vs dense scatter + F.layer_norm (f32): forward and all three gradients, rtol 1e-4 / atol 1e-5."""
+    from mask_bev_amd import ops
+    cfg = _cfg(nx=nx, ny=ny, C=C)
+    scans = _scans(cfg, sizes, seed=nx)
+    pil, (rv, rn, rc) = _check_voxelize(cfg, scans, device)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(pil.num_pillars, C, generator=g)
+    w = 1 + 0.1 * torch.randn(C, ny, nx, generator=g)
+    b = 0.1 * torch.randn(C, ny, nx, generator=g)
+    go = torch.randn(len(scans), C, ny, nx, generator=g)
+    # oracle
+    f_ref, w_ref, b_ref = feats.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    canvas = O.scatter_to_canvas(cfg, f_ref, rc, len(scans))
+    out_ref = torch.nn.functional.layer_norm(canvas, [C, ny, nx], w_ref, b_ref, 1e-3)
+    out_ref.backward(go)
+    # product
+    f_d, w_d, b_d = (t.clone().to(device).requires_grad_() for t in (feats, w, b))
+    out = ops.scatter_layernorm(f_d, w_d, b_d, pil, len(scans), ny, nx, 1e-3)
+    out.backward(go.to(device))
+    torch.testing.assert_close(out.detach().cpu(), out_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(w_d.grad.cpu(), w_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(b_d.grad.cpu(), b_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(f_d.grad.cpu(), f_ref.grad, rtol=1e-4, atol=2e-5)
