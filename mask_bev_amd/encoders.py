@@ -1,0 +1,194 @@
+"""Point-cloud → pseudo-image encoder of MaskBEV on gfx950.
+
+Interface and checkpoint keys of ``MaskBevEncoder``
+(/root/reference: mask_bev/models/encoders/mask_bev_encoders.py:21-123).  The hot path is
+``forward``: K1 voxelise → K2 pillar feature net over REAL points only → K3 scatter fused with the
+(C, ny, nx) LayerNorm; neither the zero-padded (V, 32, ·) tensors nor the dense canvas are built.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .ops import Pillars, VoxelGeometry
+
+
+class EncodingType:
+    Vanilla = 'vanilla'
+    Fourier = 'fourier'
+    Cosine = 'cosine'
+
+
+class Voxelization(nn.Module):
+    """Hard voxelisation layer with the constructor of ``mmcv.ops.Voxelization`` (mask_bev_encoders.py:69).
+    ``forward(points)`` handles one scan and returns (voxels, coors(z,y,x), num_points) like mmcv."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, deterministic=True):
+        super().__init__()
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.max_num_points = int(max_num_points)
+        self.max_voxels = int(max_voxels[0] if isinstance(max_voxels, (tuple, list)) else max_voxels)
+        self.geometry = VoxelGeometry.from_ranges(self.point_cloud_range, self.voxel_size)
+
+    def pillars(self, point_clouds: Sequence[torch.Tensor], prefilter: bool) -> Pillars:
+        return ops.voxelize(point_clouds, self.geometry, self.max_num_points, self.max_voxels, prefilter)
+
+    def forward(self, points: torch.Tensor):
+        p = self.pillars([points], prefilter=False)
+        return ops.gather_voxels(p), p.coors[:, 1:].contiguous(), p.num_points
+
+
+class _PFNLayer(nn.Module):
+    """Keys ``linear.weight`` / ``norm.*`` (mmdet3d ``PFNLayer``)."""
+
+    def __init__(self, cin: int, cout: int, last: bool):
+        super().__init__()
+        self.last_vfe = last
+        self.units = cout if last else cout // 2
+        self.linear = nn.Linear(cin, self.units, bias=False)
+        self.norm = nn.BatchNorm1d(self.units, eps=1e-3, momentum=0.01)
+
+
+class PillarFeatureNet(nn.Module):
+    """PillarFeatureNet(with_distance=True, legacy=True) evaluated on real points only.
+
+    mmdet3d runs Linear → BatchNorm1d → ReLU → max on the zero-padded (V, P, ·) tensor, so padded rows
+    take part in the batch statistics and — being relu(β − γμ/σ) ≠ 0 after BN — in the max
+    (SURVEY.md §7 "Padded-row algebra").  Here each pillar carries ONE representative padded row with
+    multiplicity P − n: identical results, ≈ n/P of the work and memory.
+    """
+
+    def __init__(self, in_channels=4, feat_channels=(64,), with_distance=False, with_cluster_center=True,
+                 with_voxel_center=True, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=None, mode='max', legacy=True):
+        super().__init__()
+        if not (with_distance and with_cluster_center and with_voxel_center and legacy and mode == 'max'):
+            raise NotImplementedError('only the MaskBEV configuration of PillarFeatureNet '
+                                      '(with_distance, cluster + voxel centre, legacy, max) is built')
+        self.in_channels = in_channels
+        chans = [in_channels + 7] + list(feat_channels)
+        self.pfn_layers = nn.ModuleList([
+            _PFNLayer(chans[i], chans[i + 1], last=(i == len(chans) - 2)) for i in range(len(chans) - 1)])
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+
+    def forward(self, p: Pillars) -> torch.Tensor:
+        rows, row_pillar = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)      # (K, D+7)
+        v, pmax = p.num_pillars, p.max_points
+        mult = (pmax - p.num_points).to(rows.dtype).unsqueeze(1)                            # (V, 1) padded rows
+        count = float(v * pmax)
+        x, pad = rows, None                      # pad: (V, Cin) representative padded row (None = all zero)
+        for layer in self.pfn_layers:
+            y = layer.linear(x)
+            y_pad = layer.linear(pad) if pad is not None else y.new_zeros(1, layer.units)
+            bn = layer.norm
+            if self.training:
+                s = y.sum(0) + (y_pad * mult).sum(0)
+                mean = s / count
+                dv, dp = y - mean, y_pad - mean
+                var = ((dv * dv).sum(0) + (dp * dp * mult).sum(0)) / count
+                with torch.no_grad():
+                    bn.running_mean.mul_(1 - bn.momentum).add_(mean.detach(), alpha=bn.momentum)
+                    unbiased = var.detach() * (count / max(count - 1.0, 1.0))
+                    bn.running_var.mul_(1 - bn.momentum).add_(unbiased, alpha=bn.momentum)
+                    bn.num_batches_tracked.add_(1)
+            else:
+                mean, var = bn.running_mean, bn.running_var
+            scale = bn.weight * torch.rsqrt(var + bn.eps)
+            shift = bn.bias - mean * scale
+            a = F.relu(y * scale + shift)
+            a_pad = F.relu(y_pad * scale + shift).expand(v, -1)
+            # max over the pillar's real rows and (if any) its padded row
+            init = torch.where(mult > 0, a_pad, a_pad.new_full((), float('-inf')))
+            mx = init.scatter_reduce(0, row_pillar.unsqueeze(1).expand(-1, layer.units), a, 'amax', include_self=True)
+            if layer.last_vfe:
+                return mx
+            x = torch.cat([a, mx[row_pillar]], dim=1)
+            pad = torch.cat([a_pad, mx], dim=1)
+        raise RuntimeError('unreachable')
+
+
+class PointPillarsScatter(nn.Module):
+    """Dense canvas scatter (API parity with mmdet3d ``PointPillarsScatter``, mask_bev_encoders.py:74).
+    Not used by ``MaskBevEncoder.forward`` — K3 fuses it with the LayerNorm."""
+
+    def __init__(self, in_channels: int, output_shape):
+        super().__init__()
+        self.in_channels = in_channels
+        self.ny, self.nx = int(output_shape[0]), int(output_shape[1])
+
+    def forward(self, voxel_features, coors, batch_size=None):
+        if batch_size is None:
+            batch_size = int(coors[:, 0].max().item()) + 1
+        ops._need_gpu(voxel_features)
+        canvas = voxel_features.new_zeros(batch_size, self.ny * self.nx, self.in_channels)
+        idx = (coors[:, 2] * self.nx + coors[:, 3]).long()
+        canvas[coors[:, 0].long(), idx] = voxel_features
+        return canvas.transpose(1, 2).reshape(batch_size, self.in_channels, self.ny, self.nx)
+
+
+class MaskBevEncoder(nn.Module):
+    """Same constructor as the reference class (mask_bev_encoders.py:22-26)."""
+
+    def __init__(self, feat_channels: List[int], x_range, y_range, z_range, voxel_size_x: float, voxel_size_y: float,
+                 voxel_size_z: float, max_num_points: int, encoding_type: str, fourier_enc_group: int,
+                 max_voxels: Union[tuple, int] = 500 * 500, deterministic: bool = True,
+                 encoder_params: Optional[Dict] = None, pc_point_dim: int = 4):
+        super().__init__()
+        encoder_params = encoder_params or {}
+        if encoding_type != EncodingType.Vanilla:
+            # no shipped config enables the fourier encoder: out of scope for this path
+            raise NotImplementedError(f'{encoding_type}')
+        self._feat_channels = list(feat_channels)
+        self._out_features = feat_channels[-1]
+        self._x_range, self._y_range, self._z_range = x_range, y_range, z_range
+        self._pos_encoder = None
+        self._num_voxel_x = int((x_range[1] - x_range[0]) / voxel_size_x)
+        self._num_voxel_y = int((y_range[1] - y_range[0]) / voxel_size_y)
+        self._num_voxel_z = 1
+        point_cloud_range = [x_range[0], y_range[0], z_range[0], x_range[1], y_range[1], z_range[1]]
+        voxel_size = [voxel_size_x, voxel_size_y, voxel_size_z]
+        self._voxel_layer = Voxelization(voxel_size, point_cloud_range, max_num_points, max_voxels, deterministic)
+        self._voxel_encoder = PillarFeatureNet(in_channels=pc_point_dim, feat_channels=self._feat_channels,
+                                               voxel_size=voxel_size, point_cloud_range=point_cloud_range,
+                                               **encoder_params)
+        out_shape = [self._num_voxel_y, self._num_voxel_x]
+        self._middle_encoder = PointPillarsScatter(in_channels=self._out_features, output_shape=out_shape)
+        self._layer_norm = nn.LayerNorm([self._out_features, *out_shape], eps=1e-3)
+
+    def forward(self, point_clouds: Sequence[torch.Tensor]) -> torch.Tensor:
+        """list of (Ni, pc_dim) device tensors → (B, C, ny, nx)."""
+        batch = len(point_clouds)
+        pillars = self._voxel_layer.pillars(point_clouds, prefilter=True)
+        feats = self._voxel_encoder(pillars)
+        ln = self._layer_norm
+        return ops.scatter_layernorm(feats, ln.weight, ln.bias, pillars, batch, self._num_voxel_y, self._num_voxel_x,
+                                     ln.eps)
+
+    # --- staged API of the reference (mask_bev_encoders.py:95-123) -------------------------------
+    def voxelize(self, point_clouds: Sequence[torch.Tensor]):
+        """→ (voxels (V, P, D), num_points (V,), coors (V, 4) = (b, z, y, x))."""
+        pillars = self._voxel_layer.pillars(point_clouds, prefilter=True)
+        self._last_pillars = pillars
+        return ops.gather_voxels(pillars), pillars.num_points, pillars.coors
+
+    def _filter_in_range(self, point_cloud: torch.Tensor) -> torch.Tensor:
+        m = (self._x_range[0] < point_cloud[:, 0]) & (point_cloud[:, 0] < self._x_range[1]) & \
+            (self._y_range[0] < point_cloud[:, 1]) & (point_cloud[:, 1] < self._y_range[1]) & \
+            (self._z_range[0] < point_cloud[:, 2]) & (point_cloud[:, 2] < self._z_range[1])
+        return point_cloud[m]
+
+    def encode(self, voxel, num_points, coords):
+        """Staged call: must follow ``voxelize`` on the same batch (the compact pillar lists are reused)."""
+        pillars = getattr(self, '_last_pillars', None)
+        if pillars is None or pillars.coors.data_ptr() != coords.data_ptr():
+            raise RuntimeError('encode() expects the tensors returned by the preceding voxelize() call')
+        return self._voxel_encoder(pillars)
+
+    def middle_encode(self, voxel_features, coors, batch_size=None):
+        return self._middle_encoder(voxel_features, coors, batch_size)

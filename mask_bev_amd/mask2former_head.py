@@ -1,0 +1,355 @@
+"""Mask2Former-style panoptic head of MaskBEV on gfx950: pixel decoder, masked-attention decoder, loss.
+
+Interface and checkpoint keys of ``Mask2FormerHead``
+(/root/reference: mask_bev/models/networks/mask2former_head/mask2former_head.py:20-562) and of the mmdet
+3.0.0 ``MSDeformAttnPixelDecoder`` / ``Mask2FormerTransformerDecoder`` it builds from the config at
+mask_bev/models/head/mask_bev_panoptic_head.py:98-215.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import ConvGN, FFN, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
+
+
+# --------------------------------------------------------------------------------------
+# pixel decoder
+# --------------------------------------------------------------------------------------
+class _DeformEncoderLayer(nn.Module):
+    def __init__(self, embed_dims, num_heads, num_levels, num_points, ffn_channels):
+        super().__init__()
+        self.self_attn = MultiScaleDeformableAttention(embed_dims, num_heads, num_levels, num_points)
+        self.ffn = FFN(embed_dims, ffn_channels, act='relu')
+        self.norms = nn.ModuleList([nn.LayerNorm(embed_dims), nn.LayerNorm(embed_dims)])
+
+    def forward(self, q, pos, ref, shapes, shapes_t, level_start):
+        q = self.norms[0](self.self_attn(q, pos, ref, shapes, shapes_t, level_start))
+        return self.norms[1](self.ffn(q))
+
+
+class _DeformEncoder(nn.Module):
+    def __init__(self, num_layers, **kw):
+        super().__init__()
+        self.layers = nn.ModuleList([_DeformEncoderLayer(**kw) for _ in range(num_layers)])
+
+
+class MSDeformAttnPixelDecoder(nn.Module):
+    """6-layer multi-scale deformable-attention encoder over the 3 coarsest maps + FPN step to stride 4.
+    Keys: input_convs.i.{conv,gn}, encoder.layers.l.{self_attn,ffn,norms}, level_encoding,
+    lateral_convs.i, output_convs.i, mask_feature."""
+
+    def __init__(self, in_channels: Sequence[int], feat_channels: int, out_channels: int, strides=(4, 8, 16, 32),
+                 num_outs: int = 3, num_layers: int = 6, num_heads: int = 8, num_levels: int = 3, num_points: int = 4,
+                 ffn_channels: int = 1024):
+        super().__init__()
+        self.strides = list(strides)
+        self.num_input_levels = len(in_channels)
+        self.num_encoder_levels = num_levels
+        self.feat_channels = feat_channels
+        n = self.num_input_levels
+        self.input_convs = nn.ModuleList([
+            ConvGN(in_channels[i], feat_channels, 1, bias=True, relu=False) for i in range(n - 1, n - num_levels - 1, -1)])
+        self.encoder = _DeformEncoder(num_layers, embed_dims=feat_channels, num_heads=num_heads, num_levels=num_levels,
+                                      num_points=num_points, ffn_channels=ffn_channels)
+        self.level_encoding = nn.Embedding(num_levels, feat_channels)
+        self.lateral_convs = nn.ModuleList()
+        self.output_convs = nn.ModuleList()
+        for i in range(n - num_levels - 1, -1, -1):
+            self.lateral_convs.append(ConvGN(in_channels[i], feat_channels, 1, bias=False, relu=False))
+            self.output_convs.append(ConvGN(feat_channels, feat_channels, 3, bias=False, relu=True))
+        self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1)
+        self.num_outs = num_outs
+        self._geom_cache: Dict[Tuple, Tuple] = {}
+
+    def init_weights(self):
+        for m in self.input_convs:
+            nn.init.xavier_uniform_(m.conv.weight, gain=1)
+            nn.init.zeros_(m.conv.bias)
+        for m in list(self.lateral_convs) + list(self.output_convs):
+            nn.init.kaiming_uniform_(m.conv.weight, a=1)
+        nn.init.kaiming_uniform_(self.mask_feature.weight, a=1)
+        nn.init.zeros_(self.mask_feature.bias)
+        nn.init.normal_(self.level_encoding.weight, mean=0, std=1)
+        for p in self.encoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+        for layer in self.encoder.layers:
+            layer.self_attn.init_weights()
+
+    def _geometry(self, shapes: Tuple[Tuple[int, int], ...], device):
+        key = (shapes, str(device))
+        g = self._geom_cache.get(key)
+        if g is None:
+            refs, pos = [], []
+            for (h, w) in shapes:
+                xs = (torch.arange(w, dtype=torch.float32, device=device) + 0.5) / w
+                ys = (torch.arange(h, dtype=torch.float32, device=device) + 0.5) / h
+                refs.append(torch.stack([xs.repeat(h), ys.view(-1, 1).repeat(1, w).view(-1)], -1))
+                pos.append(sine_positional_encoding(h, w, self.feat_channels // 2, device).flatten(2).transpose(1, 2))
+            shapes_t = torch.tensor(shapes, dtype=torch.int64, device=device)
+            starts = [0]
+            for (h, w) in shapes[:-1]:
+                starts.append(starts[-1] + h * w)
+            g = (torch.cat(refs, 0), pos, shapes_t, torch.tensor(starts, dtype=torch.int64, device=device))
+            self._geom_cache[key] = g
+        return g
+
+    def forward(self, feats: List[torch.Tensor]):
+        bs = feats[0].shape[0]
+        n, nl = self.num_input_levels, self.num_encoder_levels
+        shapes = tuple((int(feats[n - i - 1].shape[2]), int(feats[n - i - 1].shape[3])) for i in range(nl))
+        ref, pos, shapes_t, level_start = self._geometry(shapes, feats[0].device)
+        tokens, lvl_pos = [], []
+        for i in range(nl):
+            proj = self.input_convs[i](feats[n - i - 1])
+            tokens.append(proj.flatten(2).transpose(1, 2))
+            lvl_pos.append(pos[i] + self.level_encoding.weight[i].view(1, 1, -1))
+        q = torch.cat(tokens, 1)
+        qpos = torch.cat(lvl_pos, 1)
+        for layer in self.encoder.layers:
+            q = layer(q, qpos, ref, shapes, shapes_t, level_start)
+        outs = [t.transpose(1, 2).reshape(bs, -1, h, w) for t, (h, w) in
+                zip(torch.split(q, [h * w for h, w in shapes], dim=1), shapes)]
+        for j, i in enumerate(range(n - nl - 1, -1, -1)):
+            cur = self.lateral_convs[j](feats[i])
+            y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
+            outs.append(self.output_convs[j](y))
+        return self.mask_feature(outs[-1]), outs[:self.num_outs]
+
+
+# --------------------------------------------------------------------------------------
+# transformer decoder
+# --------------------------------------------------------------------------------------
+class _DecoderLayer(nn.Module):
+    """masked cross-attention → LN → self-attention → LN → FFN → LN (post-norm)."""
+
+    def __init__(self, embed_dims, num_heads, ffn_channels):
+        super().__init__()
+        self.self_attn = MultiheadAttention(embed_dims, num_heads)
+        self.cross_attn = MultiheadAttention(embed_dims, num_heads)
+        self.ffn = FFN(embed_dims, ffn_channels, act='relu')
+        self.norms = nn.ModuleList([nn.LayerNorm(embed_dims) for _ in range(3)])
+
+    def forward(self, query, memory, query_pos, memory_pos, blocked):
+        q = self.norms[0](self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked))
+        q = self.norms[1](self.self_attn(q, q, q, query_pos, query_pos, None))
+        return self.norms[2](self.ffn(q))
+
+
+class Mask2FormerTransformerDecoder(nn.Module):
+    def __init__(self, num_layers, embed_dims, num_heads, ffn_channels):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.layers = nn.ModuleList([_DecoderLayer(embed_dims, num_heads, ffn_channels) for _ in range(num_layers)])
+        self.post_norm = nn.LayerNorm(embed_dims)
+
+
+# --------------------------------------------------------------------------------------
+# head
+# --------------------------------------------------------------------------------------
+class PointSource:
+    """Uniform sampling points for the loss.  ``seed=None`` → device RNG (training); an int → a CPU
+    generator drawn in the reference's order (mask2former_head.py:191, then mmdet's
+    ``get_uncertain_point_coords_with_randomness``) so tests can share the points with the oracle."""
+
+    def __init__(self, device, seed: Optional[int] = None):
+        self.device = device
+        self.gen = None if seed is None else torch.Generator().manual_seed(seed)
+
+    def rand(self, *shape) -> torch.Tensor:
+        if self.gen is None:
+            return torch.rand(*shape, device=self.device)
+        return torch.rand(*shape, generator=self.gen).to(self.device)
+
+
+def _point_sample(inp: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
+    """inp (N, C, H, W), pts (N, P, 2) in [0, 1] → (N, C, P); bilinear, align_corners=False."""
+    return F.grid_sample(inp, 2.0 * pts.unsqueeze(2) - 1.0, align_corners=False).squeeze(3)
+
+
+class Mask2FormerHead(nn.Module):
+    def __init__(self, in_channels, feat_channels, out_channels, num_things_classes=80, num_stuff_classes=53,
+                 num_queries=100, num_transformer_feat_level=3, pixel_decoder=None, enforce_decoder_input_project=False,
+                 transformer_decoder=None, positional_encoding=None, loss_cls=None, loss_mask=None, loss_dice=None,
+                 train_cfg=None, test_cfg=None, init_cfg=None, predict_height: bool = False, loss_height=None, **kwargs):
+        super().__init__()
+        if predict_height:
+            raise NotImplementedError('predict_heights is a dead path in the reference '
+                                      '(mask2former_head.py:231-244,384; SURVEY.md Appendix B)')
+        pixel_decoder = pixel_decoder or {}
+        transformer_decoder = transformer_decoder or {}
+        train_cfg = train_cfg or {}
+        loss_cls = loss_cls or {}
+        self.num_things_classes, self.num_stuff_classes = num_things_classes, num_stuff_classes
+        self.num_classes = num_things_classes + num_stuff_classes
+        self.num_queries = num_queries
+        self.num_transformer_feat_level = num_transformer_feat_level
+        enc = pixel_decoder.get('encoder', {})
+        lcfg = enc.get('layer_cfg', {})
+        sa = lcfg.get('self_attn_cfg', {})
+        self.pixel_decoder = MSDeformAttnPixelDecoder(
+            in_channels, feat_channels, out_channels, strides=kwargs.get('strides', (4, 8, 16, 32)),
+            num_outs=pixel_decoder.get('num_outs', 3), num_layers=enc.get('num_layers', 6),
+            num_heads=sa.get('num_heads', 8), num_levels=sa.get('num_levels', 3), num_points=sa.get('num_points', 4),
+            ffn_channels=lcfg.get('ffn_cfg', {}).get('feedforward_channels', 1024))
+        assert self.pixel_decoder.num_encoder_levels == num_transformer_feat_level
+        dl = transformer_decoder.get('layer_cfg', {})
+        self.num_heads = dl.get('cross_attn_cfg', {}).get('num_heads', 8)
+        self.num_transformer_decoder_layers = transformer_decoder.get('num_layers', 9)
+        self.transformer_decoder = Mask2FormerTransformerDecoder(
+            self.num_transformer_decoder_layers, feat_channels, self.num_heads,
+            dl.get('ffn_cfg', {}).get('feedforward_channels', 2048))
+        self.decoder_embed_dims = feat_channels
+        self.decoder_input_projs = nn.ModuleList([nn.Identity() for _ in range(num_transformer_feat_level)])
+        if enforce_decoder_input_project:
+            raise NotImplementedError('MaskBEV never enables enforce_decoder_input_project '
+                                      '(mask_bev_panoptic_head.py:147)')
+        self.query_embed = nn.Embedding(num_queries, feat_channels)
+        self.query_feat = nn.Embedding(num_queries, feat_channels)
+        self.level_embed = nn.Embedding(num_transformer_feat_level, feat_channels)
+        self.height_embed = None
+        self.cls_embed = nn.Linear(feat_channels, self.num_classes + 1)
+        self.mask_embed = nn.Sequential(nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, out_channels))
+        self.num_points = train_cfg.get('num_points', 12544)
+        self.oversample_ratio = train_cfg.get('oversample_ratio', 3.0)
+        self.importance_sample_ratio = train_cfg.get('importance_sample_ratio', 0.75)
+        self.class_weight = list(loss_cls.get('class_weight', [1.0] * self.num_classes + [0.1]))
+        self.loss_cls_weight = float(loss_cls.get('loss_weight', 2.0))
+        self.loss_mask_weight = float((loss_mask or {}).get('loss_weight', 5.0))
+        self.loss_dice_weight = float((loss_dice or {}).get('loss_weight', 5.0))
+        self.point_seed: Optional[int] = None          # tests set this to share points with the oracle
+        self.world_size_fn = None                      # set by the DDP wrapper: () -> (world, all_reduce_fn)
+
+    def init_weights(self):
+        self.pixel_decoder.init_weights()
+        for p in self.transformer_decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+
+    # ------------------------------------------------------------------ forward
+    def _forward_head(self, decoder_out, mask_feature, target_size):
+        """mask2former_head.py:428-472 → cls (B,Q,K+1), mask logits (B,Q,H,W), blocked (B,1,Q,h*w) bool.
+        The boolean mask is kept once per query (broadcast over heads) instead of being repeated 8x, and
+        the 'row fully blocked → unblock the row' rule of :538-539 is applied here."""
+        x = self.transformer_decoder.post_norm(decoder_out)
+        cls_pred = self.cls_embed(x)
+        mask_embed = self.mask_embed(x)
+        mask_pred, blocked = ops.mask_logits(mask_embed, mask_feature, target_size)
+        return cls_pred, mask_pred, blocked
+
+    def forward(self, x: List[torch.Tensor], batch_data_samples=None):
+        bs = x[0].shape[0]
+        mask_features, memories = self.pixel_decoder(x)
+        dec_in, dec_pos = [], []
+        for i in range(self.num_transformer_feat_level):
+            m = memories[i]
+            h, w = m.shape[-2:]
+            dec_in.append(m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1))
+            dec_pos.append(sine_positional_encoding(h, w, self.decoder_embed_dims // 2, m.device)
+                           .flatten(2).transpose(1, 2))
+        query_feat = self.query_feat.weight.unsqueeze(0).expand(bs, -1, -1)
+        query_embed = self.query_embed.weight.unsqueeze(0).expand(bs, -1, -1)
+        cls_list, mask_list = [], []
+        cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features, memories[0].shape[-2:])
+        cls_list.append(cls_pred)
+        mask_list.append(mask_pred)
+        nl = self.num_transformer_feat_level
+        for i, layer in enumerate(self.transformer_decoder.layers):
+            lvl = i % nl
+            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked)
+            cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features,
+                                                              memories[(i + 1) % nl].shape[-2:])
+            cls_list.append(cls_pred)
+            mask_list.append(mask_pred)
+        return cls_list, mask_list, [None for _ in cls_list]
+
+    # ------------------------------------------------------------------ loss
+    @torch.no_grad()
+    def _assign(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
+        """Hungarian targets for one decoder output, whole batch (mask2former_head.py:154-232).
+        Costs: 2·(−softmax cls) + 5·BCE + 5·dice on ``num_points`` random points, all images' cost matrices
+        built on the device and moved to the host in ONE copy for scipy's assignment."""
+        from scipy.optimize import linear_sum_assignment
+        b, nq = cls_scores.shape[:2]
+        ng = labels_gt.shape[1]
+        coords = torch.stack([pts.rand(1, self.num_points, 2)[0] for _ in range(b)], 0)         # (B, P, 2)
+        mp = _point_sample(mask_preds.float(), coords)                                          # (B, Q, P)
+        gp = _point_sample(masks_gt.float(), coords)                                            # (B, G, P)
+        prob = cls_scores.float().softmax(-1)
+        cls_cost = -torch.gather(prob, 2, labels_gt.unsqueeze(1).expand(-1, nq, -1)) * 2.0       # (B, Q, G)
+        pos = F.binary_cross_entropy_with_logits(mp, torch.ones_like(mp), reduction='none')
+        neg = F.binary_cross_entropy_with_logits(mp, torch.zeros_like(mp), reduction='none')
+        bce = (torch.einsum('bnc,bmc->bnm', pos, gp) + torch.einsum('bnc,bmc->bnm', neg, 1 - gp)) / self.num_points
+        ps = mp.sigmoid()
+        num = 2 * torch.einsum('bnc,bmc->bnm', ps, gp)
+        den = ps.sum(-1)[:, :, None] + gp.sum(-1)[:, None, :]
+        dice = 1 - (num + 1.0) / (den + 1.0)
+        cost = (cls_cost + 5.0 * bce + 5.0 * dice).cpu().numpy()
+        assigned = np.full((b, nq), -1, dtype=np.int64)
+        for i in range(b):
+            r, c = linear_sum_assignment(cost[i])
+            assigned[i, r] = c
+        return torch.from_numpy(assigned).to(cls_scores.device)                                # (B, Q) gt idx or -1
+
+    def _loss_single(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
+        """mask2former_head.py:326-426 for one decoder output."""
+        b, nq = cls_scores.shape[:2]
+        assigned = self._assign(cls_scores, mask_preds, labels_gt, masks_gt, pts)
+        matched = assigned >= 0
+        safe = assigned.clamp(min=0)
+        labels = torch.where(matched, torch.gather(labels_gt, 1, safe), torch.full_like(safe, self.num_classes))
+        class_weight = cls_scores.new_tensor(self.class_weight, dtype=torch.float32)
+        flat_scores, flat_labels = cls_scores.flatten(0, 1).float(), labels.flatten()
+        ce = F.cross_entropy(flat_scores, flat_labels, weight=class_weight, reduction='none')
+        eps = torch.finfo(torch.float32).eps
+        loss_cls = self.loss_cls_weight * ce.sum() / (class_weight[flat_labels].sum() + eps)
+        # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image, then reduce_mean over ranks (:388)
+        num_total_masks = cls_scores.new_tensor([float(b * nq)], dtype=torch.float32)
+        if self.world_size_fn is not None:
+            num_total_masks = self.world_size_fn(num_total_masks)
+        num_total_masks = num_total_masks.clamp(min=1.0)
+        bi, qi = torch.nonzero(matched, as_tuple=True)
+        mp = mask_preds[bi, qi].float()                                  # (G, H, W)
+        mt = masks_gt[bi, assigned[bi, qi]].float()                      # (G, ny, nx)
+        if mp.shape[0] == 0:
+            return loss_cls, mp.sum(), mp.sum()
+        with torch.no_grad():
+            g = mp.shape[0]
+            n_samp = int(self.num_points * self.oversample_ratio)
+            coords = pts.rand(g, n_samp, 2)
+            unc = -_point_sample(mp.unsqueeze(1), coords).abs()
+            n_unc = int(self.importance_sample_ratio * self.num_points)
+            n_rand = self.num_points - n_unc
+            idx = torch.topk(unc[:, 0, :], k=n_unc, dim=1)[1]
+            coords = torch.gather(coords, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+            if n_rand > 0:
+                coords = torch.cat((coords, pts.rand(g, n_rand, 2)), dim=1)
+            tgt = _point_sample(mt.unsqueeze(1), coords).squeeze(1)
+        pred = _point_sample(mp.unsqueeze(1), coords).squeeze(1)
+        ps = pred.sigmoid()
+        d = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)
+        loss_dice = self.loss_dice_weight * (1 - d).sum() / (num_total_masks[0] + eps)
+        bce = F.binary_cross_entropy_with_logits(pred, tgt, reduction='none')
+        loss_mask = self.loss_mask_weight * bce.sum() / (num_total_masks[0] * self.num_points + eps)
+        return loss_cls, loss_mask, loss_dice
+
+    def loss(self, all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, img_metas=None, heights_pred=None,
+             heights_gt=None) -> Dict[str, torch.Tensor]:
+        """mask2former_head.py:246-298; labels (B, Q) int64, masks (B, Q, ny, nx) {0,1}."""
+        labels_gt = gt_labels_list if torch.is_tensor(gt_labels_list) else torch.stack(list(gt_labels_list), 0)
+        masks_gt = gt_masks_list if torch.is_tensor(gt_masks_list) else torch.stack(list(gt_masks_list), 0)
+        pts = PointSource(all_cls_scores[0].device, self.point_seed)
+        res = [self._loss_single(c, m, labels_gt, masks_gt, pts) for c, m in zip(all_cls_scores, all_mask_preds)]
+        out = dict(loss_cls=res[-1][0], loss_mask=res[-1][1], loss_dice=res[-1][2], loss_height=0)
+        for i, (lc, lm, ld) in enumerate(res[:-1]):
+            out[f'd{i}.loss_cls'], out[f'd{i}.loss_mask'], out[f'd{i}.loss_dice'] = lc, lm, ld
+            out[f'd{i}.loss_height'] = 0
+        return out

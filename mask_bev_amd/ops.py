@@ -194,3 +194,117 @@ def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
                       nx: int, eps: float) -> torch.Tensor:
     """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3)."""
     return _ScatterLayerNorm.apply(feats, weight, bias, p.cell_to_pillar, p.pillar_batch_start, batch, ny, nx, eps)
+
+
+# --------------------------------------------------------------------------------------
+# K4 shifted-window attention
+# --------------------------------------------------------------------------------------
+_SHIFT_MASK_CACHE = {}
+_REL_INDEX_CACHE = {}
+
+
+def _rel_index(ws: int, device) -> torch.Tensor:
+    key = (ws, str(device))
+    idx = _REL_INDEX_CACHE.get(key)
+    if idx is None:
+        c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)
+        rel = c[:, :, None] - c[:, None, :] + (ws - 1)
+        idx = (rel[0] * (2 * ws - 1) + rel[1]).reshape(-1).to(device)
+        _REL_INDEX_CACHE[key] = idx
+    return idx
+
+
+def _shift_mask(hp: int, wp: int, ws: int, shift: int, device) -> torch.Tensor:
+    """(nW, ws², ws²) additive mask, -100 between tokens of different shifted regions (swin.py:198-219)."""
+    key = (hp, wp, ws, shift, str(device))
+    m = _SHIFT_MASK_CACHE.get(key)
+    if m is None:
+        def region(n):
+            r = torch.zeros(n, dtype=torch.long)
+            r[n - ws:n - shift] = 1
+            r[n - shift:] = 2
+            return r
+        lab = region(hp)[:, None] * 3 + region(wp)[None, :]
+        lab = lab.view(hp // ws, ws, wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+        m = (lab[:, None, :] != lab[:, :, None]).to(torch.float32) * -100.0
+        m = m.to(device)
+        _SHIFT_MASK_CACHE[key] = m
+    return m
+
+
+def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torch.Tensor, num_heads: int, ws: int,
+                     shift: int) -> torch.Tensor:
+    """Shifted-window multi-head attention on a channels-last map.
+
+    qkv (B, H, W, 3C) is the fused projection of the *un-padded* tokens; tokens that the reference pads in
+    (swin.py:185-188: zeros after LayerNorm) have qkv == bias, which is what is filled in here.
+    Returns (B, H, W, C) (before the output projection).  Torch composition for now — the fused gfx950
+    kernel replaces the body of this function.
+    """
+    _need_gpu(qkv)
+    b, h, w, c3 = qkv.shape
+    c = c3 // 3
+    d = c // num_heads
+    pad_b, pad_r = (ws - h % ws) % ws, (ws - w % ws) % ws
+    hp, wp = h + pad_b, w + pad_r
+    if pad_b or pad_r:
+        full = qkv_bias.to(qkv.dtype).view(1, 1, 1, c3).expand(b, hp, wp, c3).clone()
+        full[:, :h, :w] = qkv
+        qkv = full
+    if shift:
+        qkv = torch.roll(qkv, shifts=(-shift, -shift), dims=(1, 2))
+    nh_, nw_ = hp // ws, wp // ws
+    t = qkv.view(b, nh_, ws, nw_, ws, 3, num_heads, d).permute(5, 0, 1, 3, 6, 2, 4, 7)
+    t = t.reshape(3, b, nh_ * nw_, num_heads, ws * ws, d)
+    bias = bias_table[_rel_index(ws, qkv.device)].view(ws * ws, ws * ws, num_heads).permute(2, 0, 1)
+    attn_bias = bias.unsqueeze(0)
+    if shift:
+        attn_bias = attn_bias + _shift_mask(hp, wp, ws, shift, qkv.device).unsqueeze(1)
+    attn_bias = attn_bias.to(qkv.dtype)
+    o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=attn_bias)
+    o = o.view(b, nh_, nw_, num_heads, ws, ws, d).permute(0, 1, 4, 2, 5, 3, 6).reshape(b, hp, wp, c)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    if pad_b or pad_r:
+        o = o[:, :h, :w].contiguous()
+    return o
+
+
+# --------------------------------------------------------------------------------------
+# K5 multi-scale deformable attention
+# --------------------------------------------------------------------------------------
+def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, level_start: torch.Tensor,
+                   sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
+    """value (B, N, H, D); sampling_locations (B, Nq, H, L, P, 2) in [0,1]; weights (B, Nq, H, L, P)
+    → (B, Nq, H*D).  Bilinear, zero padding, align_corners=False (mmcv ``ms_deform_attn``)."""
+    _need_gpu(value)
+    bs, _, nh, d = value.shape
+    _, nq, _, nl, npnt, _ = sampling_locations.shape
+    value_list = value.split([h * w for h, w in spatial_shapes], dim=1)
+    grids = 2 * sampling_locations - 1
+    sampled = []
+    for lvl, (h, w) in enumerate(spatial_shapes):
+        v = value_list[lvl].flatten(2).transpose(1, 2).reshape(bs * nh, d, h, w)
+        g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)
+        sampled.append(torch.nn.functional.grid_sample(v, g.to(v.dtype), mode='bilinear', padding_mode='zeros',
+                                                       align_corners=False))
+    aw = attention_weights.transpose(1, 2).reshape(bs * nh, 1, nq, nl * npnt)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * aw.to(value.dtype)).sum(-1).view(bs, nh * d, nq)
+    return out.transpose(1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# K7 per-query mask logits + attention mask of the next decoder layer
+# --------------------------------------------------------------------------------------
+def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_size):
+    """mask_embed (B, Q, C) · mask_feature (B, C, H, W) → logits (B, Q, H, W) and the boolean
+    cross-attention mask of the next layer, (B, 1, Q, h*w), True = blocked:
+    bilinear resize (align_corners=False) → sigmoid < 0.5, rows that would block every key unblocked
+    (mask2former_head.py:459-470 and :538-539).  Kept once per query and broadcast over heads."""
+    _need_gpu(mask_embed, mask_feature)
+    logits = torch.einsum('bqc,bchw->bqhw', mask_embed, mask_feature)
+    with torch.no_grad():
+        small = torch.nn.functional.interpolate(logits, tuple(target_size), mode='bilinear', align_corners=False)
+        blocked = small.flatten(2).float().sigmoid() < 0.5
+        blocked = blocked & ~blocked.all(-1, keepdim=True)
+    return logits, blocked.unsqueeze(1)

@@ -1,0 +1,151 @@
+"""Swin backbone of MaskBEV, organised around channels-last (B, H, W, C) token maps.
+
+Mirrors the interface and the checkpoint keys of ``CustomSwinTransformer``
+(/root/reference: mask_bev/models/networks/swin/swin.py:465-774); the shifted-window attention
+(swin.py:80-118,179-284) is one fused op, :func:`mask_bev_amd.ops.window_attention`, that folds
+padding, cyclic shift, window partition/reverse, relative-position bias and the shift mask into its
+addressing instead of materialising five layout copies per block.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import FFN, PatchEmbed, PatchMerging, trunc_normal_
+
+
+def relative_position_index(ws: int) -> torch.Tensor:
+    """(ws², ws²) index into the (2ws-1)² bias table: (dy + ws - 1) * (2ws - 1) + (dx + ws - 1) with
+    d = query - key.  Same values as the buffer built at swin.py:64-68."""
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)   # (2, ws²)
+    rel = coords[:, :, None] - coords[:, None, :] + (ws - 1)
+    return (rel[0] * (2 * ws - 1) + rel[1]).contiguous()
+
+
+class WindowMSA(nn.Module):
+    """Parameter holder of one window attention (keys as swin.py:59-73)."""
+
+    def __init__(self, embed_dims: int, num_heads: int, window_size: int):
+        super().__init__()
+        self.embed_dims, self.num_heads, self.window_size = embed_dims, num_heads, window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
+        self.register_buffer('relative_position_index', relative_position_index(window_size))
+        self.qkv = nn.Linear(embed_dims, embed_dims * 3)
+        self.proj = nn.Linear(embed_dims, embed_dims)
+        trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class ShiftWindowMSA(nn.Module):
+    def __init__(self, embed_dims: int, num_heads: int, window_size: int, shift_size: int):
+        super().__init__()
+        assert 0 <= shift_size < window_size
+        self.window_size, self.shift_size = window_size, shift_size
+        self.w_msa = WindowMSA(embed_dims, num_heads, window_size)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:           # (B, H, W, C) → (B, H, W, C)
+        m = self.w_msa
+        qkv = m.qkv(x)
+        o = ops.window_attention(qkv, m.qkv.bias, m.relative_position_bias_table, m.num_heads, self.window_size,
+                                 self.shift_size)
+        return m.proj(o)
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, embed_dims: int, num_heads: int, feedforward_channels: int, window_size: int, shift: bool):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(embed_dims)
+        self.attn = ShiftWindowMSA(embed_dims, num_heads, window_size, window_size // 2 if shift else 0)
+        self.norm2 = nn.LayerNorm(embed_dims)
+        self.ffn = FFN(embed_dims, feedforward_channels, act='gelu')
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x + self.attn(self.norm1(x))
+        return self.ffn(self.norm2(x), identity=x)
+
+
+class SwinBlockSequence(nn.Module):
+    def __init__(self, embed_dims: int, num_heads: int, feedforward_channels: int, depth: int, window_size: int,
+                 downsample: nn.Module = None):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            SwinBlock(embed_dims, num_heads, feedforward_channels, window_size, shift=(i % 2 == 1))
+            for i in range(depth)])
+        self.downsample = downsample
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        for blk in self.blocks:
+            x = blk(x)
+        return (self.downsample(x) if self.downsample is not None else x), x
+
+
+class CustomSwinTransformer(nn.Module):
+    """Same constructor keywords as the reference class (swin.py:523-548) for the subset MaskBEV uses
+    (mask_bev/models/backbones/mask_bev_backbone.py:39-64); dropout / drop-path are 0 there."""
+
+    def __init__(self, pretrain_img_size=224, in_channels=3, embed_dims=96, patch_size=4, window_size=7, mlp_ratio=4,
+                 depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), strides=(4, 2, 2, 2), out_indices=(0, 1, 2, 3),
+                 qkv_bias=True, qk_scale=None, patch_norm=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 use_abs_pos_embed=False, act_cfg=None, norm_cfg=None, with_cp=False, init_cfg=None,
+                 swap_dims=False, **_unused):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError('MaskBEV builds its backbone with all dropout rates at 0 '
+                                      '(mask_bev_backbone.py:55-57)')
+        if not qkv_bias or qk_scale is not None or not patch_norm:
+            raise NotImplementedError('only the MaskBEV configuration (qkv_bias, default scale, patch_norm)')
+        if isinstance(pretrain_img_size, int):
+            pretrain_img_size = (pretrain_img_size, pretrain_img_size)
+        assert strides[0] == patch_size, 'Use non-overlapping patch embed.'
+        self.out_indices = tuple(out_indices)
+        self.use_abs_pos_embed = use_abs_pos_embed
+        self.patch_embed = PatchEmbed(in_channels, embed_dims, patch_size)
+        if use_abs_pos_embed:
+            rows, cols = pretrain_img_size[0] // patch_size, pretrain_img_size[1] // patch_size
+            if swap_dims:
+                rows, cols = cols, rows
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, embed_dims, rows, cols))
+        self.stages = nn.ModuleList()
+        c = embed_dims
+        for i, depth in enumerate(depths):
+            down = PatchMerging(c, 2 * c, strides[i + 1]) if i < len(depths) - 1 else None
+            self.stages.append(SwinBlockSequence(c, num_heads[i], mlp_ratio * c, depth, window_size, down))
+            if down is not None:
+                c *= 2
+        self.num_features = [int(embed_dims * 2 ** i) for i in range(len(depths))]
+        for i in self.out_indices:
+            self.add_module(f'norm{i}', nn.LayerNorm(self.num_features[i]))
+
+    def init_weights(self):
+        """swin.py:674-682: trunc-normal(0.02) linears / abs-pos-embed, unit LayerNorms."""
+        if self.use_abs_pos_embed:
+            trunc_normal_(self.absolute_pos_embed, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = self.patch_embed(x)                                    # (B, H, W, E)
+        b, h, w, e = x.shape
+        if self.use_abs_pos_embed:
+            ape = self.absolute_pos_embed
+            w_, h_ = ape.shape[2:4]                                # swin.py:750 — (w, h) on purpose
+            if h != h_ or w != w_:
+                ape = F.interpolate(ape, size=(h, w), mode='bicubic', align_corners=False)
+            # the reference flattens the (rows, cols) map row-major into the token axis, whatever h, w are
+            x = x + ape.flatten(2).transpose(1, 2).reshape(1, h, w, e)
+        outs = []
+        for i, stage in enumerate(self.stages):
+            x, out = stage(x)
+            if i in self.out_indices:
+                out = getattr(self, f'norm{i}')(out)
+                outs.append(out.permute(0, 3, 1, 2).contiguous())
+        return outs

@@ -1,0 +1,107 @@
+"""End-to-end GPU parity of the product MaskBevModule against the oracle on identical weights and inputs.
+Tolerance: mask / class logits within 1e-3 relative (fp32), as BASELINE.json's north_star states."""
+import pytest
+import torch
+
+from oracle import maskbev_oracle as O
+from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+def _build(kw, device, seed=0):
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    cfg = O.make_cfg(**kw)
+    sd = O.make_state_dict(cfg, seed)
+    m = MaskBevModule(**kw)
+    m.load_state_dict(sd, strict=True)
+    return m.to(device), cfg, sd
+
+
+@pytest.mark.parametrize('nx,ny,ws', [(80, 80, 5), (96, 64, 5), (72, 88, 4)])
+def test_forward_matches_oracle(device, nx, ny, ws):
+    kw = tiny_kwargs(nx=nx, ny=ny, ws=ws)
+    m, cfg, sd = _build(kw, device)
+    scans = random_scans(kw, [3000, 1800], seed=nx)
+    m.train()
+    with torch.no_grad():
+        cls, masks, heights = m([s.to(device) for s in scans])
+        enc = m.forward_encode([s.to(device) for s in scans])
+    with torch.no_grad():
+        enc_ref = O.encoder_forward(cfg, sd, scans, training=True)
+        feats_ref = O.swin_forward(cfg, sd, enc_ref)
+        cls_ref, masks_ref, _ = O.head_forward(cfg, sd, feats_ref)
+    assert _rel(enc.cpu(), enc_ref) < 1e-4
+    assert len(cls) == len(masks) == len(heights) == 10 and all(h is None for h in heights)
+    for i in range(10):
+        assert cls[i].shape == cls_ref[i].shape and masks[i].shape == masks_ref[i].shape
+        assert _rel(masks[i].cpu(), masks_ref[i]) < 1e-3, f'mask logits of decoder output {i}'
+        assert _rel(cls[i].cpu(), cls_ref[i]) < 1e-3, f'class logits of decoder output {i}'
+
+
+def test_backbone_and_head_stage_outputs(device):
+    kw = tiny_kwargs()
+    m, cfg, sd = _build(kw, device, seed=3)
+    x = torch.randn(2, 32, 80, 80, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        outs = m.forward_backbone(x.to(device))
+        outs_ref = O.swin_forward(cfg, sd, x)
+    for a, b in zip(outs, outs_ref):
+        assert a.shape == b.shape
+        assert _rel(a.cpu(), b) < 2e-4
+
+
+def test_eval_mode_uses_running_stats(device):
+    kw = tiny_kwargs()
+    m, cfg, sd = _build(kw, device, seed=5)
+    for k in list(sd):
+        if k.endswith('running_mean'):
+            sd[k] = torch.randn_like(sd[k]) * 0.1
+        if k.endswith('running_var'):
+            sd[k] = torch.rand_like(sd[k]) + 0.5
+    m.load_state_dict(sd)
+    m.eval()
+    scans = random_scans(kw, [2500], seed=1)
+    with torch.no_grad():
+        enc = m.forward_encode([s.to(device) for s in scans])
+        enc_ref = O.encoder_forward(cfg, sd, scans, training=False)
+    assert _rel(enc.cpu(), enc_ref) < 1e-4
+
+
+def test_loss_and_gradients_match_oracle(device):
+    kw = tiny_kwargs()
+    m, cfg, sd = _build(kw, device, seed=7)
+    cfg.num_points = 256
+    m._panoptic_head._panoptic_head.num_points = 256
+    m._panoptic_head._panoptic_head.point_seed = 11
+    scans = random_scans(kw, [3000, 2000], seed=2)
+    labels, gt = random_gt(kw, 2, 3, seed=4)
+    m.train()
+    loss = m.training_step(([s.to(device) for s in scans], (labels.to(device), gt.to(device))), 1)
+    loss.backward()
+    # oracle
+    sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
+            for k, v in sd.items()}
+    cls_ref, masks_ref, _ = O.model_forward(cfg, sd_g, scans, training=True)
+    ld = O.loss_dict(cfg, cls_ref, masks_ref, labels, gt, O.PointSource(11))
+    loss_ref = O.total_loss(ld)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) / abs(float(loss_ref)) < 1e-3
+    got = dict(m.named_parameters())
+    checked = 0
+    for k in ['_encoder._voxel_encoder.pfn_layers.0.linear.weight', '_encoder._voxel_encoder.pfn_layers.2.norm.weight',
+              '_encoder._layer_norm.weight', '_backbone._backbone.patch_embed.projection.weight',
+              '_backbone._backbone.stages.1.blocks.1.attn.w_msa.relative_position_bias_table',
+              '_backbone._backbone.stages.2.blocks.0.ffn.layers.1.weight',
+              '_panoptic_head._panoptic_head.pixel_decoder.encoder.layers.0.self_attn.sampling_offsets.weight',
+              '_panoptic_head._panoptic_head.pixel_decoder.encoder.layers.1.self_attn.value_proj.weight',
+              '_panoptic_head._panoptic_head.transformer_decoder.layers.2.cross_attn.attn.in_proj_weight',
+              '_panoptic_head._panoptic_head.mask_embed.4.weight', '_panoptic_head._panoptic_head.query_feat.weight']:
+        g, r = got[k].grad.cpu(), sd_g[k].grad
+        assert r is not None and _rel(g, r) < 5e-3, k
+        checked += 1
+    assert checked == 11
