@@ -90,6 +90,9 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
  * [start[b], start[b+1])); cell_to_pillar (batch, cells) i32; weight/bias (C, cells) f32;
  * out (batch, C, cells) f32; stats (batch, 2) f32 = (mean, rstd), saved for backward.
  * workspace: mbv_scatter_layernorm_workspace_bytes(batch).
+ * ev_start / ev_stop: optional hipEvent_t (NULL = none) recorded on `stream` immediately before and
+ * after the dominant streaming kernel of the call (the apply kernel / the dense backward kernel), so
+ * that a caller can time exactly that kernel (bench.py's roofline figure).
  */
 size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch);
 
@@ -97,7 +100,7 @@ int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_st
                               const int32_t* cell_to_pillar, const float* weight, const float* bias,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
                               float* out, float* stats, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              void* stream, void* ev_start, void* ev_stop);
 
 /* Backward: grad_out (batch, C, cells) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
  * `accumulate` != 0 adds into grad_weight / grad_bias instead of overwriting them. */
@@ -106,7 +109,8 @@ int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats,
                               const float* weight, const float* stats,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
                               float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              void* workspace, size_t workspace_bytes, void* stream,
+                              void* ev_start, void* ev_stop);
 
 #ifdef __cplusplus
 }

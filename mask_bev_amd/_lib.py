@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MaskBevHipError(RuntimeError):
@@ -33,9 +33,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gather_voxels': (ctypes.c_int, [_P, _I, _P, _L, _I, _P, _P]),
     'mbv_pfn_decorate': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     'mbv_scatter_layernorm_workspace_bytes': (c_size_t, [_I]),
-    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, c_size_t, _P]),
+    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, c_size_t, _P, _P,
+                                                 _P]),
     'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
-                                                 c_size_t, _P]),
+                                                 c_size_t, _P, _P, _P]),
 }
 
 _lib = None

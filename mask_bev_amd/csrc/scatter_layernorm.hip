@@ -314,7 +314,8 @@ extern "C" size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch) {
 extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps, float* out,
-                                         float* stats, void* workspace, size_t workspace_bytes, void* stream_) {
+                                         float* stats, void* workspace, size_t workspace_bytes, void* stream_,
+                                         void* ev_start, void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
@@ -328,6 +329,7 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
   hipLaunchKernelGGL(k_ln_finalize, dim3((batch + 63) / 64), dim3(64), 0, stream, sums, batch, inv_count, eps, stats);
   MBV_CHECK_LAUNCH();
   const int ctiles = (channels + kCT - 1) / kCT;
+  if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
     hipLaunchKernelGGL(k_ln_apply<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar, weight,
@@ -338,6 +340,7 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
                        bias, stats, batch, channels, ny, nx, xtiles, out);
   }
   MBV_CHECK_LAUNCH();
+  if (ev_stop) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_stop), stream));
   return MBV_OK;
 }
 
@@ -345,7 +348,8 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
                                          const int32_t* cell_to_pillar, const float* weight, const float* stats,
                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
                                          float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
-                                         void* workspace, size_t workspace_bytes, void* stream_) {
+                                         void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
+                                         void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
@@ -356,6 +360,7 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
   double* sums = reinterpret_cast<double*>(workspace);
   MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * batch, stream));
   const int ctiles = (channels + kCT - 1) / kCT;
+  if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
     hipLaunchKernelGGL(k_ln_bwd_dense<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, grad_out, feats,
@@ -368,6 +373,7 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
                        grad_bias, accumulate, sums);
   }
   MBV_CHECK_LAUNCH();
+  if (ev_stop) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_stop), stream));
   if (num_pillars > 0) {
     const double inv_count = 1.0 / ((double)channels * ny * nx);
     const int64_t n4 = num_pillars * channels / 4;

@@ -31,6 +31,34 @@ def _need_gpu(*tensors: torch.Tensor) -> None:
                                   f'{t.device} tensor')
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the dominant kernel of a C-ABI call (used by bench.py's roofline leg).
+    Events are recorded by the library itself on the launch stream, right around that one kernel."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}          # name -> list of (start_event, stop_event)
+
+    def events(self, name: str):
+        if not self.enabled:
+            return None, None, ctypes.c_void_p(0), ctypes.c_void_p(0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()                 # forces creation of the underlying hipEvent_t; re-recorded by the library
+        b.record()
+        self.records.setdefault(name, []).append((a, b))
+        return a, b, ctypes.c_void_p(a.cuda_event), ctypes.c_void_p(b.cuda_event)
+
+    def summary_ms(self):
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.records.items()}
+
+    def reset(self):
+        self.records = {}
+
+
+TIMER = KernelTimer()
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -165,7 +193,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         rc = lib.mbv_scatter_layernorm_fwd(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
                                            _ptr(bias), batch, c, ny, nx, float(eps), _ptr(out), _ptr(stats), _ptr(ws),
-                                           ws.numel(), _stream())
+                                           ws.numel(), _stream(), *TIMER.events('k_ln_apply')[2:])
         check(rc, 'mbv_scatter_layernorm_fwd')
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
@@ -185,7 +213,8 @@ class _ScatterLayerNorm(torch.autograd.Function):
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), _ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar),
                                            _ptr(weight), _ptr(stats), batch, c, ny, nx, int(feats.shape[0]),
-                                           _ptr(g_feats), _ptr(g_w), _ptr(g_b), 0, _ptr(ws), ws.numel(), _stream())
+                                           _ptr(g_feats), _ptr(g_w), _ptr(g_b), 0, _ptr(ws), ws.numel(), _stream(),
+                                           *TIMER.events('k_ln_bwd_dense')[2:])
         check(rc, 'mbv_scatter_layernorm_bwd')
         return g_feats, g_w, g_b, None, None, None, None, None, None
 
