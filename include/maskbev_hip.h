@@ -112,6 +112,29 @@ int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats,
                               void* workspace, size_t workspace_bytes, void* stream,
                               void* ev_start, void* ev_stop);
 
+/* ------------------------------------------------------------------------------------------------
+ * K5 — multi-scale deformable attention of the pixel decoder, forward / backward.
+ * Replaces: mmcv MultiScaleDeformableAttention's `ms_deform_attn_forward/backward` CUDA op (or its
+ * grid_sample fallback), configured at mask_bev/models/head/mask_bev_panoptic_head.py:127-136 and run inside
+ * `self.pixel_decoder(x)` (mask_bev/models/networks/mask2former_head/mask2former_head.py:500).
+ * value (B, Nv, H, D) f32; spatial_shapes (L, 2) i64 (h, w); level_start (L) i64; sampling_loc
+ * (B, Nq, H, L, P, 2) f32 in [0, 1] (x, y); attn_weight (B, Nq, H, L, P) f32; out (B, Nq, H*D) f32.
+ * Bilinear sampling at loc*size - 0.5 with zero padding (grid_sample align_corners=False).
+ * head_dim must be a power of two <= 64.  Backward zero-fills grad_value itself, then accumulates with
+ * f32 atomics (sums may differ in the last bits from run to run).
+ */
+int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                           const float* sampling_loc, const float* attn_weight,
+                           int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
+                           int32_t num_levels, int32_t num_query, int32_t num_points,
+                           float* out, void* stream);
+
+int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
+                           int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
+                           int32_t num_levels, int32_t num_query, int32_t num_points,
+                           float* grad_value, float* grad_loc, float* grad_attn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -302,24 +302,45 @@ def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torc
 # --------------------------------------------------------------------------------------
 # K5 multi-scale deformable attention
 # --------------------------------------------------------------------------------------
+class _MSDeformAttn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, value, shapes_t, level_start, loc, attn):
+        lib = _lib.load()
+        _need_gpu(value, shapes_t, level_start, loc, attn)
+        value, loc, attn = value.contiguous(), loc.contiguous(), attn.contiguous()
+        b, nv, nh, d = value.shape
+        _, nq, _, nl, npnt, _ = loc.shape
+        out = torch.empty((b, nq, nh * d), dtype=torch.float32, device=value.device)
+        rc = lib.mbv_ms_deform_attn_fwd(_ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, nv,
+                                        nh, d, nl, nq, npnt, _ptr(out), _stream())
+        check(rc, 'mbv_ms_deform_attn_fwd')
+        ctx.save_for_backward(value, shapes_t, level_start, loc, attn)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        value, shapes_t, level_start, loc, attn = ctx.saved_tensors
+        b, nv, nh, d = value.shape
+        _, nq, _, nl, npnt, _ = loc.shape
+        grad_out = grad_out.to(torch.float32).contiguous()
+        g_value = torch.empty_like(value)
+        g_loc = torch.empty_like(loc)
+        g_attn = torch.empty_like(attn)
+        rc = lib.mbv_ms_deform_attn_bwd(_ptr(grad_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
+                                        _ptr(attn), b, nv, nh, d, nl, nq, npnt, _ptr(g_value), _ptr(g_loc),
+                                        _ptr(g_attn), _stream())
+        check(rc, 'mbv_ms_deform_attn_bwd')
+        return g_value, None, None, g_loc, g_attn
+
+
 def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, level_start: torch.Tensor,
                    sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
     """value (B, N, H, D); sampling_locations (B, Nq, H, L, P, 2) in [0,1]; weights (B, Nq, H, L, P)
-    → (B, Nq, H*D).  Bilinear, zero padding, align_corners=False (mmcv ``ms_deform_attn``)."""
-    _need_gpu(value)
-    bs, _, nh, d = value.shape
-    _, nq, _, nl, npnt, _ = sampling_locations.shape
-    value_list = value.split([h * w for h, w in spatial_shapes], dim=1)
-    grids = 2 * sampling_locations - 1
-    sampled = []
-    for lvl, (h, w) in enumerate(spatial_shapes):
-        v = value_list[lvl].flatten(2).transpose(1, 2).reshape(bs * nh, d, h, w)
-        g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)
-        sampled.append(torch.nn.functional.grid_sample(v, g.to(v.dtype), mode='bilinear', padding_mode='zeros',
-                                                       align_corners=False))
-    aw = attention_weights.transpose(1, 2).reshape(bs * nh, 1, nq, nl * npnt)
-    out = (torch.stack(sampled, dim=-2).flatten(-2) * aw.to(value.dtype)).sum(-1).view(bs, nh * d, nq)
-    return out.transpose(1, 2).contiguous()
+    → (B, Nq, H*D) f32.  Bilinear, zero padding, align_corners=False (K5, include/maskbev_hip.h)."""
+    return _MSDeformAttn.apply(value, shapes_t, level_start, sampling_locations, attention_weights)
 
 
 # --------------------------------------------------------------------------------------
