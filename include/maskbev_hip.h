@@ -6,7 +6,7 @@
  *   - the caller owns every buffer, including `workspace`; the library never allocates, frees or
  *     retains pointers, keeps no mutable global state and is re-entrant;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no hidden device sync;
- *   - return value: 0 = success, < 0 = mbv_status (bad argument), > 0 = hipError_t of a failed launch;
+ *   - return value: 0 = success, < 0 = an `mbv_status` code: bad argument, > 0 = hipError_t of a failed launch;
  *   - no exceptions, no abort, no stdout.
  *
  * Each entry point cites the reference interface it replaces (file:line under the reference tree).

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ 
     if (x0 + gcell < nx) pid = cell_to_pillar[(int64_t)b * cells + (int64_t)y * nx + x0 + gcell];
     gather_tile<VEC>(feats, channels, c0, pid, lds);
     __syncthreads();
-    double s1 = 0.0, s2 = 0.0;
+    float s1f = 0.f, s2f = 0.f;   // <= 32 terms per thread and scan: f32 partials, f64 across threads
     if (x_ok) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -231,15 +231,15 @@ __global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ 
             dw[k][e] += g[e] * xhat;
             db[k][e] += g[e];
             gw[e] = g[e] * w[k][e];
-            s1 += (double)gw[e];
-            s2 += (double)gw[e] * (double)xhat;
+            s1f += gw[e];
+            s2f += gw[e] * xhat;
           }
           store_vec<VEC>(&lds[cl * T::LD + lane * VEC], gw);
         }
       }
     }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
+    const double s1 = wave_sum_d((double)s1f);
+    const double s2 = wave_sum_d((double)s2f);
     if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -635,11 +635,12 @@ class PointSource:
     per decoder output: B x rand(1, P, 2) (matcher, mask2former_head.py:191), then rand(G, 3P, 2) and
     rand(G, P - int(0.75 P), 2) (importance sampling).  CPU generator so product and oracle can share it."""
 
-    def __init__(self, seed: int = 0):
-        self.gen = torch.Generator().manual_seed(seed)
+    def __init__(self, seed: Optional[int] = 0):
+        # seed=None → the global torch RNG (what the reference itself draws from)
+        self.gen = None if seed is None else torch.Generator().manual_seed(seed)
 
     def rand(self, *shape) -> Tensor:
-        return torch.rand(*shape, generator=self.gen)
+        return torch.rand(*shape) if self.gen is None else torch.rand(*shape, generator=self.gen)
 
 
 def point_sample(inp: Tensor, points: Tensor) -> Tensor:

@@ -1,0 +1,150 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/maskbev_hip.h declares, host-side logic
+of the boundary (constructor keys, state_dict layout, registry names, error behaviour), oracle known answers."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maskbev_oracle as O
+from tests.util_cfg import tiny_kwargs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from mask_bev_amd import _lib, build
+    build.build()
+    header = open(os.path.join(ROOT, 'include', 'maskbev_hip.h')).read()
+    declared = set(re.findall(r'\b(mbv_[a-z0-9_]+)\s*\(', header))
+    assert declared and declared == set(_lib.SIGNATURES.keys())
+    lib = _lib.load()                      # binds all of them, raises on a missing symbol
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mbv_abi_version() == _lib.ABI_VERSION
+    assert lib.mbv_voxelize_workspace_bytes(120000, 4, 512 * 512) > 4 * 4 * 120000
+
+
+def test_product_path_refuses_cpu_tensors():
+    from mask_bev_amd import ops
+    from mask_bev_amd._lib import MaskBevHipError
+    geom = ops.VoxelGeometry.from_ranges([-1, -1, -1, 1, 1, 1], [0.5, 0.5, 2])
+    assert geom.grid == [4, 4, 1]
+    with pytest.raises(MaskBevHipError):
+        ops.voxelize([torch.zeros(10, 4)], geom, 4, 100)
+    with pytest.raises(MaskBevHipError):
+        ops.window_attention(torch.zeros(1, 5, 5, 12), torch.zeros(12), torch.zeros(81, 1), 1, 5, 0)
+
+
+def test_module_constructor_state_dict_and_config_contract(tmp_path):
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    kw = tiny_kwargs()
+    extra = dict(checkpoint=None, num_workers=4, pin_memory=True, remove_unseen=True, shuffle_train=True,
+                 min_num_points=1, augmentations={}, dataset='semantic-kitti', limit_train_batches=1.0,
+                 log_every_n_steps=50, min_num_inst_pixels=10)             # YAML keys the module must swallow
+    m = MaskBevModule.from_config({**kw, **extra})
+    sd_ref = O.make_state_dict(O.make_cfg(**kw))
+    sd = m.state_dict()
+    assert set(sd) == set(sd_ref)
+    assert all(tuple(sd[k].shape) == tuple(sd_ref[k].shape) for k in sd)
+    # sub-module attribute names = checkpoint keys
+    assert hasattr(m._encoder, '_voxel_layer') and hasattr(m._encoder, '_voxel_encoder')
+    assert hasattr(m._encoder, '_middle_encoder') and hasattr(m._encoder, '_layer_norm')
+    assert hasattr(m._backbone, '_backbone') and hasattr(m._panoptic_head, '_panoptic_head')
+    opt = m.configure_optimizers()
+    assert set(opt) == {'optimizer', 'lr_scheduler', 'monitor', 'interval'} and opt['monitor'] == 'train_loss'
+    assert isinstance(opt['optimizer'], torch.optim.AdamW)
+    with pytest.raises(RuntimeError, match='Invalid batch'):
+        m.training_step((1, 2, 3, 4), 0)
+    with pytest.raises(ValueError, match='Could not load checkpoint'):
+        MaskBevModule.from_config({**kw, 'checkpoint': str(tmp_path / 'nope.ckpt')})
+    # checkpoint round trip through the Lightning-style file layout
+    path = tmp_path / 'last.ckpt'
+    torch.save({'state_dict': sd, 'hyper_parameters': {}}, path)
+    m2 = MaskBevModule.from_config({**kw, 'checkpoint': 'last'}, tmp_path)
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), sd.values()))
+    assert m.loss({'loss_a': torch.tensor(1.0), 'd0.loss_b': torch.tensor(2.0), 'other': torch.tensor(5.0)}) == 3.0
+
+
+def test_registry_resolves_reference_type_strings():
+    from mask_bev_amd.registry import MODELS, TASK_UTILS
+    for name in ['Voxelization', 'PillarFeatureNet', 'PointPillarsScatter', 'CustomSwinTransformer', 'Mask2FormerHead',
+                 'mmdet.MSDeformAttnPixelDecoder', 'mmdet.CrossEntropyLoss', 'mmdet.DiceLoss']:
+        assert MODELS.get(name) is not None
+    for name in ['mmdet.HungarianAssigner', 'mmdet.ClassificationCost', 'mmdet.CrossEntropyLossCost', 'mmdet.DiceCost',
+                 'mmdet.MaskPseudoSampler']:
+        assert TASK_UTILS.get(name) is not None
+    with pytest.raises(KeyError):
+        MODELS.get('mmdet.DoesNotExist')
+
+
+def test_relative_position_index_closed_form():
+    from mask_bev_amd.swin import relative_position_index
+    for ws in (4, 5, 7, 10):
+        assert torch.equal(relative_position_index(ws), O.rel_position_index(ws))
+
+
+def test_grid_sizes_of_all_workloads():
+    """int((max-min)/vs) (mask_bev_module.py:68-69) and mmcv's round() agree for every named workload."""
+    from mask_bev_amd import synthetic
+    want = {'semantic_kitti_512': (512, 512), 'kitti_496x432': (432, 496), 'waymo_1024': (1024, 1024)}
+    for name, (nx, ny) in want.items():
+        cfg = O.make_cfg(**synthetic.module_kwargs(name, 1))
+        assert (cfg.nx, cfg.ny) == (nx, ny) and cfg.grid3 == [nx, ny, 1]
+
+
+# ---------------------------------------------------------------- oracle known answers (A1/A2)
+def _vox(points, P=2, max_voxels=100):
+    cfg = O.make_cfg(x_range=(0, 4), y_range=(0, 4), z_range=(-1, 1), voxel_size=1.0, num_queries=1, max_num_points=P,
+                     encoder_feat_channels=[4], backbone_embed_dim=4, head_feat_channels=4, head_out_channels=4,
+                     max_voxels=max_voxels)
+    pts = torch.tensor(points, dtype=torch.float32)
+    return O.voxelize(cfg, [pts]), O.voxelize(cfg, [pts], use_c=False)
+
+
+def test_voxelize_known_answers():
+    pts = [[0.5, 0.5, 0, 1], [3.5, 0.5, 0, 2], [0.6, 0.4, 0, 3], [0.7, 0.3, 0, 4],     # third point of cell (0,0) dropped
+           [0.0, 0.5, 0, 5],                      # x == x_min: rejected by the strict pre-filter
+           [1.0, 2.0, 0, 6],                      # on a cell border: belongs to the upper cell
+           [3.999, 3.999, 0.999, 7], [2.0, 2.0, 1.0, 8]]                                # z == z_max rejected
+    (v, n, c), (v2, n2, c2) = _vox(pts)
+    assert torch.equal(c, torch.tensor([[0, 0, 0, 0], [0, 0, 0, 3], [0, 0, 2, 1], [0, 0, 3, 3]], dtype=torch.int32))
+    assert n.tolist() == [2, 1, 1, 1]
+    assert v[0, :, 3].tolist() == [1.0, 3.0] and v[1, :, 3].tolist() == [2.0, 0.0]
+    assert torch.equal(v, v2) and torch.equal(n, n2) and torch.equal(c, c2)
+
+
+def test_voxelize_first_appearance_order_and_cap():
+    pts = [[2.5, 2.5, 0, 0], [0.5, 0.5, 0, 1], [2.6, 2.6, 0, 2], [1.5, 0.5, 0, 3]]
+    (v, n, c), _ = _vox(pts)
+    assert c[:, 2:].tolist() == [[2, 2], [0, 0], [0, 1]]          # order of first appearance, not sorted
+    (v, n, c), (v2, n2, c2) = _vox(pts, max_voxels=2)
+    assert c[:, 2:].tolist() == [[2, 2], [0, 0]] and n.tolist() == [2, 1]
+    assert torch.equal(c, c2)
+
+
+def test_pfn_legacy_decoration_known_answer():
+    """Channels 0-2 become centre offsets (legacy aliasing) and the distance is their norm."""
+    cfg = O.make_cfg(x_range=(0, 4), y_range=(0, 4), z_range=(-1, 1), voxel_size=1.0, num_queries=1, max_num_points=2,
+                     encoder_feat_channels=[4], backbone_embed_dim=4, head_feat_channels=4, head_out_channels=4)
+    voxels = torch.tensor([[[2.25, 1.75, 0.5, 9.0], [2.75, 1.25, -0.5, 7.0]]])
+    d = O.pfn_decorate(cfg, voxels, torch.tensor([2]), torch.tensor([[0, 0, 1, 2]]))
+    fc0 = torch.tensor([2.25 - 2.5, 1.75 - 1.5, 0.5 - 0.0])
+    assert torch.allclose(d[0, 0, :3], fc0) and torch.allclose(d[0, 0, 7:10], fc0)
+    assert d[0, 0, 3] == 9.0
+    assert torch.allclose(d[0, 0, 4:7], torch.tensor([-0.25, 0.25, 0.5]))           # offset from the pillar mean
+    assert torch.allclose(d[0, 0, 10], fc0.norm())
+
+
+def test_window_partition_roundtrip_and_all_masked_rule():
+    x = torch.randn(2, 10, 15, 3)
+    assert torch.equal(O._window_reverse(O._window_partition(x, 5), 10, 15, 5), x)
+    cfg = O.make_cfg(**tiny_kwargs())
+    sd = O.make_state_dict(cfg)
+    # a mask feature of all-negative logits blocks every key → the reference un-blocks such rows
+    q = torch.zeros(1, cfg.num_queries, cfg.head_feat)
+    mf = -torch.ones(1, cfg.head_out, 8, 8)
+    _, _, blocked = O.forward_head(cfg, sd, q, mf, (4, 4))
+    blocked[torch.where(blocked.sum(-1) == blocked.shape[-1])] = False
+    assert not blocked.all(-1).any()
