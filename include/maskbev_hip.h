@@ -135,6 +135,30 @@ int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int6
                            int32_t num_levels, int32_t num_query, int32_t num_points,
                            float* grad_value, float* grad_loc, float* grad_attn, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K4 — fused shifted-window multi-head attention (between the qkv and the output projection).
+ * Replaces: ShiftWindowMSA.forward (mask_bev/models/networks/swin/swin.py:179-253: pad, roll, window
+ * partition, mask, reverse, un-roll, crop) + WindowMSA.forward (:80-118: head split, q k^T * scale +
+ * relative-position bias [+ shift mask], softmax, . v) + window_partition/reverse (:255-284).
+ * qkv (B, H, W, 3C) channels-last, f32 (is_bf16 = 0: exact-f32 MFMA) or bf16 (is_bf16 = 1); tokens the
+ * reference pads in take qkv_bias (3C) f32; bias_table ((2ws-1)^2, heads) f32; out (B, H, W, C) same dtype
+ * as qkv; lse: mbv_window_attn_lse_elems(...) f32, saved for backward.  head_dim = C / heads must be
+ * 16, 32 or 64 and ws <= 11.
+ * Backward zero-fills grad_table ((2ws-1)^2, heads) and grad_qkv_bias (3C: gradient reaching the bias
+ * through padded tokens) itself, then accumulates them with f32 atomics; grad_qkv (B, H, W, 3C) is
+ * written in full.
+ */
+int64_t mbv_window_attn_lse_elems(int32_t batch, int32_t H, int32_t W, int32_t heads, int32_t ws);
+
+int mbv_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_table, int32_t is_bf16,
+                        int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
+                        void* out, float* lse, void* stream);
+
+int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
+                        const void* grad_out, const float* lse, int32_t is_bf16,
+                        int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
+                        void* grad_qkv, float* grad_table, float* grad_qkv_bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

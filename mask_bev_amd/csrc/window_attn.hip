@@ -1,0 +1,585 @@
+// K4 — fused shifted-window multi-head attention (Swin W-MSA / SW-MSA), forward and backward, gfx950.
+//
+// Replaces ShiftWindowMSA.forward + WindowMSA.forward of the reference
+// (mask_bev/models/networks/swin/swin.py:179-253 and :80-118; window_partition/reverse :255-284) between the
+// qkv projection and the output projection.  The reference pads the map to a multiple of the window, rolls
+// it, partitions it into windows, permutes qkv into heads, adds the gathered relative-position bias and the
+// shift mask, soft-maxes, multiplies by v, and undoes all of that: five full-tensor layout copies per block
+// plus unfused batched GEMMs.  Here ONE workgroup owns one (window, head): padding, cyclic shift, window
+// partition/reverse and head split are pure addressing on the channels-last (B, H, W, 3C) qkv map, bias and
+// mask are added in registers, and both contractions run on MFMA:
+//     S^T = K Q^T            (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for f32 inputs: exact f32)
+//     O   = P V              (P stays in the accumulator registers: "accumulator tile as next operand",
+//                             cdna_hip_programming.md §3 — no LDS round trip for the probabilities)
+// A window has ws*ws <= 128 tokens, so the whole score matrix of a (window, head) lives in one workgroup
+// (4 waves x 32 query rows) and the softmax is exact (no online rescaling).
+//
+// Backward is flash-attention style with the forward's log-sum-exp: part 1 (lane = query) recomputes S^T,
+// P, dP, dS and forms dQ with the register trick; part 2 (wave = key block) recomputes S, P, dP, dS in the
+// un-swapped orientation, where the tiles are directly the A operands of dV = P^T dO and dK = dS^T Q.
+// Padded tokens (the reference pads AFTER LayerNorm, so their q, k, v equal the qkv bias) send their
+// gradient to a (3C) bias-gradient buffer; the relative-position-bias gradient is reduced in LDS per
+// workgroup and then added to the table gradient with one atomic per entry.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+constexpr int NPAD = 128;   // max tokens per window (ws <= 11), 4 blocks of 32
+constexpr int NBLK = 4;
+
+struct WinGeom {
+  int batch, H, W, C, heads, ws, shift, Hp, Wp, nWh, nWw, N;
+};
+
+template <bool BF16, int D>
+struct Lay {
+  using T = std::conditional_t<BF16, __bf16, float>;
+  static constexpr int RS = BF16 ? D + 8 : D + 1;          // row stride of [token][d] images (elements)
+  static constexpr int TROWS = D < 32 ? 32 : D;             // rows of [d][token] images (zero rows beyond D)
+  static constexpr int TS = NPAD + 8;                       // row stride of [d][token] images
+  static constexpr int ROW_IMG = NPAD * RS;
+  static constexpr int T_IMG = TROWS * TS;
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+
+// accumulator register i of a 32x32 tile, lane half h  ->  row inside the 32-row block
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// token t of window (wy, wx) -> pixel index inside the (H, W) map, or -1 for a padded token
+__device__ __forceinline__ int token_pixel(const WinGeom& g, int wy, int wx, int t) {
+  const int ty = t / g.ws, tx = t - ty * g.ws;
+  int y = wy * g.ws + ty + g.shift;
+  int x = wx * g.ws + tx + g.shift;
+  if (y >= g.Hp) y -= g.Hp;
+  if (x >= g.Wp) x -= g.Wp;
+  return (y < g.H && x < g.W) ? y * g.W + x : -1;
+}
+
+// region label of the shifted-window mask (swin.py:198-219)
+__device__ __forceinline__ int region_label(const WinGeom& g, int wy, int wx, int t) {
+  if (g.shift == 0) return 0;
+  const int ty = t / g.ws, tx = t - ty * g.ws;
+  const int ys = wy * g.ws + ty, xs = wx * g.ws + tx;
+  const int ry = ys < g.Hp - g.ws ? 0 : (ys < g.Hp - g.shift ? 1 : 2);
+  const int rx = xs < g.Wp - g.ws ? 0 : (xs < g.Wp - g.shift ? 1 : 2);
+  return ry * 3 + rx;
+}
+
+struct BlockId {
+  int b, wy, wx, head;
+};
+__device__ __forceinline__ BlockId decode_block(const WinGeom& g) {
+  int id = blockIdx.x;
+  BlockId r;
+  r.head = id % g.heads;
+  id /= g.heads;
+  r.wx = id % g.nWw;
+  id /= g.nWw;
+  r.wy = id % g.nWh;
+  r.b = id / g.nWh;
+  return r;
+}
+
+// Stage `part` (0 q, 1 k, 2 v) of this (window, head) into a [token][d] image and/or a [d][token] image.
+// Padded tokens take the qkv bias (swin.py:185-188 pads zeros after LayerNorm => qkv == bias).
+template <bool BF16, int D, typename TIn>
+__device__ __forceinline__ void stage_part(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
+                                           const TIn* __restrict__ src, int src_row_stride, int src_col,
+                                           const float* __restrict__ pad_vec /* may be null -> zeros */,
+                                           typename Lay<BF16, D>::T* row_img, typename Lay<BF16, D>::T* t_img) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  constexpr int CH = D / 8;   // 8-element chunks per token
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c8 = (idx - t * CH) * 8;
+    float v[8];
+    if (t < g.N) {
+      const int pix = pix_lds[t];
+      if (pix >= 0) {
+        const TIn* p = src + ((int64_t)id.b * g.H * g.W + pix) * src_row_stride + src_col + c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f(p[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pad_vec ? pad_vec[src_col + c8 + j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    if (row_img) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row_img[t * L::RS + c8 + j] = (T)v[j];
+    }
+    if (t_img) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t_img[(c8 + j) * L::TS + t] = (T)v[j];
+    }
+  }
+}
+
+template <bool BF16, int D>
+__device__ __forceinline__ void zero_t_tail(typename Lay<BF16, D>::T* t_img) {
+  using L = Lay<BF16, D>;
+  if constexpr (L::TROWS > D) {
+    for (int idx = threadIdx.x; idx < (L::TROWS - D) * L::TS; idx += blockDim.x)
+      t_img[D * L::TS + idx] = (typename L::T)0.f;
+  }
+}
+
+// ---- MFMA tile helpers ------------------------------------------------------------------------------
+// acc(32x32) += Arows[a0 + r][:] . Brows[b0 + r][:]^T   (contraction over d), both [row][d] images.
+// Result layout: col = lane&31 <-> B row, acc_row(i, h) <-> A row.
+template <bool BF16, int D>
+__device__ __forceinline__ void mma_rows(const typename Lay<BF16, D>::T* __restrict__ a_img, int a0,
+                                         const typename Lay<BF16, D>::T* __restrict__ b_img, int b0, f32x16& acc) {
+  using L = Lay<BF16, D>;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  if constexpr (BF16) {
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_img + (a0 + r) * L::RS + 16 * ks + 8 * h);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(b_img + (b0 + r) * L::RS + 16 * ks + 8 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  } else {
+#pragma unroll 8
+    for (int ks = 0; ks < D / 2; ++ks) {
+      const float a = a_img[(a0 + r) * L::RS + 2 * ks + h];
+      const float b = b_img[(b0 + r) * L::RS + 2 * ks + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+}
+
+// out(32 x 32 cols [cb]) += X^T . M  where X is an accumulator tile (rows = contraction index k0 + acc_row,
+// cols = lane = output row) and M holds the other operand: bf16 -> [d][token] image, f32 -> [token][d] image.
+template <bool BF16, int D>
+__device__ __forceinline__ void mma_acc_operand(const f32x16& x, const typename Lay<BF16, D>::T* __restrict__ m_img,
+                                                int k0, int cb, f32x16& out) {
+  using L = Lay<BF16, D>;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  if constexpr (BF16) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = (__bf16)x[8 * s + j];
+      // element j of half h is contraction index 16 s + 8 (j >> 2) + 4 h + (j & 3)
+      const typename L::T* p = m_img + (r + 32 * cb) * L::TS + k0 + 16 * s + 4 * h;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { b[j] = lo[j]; b[4 + j] = hi[j]; }
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out, 0, 0, 0);
+    }
+  } else {
+    const int col = r + 32 * cb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float b = col < D ? m_img[(k0 + acc_row(i, h)) * L::RS + col] : 0.f;
+      out = __builtin_amdgcn_mfma_f32_32x32x2f32(x[i], b, out, 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// additive bias + shift mask for (query q, key k); kinfo packs (ty | tx << 8 | label << 16) per token
+__device__ __forceinline__ float bias_mask(const float* __restrict__ tbl, const int* __restrict__ kinfo, int ws,
+                                           int q, int k, int* idx_out) {
+  const int qi = kinfo[q], ki = kinfo[k];
+  const int dy = (qi & 0xff) - (ki & 0xff) + ws - 1;
+  const int dx = ((qi >> 8) & 0xff) - ((ki >> 8) & 0xff) + ws - 1;
+  const int idx = dy * (2 * ws - 1) + dx;
+  if (idx_out) *idx_out = idx;
+  float v = tbl[idx];
+  if ((qi >> 16) != (ki >> 16)) v += -100.0f;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <bool BF16, int D, typename TIn>
+__global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__ qkv,
+                                                         const float* __restrict__ qkv_bias,
+                                                         const float* __restrict__ bias_table, WinGeom g, float scale,
+                                                         TIn* __restrict__ out, float* __restrict__ lse) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[BF16 ? L::T_IMG : L::ROW_IMG];
+  __shared__ float tbl[21 * 21];
+  __shared__ int kinfo[NPAD];
+  __shared__ int pix[NPAD];
+  const BlockId id = decode_block(g);
+  const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tbl[i] = bias_table[i * g.heads + id.head];
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    if (t < g.N) {
+      const int ty = t / g.ws, tx = t - ty * g.ws;
+      kinfo[t] = ty | (tx << 8) | (region_label(g, id.wy, id.wx, t) << 16);
+      pix[t] = token_pixel(g, id.wy, id.wx, t);
+    } else {
+      kinfo[t] = 0;
+      pix[t] = -1;
+    }
+  }
+  __syncthreads();
+  const int C3 = 3 * g.C, col = id.head * D;
+  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
+  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
+  if constexpr (BF16) {
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, nullptr, v_img);
+    zero_t_tail<BF16, D>(v_img);
+  } else {
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nblk = (g.N + 31) / 32;
+  if (wave >= nblk) return;
+  const int q = 32 * wave + r;
+  // S^T tiles: rows = keys (accumulator registers), cols = this wave's queries (lanes)
+  f32x16 s[NBLK];
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    s[kb] = zero16();
+    if (kb < nblk) mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 32 * kb + acc_row(i, h);
+      float v = -INFINITY;
+      if (kb < nblk && k < g.N) v = (q < g.N) ? s[kb][i] * scale + bias_mask(tbl, kinfo, g.ws, q, k, nullptr) : 0.f;
+      s[kb][i] = v;
+      m = fmaxf(m, v);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(s[kb][i] - m);     // exp(-inf) = 0 for padded keys
+      s[kb][i] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[kb][i] *= inv;
+  if (h == 0 && q < g.N) lse[(int64_t)blockIdx.x * NPAD + q] = m + __logf(sum);
+
+  // O = P V : rows = queries (accumulator registers), cols = d (lanes)
+  constexpr int NCB = (D + 31) / 32;
+  f32x16 o[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    o[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb)
+      if (kb < nblk) mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o[cb]);
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int dcol = r + 32 * cb;
+    if (dcol >= D) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = 32 * wave + acc_row(i, h);
+      if (qq < g.N) {
+        const int px = pix[qq];
+        if (px >= 0) out[((int64_t)id.b * g.H * g.W + px) * g.C + col + dcol] = (TIn)o[cb][i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <bool BF16, int D, typename TIn>
+__global__ void __launch_bounds__(256) k_window_attn_bwd(const TIn* __restrict__ qkv,
+                                                         const float* __restrict__ qkv_bias,
+                                                         const float* __restrict__ bias_table,
+                                                         const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
+                                                         const float* __restrict__ lse, WinGeom g, float scale,
+                                                         TIn* __restrict__ grad_qkv, float* __restrict__ grad_table,
+                                                         float* __restrict__ grad_pad /* (3C) */) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T do_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T kt_img[BF16 ? L::T_IMG : 1];
+  __shared__ __attribute__((aligned(16))) T qt_img[BF16 ? L::T_IMG : 1];
+  __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
+  __shared__ float tbl[21 * 21];
+  __shared__ float dtbl[21 * 21];
+  __shared__ int kinfo[NPAD];
+  __shared__ int pix[NPAD];
+  __shared__ float lse_s[NPAD];
+  __shared__ float delta_s[NPAD];
+  const BlockId id = decode_block(g);
+  const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) {
+    tbl[i] = bias_table[i * g.heads + id.head];
+    dtbl[i] = 0.f;
+  }
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    if (t < g.N) {
+      const int ty = t / g.ws, tx = t - ty * g.ws;
+      kinfo[t] = ty | (tx << 8) | (region_label(g, id.wy, id.wx, t) << 16);
+      pix[t] = token_pixel(g, id.wy, id.wx, t);
+      lse_s[t] = lse[(int64_t)blockIdx.x * NPAD + t];
+    } else {
+      kinfo[t] = 0;
+      pix[t] = -1;
+      lse_s[t] = 0.f;
+    }
+    delta_s[t] = 0.f;
+  }
+  __syncthreads();
+  const int C3 = 3 * g.C, col = id.head * D;
+  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, BF16 ? qt_img : nullptr);
+  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, BF16 ? kt_img : nullptr);
+  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
+  // dO is zero on padded tokens (the reference crops them away, swin.py:247-248)
+  stage_part<BF16, D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img, BF16 ? dot_img : nullptr);
+  if constexpr (BF16) {
+    zero_t_tail<BF16, D>(qt_img);
+    zero_t_tail<BF16, D>(kt_img);
+    zero_t_tail<BF16, D>(dot_img);
+  }
+  // delta[q] = sum_d dO[q][d] * O[q][d]
+  {
+    constexpr int CH = D / 8;
+    for (int idx = threadIdx.x; idx < g.N * CH; idx += blockDim.x) {
+      const int t = idx / CH, c8 = (idx - t * CH) * 8;
+      const int px = pix[t];
+      if (px < 0) continue;
+      const int64_t o = ((int64_t)id.b * g.H * g.W + px) * g.C + col + c8;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += to_f(out[o + j]) * to_f(grad_out[o + j]);
+      atomicAdd(&delta_s[t], acc);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nblk = (g.N + 31) / 32;
+  constexpr int NCB = (D + 31) / 32;
+  const int64_t row0 = (int64_t)id.b * g.H * g.W;
+
+  if (wave < nblk) {
+    // ---- part 1: lane = query.  dS^T tiles, relative-position-bias gradient, dQ
+    const int q = 32 * wave + r;
+    const float my_lse = lse_s[q], my_delta = delta_s[q];
+    f32x16 dq[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      if (kb >= nblk) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
+      mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = 32 * kb + acc_row(i, h);
+        float ds = 0.f;
+        if (q < g.N && k < g.N) {
+          int idx;
+          const float bm = bias_mask(tbl, kinfo, g.ws, q, k, &idx);
+          const float p = __expf(s[i] * scale + bm - my_lse);
+          ds = p * (dp[i] - my_delta);
+          atomicAdd(&dtbl[idx], ds);
+        }
+        s[i] = ds * scale;                       // dQ = scale * dS K
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) mma_acc_operand<BF16, D>(s, BF16 ? kt_img : k_img, 32 * kb, cb, dq[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (qq >= g.N) continue;
+        const int px = pix[qq];
+        if (px >= 0) grad_qkv[(row0 + px) * C3 + col + dcol] = (TIn)dq[cb][i];
+        else atomicAdd(&grad_pad[col + dcol], dq[cb][i]);
+      }
+    }
+
+    // ---- part 2: wave = key block.  dK, dV
+    const int kb = wave;
+    f32x16 dk[NCB], dv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
+    const int k = 32 * kb + r;                   // this lane's key (column of the un-swapped tiles)
+#pragma unroll
+    for (int qb = 0; qb < NBLK; ++qb) {
+      if (qb >= nblk) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);       // rows = queries, cols = keys
+      mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      f32x16 ds;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * qb + acc_row(i, h);
+        float p = 0.f, d = 0.f;
+        if (qq < g.N && k < g.N) {
+          p = __expf(s[i] * scale + bias_mask(tbl, kinfo, g.ws, qq, k, nullptr) - lse_s[qq]);
+          d = p * (dp[i] - delta_s[qq]) * scale;
+        }
+        s[i] = p;
+        ds[i] = d;
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        mma_acc_operand<BF16, D>(s, BF16 ? dot_img : do_img, 32 * qb, cb, dv[cb]);    // dV = P^T dO
+        mma_acc_operand<BF16, D>(ds, BF16 ? qt_img : q_img, 32 * qb, cb, dk[cb]);     // dK = scale dS^T Q
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * kb + acc_row(i, h);
+        if (kk >= g.N) continue;
+        const int px = pix[kk];
+        if (px >= 0) {
+          grad_qkv[(row0 + px) * C3 + g.C + col + dcol] = (TIn)dk[cb][i];
+          grad_qkv[(row0 + px) * C3 + 2 * g.C + col + dcol] = (TIn)dv[cb][i];
+        } else {
+          atomicAdd(&grad_pad[g.C + col + dcol], dk[cb][i]);
+          atomicAdd(&grad_pad[2 * g.C + col + dcol], dv[cb][i]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) atomicAdd(&grad_table[i * g.heads + id.head], dtbl[i]);
+}
+
+bool make_geom(int batch, int H, int W, int C, int heads, int ws, int shift, WinGeom& g) {
+  if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || ws <= 0 || shift < 0 || shift >= ws) return false;
+  if (C % heads != 0) return false;
+  g.batch = batch; g.H = H; g.W = W; g.C = C; g.heads = heads; g.ws = ws; g.shift = shift;
+  g.Hp = (H + ws - 1) / ws * ws;
+  g.Wp = (W + ws - 1) / ws * ws;
+  g.nWh = g.Hp / ws;
+  g.nWw = g.Wp / ws;
+  g.N = ws * ws;
+  return true;
+}
+
+template <bool BF16, typename TIn>
+int launch_fwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, const float* table, void* out,
+               float* lse, hipStream_t stream) {
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(256);
+  const TIn* q = reinterpret_cast<const TIn*>(qkv);
+  TIn* o = reinterpret_cast<TIn*>(out);
+  switch (D) {
+    case 16: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
+    case 64: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
+    default: return MBV_ERR_UNSUPPORTED;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+template <bool BF16, typename TIn>
+int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, const float* table, const void* out,
+               const void* grad_out, const float* lse, void* grad_qkv, float* grad_table, float* grad_pad,
+               hipStream_t stream) {
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(256);
+  const TIn* q = reinterpret_cast<const TIn*>(qkv);
+  const TIn* o = reinterpret_cast<const TIn*>(out);
+  const TIn* go = reinterpret_cast<const TIn*>(grad_out);
+  TIn* gq = reinterpret_cast<TIn*>(grad_qkv);
+  switch (D) {
+    case 16: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
+    case 64: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
+    default: return MBV_ERR_UNSUPPORTED;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mbv_window_attn_lse_elems(int32_t batch, int32_t H, int32_t W, int32_t heads, int32_t ws) {
+  if (batch <= 0 || H <= 0 || W <= 0 || heads <= 0 || ws <= 0) return 0;
+  const int64_t nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
+  return (int64_t)batch * nWh * nWw * heads * NPAD;
+}
+
+extern "C" int mbv_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_table, int32_t is_bf16,
+                                   int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws,
+                                   int32_t shift, void* out, float* lse, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g;
+  if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
+  if (g.N > NPAD || ws > 11) return MBV_ERR_UNSUPPORTED;
+  if (!qkv || !qkv_bias || !bias_table || !out || !lse) return MBV_ERR_BAD_ARG;
+  const int D = C / heads;
+  return is_bf16 ? launch_fwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, lse, stream)
+                 : launch_fwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, lse, stream);
+}
+
+extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
+                                   const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch, int32_t H,
+                                   int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, void* grad_qkv,
+                                   float* grad_table, float* grad_qkv_bias, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g;
+  if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
+  if (g.N > NPAD || ws > 11) return MBV_ERR_UNSUPPORTED;
+  if (!qkv || !qkv_bias || !bias_table || !out || !grad_out || !lse || !grad_qkv || !grad_table || !grad_qkv_bias)
+    return MBV_ERR_BAD_ARG;
+  const int D = C / heads;
+  const int tsz = (2 * ws - 1) * (2 * ws - 1);
+  MBV_CHECK_HIP(hipMemsetAsync(grad_table, 0, sizeof(float) * tsz * heads, stream));
+  MBV_CHECK_HIP(hipMemsetAsync(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
+  return is_bf16 ? launch_bwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
+                                            grad_qkv_bias, stream)
+                 : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
+                                            grad_qkv_bias, stream);
+}

@@ -228,75 +228,56 @@ def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
 # --------------------------------------------------------------------------------------
 # K4 shifted-window attention
 # --------------------------------------------------------------------------------------
-_SHIFT_MASK_CACHE = {}
-_REL_INDEX_CACHE = {}
+class _WindowAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, bias_table, num_heads, ws, shift):
+        lib = _lib.load()
+        _need_gpu(qkv, qkv_bias, bias_table)
+        if qkv.dtype not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError(f'window_attention supports f32 and bf16 qkv, got {qkv.dtype}')
+        qkv = qkv.contiguous()
+        b, h, w, c3 = qkv.shape
+        c = c3 // 3
+        bias32 = qkv_bias.detach().to(torch.float32).contiguous()
+        table32 = bias_table.detach().to(torch.float32).contiguous()
+        out = torch.empty((b, h, w, c), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((lib.mbv_window_attn_lse_elems(b, h, w, num_heads, ws),), dtype=torch.float32,
+                          device=qkv.device)
+        is_bf16 = 1 if qkv.dtype == torch.bfloat16 else 0
+        rc = lib.mbv_window_attn_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), is_bf16, b, h, w, c, num_heads, ws, shift,
+                                     _ptr(out), _ptr(lse), _stream())
+        check(rc, 'mbv_window_attn_fwd')
+        ctx.save_for_backward(qkv, bias32, table32, out, lse)
+        ctx.cfg = (num_heads, ws, shift, qkv_bias.dtype, bias_table.dtype)
+        return out
 
-
-def _rel_index(ws: int, device) -> torch.Tensor:
-    key = (ws, str(device))
-    idx = _REL_INDEX_CACHE.get(key)
-    if idx is None:
-        c = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)
-        rel = c[:, :, None] - c[:, None, :] + (ws - 1)
-        idx = (rel[0] * (2 * ws - 1) + rel[1]).reshape(-1).to(device)
-        _REL_INDEX_CACHE[key] = idx
-    return idx
-
-
-def _shift_mask(hp: int, wp: int, ws: int, shift: int, device) -> torch.Tensor:
-    """(nW, ws², ws²) additive mask, -100 between tokens of different shifted regions (swin.py:198-219)."""
-    key = (hp, wp, ws, shift, str(device))
-    m = _SHIFT_MASK_CACHE.get(key)
-    if m is None:
-        def region(n):
-            r = torch.zeros(n, dtype=torch.long)
-            r[n - ws:n - shift] = 1
-            r[n - shift:] = 2
-            return r
-        lab = region(hp)[:, None] * 3 + region(wp)[None, :]
-        lab = lab.view(hp // ws, ws, wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
-        m = (lab[:, None, :] != lab[:, :, None]).to(torch.float32) * -100.0
-        m = m.to(device)
-        _SHIFT_MASK_CACHE[key] = m
-    return m
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        qkv, bias32, table32, out, lse = ctx.saved_tensors
+        num_heads, ws, shift, bias_dtype, table_dtype = ctx.cfg
+        b, h, w, c3 = qkv.shape
+        c = c3 // 3
+        grad_out = grad_out.to(qkv.dtype).contiguous()
+        g_qkv = torch.empty_like(qkv)
+        g_table = torch.empty_like(table32)
+        g_bias = torch.empty_like(bias32)
+        is_bf16 = 1 if qkv.dtype == torch.bfloat16 else 0
+        rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
+                                     is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
+                                     _ptr(g_bias), _stream())
+        check(rc, 'mbv_window_attn_bwd')
+        return g_qkv, g_bias.to(bias_dtype), g_table.to(table_dtype), None, None, None
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torch.Tensor, num_heads: int, ws: int,
                      shift: int) -> torch.Tensor:
-    """Shifted-window multi-head attention on a channels-last map.
+    """Shifted-window multi-head attention on a channels-last map (K4, include/maskbev_hip.h).
 
     qkv (B, H, W, 3C) is the fused projection of the *un-padded* tokens; tokens that the reference pads in
-    (swin.py:185-188: zeros after LayerNorm) have qkv == bias, which is what is filled in here.
-    Returns (B, H, W, C) (before the output projection).  Torch composition for now — the fused gfx950
-    kernel replaces the body of this function.
-    """
-    _need_gpu(qkv)
-    b, h, w, c3 = qkv.shape
-    c = c3 // 3
-    d = c // num_heads
-    pad_b, pad_r = (ws - h % ws) % ws, (ws - w % ws) % ws
-    hp, wp = h + pad_b, w + pad_r
-    if pad_b or pad_r:
-        full = qkv_bias.to(qkv.dtype).view(1, 1, 1, c3).expand(b, hp, wp, c3).clone()
-        full[:, :h, :w] = qkv
-        qkv = full
-    if shift:
-        qkv = torch.roll(qkv, shifts=(-shift, -shift), dims=(1, 2))
-    nh_, nw_ = hp // ws, wp // ws
-    t = qkv.view(b, nh_, ws, nw_, ws, 3, num_heads, d).permute(5, 0, 1, 3, 6, 2, 4, 7)
-    t = t.reshape(3, b, nh_ * nw_, num_heads, ws * ws, d)
-    bias = bias_table[_rel_index(ws, qkv.device)].view(ws * ws, ws * ws, num_heads).permute(2, 0, 1)
-    attn_bias = bias.unsqueeze(0)
-    if shift:
-        attn_bias = attn_bias + _shift_mask(hp, wp, ws, shift, qkv.device).unsqueeze(1)
-    attn_bias = attn_bias.to(qkv.dtype)
-    o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], attn_mask=attn_bias)
-    o = o.view(b, nh_, nw_, num_heads, ws, ws, d).permute(0, 1, 4, 2, 5, 3, 6).reshape(b, hp, wp, c)
-    if shift:
-        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-    if pad_b or pad_r:
-        o = o[:, :h, :w].contiguous()
-    return o
+    (swin.py:185-188: zeros after LayerNorm) have qkv == bias, which the kernel substitutes while staging.
+    Returns (B, H, W, C) (before the output projection), same dtype as qkv (f32 or bf16)."""
+    return _WindowAttention.apply(qkv, qkv_bias, bias_table, num_heads, ws, shift)
 
 
 # --------------------------------------------------------------------------------------

@@ -38,8 +38,8 @@ def module_kwargs(workload: str, batch_size: int, compute_dtype: str = 'fp32', *
               differential_lr_scaling=1.0, backbone_window_size=10, pc_point_dim=w['pc_point_dim'],
               batch_size=batch_size, seed=420, compute_dtype=compute_dtype)
     if workload == 'smoke_96':
-        kw.update(encoder_feat_channels=[32, 32, 32], backbone_embed_dim=24, head_feat_channels=32,
-                  head_out_channels=32, backbone_window_size=6, max_num_points=8)
+        kw.update(encoder_feat_channels=[32, 32, 32], backbone_embed_dim=48, head_feat_channels=128,
+                  head_out_channels=128, backbone_window_size=6, max_num_points=8)
     kw.update(overrides)
     return kw
 

@@ -1,0 +1,92 @@
+"""K4 fused shifted-window attention: HIP forward/backward vs a dense f32 restatement of
+swin.py:80-118,179-253 built from the oracle's helpers.  f32 path (exact-f32 MFMA): rtol 1e-4;
+bf16 path: inputs rounded to bf16 on both sides, tolerance 2e-2 (declared bf16 tolerance)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import maskbev_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_window_attention(qkv, qkv_bias, table, heads, ws, shift):
+    b, h, w, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    pad_b, pad_r = (ws - h % ws) % ws, (ws - w % ws) % ws
+    hp, wp = h + pad_b, w + pad_r
+    full = qkv_bias.view(1, 1, 1, c3).expand(b, hp, wp, c3).clone()
+    full[:, :h, :w] = qkv
+    mask = None
+    if shift:
+        full = torch.roll(full, shifts=(-shift, -shift), dims=(1, 2))
+        img = torch.zeros((1, hp, wp, 1))
+        sl = (slice(0, -ws), slice(-ws, -shift), slice(-shift, None))
+        cnt = 0
+        for a in sl:
+            for bb in sl:
+                img[:, a, bb, :] = cnt
+                cnt += 1
+        mw = O._window_partition(img, ws).view(-1, ws * ws)
+        mask = mw.unsqueeze(1) - mw.unsqueeze(2)
+        mask = mask.masked_fill(mask != 0, -100.0).masked_fill(mask == 0, 0.0)
+    win = O._window_partition(full, ws).view(-1, ws * ws, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = win[0] * d ** -0.5, win[1], win[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = table[O.rel_position_index(ws).view(-1)].view(ws * ws, ws * ws, heads).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nw = mask.shape[0]
+        attn = (attn.view(b, nw, heads, ws * ws, ws * ws) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, ws * ws, ws * ws)
+    out = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, ws, ws, c)
+    out = O._window_reverse(out, hp, wp, ws)
+    if shift:
+        out = torch.roll(out, shifts=(shift, shift), dims=(1, 2))
+    return out[:, :h, :w].contiguous()
+
+
+CASES = [
+    # B, H, W, heads, D, ws, shift
+    (2, 10, 10, 2, 16, 5, 0),
+    (2, 10, 10, 2, 16, 5, 2),
+    (1, 13, 9, 3, 16, 4, 2),       # padding on both axes + shift
+    (2, 23, 30, 3, 64, 10, 5),     # the production shape class: 100-token windows, head dim 64, padded
+    (1, 20, 20, 2, 32, 10, 0),
+    (1, 7, 7, 1, 32, 7, 3),
+]
+
+
+@pytest.mark.parametrize('B,H,W,heads,D,ws,shift', CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_window_attention_fwd_bwd(device, B, H, W, heads, D, ws, shift, dtype):
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(H * 31 + W + shift)
+    C = heads * D
+    qkv = torch.randn(B, H, W, 3 * C, generator=g)
+    bias = torch.randn(3 * C, generator=g) * 0.5
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    go = torch.randn(B, H, W, C, generator=g)
+    if dtype == 'bf16':
+        qkv, go = qkv.bfloat16().float(), go.bfloat16().float()
+    q_r, b_r, t_r = qkv.clone().requires_grad_(), bias.clone().requires_grad_(), table.clone().requires_grad_()
+    out_ref = ref_window_attention(q_r, b_r, t_r, heads, ws, shift)
+    out_ref.backward(go)
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    q_d = qkv.to(device=device, dtype=tdt).requires_grad_()
+    b_d, t_d = bias.clone().to(device).requires_grad_(), table.clone().to(device).requires_grad_()
+    out = ops.window_attention(q_d, b_d, t_d, heads, ws, shift)
+    assert out.dtype == tdt and out.shape == (B, H, W, C)
+    out.backward(go.to(device=device, dtype=tdt))
+    if dtype == 'f32':
+        tol = dict(rtol=1e-4, atol=2e-5)
+        gtol = dict(rtol=2e-4, atol=1e-4)
+    else:
+        tol = dict(rtol=2e-2, atol=2e-2)
+        gtol = dict(rtol=3e-2, atol=6e-2)
+    torch.testing.assert_close(out.detach().float().cpu(), out_ref.detach(), **tol)
+    torch.testing.assert_close(q_d.grad.float().cpu(), q_r.grad, **gtol)
+    scale = float(t_r.grad.abs().max().clamp(min=1.0))
+    assert float((t_d.grad.cpu() - t_r.grad).abs().max()) / scale < (2e-4 if dtype == 'f32' else 3e-2)
+    scale = float(b_r.grad.abs().max().clamp(min=1.0))
+    assert float((b_d.grad.cpu() - b_r.grad).abs().max()) / scale < (2e-4 if dtype == 'f32' else 3e-2)

@@ -2,7 +2,7 @@
 import torch
 
 
-def tiny_kwargs(nx=80, ny=80, vs=0.25, q=8, p=8, c=32, e=24, f=32, ws=5, pc_dim=4):
+def tiny_kwargs(nx=80, ny=80, vs=0.25, q=8, p=8, c=32, e=48, f=128, ws=5, pc_dim=4):
     return dict(x_range=(-nx * vs / 2, nx * vs / 2), y_range=(-ny * vs / 2, ny * vs / 2), z_range=(-3, 1),
                 voxel_size=vs, num_queries=q, max_num_points=p, encoder_feat_channels=[c, c, c],
                 backbone_embed_dim=e, head_feat_channels=f, head_out_channels=f, backbone_window_size=ws,
