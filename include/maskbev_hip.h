@@ -159,6 +159,26 @@ int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bia
                         int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
                         void* grad_qkv, float* grad_table, float* grad_qkv_bias, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K8 — indexed bilinear point sampling of mask maps (loss and Hungarian targets).
+ * Replaces: mmcv point_sample (= F.grid_sample, align_corners=False, zeros) at
+ * mask_bev/models/networks/mask2former_head/mask2former_head.py:194-200,402-410 and the tensor gathers
+ * feeding it (:227 `gt_masks[pos_assigned_gt_inds]`, :393 `mask_preds[mask_weights > 0]`).
+ * out[g][p] = bilinear(src[src_index[g]] (H, W), coords[coord_index[g]][p] (x, y in [0, 1])).
+ * src (num_src_maps, H, W) f32; src_index, coord_index (num_rows) i32; coords (*, num_points, 2) f32;
+ * out / grad_out (num_rows, num_points) f32.
+ * Backward zero-fills grad_src (num_src_maps, H, W) itself.  For H*W <= 16384 each row's gradient tile is
+ * accumulated in LDS and stored once, which requires src_index to hold no duplicates; larger maps use
+ * global f32 atomics.
+ */
+int mbv_point_sample_fwd(const float* src, const int32_t* src_index, const float* coords,
+                         const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
+                         float* out, void* stream);
+
+int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const float* coords,
+                         const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
+                         int64_t num_src_maps, float* grad_src, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+// K8 — indexed bilinear point sampling of mask maps (the loss / matcher path), forward and backward.
+//
+// Replaces mmcv `point_sample` (= F.grid_sample, align_corners=False, zero padding) as used by the reference's
+// loss and Hungarian targets (mask_bev/models/networks/mask2former_head/mask2former_head.py:194-200,402-410),
+// together with the tensor gathers that feed it (`mask_preds[mask_weights > 0]`, `gt_masks[pos_assigned_gt_inds]`,
+// :227,:393 — a 420 MB copy of GT masks per decoder output at 512x512 / 100 queries / batch 4).
+// out[g][p] = bilinear(src[src_index[g]], coords[coord_index[g]][p]); nothing is gathered or copied.
+//
+// Backward: every sampled map receives 4 * P scattered adds.  Random global float atomics run at ~0.08 TB/s
+// on gfx950 (one lane per row, MI355X_MICROARCH.md "Global float atomics"); instead ONE workgroup owns one
+// map, accumulates its whole (H, W) gradient tile in LDS (64 KB at 128 x 128) with LDS atomics and writes it
+// out once with coalesced stores.  Maps larger than the LDS tile fall back to global atomics.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTileFloats = 16384;   // 64 KB LDS tile: 128 x 128 mask logits
+
+struct Bil {
+  int o[4];
+  float w[4];
+};
+
+// pixel = coord * size - 0.5 (grid_sample(2p - 1), align_corners=False), zero padding
+__device__ __forceinline__ void bil_setup(float px, float py, int H, int W, Bil& b) {
+  const float x = px * (float)W - 0.5f, y = py * (float)H - 0.5f;
+  const float xf = floorf(x), yf = floorf(y);
+  const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+  const float lx = x - xf, ly = y - yf;
+  b.w[0] = (1.f - ly) * (1.f - lx);
+  b.w[1] = (1.f - ly) * lx;
+  b.w[2] = ly * (1.f - lx);
+  b.w[3] = ly * lx;
+  const bool xv0 = x0 >= 0 && x0 < W, xv1 = x1 >= 0 && x1 < W, yv0 = y0 >= 0 && y0 < H, yv1 = y1 >= 0 && y1 < H;
+  b.o[0] = (yv0 && xv0) ? y0 * W + x0 : -1;
+  b.o[1] = (yv0 && xv1) ? y0 * W + x1 : -1;
+  b.o[2] = (yv1 && xv0) ? y1 * W + x0 : -1;
+  b.o[3] = (yv1 && xv1) ? y1 * W + x1 : -1;
+}
+
+__global__ void __launch_bounds__(256) k_point_sample_fwd(const float* __restrict__ src,
+                                                          const int32_t* __restrict__ src_index,
+                                                          const float* __restrict__ coords,
+                                                          const int32_t* __restrict__ coord_index, int P, int H, int W,
+                                                          float* __restrict__ out) {
+  const int g = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* s = src + (int64_t)src_index[g] * H * W;
+  const float* c = coords + ((int64_t)coord_index[g] * P + p) * 2;
+  Bil b;
+  bil_setup(c[0], c[1], H, W, b);
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (b.o[j] >= 0) v += b.w[j] * s[b.o[j]];
+  out[(int64_t)g * P + p] = v;
+}
+
+__global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __restrict__ grad_out,
+                                                               const int32_t* __restrict__ src_index,
+                                                               const float* __restrict__ coords,
+                                                               const int32_t* __restrict__ coord_index, int P, int H,
+                                                               int W, float* __restrict__ grad_src) {
+  __shared__ float tile[kTileFloats];
+  const int g = blockIdx.x;
+  const int hw = H * W;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = 0.f;
+  __syncthreads();
+  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  const float* go = grad_out + (int64_t)g * P;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    Bil b;
+    bil_setup(c[p * 2], c[p * 2 + 1], H, W, b);
+    const float gv = go[p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], b.w[j] * gv);
+  }
+  __syncthreads();
+  float* dst = grad_src + (int64_t)src_index[g] * hw;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = tile[i];
+}
+
+__global__ void __launch_bounds__(256) k_point_sample_bwd_atomic(const float* __restrict__ grad_out,
+                                                                 const int32_t* __restrict__ src_index,
+                                                                 const float* __restrict__ coords,
+                                                                 const int32_t* __restrict__ coord_index, int P, int H,
+                                                                 int W, float* __restrict__ grad_src) {
+  const int g = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* c = coords + ((int64_t)coord_index[g] * P + p) * 2;
+  Bil b;
+  bil_setup(c[0], c[1], H, W, b);
+  const float gv = grad_out[(int64_t)g * P + p];
+  float* dst = grad_src + (int64_t)src_index[g] * H * W;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (b.o[j] >= 0) atomicAdd(dst + b.o[j], b.w[j] * gv);
+}
+
+}  // namespace
+
+extern "C" int mbv_point_sample_fwd(const float* src, const int32_t* src_index, const float* coords,
+                                    const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H,
+                                    int32_t W, float* out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_rows < 0 || num_points <= 0 || H <= 0 || W <= 0) return MBV_ERR_BAD_ARG;
+  if (num_rows == 0) return MBV_OK;
+  if (!src || !src_index || !coords || !coord_index || !out) return MBV_ERR_BAD_ARG;
+  if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
+                     src_index, coords, coord_index, num_points, H, W, out);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const float* coords,
+                                    const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H,
+                                    int32_t W, int64_t num_src_maps, float* grad_src, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_rows < 0 || num_points <= 0 || H <= 0 || W <= 0 || num_src_maps < 0) return MBV_ERR_BAD_ARG;
+  if (!grad_src && num_src_maps > 0) return MBV_ERR_BAD_ARG;
+  MBV_CHECK_HIP(hipMemsetAsync(grad_src, 0, sizeof(float) * (size_t)num_src_maps * H * W, stream));
+  if (num_rows == 0) return MBV_OK;
+  if (!grad_out || !src_index || !coords || !coord_index) return MBV_ERR_BAD_ARG;
+  if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;
+  if ((int64_t)H * W <= kTileFloats) {
+    hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3(num_rows), dim3(1024), 0, stream, grad_out, src_index, coords,
+                       coord_index, num_points, H, W, grad_src);
+  } else {
+    hipLaunchKernelGGL(k_point_sample_bwd_atomic, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream,
+                       grad_out, src_index, coords, coord_index, num_points, H, W, grad_src);
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}

@@ -226,6 +226,7 @@ class Mask2FormerHead(nn.Module):
         self.loss_mask_weight = float((loss_mask or {}).get('loss_weight', 5.0))
         self.loss_dice_weight = float((loss_dice or {}).get('loss_weight', 5.0))
         self.point_seed: Optional[int] = None          # tests set this to share points with the oracle
+        self._iota_cache: Dict = {}
         self.world_size_fn = None                      # set by the DDP wrapper: () -> (world, all_reduce_fn)
 
     def init_weights(self):
@@ -272,6 +273,14 @@ class Mask2FormerHead(nn.Module):
         return cls_list, mask_list, [None for _ in cls_list]
 
     # ------------------------------------------------------------------ loss
+    def _iota(self, n: int, device, div: int = 1) -> torch.Tensor:
+        key = (n, div, str(device))
+        t = self._iota_cache.get(key)
+        if t is None:
+            t = (torch.arange(n, device=device) // div).to(torch.int32)
+            self._iota_cache[key] = t
+        return t
+
     @torch.no_grad()
     def _assign(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
         """Hungarian targets for one decoder output, whole batch (mask2former_head.py:154-232).
@@ -280,13 +289,16 @@ class Mask2FormerHead(nn.Module):
         from scipy.optimize import linear_sum_assignment
         b, nq = cls_scores.shape[:2]
         ng = labels_gt.shape[1]
+        dev = cls_scores.device
         coords = torch.stack([pts.rand(1, self.num_points, 2)[0] for _ in range(b)], 0)         # (B, P, 2)
-        mp = _point_sample(mask_preds.float(), coords)                                          # (B, Q, P)
-        gp = _point_sample(masks_gt.float(), coords)                                            # (B, G, P)
+        mp = ops.point_sample(mask_preds.flatten(0, 1), self._iota(b * nq, dev), coords,
+                              self._iota(b * nq, dev, nq)).view(b, nq, -1)                       # (B, Q, P)
+        gp = ops.point_sample(masks_gt.flatten(0, 1), self._iota(b * ng, dev), coords,
+                              self._iota(b * ng, dev, ng)).view(b, ng, -1)                       # (B, G, P)
         prob = cls_scores.float().softmax(-1)
         cls_cost = -torch.gather(prob, 2, labels_gt.unsqueeze(1).expand(-1, nq, -1)) * 2.0       # (B, Q, G)
-        pos = F.binary_cross_entropy_with_logits(mp, torch.ones_like(mp), reduction='none')
-        neg = F.binary_cross_entropy_with_logits(mp, torch.zeros_like(mp), reduction='none')
+        pos = F.softplus(-mp)                    # BCE-with-logits against 1
+        neg = pos + mp                           # BCE-with-logits against 0: softplus(x) = softplus(-x) + x
         bce = (torch.einsum('bnc,bmc->bnm', pos, gp) + torch.einsum('bnc,bmc->bnm', neg, 1 - gp)) / self.num_points
         ps = mp.sigmoid()
         num = 2 * torch.einsum('bnc,bmc->bnm', ps, gp)
@@ -297,7 +309,7 @@ class Mask2FormerHead(nn.Module):
         for i in range(b):
             r, c = linear_sum_assignment(cost[i])
             assigned[i, r] = c
-        return torch.from_numpy(assigned).to(cls_scores.device)                                # (B, Q) gt idx or -1
+        return torch.from_numpy(assigned).to(dev)                                               # (B, Q) gt idx or -1
 
     def _loss_single(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
         """mask2former_head.py:326-426 for one decoder output."""
@@ -317,23 +329,28 @@ class Mask2FormerHead(nn.Module):
             num_total_masks = self.world_size_fn(num_total_masks)
         num_total_masks = num_total_masks.clamp(min=1.0)
         bi, qi = torch.nonzero(matched, as_tuple=True)
-        mp = mask_preds[bi, qi].float()                                  # (G, H, W)
-        mt = masks_gt[bi, assigned[bi, qi]].float()                      # (G, ny, nx)
-        if mp.shape[0] == 0:
-            return loss_cls, mp.sum(), mp.sum()
+        g = int(bi.shape[0])
+        if g == 0:
+            z = mask_preds.sum() * 0.0
+            return loss_cls, z, z
+        ng = masks_gt.shape[1]
+        pred_index = (bi * nq + qi).to(torch.int32)                      # rows of mask_preds.flatten(0, 1)
+        gt_index = (bi * ng + assigned[bi, qi]).to(torch.int32)          # rows of masks_gt.flatten(0, 1)
+        rows = self._iota(g, cls_scores.device)
+        preds_flat, gt_flat = mask_preds.flatten(0, 1), masks_gt.flatten(0, 1)
         with torch.no_grad():
-            g = mp.shape[0]
             n_samp = int(self.num_points * self.oversample_ratio)
             coords = pts.rand(g, n_samp, 2)
-            unc = -_point_sample(mp.unsqueeze(1), coords).abs()
+            unc = -ops.point_sample(preds_flat.detach(), pred_index, coords, rows).abs()
             n_unc = int(self.importance_sample_ratio * self.num_points)
             n_rand = self.num_points - n_unc
-            idx = torch.topk(unc[:, 0, :], k=n_unc, dim=1)[1]
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
             coords = torch.gather(coords, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
             if n_rand > 0:
                 coords = torch.cat((coords, pts.rand(g, n_rand, 2)), dim=1)
-            tgt = _point_sample(mt.unsqueeze(1), coords).squeeze(1)
-        pred = _point_sample(mp.unsqueeze(1), coords).squeeze(1)
+            coords = coords.contiguous()
+            tgt = ops.point_sample(gt_flat, gt_index, coords, rows)
+        pred = ops.point_sample(preds_flat, pred_index, coords, rows)
         ps = pred.sigmoid()
         d = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)
         loss_dice = self.loss_dice_weight * (1 - d).sum() / (num_total_masks[0] + eps)

@@ -222,7 +222,8 @@ class _ScatterLayerNorm(torch.autograd.Function):
 def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, p: Pillars, batch: int, ny: int,
                       nx: int, eps: float) -> torch.Tensor:
     """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3)."""
-    return _ScatterLayerNorm.apply(feats, weight, bias, p.cell_to_pillar, p.pillar_batch_start, batch, ny, nx, eps)
+    return _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
+                                   p.pillar_batch_start, batch, ny, nx, eps)
 
 
 # --------------------------------------------------------------------------------------
@@ -321,7 +322,8 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, 
                    sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
     """value (B, N, H, D); sampling_locations (B, Nq, H, L, P, 2) in [0,1]; weights (B, Nq, H, L, P)
     → (B, Nq, H*D) f32.  Bilinear, zero padding, align_corners=False (K5, include/maskbev_hip.h)."""
-    return _MSDeformAttn.apply(value, shapes_t, level_start, sampling_locations, attention_weights)
+    return _MSDeformAttn.apply(value.float(), shapes_t, level_start, sampling_locations.float(),
+                               attention_weights.float())
 
 
 # --------------------------------------------------------------------------------------
@@ -339,3 +341,47 @@ def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_siz
         blocked = small.flatten(2).float().sigmoid() < 0.5
         blocked = blocked & ~blocked.all(-1, keepdim=True)
     return logits, blocked.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# K8 indexed bilinear point sampling (loss / matcher)
+# --------------------------------------------------------------------------------------
+class _PointSample(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, src, src_index, coords, coord_index):
+        lib = _lib.load()
+        _need_gpu(src, src_index, coords, coord_index)
+        src, coords = src.contiguous(), coords.contiguous()
+        n_src, h, w = src.shape
+        g = int(src_index.shape[0])
+        p = int(coords.shape[1])
+        out = torch.empty((g, p), dtype=torch.float32, device=src.device)
+        rc = lib.mbv_point_sample_fwd(_ptr(src), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, h, w, _ptr(out),
+                                      _stream())
+        check(rc, 'mbv_point_sample_fwd')
+        ctx.save_for_backward(src_index, coords, coord_index)
+        ctx.dims = (n_src, h, w)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        src_index, coords, coord_index = ctx.saved_tensors
+        n_src, h, w = ctx.dims
+        grad_out = grad_out.to(torch.float32).contiguous()
+        g, p = grad_out.shape
+        g_src = torch.empty((n_src, h, w), dtype=torch.float32, device=grad_out.device)
+        rc = lib.mbv_point_sample_bwd(_ptr(grad_out), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, h, w, n_src,
+                                      _ptr(g_src), _stream())
+        check(rc, 'mbv_point_sample_bwd')
+        return g_src, None, None, None
+
+
+def point_sample(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tensor,
+                 coord_index: torch.Tensor) -> torch.Tensor:
+    """out[g, p] = bilinear(src[src_index[g]], coords[coord_index[g], p]) — mmcv ``point_sample`` semantics
+    (grid_sample at 2p-1, align_corners=False, zero padding) without gathering the maps first (K8).
+    src (N, H, W); indices int32 (G,), ``src_index`` without duplicates; coords (*, P, 2) in [0, 1] as (x, y)."""
+    return _PointSample.apply(src.float(), src_index, coords.float(), coord_index)
