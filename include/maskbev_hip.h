@@ -179,6 +179,16 @@ int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const 
                          const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
                          int64_t num_src_maps, float* grad_src, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
+ * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
+ * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).
+ * cost (batch, num_rows, num_cols) f32 (finite); row_to_col (batch, num_rows) i32 = assigned column of each
+ * row, -1 for rows left unassigned when num_rows > num_cols.  num_rows, num_cols <= 128.
+ */
+int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
+                  int32_t* row_to_col, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

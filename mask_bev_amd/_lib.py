@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MaskBevHipError(RuntimeError):
@@ -44,6 +44,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_point_sample_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'mbv_point_sample_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P]),
+    'mbv_hungarian': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,124 @@
+// K9 — batched linear-sum assignment (Hungarian / Kuhn-Munkres with potentials) on the device.
+//
+// Replaces the host round trip of mmdet's HungarianAssigner → scipy.optimize.linear_sum_assignment, reached
+// from Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:
+// 207-210) once per image per decoder output (10 x B device→host syncs per training step).
+// One wavefront solves one (rows x cols) cost matrix with the O(n^3) shortest-augmenting-path algorithm; the
+// per-column work of every step (reduced-cost update, arg-min, potential update) is spread over the 64 lanes
+// (two columns per lane for up to 128 columns).  All matrices of a step (decoder outputs x images) are solved
+// by one launch.  Potentials are kept in f64 like scipy's solver.  The optimum it returns is the same
+// assignment as scipy's whenever the optimum is unique; among exactly tied optima (e.g. identical zero-padded
+// ground-truth columns) any of them gives identical targets and loss.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxDim = 128;
+
+// rows <= cols.  cost: (rows, cols) row-major f32.  row_to_col: (rows) i32.
+__global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost_all, int rows, int cols,
+                                                  int transposed, int32_t* __restrict__ out_all, int out_len) {
+  __shared__ double u[kMaxDim + 1];
+  __shared__ int p[kMaxDim + 1];      // p[j] = row matched to column j (1-based), 0 = free
+  __shared__ int way[kMaxDim + 1];
+  const int lane = threadIdx.x;
+  const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
+  int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
+  // element (i, j) of the rows<=cols problem; `transposed` means the caller's matrix is (cols x rows)
+  auto a = [&](int i, int j) -> double {
+    return transposed ? (double)cost[(int64_t)j * rows + i] : (double)cost[(int64_t)i * cols + j];
+  };
+  // this lane owns columns j = lane + 1 and lane + 65 (1-based)
+  const int jA = lane + 1, jB = lane + 65;
+  const bool hasA = jA <= cols, hasB = jB <= cols;
+  double vA = 0.0, vB = 0.0;
+  for (int i = lane; i <= kMaxDim; i += 64) {
+    u[i] = 0.0;
+    p[i] = 0;
+    way[i] = 0;
+  }
+  __syncthreads();
+  const double INF = 1e300;
+  for (int i = 1; i <= rows; ++i) {
+    if (lane == 0) p[0] = i;
+    double minA = INF, minB = INF;
+    bool usedA = false, usedB = false;
+    int j0 = 0;
+    __syncthreads();
+    while (true) {
+      // mark j0 used
+      if (j0 == jA) usedA = true;
+      if (j0 == jB) usedB = true;
+      const int i0 = p[j0];
+      const double ui0 = u[i0];
+      double best = INF;
+      int bestj = 0x7fffffff;
+      if (hasA && !usedA) {
+        const double cur = a(i0 - 1, jA - 1) - ui0 - vA;
+        if (cur < minA) { minA = cur; way[jA] = j0; }
+        if (minA < best) { best = minA; bestj = jA; }
+      }
+      if (hasB && !usedB) {
+        const double cur = a(i0 - 1, jB - 1) - ui0 - vB;
+        if (cur < minB) { minB = cur; way[jB] = j0; }
+        if (minB < best) { best = minB; bestj = jB; }
+      }
+      // wave arg-min (smallest column index on ties)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oj = __shfl_xor(bestj, o, 64);
+        if (ob < best || (ob == best && oj < bestj)) { best = ob; bestj = oj; }
+      }
+      const double delta = best;
+      const int j1 = bestj;
+      // potentials: used columns (incl. the virtual column 0) move their rows; free columns tighten
+      if (lane == 0) u[p[0]] += delta;
+      if (hasA) { if (usedA) { u[p[jA]] += delta; vA -= delta; } else minA -= delta; }
+      if (hasB) { if (usedB) { u[p[jB]] += delta; vB -= delta; } else minB -= delta; }
+      j0 = j1;
+      __syncthreads();
+      if (p[j0] == 0) break;
+    }
+    // augment along the alternating path (sequential, <= rows steps)
+    if (lane == 0) {
+      int j = j0;
+      while (j != 0) {
+        const int jp = way[j];
+        p[j] = p[jp];
+        j = jp;
+      }
+    }
+    __syncthreads();
+  }
+  // outputs
+  if (!transposed) {
+    // out[row] = col
+    for (int j = lane + 1; j <= cols; j += 64)
+      if (p[j] > 0) out[p[j] - 1] = j - 1;
+  } else {
+    // the caller's rows are this problem's columns: out[caller_row] = caller_col or -1
+    for (int j = lane + 1; j <= cols; j += 64) out[j - 1] = p[j] > 0 ? p[j] - 1 : -1;
+  }
+}
+
+}  // namespace
+
+extern "C" int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
+                             int32_t* row_to_col, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch < 0 || num_rows <= 0 || num_cols <= 0) return MBV_ERR_BAD_ARG;
+  if (num_rows > kMaxDim || num_cols > kMaxDim) return MBV_ERR_UNSUPPORTED;
+  if (batch == 0) return MBV_OK;
+  if (!cost || !row_to_col) return MBV_ERR_BAD_ARG;
+  if (num_rows <= num_cols) {
+    hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
+                       num_rows);
+  } else {
+    // more rows than columns: solve the transposed problem; unmatched rows get -1
+    hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_cols, num_rows, 1, row_to_col,
+                       num_rows);
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}

@@ -273,100 +273,130 @@ class Mask2FormerHead(nn.Module):
         return cls_list, mask_list, [None for _ in cls_list]
 
     # ------------------------------------------------------------------ loss
-    def _iota(self, n: int, device, div: int = 1) -> torch.Tensor:
-        key = (n, div, str(device))
+    def _iota(self, n: int, device, div: int = 1, mod: int = 0) -> torch.Tensor:
+        key = (n, div, mod, str(device))
         t = self._iota_cache.get(key)
         if t is None:
-            t = (torch.arange(n, device=device) // div).to(torch.int32)
+            t = torch.arange(n, device=device)
+            t = t // div if div > 1 else t
+            t = t % mod if mod > 0 else t
+            t = t.to(torch.int32)
             self._iota_cache[key] = t
         return t
 
-    @torch.no_grad()
-    def _assign(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
-        """Hungarian targets for one decoder output, whole batch (mask2former_head.py:154-232).
-        Costs: 2·(−softmax cls) + 5·BCE + 5·dice on ``num_points`` random points, all images' cost matrices
-        built on the device and moved to the host in ONE copy for scipy's assignment."""
-        from scipy.optimize import linear_sum_assignment
-        b, nq = cls_scores.shape[:2]
-        ng = labels_gt.shape[1]
-        dev = cls_scores.device
-        coords = torch.stack([pts.rand(1, self.num_points, 2)[0] for _ in range(b)], 0)         # (B, P, 2)
-        mp = ops.point_sample(mask_preds.flatten(0, 1), self._iota(b * nq, dev), coords,
-                              self._iota(b * nq, dev, nq)).view(b, nq, -1)                       # (B, Q, P)
-        gp = ops.point_sample(masks_gt.flatten(0, 1), self._iota(b * ng, dev), coords,
-                              self._iota(b * ng, dev, ng)).view(b, ng, -1)                       # (B, G, P)
-        prob = cls_scores.float().softmax(-1)
-        cls_cost = -torch.gather(prob, 2, labels_gt.unsqueeze(1).expand(-1, nq, -1)) * 2.0       # (B, Q, G)
-        pos = F.softplus(-mp)                    # BCE-with-logits against 1
-        neg = pos + mp                           # BCE-with-logits against 0: softplus(x) = softplus(-x) + x
-        bce = (torch.einsum('bnc,bmc->bnm', pos, gp) + torch.einsum('bnc,bmc->bnm', neg, 1 - gp)) / self.num_points
-        ps = mp.sigmoid()
-        num = 2 * torch.einsum('bnc,bmc->bnm', ps, gp)
-        den = ps.sum(-1)[:, :, None] + gp.sum(-1)[:, None, :]
-        dice = 1 - (num + 1.0) / (den + 1.0)
-        cost = (cls_cost + 5.0 * bce + 5.0 * dice).cpu().numpy()
-        assigned = np.full((b, nq), -1, dtype=np.int64)
-        for i in range(b):
-            r, c = linear_sum_assignment(cost[i])
-            assigned[i, r] = c
-        return torch.from_numpy(assigned).to(dev)                                               # (B, Q) gt idx or -1
-
-    def _loss_single(self, cls_scores, mask_preds, labels_gt, masks_gt, pts: PointSource):
-        """mask2former_head.py:326-426 for one decoder output."""
-        b, nq = cls_scores.shape[:2]
-        assigned = self._assign(cls_scores, mask_preds, labels_gt, masks_gt, pts)
-        matched = assigned >= 0
-        safe = assigned.clamp(min=0)
-        labels = torch.where(matched, torch.gather(labels_gt, 1, safe), torch.full_like(safe, self.num_classes))
-        class_weight = cls_scores.new_tensor(self.class_weight, dtype=torch.float32)
-        flat_scores, flat_labels = cls_scores.flatten(0, 1).float(), labels.flatten()
-        ce = F.cross_entropy(flat_scores, flat_labels, weight=class_weight, reduction='none')
-        eps = torch.finfo(torch.float32).eps
-        loss_cls = self.loss_cls_weight * ce.sum() / (class_weight[flat_labels].sum() + eps)
-        # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image, then reduce_mean over ranks (:388)
-        num_total_masks = cls_scores.new_tensor([float(b * nq)], dtype=torch.float32)
-        if self.world_size_fn is not None:
-            num_total_masks = self.world_size_fn(num_total_masks)
-        num_total_masks = num_total_masks.clamp(min=1.0)
-        bi, qi = torch.nonzero(matched, as_tuple=True)
-        g = int(bi.shape[0])
-        if g == 0:
-            z = mask_preds.sum() * 0.0
-            return loss_cls, z, z
-        ng = masks_gt.shape[1]
-        pred_index = (bi * nq + qi).to(torch.int32)                      # rows of mask_preds.flatten(0, 1)
-        gt_index = (bi * ng + assigned[bi, qi]).to(torch.int32)          # rows of masks_gt.flatten(0, 1)
-        rows = self._iota(g, cls_scores.device)
-        preds_flat, gt_flat = mask_preds.flatten(0, 1), masks_gt.flatten(0, 1)
-        with torch.no_grad():
-            n_samp = int(self.num_points * self.oversample_ratio)
-            coords = pts.rand(g, n_samp, 2)
-            unc = -ops.point_sample(preds_flat.detach(), pred_index, coords, rows).abs()
-            n_unc = int(self.importance_sample_ratio * self.num_points)
-            n_rand = self.num_points - n_unc
-            idx = torch.topk(unc, k=n_unc, dim=1)[1]
-            coords = torch.gather(coords, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+    def _draw_points(self, pts: PointSource, num_layers: int, batch: int, g: int):
+        """All uniform points of one loss evaluation, drawn in the reference's order (per decoder output:
+        B x rand(1, P, 2) for the matcher at mask2former_head.py:191, then rand(g, 3P, 2) and
+        rand(g, P - int(0.75 P), 2) inside get_uncertain_point_coords_with_randomness)."""
+        p = self.num_points
+        n_samp = int(p * self.oversample_ratio)
+        n_rand = p - int(self.importance_sample_ratio * p)
+        if pts.gen is None:                       # device RNG: the draw order is irrelevant, draw in bulk
+            return (pts.rand(num_layers * batch, p, 2), pts.rand(num_layers * g, n_samp, 2),
+                    pts.rand(num_layers * g, n_rand, 2) if n_rand > 0 else None)
+        mc, oc, rc = [], [], []
+        for _ in range(num_layers):
+            mc.append(torch.cat([pts.rand(1, p, 2) for _ in range(batch)], 0))
+            oc.append(pts.rand(g, n_samp, 2))
             if n_rand > 0:
-                coords = torch.cat((coords, pts.rand(g, n_rand, 2)), dim=1)
-            coords = coords.contiguous()
-            tgt = ops.point_sample(gt_flat, gt_index, coords, rows)
-        pred = ops.point_sample(preds_flat, pred_index, coords, rows)
-        ps = pred.sigmoid()
-        d = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)
-        loss_dice = self.loss_dice_weight * (1 - d).sum() / (num_total_masks[0] + eps)
-        bce = F.binary_cross_entropy_with_logits(pred, tgt, reduction='none')
-        loss_mask = self.loss_mask_weight * bce.sum() / (num_total_masks[0] * self.num_points + eps)
-        return loss_cls, loss_mask, loss_dice
+                rc.append(pts.rand(g, n_rand, 2))
+        return torch.cat(mc, 0), torch.cat(oc, 0), (torch.cat(rc, 0) if rc else None)
+
+    @torch.no_grad()
+    def _assign(self, cls, masks_flat, labels_gt, gt_flat, match_coords):
+        """Hungarian targets of ALL decoder outputs and images at once (mask2former_head.py:154-232).
+        cls (D, B, Q, K+1); masks_flat (D*B*Q, H, W); match_coords (D*B, P, 2).  Costs 2*(-softmax cls) +
+        5*BCE + 5*dice on the sampled points; the D*B assignment problems are solved on the device by one
+        launch of K9 — no device→host copy, no scipy."""
+        d, b, nq = cls.shape[:3]
+        ng = labels_gt.shape[1]
+        dev = cls.device
+        mp = ops.point_sample(masks_flat, self._iota(d * b * nq, dev), match_coords,
+                              self._iota(d * b * nq, dev, div=nq)).view(d, b, nq, -1)            # (D, B, Q, P)
+        gp = ops.point_sample(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
+                              self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)            # (D, B, G, P)
+        prob = cls.softmax(-1)
+        lab = labels_gt.view(1, b, 1, ng).expand(d, b, nq, ng)
+        cls_cost = -torch.gather(prob, 3, lab) * 2.0                                            # (D, B, Q, G)
+        pos = F.softplus(-mp)                    # BCE-with-logits against 1
+        neg = pos + mp                           # against 0: softplus(x) = softplus(-x) + x
+        gpt = gp.transpose(2, 3)
+        bce = (torch.matmul(pos, gpt) + torch.matmul(neg, 1 - gpt)) / self.num_points
+        ps = mp.sigmoid()
+        num = 2 * torch.matmul(ps, gpt)
+        den = ps.sum(-1)[..., :, None] + gp.sum(-1)[..., None, :]
+        dice = 1 - (num + 1.0) / (den + 1.0)
+        cost = cls_cost + 5.0 * bce + 5.0 * dice
+        return ops.hungarian(cost.flatten(0, 1)).view(d, b, nq)                                 # gt index or -1
 
     def loss(self, all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, img_metas=None, heights_pred=None,
              heights_gt=None) -> Dict[str, torch.Tensor]:
-        """mask2former_head.py:246-298; labels (B, Q) int64, masks (B, Q, ny, nx) {0,1}."""
+        """Mask2FormerHead.loss (mask2former_head.py:246-298 → _loss_by_feat_single :326-426) evaluated for all
+        decoder outputs in one batched pass; labels (B, G) int64, masks (B, G, ny, nx) {0,1}.
+        Differences in *mechanism* only: points are sampled by K8 straight from the (B, Q, H, W) logits and
+        the (B, G, ny, nx) GT masks (no gathered copies), the assignments come from K9 on the device, and
+        nothing synchronises with the host."""
         labels_gt = gt_labels_list if torch.is_tensor(gt_labels_list) else torch.stack(list(gt_labels_list), 0)
         masks_gt = gt_masks_list if torch.is_tensor(gt_masks_list) else torch.stack(list(gt_masks_list), 0)
-        pts = PointSource(all_cls_scores[0].device, self.point_seed)
-        res = [self._loss_single(c, m, labels_gt, masks_gt, pts) for c, m in zip(all_cls_scores, all_mask_preds)]
-        out = dict(loss_cls=res[-1][0], loss_mask=res[-1][1], loss_dice=res[-1][2], loss_height=0)
-        for i, (lc, lm, ld) in enumerate(res[:-1]):
-            out[f'd{i}.loss_cls'], out[f'd{i}.loss_mask'], out[f'd{i}.loss_dice'] = lc, lm, ld
+        dev = all_cls_scores[0].device
+        d = len(all_cls_scores)
+        b, nq = all_cls_scores[0].shape[:2]
+        ng = labels_gt.shape[1]
+        m = min(nq, ng)                                   # matched pairs per image (LSA matches min(Q, G))
+        g = b * m
+        p = self.num_points
+        eps = torch.finfo(torch.float32).eps
+        cls = torch.stack([c.float() for c in all_cls_scores], 0)                                # (D, B, Q, K+1)
+        masks_flat = torch.stack([mk.float() for mk in all_mask_preds], 0).flatten(0, 2)         # (D*B*Q, H, W)
+        gt_flat = masks_gt.float().flatten(0, 1)                                                 # (B*G, ny, nx)
+        pts = PointSource(dev, self.point_seed)
+        match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
+        assigned = self._assign(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)          # (D, B, Q) i32
+        matched = assigned >= 0
+        safe = assigned.clamp(min=0).long()
+
+        # classification loss (class-weighted CE, avg_factor = sum of the class weights of the targets)
+        labels = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, safe),
+                             torch.full_like(safe, self.num_classes))
+        class_weight = cls.new_tensor(self.class_weight)
+        ce = F.cross_entropy(cls.flatten(0, 2), labels.flatten(), weight=class_weight, reduction='none').view(d, -1)
+        loss_cls = self.loss_cls_weight * ce.sum(1) / (class_weight[labels].view(d, -1).sum(1) + eps)
+
+        # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image; reduce_mean over ranks (:388) is the
+        # identity for equal per-rank batches (drop_last=True), see ddp.py
+        num_total_masks = cls.new_tensor([float(b * nq)])
+        if self.world_size_fn is not None:
+            num_total_masks = self.world_size_fn(num_total_masks)
+        num_total_masks = num_total_masks.clamp(min=1.0)[0]
+
+        # matched (decoder output, image, query) rows in (d, b, q) order, without a host sync
+        if m == nq:
+            qsel = self._iota(nq, dev).long().view(1, 1, nq).expand(d, b, nq)
+        else:
+            qsel = torch.sort((~matched).to(torch.uint8), dim=-1, stable=True).indices[..., :m]
+        db = self._iota(d * b, dev).long().view(d, b, 1)
+        pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
+        bsel = self._iota(b, dev).long().view(1, b, 1)
+        gt_index = (bsel * ng + torch.gather(safe, 2, qsel)).flatten().to(torch.int32)           # rows of gt_flat
+        rows = self._iota(d * g, dev)
+        with torch.no_grad():
+            unc = -ops.point_sample(masks_flat.detach(), pred_index, over_c, rows).abs()
+            n_unc = int(self.importance_sample_ratio * p)
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
+            coords = torch.gather(over_c, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+            if rand_c is not None:
+                coords = torch.cat((coords, rand_c), dim=1)
+            coords = coords.contiguous()
+            tgt = ops.point_sample(gt_flat, gt_index, coords, rows)                              # (D*g, P)
+        pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
+        ps = pred.sigmoid()
+        dice = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)
+        loss_dice = self.loss_dice_weight * (1 - dice).view(d, g).sum(1) / (num_total_masks + eps)
+        bce = F.binary_cross_entropy_with_logits(pred, tgt, reduction='none').view(d, -1).sum(1)
+        loss_mask = self.loss_mask_weight * bce / (num_total_masks * p + eps)
+
+        out = dict(loss_cls=loss_cls[-1], loss_mask=loss_mask[-1], loss_dice=loss_dice[-1], loss_height=0)
+        for i in range(d - 1):
+            out[f'd{i}.loss_cls'], out[f'd{i}.loss_mask'], out[f'd{i}.loss_dice'] = loss_cls[i], loss_mask[i], loss_dice[i]
             out[f'd{i}.loss_height'] = 0
         return out

@@ -384,4 +384,26 @@ def point_sample(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tenso
     """out[g, p] = bilinear(src[src_index[g]], coords[coord_index[g], p]) — mmcv ``point_sample`` semantics
     (grid_sample at 2p-1, align_corners=False, zero padding) without gathering the maps first (K8).
     src (N, H, W); indices int32 (G,), ``src_index`` without duplicates; coords (*, P, 2) in [0, 1] as (x, y)."""
-    return _PointSample.apply(src.float(), src_index, coords.float(), coord_index)
+    src, coords = src.float(), coords.float()
+    n = int(src_index.shape[0])
+    if n <= 65535:
+        return _PointSample.apply(src, src_index, coords, coord_index)
+    return torch.cat([_PointSample.apply(src, src_index[i:i + 65535], coords, coord_index[i:i + 65535])
+                      for i in range(0, n, 65535)], 0)
+
+
+# --------------------------------------------------------------------------------------
+# K9 batched Hungarian assignment
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def hungarian(cost: torch.Tensor) -> torch.Tensor:
+    """cost (N, R, C) f32 on the device → (N, R) int32: column assigned to each row (min total cost), -1 for
+    rows left out when R > C.  No host synchronisation (K9, include/maskbev_hip.h)."""
+    lib = _lib.load()
+    _need_gpu(cost)
+    cost = cost.to(torch.float32).contiguous()
+    n, r, c = cost.shape
+    out = torch.full((n, r), -1, dtype=torch.int32, device=cost.device)
+    rc = lib.mbv_hungarian(_ptr(cost), n, r, c, _ptr(out), _stream())
+    check(rc, 'mbv_hungarian')
+    return out
