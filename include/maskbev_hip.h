@@ -179,6 +179,19 @@ int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const 
                          const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
                          int64_t num_src_maps, float* grad_src, void* stream);
 
+/* Binary ({0, 1}-valued) maps packed 32 pixels per word, and K8's forward on the packed form: a whole
+ * 512 x 512 ground-truth mask is 32 KB and is staged in LDS by the workgroup that samples it.
+ * The batch contract of the reference makes GT masks float32 {0, 1}
+ * (mask_bev/datasets/semantic_kitti/semantic_kitti_transforms.py:77-81,95-106); bit = (value != 0).
+ * packed: (num_maps, mbv_packed_mask_words(H, W)) u32.  H*W <= 1024*1024. */
+int64_t mbv_packed_mask_words(int32_t H, int32_t W);
+
+int mbv_pack_binary_masks(const float* src, int64_t num_maps, int32_t H, int32_t W, uint32_t* packed, void* stream);
+
+int mbv_point_sample_packed_fwd(const uint32_t* packed, const int32_t* src_index, const float* coords,
+                                const int32_t* coord_index, int32_t num_rows, int32_t num_points,
+                                int32_t H, int32_t W, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from

@@ -21,13 +21,18 @@ __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost
   __shared__ double u[kMaxDim + 1];
   __shared__ int p[kMaxDim + 1];      // p[j] = row matched to column j (1-based), 0 = free
   __shared__ int way[kMaxDim + 1];
+  __shared__ float a_lds[kMaxDim * (kMaxDim + 1)];   // the whole cost matrix: every search step reads one row
   const int lane = threadIdx.x;
   const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
   int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
   // element (i, j) of the rows<=cols problem; `transposed` means the caller's matrix is (cols x rows)
-  auto a = [&](int i, int j) -> double {
-    return transposed ? (double)cost[(int64_t)j * rows + i] : (double)cost[(int64_t)i * cols + j];
-  };
+  constexpr int LD = kMaxDim + 1;
+  for (int e = lane; e < rows * cols; e += 64) {
+    int i, j;
+    if (transposed) { j = e / rows; i = e - j * rows; } else { i = e / cols; j = e - i * cols; }
+    a_lds[i * LD + j] = cost[e];
+  }
+  auto a = [&](int i, int j) -> double { return (double)a_lds[i * LD + j]; };
   // this lane owns columns j = lane + 1 and lane + 65 (1-based)
   const int jA = lane + 1, jB = lane + 65;
   const bool hasA = jA <= cols, hasB = jB <= cols;

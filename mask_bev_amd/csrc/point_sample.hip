@@ -57,6 +57,78 @@ __global__ void __launch_bounds__(256) k_point_sample_fwd(const float* __restric
   out[(int64_t)g * P + p] = v;
 }
 
+// forward, one workgroup per row: the whole (H, W) map is staged in LDS with coalesced loads, then sampled from
+// LDS — instead of 4 random 4-byte HBM/L2 gathers per point
+__global__ void __launch_bounds__(512) k_point_sample_fwd_lds(const float* __restrict__ src,
+                                                              const int32_t* __restrict__ src_index,
+                                                              const float* __restrict__ coords,
+                                                              const int32_t* __restrict__ coord_index, int P, int H,
+                                                              int W, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+  const int g = blockIdx.x;
+  const int hw = H * W;
+  const float* s = src + (int64_t)src_index[g] * hw;
+  if ((hw & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(&tile[i]) = *reinterpret_cast<const float4*>(s + i);
+  } else {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = s[i];
+  }
+  __syncthreads();
+  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  float* o = out + (int64_t)g * P;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const float2 xy = *reinterpret_cast<const float2*>(c + p * 2);
+    Bil b;
+    bil_setup(xy.x, xy.y, H, W, b);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (b.o[j] >= 0) v += b.w[j] * tile[b.o[j]];
+    o[p] = v;
+  }
+}
+
+// binary maps packed 32 pixels / word (bit i of word k = pixel 32 k + i != 0)
+__global__ void __launch_bounds__(256) k_pack_binary(const float* __restrict__ src, int64_t hw, int64_t words_per_map,
+                                                     uint32_t* __restrict__ packed) {
+  const int64_t map = blockIdx.y;
+  const int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const bool bit = pix < hw && src[map * hw + pix] != 0.f;
+  const unsigned long long m = __ballot(bit);
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = pix / 32;
+  if (lane == 0 && w0 < words_per_map) packed[map * words_per_map + w0] = (uint32_t)(m & 0xffffffffull);
+  if (lane == 32 && w0 < words_per_map) packed[map * words_per_map + w0] = (uint32_t)(m >> 32);
+}
+
+constexpr int kPackedWords = 32768;   // 128 KB LDS: up to 1024 x 1024 binary pixels
+
+__global__ void __launch_bounds__(512) k_point_sample_packed(const uint32_t* __restrict__ packed,
+                                                             int64_t words_per_map,
+                                                             const int32_t* __restrict__ src_index,
+                                                             const float* __restrict__ coords,
+                                                             const int32_t* __restrict__ coord_index, int P, int H,
+                                                             int W, float* __restrict__ out) {
+  __shared__ uint32_t bits[kPackedWords];
+  const int g = blockIdx.x;
+  const uint32_t* s = packed + (int64_t)src_index[g] * words_per_map;
+  for (int i = threadIdx.x; i < (int)words_per_map; i += blockDim.x) bits[i] = s[i];
+  __syncthreads();
+  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  float* o = out + (int64_t)g * P;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const float2 xy = *reinterpret_cast<const float2*>(c + p * 2);
+    Bil b;
+    bil_setup(xy.x, xy.y, H, W, b);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (b.o[j] >= 0 && ((bits[b.o[j] >> 5] >> (b.o[j] & 31)) & 1u)) v += b.w[j];
+    o[p] = v;
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __restrict__ grad_out,
                                                                const int32_t* __restrict__ src_index,
                                                                const float* __restrict__ coords,
@@ -110,8 +182,47 @@ extern "C" int mbv_point_sample_fwd(const float* src, const int32_t* src_index, 
   if (num_rows == 0) return MBV_OK;
   if (!src || !src_index || !coords || !coord_index || !out) return MBV_ERR_BAD_ARG;
   if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
-                     src_index, coords, coord_index, num_points, H, W, out);
+  if ((int64_t)H * W <= kTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W) {
+    hipLaunchKernelGGL(k_point_sample_fwd_lds, dim3(num_rows), dim3(512), 0, stream, src, src_index, coords,
+                       coord_index, num_points, H, W, out);
+  } else {
+    hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
+                       src_index, coords, coord_index, num_points, H, W, out);
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int64_t mbv_packed_mask_words(int32_t H, int32_t W) {
+  if (H <= 0 || W <= 0) return 0;
+  return ((int64_t)H * W + 63) / 64 * 2;   // whole 64-pixel groups (one wavefront ballot each)
+}
+
+extern "C" int mbv_pack_binary_masks(const float* src, int64_t num_maps, int32_t H, int32_t W, uint32_t* packed,
+                                     void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_maps < 0 || H <= 0 || W <= 0) return MBV_ERR_BAD_ARG;
+  if (num_maps == 0) return MBV_OK;
+  if (!src || !packed) return MBV_ERR_BAD_ARG;
+  if (num_maps > 65535) return MBV_ERR_UNSUPPORTED;
+  const int64_t hw = (int64_t)H * W, words = mbv_packed_mask_words(H, W);
+  hipLaunchKernelGGL(k_pack_binary, dim3((unsigned)((words * 32 + 255) / 256), (unsigned)num_maps), dim3(256), 0, stream,
+                     src, hw, words, packed);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_point_sample_packed_fwd(const uint32_t* packed, const int32_t* src_index, const float* coords,
+                                           const int32_t* coord_index, int32_t num_rows, int32_t num_points,
+                                           int32_t H, int32_t W, float* out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_rows < 0 || num_points <= 0 || H <= 0 || W <= 0) return MBV_ERR_BAD_ARG;
+  if (num_rows == 0) return MBV_OK;
+  if (!packed || !src_index || !coords || !coord_index || !out) return MBV_ERR_BAD_ARG;
+  const int64_t words = mbv_packed_mask_words(H, W);
+  if (words > kPackedWords) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_point_sample_packed, dim3(num_rows), dim3(512), 0, stream, packed, words, src_index, coords,
+                     coord_index, num_points, H, W, out);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -227,6 +227,9 @@ class Mask2FormerHead(nn.Module):
         self.loss_dice_weight = float((loss_dice or {}).get('loss_weight', 5.0))
         self.point_seed: Optional[int] = None          # tests set this to share points with the oracle
         self._iota_cache: Dict = {}
+        # GT masks are float32 {0, 1} by the reference's batch contract (semantic_kitti_transforms.py:77-81);
+        # set False to sample arbitrary-valued maps through the generic f32 path
+        self.binary_gt_masks = True
         self.world_size_fn = None                      # set by the DDP wrapper: () -> (world, all_reduce_fn)
 
     def init_weights(self):
@@ -302,6 +305,11 @@ class Mask2FormerHead(nn.Module):
                 rc.append(pts.rand(g, n_rand, 2))
         return torch.cat(mc, 0), torch.cat(oc, 0), (torch.cat(rc, 0) if rc else None)
 
+    def _sample_gt(self, gt, src_index, coords, coord_index):
+        if isinstance(gt, ops.PackedMasks):
+            return ops.point_sample_packed(gt, src_index, coords, coord_index)
+        return ops.point_sample(gt, src_index, coords, coord_index)
+
     @torch.no_grad()
     def _assign(self, cls, masks_flat, labels_gt, gt_flat, match_coords):
         """Hungarian targets of ALL decoder outputs and images at once (mask2former_head.py:154-232).
@@ -313,8 +321,8 @@ class Mask2FormerHead(nn.Module):
         dev = cls.device
         mp = ops.point_sample(masks_flat, self._iota(d * b * nq, dev), match_coords,
                               self._iota(d * b * nq, dev, div=nq)).view(d, b, nq, -1)            # (D, B, Q, P)
-        gp = ops.point_sample(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
-                              self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)            # (D, B, G, P)
+        gp = self._sample_gt(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
+                             self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)             # (D, B, G, P)
         prob = cls.softmax(-1)
         lab = labels_gt.view(1, b, 1, ng).expand(d, b, nq, ng)
         cls_cost = -torch.gather(prob, 3, lab) * 2.0                                            # (D, B, Q, G)
@@ -349,6 +357,8 @@ class Mask2FormerHead(nn.Module):
         cls = torch.stack([c.float() for c in all_cls_scores], 0)                                # (D, B, Q, K+1)
         masks_flat = torch.stack([mk.float() for mk in all_mask_preds], 0).flatten(0, 2)         # (D*B*Q, H, W)
         gt_flat = masks_gt.float().flatten(0, 1)                                                 # (B*G, ny, nx)
+        if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
+            gt_flat = ops.pack_binary_masks(gt_flat)      # {0,1} by the batch contract: 32 KB per 512x512 mask
         pts = PointSource(dev, self.point_seed)
         match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
         assigned = self._assign(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)          # (D, B, Q) i32
@@ -387,7 +397,7 @@ class Mask2FormerHead(nn.Module):
             if rand_c is not None:
                 coords = torch.cat((coords, rand_c), dim=1)
             coords = coords.contiguous()
-            tgt = ops.point_sample(gt_flat, gt_index, coords, rows)                              # (D*g, P)
+            tgt = self._sample_gt(gt_flat, gt_index, coords, rows)                               # (D*g, P)
         pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
         ps = pred.sigmoid()
         dice = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)

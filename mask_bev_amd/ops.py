@@ -392,6 +392,43 @@ def point_sample(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tenso
                       for i in range(0, n, 65535)], 0)
 
 
+class PackedMasks:
+    """Binary maps packed 32 pixels / word (see include/maskbev_hip.h)."""
+
+    def __init__(self, words: torch.Tensor, h: int, w: int):
+        self.words, self.h, self.w = words, h, w
+
+
+@torch.no_grad()
+def pack_binary_masks(masks: torch.Tensor) -> PackedMasks:
+    """masks (N, H, W) with values in {0, 1} → bit-packed form for :func:`point_sample_packed`."""
+    lib = _lib.load()
+    _need_gpu(masks)
+    masks = masks.float().contiguous()
+    n, h, w = masks.shape
+    words = torch.empty((n, lib.mbv_packed_mask_words(h, w)), dtype=torch.int32, device=masks.device)
+    for i in range(0, n, 65535):
+        rc = lib.mbv_pack_binary_masks(_ptr(masks[i:i + 65535]), min(65535, n - i), h, w, _ptr(words[i:i + 65535]),
+                                       _stream())
+        check(rc, 'mbv_pack_binary_masks')
+    return PackedMasks(words, h, w)
+
+
+@torch.no_grad()
+def point_sample_packed(pm: PackedMasks, src_index: torch.Tensor, coords: torch.Tensor,
+                        coord_index: torch.Tensor) -> torch.Tensor:
+    """:func:`point_sample` on bit-packed binary maps (no gradient: GT masks only)."""
+    lib = _lib.load()
+    _need_gpu(src_index, coords, coord_index)
+    coords = coords.float().contiguous()
+    g, p = int(src_index.shape[0]), int(coords.shape[1])
+    out = torch.empty((g, p), dtype=torch.float32, device=coords.device)
+    rc = lib.mbv_point_sample_packed_fwd(_ptr(pm.words), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, pm.h,
+                                         pm.w, _ptr(out), _stream())
+    check(rc, 'mbv_point_sample_packed_fwd')
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # K9 batched Hungarian assignment
 # --------------------------------------------------------------------------------------

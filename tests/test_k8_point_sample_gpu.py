@@ -27,3 +27,31 @@ def test_point_sample_fwd_bwd(device, N, H, W, G, P, shared):
     out.backward(go.to(device))
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(s_d.grad.cpu(), s_r.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('N,H,W,G,P', [(6, 64, 64, 9, 700), (3, 512, 512, 5, 3000), (2, 37, 29, 2, 100)])
+def test_point_sample_packed_binary(device, N, H, W, G, P):
+    """Bit-packed binary maps: identical to grid_sample on the {0,1} float maps (duplicated indices allowed)."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(N + H)
+    src = (torch.rand(N, H, W, generator=g) > 0.6).float()
+    src[0] = 0                                                            # an all-zero (padding) mask
+    src_index = torch.randint(0, N, (G,), generator=g)
+    coords = torch.rand(G, P, 2, generator=g) * 1.1 - 0.05
+    ref = F.grid_sample(src[src_index].unsqueeze(1), 2.0 * coords.unsqueeze(2) - 1.0, align_corners=False).squeeze(3).squeeze(1)
+    pm = ops.pack_binary_masks(src.to(device))
+    out = ops.point_sample_packed(pm, src_index.to(device=device, dtype=torch.int32), coords.to(device),
+                                  torch.arange(G, dtype=torch.int32, device=device))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=5e-6)
+
+
+def test_point_sample_bf16_source_outside_autocast(device):
+    """Regression: a bf16 source outside an autocast region must be converted, not reinterpreted."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(4, 32, 32, generator=g).bfloat16()
+    coords = torch.rand(4, 50, 2, generator=g)
+    idx = torch.arange(4, dtype=torch.int32, device=device)
+    out = ops.point_sample(src.to(device), idx, coords.to(device), idx)
+    ref = F.grid_sample(src.float().unsqueeze(1), 2.0 * coords.unsqueeze(2) - 1.0, align_corners=False).squeeze(3).squeeze(1)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
