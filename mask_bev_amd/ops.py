@@ -329,18 +329,54 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, 
 # --------------------------------------------------------------------------------------
 # K7 per-query mask logits + attention mask of the next decoder layer
 # --------------------------------------------------------------------------------------
+class _MaskLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask_embed, mask_feature):
+        lib = _lib.load()
+        _need_gpu(mask_embed, mask_feature)
+        dt = mask_feature.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError(f'mask_logits supports f32 and bf16, got {dt}')
+        e = mask_embed.to(dt).contiguous()
+        f = mask_feature.contiguous()
+        b, q, c = e.shape
+        h, w = f.shape[-2:]
+        out = torch.empty((b, q, h, w), dtype=dt, device=f.device)
+        rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), 1 if dt == torch.bfloat16 else 0, b, q, c, h * w, _ptr(out),
+                                     _stream())
+        check(rc, 'mbv_mask_logits_fwd')
+        ctx.save_for_backward(e, f)
+        ctx.embed_dtype = mask_embed.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        # two plain library GEMMs (hipBLASLt through torch): dE = dL . F^T, dF = E^T . dL
+        e, f = ctx.saved_tensors
+        b, q, c = e.shape
+        h, w = f.shape[-2:]
+        dl = grad_logits.to(e.dtype).reshape(b, q, h * w)
+        ff = f.reshape(b, c, h * w)
+        g_e = torch.matmul(dl, ff.transpose(1, 2)).to(ctx.embed_dtype)
+        g_f = torch.matmul(e.transpose(1, 2), dl).reshape(b, c, h, w)
+        return g_e, g_f
+
+
 def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_size):
-    """mask_embed (B, Q, C) · mask_feature (B, C, H, W) → logits (B, Q, H, W) and the boolean
-    cross-attention mask of the next layer, (B, 1, Q, h*w), True = blocked:
+    """mask_embed (B, Q, C) · mask_feature (B, C, H, W) → logits (B, Q, H, W) (MFMA contraction, K7) and the
+    boolean cross-attention mask of the next layer, (B, 1, Q, h*w), True = blocked:
     bilinear resize (align_corners=False) → sigmoid < 0.5, rows that would block every key unblocked
     (mask2former_head.py:459-470 and :538-539).  Kept once per query and broadcast over heads."""
-    _need_gpu(mask_embed, mask_feature)
-    logits = torch.einsum('bqc,bchw->bqhw', mask_embed, mask_feature)
-    with torch.no_grad():
-        small = torch.nn.functional.interpolate(logits, tuple(target_size), mode='bilinear', align_corners=False)
-        blocked = small.flatten(2).float().sigmoid() < 0.5
-        blocked = blocked & ~blocked.all(-1, keepdim=True)
-    return logits, blocked.unsqueeze(1)
+    lib = _lib.load()
+    logits = _MaskLogits.apply(mask_embed, mask_feature)
+    b, q, h, w = logits.shape
+    th, tw = int(target_size[0]), int(target_size[1])
+    blocked = torch.empty((b, 1, q, th * tw), dtype=torch.bool, device=logits.device)
+    src = logits.detach()
+    rc = lib.mbv_attn_mask_from_logits(_ptr(src), 1 if src.dtype == torch.bfloat16 else 0, b * q, h, w, th, tw,
+                                       _ptr(blocked), _stream())
+    check(rc, 'mbv_attn_mask_from_logits')
+    return logits, blocked
 
 
 # --------------------------------------------------------------------------------------

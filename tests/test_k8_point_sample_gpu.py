@@ -42,7 +42,8 @@ def test_point_sample_packed_binary(device, N, H, W, G, P):
     pm = ops.pack_binary_masks(src.to(device))
     out = ops.point_sample_packed(pm, src_index.to(device=device, dtype=torch.int32), coords.to(device),
                                   torch.arange(G, dtype=torch.int32, device=device))
-    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=5e-6)
+    # pixel coordinates of magnitude W carry ~W * 2^-24 of f32 rounding, which is the weight error bound
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=max(5e-6, W * 1.2e-7))
 
 
 def test_point_sample_bf16_source_outside_autocast(device):
