@@ -15,6 +15,30 @@ namespace {
 
 constexpr int kMaxDim = 128;
 
+// wave64 unsigned-min on the DPP network (no LDS round trips): 4 row shifts, then the two cross-row
+// broadcasts; the total lands in lane 63 and is read back through a scalar register.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define MBV_DPP_MIN(ctrl, rmask)                                                                  \
+  {                                                                                               \
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); \
+    v = t < v ? t : v;                                                                            \
+  }
+  MBV_DPP_MIN(0x111, 0xf)   // row_shr:1
+  MBV_DPP_MIN(0x112, 0xf)   // row_shr:2
+  MBV_DPP_MIN(0x114, 0xf)   // row_shr:4
+  MBV_DPP_MIN(0x118, 0xf)   // row_shr:8
+  MBV_DPP_MIN(0x142, 0xa)   // row_bcast:15
+  MBV_DPP_MIN(0x143, 0xc)   // row_bcast:31
+#undef MBV_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// order-preserving map double -> u64 (total order of finite values)
+__device__ __forceinline__ unsigned long long orderable(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 // rows <= cols.  cost: (rows, cols) row-major f32.  row_to_col: (rows) i32.
 __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost_all, int rows, int cols,
                                                   int transposed, int32_t* __restrict__ out_all, int out_len) {
@@ -68,15 +92,18 @@ __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost
         if (cur < minB) { minB = cur; way[jB] = j0; }
         if (minB < best) { best = minB; bestj = jB; }
       }
-      // wave arg-min (smallest column index on ties)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int oj = __shfl_xor(bestj, o, 64);
-        if (ob < best || (ob == best && oj < bestj)) { best = ob; bestj = oj; }
-      }
-      const double delta = best;
-      const int j1 = bestj;
+      // wave arg-min: 64-bit key = (orderable reduced cost with its 8 lowest mantissa bits cleared | column),
+      // minimised in two 32-bit DPP passes (high word, then low word among the lanes holding the minimum)
+      const unsigned long long key =
+          bestj == 0x7fffffff ? ~0ull : ((orderable(best) & ~0xffull) | (unsigned long long)bestj);
+      const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+      const unsigned mhi = wave_min_u32(hi);
+      const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+      const int j1 = (int)(mlo & 0xffu);
+      // exact delta = minv[j1], read from the lane that owns column j1
+      const int owner = (j1 - 1) & 63;
+      const double cand = (j1 == jA) ? minA : minB;
+      const double delta = __shfl(cand, owner, 64);
       // potentials: used columns (incl. the virtual column 0) move their rows; free columns tighten
       if (lane == 0) u[p[0]] += delta;
       if (hasA) { if (usedA) { u[p[jA]] += delta; vA -= delta; } else minA -= delta; }
