@@ -218,6 +218,29 @@ int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feature, int32_
 int mbv_attn_mask_from_logits(const void* logits, int32_t is_bf16, int64_t rows, int32_t H, int32_t W,
                               int32_t h, int32_t w, uint8_t* blocked, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K6 — multi-head (masked) attention of the transformer decoder, forward / backward on MFMA.
+ * Replaces: the nn.MultiheadAttention cores (via mmcv MultiheadAttention) of the decoder loop at
+ * mask_bev/models/networks/mask2former_head/mask2former_head.py:542-553 (masked cross-attention over the
+ * L = h*w memory tokens of one level, then query self-attention); heads/ffn configured at
+ * mask_bev/models/head/mask_bev_panoptic_head.py:150-176.
+ * q (B, Q, heads*D), k, v (B, L, heads*D): projected inputs, all f32 (is_bf16 = 0) or all bf16; the softmax
+ * scale 1/sqrt(D) is applied inside.  blocked (B, Q, L) u8, 1 = may not attend, or NULL (self-attention);
+ * every row must keep at least one attendable key (mbv_attn_mask_from_logits guarantees it).
+ * out (B, Q, heads*D) same dtype; lse (B, heads, Q) f32 saved for backward.  head_dim in {16, 32, 64}.
+ * Backward writes f32 gradients grad_q (B, Q, E), grad_k / grad_v (B, L, E) in full.
+ */
+size_t mbv_attn_workspace_bytes(int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim);
+
+int mbv_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* blocked, int32_t is_bf16,
+                 int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
+                 void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream);
+
+int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blocked, const void* out,
+                 const void* grad_out, const float* lse, int32_t is_bf16,
+                 int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
+                 float* grad_q, float* grad_k, float* grad_v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,444 @@
+// K6 — multi-head (masked) attention of the Mask2Former transformer decoder on MFMA, forward and backward.
+//
+// Replaces the `nn.MultiheadAttention` cores reached through mmcv's MultiheadAttention wrapper from the decoder
+// loop of mask_bev/models/networks/mask2former_head/mask2former_head.py:535-560 (configured at
+// mask_bev/models/head/mask_bev_panoptic_head.py:150-176): masked cross-attention of the Q = 100 queries over
+// L in {256, 1024, 4096} memory tokens (8 heads x 32) and the 100 x 100 self-attention.
+// The boolean mask is the (B, Q, L) byte map written by K7 — kept once per query, not once per head.
+//
+// Forward is split over L ("flash-decoding"): one workgroup owns (batch, head, 128-key split) and, like K4,
+// holds the whole 128-query x 128-key score tile of its split in MFMA accumulators (S^T = K Q^T, exact
+// softmax inside the split, O_s = P V with P as the next MFMA's operand).  It emits (m_s, l_s, O_s); a small
+// combine kernel merges the splits and writes the output and the row log-sum-exp.  L = 4096 gives
+// 32 splits x 32 (batch, head) = 1024 workgroups instead of 32.
+// Backward per split: part 1 (lane = query) forms dQ (f32 atomics into (B, Q, E): splits x 400 x 256 floats),
+// part 2 (wave = key block) forms dK, dV of the split's keys with plain stores.
+#include "mfma_tiles.hpp"
+
+namespace {
+
+using namespace mbv_tiles;
+
+struct AttnGeom {
+  int B, Q, L, heads, E, nsplit, nsuper;
+};
+
+struct AttnBlock {
+  int b, head, su, split, q0, k0, nq, nk, ws_row;
+};
+
+__device__ __forceinline__ AttnBlock decode(const AttnGeom& g) {
+  int id = blockIdx.x;
+  AttnBlock r;
+  r.ws_row = id;
+  r.split = id % g.nsplit;
+  id /= g.nsplit;
+  r.su = id % g.nsuper;
+  id /= g.nsuper;
+  r.head = id % g.heads;
+  r.b = id / g.heads;
+  r.q0 = r.su * NPAD;
+  r.k0 = r.split * NPAD;
+  r.nq = min(NPAD, g.Q - r.q0);
+  r.nk = min(NPAD, g.L - r.k0);
+  return r;
+}
+
+// rows [r0, r0 + n) of src (B, R, E), columns [col, col + D) -> [row][d] and/or [d][row] images (zero padded)
+template <bool BF16, int D, typename TIn>
+__device__ __forceinline__ void stage_rows(const TIn* __restrict__ src, int64_t batch_off, int E, int r0, int n,
+                                           int col, typename Lay<BF16, D>::T* row_img,
+                                           typename Lay<BF16, D>::T* t_img) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  constexpr int CH = D / 8;
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c8 = (idx - t * CH) * 8;
+    float v[8];
+    if (t < n) {
+      const TIn* p = src + batch_off + (int64_t)(r0 + t) * E + col + c8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = to_f(p[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    if (row_img) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row_img[t * L::RS + c8 + j] = (T)v[j];
+    }
+    if (t_img) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t_img[(c8 + j) * L::TS + t] = (T)v[j];
+    }
+  }
+}
+
+template <bool BF16, int D>
+__device__ __forceinline__ void zero_tail(typename Lay<BF16, D>::T* t_img) {
+  using L = Lay<BF16, D>;
+  if constexpr (L::TROWS > D) {
+    for (int idx = threadIdx.x; idx < (L::TROWS - D) * L::TS; idx += blockDim.x)
+      t_img[D * L::TS + idx] = (typename L::T)0.f;
+  }
+}
+
+// mask tile [query][key] (1 = blocked) of this block into LDS; keys / queries out of range are blocked
+__device__ __forceinline__ void stage_mask(const uint8_t* __restrict__ mask, const AttnGeom& g, const AttnBlock& k,
+                                           uint8_t* __restrict__ m_lds) {
+  for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += blockDim.x) {
+    const int q = idx / NPAD, kk = idx - q * NPAD;
+    uint8_t v = 1;
+    if (q < k.nq && kk < k.nk) v = mask ? mask[((int64_t)k.b * g.Q + k.q0 + q) * g.L + k.k0 + kk] : 0;
+    m_lds[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: per-split partials
+// ---------------------------------------------------------------------------------------------
+template <bool BF16, int D, typename TIn>
+__global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ q, const TIn* __restrict__ k,
+                                                        const TIn* __restrict__ v, const uint8_t* __restrict__ mask,
+                                                        AttnGeom g, float scale, float* __restrict__ ws_m,
+                                                        float* __restrict__ ws_l, float* __restrict__ ws_o) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[BF16 ? L::T_IMG : L::ROW_IMG];
+  __shared__ uint8_t m_lds[NPAD * NPAD];
+  const AttnBlock blk = decode(g);
+  const int col = blk.head * D;
+  stage_rows<BF16, D, TIn>(q, (int64_t)blk.b * g.Q * g.E, g.E, blk.q0, blk.nq, col, q_img, nullptr);
+  stage_rows<BF16, D, TIn>(k, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, k_img, nullptr);
+  if constexpr (BF16) {
+    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, nullptr, v_img);
+    zero_tail<BF16, D>(v_img);
+  } else {
+    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, v_img, nullptr);
+  }
+  stage_mask(mask, g, blk, m_lds);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqb = (blk.nq + 31) / 32, nkb = (blk.nk + 31) / 32;
+  if (wave >= nqb) return;
+  const int ql = 32 * wave + r;
+  f32x16 s[NBLK];
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    s[kb] = zero16();
+    if (kb < nkb) mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = 32 * kb + acc_row(i, h);
+      const bool ok = kb < nkb && !m_lds[ql * NPAD + kk];
+      const float val = ok ? s[kb][i] * scale : -INFINITY;
+      s[kb][i] = val;
+      m = fmaxf(m, val);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const float m_use = (m == -INFINITY) ? 0.f : m;
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(s[kb][i] - m_use);
+      s[kb][i] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const int64_t wrow = (int64_t)blk.ws_row * NPAD;
+  if (h == 0) {
+    ws_m[wrow + ql] = m;
+    ws_l[wrow + ql] = sum;
+  }
+  constexpr int NCB = (D + 31) / 32;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    f32x16 o = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb)
+      if (kb < nkb) mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o);
+    const int dcol = r + 32 * cb;
+    if (dcol < D) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ws_o[(wrow + 32 * wave + acc_row(i, h)) * D + dcol] = o[i];
+    }
+  }
+}
+
+// merge the splits: out[b][q][head*D + d], lse[b][head][q]
+template <typename TOut>
+__global__ void __launch_bounds__(256) k_attn_combine(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
+                                                      const float* __restrict__ ws_o, AttnGeom g, int D,
+                                                      TOut* __restrict__ out, float* __restrict__ lse) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)g.B * g.heads * g.Q * D;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  int64_t t = idx / D;
+  const int qq = (int)(t % g.Q);
+  t /= g.Q;
+  const int head = (int)(t % g.heads);
+  const int b = (int)(t / g.heads);
+  const int su = qq / NPAD, ql = qq - su * NPAD;
+  const int64_t base = (((int64_t)b * g.heads + head) * g.nsuper + su) * g.nsplit;
+  float M = -INFINITY;
+  for (int s = 0; s < g.nsplit; ++s) M = fmaxf(M, ws_m[(base + s) * NPAD + ql]);
+  float den = 0.f, num = 0.f;
+  for (int s = 0; s < g.nsplit; ++s) {
+    const float ms = ws_m[(base + s) * NPAD + ql];
+    if (ms == -INFINITY) continue;
+    const float w = __expf(ms - M);
+    den += w * ws_l[(base + s) * NPAD + ql];
+    num += w * ws_o[((base + s) * NPAD + ql) * D + d];
+  }
+  out[((int64_t)b * g.Q + qq) * g.E + head * D + d] = (TOut)(num / den);
+  if (d == 0) lse[((int64_t)b * g.heads + head) * g.Q + qq] = M + __logf(den);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <bool BF16, int D, typename TIn>
+__global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, const TIn* __restrict__ k,
+                                                  const TIn* __restrict__ v, const uint8_t* __restrict__ mask,
+                                                  const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
+                                                  const float* __restrict__ lse, AttnGeom g, float scale,
+                                                  float* __restrict__ grad_q, float* __restrict__ grad_k,
+                                                  float* __restrict__ grad_v) {
+  using L = Lay<BF16, D>;
+  using T = typename L::T;
+  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T do_img[L::ROW_IMG];
+  __shared__ __attribute__((aligned(16))) T kt_img[BF16 ? L::T_IMG : 1];
+  __shared__ __attribute__((aligned(16))) T qt_img[BF16 ? L::T_IMG : 1];
+  __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
+  __shared__ uint8_t m_lds[NPAD * NPAD];
+  __shared__ float lse_s[NPAD];
+  __shared__ float delta_s[NPAD];
+  const AttnBlock blk = decode(g);
+  const int col = blk.head * D;
+  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.E;
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    lse_s[t] = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
+    delta_s[t] = 0.f;
+  }
+  stage_rows<BF16, D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, BF16 ? qt_img : nullptr);
+  stage_rows<BF16, D, TIn>(k, koff, g.E, blk.k0, blk.nk, col, k_img, BF16 ? kt_img : nullptr);
+  stage_rows<BF16, D, TIn>(v, koff, g.E, blk.k0, blk.nk, col, v_img, nullptr);
+  stage_rows<BF16, D, TIn>(grad_out, qoff, g.E, blk.q0, blk.nq, col, do_img, BF16 ? dot_img : nullptr);
+  if constexpr (BF16) {
+    zero_tail<BF16, D>(qt_img);
+    zero_tail<BF16, D>(kt_img);
+    zero_tail<BF16, D>(dot_img);
+  }
+  stage_mask(mask, g, blk, m_lds);
+  __syncthreads();
+  {
+    constexpr int CH = D / 8;
+    for (int idx = threadIdx.x; idx < blk.nq * CH; idx += blockDim.x) {
+      const int t = idx / CH, c8 = (idx - t * CH) * 8;
+      const int64_t o = qoff + (int64_t)(blk.q0 + t) * g.E + col + c8;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += to_f(out[o + j]) * to_f(grad_out[o + j]);
+      atomicAdd(&delta_s[t], acc);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqb = (blk.nq + 31) / 32, nkb = (blk.nk + 31) / 32;
+  constexpr int NCB = (D + 31) / 32;
+
+  if (wave < nqb) {   // ---- part 1: lane = query → dQ partial of this key split
+    const int ql = 32 * wave + r;
+    const float my_lse = lse_s[ql], my_delta = delta_s[ql];
+    f32x16 dq[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      if (kb >= nkb) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
+      mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * kb + acc_row(i, h);
+        float ds = 0.f;
+        if (!m_lds[ql * NPAD + kk]) {
+          const float p = __expf(s[i] * scale - my_lse);
+          ds = p * (dp[i] - my_delta) * scale;
+        }
+        s[i] = ds;
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) mma_acc_operand<BF16, D>(s, BF16 ? kt_img : k_img, 32 * kb, cb, dq[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (qq < blk.nq) {
+          float* dst = grad_q + qoff + (int64_t)(blk.q0 + qq) * g.E + col + dcol;
+          if (g.nsplit > 1) atomicAdd(dst, dq[cb][i]);
+          else *dst = dq[cb][i];
+        }
+      }
+    }
+  }
+  if (wave < nkb) {   // ---- part 2: wave = key block → dK, dV of this split's keys
+    const int kb = wave;
+    const int kl = 32 * kb + r;
+    f32x16 dk[NCB], dv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
+#pragma unroll
+    for (int qb = 0; qb < NBLK; ++qb) {
+      if (qb >= nqb) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);
+      mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      f32x16 ds;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * qb + acc_row(i, h);
+        float p = 0.f, d = 0.f;
+        if (!m_lds[qq * NPAD + kl]) {
+          p = __expf(s[i] * scale - lse_s[qq]);
+          d = p * (dp[i] - delta_s[qq]) * scale;
+        }
+        s[i] = p;
+        ds[i] = d;
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        mma_acc_operand<BF16, D>(s, BF16 ? dot_img : do_img, 32 * qb, cb, dv[cb]);
+        mma_acc_operand<BF16, D>(ds, BF16 ? qt_img : q_img, 32 * qb, cb, dk[cb]);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * kb + acc_row(i, h);
+        if (kk < blk.nk) {
+          const int64_t o = koff + (int64_t)(blk.k0 + kk) * g.E + col + dcol;
+          if (g.nsuper > 1) { atomicAdd(grad_k + o, dk[cb][i]); atomicAdd(grad_v + o, dv[cb][i]); }
+          else { grad_k[o] = dk[cb][i]; grad_v[o] = dv[cb][i]; }
+        }
+      }
+    }
+  }
+}
+
+bool make_attn_geom(int B, int Q, int L, int heads, int D, AttnGeom& g) {
+  if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || D <= 0) return false;
+  g.B = B; g.Q = Q; g.L = L; g.heads = heads; g.E = heads * D;
+  g.nsplit = (L + NPAD - 1) / NPAD;
+  g.nsuper = (Q + NPAD - 1) / NPAD;
+  return true;
+}
+
+size_t attn_ws_floats(const AttnGeom& g, int D) {
+  const size_t rows = (size_t)g.B * g.heads * g.nsuper * g.nsplit * NPAD;
+  return rows * (2 + D);
+}
+
+template <bool BF16, typename TIn>
+int attn_fwd_launch(const AttnGeom& g, int D, const void* q, const void* k, const void* v, const uint8_t* mask,
+                    void* out, float* lse, float* ws, hipStream_t stream) {
+  const float scale = 1.0f / sqrtf((float)D);
+  const size_t rows = (size_t)g.B * g.heads * g.nsuper * g.nsplit * NPAD;
+  float *ws_m = ws, *ws_l = ws + rows, *ws_o = ws + 2 * rows;
+  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(256);
+  const TIn *qq = (const TIn*)q, *kk = (const TIn*)k, *vv = (const TIn*)v;
+  switch (D) {
+    case 16: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 16, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
+    case 32: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 32, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
+    case 64: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 64, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
+    default: return MBV_ERR_UNSUPPORTED;
+  }
+  MBV_CHECK_LAUNCH();
+  const int64_t total = (int64_t)g.B * g.heads * g.Q * D;
+  hipLaunchKernelGGL((k_attn_combine<TIn>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws_m, ws_l,
+                     ws_o, g, D, (TIn*)out, lse);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+template <bool BF16, typename TIn>
+int attn_bwd_launch(const AttnGeom& g, int D, const void* q, const void* k, const void* v, const uint8_t* mask,
+                    const void* out, const void* grad_out, const float* lse, float* gq, float* gk, float* gv,
+                    hipStream_t stream) {
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(256);
+  const TIn *qq = (const TIn*)q, *kk = (const TIn*)k, *vv = (const TIn*)v, *oo = (const TIn*)out, *go = (const TIn*)grad_out;
+  switch (D) {
+    case 16: hipLaunchKernelGGL((k_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, qq, kk, vv, mask, oo, go, lse, g, scale, gq, gk, gv); break;
+    case 32: hipLaunchKernelGGL((k_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, qq, kk, vv, mask, oo, go, lse, g, scale, gq, gk, gv); break;
+    case 64: hipLaunchKernelGGL((k_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, qq, kk, vv, mask, oo, go, lse, g, scale, gq, gk, gv); break;
+    default: return MBV_ERR_UNSUPPORTED;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mbv_attn_workspace_bytes(int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads,
+                                           int32_t head_dim) {
+  AttnGeom g;
+  if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return 0;
+  return mbv_align_up(attn_ws_floats(g, head_dim) * sizeof(float), 256);
+}
+
+extern "C" int mbv_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* blocked, int32_t is_bf16,
+                            int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
+                            void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnGeom g;
+  if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
+  if (!q || !k || !v || !out || !lse) return MBV_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mbv_attn_workspace_bytes(batch, num_queries, num_keys, heads, head_dim))
+    return MBV_ERR_WORKSPACE;
+  float* ws = reinterpret_cast<float*>(workspace);
+  return is_bf16 ? attn_fwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, lse, ws, stream)
+                 : attn_fwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, lse, ws, stream);
+}
+
+extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blocked, const void* out,
+                            const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
+                            int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
+                            float* grad_k, float* grad_v, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnGeom g;
+  if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
+  if (!q || !k || !v || !out || !grad_out || !lse || !grad_q || !grad_k || !grad_v) return MBV_ERR_BAD_ARG;
+  if (g.nsplit > 1)
+    MBV_CHECK_HIP(hipMemsetAsync(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
+  if (g.nsuper > 1) {
+    MBV_CHECK_HIP(hipMemsetAsync(grad_k, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+    MBV_CHECK_HIP(hipMemsetAsync(grad_v, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+  }
+  return is_bf16 ? attn_bwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, grad_k,
+                                                 grad_v, stream)
+                 : attn_bwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, grad_k,
+                                                 grad_v, stream);
+}

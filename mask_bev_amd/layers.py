@@ -152,14 +152,10 @@ class MultiheadAttention(nn.Module):
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         q = query + query_pos if query_pos is not None else query
         k = key + key_pos if key_pos is not None else key
-        b, nq, _ = q.shape
-        nl = k.shape[1]
-        q = F.linear(q, w[:e], bias[:e]).view(b, nq, h, e // h).transpose(1, 2)
-        k = F.linear(k, w[e:2 * e], bias[e:2 * e]).view(b, nl, h, e // h).transpose(1, 2)
-        v = F.linear(value, w[2 * e:], bias[2 * e:]).view(b, nl, h, e // h).transpose(1, 2)
-        mask = None if blocked is None else ~blocked
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        o = o.transpose(1, 2).reshape(b, nq, e)
+        q = F.linear(q, w[:e], bias[:e])
+        k = F.linear(k, w[e:2 * e], bias[e:2 * e])
+        v = F.linear(value, w[2 * e:], bias[2 * e:])
+        o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
         return query + self.attn.out_proj(o)
 
 

@@ -327,6 +327,60 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, 
 
 
 # --------------------------------------------------------------------------------------
+# K6 decoder multi-head attention
+# --------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, blocked, num_heads):
+        lib = _lib.load()
+        _need_gpu(q, k, v, blocked)
+        dt = q.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError(f'attention supports f32 and bf16, got {dt}')
+        q, k, v = q.contiguous(), k.to(dt).contiguous(), v.to(dt).contiguous()
+        b, nq, e = q.shape
+        nl = k.shape[1]
+        d = e // num_heads
+        mask = None
+        if blocked is not None:
+            mask = blocked.reshape(b, nq, nl).contiguous()
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        out = torch.empty_like(q)
+        lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
+        ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
+        rc = lib.mbv_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), 1 if dt == torch.bfloat16 else 0, b, nq, nl,
+                              num_heads, d, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+        check(rc, 'mbv_attn_fwd')
+        ctx.save_for_backward(q, k, v, mask, out, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        q, k, v, mask, out, lse = ctx.saved_tensors
+        b, nq, e = q.shape
+        nl = k.shape[1]
+        h = ctx.num_heads
+        grad_out = grad_out.to(q.dtype).contiguous()
+        g_q = torch.empty((b, nq, e), dtype=torch.float32, device=q.device)
+        g_k = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
+        g_v = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
+        rc = lib.mbv_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse),
+                              1 if q.dtype == torch.bfloat16 else 0, b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
+                              _ptr(g_v), _stream())
+        check(rc, 'mbv_attn_bwd')
+        return g_q.to(q.dtype), g_k.to(q.dtype), g_v.to(q.dtype), None, None
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, blocked: Optional[torch.Tensor],
+              num_heads: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) masked) v per head on MFMA (K6).  q (B, Q, E), k / v (B, L, E) projected inputs;
+    ``blocked`` (B, 1|-, Q, L) bool/u8 with True = may not attend, or None.  Returns (B, Q, E)."""
+    return _Attention.apply(q, k, v, blocked, num_heads)
+
+
+# --------------------------------------------------------------------------------------
 # K7 per-query mask logits + attention mask of the next decoder layer
 # --------------------------------------------------------------------------------------
 class _MaskLogits(torch.autograd.Function):
