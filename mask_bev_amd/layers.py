@@ -20,6 +20,13 @@ def trunc_normal_(t: torch.Tensor, std: float = 0.02) -> torch.Tensor:
     return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std)
 
 
+class Linear(nn.Linear):
+    """``nn.Linear`` (same parameters / checkpoint keys) routed through :func:`ops.linear`."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.linear(x, self.weight, self.bias)
+
+
 class FFN(nn.Module):
     """Two-layer MLP with residual; keys ``layers.0.0.*`` / ``layers.1.*`` (mmcv ``FFN`` layout, used at
     mask_bev/models/networks/swin/swin.py:347-355 and mask_bev_panoptic_head.py:137-142,168-175)."""
@@ -27,8 +34,8 @@ class FFN(nn.Module):
     def __init__(self, embed_dims: int, feedforward_channels: int, act: str = 'gelu'):
         super().__init__()
         self.layers = nn.Sequential(
-            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU() if act == 'gelu' else nn.ReLU()),
-            nn.Linear(feedforward_channels, embed_dims))
+            nn.Sequential(Linear(embed_dims, feedforward_channels), nn.GELU() if act == 'gelu' else nn.ReLU()),
+            Linear(feedforward_channels, embed_dims))
 
     def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
         return (x if identity is None else identity) + self.layers(x)
@@ -65,7 +72,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.stride = stride
         self.norm = nn.LayerNorm(4 * in_channels)
-        self.reduction = nn.Linear(4 * in_channels, out_channels, bias=False)
+        self.reduction = Linear(4 * in_channels, out_channels, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:          # (B, H, W, C) → (B, H', W', 2C)
         b, h, w, c = x.shape
@@ -152,9 +159,9 @@ class MultiheadAttention(nn.Module):
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         q = query + query_pos if query_pos is not None else query
         k = key + key_pos if key_pos is not None else key
-        q = F.linear(q, w[:e], bias[:e])
-        k = F.linear(k, w[e:2 * e], bias[e:2 * e])
-        v = F.linear(value, w[2 * e:], bias[2 * e:])
+        q = ops.linear(q, w[:e], bias[:e])
+        k = ops.linear(k, w[e:2 * e], bias[e:2 * e])
+        v = ops.linear(value, w[2 * e:], bias[2 * e:])
         o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
         return query + self.attn.out_proj(o)
 
@@ -167,10 +174,10 @@ class MultiScaleDeformableAttention(nn.Module):
     def __init__(self, embed_dims: int = 256, num_heads: int = 8, num_levels: int = 3, num_points: int = 4):
         super().__init__()
         self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import FFN, PatchEmbed, PatchMerging, trunc_normal_
+from .layers import FFN, Linear, PatchEmbed, PatchMerging, trunc_normal_
 
 
 def relative_position_index(ws: int) -> torch.Tensor:
@@ -34,8 +34,8 @@ class WindowMSA(nn.Module):
         self.embed_dims, self.num_heads, self.window_size = embed_dims, num_heads, window_size
         self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
         self.register_buffer('relative_position_index', relative_position_index(window_size))
-        self.qkv = nn.Linear(embed_dims, embed_dims * 3)
-        self.proj = nn.Linear(embed_dims, embed_dims)
+        self.qkv = Linear(embed_dims, embed_dims * 3)
+        self.proj = Linear(embed_dims, embed_dims)
         trunc_normal_(self.relative_position_bias_table, std=0.02)
 
 
