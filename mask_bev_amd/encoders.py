@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .layers import Linear
 from .ops import Pillars, VoxelGeometry
 
 
@@ -50,7 +51,7 @@ class _PFNLayer(nn.Module):
         super().__init__()
         self.last_vfe = last
         self.units = cout if last else cout // 2
-        self.linear = nn.Linear(cin, self.units, bias=False)
+        self.linear = Linear(cin, self.units, bias=False)
         self.norm = nn.BatchNorm1d(self.units, eps=1e-3, momentum=0.01)
 
 

@@ -12,6 +12,9 @@ def step(i):
     loss = m.training_step(pool[i % 2], i); loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
 for i in range(3): step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(3); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=60))
+evs = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ('aten::mm', 'aten::addmm', 'aten::bmm', 'aten::copy_', 'aten::sum', 'aten::convolution_backward', 'aten::miopen_convolution', 'aten::add', 'aten::mul')]
+evs.sort(key=lambda e: -e.self_device_time_total)
+for e in evs[:40]:
+    print(f'{e.key:28s} {e.self_device_time_total/1e3:8.2f} ms  n={e.count:4d}  {str(e.input_shapes)[:120]}')
