@@ -83,6 +83,44 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
                      float* rows, int64_t* row_pillar, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K2b — the per-pillar (non-GEMM) parts of the PFNLayer stack, on real points + one representative padded row
+ * per pillar with multiplicity max_points - n (identical to mmdet3d's dense zero-padded evaluation).
+ * Replaces: mmdet3d PFNLayer.forward (Linear → BatchNorm1d(eps 1e-3, momentum 0.01) → ReLU → max over the point
+ * slots → concat) reached from MaskBevEncoder.encode (mask_bev/models/encoders/mask_bev_encoders.py:70-72,
+ * 119-120).  The Linear parts stay library GEMMs (y = a_prev W_a^T, t = max_prev W_b^T, y_pad = a_pad_prev W_a^T).
+ * All tensors f32; `units` <= 128 channels; rows of pillar v are [row_start[v], row_start[v] + num_points[v]).
+ *   mbv_pfn_stats       y[r] += t[v], y_pad[v] += t[v] (when t != NULL); sums[0:U] = sum y, sums[U:2U] = sum y^2
+ *                       over all V * max_points rows (padded rows weighted by their multiplicity), f64
+ *   mbv_pfn_bn_finalize batch (training != 0) or running statistics → scale, shift, mean, rstd; updates the
+ *                       running buffers in training mode (momentum, unbiased variance)
+ *   mbv_pfn_apply_max   a = relu(y*scale+shift) (K, U), a_pad (V, U), m[v] = max over the pillar's rows and, if
+ *                       n < max_points, its padded row; a / a_pad may be NULL for the last layer
+ *   mbv_pfn_bwd_route   dz = relu'(.) * (dA + dM routed to the first maximal row [padded row last]); dz_pad holds
+ *                       the SUM over the padded copies; sums = (sum dz, sum dz*xhat) f64 → d beta, d gamma
+ *   mbv_pfn_bwd_bn      BatchNorm backward in place (dz → dy, dz_pad → summed dy_pad), dt[v] = sum_r dy[r] + dy_pad[v]
+ */
+int mbv_pfn_stats(float* y, const float* t, float* y_pad, const int32_t* row_start, const int32_t* num_points,
+                  int64_t num_pillars, int32_t units, int32_t max_points, double* sums, void* stream);
+
+int mbv_pfn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                        float momentum, int32_t training, float* running_mean, float* running_var, int32_t units,
+                        float* scale, float* shift, float* mean, float* rstd, void* stream);
+
+int mbv_pfn_apply_max(const float* y, const float* y_pad, const float* scale, const float* shift,
+                      const int32_t* row_start, const int32_t* num_points, int64_t num_pillars, int32_t units,
+                      int32_t max_points, float* a, float* a_pad, float* m, void* stream);
+
+int mbv_pfn_bwd_route(const float* y, const float* y_pad, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, float* dz, int32_t has_da, const float* sum_da_pad,
+                      const float* dm, const int32_t* row_start, const int32_t* num_points, int64_t num_pillars,
+                      int32_t units, int32_t max_points, float* dz_pad, double* sums, void* stream);
+
+int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, float* dz_pad, const float* mean,
+                   const float* rstd, const float* gamma, const double* sums, double count, int32_t training,
+                   const int32_t* row_start, const int32_t* num_points, int64_t num_pillars, int32_t units,
+                   int32_t max_points, float* dt, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K3 — PointPillarsScatter fused with the (C, H, W) LayerNorm; the dense canvas is never built.
  * Replaces: MaskBevEncoder.middle_encode (mask_bev_encoders.py:122-123 → mmdet3d PointPillarsScatter)
  *           + nn.LayerNorm([C, ny, nx], eps) (:75, :92).

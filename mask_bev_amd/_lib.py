@@ -6,13 +6,13 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 from typing import Dict, List, Tuple
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MaskBevHipError(RuntimeError):
@@ -32,6 +32,11 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                     _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     'mbv_gather_voxels': (ctypes.c_int, [_P, _I, _P, _L, _I, _P, _P]),
     'mbv_pfn_decorate': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    'mbv_pfn_stats': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    'mbv_pfn_bn_finalize': (ctypes.c_int, [_P, c_double, _P, _P, _F, _F, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    'mbv_pfn_apply_max': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    'mbv_pfn_bwd_route': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    'mbv_pfn_bwd_bn': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, _I, _P, _P, _L, _I, _I, _P, _P]),
     'mbv_scatter_layernorm_workspace_bytes': (c_size_t, [_I]),
     'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, c_size_t, _P, _P,
                                                  _P]),

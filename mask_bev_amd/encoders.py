@@ -79,39 +79,15 @@ class PillarFeatureNet(nn.Module):
         self.point_cloud_range = [float(v) for v in point_cloud_range]
 
     def forward(self, p: Pillars) -> torch.Tensor:
-        rows, row_pillar = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)      # (K, D+7)
-        v, pmax = p.num_pillars, p.max_points
-        mult = (pmax - p.num_points).to(rows.dtype).unsqueeze(1)                            # (V, 1) padded rows
-        count = float(v * pmax)
-        x, pad = rows, None                      # pad: (V, Cin) representative padded row (None = all zero)
-        for layer in self.pfn_layers:
-            y = layer.linear(x)
-            y_pad = layer.linear(pad) if pad is not None else y.new_zeros(1, layer.units)
-            bn = layer.norm
-            if self.training:
-                s = y.sum(0) + (y_pad * mult).sum(0)
-                mean = s / count
-                dv, dp = y - mean, y_pad - mean
-                var = ((dv * dv).sum(0) + (dp * dp * mult).sum(0)) / count
-                with torch.no_grad():
-                    bn.running_mean.mul_(1 - bn.momentum).add_(mean.detach(), alpha=bn.momentum)
-                    unbiased = var.detach() * (count / max(count - 1.0, 1.0))
-                    bn.running_var.mul_(1 - bn.momentum).add_(unbiased, alpha=bn.momentum)
-                    bn.num_batches_tracked.add_(1)
-            else:
-                mean, var = bn.running_mean, bn.running_var
-            scale = bn.weight * torch.rsqrt(var + bn.eps)
-            shift = bn.bias - mean * scale
-            a = F.relu(y * scale + shift)
-            a_pad = F.relu(y_pad * scale + shift).expand(v, -1)
-            # max over the pillar's real rows and (if any) its padded row
-            init = torch.where(mult > 0, a_pad, a_pad.new_full((), float('-inf')))
-            mx = init.scatter_reduce(0, row_pillar.unsqueeze(1).expand(-1, layer.units), a, 'amax', include_self=True)
-            if layer.last_vfe:
-                return mx
-            x = torch.cat([a, mx[row_pillar]], dim=1)
-            pad = torch.cat([a_pad, mx], dim=1)
-        raise RuntimeError('unreachable')
+        rows, _ = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)              # K2a: (K, D+7)
+        layers = [(l.linear.weight, l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var, l.norm.eps,
+                   l.norm.momentum) for l in self.pfn_layers]
+        out = ops.pfn_layers(rows, p, layers, self.training)                                # K2b
+        if self.training:
+            with torch.no_grad():
+                for l in self.pfn_layers:
+                    l.norm.num_batches_tracked.add_(1)
+        return out
 
 
 class PointPillarsScatter(nn.Module):

@@ -175,6 +175,114 @@ def pfn_decorate(p: Pillars, voxel_size: Sequence[float], pc_range: Sequence[flo
 
 
 # --------------------------------------------------------------------------------------
+# K2b PillarFeatureNet layers (per-pillar kernels + f32 library GEMMs)
+# --------------------------------------------------------------------------------------
+class _PillarFeatureNet(torch.autograd.Function):
+    """forward(rows, row_start, num_points, V, P, training, eps, momentum, W_0, gamma_0, beta_0, rmean_0, rvar_0, …)
+    → (V, C_last).  Everything is f32 whatever the autocast state: the GEMMs are ~7 GFLOP and the BatchNorm
+    statistics / pillar indices must not lose precision."""
+
+    @staticmethod
+    def forward(ctx, rows, row_start, num_points, v, p, training, eps, momentum, *params):
+        lib = _lib.load()
+        _need_gpu(rows, row_start, num_points)
+        dev = rows.device
+        n_layers = len(params) // 5
+        k = int(rows.shape[0])
+        count = float(v * p)
+        st = _stream()
+        with torch.autocast('cuda', enabled=False):
+            a_prev, apad_prev, m_prev = rows.float().contiguous(), None, None
+            saved = []
+            for l in range(n_layers):
+                w, g, b, rm, rv = params[5 * l:5 * l + 5]
+                w = w.float()
+                u = int(w.shape[0])
+                if l == 0:
+                    y = a_prev.mm(w.t())
+                    ypad = torch.zeros((v, u), dtype=torch.float32, device=dev)     # W . 0
+                    t = None
+                else:
+                    ca = int(a_prev.shape[1])
+                    y = a_prev.mm(w[:, :ca].t())
+                    ypad = apad_prev.mm(w[:, :ca].t())
+                    t = m_prev.mm(w[:, ca:].t())
+                sums = torch.empty(2 * u, dtype=torch.float64, device=dev)
+                check(lib.mbv_pfn_stats(_ptr(y), _ptr(t), _ptr(ypad), _ptr(row_start), _ptr(num_points), v, u, p,
+                                        _ptr(sums), st), 'mbv_pfn_stats')
+                scale, shift, mean, rstd = (torch.empty(u, dtype=torch.float32, device=dev) for _ in range(4))
+                check(lib.mbv_pfn_bn_finalize(_ptr(sums), count, _ptr(g.float()), _ptr(b.float()), float(eps),
+                                              float(momentum), 1 if training else 0, _ptr(rm), _ptr(rv), u,
+                                              _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), st),
+                      'mbv_pfn_bn_finalize')
+                last = l == n_layers - 1
+                a = None if last else torch.empty((k, u), dtype=torch.float32, device=dev)
+                apad = None if last else torch.empty((v, u), dtype=torch.float32, device=dev)
+                m = torch.empty((v, u), dtype=torch.float32, device=dev)
+                check(lib.mbv_pfn_apply_max(_ptr(y), _ptr(ypad), _ptr(scale), _ptr(shift), _ptr(row_start),
+                                            _ptr(num_points), v, u, p, _ptr(a), _ptr(apad), _ptr(m), st),
+                      'mbv_pfn_apply_max')
+                saved.append((a_prev, apad_prev, m_prev, y, ypad, scale, shift, mean, rstd, w, g.float()))
+                a_prev, apad_prev, m_prev = a, apad, m
+        ctx.saved = saved
+        ctx.meta = (row_start, num_points, v, p, training, count, [t.dtype for t in params])
+        return m_prev
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        row_start, num_points, v, p, training, count, dtypes = ctx.meta
+        st = _stream()
+        n_layers = len(ctx.saved)
+        grads = [None] * (5 * n_layers)
+        with torch.autocast('cuda', enabled=False):
+            dm = d_out.float().contiguous()
+            da, sapad = None, None
+            for l in reversed(range(n_layers)):
+                a_prev, apad_prev, m_prev, y, ypad, scale, shift, mean, rstd, w, g = ctx.saved[l]
+                u = int(w.shape[0])
+                dev = y.device
+                dz = da if da is not None else torch.empty_like(y)
+                dzpad = torch.empty_like(ypad)
+                sums = torch.empty(2 * u, dtype=torch.float64, device=dev)
+                check(lib.mbv_pfn_bwd_route(_ptr(y), _ptr(ypad), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                            _ptr(dz), 1 if da is not None else 0, _ptr(sapad), _ptr(dm),
+                                            _ptr(row_start), _ptr(num_points), v, u, p, _ptr(dzpad), _ptr(sums), st),
+                      'mbv_pfn_bwd_route')
+                grads[5 * l + 1] = sums[u:].to(dtypes[5 * l + 1])          # d gamma = sum dz * xhat
+                grads[5 * l + 2] = sums[:u].to(dtypes[5 * l + 2])          # d beta  = sum dz
+                dt = torch.empty_like(ypad) if l > 0 else None
+                check(lib.mbv_pfn_bwd_bn(_ptr(y), _ptr(ypad), _ptr(dz), _ptr(dzpad), _ptr(mean), _ptr(rstd), _ptr(g),
+                                         _ptr(sums), count, 1 if training else 0, _ptr(row_start), _ptr(num_points),
+                                         v, u, p, _ptr(dt), st), 'mbv_pfn_bwd_bn')
+                dy, dypad = dz, dzpad
+                if l == 0:
+                    gw = _wgrad(dy, a_prev)
+                    da = sapad = dm = None
+                else:
+                    ca = int(a_prev.shape[1])
+                    wa, wb = w[:, :ca], w[:, ca:]
+                    gw = torch.cat([_wgrad(dy, a_prev) + dypad.t().mm(apad_prev), dt.t().mm(m_prev)], dim=1)
+                    da = dy.mm(wa)
+                    sapad = dypad.mm(wa)
+                    dm = dt.mm(wb)
+                grads[5 * l] = gw.to(dtypes[5 * l])
+        ctx.saved = None
+        return (None,) * 8 + tuple(grads)
+
+
+def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torch.Tensor:
+    """PFNLayer stack on the compact decorated rows (K2b).  ``layers``: sequence of (weight, bn_weight, bn_bias,
+    running_mean, running_var, eps, momentum); running buffers are updated in place in training mode."""
+    flat = []
+    for (w, g, b, rm, rv, _eps, _mom) in layers:
+        flat += [w, g, b, rm, rv]
+    eps, mom = layers[0][5], layers[0][6]
+    return _PillarFeatureNet.apply(rows, p.row_start, p.num_points, p.num_pillars, p.max_points, training, eps, mom,
+                                   *flat)
+
+
+# --------------------------------------------------------------------------------------
 # K3 scatter + (C, H, W) LayerNorm
 # --------------------------------------------------------------------------------------
 class _ScatterLayerNorm(torch.autograd.Function):
@@ -339,6 +447,19 @@ def _wgrad_splits(tokens: int) -> int:
     return 1
 
 
+def _wgrad(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW (out, in) = g2^T x2 for token-major g2 (T, out), x2 (T, in); f32 result, split-K for large T."""
+    t = g2.shape[0]
+    s = _wgrad_splits(t)
+    if s == 1:
+        return g2.t().mm(x2).float()
+    c = t // s                          # rows per chunk; the ragged tail (< s rows) is one more small GEMM
+    gw = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1)).sum(0, dtype=torch.float32)
+    if s * c < t:
+        gw = gw + g2[s * c:].t().mm(x2[s * c:]).float()
+    return gw
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -365,17 +486,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g2.mm(w).view_as(x)
         if ctx.needs_input_grad[1]:
-            t = g2.shape[0]
-            s = _wgrad_splits(t)
-            if s > 1:
-                c = t // s                          # rows per chunk; the ragged tail (< s rows) is one more small GEMM
-                gw = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1)).sum(
-                    0, dtype=torch.float32)
-                if s * c < t:
-                    gw = gw + g2[s * c:].t().mm(x2[s * c:]).float()
-            else:
-                gw = g2.t().mm(x2)
-            gw = gw.to(ctx.param_dtype)
+            gw = _wgrad(g2, x2).to(ctx.param_dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0, dtype=torch.float32).to(ctx.param_dtype)
         return gx, gw, gb

@@ -1,0 +1,61 @@
+"""K2 PillarFeatureNet (K2a decoration + K2b per-pillar kernels, padded-row algebra) vs the oracle's dense
+zero-padded PFN: output, gradients of every parameter, BatchNorm running statistics; train and eval mode.
+f32: output rtol 1e-4, gradients 2e-3 relative to the tensor's max."""
+import pytest
+import torch
+
+from oracle import maskbev_oracle as O
+from tests.util_cfg import random_scans
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+@pytest.mark.parametrize('chans,P,sizes,training', [([32, 32, 32], 8, [3000, 2000], True),
+                                                    ([128, 128, 128], 32, [6000], True),
+                                                    ([64, 128], 4, [1500, 10, 900], True),
+                                                    ([32, 32, 32], 8, [2500], False)])
+def test_pfn_matches_dense_oracle(device, chans, P, sizes, training):
+    from mask_bev_amd import ops
+    from mask_bev_amd.encoders import PillarFeatureNet
+    kw = dict(x_range=(-10, 10), y_range=(-10, 10), z_range=(-3, 1), voxel_size=0.25, num_queries=4, max_num_points=P,
+              encoder_feat_channels=chans, backbone_embed_dim=48, head_feat_channels=128, head_out_channels=128)
+    cfg = O.make_cfg(**kw)
+    sd = {k: v for k, v in O.make_state_dict(cfg, 3).items() if k.startswith(O.ENC + '_voxel_encoder')}
+    for k in list(sd):
+        if k.endswith('running_mean'):
+            sd[k] = torch.randn_like(sd[k]) * 0.1
+        if k.endswith('running_var'):
+            sd[k] = torch.rand_like(sd[k]) + 0.5
+    scans = random_scans(kw, sizes, seed=P)
+    # oracle (dense, zero padded)
+    voxels, nump, coors = O.voxelize(cfg, scans)
+    sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
+            for k, v in sd.items()}
+    bufs = {k: v.clone() for k, v in sd.items() if 'running_' in k}
+    ref = O.pfn_forward(cfg, sd_g, voxels, nump, coors, training, bn_buffers=bufs)
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    ref.backward(go)
+    # product
+    net = PillarFeatureNet(in_channels=4, feat_channels=chans, with_distance=True, voxel_size=cfg.voxel_size3,
+                           point_cloud_range=cfg.pc_range)
+    net.load_state_dict({k[len(O.ENC + '_voxel_encoder.'):]: v for k, v in sd.items()})
+    net = net.to(device).train(training)
+    geom = ops.VoxelGeometry.from_ranges(cfg.pc_range, cfg.voxel_size3)
+    pil = ops.voxelize([s.to(device) for s in scans], geom, P, cfg.max_voxels)
+    out = net(pil)
+    out.backward(go.to(device))
+    assert out.shape == ref.shape
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-4
+    for name, prm in net.named_parameters():
+        r = sd_g[O.ENC + '_voxel_encoder.' + name].grad
+        assert r is not None and _rel(prm.grad.cpu(), r) < 2e-3, name
+    for name, buf in net.named_buffers():
+        if 'running_' in name:
+            want = bufs[O.ENC + '_voxel_encoder.' + name]
+            torch.testing.assert_close(buf.cpu(), want, rtol=1e-4, atol=1e-6)
+        if 'num_batches_tracked' in name:
+            assert int(buf) == (1 if training else 0)
