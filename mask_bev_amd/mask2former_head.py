@@ -7,6 +7,7 @@ mask_bev/models/head/mask_bev_panoptic_head.py:98-215.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -227,6 +228,8 @@ class Mask2FormerHead(nn.Module):
         self.loss_dice_weight = float((loss_dice or {}).get('loss_weight', 5.0))
         self.point_seed: Optional[int] = None          # tests set this to share points with the oracle
         self._iota_cache: Dict = {}
+        self._side_streams: Dict = {}
+        self.overlap_matcher = os.environ.get('MBV_OVERLAP_MATCHER', '1') != '0'
         # GT masks are float32 {0, 1} by the reference's batch contract (semantic_kitti_transforms.py:77-81);
         # set False to sample arbitrary-valued maps through the generic f32 path
         self.binary_gt_masks = True
@@ -311,10 +314,10 @@ class Mask2FormerHead(nn.Module):
         return ops.point_sample(gt, src_index, coords, coord_index)
 
     @torch.no_grad()
-    def _assign(self, cls, masks_flat, labels_gt, gt_flat, match_coords):
-        """Hungarian targets of ALL decoder outputs and images at once (mask2former_head.py:154-232).
+    def _match_cost(self, cls, masks_flat, labels_gt, gt_flat, match_coords):
+        """Matching costs of ALL decoder outputs and images at once (mask2former_head.py:154-210).
         cls (D, B, Q, K+1); masks_flat (D*B*Q, H, W); match_coords (D*B, P, 2).  Costs 2*(-softmax cls) +
-        5*BCE + 5*dice on the sampled points; the D*B assignment problems are solved on the device by one
+        5*BCE + 5*dice on the sampled points; the D*B assignment problems are then solved on the device by one
         launch of K9 — no device→host copy, no scipy."""
         d, b, nq = cls.shape[:3]
         ng = labels_gt.shape[1]
@@ -334,8 +337,7 @@ class Mask2FormerHead(nn.Module):
         num = 2 * torch.matmul(ps, gpt)
         den = ps.sum(-1)[..., :, None] + gp.sum(-1)[..., None, :]
         dice = 1 - (num + 1.0) / (den + 1.0)
-        cost = cls_cost + 5.0 * bce + 5.0 * dice
-        return ops.hungarian(cost.flatten(0, 1)).view(d, b, nq)                                 # gt index or -1
+        return (cls_cost + 5.0 * bce + 5.0 * dice).flatten(0, 1)                               # (D*B, Q, G)
 
     def loss(self, all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, img_metas=None, heights_pred=None,
              heights_gt=None) -> Dict[str, torch.Tensor]:
@@ -361,9 +363,51 @@ class Mask2FormerHead(nn.Module):
             gt_flat = ops.pack_binary_masks(gt_flat)      # {0,1} by the batch contract: 32 KB per 512x512 mask
         pts = PointSource(dev, self.point_seed)
         match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
-        assigned = self._assign(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)          # (D, B, Q) i32
-        matched = assigned >= 0
-        safe = assigned.clamp(min=0).long()
+        cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)
+        # K9 is latency-bound (one wavefront per problem).  When every query gets matched (G >= Q, the dataset's
+        # padding convention) nothing of the importance sampling below depends on the assignment, so K9 runs on
+        # a side stream underneath it.
+        overlap = m == nq and self.overlap_matcher
+        main = torch.cuda.current_stream()
+        if overlap:
+            side = self._side_streams.get(dev)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                assigned = ops.hungarian(cost).view(d, b, nq)
+            cost.record_stream(side)
+        else:
+            assigned = ops.hungarian(cost).view(d, b, nq)                                        # (D, B, Q) i32
+            matched = assigned >= 0
+            safe = assigned.clamp(min=0).long()
+
+        # matched (decoder output, image, query) rows in (d, b, q) order, without a host sync
+        if m == nq:
+            qsel = self._iota(nq, dev).long().view(1, 1, nq).expand(d, b, nq)
+        else:
+            qsel = torch.sort((~matched).to(torch.uint8), dim=-1, stable=True).indices[..., :m]
+        db = self._iota(d * b, dev).long().view(d, b, 1)
+        pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
+        rows = self._iota(d * g, dev)
+        with torch.no_grad():
+            unc = -ops.point_sample(masks_flat.detach(), pred_index, over_c, rows).abs()
+            n_unc = int(self.importance_sample_ratio * p)
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
+            coords = torch.gather(over_c, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+            if rand_c is not None:
+                coords = torch.cat((coords, rand_c), dim=1)
+            coords = coords.contiguous()
+        pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
+        if overlap:                                     # join the matcher
+            main.wait_stream(side)
+            assigned.record_stream(main)
+            matched = assigned >= 0
+            safe = assigned.clamp(min=0).long()
+        with torch.no_grad():
+            bsel = self._iota(b, dev).long().view(1, b, 1)
+            gt_index = (bsel * ng + torch.gather(safe, 2, qsel)).flatten().to(torch.int32)       # rows of gt_flat
+            tgt = self._sample_gt(gt_flat, gt_index, coords, rows)                               # (D*g, P)
 
         # classification loss (class-weighted CE, avg_factor = sum of the class weights of the targets)
         labels = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, safe),
@@ -379,26 +423,6 @@ class Mask2FormerHead(nn.Module):
             num_total_masks = self.world_size_fn(num_total_masks)
         num_total_masks = num_total_masks.clamp(min=1.0)[0]
 
-        # matched (decoder output, image, query) rows in (d, b, q) order, without a host sync
-        if m == nq:
-            qsel = self._iota(nq, dev).long().view(1, 1, nq).expand(d, b, nq)
-        else:
-            qsel = torch.sort((~matched).to(torch.uint8), dim=-1, stable=True).indices[..., :m]
-        db = self._iota(d * b, dev).long().view(d, b, 1)
-        pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
-        bsel = self._iota(b, dev).long().view(1, b, 1)
-        gt_index = (bsel * ng + torch.gather(safe, 2, qsel)).flatten().to(torch.int32)           # rows of gt_flat
-        rows = self._iota(d * g, dev)
-        with torch.no_grad():
-            unc = -ops.point_sample(masks_flat.detach(), pred_index, over_c, rows).abs()
-            n_unc = int(self.importance_sample_ratio * p)
-            idx = torch.topk(unc, k=n_unc, dim=1)[1]
-            coords = torch.gather(over_c, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
-            if rand_c is not None:
-                coords = torch.cat((coords, rand_c), dim=1)
-            coords = coords.contiguous()
-            tgt = self._sample_gt(gt_flat, gt_index, coords, rows)                               # (D*g, P)
-        pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
         ps = pred.sigmoid()
         dice = (2 * (ps * tgt).sum(1) + 1.0) / (ps.sum(1) + tgt.sum(1) + 1.0)
         loss_dice = self.loss_dice_weight * (1 - dice).view(d, g).sum(1) / (num_total_masks + eps)

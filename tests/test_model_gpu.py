@@ -105,3 +105,27 @@ def test_loss_and_gradients_match_oracle(device):
         assert r is not None and _rel(g, r) < 5e-3, k
         checked += 1
     assert checked == 11
+
+
+@pytest.mark.parametrize('n_gt', [5, 8, 12])
+def test_loss_on_given_logits_any_gt_count(device, n_gt):
+    """Product loss (K8 sampling, K9 matcher, layer-batched) vs oracle loss on the SAME logits, with fewer / equal /
+    more ground-truth instances than queries; shared sampling points.  Every one of the 4 x 10 terms, rel 2e-4."""
+    kw = tiny_kwargs()
+    m, cfg, sd = _build(kw, device, seed=9)
+    cfg.num_points = 200
+    head = m._panoptic_head._panoptic_head
+    head.num_points = 200
+    head.point_seed = 5
+    g = torch.Generator().manual_seed(n_gt)
+    q = kw['num_queries']
+    cls = [torch.randn(2, q, 2, generator=g) for _ in range(10)]
+    masks = [torch.randn(2, q, 20, 20, generator=g) * 3 for _ in range(10)]
+    labels = torch.randint(0, 2, (2, n_gt), generator=g)
+    gt = (torch.rand(2, n_gt, 80, 80, generator=g) > 0.7).float()
+    gt[:, -1] = 0
+    ref = O.loss_dict(cfg, cls, masks, labels, gt, O.PointSource(5))
+    got = head.loss([c.to(device) for c in cls], [mk.to(device) for mk in masks], labels.to(device), gt.to(device))
+    assert list(got.keys()) == list(ref.keys())
+    for k in ref:
+        assert float(got[k]) == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), k
