@@ -231,6 +231,16 @@ int mbv_point_sample_packed_fwd(const uint32_t* packed, const int32_t* src_index
                                 int32_t H, int32_t W, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K10 — importance sampling of the mask loss: the k points with the smallest |logit| of each row.
+ * Replaces: torch.topk(-|logits|, k) + coordinate gather of mmdet's get_uncertain_point_coords_with_randomness,
+ * called at mask_bev/models/networks/mask2former_head/mask2former_head.py:401-404.
+ * logits (rows, n) f32; coords (rows, n, 2) f32; out_coords (rows, k, 2) f32: the coordinates of the selected
+ * points in ascending index order (same SET as top-k; ties at the threshold resolved towards lower indices).
+ */
+int mbv_select_uncertain_points(const float* logits, const float* coords, int64_t rows, int32_t n, int32_t k,
+                                float* out_coords, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

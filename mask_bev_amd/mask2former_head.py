@@ -391,10 +391,9 @@ class Mask2FormerHead(nn.Module):
         pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
         rows = self._iota(d * g, dev)
         with torch.no_grad():
-            unc = -ops.point_sample(masks_flat.detach(), pred_index, over_c, rows).abs()
+            over_logits = ops.point_sample(masks_flat.detach(), pred_index, over_c, rows)
             n_unc = int(self.importance_sample_ratio * p)
-            idx = torch.topk(unc, k=n_unc, dim=1)[1]
-            coords = torch.gather(over_c, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+            coords = ops.select_uncertain_points(over_logits, over_c, n_unc)          # most uncertain = smallest |logit|
             if rand_c is not None:
                 coords = torch.cat((coords, rand_c), dim=1)
             coords = coords.contiguous()

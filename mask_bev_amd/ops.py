@@ -705,3 +705,20 @@ def hungarian(cost: torch.Tensor) -> torch.Tensor:
     rc = lib.mbv_hungarian(_ptr(cost), n, r, c, _ptr(out), _stream())
     check(rc, 'mbv_hungarian')
     return out
+
+
+# --------------------------------------------------------------------------------------
+# K10 importance sampling: the k most uncertain points of each row
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def select_uncertain_points(logits: torch.Tensor, coords: torch.Tensor, k: int) -> torch.Tensor:
+    """logits (R, n) sampled mask logits, coords (R, n, 2) → (R, k, 2): coordinates of the k points with the
+    smallest |logit| per row (radix select + ordered compaction, K10); same set as ``topk(-|logits|, k)``."""
+    lib = _lib.load()
+    _need_gpu(logits, coords)
+    logits, coords = logits.float().contiguous(), coords.float().contiguous()
+    r, n = logits.shape
+    out = torch.empty((r, k, 2), dtype=torch.float32, device=logits.device)
+    rc = lib.mbv_select_uncertain_points(_ptr(logits), _ptr(coords), r, n, int(k), _ptr(out), _stream())
+    check(rc, 'mbv_select_uncertain_points')
+    return out
