@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-budget-s', type=float, default=90.0)
     ap.add_argument('--pool', type=int, default=2, help='distinct synthetic batches kept resident in HBM')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the HIP graph')
     return ap.parse_args()
 
 
@@ -110,8 +111,17 @@ def main():
     pool = [synthetic.make_batch(args.workload, args.batch, rank, s, device) for s in range(args.pool)]
     torch.cuda.synchronize()
 
+    graphed = None
+    if not args.no_graph:
+        from mask_bev_amd.graph import GraphedTrainStep
+        if reducer is not None:
+            reducer.no_sync(True)          # gradients are averaged after the replay, not from hooks inside it
+        graphed = GraphedTrainStep(model, opt, pool[0], reducer=reducer)
+
     def step(i: int):
         scans, gt = pool[i % len(pool)]
+        if graphed is not None:
+            return graphed.step((scans, gt))
         if reducer is not None:
             reducer.sync_buffers()
         loss = model.training_step((scans, gt), i)
@@ -171,7 +181,8 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW', final_loss=final_loss),
+                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph',
+                        final_loss=final_loss),
             roofline=dominant, roofline_all=list(roof.values()))
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -22,6 +22,27 @@
 
 static inline size_t mbv_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Zero / byte-fill device memory with a KERNEL.  hipMemsetAsync issued from inside this library was observed not
+// to be re-executed when the enclosing stream capture is replayed as a HIP graph (gradients accumulated into
+// stale pool memory from the second replay on); a kernel node always replays.
+static __global__ void __launch_bounds__(256) mbv_k_fill_bytes(unsigned char* __restrict__ p, int value, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i + 16 <= n && (reinterpret_cast<size_t>(p) & 15) == 0) {
+    const unsigned v4 = 0x01010101u * (unsigned)(value & 0xff);
+    *reinterpret_cast<uint4*>(p + i) = make_uint4(v4, v4, v4, v4);
+  } else {
+    for (size_t j = i; j < n && j < i + 16; ++j) p[j] = (unsigned char)value;
+  }
+}
+
+static inline hipError_t mbv_fill_async(void* ptr, int value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  const size_t threads = (bytes + 15) / 16;
+  hipLaunchKernelGGL(mbv_k_fill_bytes, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<unsigned char*>(ptr), value, bytes);
+  return hipGetLastError();
+}
+
 // Carves 256-byte aligned pieces out of a caller-provided workspace.
 struct MbvCarver {
   char* base;

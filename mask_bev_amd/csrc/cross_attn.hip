@@ -432,10 +432,10 @@ extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const u
   if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
   if (!q || !k || !v || !out || !grad_out || !lse || !grad_q || !grad_k || !grad_v) return MBV_ERR_BAD_ARG;
   if (g.nsplit > 1)
-    MBV_CHECK_HIP(hipMemsetAsync(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
   if (g.nsuper > 1) {
-    MBV_CHECK_HIP(hipMemsetAsync(grad_k, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
-    MBV_CHECK_HIP(hipMemsetAsync(grad_v, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_k, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_v, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
   }
   return is_bf16 ? attn_bwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, grad_k,
                                                  grad_v, stream)

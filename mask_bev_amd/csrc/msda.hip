@@ -175,7 +175,7 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_value ||
       !grad_loc || !grad_attn)
     return MBV_ERR_BAD_ARG;
-  MBV_CHECK_HIP(hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)batch * num_value * num_heads * head_dim, stream));
+  MBV_CHECK_HIP(mbv_fill_async(grad_value, 0, sizeof(float) * (size_t)batch * num_value * num_heads * head_dim, stream));
   const int64_t total = (int64_t)batch * num_query * num_heads * head_dim;
   hipLaunchKernelGGL(k_msda_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, grad_out, value,
                      spatial_shapes, level_start, sampling_loc, attn_weight, total, num_value, num_heads, head_dim,

@@ -283,7 +283,7 @@ extern "C" int mbv_pfn_stats(float* y, const float* t, float* y_pad, const int32
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (int rc = pfn_check(num_pillars, units, max_points)) return rc;
   if (!sums) return MBV_ERR_BAD_ARG;
-  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * units, stream));
+  MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * units, stream));
   if (num_pillars == 0) return MBV_OK;
   if (!y || !y_pad || !row_start || !num_points) return MBV_ERR_BAD_ARG;
   MBV_PFN_DISPATCH(k_pfn_stats, y, t, y_pad, row_start, num_points, (int)num_pillars, max_points, units, sums)
@@ -327,7 +327,7 @@ extern "C" int mbv_pfn_bwd_route(const float* y, const float* y_pad, const float
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (int rc = pfn_check(num_pillars, units, max_points)) return rc;
   if (!sums) return MBV_ERR_BAD_ARG;
-  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * units, stream));
+  MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * units, stream));
   if (num_pillars == 0) return MBV_OK;
   if (!y || !y_pad || !scale || !shift || !mean || !rstd || !dz || !dm || !row_start || !num_points || !dz_pad)
     return MBV_ERR_BAD_ARG;

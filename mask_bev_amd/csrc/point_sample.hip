@@ -233,7 +233,7 @@ extern "C" int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_in
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (num_rows < 0 || num_points <= 0 || H <= 0 || W <= 0 || num_src_maps < 0) return MBV_ERR_BAD_ARG;
   if (!grad_src && num_src_maps > 0) return MBV_ERR_BAD_ARG;
-  MBV_CHECK_HIP(hipMemsetAsync(grad_src, 0, sizeof(float) * (size_t)num_src_maps * H * W, stream));
+  MBV_CHECK_HIP(mbv_fill_async(grad_src, 0, sizeof(float) * (size_t)num_src_maps * H * W, stream));
   if (num_rows == 0) return MBV_OK;
   if (!grad_out || !src_index || !coords || !coord_index) return MBV_ERR_BAD_ARG;
   if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;

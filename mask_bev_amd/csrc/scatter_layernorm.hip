@@ -322,7 +322,7 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
   if (!feats || !pillar_batch_start || !cell_to_pillar || !weight || !bias || !out || !stats) return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
   double* sums = reinterpret_cast<double*>(workspace);
-  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * batch, stream));
+  MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * batch, stream));
   hipLaunchKernelGGL(k_ln_stats, dim3(256, batch), dim3(256), 0, stream, feats, pillar_batch_start, channels, sums);
   MBV_CHECK_LAUNCH();
   const double inv_count = 1.0 / ((double)channels * ny * nx);
@@ -358,7 +358,7 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
     return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
   double* sums = reinterpret_cast<double*>(workspace);
-  MBV_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * batch, stream));
+  MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * batch, stream));
   const int ctiles = (channels + kCT - 1) / kCT;
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (nx % 4 == 0) {

@@ -401,9 +401,9 @@ extern "C" int mbv_voxelize(const float* points, int32_t point_dim, int64_t tota
   const uint32_t cells = (uint32_t)cells64;
   const uint32_t invalid_key = cells * (uint32_t)batch;  // sorts after every real key
 
-  MBV_CHECK_HIP(hipMemsetAsync(cell_to_pillar, 0xff, sizeof(int32_t) * cells64 * batch, stream));
-  MBV_CHECK_HIP(hipMemsetAsync(num_points, 0, sizeof(int32_t) * pillar_capacity, stream));
-  MBV_CHECK_HIP(hipMemsetAsync(w.flags, 0, sizeof(uint32_t) * (n + 1), stream));
+  MBV_CHECK_HIP(mbv_fill_async(cell_to_pillar, 0xff, sizeof(int32_t) * cells64 * batch, stream));
+  MBV_CHECK_HIP(mbv_fill_async(num_points, 0, sizeof(int32_t) * pillar_capacity, stream));
+  MBV_CHECK_HIP(mbv_fill_async(w.flags, 0, sizeof(uint32_t) * (n + 1), stream));
 
   if (n > 0) {
     // 1. keys.  The y dimension of the grid walks the scans; x covers the longest scan.
@@ -448,7 +448,7 @@ extern "C" int mbv_voxelize(const float* points, int32_t point_dim, int64_t tota
                        cell_to_pillar);
     MBV_CHECK_LAUNCH();
   } else {
-    MBV_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (batch + 2), stream));
+    MBV_CHECK_HIP(mbv_fill_async(counts, 0, sizeof(int32_t) * (batch + 2), stream));
   }
   // row_start = exclusive scan of num_points (zero beyond V), K = row_start[V]
   int rc = launch_exclusive_scan(reinterpret_cast<const uint32_t*>(num_points),

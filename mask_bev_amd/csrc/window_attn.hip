@@ -491,8 +491,8 @@ extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const
     return MBV_ERR_BAD_ARG;
   const int D = C / heads;
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
-  MBV_CHECK_HIP(hipMemsetAsync(grad_table, 0, sizeof(float) * tsz * heads, stream));
-  MBV_CHECK_HIP(hipMemsetAsync(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
+  MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
+  MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
   return is_bf16 ? launch_bwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
                                             grad_qkv_bias, stream)
                  : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,

@@ -135,6 +135,12 @@ class GradientAllReducer:
                 p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
         self._reset()
 
+    def reduce_all(self):
+        """Average every gradient now (all buckets launched back to back, then awaited).  Used when the backward
+        ran inside a HIP graph (mask_bev_amd/graph.py), where the per-parameter hooks are switched off with
+        ``no_sync(True)`` because collectives must not be issued during capture / replay."""
+        self.finish()
+
     def no_sync(self, flag: bool = True):
         self._active = not flag
 

@@ -1,0 +1,98 @@
+"""HIP-graph training step.
+
+A MaskBEV training step at batch 4 issues ≈ 5 000 kernel launches; measured on MI355X the step costs ≈ 50 ms of
+fixed, launch-bound time plus only ≈ 6 ms of GPU work per scan (step time vs batch size: 55 / 61 / 72 / 101 ms at
+B = 1 / 2 / 4 / 8).  Everything downstream of the BEV pseudo-image has static shapes, so it is captured ONCE into
+a HIP graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) — Swin backbone, pixel decoder, masked-attention
+decoder, the sync-free loss (K8/K9/K10) and their whole backward — and replayed every step:
+
+    eager   K1 voxelise → K2 PFN → K3 scatter+LayerNorm          (pillar counts differ per batch: dynamic shapes)
+    replay  backbone → head → loss → backward                     (one graph launch)
+    eager   backward of K3 / K2 from the graph's d(loss)/d(pseudo-image), optimizer step
+
+The graph's inputs (pseudo-image, labels, GT masks) and outputs (loss, parameter gradients, gradient of the
+pseudo-image) live in static buffers.  This is the "HIP streams and graphs instead of a tracing compiler" part of
+the design: no kernel is changed, only how they are launched.
+
+Construct :class:`GraphedTrainStep` before running any eager backward of the module on the default stream (or run
+such eager code inside ``torch.cuda.stream(side)``): like PyTorch's whole-network capture, the warm-up iterations
+here run on a side stream because autograd state created on the legacy default stream cannot be captured.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .mask_bev_module import MaskBevModule
+
+
+class GraphedTrainStep:
+    """``step(batch) -> loss`` with the static-shape part of the step replayed from a HIP graph."""
+
+    def __init__(self, module: MaskBevModule, optimizer: torch.optim.Optimizer, example_batch, warmup_iters: int = 3,
+                 reducer=None):
+        self.m = module
+        self.opt = optimizer
+        self.reducer = reducer
+        scans, labels, masks, _ = module._unpack(example_batch)
+        dev = labels.device
+        head = module._panoptic_head._panoptic_head
+        self._overlap_prev = head.overlap_matcher
+        head.overlap_matcher = False          # stream fork/join bookkeeping is not needed inside a graph
+        with torch.no_grad(), module._autocast():
+            x = module._encoder(scans)
+        self.x_static = torch.zeros_like(x).requires_grad_()
+        self.labels = labels.clone()
+        self.masks = masks.clone()
+        self._graph_params = list(module._backbone.parameters()) + list(module._panoptic_head.parameters())
+        # warm-up on a side stream (allocator / library workspaces / autotuning settle before capture)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.x_static.data.copy_(x)
+            for _ in range(warmup_iters):
+                self._forward_backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self._graph_params:
+            p.grad = None
+        self.x_static.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss_static = self._forward_backward()
+        torch.cuda.synchronize()
+
+    def _forward_backward(self) -> torch.Tensor:
+        m = self.m
+        dt = m._compute_dtype
+        with torch.autocast('cuda', dtype=dt or torch.bfloat16, enabled=dt is not None, cache_enabled=False):
+            feats = m._backbone(self.x_static)
+            cls, masks, heights = m._panoptic_head(feats)
+        loss = m.loss(m.compute_loss(cls, masks, self.labels, self.masks, heights, None))
+        loss.backward()
+        return loss.detach()
+
+    def step(self, batch) -> torch.Tensor:
+        m = self.m
+        scans, labels, masks, _ = m._unpack(batch)
+        if self.reducer is not None:
+            self.reducer.sync_buffers()
+        with m._autocast():
+            x = m._encoder(scans)                          # eager: K1 → K2 → K3
+        self.x_static.data.copy_(x.detach())
+        if labels.data_ptr() != self.labels.data_ptr():
+            self.labels.copy_(labels)
+        if masks.data_ptr() != self.masks.data_ptr():
+            self.masks.copy_(masks)
+        self.graph.replay()                                # backbone, head, loss and their backward
+        x.backward(self.x_static.grad)                     # eager: backward of K3 / K2
+        if self.reducer is not None:
+            self.reducer.reduce_all()
+        self.opt.step()
+        for p in self.m._encoder.parameters():             # graph-owned gradients are overwritten by the replay
+            p.grad = None
+        return self.loss_static
+
+    def close(self):
+        self.m._panoptic_head._panoptic_head.overlap_matcher = self._overlap_prev

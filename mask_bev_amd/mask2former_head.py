@@ -290,6 +290,15 @@ class Mask2FormerHead(nn.Module):
             self._iota_cache[key] = t
         return t
 
+    def _const(self, device, values) -> torch.Tensor:
+        """Small f32 constants as cached device tensors (a host→device copy is not capturable in a HIP graph)."""
+        key = ('const', str(device), tuple(float(v) for v in values))
+        t = self._iota_cache.get(key)
+        if t is None:
+            t = torch.tensor(list(key[2]), dtype=torch.float32, device=device)
+            self._iota_cache[key] = t
+        return t
+
     def _draw_points(self, pts: PointSource, num_layers: int, batch: int, g: int):
         """All uniform points of one loss evaluation, drawn in the reference's order (per decoder output:
         B x rand(1, P, 2) for the matcher at mask2former_head.py:191, then rand(g, 3P, 2) and
@@ -373,10 +382,14 @@ class Mask2FormerHead(nn.Module):
             side = self._side_streams.get(dev)
             if side is None:
                 side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            # every buffer the side stream touches is allocated on the main stream and outlives the join below,
+            # so no record_stream bookkeeping is needed (it also upsets a later HIP-graph capture)
+            cost = cost.float().contiguous()
+            assigned = torch.empty((d * b, nq), dtype=torch.int32, device=dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                assigned = ops.hungarian(cost).view(d, b, nq)
-            cost.record_stream(side)
+                ops.hungarian(cost, out=assigned)
+            assigned = assigned.view(d, b, nq)
         else:
             assigned = ops.hungarian(cost).view(d, b, nq)                                        # (D, B, Q) i32
             matched = assigned >= 0
@@ -400,7 +413,6 @@ class Mask2FormerHead(nn.Module):
         pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
         if overlap:                                     # join the matcher
             main.wait_stream(side)
-            assigned.record_stream(main)
             matched = assigned >= 0
             safe = assigned.clamp(min=0).long()
         with torch.no_grad():
@@ -411,13 +423,13 @@ class Mask2FormerHead(nn.Module):
         # classification loss (class-weighted CE, avg_factor = sum of the class weights of the targets)
         labels = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, safe),
                              torch.full_like(safe, self.num_classes))
-        class_weight = cls.new_tensor(self.class_weight)
+        class_weight = self._const(dev, self.class_weight)
         ce = F.cross_entropy(cls.flatten(0, 2), labels.flatten(), weight=class_weight, reduction='none').view(d, -1)
         loss_cls = self.loss_cls_weight * ce.sum(1) / (class_weight[labels].view(d, -1).sum(1) + eps)
 
         # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image; reduce_mean over ranks (:388) is the
         # identity for equal per-rank batches (drop_last=True), see ddp.py
-        num_total_masks = cls.new_tensor([float(b * nq)])
+        num_total_masks = self._const(dev, [float(b * nq)])
         if self.world_size_fn is not None:
             num_total_masks = self.world_size_fn(num_total_masks)
         num_total_masks = num_total_masks.clamp(min=1.0)[0]

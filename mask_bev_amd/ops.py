@@ -694,14 +694,16 @@ def point_sample_packed(pm: PackedMasks, src_index: torch.Tensor, coords: torch.
 # K9 batched Hungarian assignment
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
-def hungarian(cost: torch.Tensor) -> torch.Tensor:
+def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cost (N, R, C) f32 on the device → (N, R) int32: column assigned to each row (min total cost), -1 for
     rows left out when R > C.  No host synchronisation (K9, include/maskbev_hip.h)."""
     lib = _lib.load()
     _need_gpu(cost)
     cost = cost.to(torch.float32).contiguous()
     n, r, c = cost.shape
-    out = torch.full((n, r), -1, dtype=torch.int32, device=cost.device)
+    if out is None:
+        out = torch.empty((n, r), dtype=torch.int32, device=cost.device)
+    out.fill_(-1)
     rc = lib.mbv_hungarian(_ptr(cost), n, r, c, _ptr(out), _stream())
     check(rc, 'mbv_hungarian')
     return out
