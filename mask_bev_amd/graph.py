@@ -31,7 +31,7 @@ class GraphedTrainStep:
     """``step(batch) -> loss`` with the static-shape part of the step replayed from a HIP graph."""
 
     def __init__(self, module: MaskBevModule, optimizer: torch.optim.Optimizer, example_batch, warmup_iters: int = 3,
-                 reducer=None):
+                 reducer=None, overlap_matcher: bool = True):
         self.m = module
         self.opt = optimizer
         self.reducer = reducer
@@ -39,7 +39,8 @@ class GraphedTrainStep:
         dev = labels.device
         head = module._panoptic_head._panoptic_head
         self._overlap_prev = head.overlap_matcher
-        head.overlap_matcher = False          # stream fork/join bookkeeping is not needed inside a graph
+        # the matcher's side-stream fork / join is captured as a parallel branch of the graph
+        head.overlap_matcher = overlap_matcher
         with torch.no_grad(), module._autocast():
             x = module._encoder(scans)
         self.x_static = torch.zeros_like(x).requires_grad_()
