@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-budget-s', type=float, default=90.0)
     ap.add_argument('--pool', type=int, default=2, help='distinct synthetic batches kept resident in HBM')
+    ap.add_argument('--no-arena', action='store_true', help='per-tensor parameters and torch.optim.AdamW')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the HIP graph')
     return ap.parse_args()
 
@@ -102,6 +103,8 @@ def main():
     model = MaskBevModule(**kw).to(device)
     model.train()
     model.log_scalars = False           # scalar logging is host-side bookkeeping, not the path
+    if not args.no_arena:
+        model.flatten_parameters()      # flat param / grad / bf16-shadow arena + single-launch AdamW (K11)
     opt = model.configure_optimizers()['optimizer']
     reducer = None
     if world > 1:
@@ -129,7 +132,7 @@ def main():
         if reducer is not None:
             reducer.finish()
         opt.step()
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=args.no_arena)
         return loss
 
     for i in range(args.warmup):

@@ -241,6 +241,28 @@ int mbv_select_uncertain_points(const float* logits, const float* coords, int64_
                                 float* out_coords, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K11 — parameter-arena kernels of the optimisation step.
+ * Replaces: torch.optim.AdamW / Adam built by MaskBevModule.configure_optimizers
+ * (mask_bev/mask_bev_module.py:131-166; update order of torch/optim/adamw.py `_single_tensor_adamw`) and the
+ * bias-gradient reductions of every nn.Linear on the path.
+ * mbv_adamw_step: ONE pass over a flat f32 arena of n parameters: param, grad, exp_avg, exp_avg_sq (all 16-byte
+ *   aligned, n elements).  step >= 1 is the 1-based update count (bias corrections are computed on the host in
+ *   f64).  decoupled=1 → AdamW (param *= 1 - lr*wd), 0 → Adam (grad += wd*param).  grad is multiplied by
+ *   grad_scale first (1/world_size after a SUM all-reduce).  shadow_bf16 (nullable, 8-byte aligned) receives the
+ *   updated parameters rounded to nearest-even bf16 — the copy the bf16 GEMMs read.  zero_grad=1 clears grad in
+ *   the same pass.
+ * mbv_refresh_shadow: shadow_bf16[i] = bf16(param[i]) (after load_state_dict / broadcast).
+ * mbv_colsum_accum: out[c] += sum_r g[r, c] for row-major g (rows, n), bf16 (is_bf16=1) or f32; f32 atomics.
+ */
+int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   float grad_scale, int32_t decoupled, int32_t zero_grad, void* stream);
+
+int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* stream);
+
+int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

@@ -1,0 +1,200 @@
+"""Parameter arena: every parameter, gradient and optimizer moment of a ``MaskBevModule`` laid out in four flat
+HBM buffers (288 GB of HBM3E makes the extra bf16 shadow free), so that the per-step bookkeeping of ≈ 700 tensors
+collapses into a handful of launches (K11, csrc/optim.hip):
+
+* ``param``   f32 — ``p.data`` of every parameter is a view into it (checkpoint keys and shapes unchanged);
+* ``grad``    f32 — ``p.grad`` is a view; the Linear layers accumulate their weight / bias gradients straight into
+                    it (``ops.linear``), autograd adds the rest in place; one fill clears it, and the gradient
+                    all-reduce runs over contiguous chunks of it with no bucket copies;
+* ``shadow``  bf16 — the copy of the weights the bf16 GEMMs read, written by the optimizer kernel itself instead
+                    of ≈ 450 per-layer cast kernels per step;
+* ``exp_avg``, ``exp_avg_sq`` f32 — Adam moments (owned by :class:`FlatAdam`).
+
+The arena is laid out in the reference's differential-lr groups — encoder, backbone, head
+(/root/reference: mask_bev/mask_bev_module.py:131-139) — each a contiguous segment, so an optimizer step is one
+``mbv_adamw_step`` launch per group (one launch in total when the groups share a learning rate).
+
+Build it after the module is on its GPU (``module.to(device)`` re-allocates parameters and would detach the views).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check
+
+_ALIGN = 64          # elements: every parameter starts on a 256-byte boundary
+
+
+def _round_up(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+class ParameterArena:
+    def __init__(self, segments: Iterable[Tuple[str, nn.Module]], shadow_dtype: Optional[torch.dtype] = torch.bfloat16):
+        segments = list(segments)
+        seen = set()
+        self.layout: List[Tuple[nn.Parameter, int]] = []          # (parameter, offset)
+        self.segments: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        device = None
+        for name, mod in segments:
+            start = off
+            for p in mod.parameters():
+                if id(p) in seen:
+                    continue
+                seen.add(id(p))
+                if p.dtype != torch.float32:
+                    raise TypeError('the arena holds f32 master parameters')
+                device = device or p.device
+                if p.device != device:
+                    raise ValueError('all parameters must live on one device')
+                self.layout.append((p, off))
+                off += _round_up(p.numel(), _ALIGN)
+            self.segments[name] = (start, off)
+        if device is None:
+            raise ValueError('no parameters')
+        self.numel = off
+        self.device = device
+        self.param = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.shadow = None
+        if shadow_dtype is not None:
+            if shadow_dtype != torch.bfloat16:
+                raise TypeError('the shadow copy is bf16')
+            self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        with torch.no_grad():
+            for p, o in self.layout:
+                n = p.numel()
+                view = self.param[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + n].view(p.shape)
+                p._mbv_arena = True                         # ops.linear accumulates dW / db into p.grad directly
+                if self.shadow is not None:
+                    p._mbv_shadow = self.shadow[o:o + n].view(p.shape)
+        self.refresh_shadow()
+
+    # -- views ------------------------------------------------------------------------------------------
+    def segment(self, name: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        a, b = self.segments[name]
+        return self.param[a:b], self.grad[a:b]
+
+    def span(self, names: Iterable[str]) -> Tuple[int, int]:
+        """Smallest contiguous range covering the named segments."""
+        ab = [self.segments[n] for n in names]
+        return min(a for a, _ in ab), max(b for _, b in ab)
+
+    # -- maintenance ------------------------------------------------------------------------------------
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow from the f32 parameters (after load_state_dict / broadcast / manual edits)."""
+        if self.shadow is None or self.numel == 0:
+            return
+        if self.device.type != 'cuda':
+            self.shadow.copy_(self.param)
+            return
+        lib = _lib.load()
+        check(lib.mbv_refresh_shadow(self.param.data_ptr(), self.shadow.data_ptr(), self.numel,
+                                     torch.cuda.current_stream(self.device).cuda_stream), 'mbv_refresh_shadow')
+
+    def zero_grad(self, names: Optional[Iterable[str]] = None):
+        if names is None:
+            self.grad.zero_()
+        else:
+            a, b = self.span(names)
+            self.grad[a:b].zero_()
+
+    def rebind(self):
+        """Re-attach ``p.grad`` views (an ``optimizer.zero_grad(set_to_none=True)`` drops them)."""
+        for p, o in self.layout:
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def intact(self) -> bool:
+        base = self.param.untyped_storage().data_ptr()
+        return all(p.data.untyped_storage().data_ptr() == base for p, _ in self.layout)
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam / AdamW over a :class:`ParameterArena`: one ``mbv_adamw_step`` launch per parameter group.
+
+    ``param_groups`` carry ``lr`` / ``weight_decay`` / ``betas`` / ``eps`` like torch's optimizers, so the
+    reference's schedulers (ReduceLROnPlateau, CosineAnnealingLR — mask_bev_module.py:153-159) drive it unchanged.
+    Adjacent groups with identical hyper-parameters are fused into one launch.  ``step()`` also refreshes the bf16
+    shadow and clears the gradient in the same pass (``zero_grad=True``)."""
+
+    def __init__(self, arena: ParameterArena, groups: List[dict], lr: float = 1e-3, betas=(0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 1e-2, decoupled: bool = True, zero_grad: bool = True):
+        self.arena = arena
+        self.decoupled = decoupled
+        self.zero_grad_in_step = zero_grad
+        self.grad_scale = 1.0
+        pgs = []
+        for g in groups:
+            a, b = arena.segments[g['segment']]
+            flat = nn.Parameter(arena.param[a:b], requires_grad=True)
+            flat.grad = arena.grad[a:b]
+            pg = {k: v for k, v in g.items() if k != 'segment'}
+            pg['params'] = [flat]
+            pg['segment'] = g['segment']
+            pgs.append(pg)
+        super().__init__(pgs, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.exp_avg = torch.zeros_like(arena.param)
+        self.exp_avg_sq = torch.zeros_like(arena.param)
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        ar = self.arena
+        if ar.device.type != 'cuda':
+            raise _lib.MaskBevHipError('FlatAdam runs on the MI355X only (mbv_adamw_step)')
+        lib = _lib.load()
+        self.steps += 1
+        stream = torch.cuda.current_stream(ar.device).cuda_stream
+        # fuse adjacent groups with the same hyper-parameters into one launch
+        runs: List[list] = []
+        for pg in self.param_groups:
+            a, b = ar.segments[pg['segment']]
+            hp = (float(pg['lr']), float(pg['betas'][0]), float(pg['betas'][1]), float(pg['eps']),
+                  float(pg['weight_decay']))
+            if runs and runs[-1][2] == hp and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b, hp])
+        for a, b, (lr, b1, b2, eps, wd) in runs:
+            if b == a:
+                continue
+            sh = 0 if ar.shadow is None else ar.shadow.data_ptr() + 2 * a
+            check(lib.mbv_adamw_step(ar.param.data_ptr() + 4 * a, ar.grad.data_ptr() + 4 * a,
+                                     self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, sh, b - a,
+                                     lr, b1, b2, eps, wd, self.steps, float(self.grad_scale),
+                                     1 if self.decoupled else 0, 1 if self.zero_grad_in_step else 0, stream),
+                  'mbv_adamw_step')
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients live in the arena: clear in place (``step()`` already did when ``zero_grad=True``)."""
+        if not self.zero_grad_in_step:
+            self.arena.zero_grad()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['flat_state'] = dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, steps=self.steps)
+        return sd
+
+    def load_state_dict(self, sd):
+        flat = sd.get('flat_state')
+        if flat is not None:
+            self.exp_avg.copy_(flat['exp_avg'])
+            self.exp_avg_sq.copy_(flat['exp_avg_sq'])
+            self.steps = int(flat['steps'])
+        for pg, saved in zip(self.param_groups, sd.get('param_groups', [])):
+            for k in ('lr', 'betas', 'eps', 'weight_decay'):
+                if k in saved:
+                    pg[k] = saved[k]

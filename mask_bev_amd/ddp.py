@@ -141,6 +141,32 @@ class GradientAllReducer:
         ``no_sync(True)`` because collectives must not be issued during capture / replay."""
         self.finish()
 
+    def start_arena(self, arena, names, chunk_mb: float = 256.0) -> list:
+        """Launch SUM all-reduces over the named arena segments' gradients (arena.py) in contiguous chunks — no
+        bucket copies; asynchronous on RCCL's stream, ordered after the work already queued on this stream."""
+        handles = []
+        step = max(1, int(chunk_mb * 1024 * 1024) // 4)
+        for name in names:
+            a, b = arena.segments[name]
+            for lo in range(a, b, step):
+                handles.append(dist.all_reduce(arena.grad[lo:min(b, lo + step)], op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
+        return handles
+
+    def finish_arena(self, arena, handles: list, optimizer=None):
+        """Wait for :meth:`start_arena`; the mean is applied by the optimizer kernel (``grad_scale = 1/world``)
+        when it supports it, else by one in-place division."""
+        for h in handles:
+            h.wait()
+        if optimizer is not None and hasattr(optimizer, 'grad_scale'):
+            optimizer.grad_scale = 1.0 / self.world
+        else:
+            arena.grad.div_(self.world)
+
+    def reduce_arena(self, arena, optimizer=None, order=('head', 'backbone', 'encoder')):
+        """Segments are reduced in the order their gradients complete (head first, encoder last)."""
+        self.finish_arena(arena, self.start_arena(arena, order), optimizer)
+
     def no_sync(self, flag: bool = True):
         self._active = not flag
 

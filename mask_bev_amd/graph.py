@@ -10,6 +10,10 @@ decoder, the sync-free loss (K8/K9/K10) and their whole backward — and replaye
     replay  backbone → head → loss → backward                     (one graph launch)
     eager   backward of K3 / K2 from the graph's d(loss)/d(pseudo-image), optimizer step
 
+With a parameter arena (``module.flatten_parameters()``, arena.py) the graph accumulates into the arena's static
+gradient buffer, the optimizer step is one K11 launch that also clears the gradient and refreshes the bf16 weight
+shadow, and the data-parallel all-reduce runs over contiguous arena chunks.
+
 The graph's inputs (pseudo-image, labels, GT masks) and outputs (loss, parameter gradients, gradient of the
 pseudo-image) live in static buffers.  This is the "HIP streams and graphs instead of a tracing compiler" part of
 the design: no kernel is changed, only how they are launched.
@@ -56,8 +60,13 @@ class GraphedTrainStep:
                 self._forward_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        for p in self._graph_params:
-            p.grad = None
+        self.arena = getattr(module, '_arena', None)
+        if self.arena is not None:
+            # gradients are static arena views: accumulated in place by the graph, cleared by the optimizer kernel
+            self.arena.zero_grad()
+        else:
+            for p in self._graph_params:
+                p.grad = None
         self.x_static.grad = None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -87,12 +96,21 @@ class GraphedTrainStep:
         if masks.data_ptr() != self.masks.data_ptr():
             self.masks.copy_(masks)
         self.graph.replay()                                # backbone, head, loss and their backward
+        handles = None
+        if self.reducer is not None and self.arena is not None:
+            handles = self.reducer.start_arena(self.arena, ('head', 'backbone'))   # overlaps the encoder backward
         x.backward(self.x_static.grad)                     # eager: backward of K3 / K2
-        if self.reducer is not None:
+        if handles is not None:
+            handles += self.reducer.start_arena(self.arena, ('encoder',))
+            self.reducer.finish_arena(self.arena, handles, self.opt)
+        elif self.reducer is not None:
             self.reducer.reduce_all()
         self.opt.step()
-        for p in self.m._encoder.parameters():             # graph-owned gradients are overwritten by the replay
-            p.grad = None
+        if self.arena is None:
+            for p in self.m._encoder.parameters():         # graph-owned gradients are overwritten by the replay
+                p.grad = None
+        elif not getattr(self.opt, 'zero_grad_in_step', False):
+            self.arena.zero_grad()
         return self.loss_static
 
     def close(self):

@@ -159,9 +159,9 @@ class MultiheadAttention(nn.Module):
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         q = query + query_pos if query_pos is not None else query
         k = key + key_pos if key_pos is not None else key
-        q = ops.linear(q, w[:e], bias[:e])
-        k = ops.linear(k, w[e:2 * e], bias[e:2 * e])
-        v = ops.linear(value, w[2 * e:], bias[2 * e:])
+        q = ops.linear(q, w, bias, rows=(0, e))
+        k = ops.linear(k, w, bias, rows=(e, 2 * e))
+        v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
         o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
         return query + self.attn.out_proj(o)
 

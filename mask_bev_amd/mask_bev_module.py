@@ -86,6 +86,7 @@ class MaskBevModule(_Base):
         self._differential_lr = differential_lr
         self._differential_lr_scaling = differential_lr_scaling
         self._predict_heights = predict_heights
+        self._arena = None
         # build extension (not a reference key): arithmetic type of the GEMM-shaped layers
         self._compute_dtype = {'fp32': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[
             kwargs.get('compute_dtype', 'fp32')]
@@ -110,6 +111,7 @@ class MaskBevModule(_Base):
         # they are off the forward/backward path and torchmetrics is not available here.
         self._train_metric_per_layer: Dict[int, Any] = {}
         self._val_metric_per_layer: Dict[int, Any] = {}
+        self.register_load_state_dict_post_hook(MaskBevModule._refresh_arena_after_load)
         if pl is not None:  # pragma: no cover
             self.save_hyperparameters()
         else:
@@ -133,7 +135,35 @@ class MaskBevModule(_Base):
             raise ValueError(f'Could not load checkpoint at path {checkpoint}')
         return MaskBevModule(**config)
 
+    @staticmethod
+    def _refresh_arena_after_load(module, incompatible_keys):
+        if getattr(module, '_arena', None) is not None:
+            module._arena.refresh_shadow()
+
+    def flatten_parameters(self):
+        """Build extension: move parameters / gradients into one :class:`~mask_bev_amd.arena.ParameterArena`
+        (call after ``.to(device)``).  ``configure_optimizers`` then returns the single-launch ``FlatAdam`` for
+        Adam / AdamW; checkpoint keys and shapes are unchanged."""
+        from .arena import ParameterArena
+        self._arena = ParameterArena([('encoder', self._encoder), ('backbone', self._backbone),
+                                      ('head', self._panoptic_head)],
+                                     shadow_dtype=torch.bfloat16 if self._compute_dtype == torch.bfloat16 else None)
+        return self._arena
+
+    def _flat_optimizer(self):
+        from .arena import FlatAdam
+        scale = self._differential_lr_scaling if self._differential_lr else 1.0
+        groups = [dict(segment='encoder', lr=self._lr * scale), dict(segment='backbone', lr=self._lr * scale),
+                  dict(segment='head', lr=self._lr)]
+        if self._optimiser_type == OptimizerType.ADAM_W:      # torch defaults: betas (0.9, 0.999), eps 1e-8
+            return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=True)
+        return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=False)
+
     def configure_optimizers(self):
+        if getattr(self, '_arena', None) is not None and self._optimiser_type in (OptimizerType.ADAM,
+                                                                                  OptimizerType.ADAM_W):
+            optimizer = self._flat_optimizer()
+            return self._with_scheduler(optimizer)
         if self._differential_lr:
             grouped = [
                 {'params': self._encoder.parameters(), 'lr': self._lr * self._differential_lr_scaling},
@@ -151,6 +181,9 @@ class MaskBevModule(_Base):
             optimizer = AdamW(grouped, lr=self._lr, weight_decay=self._weight_decay, amsgrad=False)
         else:  # LAMB needs torch_optimizer, which is not part of this path
             raise NotImplementedError(str(self._optimiser_type))
+        return self._with_scheduler(optimizer)
+
+    def _with_scheduler(self, optimizer):
         if self._lr_schedulers_type == LrSchedulerType.REDUCE_ON_PLATEAU:
             lr_scheduler = ReduceLROnPlateau(optimizer, patience=10)
         elif self._lr_schedulers_type == LrSchedulerType.COSINE:

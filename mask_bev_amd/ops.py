@@ -460,25 +460,71 @@ def _wgrad(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return gw
 
 
+def _compute_copy(p: Optional[torch.Tensor], dt: torch.dtype) -> Optional[torch.Tensor]:
+    """The parameter in the compute dtype: the arena's bf16 shadow when there is one (arena.py), else a cast."""
+    if p is None or p.dtype == dt:
+        return p
+    sh = getattr(p, '_mbv_shadow', None)
+    if sh is not None and sh.dtype == dt:
+        return sh
+    return p.to(dt)
+
+
+def _fire_grad_hooks(p: torch.Tensor):
+    """Gradients accumulated outside autograd still announce themselves to post-accumulate hooks (ddp.py)."""
+    hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+    if hooks:
+        for h in list(hooks.values()):
+            h(p)
+
+
+def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
+    """out (N,) f32 += column sums of g2 (T, N) (bf16 or f32) — the bias gradient, in one launch."""
+    lib = _lib.load()
+    _need_gpu(g2, out)
+    if g2.dtype not in (torch.float32, torch.bfloat16) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise MaskBevHipError('colsum_accum: g2 must be f32/bf16 and out contiguous f32')
+    g2 = g2.contiguous()
+    check(lib.mbv_colsum_accum(_ptr(g2), 1 if g2.dtype == torch.bfloat16 else 0, g2.shape[0], g2.shape[1], _ptr(out),
+                               _stream()), 'mbv_colsum_accum')
+
+
+def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor):
+    """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add)."""
+    t = g2.shape[0]
+    s = _wgrad_splits(t)
+    od = {} if g2.dtype == torch.float32 else dict(out_dtype=torch.float32)
+    if s == 1:
+        torch.addmm(acc, g2.t(), x2, out=acc, **od)
+        return
+    c = t // s
+    part = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1), **od)
+    if s * c < t:
+        torch.addmm(acc, g2[s * c:].t(), x2[s * c:], out=acc, **od)
+    acc.add_(part.sum(0))
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, rows):
         if torch.is_autocast_enabled('cuda'):
             dt = torch.get_autocast_dtype('cuda')
-            x, w = x.to(dt), weight.to(dt)
-            b = None if bias is None else bias.to(dt)
+            x, w, b = x.to(dt), _compute_copy(weight, dt), _compute_copy(bias, dt)
         else:
             w, b = weight, bias
+        if rows is not None:
+            w = w[rows[0]:rows[1]]
+            b = None if b is None else b[rows[0]:rows[1]]
         with torch.autocast('cuda', enabled=False):
             y = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        ctx.param_dtype = weight.dtype
+        ctx.weight, ctx.bias, ctx.rows = weight, bias, rows
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        weight, bias, rows = ctx.weight, ctx.bias, ctx.rows
         gy = gy.to(x.dtype)
         g2 = gy.reshape(-1, gy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
@@ -486,15 +532,35 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g2.mm(w).view_as(x)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(g2, x2).to(ctx.param_dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0, dtype=torch.float32).to(ctx.param_dtype)
-        return gx, gw, gb
+            if getattr(weight, '_mbv_arena', False) and weight.grad is not None and weight.grad.dtype == torch.float32:
+                acc = weight.grad if rows is None else weight.grad[rows[0]:rows[1]]
+                _wgrad_into(acc, g2, x2)                    # straight into the arena gradient
+                _fire_grad_hooks(weight)
+            elif rows is None:
+                gw = _wgrad(g2, x2).to(weight.dtype)
+            else:
+                gw = torch.zeros_like(weight)
+                gw[rows[0]:rows[1]] = _wgrad(g2, x2)
+        if bias is not None and ctx.needs_input_grad[2]:
+            if getattr(bias, '_mbv_arena', False) and bias.grad is not None and bias.grad.dtype == torch.float32:
+                colsum_accum(g2, bias.grad if rows is None else bias.grad[rows[0]:rows[1]])
+                _fire_grad_hooks(bias)
+            elif rows is None:
+                gb = g2.sum(0, dtype=torch.float32).to(bias.dtype)
+            else:
+                gb = torch.zeros_like(bias)
+                gb[rows[0]:rows[1]] = g2.sum(0, dtype=torch.float32)
+        return gx, gw, gb, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x W^T + b on the library GEMM (hipBLASLt) honouring autocast, with the split-K weight gradient."""
-    return _Linear.apply(x, weight, bias)
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           rows: Optional[tuple] = None) -> torch.Tensor:
+    """y = x W^T + b on the library GEMM (hipBLASLt) honouring autocast, with the split-K weight gradient.
+    ``rows=(r0, r1)`` uses rows r0:r1 of the parameters (the q / k / v blocks of a packed ``in_proj_weight``)
+    without materialising slices or zero-padded slice gradients.  Parameters that live in a
+    :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
+    direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
+    return _Linear.apply(x, weight, bias, rows)
 
 
 # --------------------------------------------------------------------------------------

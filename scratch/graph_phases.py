@@ -6,6 +6,8 @@ from mask_bev_amd.graph import GraphedTrainStep
 dev = torch.device('cuda:0')
 kw = synthetic.module_kwargs('semantic_kitti_512', 4, compute_dtype='bf16')
 m = MaskBevModule(**kw).to(dev).train(); m.log_scalars = False
+import os
+if os.environ.get("ARENA","1")=="1": m.flatten_parameters()
 opt = m.configure_optimizers()['optimizer']
 pool = [synthetic.make_batch('semantic_kitti_512', 4, 0, s, dev) for s in range(2)]
 g = GraphedTrainStep(m, opt, pool[0])

@@ -1,0 +1,160 @@
+"""K11 parameter arena: the flat AdamW / Adam kernel vs torch.optim (f32 rounding), the bias-gradient column sum,
+the direct weight-gradient accumulation of ops.linear, and the whole module trained through the arena."""
+import pytest
+import torch
+
+from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(37, 19)
+        self.b = torch.nn.Linear(19, 5)
+        self.n = torch.nn.LayerNorm(19)
+
+
+@pytest.mark.parametrize('decoupled', [True, False])
+def test_flat_adam_matches_torch(device, decoupled):
+    from mask_bev_amd.arena import FlatAdam, ParameterArena
+    torch.manual_seed(1)
+    ref = _Toy().to(device)
+    mine = _Toy().to(device)
+    mine.load_state_dict(ref.state_dict())
+    arena = ParameterArena([('encoder', mine.a), ('backbone', mine.n), ('head', mine.b)])
+    assert arena.intact()
+    groups = [dict(segment='encoder', lr=3e-3), dict(segment='backbone', lr=3e-3), dict(segment='head', lr=1e-2)]
+    opt = FlatAdam(arena, groups, lr=3e-3, weight_decay=0.05, decoupled=decoupled)
+    cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+    topt = cls([dict(params=list(ref.a.parameters()) + list(ref.n.parameters()), lr=3e-3),
+                dict(params=ref.b.parameters(), lr=1e-2)], lr=3e-3, weight_decay=0.05)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for it in range(6):
+        for (n1, p), (n2, q) in zip(ref.named_parameters(), mine.named_parameters()):
+            gr = torch.randn(p.shape, generator=g).to(device)
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        topt.step()
+        opt.step()
+        for (n1, p), (n2, q) in zip(ref.named_parameters(), mine.named_parameters()):
+            assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (it, n1, (p - q).abs().max())
+            assert float(q.grad.abs().max()) == 0.0                     # cleared by the same pass
+            assert torch.equal(q._mbv_shadow, q.detach().to(torch.bfloat16))   # shadow = RNE bf16 of the new value
+
+
+@pytest.mark.parametrize('T,N,dt', [(400, 256, torch.bfloat16), (65536, 384, torch.bfloat16), (1000, 2, torch.float32),
+                                    (777, 131, torch.bfloat16), (5000, 1024, torch.float32)])
+def test_colsum_accum(device, T, N, dt):
+    from mask_bev_amd import ops
+    g = torch.randn(T, N, device=device).to(dt)
+    out = torch.randn(N, device=device)
+    want = out.double() + g.double().sum(0)
+    ops.colsum_accum(g, out)
+    assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-3 * (T ** 0.5) * 1e-2 + 1e-4)
+
+
+@pytest.mark.parametrize('dt', [None, torch.bfloat16])
+def test_linear_direct_grad_matches_autograd(device, dt):
+    """Same Linear stack with and without the arena: outputs and parameter gradients agree."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.arena import ParameterArena
+    torch.manual_seed(2)
+    ref, mine = _Toy().to(device), _Toy().to(device)
+    mine.load_state_dict(ref.state_dict())
+    arena = ParameterArena([('all', mine)], shadow_dtype=torch.bfloat16)
+
+    def run(m, x):
+        with torch.autocast('cuda', dtype=dt or torch.bfloat16, enabled=dt is not None):
+            h = ops.linear(x, m.a.weight, m.a.bias)
+            h = m.n(h.float())
+            y = ops.linear(h, m.b.weight, m.b.bias, rows=(1, 4)) + ops.linear(h, m.b.weight, m.b.bias, rows=(0, 3))
+        return y
+
+    x = torch.randn(9000, 37, device=device)          # > 8192 rows: exercises the split-K weight gradient
+    y0 = run(ref, x)
+    y0.float().square().mean().backward()
+    y1 = run(mine, x)
+    y1.float().square().mean().backward()
+    tol = 1e-5 if dt is None else 3e-2
+    assert torch.allclose(y0.float(), y1.float(), rtol=tol, atol=tol)
+    for (n, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert q.grad.data_ptr() >= arena.grad.data_ptr()             # still the arena view
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((p.grad - q.grad).abs().max()) <= tol * scale, n
+
+
+def test_module_trains_through_arena(device):
+    """flatten_parameters(): same state_dict keys, same loss as the per-tensor module, parameters move, shadows and
+    arena stay intact over optimizer steps; load_state_dict refreshes the shadow."""
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    torch.manual_seed(0)
+    kw = tiny_kwargs(nx=96, ny=96, q=8)
+    kw['compute_dtype'] = 'bf16'
+    kw['optimiser_type'] = 'adam_w'
+    kw['lr'] = 5e-4
+    m = MaskBevModule(**kw).to(device).train()
+    m.log_scalars = False
+    m._panoptic_head._panoptic_head.num_points = 2000
+    keys_before = list(m.state_dict().keys())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    arena = m.flatten_parameters()
+    assert list(m.state_dict().keys()) == keys_before
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    opt = m.configure_optimizers()['optimizer']
+    scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
+    labels, gt = random_gt(kw, 2, 3, seed=10)
+    batch = (scans, (labels.to(device), gt.to(device)))
+    losses = []
+    for it in range(4):
+        loss = m.training_step(batch, it)
+        loss.backward()
+        assert float(arena.grad.abs().sum()) > 0
+        opt.step()
+        opt.zero_grad()
+        assert float(arena.grad.abs().max()) == 0.0
+        losses.append(float(loss))
+    assert arena.intact()
+    assert all(l == l and abs(l) < 1e6 for l in losses)
+    assert min(losses[1:]) < losses[0]
+    w = m._backbone._backbone.stages[0].blocks[0].ffn.layers[0][0].weight
+    assert not torch.equal(w, sd['_backbone._backbone.stages.0.blocks.0.ffn.layers.0.0.weight'])
+    assert torch.equal(w._mbv_shadow, w.detach().to(torch.bfloat16))
+    m.load_state_dict(sd)
+    assert torch.equal(w._mbv_shadow, sd['_backbone._backbone.stages.0.blocks.0.ffn.layers.0.0.weight'].to(torch.bfloat16))
+
+
+def test_graph_step_with_arena(device):
+    """HIP-graph step over the arena: gradients accumulate into the static arena buffer inside the replay, the K11
+    step clears them, and the loss goes down over a few steps on a fixed batch."""
+    from mask_bev_amd.graph import GraphedTrainStep
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    torch.manual_seed(0)
+    kw = tiny_kwargs(nx=96, ny=96, q=8)
+    kw['compute_dtype'] = 'bf16'
+    kw['lr'] = 5e-4
+    m = MaskBevModule(**kw).to(device).train()
+    m.log_scalars = False
+    m._panoptic_head._panoptic_head.num_points = 2000
+    arena = m.flatten_parameters()
+    opt = m.configure_optimizers()['optimizer']
+    scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
+    labels, gt = random_gt(kw, 2, 3, seed=10)
+    batch = (scans, (labels.to(device), gt.to(device)))
+    g = GraphedTrainStep(m, opt, batch)
+    p0 = arena.param.clone()
+    losses = []
+    for it in range(6):
+        losses.append(float(g.step(batch)))
+        assert float(arena.grad.abs().max()) == 0.0
+    torch.cuda.synchronize()
+    assert arena.intact()
+    assert all(l == l for l in losses), losses
+    assert min(losses[2:]) < losses[0], losses
+    a, b = arena.segments['encoder']
+    assert float((arena.param[a:b] - p0[a:b]).abs().max()) > 0          # encoder (eager) parameters move
+    a, b = arena.segments['head']
+    assert float((arena.param[a:b] - p0[a:b]).abs().max()) > 0          # graph-owned parameters move
+    g.close()
