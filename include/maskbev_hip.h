@@ -262,6 +262,10 @@ int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* s
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
 
+/* Weight gradient of a Linear applied to few tokens (the decoder's B*Q query rows), exact f32:
+ * acc (O, I) += g^T x with g (T, O), x (T, I) row-major f32; f32 MFMA, f32 atomics into acc. */
+int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from

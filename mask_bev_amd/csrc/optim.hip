@@ -161,6 +161,56 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long ro
   }
 }
 
+// Small-token weight gradient in exact f32: acc (O, I) += g^T x for g (T, O), x (T, I), T = the decoder's B*Q rows.
+// The library's f32 GEMM heuristics pick one 256x256 macro-tile for this shape (measured 98 us per call); here one
+// wave owns a 32 x 32 output tile and a slice of T, multiplies with v_mfma_f32_32x32x2_f32 straight from global
+// memory (for a fixed t the 32 o's / i's of a tile are one contiguous 128 B line, and both operands stay in L2),
+// and adds its tile into the arena gradient with f32 atomics.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g, const float* __restrict__ x, int T,
+                                                     int O, int I, int tiles_i, int ntiles, int rows_per_slice,
+                                                     float* __restrict__ acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = wg % ntiles, slice = wg / ntiles;
+  const int o0 = (tile / tiles_i) * 32, i0 = (tile % tiles_i) * 32;
+  const int t0 = slice * rows_per_slice;
+  const int t1 = t0 + rows_per_slice < T ? t0 + rows_per_slice : T;
+  if (t0 >= T) return;
+  const bool ov = o0 + r < O, iv = i0 + r < I;
+  const float* gp = g + (o0 + r);
+  const float* xp = x + (i0 + r);
+  f32x16_t c;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) c[k] = 0.f;
+  int tb = t0;                            // wave-uniform row base; half h of the wave reads row tb + 2u + h
+  for (; tb + 8 <= t1; tb += 8) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = ov ? gp[(long)(tb + 2 * u + h) * O] : 0.f;
+      b[u] = iv ? xp[(long)(tb + 2 * u + h) * I] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], c, 0, 0, 0);
+  }
+  for (; tb < t1; tb += 2) {              // out-of-range rows contribute 0
+    const int t = tb + h;
+    const bool tv = t < t1;
+    const float a = (ov && tv) ? gp[(long)t * O] : 0.f;
+    const float b = (iv && tv) ? xp[(long)t * I] : 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  if (iv) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int o = o0 + (k & 3) + 8 * (k >> 2) + 4 * h;
+      if (o < O) atomicAdd(acc + (long)o * I + i0 + r, c[k]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
@@ -218,6 +268,26 @@ extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, in
   else
     hipLaunchKernelGGL(k_colsum<float>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(g), (long)rows, n, out, vec, W);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc,
+                                   void* stream) {
+  if (T < 0 || O <= 0 || I <= 0 || !g || !x || !acc) return MBV_ERR_BAD_ARG;
+  if (T == 0) return MBV_OK;
+  const int tiles_o = (O + 31) / 32, tiles_i = (I + 31) / 32;
+  const int ntiles = tiles_o * tiles_i;
+  int slices = (1024 + ntiles - 1) / ntiles;            // ≈ 1024 waves = 4 per CU
+  const int max_slices = (T + 31) / 32;                 // at least 32 rows per slice
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  int rows_per_slice = (T + slices - 1) / slices;
+  rows_per_slice = (rows_per_slice + 1) & ~1;           // even: the two k-halves of the MFMA stay aligned
+  slices = (T + rows_per_slice - 1) / rows_per_slice;
+  const long waves = (long)ntiles * slices;
+  hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, x, T, O,
+                     I, tiles_i, ntiles, rows_per_slice, acc);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import ConvGN, FFN, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
+from .layers import ConvGN, FFN, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
 
 
 # --------------------------------------------------------------------------------------
@@ -137,8 +137,14 @@ class _DecoderLayer(nn.Module):
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
         self.norms = nn.ModuleList([nn.LayerNorm(embed_dims) for _ in range(3)])
 
-    def forward(self, query, memory, query_pos, memory_pos, blocked):
-        q = self.norms[0](self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked))
+    def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None):
+        """``memory_key`` = memory + memory_pos when the caller has it (it is the same for every layer that reads
+        this level)."""
+        if memory_key is None:
+            q = self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked)
+        else:
+            q = self.cross_attn(query, memory_key, memory, query_pos, None, blocked)
+        q = self.norms[0](q)
         q = self.norms[1](self.self_attn(q, q, q, query_pos, query_pos, None))
         return self.norms[2](self.ffn(q))
 
@@ -215,10 +221,10 @@ class Mask2FormerHead(nn.Module):
         self.query_feat = nn.Embedding(num_queries, feat_channels)
         self.level_embed = nn.Embedding(num_transformer_feat_level, feat_channels)
         self.height_embed = None
-        self.cls_embed = nn.Linear(feat_channels, self.num_classes + 1)
-        self.mask_embed = nn.Sequential(nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
-                                        nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
-                                        nn.Linear(feat_channels, out_channels))
+        self.cls_embed = Linear(feat_channels, self.num_classes + 1)
+        self.mask_embed = nn.Sequential(Linear(feat_channels, feat_channels), nn.ReLU(),
+                                        Linear(feat_channels, feat_channels), nn.ReLU(),
+                                        Linear(feat_channels, out_channels))
         self.num_points = train_cfg.get('num_points', 12544)
         self.oversample_ratio = train_cfg.get('oversample_ratio', 3.0)
         self.importance_sample_ratio = train_cfg.get('importance_sample_ratio', 0.75)
@@ -262,6 +268,7 @@ class Mask2FormerHead(nn.Module):
             dec_in.append(m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1))
             dec_pos.append(sine_positional_encoding(h, w, self.decoder_embed_dims // 2, m.device)
                            .flatten(2).transpose(1, 2))
+        dec_key = [a + b for a, b in zip(dec_in, dec_pos)]     # key = memory + pos, shared by the 3 layers of a level
         query_feat = self.query_feat.weight.unsqueeze(0).expand(bs, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(bs, -1, -1)
         cls_list, mask_list = [], []
@@ -271,7 +278,7 @@ class Mask2FormerHead(nn.Module):
         nl = self.num_transformer_feat_level
         for i, layer in enumerate(self.transformer_decoder.layers):
             lvl = i % nl
-            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked)
+            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl])
             cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features,
                                                               memories[(i + 1) % nl].shape[-2:])
             cls_list.append(cls_pred)

@@ -492,6 +492,13 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
 def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor):
     """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add)."""
     t = g2.shape[0]
+    if (g2.dtype == torch.float32 and x2.dtype == torch.float32 and t <= _SMALL_F32_ROWS and g2.is_cuda
+            and acc.is_contiguous()):
+        lib = _lib.load()
+        g2, x2 = g2.contiguous(), x2.contiguous()
+        check(lib.mbv_wgrad_small_f32(_ptr(g2), _ptr(x2), t, g2.shape[1], x2.shape[1], _ptr(acc), _stream()),
+              'mbv_wgrad_small_f32')
+        return
     s = _wgrad_splits(t)
     od = {} if g2.dtype == torch.float32 else dict(out_dtype=torch.float32)
     if s == 1:
@@ -504,10 +511,18 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor):
     acc.add_(part.sum(0))
 
 
+# Under autocast, f32 activations with at most this many rows (the decoder's B*Q query tokens) are multiplied in
+# f32: the GEMM is microseconds either way, and the five cast kernels per layer and direction are not.
+_SMALL_F32_ROWS = 2048
+_SMALL_F32_MACS = 1 << 30          # … and only while the f32 GEMM itself stays in the microseconds
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, rows):
-        if torch.is_autocast_enabled('cuda'):
+        if torch.is_autocast_enabled('cuda') and not (
+                x.dtype == torch.float32 and weight.dtype == torch.float32
+                and x.numel() <= _SMALL_F32_ROWS * x.shape[-1] and x.numel() * weight.shape[0] <= _SMALL_F32_MACS):
             dt = torch.get_autocast_dtype('cuda')
             x, w, b = x.to(dt), _compute_copy(weight, dt), _compute_copy(bias, dt)
         else:
@@ -571,10 +586,11 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, q, k, v, blocked, num_heads):
         lib = _lib.load()
         _need_gpu(q, k, v, blocked)
-        dt = q.dtype
+        dt = k.dtype                     # the (large) key / value side decides; q (B*Q rows) is cast to it
         if dt not in (torch.float32, torch.bfloat16):
             raise MaskBevHipError(f'attention supports f32 and bf16, got {dt}')
-        q, k, v = q.contiguous(), k.to(dt).contiguous(), v.to(dt).contiguous()
+        ctx.in_dtypes = (q.dtype, k.dtype, v.dtype)
+        q, k, v = q.to(dt).contiguous(), k.contiguous(), v.to(dt).contiguous()
         b, nq, e = q.shape
         nl = k.shape[1]
         d = e // num_heads
@@ -607,7 +623,8 @@ class _Attention(torch.autograd.Function):
                               1 if q.dtype == torch.bfloat16 else 0, b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
                               _ptr(g_v), _stream())
         check(rc, 'mbv_attn_bwd')
-        return g_q.to(q.dtype), g_k.to(q.dtype), g_v.to(q.dtype), None, None
+        dq, dk, dv = ctx.in_dtypes
+        return g_q.to(dq), g_k.to(dk), g_v.to(dv), None, None
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, blocked: Optional[torch.Tensor],

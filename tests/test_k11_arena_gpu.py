@@ -158,3 +158,18 @@ def test_graph_step_with_arena(device):
     a, b = arena.segments['head']
     assert float((arena.param[a:b] - p0[a:b]).abs().max()) > 0          # graph-owned parameters move
     g.close()
+
+
+@pytest.mark.parametrize('T,O,I', [(400, 256, 256), (400, 2048, 256), (400, 2, 256), (801, 256, 2048), (37, 19, 5),
+                                   (2048, 96, 130)])
+def test_wgrad_small_f32(device, T, O, I):
+    from mask_bev_amd import _lib
+    lib = _lib.load()
+    g = torch.randn(T, O, device=device)
+    x = torch.randn(T, I, device=device)
+    acc = torch.randn(O, I, device=device)
+    want = acc.double() + g.double().t() @ x.double()
+    rc = lib.mbv_wgrad_small_f32(g.data_ptr(), x.data_ptr(), T, O, I, acc.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.allclose(acc.double(), want, rtol=1e-5, atol=2e-5 * T ** 0.5)
