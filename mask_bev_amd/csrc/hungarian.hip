@@ -39,98 +39,167 @@ __device__ __forceinline__ unsigned long long orderable(double x) {
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+__device__ __forceinline__ double readlane_f64(double x, int src_lane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)b, src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // rows <= cols.  cost: (rows, cols) row-major f32.  row_to_col: (rows) i32.
+//
+// State lives in registers of the lane that owns a column (columns lane + 1 and lane + 65, 1-based): its dual v,
+// the row matched to it (p), THAT ROW's dual u (a row is matched to at most one column, so its u can travel with
+// the column), the search's minv / way / used.  The search column j0 is wave-uniform, so everything the classic
+// formulation reads through arrays (p[j0], u[p[j0]], way[j]) is one v_readlane from the owner lane; LDS holds
+// only the read-only cost matrix and there is no barrier inside the search.
+//
+// Start: the duals of the textbook row / column reduction (u_i = min_j a_ij, v_j = min_i (a_ij - u_i)) and the
+// greedy matching on their zero reduced costs — a feasible dual with complementary slackness, so the
+// shortest-augmenting-path search only has to run for the rows the greedy pass left unmatched and still ends in
+// an optimal assignment (the same one as scipy's when the optimum is unique).
 __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost_all, int rows, int cols,
                                                   int transposed, int32_t* __restrict__ out_all, int out_len) {
-  __shared__ double u[kMaxDim + 1];
-  __shared__ int p[kMaxDim + 1];      // p[j] = row matched to column j (1-based), 0 = free
-  __shared__ int way[kMaxDim + 1];
+  __shared__ double u_row[kMaxDim];
+  __shared__ int row_matched[kMaxDim];
   __shared__ float a_lds[kMaxDim * (kMaxDim + 1)];   // the whole cost matrix: every search step reads one row
   const int lane = threadIdx.x;
   const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
   int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
-  // element (i, j) of the rows<=cols problem; `transposed` means the caller's matrix is (cols x rows)
   constexpr int LD = kMaxDim + 1;
   for (int e = lane; e < rows * cols; e += 64) {
     int i, j;
     if (transposed) { j = e / rows; i = e - j * rows; } else { i = e / cols; j = e - i * cols; }
     a_lds[i * LD + j] = cost[e];
   }
-  auto a = [&](int i, int j) -> double { return (double)a_lds[i * LD + j]; };
-  // this lane owns columns j = lane + 1 and lane + 65 (1-based)
+  __syncthreads();
   const int jA = lane + 1, jB = lane + 65;
   const bool hasA = jA <= cols, hasB = jB <= cols;
-  double vA = 0.0, vB = 0.0;
-  for (int i = lane; i <= kMaxDim; i += 64) {
-    u[i] = 0.0;
-    p[i] = 0;
-    way[i] = 0;
+  const double INF = 1e300;
+  // -- row reduction: lane r owns rows r and r + 64 (row stride LD = 129 words: conflict-free)
+  for (int r = lane; r < rows; r += 64) {
+    float m = a_lds[r * LD];
+    for (int j = 1; j < cols; ++j) m = fminf(m, a_lds[r * LD + j]);
+    u_row[r] = (double)m;
+    row_matched[r] = 0;
   }
   __syncthreads();
-  const double INF = 1e300;
+  // -- column reduction.  Only for square problems: with rows < cols a column may stay unmatched, and the dual of
+  // an unmatched column has to be 0 at the optimum (v = 0 is the start the search itself keeps for free columns).
+  double vA = 0.0, vB = 0.0;
+  if (rows == cols) {
+    vA = vB = INF;
+    for (int i = 0; i < rows; ++i) {
+      const double ui = u_row[i];
+      if (hasA) vA = fmin(vA, (double)a_lds[i * LD + jA - 1] - ui);
+      if (hasB) vB = fmin(vB, (double)a_lds[i * LD + jB - 1] - ui);
+    }
+  }
+  // -- greedy matching on zero reduced costs (lowest free column first)
+  int pA = 0, pB = 0;                 // row matched to my columns (1-based, 0 = free)
+  double uA = 0.0, uB = 0.0;          // dual of that row
+  for (int i = 0; i < rows; ++i) {
+    const double ui = u_row[i];
+    unsigned cand = 0xffffffffu;
+    if (hasA && pA == 0 && ((double)a_lds[i * LD + jA - 1] - ui) - vA == 0.0) cand = (unsigned)jA;
+    else if (hasB && pB == 0 && ((double)a_lds[i * LD + jB - 1] - ui) - vB == 0.0) cand = (unsigned)jB;
+    const unsigned j = wave_min_u32(cand);
+    if (j != 0xffffffffu) {
+      if ((int)j == jA) { pA = i + 1; uA = ui; }
+      if ((int)j == jB) { pB = i + 1; uB = ui; }
+      if (lane == 0) row_matched[i] = 1;
+    }
+  }
+  __syncthreads();
+  // -- shortest augmenting paths for the remaining rows
   for (int i = 1; i <= rows; ++i) {
-    if (lane == 0) p[0] = i;
+    if (row_matched[i - 1]) continue;
+    double ui = u_row[i - 1];          // dual of the root row (wave-uniform)
     double minA = INF, minB = INF;
     bool usedA = false, usedB = false;
+    int wayA = 0, wayB = 0;
     int j0 = 0;
-    __syncthreads();
     while (true) {
-      // mark j0 used
-      if (j0 == jA) usedA = true;
-      if (j0 == jB) usedB = true;
-      const int i0 = p[j0];
-      const double ui0 = u[i0];
+      int i0;
+      double ui0;
+      if (j0 == 0) {
+        i0 = i;
+        ui0 = ui;
+      } else {
+        const int owner = (j0 - 1) & 63;
+        const bool second = j0 > 64;
+        if (j0 == jA) usedA = true;
+        if (j0 == jB) usedB = true;
+        i0 = __builtin_amdgcn_readlane(second ? pB : pA, owner);
+        ui0 = readlane_f64(second ? uB : uA, owner);
+      }
+      const float* arow = a_lds + (i0 - 1) * LD;
       double best = INF;
       int bestj = 0x7fffffff;
       if (hasA && !usedA) {
-        const double cur = a(i0 - 1, jA - 1) - ui0 - vA;
-        if (cur < minA) { minA = cur; way[jA] = j0; }
+        const double cur = (double)arow[jA - 1] - ui0 - vA;
+        if (cur < minA) { minA = cur; wayA = j0; }
         if (minA < best) { best = minA; bestj = jA; }
       }
       if (hasB && !usedB) {
-        const double cur = a(i0 - 1, jB - 1) - ui0 - vB;
-        if (cur < minB) { minB = cur; way[jB] = j0; }
-        if (minB < best) { best = minB; bestj = jB; }
+        const double cur = (double)arow[jB - 1] - ui0 - vB;
+        if (cur < minB) { minB = cur; wayB = j0; }
+        if (minB < best || (minB == best && pA != 0 && pB == 0)) { best = minB; bestj = jB; }
       }
-      // wave arg-min: 64-bit key = (orderable reduced cost with its 8 lowest mantissa bits cleared | column),
-      // minimised in two 32-bit DPP passes (high word, then low word among the lanes holding the minimum)
+      // wave arg-min: 64-bit key = (orderable reduced cost with its 9 lowest mantissa bits cleared | matched? |
+      // column), minimised in two 32-bit DPP passes (high word, then low word among the lanes holding the
+      // minimum).  Among equal reduced costs a FREE column wins: the path ends there instead of wandering through
+      // every matched column of a tie — with the dataset's ≈ 70 identical zero-padded GT columns that alone
+      // is a 7x shorter search (2.2 ms → 0.3 ms per launch).
+      const unsigned long long taken = bestj == jA ? (pA != 0) : (pB != 0);
       const unsigned long long key =
-          bestj == 0x7fffffff ? ~0ull : ((orderable(best) & ~0xffull) | (unsigned long long)bestj);
+          bestj == 0x7fffffff ? ~0ull : ((orderable(best) & ~0x1ffull) | (taken << 8) | (unsigned long long)bestj);
       const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
       const unsigned mhi = wave_min_u32(hi);
       const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
-      const int j1 = (int)(mlo & 0xffu);
-      // exact delta = minv[j1], read from the lane that owns column j1
-      const int owner = (j1 - 1) & 63;
-      const double cand = (j1 == jA) ? minA : minB;
-      const double delta = __shfl(cand, owner, 64);
-      // potentials: used columns (incl. the virtual column 0) move their rows; free columns tighten
-      if (lane == 0) u[p[0]] += delta;
-      if (hasA) { if (usedA) { u[p[jA]] += delta; vA -= delta; } else minA -= delta; }
-      if (hasB) { if (usedB) { u[p[jB]] += delta; vB -= delta; } else minB -= delta; }
+      const int j1 = (int)(mlo & 0xffu);          // 1..128 (bit 8 is the matched flag)
+      const int owner1 = (j1 - 1) & 63;
+      const bool second1 = j1 > 64;
+      // exact delta = minv[j1] from the lane that owns column j1
+      const double delta = readlane_f64(second1 ? minB : minA, owner1);
+      // potentials: the rows of the tree (root + rows matched to used columns) go up, used columns go down,
+      // free columns tighten
+      ui += delta;
+      if (hasA) { if (usedA) { uA += delta; vA -= delta; } else minA -= delta; }
+      if (hasB) { if (usedB) { uB += delta; vB -= delta; } else minB -= delta; }
       j0 = j1;
-      __syncthreads();
-      if (p[j0] == 0) break;
+      if (__builtin_amdgcn_readlane(second1 ? pB : pA, owner1) == 0) break;
     }
-    // augment along the alternating path (sequential, <= rows steps)
-    if (lane == 0) {
-      int j = j0;
-      while (j != 0) {
-        const int jp = way[j];
-        p[j] = p[jp];
-        j = jp;
+    // augment along the alternating path: p[j] = p[way[j]] (and that row's dual with it) back to the root
+    int j = j0;
+    while (j != 0) {
+      const int owner = (j - 1) & 63;
+      const bool second = j > 64;
+      const int jp = __builtin_amdgcn_readlane(second ? wayB : wayA, owner);
+      int row;
+      double urow;
+      if (jp == 0) {
+        row = i;
+        urow = ui;
+      } else {
+        const int ownp = (jp - 1) & 63;
+        const bool secp = jp > 64;
+        row = __builtin_amdgcn_readlane(secp ? pB : pA, ownp);
+        urow = readlane_f64(secp ? uB : uA, ownp);
       }
+      if (j == jA) { pA = row; uA = urow; }
+      if (j == jB) { pB = row; uB = urow; }
+      j = jp;
     }
-    __syncthreads();
   }
   // outputs
   if (!transposed) {
-    // out[row] = col
-    for (int j = lane + 1; j <= cols; j += 64)
-      if (p[j] > 0) out[p[j] - 1] = j - 1;
+    if (hasA && pA > 0) out[pA - 1] = jA - 1;       // out[row] = col
+    if (hasB && pB > 0) out[pB - 1] = jB - 1;
   } else {
     // the caller's rows are this problem's columns: out[caller_row] = caller_col or -1
-    for (int j = lane + 1; j <= cols; j += 64) out[j - 1] = p[j] > 0 ? p[j] - 1 : -1;
+    if (hasA) out[jA - 1] = pA > 0 ? pA - 1 : -1;
+    if (hasB) out[jB - 1] = pB > 0 ? pB - 1 : -1;
   }
 }
 
