@@ -267,6 +267,20 @@ int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, fl
 int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K13 — row sums of the point-sampled mask losses and their gradient.
+ * Replaces: the elementwise chains of mmdet DiceLoss(naive_dice=True, eps=1) and CrossEntropyLoss(use_sigmoid=True)
+ * on the sampled points (mask_bev/models/networks/mask2former_head/mask2former_head.py:406-424).
+ * logits, targets (rows, points) f32.  out_sums (rows, 4) f32 = [sum sigmoid(x)*t, sum sigmoid(x), sum t,
+ * sum bce_with_logits(x, t)].  bwd: grad_sums (rows, 4) → grad_logits (rows, points); the gradient of sum t
+ * (column 2) is ignored (targets carry no gradient).
+ */
+int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t rows, int32_t points, float* out_sums,
+                           void* stream);
+
+int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const float* grad_sums, int64_t rows,
+                           int32_t points, float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

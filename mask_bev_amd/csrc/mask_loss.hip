@@ -1,0 +1,115 @@
+// K13 — row sums of the point-sampled mask losses (dice + BCE) and their gradient, one pass each.
+//
+// Replaces the elementwise chain of mmdet's DiceLoss (naive_dice, eps 1) and CrossEntropyLoss(use_sigmoid) as
+// called on the sampled points at mask_bev/models/networks/mask2former_head/mask2former_head.py:406-424:
+// sigmoid, product, three row reductions, binary_cross_entropy_with_logits and its reduction — ten passes over
+// the (10·B·Q, 12 544) f32 point logits forward and about as many backward (≈ 1.9 ms per step measured) —
+// by one read of (logits, targets) forward and one read + one write backward.  HBM-bound; no MFMA.
+//
+//   fwd:  out[r] = ( Σ σ(x)·t,  Σ σ(x),  Σ t,  Σ bce(x, t) ),   bce = max(x, 0) − x·t + log1p(exp(−|x|))
+//   bwd:  dx = σ(1 − σ)·(g0·t + g1) + g3·(σ − t)      (g2, the gradient of Σ t, does not reach x)
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void acc_point(float x, float t, float& s_it, float& s_p, float& s_t, float& s_b) {
+  const float e = __expf(-fabsf(x));                  // in (0, 1]
+  const float inv = 1.0f / (1.0f + e);
+  const float sig = x >= 0.f ? inv : e * inv;
+  s_it += sig * t;
+  s_p += sig;
+  s_t += t;
+  s_b += fmaxf(x, 0.f) - x * t + log1pf(e);
+}
+
+__global__ void __launch_bounds__(kThreads) k_mask_loss_rows_fwd(const float* __restrict__ x, const float* __restrict__ t,
+                                                                 int p, float* __restrict__ out) {
+  __shared__ float red[4][kThreads / 64];
+  const long row = blockIdx.x;
+  const float* xr = x + row * p;
+  const float* tr = t + row * p;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const bool vec = (p & 3) == 0 && ((reinterpret_cast<size_t>(xr) | reinterpret_cast<size_t>(tr)) & 15) == 0;
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < p; i += kThreads * 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + i);
+      const float4 tv = *reinterpret_cast<const float4*>(tr + i);
+      acc_point(xv.x, tv.x, s0, s1, s2, s3);
+      acc_point(xv.y, tv.y, s0, s1, s2, s3);
+      acc_point(xv.z, tv.z, s0, s1, s2, s3);
+      acc_point(xv.w, tv.w, s0, s1, s2, s3);
+    }
+  } else {
+    for (int i = threadIdx.x; i < p; i += kThreads) acc_point(xr[i], tr[i], s0, s1, s2, s3);
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; red[3][wave] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float s = 0.f;
+    for (int w = 0; w < kThreads / 64; ++w) s += red[threadIdx.x][w];
+    out[row * 4 + threadIdx.x] = s;
+  }
+}
+
+__device__ __forceinline__ float grad_point(float x, float t, float g0, float g1, float g3) {
+  const float e = __expf(-fabsf(x));
+  const float inv = 1.0f / (1.0f + e);
+  const float sig = x >= 0.f ? inv : e * inv;
+  return sig * (1.0f - sig) * (g0 * t + g1) + g3 * (sig - t);
+}
+
+__global__ void __launch_bounds__(kThreads) k_mask_loss_rows_bwd(const float* __restrict__ x, const float* __restrict__ t,
+                                                                 const float* __restrict__ g, int p,
+                                                                 float* __restrict__ dx) {
+  const long row = blockIdx.x;
+  const float* xr = x + row * p;
+  const float* tr = t + row * p;
+  float* dr = dx + row * p;
+  const float g0 = g[row * 4 + 0], g1 = g[row * 4 + 1], g3 = g[row * 4 + 3];
+  const bool vec = (p & 3) == 0 &&
+                   ((reinterpret_cast<size_t>(xr) | reinterpret_cast<size_t>(tr) | reinterpret_cast<size_t>(dr)) & 15) == 0;
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < p; i += kThreads * 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + i);
+      const float4 tv = *reinterpret_cast<const float4*>(tr + i);
+      float4 d;
+      d.x = grad_point(xv.x, tv.x, g0, g1, g3);
+      d.y = grad_point(xv.y, tv.y, g0, g1, g3);
+      d.z = grad_point(xv.z, tv.z, g0, g1, g3);
+      d.w = grad_point(xv.w, tv.w, g0, g1, g3);
+      *reinterpret_cast<float4*>(dr + i) = d;
+    }
+  } else {
+    for (int i = threadIdx.x; i < p; i += kThreads) dr[i] = grad_point(xr[i], tr[i], g0, g1, g3);
+  }
+}
+
+}  // namespace
+
+extern "C" int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t rows, int32_t points,
+                                      float* out_sums, void* stream) {
+  if (rows < 0 || points <= 0) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!logits || !targets || !out_sums) return MBV_ERR_BAD_ARG;
+  if (rows > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_mask_loss_rows_fwd, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     points, out_sums);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const float* grad_sums, int64_t rows,
+                                      int32_t points, float* grad_logits, void* stream) {
+  if (rows < 0 || points <= 0) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!logits || !targets || !grad_sums || !grad_logits) return MBV_ERR_BAD_ARG;
+  if (rows > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_mask_loss_rows_bwd, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
+                     grad_sums, points, grad_logits);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}

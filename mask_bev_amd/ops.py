@@ -807,3 +807,39 @@ def select_uncertain_points(logits: torch.Tensor, coords: torch.Tensor, k: int) 
     rc = lib.mbv_select_uncertain_points(_ptr(logits), _ptr(coords), r, n, int(k), _ptr(out), _stream())
     check(rc, 'mbv_select_uncertain_points')
     return out
+
+
+# --------------------------------------------------------------------------------------
+# K13 row sums of the point-sampled dice / BCE losses
+# --------------------------------------------------------------------------------------
+class _MaskLossRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        lib = _lib.load()
+        _need_gpu(logits, targets)
+        x = logits.float().contiguous()
+        t = targets.float().contiguous()
+        if x.shape != t.shape or x.dim() != 2:
+            raise MaskBevHipError('mask_loss_rows: logits and targets must both be (rows, points)')
+        out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
+        check(lib.mbv_mask_loss_rows_fwd(_ptr(x), _ptr(t), x.shape[0], x.shape[1], _ptr(out), _stream()),
+              'mbv_mask_loss_rows_fwd')
+        ctx.save_for_backward(x, t)
+        ctx.in_dtype = logits.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_sums):
+        lib = _lib.load()
+        x, t = ctx.saved_tensors
+        g = grad_sums.float().contiguous()
+        dx = torch.empty_like(x)
+        check(lib.mbv_mask_loss_rows_bwd(_ptr(x), _ptr(t), _ptr(g), x.shape[0], x.shape[1], _ptr(dx), _stream()),
+              'mbv_mask_loss_rows_bwd')
+        return dx.to(ctx.in_dtype), None
+
+
+def mask_loss_rows(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """(rows, points) logits / targets → (rows, 4) f32 [Σ σ(x)·t, Σ σ(x), Σ t, Σ bce_with_logits(x, t)] in one pass
+    (K13); differentiable w.r.t. the logits."""
+    return _MaskLossRows.apply(logits, targets)

@@ -1,0 +1,26 @@
+"""K13 fused dice/BCE row sums vs the torch expressions of the oracle's loss (forward and gradient)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('R,P', [(40, 12544), (7, 1001), (3, 4), (1, 1)])
+def test_mask_loss_rows(device, R, P):
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(R * 7 + P)
+    x = (torch.randn(R, P, generator=g) * 6).to(device).requires_grad_()
+    t = (torch.rand(R, P, generator=g) > 0.6).float().to(device)
+    t[0] = torch.rand(P, generator=g).to(device)                     # non-binary targets are allowed
+    xr = x.detach().double().requires_grad_()
+    td = t.double()
+    ps = xr.sigmoid()
+    want = torch.stack([(ps * td).sum(1), ps.sum(1), td.sum(1),
+                        F.binary_cross_entropy_with_logits(xr, td, reduction='none').sum(1)], 1)
+    got = ops.mask_loss_rows(x, t)
+    assert torch.allclose(got.double(), want, rtol=2e-5, atol=1e-4)
+    w = torch.randn(R, 4, generator=g).to(device)
+    (got * w).sum().backward()
+    (want * w.double()).sum().backward()
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-4, atol=1e-6)
