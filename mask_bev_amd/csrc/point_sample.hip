@@ -11,32 +11,11 @@
 // map, accumulates its whole (H, W) gradient tile in LDS (64 KB at 128 x 128) with LDS atomics and writes it
 // out once with coalesced stores.  Maps larger than the LDS tile fall back to global atomics.
 #include "common.hpp"
+#include "bilinear.hpp"
 
 namespace {
 
 constexpr int kTileFloats = 16384;   // 64 KB LDS tile: 128 x 128 mask logits
-
-struct Bil {
-  int o[4];
-  float w[4];
-};
-
-// pixel = coord * size - 0.5 (grid_sample(2p - 1), align_corners=False), zero padding
-__device__ __forceinline__ void bil_setup(float px, float py, int H, int W, Bil& b) {
-  const float x = px * (float)W - 0.5f, y = py * (float)H - 0.5f;
-  const float xf = floorf(x), yf = floorf(y);
-  const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
-  const float lx = x - xf, ly = y - yf;
-  b.w[0] = (1.f - ly) * (1.f - lx);
-  b.w[1] = (1.f - ly) * lx;
-  b.w[2] = ly * (1.f - lx);
-  b.w[3] = ly * lx;
-  const bool xv0 = x0 >= 0 && x0 < W, xv1 = x1 >= 0 && x1 < W, yv0 = y0 >= 0 && y0 < H, yv1 = y1 >= 0 && y1 < H;
-  b.o[0] = (yv0 && xv0) ? y0 * W + x0 : -1;
-  b.o[1] = (yv0 && xv1) ? y0 * W + x1 : -1;
-  b.o[2] = (yv1 && xv0) ? y1 * W + x0 : -1;
-  b.o[3] = (yv1 && xv1) ? y1 * W + x1 : -1;
-}
 
 __global__ void __launch_bounds__(256) k_point_sample_fwd(const float* __restrict__ src,
                                                           const int32_t* __restrict__ src_index,

@@ -9,6 +9,7 @@
 // selected points' (x, y) coordinates in ascending index order (ties at the threshold: lowest indices first).
 // The SET of selected points equals top-k's; their order differs, which no consumer depends on (the loss sums).
 #include "common.hpp"
+#include "bilinear.hpp"
 
 namespace {
 
@@ -114,6 +115,158 @@ __global__ void __launch_bounds__(kThreads) k_select_smallest_abs(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused form: sample the n candidate points of a row from its (H, W) logit map AND select the k most uncertain, in
+// one workgroup per row — the (rows, n) over-sampled logits (600 MB per step at 10 x B x Q rows, n = 37 632)
+// never exist in HBM.  The map sits in a 64 KB LDS tile (K8's layout), every thread keeps the |logit| keys of its
+// n / 1024 points in registers, the 3-pass radix select histograms them from there, and the compaction (same
+// order and tie rule as above) places a point from per-(chunk, wave) ballot counts, so the only barriers left are
+// the four of the select.  The uniform tail of the reference's sampling (rand_coords) is copied behind the
+// selected points, which removes the torch.cat of the two coordinate sets as well.
+constexpr int kFusedThreads = 1024;
+constexpr int kKeysPerThread = 40;                       // n <= 40 960
+constexpr int kFusedWaves = kFusedThreads / 64;
+
+__global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __restrict__ src,
+                                                                 const int32_t* __restrict__ src_index,
+                                                                 const float* __restrict__ coords, int n, int k, int H,
+                                                                 int W, const float* __restrict__ rand_coords,
+                                                                 int n_rand, float* __restrict__ out_coords) {
+  __shared__ __attribute__((aligned(16))) float tile[16384];
+  __shared__ int hist[kBins];
+  __shared__ int cnt_lt[kKeysPerThread * kFusedWaves + 1], cnt_eq[kKeysPerThread * kFusedWaves + 1];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_krem;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hw = H * W;
+  const float* s = src + (int64_t)src_index[row] * hw;
+  if ((hw & 3) == 0) {
+    for (int i = tid * 4; i < hw; i += kFusedThreads * 4)
+      *reinterpret_cast<float4*>(&tile[i]) = *reinterpret_cast<const float4*>(s + i);
+  } else {
+    for (int i = tid; i < hw; i += kFusedThreads) tile[i] = s[i];
+  }
+  __syncthreads();
+  const float* cr = coords + row * (int64_t)n * 2;
+  uint32_t keys[kKeysPerThread];
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int p = j * kFusedThreads + tid;
+    keys[j] = 0xffffffffu;
+    if (p < n) {
+      const float2 xy = *reinterpret_cast<const float2*>(cr + (int64_t)p * 2);
+      Bil b;
+      bil_setup(xy.x, xy.y, H, W, b);
+      float v = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (b.o[c] >= 0) v += b.w[c] * tile[b.o[c]];
+      keys[j] = abs_key(v);
+    }
+  }
+  // -- radix select of the k-th smallest key (11 + 11 + 10 bits), keys in registers
+  uint32_t prefix = 0, prefix_mask = 0;
+  int krem = k;
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = shifts[pass], nb = 1 << widths[pass];
+    for (int i = tid; i < kBins; i += kFusedThreads) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+      const bool valid = j * kFusedThreads + tid < n;
+      if (valid && (keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
+    }
+    __syncthreads();
+    // cumulative search: thread t owns bins 2t, 2t + 1; wave totals through LDS (cnt_lt doubles as scratch)
+    const int b0 = tid * 2;
+    const int h0 = b0 < nb ? hist[b0] : 0, h1 = b0 + 1 < nb ? hist[b0 + 1] : 0;
+    int inc = h0 + h1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) cnt_lt[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += cnt_lt[w];
+    const int excl = off + inc - (h0 + h1);
+    if (excl < krem && krem <= excl + h0 + h1) {         // exactly one thread
+      if (krem <= excl + h0) {
+        s_prefix = prefix | ((uint32_t)b0 << shift);
+        s_krem = krem - excl;
+      } else {
+        s_prefix = prefix | ((uint32_t)(b0 + 1) << shift);
+        s_krem = krem - excl - h0;
+      }
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    krem = s_krem;
+    prefix_mask |= (uint32_t)(nb - 1) << shift;
+  }
+  // -- compaction in index order: element (chunk j, thread t) has index j * 1024 + t
+  const uint32_t T = prefix;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const bool valid = j * kFusedThreads + tid < n;
+    const unsigned long long m_lt = __ballot(valid && keys[j] < T), m_eq = __ballot(valid && keys[j] == T);
+    if (lane == 0) {
+      cnt_lt[j * kFusedWaves + wave] = __popcll(m_lt);
+      cnt_eq[j * kFusedWaves + wave] = __popcll(m_eq);
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {                                         // wave 0 scans cnt_lt, wave 1 cnt_eq (exclusive, in place)
+    int* c = wave == 0 ? cnt_lt : cnt_eq;
+    constexpr int PER = (kKeysPerThread * kFusedWaves + 63) / 64;      // 10 consecutive entries per lane
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = lane * PER + q;
+      loc[q] = e < kKeysPerThread * kFusedWaves ? c[e] : 0;
+      sum += loc[q];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = lane * PER + q;
+      if (e < kKeysPerThread * kFusedWaves) c[e] = run;
+      run += loc[q];
+    }
+  }
+  __syncthreads();
+  float* orow = out_coords + row * (int64_t)(k + n_rand) * 2;
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int p = j * kFusedThreads + tid;
+    const bool valid = p < n;
+    const bool is_lt = valid && keys[j] < T, is_eq = valid && keys[j] == T;
+    const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
+    const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
+    const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
+    if (is_lt || (is_eq && eq_before < krem)) {
+      const int pos = lt_before + min(krem, eq_before);
+      *reinterpret_cast<float2*>(orow + (int64_t)pos * 2) = *reinterpret_cast<const float2*>(cr + (int64_t)p * 2);
+    }
+  }
+  if (n_rand > 0) {
+    const float2* rr = reinterpret_cast<const float2*>(rand_coords + row * (int64_t)n_rand * 2);
+    float2* ot = reinterpret_cast<float2*>(orow + (int64_t)k * 2);
+    for (int i = tid; i < n_rand; i += kFusedThreads) ot[i] = rr[i];
+  }
+}
+
 }  // namespace
 
 extern "C" int mbv_select_uncertain_points(const float* logits, const float* coords, int64_t rows, int32_t n,
@@ -124,6 +277,21 @@ extern "C" int mbv_select_uncertain_points(const float* logits, const float* coo
   if (!logits || !coords || !out_coords) return MBV_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_select_smallest_abs, dim3((unsigned)rows), dim3(kThreads), 0, stream, logits, coords, n, k,
                      out_coords);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_sample_select_uncertain(const float* src, const int32_t* src_index, const float* coords,
+                                           int64_t rows, int32_t n, int32_t k, int32_t H, int32_t W,
+                                           const float* rand_coords, int32_t n_rand, float* out_coords,
+                                           void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (rows < 0 || n <= 0 || k <= 0 || k > n || H <= 0 || W <= 0 || n_rand < 0) return MBV_ERR_BAD_ARG;
+  if ((int64_t)H * W > 16384 || n > kKeysPerThread * kFusedThreads) return MBV_ERR_UNSUPPORTED;
+  if (rows == 0) return MBV_OK;
+  if (!src || !src_index || !coords || !out_coords || (n_rand > 0 && !rand_coords)) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_sample_select, dim3((unsigned)rows), dim3(kFusedThreads), 0, stream, src, src_index, coords, n,
+                     k, H, W, rand_coords, n_rand, out_coords);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -160,6 +160,13 @@ class Mask2FormerTransformerDecoder(nn.Module):
 # --------------------------------------------------------------------------------------
 # head
 # --------------------------------------------------------------------------------------
+class LossDict(dict):
+    """The reference's loss dictionary (40 scalars, same keys) plus ``total``: the sum of all its ``*loss*`` entries
+    computed vectorised.  ``MaskBevModule.loss`` (mask_bev_module.py:193-195 in the reference) returns ``total``
+    when it is handed this object, and falls back to summing the entries otherwise."""
+    total: Optional[torch.Tensor] = None
+
+
 class PointSource:
     """Uniform sampling points for the loss.  ``seed=None`` → device RNG (training); an int → a CPU
     generator drawn in the reference's order (mask2former_head.py:191, then mmdet's
@@ -411,12 +418,9 @@ class Mask2FormerHead(nn.Module):
         pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
         rows = self._iota(d * g, dev)
         with torch.no_grad():
-            over_logits = ops.point_sample(masks_flat.detach(), pred_index, over_c, rows)
             n_unc = int(self.importance_sample_ratio * p)
-            coords = ops.select_uncertain_points(over_logits, over_c, n_unc)          # most uncertain = smallest |logit|
-            if rand_c is not None:
-                coords = torch.cat((coords, rand_c), dim=1)
-            coords = coords.contiguous()
+            # most uncertain = smallest |logit| among the over-sampled candidates, then the uniform tail
+            coords = ops.sample_select_uncertain(masks_flat.detach(), pred_index, over_c, n_unc, rand_c)
         pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
         if overlap:                                     # join the matcher
             main.wait_stream(side)
@@ -446,8 +450,11 @@ class Mask2FormerHead(nn.Module):
         loss_dice = self.loss_dice_weight * (1 - dice).view(d, g).sum(1) / (num_total_masks + eps)
         loss_mask = self.loss_mask_weight * sums[:, 3].view(d, g).sum(1) / (num_total_masks * p + eps)
 
-        out = dict(loss_cls=loss_cls[-1], loss_mask=loss_mask[-1], loss_dice=loss_dice[-1], loss_height=0)
+        out = LossDict(loss_cls=loss_cls[-1], loss_mask=loss_mask[-1], loss_dice=loss_dice[-1], loss_height=0)
         for i in range(d - 1):
             out[f'd{i}.loss_cls'], out[f'd{i}.loss_mask'], out[f'd{i}.loss_dice'] = loss_cls[i], loss_mask[i], loss_dice[i]
             out[f'd{i}.loss_height'] = 0
+        # the sum of every entry, taken on the (D,) vectors: 3 reductions instead of 40 scalar adds forward and
+        # ≈ 120 slice-gradient kernels backward (MaskBevModule.loss returns it when handed this dict)
+        out.total = loss_cls.sum() + loss_mask.sum() + loss_dice.sum()
         return out

@@ -220,6 +220,9 @@ class MaskBevModule(_Base):
         return self._panoptic_head.loss(cls, masks, labels_gt, masks_gt, heights_pred, heights_gt)
 
     def loss(self, loss_dict):
+        total = getattr(loss_dict, 'total', None)
+        if total is not None and all('loss' in k for k in loss_dict):      # the head's own, unmodified dictionary
+            return total
         return sum(value for key, value in loss_dict.items() if 'loss' in key)
 
     # ------------------------------------------------------------------ steps

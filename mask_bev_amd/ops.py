@@ -809,6 +809,33 @@ def select_uncertain_points(logits: torch.Tensor, coords: torch.Tensor, k: int) 
     return out
 
 
+@torch.no_grad()
+def sample_select_uncertain(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tensor, k: int,
+                            rand_coords: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Importance sampling of the mask loss in one launch (fused K8 + K10): for row r, sample ``coords[r]`` (n, 2)
+    from the map ``src[src_index[r]]`` (H, W), keep the k points with the smallest |logit|, append
+    ``rand_coords[r]``.  Returns (R, k + n_rand, 2).  Falls back to the two-kernel form for maps larger than the
+    64 KB LDS tile or more than 40 960 candidates per row."""
+    lib = _lib.load()
+    _need_gpu(src, src_index, coords, rand_coords)
+    src, coords = src.float().contiguous(), coords.float().contiguous()
+    src_index = src_index.to(torch.int32).contiguous()
+    r, n = coords.shape[:2]
+    h, w = src.shape[-2:]
+    n_rand = 0 if rand_coords is None else rand_coords.shape[1]
+    if h * w > 16384 or n > 40960:
+        rows = torch.arange(r, device=src.device, dtype=torch.int32)
+        sel = select_uncertain_points(point_sample(src, src_index, coords, rows), coords, k)
+        return sel if rand_coords is None else torch.cat((sel, rand_coords.float()), dim=1).contiguous()
+    if rand_coords is not None:
+        rand_coords = rand_coords.float().contiguous()
+    out = torch.empty((r, k + n_rand, 2), dtype=torch.float32, device=src.device)
+    rc = lib.mbv_sample_select_uncertain(_ptr(src), _ptr(src_index), _ptr(coords), r, n, int(k), h, w,
+                                         _ptr(rand_coords), n_rand, _ptr(out), _stream())
+    check(rc, 'mbv_sample_select_uncertain')
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # K13 row sums of the point-sampled dice / BCE losses
 # --------------------------------------------------------------------------------------
