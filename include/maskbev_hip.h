@@ -243,13 +243,19 @@ int mbv_select_uncertain_points(const float* logits, const float* coords, int64_
 /* Fused K8 + K10: sample the n candidate points of each row from its source map and keep the k most uncertain,
  * without materialising the (rows, n) sampled logits (the whole of get_uncertain_point_coords_with_randomness,
  * mask2former_head.py:401-404).  src (N, H, W) f32 with H*W <= 16384; src_index (rows) i32 → source map of a row;
- * coords (rows, n, 2) f32 in [0, 1], n <= 40960; rand_coords (rows, n_rand, 2) f32 (nullable when n_rand == 0):
- * the uniform tail, copied behind the selected points; out_coords (rows, k + n_rand, 2).  Same selection, order
- * and tie rule as mbv_point_sample_fwd followed by mbv_select_uncertain_points.  MBV_ERR_UNSUPPORTED outside
- * those limits (callers then use the two-kernel form). */
-int mbv_sample_select_uncertain(const float* src, const int32_t* src_index, const float* coords, int64_t rows,
-                                int32_t n, int32_t k, int32_t H, int32_t W, const float* rand_coords, int32_t n_rand,
-                                float* out_coords, void* stream);
+ * n <= 40960 candidates per row, given EITHER as coords (rows, n, 2) f32 in [0, 1] (seed NULL) OR generated in the
+ * kernel from the device-resident 64-bit *seed (coords NULL): point p of row r is mbv_uniform_points' value, so
+ * the 1.2 GB candidate tensor of a training step is never written or read.  rand_coords (rows, n_rand, 2) f32
+ * (nullable when n_rand == 0): the uniform tail, copied behind the selected points; out_coords
+ * (rows, k + n_rand, 2).  Same selection, order and tie rule as mbv_point_sample_fwd followed by
+ * mbv_select_uncertain_points.  MBV_ERR_UNSUPPORTED outside those limits (callers use the two-kernel form). */
+int mbv_sample_select_uncertain(const float* src, const int32_t* src_index, const float* coords, const int64_t* seed,
+                                int64_t rows, int32_t n, int32_t k, int32_t H, int32_t W, const float* rand_coords,
+                                int32_t n_rand, float* out_coords, void* stream);
+
+/* The generator behind the seed form above, written out: out_coords (rows, n, 2) f32 uniform in [0, 1), a pure
+ * function of (*seed, row, point) — replaces torch.rand of mmdet's get_uncertain_point_coords_with_randomness. */
+int mbv_uniform_points(const int64_t* seed, int64_t rows, int32_t n, float* out_coords, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K11 — parameter-arena kernels of the optimisation step.

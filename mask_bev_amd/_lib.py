@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class MaskBevHipError(RuntimeError):
@@ -57,7 +57,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_wgrad_small_f32': (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     'mbv_mask_loss_rows_fwd': (ctypes.c_int, [_P, _P, _L, _I, _P, _P]),
     'mbv_mask_loss_rows_bwd': (ctypes.c_int, [_P, _P, _P, _L, _I, _P, _P]),
-    'mbv_sample_select_uncertain': (ctypes.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P]),
+    'mbv_sample_select_uncertain': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P]),
+    'mbv_uniform_points': (ctypes.c_int, [_P, _L, _I, _P, _P]),
     'mbv_packed_mask_words': (_L, [_I, _I]),
     'mbv_pack_binary_masks': (ctypes.c_int, [_P, _L, _I, _I, _P, _P]),
     'mbv_point_sample_packed_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

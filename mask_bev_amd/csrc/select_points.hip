@@ -127,9 +127,36 @@ constexpr int kFusedThreads = 1024;
 constexpr int kKeysPerThread = 40;                       // n <= 40 960
 constexpr int kFusedWaves = kFusedThreads / 64;
 
+// Counter-based uniform points for the training path (PCG output hash of a per-row offset + point counter): with
+// RNG = true the candidate coordinates are generated where they are consumed — once for sampling, once more in
+// the compaction — instead of being drawn by torch.rand into a 1.2 GB tensor, read, and read again.  The same
+// generator filled into a tensor by mbv_uniform_points gives the tests an exact two-kernel reference.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+  const uint32_t s = v * 747796405u + 2891336453u;
+  const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ uint32_t row_stream(int64_t seed, int64_t row) {
+  return pcg_hash((uint32_t)seed ^ pcg_hash((uint32_t)(seed >> 32) + (uint32_t)row * 0x9E3779B9u + (uint32_t)(row >> 32)));
+}
+__device__ __forceinline__ float2 uniform_point(uint32_t stream, int p) {
+  const uint32_t a = pcg_hash(stream + 2u * (uint32_t)p), b = pcg_hash(stream + 2u * (uint32_t)p + 1u);
+  return make_float2((float)(a >> 8) * 5.9604644775390625e-08f, (float)(b >> 8) * 5.9604644775390625e-08f);   // [0, 1)
+}
+
+__global__ void __launch_bounds__(256) k_uniform_points(const int64_t* __restrict__ seed, int64_t rows, int n,
+                                                        float* __restrict__ out) {
+  const int64_t row = blockIdx.y;
+  const uint32_t stream = row_stream(seed[0], row);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) *reinterpret_cast<float2*>(out + (row * n + p) * 2) = uniform_point(stream, p);
+}
+
+template <bool RNG>
 __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __restrict__ src,
                                                                  const int32_t* __restrict__ src_index,
-                                                                 const float* __restrict__ coords, int n, int k, int H,
+                                                                 const float* __restrict__ coords,
+                                                                 const int64_t* __restrict__ seed, int n, int k, int H,
                                                                  int W, const float* __restrict__ rand_coords,
                                                                  int n_rand, float* __restrict__ out_coords) {
   __shared__ __attribute__((aligned(16))) float tile[16384];
@@ -148,22 +175,34 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     for (int i = tid; i < hw; i += kFusedThreads) tile[i] = s[i];
   }
   __syncthreads();
-  const float* cr = coords + row * (int64_t)n * 2;
+  const float* cr = RNG ? nullptr : coords + row * (int64_t)n * 2;
+  const uint32_t stream = RNG ? row_stream(seed[0], row) : 0u;
   uint32_t keys[kKeysPerThread];
+  // batches of BATCH points: their coordinate loads are issued together (one HBM round trip per batch, not per
+  // point); a scheduling barrier after every batch keeps the compiler from hoisting later batches' loads over the
+  // 40 live key registers (it spilled 197 VGPRs without it)
+  constexpr int BATCH = 8;
 #pragma unroll
-  for (int j = 0; j < kKeysPerThread; ++j) {
-    const int p = j * kFusedThreads + tid;
-    keys[j] = 0xffffffffu;
-    if (p < n) {
-      const float2 xy = *reinterpret_cast<const float2*>(cr + (int64_t)p * 2);
+  for (int jb = 0; jb < kKeysPerThread; jb += BATCH) {
+    float2 xy[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int p = (jb + u) * kFusedThreads + tid;
+      if constexpr (RNG) xy[u] = uniform_point(stream, p);
+      else xy[u] = p < n ? *reinterpret_cast<const float2*>(cr + (int64_t)p * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int p = (jb + u) * kFusedThreads + tid;
       Bil b;
-      bil_setup(xy.x, xy.y, H, W, b);
+      bil_setup(xy[u].x, xy[u].y, H, W, b);
       float v = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (b.o[c] >= 0) v += b.w[c] * tile[b.o[c]];
-      keys[j] = abs_key(v);
+      keys[jb + u] = p < n ? abs_key(v) : 0xffffffffu;
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // -- radix select of the k-th smallest key (11 + 11 + 10 bits), keys in registers
   uint32_t prefix = 0, prefix_mask = 0;
@@ -180,10 +219,16 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
       if (valid && (keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
     }
     __syncthreads();
-    // cumulative search: thread t owns bins 2t, 2t + 1; wave totals through LDS (cnt_lt doubles as scratch)
-    const int b0 = tid * 2;
-    const int h0 = b0 < nb ? hist[b0] : 0, h1 = b0 + 1 < nb ? hist[b0 + 1] : 0;
-    int inc = h0 + h1;
+    // cumulative search: thread t owns bins 4t … 4t + 3; wave totals through LDS (cnt_lt doubles as scratch)
+    constexpr int PERB = kBins / kFusedThreads;
+    int hb[PERB], hsum = 0;
+#pragma unroll
+    for (int q = 0; q < PERB; ++q) {
+      const int bin = tid * PERB + q;
+      hb[q] = bin < nb ? hist[bin] : 0;
+      hsum += hb[q];
+    }
+    int inc = hsum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int t = __shfl_up(inc, o, 64);
@@ -193,14 +238,15 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     __syncthreads();
     int off = 0;
     for (int w = 0; w < wave; ++w) off += cnt_lt[w];
-    const int excl = off + inc - (h0 + h1);
-    if (excl < krem && krem <= excl + h0 + h1) {         // exactly one thread
-      if (krem <= excl + h0) {
-        s_prefix = prefix | ((uint32_t)b0 << shift);
-        s_krem = krem - excl;
-      } else {
-        s_prefix = prefix | ((uint32_t)(b0 + 1) << shift);
-        s_krem = krem - excl - h0;
+    int acc = off + inc - hsum;
+    if (acc < krem && krem <= acc + hsum) {               // exactly one thread
+#pragma unroll
+      for (int q = 0; q < PERB; ++q) {
+        if (acc < krem && krem <= acc + hb[q]) {
+          s_prefix = prefix | ((uint32_t)(tid * PERB + q) << shift);
+          s_krem = krem - acc;
+        }
+        acc += hb[q];
       }
     }
     __syncthreads();
@@ -208,7 +254,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     krem = s_krem;
     prefix_mask |= (uint32_t)(nb - 1) << shift;
   }
-  // -- compaction in index order: element (chunk j, thread t) has index j * 1024 + t
+  // -- compaction in index order: element (chunk j, thread t) has index j * kFusedThreads + t
   const uint32_t T = prefix;
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -247,18 +293,36 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   }
   __syncthreads();
   float* orow = out_coords + row * (int64_t)(k + n_rand) * 2;
+  // The coordinates are produced a second time here (regenerated / re-read).  Hide that from the compiler: it
+  // recognises the repeated pure computation and would otherwise keep all 80 coordinate values of the sampling
+  // phase alive for reuse — 198 spilled VGPRs.
 #pragma unroll
-  for (int j = 0; j < kKeysPerThread; ++j) {
-    const int p = j * kFusedThreads + tid;
-    const bool valid = p < n;
-    const bool is_lt = valid && keys[j] < T, is_eq = valid && keys[j] == T;
-    const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
-    const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
-    const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
-    if (is_lt || (is_eq && eq_before < krem)) {
-      const int pos = lt_before + min(krem, eq_before);
-      *reinterpret_cast<float2*>(orow + (int64_t)pos * 2) = *reinterpret_cast<const float2*>(cr + (int64_t)p * 2);
+  for (int j = 0; j < kKeysPerThread; ++j) asm volatile("" : "+v"(keys[j]));   // same reason: the ballots below
+  uint32_t stream2 = stream;
+  const float* cr2 = cr;
+  asm volatile("" : "+s"(stream2));
+  asm volatile("" : "+s"(cr2));
+#pragma unroll
+  for (int jb = 0; jb < kKeysPerThread; jb += BATCH) {
+    int pos[BATCH];
+    float2 xy[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int j = jb + u;
+      const int p = j * kFusedThreads + tid;
+      const bool valid = p < n;
+      const bool is_lt = valid && keys[j] < T, is_eq = valid && keys[j] == T;
+      const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
+      const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
+      const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
+      pos[u] = (is_lt || (is_eq && eq_before < krem)) ? lt_before + min(krem, eq_before) : -1;
+      if constexpr (RNG) xy[u] = uniform_point(stream2, p);
+      else if (pos[u] >= 0) xy[u] = *reinterpret_cast<const float2*>(cr2 + (int64_t)p * 2);
     }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (pos[u] >= 0) *reinterpret_cast<float2*>(orow + (int64_t)pos[u] * 2) = xy[u];
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (n_rand > 0) {
     const float2* rr = reinterpret_cast<const float2*>(rand_coords + row * (int64_t)n_rand * 2);
@@ -282,16 +346,32 @@ extern "C" int mbv_select_uncertain_points(const float* logits, const float* coo
 }
 
 extern "C" int mbv_sample_select_uncertain(const float* src, const int32_t* src_index, const float* coords,
-                                           int64_t rows, int32_t n, int32_t k, int32_t H, int32_t W,
-                                           const float* rand_coords, int32_t n_rand, float* out_coords,
+                                           const int64_t* seed, int64_t rows, int32_t n, int32_t k, int32_t H,
+                                           int32_t W, const float* rand_coords, int32_t n_rand, float* out_coords,
                                            void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (rows < 0 || n <= 0 || k <= 0 || k > n || H <= 0 || W <= 0 || n_rand < 0) return MBV_ERR_BAD_ARG;
   if ((int64_t)H * W > 16384 || n > kKeysPerThread * kFusedThreads) return MBV_ERR_UNSUPPORTED;
   if (rows == 0) return MBV_OK;
-  if (!src || !src_index || !coords || !out_coords || (n_rand > 0 && !rand_coords)) return MBV_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_sample_select, dim3((unsigned)rows), dim3(kFusedThreads), 0, stream, src, src_index, coords, n,
-                     k, H, W, rand_coords, n_rand, out_coords);
+  if (!src || !src_index || !out_coords || (n_rand > 0 && !rand_coords)) return MBV_ERR_BAD_ARG;
+  if ((coords == nullptr) == (seed == nullptr)) return MBV_ERR_BAD_ARG;      // exactly one source of points
+  if (coords)
+    hipLaunchKernelGGL(k_sample_select<false>, dim3((unsigned)rows), dim3(kFusedThreads), 0, stream, src, src_index,
+                       coords, seed, n, k, H, W, rand_coords, n_rand, out_coords);
+  else
+    hipLaunchKernelGGL(k_sample_select<true>, dim3((unsigned)rows), dim3(kFusedThreads), 0, stream, src, src_index,
+                       coords, seed, n, k, H, W, rand_coords, n_rand, out_coords);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_uniform_points(const int64_t* seed, int64_t rows, int32_t n, float* out_coords, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (rows < 0 || n <= 0 || rows > 65535) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!seed || !out_coords) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_uniform_points, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, stream, seed,
+                     rows, n, out_coords);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

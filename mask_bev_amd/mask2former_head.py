@@ -313,6 +313,20 @@ class Mask2FormerHead(nn.Module):
             self._iota_cache[key] = t
         return t
 
+    def _next_point_seed(self, device) -> torch.Tensor:
+        """Device-resident 64-bit seed of the in-kernel point generator, advanced in place once per loss evaluation
+        (an ordinary kernel: it is captured and replayed with a HIP graph).  Initialised from torch's generator, so
+        ``torch.manual_seed`` makes runs repeatable; ranks are decorrelated by their rank."""
+        key = ('point_seed', str(device))
+        t = self._iota_cache.get(key)
+        if t is None:
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available()
+                                                    and torch.distributed.is_initialized()) else 0
+            t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device) + rank * 1_000_003
+            self._iota_cache[key] = t
+        t.add_(0x2545F4914F6CDD1D)            # wraps modulo 2^64
+        return t
+
     def _draw_points(self, pts: PointSource, num_layers: int, batch: int, g: int):
         """All uniform points of one loss evaluation, drawn in the reference's order (per decoder output:
         B x rand(1, P, 2) for the matcher at mask2former_head.py:191, then rand(g, 3P, 2) and
@@ -321,7 +335,9 @@ class Mask2FormerHead(nn.Module):
         n_samp = int(p * self.oversample_ratio)
         n_rand = p - int(self.importance_sample_ratio * p)
         if pts.gen is None:                       # device RNG: the draw order is irrelevant, draw in bulk
-            return (pts.rand(num_layers * batch, p, 2), pts.rand(num_layers * g, n_samp, 2),
+            # the 3P over-sampled candidates (1.2 GB per step) are not drawn at all: the fused importance sampling
+            # generates them in-kernel from the device seed (None here)
+            return (pts.rand(num_layers * batch, p, 2), None,
                     pts.rand(num_layers * g, n_rand, 2) if n_rand > 0 else None)
         mc, oc, rc = [], [], []
         for _ in range(num_layers):
@@ -420,7 +436,12 @@ class Mask2FormerHead(nn.Module):
         with torch.no_grad():
             n_unc = int(self.importance_sample_ratio * p)
             # most uncertain = smallest |logit| among the over-sampled candidates, then the uniform tail
-            coords = ops.sample_select_uncertain(masks_flat.detach(), pred_index, over_c, n_unc, rand_c)
+            if over_c is None:
+                coords = ops.sample_select_uncertain(masks_flat.detach(), pred_index, None, n_unc, rand_c,
+                                                     seed=self._next_point_seed(dev),
+                                                     num_candidates=int(p * self.oversample_ratio))
+            else:
+                coords = ops.sample_select_uncertain(masks_flat.detach(), pred_index, over_c, n_unc, rand_c)
         pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
         if overlap:                                     # join the matcher
             main.wait_stream(side)

@@ -810,27 +810,56 @@ def select_uncertain_points(logits: torch.Tensor, coords: torch.Tensor, k: int) 
 
 
 @torch.no_grad()
-def sample_select_uncertain(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tensor, k: int,
-                            rand_coords: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Importance sampling of the mask loss in one launch (fused K8 + K10): for row r, sample ``coords[r]`` (n, 2)
-    from the map ``src[src_index[r]]`` (H, W), keep the k points with the smallest |logit|, append
-    ``rand_coords[r]``.  Returns (R, k + n_rand, 2).  Falls back to the two-kernel form for maps larger than the
-    64 KB LDS tile or more than 40 960 candidates per row."""
+def uniform_points(seed: torch.Tensor, rows: int, n: int) -> torch.Tensor:
+    """(rows, n, 2) f32 uniform points in [0, 1): the counter-based generator of the fused importance sampling,
+    written out (``seed``: device int64 tensor with one element)."""
     lib = _lib.load()
-    _need_gpu(src, src_index, coords, rand_coords)
-    src, coords = src.float().contiguous(), coords.float().contiguous()
+    _need_gpu(seed)
+    if seed.dtype != torch.int64 or seed.numel() != 1:
+        raise MaskBevHipError('uniform_points: seed must be one device int64')
+    out = torch.empty((rows, n, 2), dtype=torch.float32, device=seed.device)
+    for r0 in range(0, rows, 65535):                      # grid.y limit
+        r1 = min(rows, r0 + 65535)
+        if r0 == 0 and r1 == rows:
+            check(lib.mbv_uniform_points(_ptr(seed), rows, n, _ptr(out), _stream()), 'mbv_uniform_points')
+        else:
+            raise MaskBevHipError('uniform_points: more than 65 535 rows')
+    return out
+
+
+@torch.no_grad()
+def sample_select_uncertain(src: torch.Tensor, src_index: torch.Tensor, coords: Optional[torch.Tensor], k: int,
+                            rand_coords: Optional[torch.Tensor] = None, seed: Optional[torch.Tensor] = None,
+                            num_candidates: Optional[int] = None) -> torch.Tensor:
+    """Importance sampling of the mask loss in one launch (fused K8 + K10): for row r, sample n candidate points
+    from the map ``src[src_index[r]]`` (H, W), keep the k with the smallest |logit|, append ``rand_coords[r]``.
+    The candidates are either ``coords`` (R, n, 2) or — ``coords=None`` — generated inside the kernel from the
+    device int64 ``seed`` (``num_candidates`` per row; equal to ``uniform_points(seed, R, n)``).  Returns
+    (R, k + n_rand, 2).  Falls back to the two-kernel form for maps larger than the 64 KB LDS tile or more than
+    40 960 candidates per row."""
+    lib = _lib.load()
+    _need_gpu(src, src_index, coords, rand_coords, seed)
+    if (coords is None) == (seed is None):
+        raise MaskBevHipError('sample_select_uncertain: give either coords or seed')
+    src = src.float().contiguous()
     src_index = src_index.to(torch.int32).contiguous()
-    r, n = coords.shape[:2]
+    r = src_index.shape[0]
+    n = coords.shape[1] if coords is not None else int(num_candidates)
     h, w = src.shape[-2:]
     n_rand = 0 if rand_coords is None else rand_coords.shape[1]
     if h * w > 16384 or n > 40960:
+        if coords is None:
+            coords = uniform_points(seed, r, n)
+        coords = coords.float().contiguous()
         rows = torch.arange(r, device=src.device, dtype=torch.int32)
         sel = select_uncertain_points(point_sample(src, src_index, coords, rows), coords, k)
         return sel if rand_coords is None else torch.cat((sel, rand_coords.float()), dim=1).contiguous()
+    if coords is not None:
+        coords = coords.float().contiguous()
     if rand_coords is not None:
         rand_coords = rand_coords.float().contiguous()
     out = torch.empty((r, k + n_rand, 2), dtype=torch.float32, device=src.device)
-    rc = lib.mbv_sample_select_uncertain(_ptr(src), _ptr(src_index), _ptr(coords), r, n, int(k), h, w,
+    rc = lib.mbv_sample_select_uncertain(_ptr(src), _ptr(src_index), _ptr(coords), _ptr(seed), r, n, int(k), h, w,
                                          _ptr(rand_coords), n_rand, _ptr(out), _stream())
     check(rc, 'mbv_sample_select_uncertain')
     return out

@@ -44,3 +44,28 @@ def test_fused_sample_select_equals_two_kernel_form(device, R, n, k, H, W, n_ran
     got = ops.sample_select_uncertain(src, idx, coords, k, rand_c)
     assert got.shape == want.shape
     assert torch.equal(got, want)
+
+
+def test_fused_sample_select_in_kernel_points(device):
+    """Seed form: the candidates generated inside the kernel are exactly uniform_points(seed); the selection equals
+    the two-kernel form on them; the generator is uniform and changes with the seed and the row."""
+    from mask_bev_amd import ops
+    R, n, k, H, W, n_rand = 5, 37632, 9408, 128, 128, 3136
+    g = torch.Generator().manual_seed(3)
+    src = (torch.randn(R, H, W, generator=g) * 5).to(device)
+    idx = torch.arange(R, dtype=torch.int32, device=device)
+    rand_c = torch.rand(R, n_rand, 2, generator=g).to(device)
+    seed = torch.tensor([0x1234_5678_9ABC_DEF], dtype=torch.int64, device=device)
+    coords = ops.uniform_points(seed, R, n)
+    assert coords.shape == (R, n, 2) and float(coords.min()) >= 0.0 and float(coords.max()) < 1.0
+    assert abs(float(coords.mean()) - 0.5) < 2e-3 and abs(float(coords.var()) - 1.0 / 12.0) < 1e-3
+    hist = torch.histc(coords[..., 0].flatten(), bins=64, min=0, max=1)
+    assert float((hist - hist.mean()).abs().max() / hist.mean()) < 0.10          # 5 sigma of a 2940-count bin
+    cx = coords[0, :, 0] - 0.5
+    assert abs(float((cx[:-1] * cx[1:]).mean()) * 12.0) < 0.02                 # no lag-1 correlation
+    assert not torch.equal(coords[0], coords[1])
+    seed2 = seed + 1
+    assert not torch.equal(ops.uniform_points(seed2, R, n), coords)
+    want = ops.sample_select_uncertain(src, idx, coords, k, rand_c)
+    got = ops.sample_select_uncertain(src, idx, None, k, rand_c, seed=seed, num_candidates=n)
+    assert torch.equal(got, want)
