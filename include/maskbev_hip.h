@@ -298,6 +298,30 @@ int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const floa
                            int32_t points, float* grad_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K12 — fused residual-add + LayerNorm over the last (channel) axis of token-major activations.
+ * Replaces: the `x + f(x)` → nn.LayerNorm(C) pairs of SwinBlock.forward (mask_bev/models/networks/swin/swin.py:
+ * 357-377), of the pixel-decoder and masked-attention decoder layers (mmdet, configured at
+ * mask_bev/models/head/mask_bev_panoptic_head.py:119-176) and the decoder's post_norm
+ * (mask2former_head.py:448), forward and backward.
+ * a, b: (rows, C) f32 or bf16 (`*_bf16` flags; b nullable = plain LayerNorm); gamma, beta (C) f32; C % 4 == 0,
+ * C <= 2048 (mbv_add_layernorm_supported).  fwd writes sum_out = a + b (f32, the tensor the backward needs; may be
+ * NULL only for a lone f32 `a`, which then serves as the saved input), y in f32 or bf16, mean / rstd (rows) f32.
+ * bwd: dy (rows, C) f32/bf16, ds nullable (gradient reaching the sum from the residual path), s = the saved sum;
+ * writes dx (rows, C) f32 (the gradient of a and of b), optionally the same in bf16 (dx_bf16), and
+ * dgamma / dbeta (C) f32 — overwritten, or accumulated into when accumulate != 0 (parameter-arena gradients).
+ * partial_ws: mbv_add_layernorm_bwd_blocks(rows, C) * 2 * C floats.
+ */
+int mbv_add_layernorm_supported(int32_t C);
+int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C);
+int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+                          const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y, int32_t y_bf16,
+                          float* mean, float* rstd, void* stream);
+int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
+                          const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
+                          void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate, float* partial_ws,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

@@ -1,0 +1,285 @@
+// K12 — fused residual-add + LayerNorm over the channel axis of token-major activations, forward and backward.
+//
+// Replaces the `x + f(x)` → `nn.LayerNorm(C)` pairs of the Swin blocks (mask_bev/models/networks/swin/swin.py:
+// 357-377), of the pixel-decoder layers and of the masked-attention decoder layers (post-LN; mmdet layers configured
+// at mask_bev/models/head/mask_bev_panoptic_head.py:119-176).  Per (add, LN) pair torch runs an add kernel, the LN
+// kernel and — under autocast — a cast of the LN output forward, and the LN input-gradient kernel, two
+// gamma/beta-gradient kernels, two gradient-accumulation adds and the residual gradient add backward; here it is
+// one kernel forward and two backward (the second a small column reduction), the normalised output is written
+// directly in the consumer's dtype, and d(gamma), d(beta) land in the parameter arena's gradient by accumulation.
+// HBM-bound: one wave per row, 16-byte accesses, every tensor touched once.
+//
+//   fwd:  s = a (+ b);  mean, rstd over C;  y = (s - mean) * rstd * gamma + beta
+//   bwd:  g = dy * gamma;  dx = rstd * (g - mean_C(g) - xhat * mean_C(g * xhat)) (+ ds);  dgamma += Σ_rows dy * xhat;
+//         dbeta += Σ_rows dy
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// 4 consecutive channels of a row, f32 or bf16 storage
+__device__ __forceinline__ float4 load4(const void* base, bool bf16, long elem) {
+  if (bf16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+}
+__device__ __forceinline__ void store4(void* base, bool bf16, long elem, float4 v) {
+  if (bf16) {
+    uint2 u;
+    u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = u;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
+  }
+}
+
+struct LnIo {
+  const void* a; const void* b;      // inputs (b nullable)
+  int a_bf16, b_bf16;
+  const float* gamma; const float* beta;
+  float* s;                          // the sum, f32 (saved for the backward; nullable only when b == nullptr && !a_bf16)
+  void* y; int y_bf16;
+  float* mean; float* rstd;
+};
+
+// ITERS float4 per lane: C <= 256 * ITERS, C % 4 == 0
+template <int ITERS>
+__global__ void __launch_bounds__(256) k_add_ln_fwd(LnIo io, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C >> 2;
+  const long base = row * C;
+  float4 x[ITERS];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int v = lane + 64 * i;
+    x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v < nvec) {
+      x[i] = load4(io.a, io.a_bf16, base + 4 * v);
+      if (io.b) {
+        const float4 t = load4(io.b, io.b_bf16, base + 4 * v);
+        x[i].x += t.x; x[i].y += t.y; x[i].z += t.z; x[i].w += t.w;
+      }
+      if (io.s) *reinterpret_cast<float4*>(io.s + base + 4 * v) = x[i];
+      sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      const float d0 = x[i].x - mean, d1 = x[i].y - mean, d2 = x[i].z - mean, d3 = x[i].w - mean;
+      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  if (lane == 0) {
+    io.mean[row] = mean;
+    io.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      const float4 g = *reinterpret_cast<const float4*>(io.gamma + 4 * v);
+      const float4 be = *reinterpret_cast<const float4*>(io.beta + 4 * v);
+      float4 o;
+      o.x = (x[i].x - mean) * rstd * g.x + be.x;
+      o.y = (x[i].y - mean) * rstd * g.y + be.y;
+      o.z = (x[i].z - mean) * rstd * g.z + be.z;
+      o.w = (x[i].w - mean) * rstd * g.w + be.w;
+      store4(io.y, io.y_bf16, base + 4 * v, o);
+    }
+  }
+}
+
+struct LnBwdIo {
+  const void* dy; int dy_bf16;
+  const void* ds; int ds_bf16;       // gradient arriving at the sum from the residual path (nullable)
+  const float* s; const float* mean; const float* rstd; const float* gamma;
+  float* dx;                         // f32 gradient of the sum (= of a and of b)
+  void* dx_lo;                       // optional bf16 copy of dx for a bf16 branch input (nullable)
+  float* partial;                    // (gridDim.x, 2, C) per-block Σ dy*xhat, Σ dy
+};
+
+template <int ITERS>
+__global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C) {
+  extern __shared__ float red[];     // [2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 2;
+  for (int i = threadIdx.x; i < 2 * C; i += 512) red[i] = 0.f;
+  __syncthreads();
+  float4 dg[ITERS], db[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gam[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int v = lane + 64 * i;
+    gam[i] = v < nvec ? *reinterpret_cast<const float4*>(io.gamma + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long row = (long)blockIdx.x * 8 + wave; row < rows; row += (long)gridDim.x * 8) {
+    const long base = row * C;
+    const float mean = io.mean[row], rstd = io.rstd[row];
+    float4 g[ITERS], xh[ITERS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int v = lane + 64 * i;
+      g[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < nvec) {
+        const float4 dy = load4(io.dy, io.dy_bf16, base + 4 * v);
+        const float4 sv = *reinterpret_cast<const float4*>(io.s + base + 4 * v);
+        xh[i].x = (sv.x - mean) * rstd; xh[i].y = (sv.y - mean) * rstd;
+        xh[i].z = (sv.z - mean) * rstd; xh[i].w = (sv.w - mean) * rstd;
+        dg[i].x += dy.x * xh[i].x; dg[i].y += dy.y * xh[i].y; dg[i].z += dy.z * xh[i].z; dg[i].w += dy.w * xh[i].w;
+        db[i].x += dy.x; db[i].y += dy.y; db[i].z += dy.z; db[i].w += dy.w;
+        g[i].x = dy.x * gam[i].x; g[i].y = dy.y * gam[i].y; g[i].z = dy.z * gam[i].z; g[i].w = dy.w * gam[i].w;
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nvec) {
+        float4 d;
+        d.x = rstd * (g[i].x - c1 - xh[i].x * c2);
+        d.y = rstd * (g[i].y - c1 - xh[i].y * c2);
+        d.z = rstd * (g[i].z - c1 - xh[i].z * c2);
+        d.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+        if (io.ds) {
+          const float4 t = load4(io.ds, io.ds_bf16, base + 4 * v);
+          d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        }
+        *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
+        if (io.dx_lo) store4(io.dx_lo, 1, base + 4 * v, d);
+      }
+    }
+  }
+  // the 8 waves' column sums meet in LDS, then one (2, C) row of partials per block
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int v = lane + 64 * i;
+    if (v < nvec) {
+      atomicAdd(&red[4 * v + 0], dg[i].x); atomicAdd(&red[4 * v + 1], dg[i].y);
+      atomicAdd(&red[4 * v + 2], dg[i].z); atomicAdd(&red[4 * v + 3], dg[i].w);
+      atomicAdd(&red[C + 4 * v + 0], db[i].x); atomicAdd(&red[C + 4 * v + 1], db[i].y);
+      atomicAdd(&red[C + 4 * v + 2], db[i].z); atomicAdd(&red[C + 4 * v + 3], db[i].w);
+    }
+  }
+  __syncthreads();
+  float* prow = io.partial + (long)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 512) prow[i] = red[i];
+}
+
+// dgamma[c] (+)= Σ_blocks partial[blk][0][c], dbeta likewise.  Block = 64 columns x 4 block-slices.
+__global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nblk, int C,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         int accumulate) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);     // over 2C columns: [0, C) gamma, [C, 2C) beta
+  const int slice = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (col < 2 * C)
+    for (int b = slice; b < nblk; b += 4) acc += partial[(long)b * 2 * C + col];
+  red[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && col < 2 * C) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* dst = col < C ? dgamma + col : dbeta + (col - C);
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
+int iters_for(int C) {
+  if (C <= 0 || (C & 3)) return 0;
+  if (C <= 256) return 1;
+  if (C <= 512) return 2;
+  if (C <= 1024) return 4;
+  if (C <= 2048) return 8;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mbv_add_layernorm_supported(int32_t C) { return iters_for(C) ? 1 : 0; }
+
+// one 512-thread block per CU for wide rows (≤ 256 VGPRs), up to four for narrow ones
+extern "C" int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C) {
+  const int64_t cap = iters_for(C) <= 2 ? 1024 : 256;
+  int64_t b = (rows + 7) / 8;
+  return b < 1 ? 1 : (b > cap ? cap : b);
+}
+
+extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+                                     const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
+                                     int32_t y_bf16, float* mean, float* rstd, void* stream) {
+  const int it = iters_for(C);
+  if (!it) return MBV_ERR_UNSUPPORTED;
+  if (rows < 0) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!a || !gamma || !beta || !y || !mean || !rstd) return MBV_ERR_BAD_ARG;
+  if (!sum_out && (b || a_bf16)) return MBV_ERR_BAD_ARG;       // the backward needs the f32 LN input
+  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd};
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (it) {
+    case 1: hipLaunchKernelGGL(k_add_ln_fwd<1>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    case 2: hipLaunchKernelGGL(k_add_ln_fwd<2>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    case 4: hipLaunchKernelGGL(k_add_ln_fwd<4>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    default: hipLaunchKernelGGL(k_add_ln_fwd<8>, grid, block, 0, st, io, (long)rows, C, eps); break;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
+                                     const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
+                                     float* dx, void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate,
+                                     float* partial_ws, void* stream) {
+  const int it = iters_for(C);
+  if (!it) return MBV_ERR_UNSUPPORTED;
+  if (rows < 0) return MBV_ERR_BAD_ARG;
+  if (!dgamma || !dbeta) return MBV_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    if (!accumulate) {
+      MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
+      MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
+    }
+    return MBV_OK;
+  }
+  if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
+  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, partial_ws};
+  const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
+  const dim3 grid(nblk), block(512);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  switch (it) {
+    case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
+    case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;
+    case 4: hipLaunchKernelGGL(k_add_ln_bwd<4>, grid, block, lds, st, io, (long)rows, C); break;
+    default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
+  }
+  MBV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((2 * C + 63) / 64)), dim3(256), 0, st, partial_ws, nblk, C,
+                     dgamma, dbeta, accumulate);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}

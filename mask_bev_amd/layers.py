@@ -27,6 +27,29 @@ class Linear(nn.Linear):
         return ops.linear(x, self.weight, self.bias)
 
 
+class LayerNorm(nn.LayerNorm):
+    """``nn.LayerNorm(C)`` (same parameters / checkpoint keys) on K12: optionally fused with the residual add that
+    feeds it, writing straight in the consumer's dtype.
+
+    ``forward(x, residual=None, gemm_input=False, return_sum=False)``:
+    ``y = LN(x + residual)``; ``gemm_input=True`` says y only feeds GEMM layers, so under autocast it is stored in
+    the autocast dtype (what the GEMM would cast it to anyway); ``return_sum`` also returns the f32 sum."""
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, gemm_input: bool = False,
+                return_sum: bool = False):
+        c = x.shape[-1]
+        if (x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
+                and ops.add_layernorm_supported(c) and x.dtype in (torch.float32, torch.bfloat16)
+                and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+            out_dtype = torch.float32
+            if gemm_input and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+                out_dtype = torch.bfloat16
+            return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum)
+        s = x if residual is None else x + residual
+        y = super().forward(s.float() if s.dtype != torch.float32 and not torch.is_autocast_enabled('cuda') else s)
+        return (y, s) if return_sum else y
+
+
 class FFN(nn.Module):
     """Two-layer MLP with residual; keys ``layers.0.0.*`` / ``layers.1.*`` (mmcv ``FFN`` layout, used at
     mask_bev/models/networks/swin/swin.py:347-355 and mask_bev_panoptic_head.py:137-142,168-175)."""
@@ -37,7 +60,11 @@ class FFN(nn.Module):
             nn.Sequential(Linear(embed_dims, feedforward_channels), nn.GELU() if act == 'gelu' else nn.ReLU()),
             Linear(feedforward_channels, embed_dims))
 
-    def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None, add_identity: bool = True) -> torch.Tensor:
+        """``add_identity=False`` returns the branch alone: the caller fuses the residual add into the LayerNorm
+        that follows (K12)."""
+        if not add_identity:
+            return self.layers(x)
         return (x if identity is None else identity) + self.layers(x)
 
 
@@ -57,7 +84,7 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.patch = patch
         self.projection = nn.Conv2d(in_channels, embed_dims, kernel_size=patch, stride=patch)
-        self.norm = nn.LayerNorm(embed_dims)
+        self.norm = LayerNorm(embed_dims)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.projection(corner_pad(x, self.patch, self.patch))
@@ -71,7 +98,7 @@ class PatchMerging(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, stride: int = 2):
         super().__init__()
         self.stride = stride
-        self.norm = nn.LayerNorm(4 * in_channels)
+        self.norm = LayerNorm(4 * in_channels)
         self.reduction = Linear(4 * in_channels, out_channels, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:          # (B, H, W, C) → (B, H', W', 2C)
@@ -87,7 +114,7 @@ class PatchMerging(nn.Module):
             x = x[:, :oh * 2, :ow * 2].reshape(b, oh, 2, ow, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(b, oh, ow, 4 * c)
         else:
             x = F.unfold(x.permute(0, 3, 1, 2), kernel_size=2, stride=s).transpose(1, 2).reshape(b, oh, ow, 4 * c)
-        return self.reduction(self.norm(x))
+        return self.reduction(self.norm(x, gemm_input=True))
 
 
 class ConvGN(nn.Module):
@@ -153,8 +180,10 @@ class MultiheadAttention(nn.Module):
         self.embed_dims, self.num_heads = embed_dims, num_heads
         self.attn = _AttnParams(embed_dims)
 
-    def forward(self, query, key, value, query_pos=None, key_pos=None, blocked: Optional[torch.Tensor] = None):
-        """query (B, Q, E), key/value (B, L, E); ``blocked`` (B, 1|H, Q, L) bool, True = may NOT attend."""
+    def forward(self, query, key, value, query_pos=None, key_pos=None, blocked: Optional[torch.Tensor] = None,
+                add_identity: bool = True):
+        """query (B, Q, E), key/value (B, L, E); ``blocked`` (B, 1|H, Q, L) bool, True = may NOT attend.
+        ``add_identity=False`` returns the attention branch alone (residual add fused into the next LayerNorm)."""
         e, h = self.embed_dims, self.num_heads
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         q = query + query_pos if query_pos is not None else query
@@ -163,7 +192,8 @@ class MultiheadAttention(nn.Module):
         k = ops.linear(k, w, bias, rows=(e, 2 * e))
         v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
         o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
-        return query + self.attn.out_proj(o)
+        o = self.attn.out_proj(o)
+        return query + o if add_identity else o
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -198,7 +228,8 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.zeros_(self.output_proj.bias)
 
     def forward(self, query: torch.Tensor, query_pos: torch.Tensor, reference_points: torch.Tensor,
-                spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor):
+                spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor,
+                add_identity: bool = True):
         """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y)."""
         b, n, e = query.shape
         h, l, p = self.num_heads, self.num_levels, self.num_points
@@ -209,4 +240,5 @@ class MultiScaleDeformableAttention(nn.Module):
         normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(off.dtype)          # (L, 2) = (w, h)
         loc = reference_points.view(1, n, 1, 1, 1, 2) + off / normalizer.view(1, 1, 1, l, 1, 2)
         out = ops.ms_deform_attn(value, spatial_shapes, shapes_t, level_start, loc, aw)
-        return self.output_proj(out) + query
+        out = self.output_proj(out)
+        return out + query if add_identity else out

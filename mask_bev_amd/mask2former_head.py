@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import ConvGN, FFN, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
+from .layers import ConvGN, FFN, LayerNorm, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
 
 
 # --------------------------------------------------------------------------------------
@@ -27,11 +27,12 @@ class _DeformEncoderLayer(nn.Module):
         super().__init__()
         self.self_attn = MultiScaleDeformableAttention(embed_dims, num_heads, num_levels, num_points)
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
-        self.norms = nn.ModuleList([nn.LayerNorm(embed_dims), nn.LayerNorm(embed_dims)])
+        self.norms = nn.ModuleList([LayerNorm(embed_dims), LayerNorm(embed_dims)])
 
     def forward(self, q, pos, ref, shapes, shapes_t, level_start):
-        q = self.norms[0](self.self_attn(q, pos, ref, shapes, shapes_t, level_start))
-        return self.norms[1](self.ffn(q))
+        # post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12)
+        q = self.norms[0](q, self.self_attn(q, pos, ref, shapes, shapes_t, level_start, add_identity=False))
+        return self.norms[1](q, self.ffn(q, add_identity=False))
 
 
 class _DeformEncoder(nn.Module):
@@ -135,18 +136,18 @@ class _DecoderLayer(nn.Module):
         self.self_attn = MultiheadAttention(embed_dims, num_heads)
         self.cross_attn = MultiheadAttention(embed_dims, num_heads)
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
-        self.norms = nn.ModuleList([nn.LayerNorm(embed_dims) for _ in range(3)])
+        self.norms = nn.ModuleList([LayerNorm(embed_dims) for _ in range(3)])
 
     def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None):
         """``memory_key`` = memory + memory_pos when the caller has it (it is the same for every layer that reads
         this level)."""
         if memory_key is None:
-            q = self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked)
+            r = self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked, add_identity=False)
         else:
-            q = self.cross_attn(query, memory_key, memory, query_pos, None, blocked)
-        q = self.norms[0](q)
-        q = self.norms[1](self.self_attn(q, q, q, query_pos, query_pos, None))
-        return self.norms[2](self.ffn(q))
+            r = self.cross_attn(query, memory_key, memory, query_pos, None, blocked, add_identity=False)
+        q = self.norms[0](query, r)                      # post-LN, residual add inside the LayerNorm kernel (K12)
+        q = self.norms[1](q, self.self_attn(q, q, q, query_pos, query_pos, None, add_identity=False))
+        return self.norms[2](q, self.ffn(q, add_identity=False))
 
 
 class Mask2FormerTransformerDecoder(nn.Module):
@@ -154,7 +155,7 @@ class Mask2FormerTransformerDecoder(nn.Module):
         super().__init__()
         self.embed_dims = embed_dims
         self.layers = nn.ModuleList([_DecoderLayer(embed_dims, num_heads, ffn_channels) for _ in range(num_layers)])
-        self.post_norm = nn.LayerNorm(embed_dims)
+        self.post_norm = LayerNorm(embed_dims)
 
 
 # --------------------------------------------------------------------------------------

@@ -899,3 +899,101 @@ def mask_loss_rows(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
     """(rows, points) logits / targets → (rows, 4) f32 [Σ σ(x)·t, Σ σ(x), Σ t, Σ bce_with_logits(x, t)] in one pass
     (K13); differentiable w.r.t. the logits."""
     return _MaskLossRows.apply(logits, targets)
+
+
+# --------------------------------------------------------------------------------------
+# K12 fused residual-add + LayerNorm
+# --------------------------------------------------------------------------------------
+def add_layernorm_supported(channels: int) -> bool:
+    return channels % 4 == 0 and 0 < channels <= 2048
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps, out_dtype):
+        lib = _lib.load()
+        _need_gpu(a, b, weight, bias)
+        c = a.shape[-1]
+        ok = (torch.float32, torch.bfloat16)
+        if a.dtype not in ok or (b is not None and b.dtype not in ok) or out_dtype not in ok:
+            raise MaskBevHipError('add_layernorm supports f32 and bf16 activations')
+        if weight.dtype != torch.float32 or bias.dtype != torch.float32:
+            raise MaskBevHipError('add_layernorm: f32 affine parameters')
+        a2 = a.contiguous()
+        b2 = None if b is None else b.contiguous()
+        if b2 is not None and b2.shape != a2.shape:
+            raise MaskBevHipError('add_layernorm: a and b must have the same shape')
+        rows = a2.numel() // c
+        need_sum = b2 is not None or a2.dtype != torch.float32
+        s = torch.empty(a2.shape, dtype=torch.float32, device=a.device) if need_sum else None
+        y = torch.empty(a2.shape, dtype=out_dtype, device=a.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+        w, bb = weight.contiguous(), bias.contiguous()
+        check(lib.mbv_add_layernorm_fwd(_ptr(a2), int(a2.dtype == torch.bfloat16), _ptr(b2),
+                                        int(b2 is not None and b2.dtype == torch.bfloat16), _ptr(w), _ptr(bb), rows, c,
+                                        float(eps), _ptr(s), _ptr(y), int(out_dtype == torch.bfloat16), _ptr(mean),
+                                        _ptr(rstd), _stream()), 'mbv_add_layernorm_fwd')
+        ctx.save_for_backward(a2 if s is None else s, mean, rstd, w)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.dtypes = (a.dtype, None if b is None else b.dtype)
+        ctx.set_materialize_grads(False)
+        return y, s                                       # s is None for a lone f32 input (it IS the input)
+
+    @staticmethod
+    def backward(ctx, gy, gs):
+        lib = _lib.load()
+        s, mean, rstd, w = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        da, db = ctx.dtypes
+        if gy is None:                                    # only the residual path carries gradient
+            ga = None if gs is None else gs.to(da)
+            gb = None if (gs is None or db is None) else gs.to(db)
+            return ga, gb, None, None, None, None
+        c = s.shape[-1]
+        rows = s.numel() // c
+        gy = gy.contiguous()
+        if gy.dtype not in (torch.float32, torch.bfloat16):
+            gy = gy.float()
+        if gs is not None:
+            gs = gs.contiguous()
+            if gs.dtype not in (torch.float32, torch.bfloat16):
+                gs = gs.float()
+        dx = torch.empty(s.shape, dtype=torch.float32, device=s.device)
+        want_lo = da == torch.bfloat16 or db == torch.bfloat16
+        dx_lo = torch.empty(s.shape, dtype=torch.bfloat16, device=s.device) if want_lo else None
+        direct = (getattr(weight, '_mbv_arena', False) and getattr(bias, '_mbv_arena', False)
+                  and weight.grad is not None and bias.grad is not None
+                  and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32)
+        if direct:
+            dgamma, dbeta = weight.grad, bias.grad
+        else:
+            dgamma = torch.empty(c, dtype=torch.float32, device=s.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=s.device)
+        nblk = lib.mbv_add_layernorm_bwd_blocks(rows, c)
+        ws = torch.empty(max(1, nblk * 2 * c), dtype=torch.float32, device=s.device)
+        check(lib.mbv_add_layernorm_bwd(_ptr(gy), int(gy.dtype == torch.bfloat16), _ptr(gs),
+                                        int(gs is not None and gs.dtype == torch.bfloat16), _ptr(s), _ptr(mean),
+                                        _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo), _ptr(dgamma), _ptr(dbeta),
+                                        1 if direct else 0, _ptr(ws), _stream()), 'mbv_add_layernorm_bwd')
+        if direct:
+            _fire_grad_hooks(weight)
+            _fire_grad_hooks(bias)
+            dgamma = dbeta = None
+        else:
+            dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
+        ga = dx_lo if da == torch.bfloat16 else dx
+        gb = None if db is None else (dx_lo if db == torch.bfloat16 else dx)
+        return ga, gb, dgamma, dbeta, None, None
+
+
+def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
+                  eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, return_sum: bool = False):
+    """``y = LayerNorm_C(a + b)`` over the last axis in one pass (K12); ``b=None`` is a plain LayerNorm.
+    ``out_dtype`` (default: the autocast dtype when autocast is on and the consumer is a GEMM — pass it explicitly —
+    else f32) is the storage type of y; statistics and the sum are f32.  With ``return_sum`` the f32 sum ``a + b``
+    (the new residual stream of a pre-LN block) is returned as well: ``(y, s)``."""
+    if out_dtype is None:
+        out_dtype = torch.float32
+    y, s = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype)
+    return (y, a if s is None else s) if return_sum else y

@@ -8,14 +8,14 @@ addressing instead of materialising five layout copies per block.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import FFN, Linear, PatchEmbed, PatchMerging, trunc_normal_
+from .layers import FFN, LayerNorm, Linear, PatchEmbed, PatchMerging, trunc_normal_
 
 
 def relative_position_index(ws: int) -> torch.Tensor:
@@ -57,14 +57,18 @@ class ShiftWindowMSA(nn.Module):
 class SwinBlock(nn.Module):
     def __init__(self, embed_dims: int, num_heads: int, feedforward_channels: int, window_size: int, shift: bool):
         super().__init__()
-        self.norm1 = nn.LayerNorm(embed_dims)
+        self.norm1 = LayerNorm(embed_dims)
         self.attn = ShiftWindowMSA(embed_dims, num_heads, window_size, window_size // 2 if shift else 0)
-        self.norm2 = nn.LayerNorm(embed_dims)
+        self.norm2 = LayerNorm(embed_dims)
         self.ffn = FFN(embed_dims, feedforward_channels, act='gelu')
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = x + self.attn(self.norm1(x))
-        return self.ffn(self.norm2(x), identity=x)
+    def forward(self, x: torch.Tensor, pending: Optional[torch.Tensor] = None):
+        """Pre-LN block (swin.py:357-377): x ← x + attn(LN1(x)); x ← x + ffn(LN2(x)).  The residual adds are fused
+        into the LayerNorm that reads their result (K12): the block takes the not-yet-added output ``pending`` of
+        the previous block's FFN and returns ``(x, pending)`` with the stream's value being ``x + pending``."""
+        y, x = self.norm1(x, pending, gemm_input=True, return_sum=True)
+        y, x = self.norm2(x, self.attn(y), gemm_input=True, return_sum=True)
+        return x, self.ffn(y, add_identity=False)
 
 
 class SwinBlockSequence(nn.Module):
@@ -76,10 +80,18 @@ class SwinBlockSequence(nn.Module):
             for i in range(depth)])
         self.downsample = downsample
 
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None):
+        """→ (input of the next stage, this stage's output — normalised by ``out_norm`` when given; the last
+        residual add of the stage is fused into that LayerNorm)."""
+        pending = None
         for blk in self.blocks:
-            x = blk(x)
-        return (self.downsample(x) if self.downsample is not None else x), x
+            x, pending = blk(x, pending)
+        if out_norm is not None:
+            out, x = out_norm(x, pending, return_sum=True)
+        else:
+            x = x if pending is None else x + pending
+            out = x
+        return (self.downsample(x) if self.downsample is not None else x), out
 
 
 class CustomSwinTransformer(nn.Module):
@@ -117,7 +129,7 @@ class CustomSwinTransformer(nn.Module):
                 c *= 2
         self.num_features = [int(embed_dims * 2 ** i) for i in range(len(depths))]
         for i in self.out_indices:
-            self.add_module(f'norm{i}', nn.LayerNorm(self.num_features[i]))
+            self.add_module(f'norm{i}', LayerNorm(self.num_features[i]))
 
     def init_weights(self):
         """swin.py:674-682: trunc-normal(0.02) linears / abs-pos-embed, unit LayerNorms."""
@@ -144,8 +156,7 @@ class CustomSwinTransformer(nn.Module):
             x = x + ape.flatten(2).transpose(1, 2).reshape(1, h, w, e)
         outs = []
         for i, stage in enumerate(self.stages):
-            x, out = stage(x)
+            x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None)
             if i in self.out_indices:
-                out = getattr(self, f'norm{i}')(out)
                 outs.append(out.permute(0, 3, 1, 2).contiguous())
         return outs
