@@ -189,22 +189,31 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
   for (int i = threadIdx.x; i < 2 * C; i += 512) prow[i] = red[i];
 }
 
-// dgamma[c] (+)= Σ_blocks partial[blk][0][c], dbeta likewise.  Block = 64 columns x 4 block-slices.
+// dgamma[c] += Σ_blocks partial[blk][0][c], dbeta likewise.  Block = 64 columns x 4 slices over one chunk of 64
+// partial rows (blockIdx.y); chunks meet through f32 atomics (≤ 16 adds per address), the destination is cleared
+// by the caller when it is not accumulated into.
 __global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nblk, int C,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         int accumulate) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);     // over 2C columns: [0, C) gamma, [C, 2C) beta
   const int slice = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (col < 2 * C)
-    for (int b = slice; b < nblk; b += 4) acc += partial[(long)b * 2 * C + col];
-  red[slice][threadIdx.x & 63] = acc;
+  const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  if (col < 2 * C) {
+    int b = b0 + slice;
+    for (; b + 12 < b1; b += 16) {
+      acc0 += partial[(long)b * 2 * C + col];
+      acc1 += partial[(long)(b + 4) * 2 * C + col];
+      acc2 += partial[(long)(b + 8) * 2 * C + col];
+      acc3 += partial[(long)(b + 12) * 2 * C + col];
+    }
+    for (; b < b1; b += 4) acc0 += partial[(long)b * 2 * C + col];
+  }
+  red[slice][threadIdx.x & 63] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
   if (slice == 0 && col < 2 * C) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* dst = col < C ? dgamma + col : dbeta + (col - C);
-    *dst = accumulate ? *dst + t : t;
+    atomicAdd(col < C ? dgamma + col : dbeta + (col - C), t);
   }
 }
 
@@ -278,8 +287,12 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
     default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
   }
   MBV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((2 * C + 63) / 64)), dim3(256), 0, st, partial_ws, nblk, C,
-                     dgamma, dbeta, accumulate);
+  if (!accumulate) {
+    MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
+    MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
+  }
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((2 * C + 63) / 64), (unsigned)((nblk + 63) / 64)), dim3(256), 0,
+                     st, partial_ws, nblk, C, dgamma, dbeta);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
