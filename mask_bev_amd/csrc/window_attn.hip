@@ -30,6 +30,7 @@ using namespace mbv_tiles;
 
 struct WinGeom {
   int batch, H, W, C, heads, ws, shift, Hp, Wp, nWh, nWw, N;
+  int vec_ok;   // bf16 tensors 16-byte aligned and C % 8 == 0: fused 16-byte staging
 };
 
 // token t of window (wy, wx) -> pixel index inside the (H, W) map, or -1 for a padded token
@@ -114,6 +115,109 @@ __device__ __forceinline__ void zero_t_tail(typename Lay<BF16, D>::T* t_img) {
   }
 }
 
+// ---- fused staging for bf16 activations -------------------------------------------------------------------
+// One pass over the (token, 8-channel chunk) items of a window: ALL the 16-byte global loads an item needs (q, k, v
+// and, in the backward, dO and O) are issued together, then written to the LDS images with 16-byte row stores and
+// scattered 2-byte transposed stores.  The per-part form above pays one dependent HBM round trip per part and
+// loop iteration (≈ 9 in the backward); this is one or two.  Requires C % 8 == 0 and 16-byte aligned tensors.
+union Pack8 {
+  uint4 u;
+  __bf16 h[8];
+};
+
+__device__ __forceinline__ Pack8 pad_pack(const float* __restrict__ vec, int c) {
+  Pack8 p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p.h[j] = (__bf16)(vec ? vec[c + j] : 0.f);
+  return p;
+}
+
+template <int D>
+__device__ __forceinline__ void put_row(__bf16* img, int t, int c8, const Pack8& p) {
+  *reinterpret_cast<uint4*>(img + t * Lay<true, D>::RS + c8) = p.u;
+}
+template <int D>
+__device__ __forceinline__ void put_t(__bf16* img, int t, int c8, const Pack8& p) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) img[(c8 + j) * Lay<true, D>::TS + t] = p.h[j];
+}
+
+template <int D>
+__device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
+                                               const __bf16* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                               int col, __bf16* q_img, __bf16* k_img, __bf16* vt_img) {
+  constexpr int CH = D / 8;
+  const int C3 = 3 * g.C;
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c8 = (idx - t * CH) * 8;
+    Pack8 q, k, v;
+    q.u = k.u = v.u = make_uint4(0, 0, 0, 0);
+    if (t < g.N) {
+      const int pix = pix_lds[t];
+      if (pix >= 0) {
+        const __bf16* p = qkv + ((int64_t)id.b * g.H * g.W + pix) * C3 + col + c8;
+        q.u = *reinterpret_cast<const uint4*>(p);
+        k.u = *reinterpret_cast<const uint4*>(p + g.C);
+        v.u = *reinterpret_cast<const uint4*>(p + 2 * g.C);
+      } else {
+        q = pad_pack(qkv_bias, col + c8);
+        k = pad_pack(qkv_bias, g.C + col + c8);
+        v = pad_pack(qkv_bias, 2 * g.C + col + c8);
+      }
+    }
+    put_row<D>(q_img, t, c8, q);
+    put_row<D>(k_img, t, c8, k);
+    put_t<D>(vt_img, t, c8, v);
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
+                                               const __bf16* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                               const __bf16* __restrict__ out, const __bf16* __restrict__ grad_out,
+                                               int col, __bf16* q_img, __bf16* qt_img, __bf16* k_img, __bf16* kt_img,
+                                               __bf16* v_img, __bf16* do_img, __bf16* dot_img, float* delta_s) {
+  constexpr int CH = D / 8;
+  const int C3 = 3 * g.C;
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c8 = (idx - t * CH) * 8;
+    Pack8 q, k, v, d, o;
+    q.u = k.u = v.u = d.u = o.u = make_uint4(0, 0, 0, 0);
+    bool real = false;
+    if (t < g.N) {
+      const int pix = pix_lds[t];
+      if (pix >= 0) {
+        real = true;
+        const int64_t row = (int64_t)id.b * g.H * g.W + pix;
+        const __bf16* p = qkv + row * C3 + col + c8;
+        q.u = *reinterpret_cast<const uint4*>(p);
+        k.u = *reinterpret_cast<const uint4*>(p + g.C);
+        v.u = *reinterpret_cast<const uint4*>(p + 2 * g.C);
+        d.u = *reinterpret_cast<const uint4*>(grad_out + row * g.C + col + c8);
+        o.u = *reinterpret_cast<const uint4*>(out + row * g.C + col + c8);
+      } else {                      // padded token: q, k, v are the qkv bias; dO is zero (swin.py:247-248 crops it)
+        q = pad_pack(qkv_bias, col + c8);
+        k = pad_pack(qkv_bias, g.C + col + c8);
+        v = pad_pack(qkv_bias, 2 * g.C + col + c8);
+      }
+    }
+    put_row<D>(q_img, t, c8, q);
+    put_row<D>(k_img, t, c8, k);
+    put_row<D>(v_img, t, c8, v);
+    put_row<D>(do_img, t, c8, d);
+    put_t<D>(qt_img, t, c8, q);
+    put_t<D>(kt_img, t, c8, k);
+    put_t<D>(dot_img, t, c8, d);
+    if (real) {                     // delta[q] = sum_d dO[q][d] * O[q][d]
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (float)o.h[j] * (float)d.h[j];
+      atomicAdd(&delta_s[t], acc);
+    }
+  }
+}
+
 // additive bias + shift mask for (query q, key k); kinfo packs (ty | tx << 8 | label << 16) per token
 __device__ __forceinline__ float bias_mask(const float* __restrict__ tbl, const int* __restrict__ kinfo, int ws,
                                            int q, int k, int* idx_out) {
@@ -158,12 +262,24 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
   }
   __syncthreads();
   const int C3 = 3 * g.C, col = id.head * D;
-  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
-  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
-  if constexpr (BF16) {
+  const bool vec_ok = g.vec_ok != 0;
+  bool fused = false;
+  if constexpr (BF16 && std::is_same_v<TIn, __bf16>) {
+    if (vec_ok) {
+      fused = true;
+      stage_fwd_bf16<D>(g, id, pix, qkv, qkv_bias, col, q_img, k_img, v_img);
+      zero_t_tail<BF16, D>(v_img);
+    }
+  }
+  if (fused) {
+  } else if constexpr (BF16) {
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
     stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, nullptr, v_img);
     zero_t_tail<BF16, D>(v_img);
   } else {
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
     stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
   }
   __syncthreads();
@@ -238,8 +354,12 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+// 512 threads: waves 0-3 own the query blocks (dS^T tiles → bias-table gradient, dQ) while waves 4-7 own the key
+// blocks (dK, dV) — the two halves of the backward share the staged LDS images and run side by side (the LDS
+// footprint, ≈ 125 KB in bf16 at D = 64, allows one workgroup per CU, so the second half would otherwise wait for
+// the first with four waves on the CU).
 template <bool BF16, int D, typename TIn>
-__global__ void __launch_bounds__(256) k_window_attn_bwd(const TIn* __restrict__ qkv,
+__global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__ qkv,
                                                          const float* __restrict__ qkv_bias,
                                                          const float* __restrict__ bias_table,
                                                          const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
@@ -282,18 +402,29 @@ __global__ void __launch_bounds__(256) k_window_attn_bwd(const TIn* __restrict__
   }
   __syncthreads();
   const int C3 = 3 * g.C, col = id.head * D;
-  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, BF16 ? qt_img : nullptr);
-  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, BF16 ? kt_img : nullptr);
-  stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
-  // dO is zero on padded tokens (the reference crops them away, swin.py:247-248)
-  stage_part<BF16, D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img, BF16 ? dot_img : nullptr);
-  if constexpr (BF16) {
-    zero_t_tail<BF16, D>(qt_img);
-    zero_t_tail<BF16, D>(kt_img);
-    zero_t_tail<BF16, D>(dot_img);
+  bool fused = false;
+  if constexpr (BF16 && std::is_same_v<TIn, __bf16>) {
+    if (g.vec_ok) {
+      fused = true;
+      stage_bwd_bf16<D>(g, id, pix, qkv, qkv_bias, out, grad_out, col, q_img, qt_img, k_img, kt_img, v_img, do_img,
+                        dot_img, delta_s);
+      zero_t_tail<BF16, D>(qt_img);
+      zero_t_tail<BF16, D>(kt_img);
+      zero_t_tail<BF16, D>(dot_img);
+    }
   }
-  // delta[q] = sum_d dO[q][d] * O[q][d]
-  {
+  if (!fused) {
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, BF16 ? qt_img : nullptr);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, BF16 ? kt_img : nullptr);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
+    // dO is zero on padded tokens (the reference crops them away, swin.py:247-248)
+    stage_part<BF16, D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img, BF16 ? dot_img : nullptr);
+    if constexpr (BF16) {
+      zero_t_tail<BF16, D>(qt_img);
+      zero_t_tail<BF16, D>(kt_img);
+      zero_t_tail<BF16, D>(dot_img);
+    }
+    // delta[q] = sum_d dO[q][d] * O[q][d]
     constexpr int CH = D / 8;
     for (int idx = threadIdx.x; idx < g.N * CH; idx += blockDim.x) {
       const int t = idx / CH, c8 = (idx - t * CH) * 8;
@@ -308,12 +439,13 @@ __global__ void __launch_bounds__(256) k_window_attn_bwd(const TIn* __restrict__
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = threadIdx.x >> 8;
+  const int r = lane & 31, h = lane >> 5;
   const int nblk = (g.N + 31) / 32;
   constexpr int NCB = (D + 31) / 32;
   const int64_t row0 = (int64_t)id.b * g.H * g.W;
 
-  if (wave < nblk) {
+  if (wave < nblk && part == 0) {
     // ---- part 1: lane = query.  dS^T tiles, relative-position-bias gradient, dQ
     const int q = 32 * wave + r;
     const float my_lse = lse_s[q], my_delta = delta_s[q];
@@ -355,7 +487,8 @@ __global__ void __launch_bounds__(256) k_window_attn_bwd(const TIn* __restrict__
         else atomicAdd(&grad_pad[col + dcol], dq[cb][i]);
       }
     }
-
+  }
+  if (wave < nblk && part == 1) {
     // ---- part 2: wave = key block.  dK, dV
     const int kb = wave;
     f32x16 dk[NCB], dv[NCB];
@@ -418,6 +551,7 @@ bool make_geom(int batch, int H, int W, int C, int heads, int ws, int shift, Win
   g.nWh = g.Hp / ws;
   g.nWw = g.Wp / ws;
   g.N = ws * ws;
+  g.vec_ok = 0;
   return true;
 }
 
@@ -428,10 +562,12 @@ int launch_fwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
   const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(256);
   const TIn* q = reinterpret_cast<const TIn*>(qkv);
   TIn* o = reinterpret_cast<TIn*>(out);
+  WinGeom gv = g;
+  gv.vec_ok = BF16 && g.C % 8 == 0 && (reinterpret_cast<size_t>(qkv) & 15) == 0;
   switch (D) {
-    case 16: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
-    case 32: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
-    case 64: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, g, scale, o, lse); break;
+    case 16: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, gv, scale, o, lse); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, gv, scale, o, lse); break;
+    case 64: hipLaunchKernelGGL((k_window_attn_fwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, gv, scale, o, lse); break;
     default: return MBV_ERR_UNSUPPORTED;
   }
   MBV_CHECK_LAUNCH();
@@ -443,15 +579,18 @@ int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
                const void* grad_out, const float* lse, void* grad_qkv, float* grad_table, float* grad_pad,
                hipStream_t stream) {
   const float scale = 1.0f / sqrtf((float)D);
-  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(256);
+  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(512);
   const TIn* q = reinterpret_cast<const TIn*>(qkv);
   const TIn* o = reinterpret_cast<const TIn*>(out);
   const TIn* go = reinterpret_cast<const TIn*>(grad_out);
   TIn* gq = reinterpret_cast<TIn*>(grad_qkv);
+  WinGeom gv = g;
+  gv.vec_ok = BF16 && g.C % 8 == 0 &&
+              ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(grad_out)) & 15) == 0;
   switch (D) {
-    case 16: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
-    case 32: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
-    case 64: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, g, scale, gq, grad_table, grad_pad); break;
+    case 16: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
+    case 64: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
     default: return MBV_ERR_UNSUPPORTED;
   }
   MBV_CHECK_LAUNCH();
