@@ -262,7 +262,7 @@ class _PillarFeatureNet(torch.autograd.Function):
                 else:
                     ca = int(a_prev.shape[1])
                     wa, wb = w[:, :ca], w[:, ca:]
-                    gw = torch.cat([_wgrad(dy, a_prev) + dypad.t().mm(apad_prev), dt.t().mm(m_prev)], dim=1)
+                    gw = torch.cat([_wgrad(dy, a_prev) + _wgrad(dypad, apad_prev), _wgrad(dt, m_prev)], dim=1)
                     da = dy.mm(wa)
                     sapad = dypad.mm(wa)
                     dm = dt.mm(wb)
@@ -441,7 +441,7 @@ def _wgrad_splits(tokens: int) -> int:
     """The weight gradient dW = dY^T X has tiny M x N (channels) and K = tokens (up to 65 536): one library GEMM
     under-fills the chip (measured 290 us vs 47 us at T = 65 536, 192 -> 576, MI355X).  Split K into chunks
     solved as one batched GEMM and reduce the partials in f32."""
-    for s, t in ((32, 32768), (8, 8192)):
+    for s, t in ((128, 131072), (32, 32768), (8, 8192)):
         if tokens >= t:
             return s
     return 1
