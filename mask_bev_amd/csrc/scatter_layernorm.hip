@@ -63,19 +63,19 @@ __global__ void k_ln_finalize(const double* __restrict__ sums, int batch, double
 // ---------------------------------------------------------------------------------------------
 // tile helpers.  A block owns one BEV row y, XT = 64*VEC consecutive cells and kCT channels.
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int THREADS = 256>
 struct Tile {
   static constexpr int XT = 64 * VEC;          // cells per tile
   static constexpr int LD = XT + 4;            // padded row (keeps float4 reads 16 B aligned)
-  static constexpr int GROUPS = 256 / XT;      // threads sharing one cell in the gather phase
+  static constexpr int GROUPS = THREADS / XT;  // threads sharing one cell in the gather phase
   static constexpr int CH_PER_THREAD = kCT / GROUPS;
 };
 
 // gather feats[pid][c0 .. c0+kCT) of the tile's cells into lds[c][x] (zeros for empty cells)
-template <int VEC>
+template <int VEC, int THREADS = 256>
 __device__ __forceinline__ void gather_tile(const float* __restrict__ feats, int channels, int c0, int32_t pid,
                                             float* __restrict__ lds) {
-  using T = Tile<VEC>;
+  using T = Tile<VEC, THREADS>;
   const int cell = threadIdx.x % T::XT;
   const int grp = threadIdx.x / T::XT;
   const int cbeg = grp * T::CH_PER_THREAD;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
 // occupied cells scattered back into (pillar, channel) rows.
 // ---------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ grad_out,
+__global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ grad_out,
                                                       const float* __restrict__ feats,
                                                       const int32_t* __restrict__ cell_to_pillar,
                                                       const float* __restrict__ weight,
@@ -189,9 +189,18 @@ __global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ 
                                                       int ny, int nx, int xtiles, float* __restrict__ grad_feats,
                                                       float* __restrict__ grad_weight, float* __restrict__ grad_bias,
                                                       int accumulate, double* __restrict__ sums /* [batch][2] */) {
-  using T = Tile<VEC>;
+  // 8 waves x 4 channels (126 VGPRs: two workgroups per CU).  Per scan the 4 grad_out vectors of a thread are
+  // requested FIRST, so that they are in flight underneath the two dependent round trips of the gather (cell →
+  // pillar id → pillar row), and the pillar id of the next scan is prefetched.  The per-scan sums meet in LDS and
+  // leave as one pair of f64 atomics per block and scan after the loop.  (Measured at B=4, 128 x 512 x 512:
+  // 463 us with 4 waves x 8 channels and the reduction + atomics inside the loop, 244 us in this form; a
+  // register-only variant without the LDS tile — occupied cells as per-lane float4 loads — ran at 300-370 us:
+  // its dependent, divergent loads sit on every wave's critical path.)
+  constexpr int THREADS = 512, WAVES = THREADS / 64, CPW = kCT / WAVES;
+  using T = Tile<VEC, THREADS>;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
-  __shared__ double red[2][4];
+  constexpr int MAXB = 16;
+  __shared__ double acc[MAXB][2][WAVES];
   const int y = blockIdx.x / xtiles;
   const int x0 = (blockIdx.x % xtiles) * T::XT;
   const int c0 = blockIdx.y * kCT;
@@ -199,72 +208,90 @@ __global__ void __launch_bounds__(256) k_ln_bwd_dense(const float* __restrict__ 
   const int64_t cells = (int64_t)ny * nx;
   const int xv = x0 + lane * VEC;
   const bool x_ok = xv < nx;
-  float w[8][VEC], dw[8][VEC], db[8][VEC];
+  float w[CPW][VEC], dw[CPW][VEC], db[CPW][VEC];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int c = c0 + wave * 8 + k;
+  for (int k = 0; k < CPW; ++k) {
+    const int c = c0 + wave * CPW + k;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; dw[k][e] = 0.f; db[k][e] = 0.f; }
     if (x_ok && c < channels) load_vec<VEC>(weight + ((int64_t)c * ny + y) * nx + xv, w[k]);
   }
   const int gcell = threadIdx.x % T::XT;
   const int grp = threadIdx.x / T::XT;
-  for (int b = 0; b < batch; ++b) {
-    const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
-    int32_t pid = -1;
-    if (x0 + gcell < nx) pid = cell_to_pillar[(int64_t)b * cells + (int64_t)y * nx + x0 + gcell];
-    gather_tile<VEC>(feats, channels, c0, pid, lds);
-    __syncthreads();
-    float s1f = 0.f, s2f = 0.f;   // <= 32 terms per thread and scan: f32 partials, f64 across threads
-    if (x_ok) {
+  for (int bb0 = 0; bb0 < batch; bb0 += MAXB) {
+    int32_t pid_next = -1;
+    if (x0 + gcell < nx) pid_next = cell_to_pillar[(int64_t)bb0 * cells + (int64_t)y * nx + x0 + gcell];
+    const int bend = min(batch, bb0 + MAXB);
+#pragma unroll 1
+    for (int b = bb0; b < bend; ++b) {
+      const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+      const int32_t pid = pid_next;
+      float g[CPW][VEC];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int cl = wave * 8 + k;
-        const int c = c0 + cl;
-        if (c < channels) {
-          float f[VEC], g[VEC], gw[VEC];
-          load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
-          load_vec<VEC>(grad_out + (((int64_t)b * channels + c) * ny + y) * nx + xv, g);
+      for (int k = 0; k < CPW; ++k) {
+        const int c = c0 + wave * CPW + k;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float xhat = (f[e] - mean) * rstd;
-            dw[k][e] += g[e] * xhat;
-            db[k][e] += g[e];
-            gw[e] = g[e] * w[k][e];
-            s1f += gw[e];
-            s2f += gw[e] * xhat;
+        for (int e = 0; e < VEC; ++e) g[k][e] = 0.f;
+        if (x_ok && c < channels) load_vec<VEC>(grad_out + (((int64_t)b * channels + c) * ny + y) * nx + xv, g[k]);
+      }
+      pid_next = -1;
+      if (b + 1 < bend && x0 + gcell < nx)
+        pid_next = cell_to_pillar[(int64_t)(b + 1) * cells + (int64_t)y * nx + x0 + gcell];
+      gather_tile<VEC, THREADS>(feats, channels, c0, pid, lds);
+      __syncthreads();
+      float s1f = 0.f, s2f = 0.f;   // <= 16 terms per thread and scan: f32 partials, f64 across threads
+      if (x_ok) {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int cl = wave * CPW + k;
+          const int c = c0 + cl;
+          if (c < channels) {
+            float f[VEC], gw[VEC];
+            load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float xhat = (f[e] - mean) * rstd;
+              dw[k][e] += g[k][e] * xhat;
+              db[k][e] += g[k][e];
+              gw[e] = g[k][e] * w[k][e];
+              s1f += gw[e];
+              s2f += gw[e] * xhat;
+            }
+            store_vec<VEC>(&lds[cl * T::LD + lane * VEC], gw);
           }
-          store_vec<VEC>(&lds[cl * T::LD + lane * VEC], gw);
         }
       }
-    }
-    const double s1 = wave_sum_d((double)s1f);
-    const double s2 = wave_sum_d((double)s2f);
-    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      atomicAdd(&sums[b * 2 + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-      atomicAdd(&sums[b * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-    }
-    // scatter g*w of the occupied cells back to (pillar, channel) rows
-    if (pid >= 0) {
-      const int cbeg = grp * T::CH_PER_THREAD;
+      const double s1 = wave_sum_d((double)s1f);
+      const double s2 = wave_sum_d((double)s2f);
+      if (lane == 0) { acc[b - bb0][0][wave] = s1; acc[b - bb0][1][wave] = s2; }
+      __syncthreads();
+      // scatter g*w of the occupied cells back to (pillar, channel) rows
+      if (pid >= 0) {
+        const int cbeg = grp * T::CH_PER_THREAD;
 #pragma unroll
-      for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
-        const int c = c0 + cbeg + k;
-        if (c < channels) {
-          const float4 v = make_float4(lds[(cbeg + k + 0) * T::LD + gcell], lds[(cbeg + k + 1) * T::LD + gcell],
-                                       lds[(cbeg + k + 2) * T::LD + gcell], lds[(cbeg + k + 3) * T::LD + gcell]);
-          *reinterpret_cast<float4*>(grad_feats + (int64_t)pid * channels + c) = v;
+        for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
+          const int c = c0 + cbeg + k;
+          if (c < channels) {
+            const float4 v = make_float4(lds[(cbeg + k + 0) * T::LD + gcell], lds[(cbeg + k + 1) * T::LD + gcell],
+                                         lds[(cbeg + k + 2) * T::LD + gcell], lds[(cbeg + k + 3) * T::LD + gcell]);
+            *reinterpret_cast<float4*>(grad_feats + (int64_t)pid * channels + c) = v;
+          }
         }
       }
+      __syncthreads();
+    }
+    // one pair of f64 atomics per block and scan (the waves' sums met in LDS, ordered by the barriers above)
+    if ((int)threadIdx.x < 2 * (bend - bb0)) {
+      const int bi = threadIdx.x >> 1, j = threadIdx.x & 1;
+      atomicAdd(&sums[(bb0 + bi) * 2 + j], ((acc[bi][j][0] + acc[bi][j][1]) + (acc[bi][j][2] + acc[bi][j][3])) +
+                                               ((acc[bi][j][4] + acc[bi][j][5]) + (acc[bi][j][6] + acc[bi][j][7])));
     }
     __syncthreads();
   }
   if (x_ok) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = c0 + wave * 8 + k;
+    for (int k = 0; k < CPW; ++k) {
+      const int c = c0 + wave * CPW + k;
       if (c < channels) {
         const int64_t o = ((int64_t)c * ny + y) * nx + xv;
         if (accumulate) {
@@ -363,12 +390,12 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL(k_ln_bwd_dense<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL(k_ln_bwd_dense<4>, dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL(k_ln_bwd_dense<1>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL(k_ln_bwd_dense<1>, dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   }
