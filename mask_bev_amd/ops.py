@@ -305,6 +305,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         check(rc, 'mbv_scatter_layernorm_fwd')
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
+        ctx.params = (weight, bias)
         return out
 
     @staticmethod
@@ -316,14 +317,24 @@ class _ScatterLayerNorm(torch.autograd.Function):
         grad_out = grad_out.to(torch.float32).contiguous()
         dev = feats.device
         g_feats = torch.empty_like(feats)
-        g_w = torch.empty_like(weight)
-        g_b = torch.empty_like(weight)
+        wp, bp = ctx.params
+        direct = all(getattr(t, '_mbv_arena', False) and t.grad is not None and t.grad.dtype == torch.float32
+                     and t.grad.is_contiguous() for t in (wp, bp))
+        if direct:          # the two 134 MB affine gradients accumulate straight into the arena (no temporaries)
+            g_w, g_b = wp.grad, bp.grad
+        else:
+            g_w = torch.empty_like(weight)
+            g_b = torch.empty_like(weight)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), _ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar),
                                            _ptr(weight), _ptr(stats), batch, c, ny, nx, int(feats.shape[0]),
-                                           _ptr(g_feats), _ptr(g_w), _ptr(g_b), 0, _ptr(ws), ws.numel(), _stream(),
-                                           *TIMER.events('k_ln_bwd_dense')[2:])
+                                           _ptr(g_feats), _ptr(g_w), _ptr(g_b), 1 if direct else 0, _ptr(ws),
+                                           ws.numel(), _stream(), *TIMER.events('k_ln_bwd_dense')[2:])
         check(rc, 'mbv_scatter_layernorm_bwd')
+        if direct:
+            _fire_grad_hooks(wp)
+            _fire_grad_hooks(bp)
+            return g_feats, None, None, None, None, None, None, None, None
         return g_feats, g_w, g_b, None, None, None, None, None, None
 
 
