@@ -167,15 +167,23 @@ def main():
         # output; bwd reads grad_out and weight, writes grad_weight+grad_bias.  V*C*4 pillar rows are < 2 % and
         # left out (stated in DESIGN.md), as is the 4 B/cell map.
         cells = nx * ny
+        acc = 0 if args.no_arena else 2 * c * cells          # arena: d(weight), d(bias) are read and accumulated into
+        n_params = sum(p.numel() for p in model.parameters())
         algo = {'k_ln_apply': (2 * c * cells + args.batch * c * cells) * 4.0,
-                'k_ln_bwd_dense': (args.batch * c * cells + c * cells + 2 * c * cells) * 4.0}
+                'k_ln_bwd_dense': (args.batch * c * cells + c * cells + 2 * c * cells + acc) * 4.0,
+                # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
+                'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
+        # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
+        # MI355X_MICROARCH.md); same workload, same build
+        traffic = {'k_ln_apply': 826.1e6, 'k_ln_bwd_dense': 1249.9e6, 'k_adamw': 6511.5e6} \
+            if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena) else {}
         roof = {}
         for name, ms in times.items():
-            if not ms:
+            if not ms or name not in algo:
                 continue
             avg = sum(ms) / len(ms)
             roof[name] = dict(bound='hbm', achieved=algo[name] / (avg * 1e-3) / 1e9, peak=8000.0, unit='GB/s',
-                              frac=algo[name] / (avg * 1e-3) / 1e9 / 8000.0, traffic=None,
+                              frac=algo[name] / (avg * 1e-3) / 1e9 / 8000.0, traffic=traffic.get(name),
                               kernel=name, avg_ms=avg, launches=len(ms), algorithmic_bytes=algo[name])
         dominant = max(roof.values(), key=lambda r: r['avg_ms']) if roof else None
         line = dict(

@@ -23,7 +23,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 _ALIGN = 64          # elements: every parameter starts on a 256-byte boundary
@@ -171,11 +171,12 @@ class FlatAdam(torch.optim.Optimizer):
             if b == a:
                 continue
             sh = 0 if ar.shadow is None else ar.shadow.data_ptr() + 2 * a
-            check(lib.mbv_adamw_step(ar.param.data_ptr() + 4 * a, ar.grad.data_ptr() + 4 * a,
-                                     self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, sh, b - a,
-                                     lr, b1, b2, eps, wd, self.steps, float(self.grad_scale),
-                                     1 if self.decoupled else 0, 1 if self.zero_grad_in_step else 0, stream),
-                  'mbv_adamw_step')
+            with ops.TIMER.span('k_adamw'):
+                check(lib.mbv_adamw_step(ar.param.data_ptr() + 4 * a, ar.grad.data_ptr() + 4 * a,
+                                         self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, sh,
+                                         b - a, lr, b1, b2, eps, wd, self.steps, float(self.grad_scale),
+                                         1 if self.decoupled else 0, 1 if self.zero_grad_in_step else 0, stream),
+                      'mbv_adamw_step')
         return loss
 
     def zero_grad(self, set_to_none: bool = False):

@@ -48,6 +48,28 @@ class KernelTimer:
         self.records.setdefault(name, []).append((a, b))
         return a, b, ctypes.c_void_p(a.cuda_event), ctypes.c_void_p(b.cuda_event)
 
+    def span(self, name: str):
+        """Context manager: HIP events on torch's current stream around a C-ABI call that launches exactly one
+        kernel on that stream (K11's optimizer step)."""
+        timer = self
+
+        class _Span:
+            def __enter__(self_inner):
+                self_inner.ev = None
+                if timer.enabled:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    self_inner.ev = (a, b)
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                if self_inner.ev is not None:
+                    self_inner.ev[1].record()
+                    timer.records.setdefault(name, []).append(self_inner.ev)
+                return False
+
+        return _Span()
+
     def summary_ms(self):
         torch.cuda.synchronize()
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.records.items()}

@@ -81,3 +81,54 @@ def test_gradient_allreduce_world2_matches_single_process():
         opt.zero_grad()
     for a, b in zip(p0, ref.parameters()):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mask_bev_amd.arena import ParameterArena
+    from mask_bev_amd.ddp import GradientAllReducer
+    torch.manual_seed(100 + rank)
+    enc, bb, head = nn.Linear(8, 32), nn.Linear(32, 16), nn.Linear(16, 1)
+    m = nn.Sequential(enc, nn.ReLU(), bb, nn.ReLU(), head)
+    red = GradientAllReducer(m, bucket_mb=0.001)           # broadcasts rank 0's parameters
+    red.no_sync(True)                                      # graph-step mode: no hook-driven buckets
+    arena = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None)
+    torch.manual_seed(7)
+    x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
+    idx = list(range(rank, 8, world))
+    for _ in range(2):
+        ((m(x_all[idx]) - y_all[idx]) ** 2).mean().backward()          # accumulates into the arena views
+        handles = red.start_arena(arena, ('head', 'backbone'), chunk_mb=0.0005)   # several chunks per segment
+        handles += red.start_arena(arena, ('encoder',), chunk_mb=0.0005)
+        red.finish_arena(arena, handles)                                # no optimizer hook → divides in place
+        with torch.no_grad():
+            arena.param.sub_(0.1 * arena.grad)
+        arena.zero_grad()
+    out[rank] = arena.param.clone()
+    dist.destroy_process_group()
+
+
+def test_arena_allreduce_world2_matches_single_process():
+    """The graph step's data-parallel exchange: contiguous chunks of the arena gradient, no bucket copies."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_arena_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0], out[1])
+    torch.manual_seed(100)
+    enc, bb, head = nn.Linear(8, 32), nn.Linear(32, 16), nn.Linear(16, 1)
+    ref = nn.Sequential(enc, nn.ReLU(), bb, nn.ReLU(), head)
+    torch.manual_seed(7)
+    x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
+    for _ in range(2):
+        gs = []
+        for r in range(2):
+            idx = list(range(r, 8, 2))
+            gs.append(torch.autograd.grad(((ref(x_all[idx]) - y_all[idx]) ** 2).mean(), list(ref.parameters())))
+        with torch.no_grad():
+            for p, g0, g1 in zip(ref.parameters(), *gs):
+                p.sub_(0.1 * (g0 + g1) / 2)
+    from mask_bev_amd.arena import ParameterArena
+    want = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None).param
+    assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-6)
