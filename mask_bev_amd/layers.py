@@ -164,7 +164,7 @@ class _AttnParams(nn.Module):
         super().__init__()
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dims, embed_dims))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dims))
-        self.out_proj = nn.Linear(embed_dims, embed_dims)
+        self.out_proj = Linear(embed_dims, embed_dims)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
