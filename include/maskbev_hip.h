@@ -279,9 +279,11 @@ int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* s
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
 
-/* Weight gradient of a Linear applied to few tokens (the decoder's B*Q query rows), exact f32:
- * acc (O, I) += g^T x with g (T, O), x (T, I) row-major f32; f32 MFMA, f32 atomics into acc. */
-int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc, void* stream);
+/* Weight (and bias) gradient of a Linear applied to few tokens (the decoder's B*Q query rows), exact f32:
+ * acc (O, I) += g^T x with g (T, O), x (T, I) row-major f32; bias_acc (O) += column sums of g when not NULL;
+ * f32 MFMA, f32 atomics into acc / bias_acc. */
+int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc, float* bias_acc,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K13 — row sums of the point-sampled mask losses and their gradient.

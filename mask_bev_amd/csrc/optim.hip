@@ -170,7 +170,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g, const float* __restrict__ x, int T,
                                                      int O, int I, int tiles_i, int ntiles, int rows_per_slice,
-                                                     float* __restrict__ acc) {
+                                                     float* __restrict__ acc, float* __restrict__ bias_acc) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tile = wg % ntiles, slice = wg / ntiles;
@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g
   f32x16_t c;
 #pragma unroll
   for (int k = 0; k < 16; ++k) c[k] = 0.f;
+  float bsum = 0.f;                       // bias gradient: the waves of the first column of tiles also sum g over t
   int tb = t0;                            // wave-uniform row base; half h of the wave reads row tb + 2u + h
   for (; tb + 8 <= t1; tb += 8) {
     float a[4], b[4];
@@ -194,6 +195,7 @@ __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], c, 0, 0, 0);
+    bsum += (a[0] + a[1]) + (a[2] + a[3]);
   }
   for (; tb < t1; tb += 2) {              // out-of-range rows contribute 0
     const int t = tb + h;
@@ -201,6 +203,11 @@ __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g
     const float a = (ov && tv) ? gp[(long)t * O] : 0.f;
     const float b = (iv && tv) ? xp[(long)t * I] : 0.f;
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    bsum += a;
+  }
+  if (bias_acc && i0 == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0 && ov) atomicAdd(bias_acc + o0 + r, bsum);
   }
   if (iv) {
 #pragma unroll
@@ -273,7 +280,7 @@ extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, in
 }
 
 extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, int32_t O, int32_t I, float* acc,
-                                   void* stream) {
+                                   float* bias_acc, void* stream) {
   if (T < 0 || O <= 0 || I <= 0 || !g || !x || !acc) return MBV_ERR_BAD_ARG;
   if (T == 0) return MBV_OK;
   const int tiles_o = (O + 31) / 32, tiles_i = (I + 31) / 32;
@@ -287,7 +294,7 @@ extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, in
   slices = (T + rows_per_slice - 1) / rows_per_slice;
   const long waves = (long)ntiles * slices;
   hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, x, T, O,
-                     I, tiles_i, ntiles, rows_per_slice, acc);
+                     I, tiles_i, ntiles, rows_per_slice, acc, bias_acc);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

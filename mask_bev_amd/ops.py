@@ -522,26 +522,30 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
                                _stream()), 'mbv_colsum_accum')
 
 
-def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor):
-    """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add)."""
+def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc: Optional[torch.Tensor] = None) -> bool:
+    """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add).
+    Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch."""
     t = g2.shape[0]
     if (g2.dtype == torch.float32 and x2.dtype == torch.float32 and t <= _SMALL_F32_ROWS and g2.is_cuda
             and acc.is_contiguous()):
         lib = _lib.load()
         g2, x2 = g2.contiguous(), x2.contiguous()
-        check(lib.mbv_wgrad_small_f32(_ptr(g2), _ptr(x2), t, g2.shape[1], x2.shape[1], _ptr(acc), _stream()),
+        fuse = bias_acc is not None and bias_acc.is_contiguous() and bias_acc.dtype == torch.float32
+        check(lib.mbv_wgrad_small_f32(_ptr(g2), _ptr(x2), t, g2.shape[1], x2.shape[1], _ptr(acc),
+                                      _ptr(bias_acc) if fuse else ctypes.c_void_p(0), _stream()),
               'mbv_wgrad_small_f32')
-        return
+        return fuse
     s = _wgrad_splits(t)
     od = {} if g2.dtype == torch.float32 else dict(out_dtype=torch.float32)
     if s == 1:
         torch.addmm(acc, g2.t(), x2, out=acc, **od)
-        return
+        return False
     c = t // s
     part = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1), **od)
     if s * c < t:
         torch.addmm(acc, g2[s * c:].t(), x2[s * c:], out=acc, **od)
     acc.add_(part.sum(0))
+    return False
 
 
 # Under autocast, f32 activations with at most this many rows (the decoder's B*Q query tokens) are multiplied in
@@ -579,18 +583,26 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = g2.mm(w).view_as(x)
+        bias_direct = (bias is not None and ctx.needs_input_grad[2] and getattr(bias, '_mbv_arena', False)
+                       and bias.grad is not None and bias.grad.dtype == torch.float32)
+        bias_done = False
         if ctx.needs_input_grad[1]:
             if getattr(weight, '_mbv_arena', False) and weight.grad is not None and weight.grad.dtype == torch.float32:
                 acc = weight.grad if rows is None else weight.grad[rows[0]:rows[1]]
-                _wgrad_into(acc, g2, x2)                    # straight into the arena gradient
+                bacc = None
+                if bias_direct:
+                    bacc = bias.grad if rows is None else bias.grad[rows[0]:rows[1]]
+                bias_done = _wgrad_into(acc, g2, x2, bacc)  # straight into the arena gradient
                 _fire_grad_hooks(weight)
+                if bias_done:
+                    _fire_grad_hooks(bias)
             elif rows is None:
                 gw = _wgrad(g2, x2).to(weight.dtype)
             else:
                 gw = torch.zeros_like(weight)
                 gw[rows[0]:rows[1]] = _wgrad(g2, x2)
-        if bias is not None and ctx.needs_input_grad[2]:
-            if getattr(bias, '_mbv_arena', False) and bias.grad is not None and bias.grad.dtype == torch.float32:
+        if bias is not None and ctx.needs_input_grad[2] and not bias_done:
+            if bias_direct:
                 colsum_accum(g2, bias.grad if rows is None else bias.grad[rows[0]:rows[1]])
                 _fire_grad_hooks(bias)
             elif rows is None:

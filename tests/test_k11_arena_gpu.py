@@ -168,8 +168,11 @@ def test_wgrad_small_f32(device, T, O, I):
     g = torch.randn(T, O, device=device)
     x = torch.randn(T, I, device=device)
     acc = torch.randn(O, I, device=device)
+    bacc = torch.randn(O, device=device)
     want = acc.double() + g.double().t() @ x.double()
-    rc = lib.mbv_wgrad_small_f32(g.data_ptr(), x.data_ptr(), T, O, I, acc.data_ptr(),
+    bwant = bacc.double() + g.double().sum(0)
+    rc = lib.mbv_wgrad_small_f32(g.data_ptr(), x.data_ptr(), T, O, I, acc.data_ptr(), bacc.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert torch.allclose(acc.double(), want, rtol=1e-5, atol=2e-5 * T ** 0.5)
+    assert torch.allclose(bacc.double(), bwant, rtol=1e-5, atol=2e-5 * T ** 0.5)
