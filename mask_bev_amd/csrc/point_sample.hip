@@ -113,10 +113,13 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
                                                                const float* __restrict__ coords,
                                                                const int32_t* __restrict__ coord_index, int P, int H,
                                                                int W, float* __restrict__ grad_src) {
-  __shared__ float tile[kTileFloats];
+  // f64 accumulators: on gfx950 an LDS ds_add_f32 wave instruction takes ≈ 192 cycles (the lanes are serialised),
+  // ds_add_f64 / ds_add_u64 ≈ 9-16 (scratch/ubench/lds_atomic.hip) — the f32 form of this kernel ran 1.0 ms, bound
+  // by exactly that.  128 KB for a 128 x 128 map; the sum is also order-independent to f32 precision.
+  __shared__ double tile[kTileFloats];
   const int g = blockIdx.x;
   const int hw = H * W;
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = 0.f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = 0.0;
   __syncthreads();
   const float* c = coords + (int64_t)coord_index[g] * P * 2;
   const float* go = grad_out + (int64_t)g * P;
@@ -126,11 +129,11 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
     const float gv = go[p];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], b.w[j] * gv);
+      if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], (double)(b.w[j] * gv));
   }
   __syncthreads();
   float* dst = grad_src + (int64_t)src_index[g] * hw;
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = tile[i];
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (float)tile[i];
 }
 
 __global__ void __launch_bounds__(256) k_point_sample_bwd_atomic(const float* __restrict__ grad_out,
