@@ -225,13 +225,13 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
   __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
   __shared__ uint8_t m_lds[NPAD * NPAD];
   __shared__ float lse_s[NPAD];
-  __shared__ float delta_s[NPAD];
+  __shared__ double delta_s[NPAD];     // f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   const AttnBlock blk = decode(g);
   const int col = blk.head * D;
   const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.E;
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     lse_s[t] = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
-    delta_s[t] = 0.f;
+    delta_s[t] = 0.0;
   }
   stage_rows<BF16, D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, BF16 ? qt_img : nullptr);
   stage_rows<BF16, D, TIn>(k, koff, g.E, blk.k0, blk.nk, col, k_img, BF16 ? kt_img : nullptr);
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += to_f(out[o + j]) * to_f(grad_out[o + j]);
-      atomicAdd(&delta_s[t], acc);
+      atomicAdd(&delta_s[t], (double)acc);
     }
   }
   __syncthreads();
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
 
   if (wave < nqb) {   // ---- part 1: lane = query → dQ partial of this key split
     const int ql = 32 * wave + r;
-    const float my_lse = lse_s[ql], my_delta = delta_s[ql];
+    const float my_lse = lse_s[ql], my_delta = (float)delta_s[ql];
     f32x16 dq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
         float p = 0.f, d = 0.f;
         if (!m_lds[qq * NPAD + kl]) {
           p = __expf(s[i] * scale - lse_s[qq]);
-          d = p * (dp[i] - delta_s[qq]) * scale;
+          d = p * (dp[i] - (float)delta_s[qq]) * scale;
         }
         s[i] = p;
         ds[i] = d;

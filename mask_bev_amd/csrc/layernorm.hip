@@ -119,10 +119,10 @@ struct LnBwdIo {
 
 template <int ITERS>
 __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C) {
-  extern __shared__ float red[];     // [2][C]
+  extern __shared__ double red[];    // [2][C]; f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
-  for (int i = threadIdx.x; i < 2 * C; i += 512) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += 512) red[i] = 0.0;
   __syncthreads();
   float4 dg[ITERS], db[ITERS];
 #pragma unroll
@@ -178,15 +178,15 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
   for (int i = 0; i < ITERS; ++i) {
     const int v = lane + 64 * i;
     if (v < nvec) {
-      atomicAdd(&red[4 * v + 0], dg[i].x); atomicAdd(&red[4 * v + 1], dg[i].y);
-      atomicAdd(&red[4 * v + 2], dg[i].z); atomicAdd(&red[4 * v + 3], dg[i].w);
-      atomicAdd(&red[C + 4 * v + 0], db[i].x); atomicAdd(&red[C + 4 * v + 1], db[i].y);
-      atomicAdd(&red[C + 4 * v + 2], db[i].z); atomicAdd(&red[C + 4 * v + 3], db[i].w);
+      atomicAdd(&red[4 * v + 0], (double)dg[i].x); atomicAdd(&red[4 * v + 1], (double)dg[i].y);
+      atomicAdd(&red[4 * v + 2], (double)dg[i].z); atomicAdd(&red[4 * v + 3], (double)dg[i].w);
+      atomicAdd(&red[C + 4 * v + 0], (double)db[i].x); atomicAdd(&red[C + 4 * v + 1], (double)db[i].y);
+      atomicAdd(&red[C + 4 * v + 2], (double)db[i].z); atomicAdd(&red[C + 4 * v + 3], (double)db[i].w);
     }
   }
   __syncthreads();
   float* prow = io.partial + (long)blockIdx.x * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 512) prow[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * C; i += 512) prow[i] = (float)red[i];
 }
 
 // dgamma[c] += Σ_blocks partial[blk][0][c], dbeta likewise.  Block = 64 columns x 4 slices over one chunk of 64
@@ -279,7 +279,7 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
   LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, partial_ws};
   const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
   const dim3 grid(nblk), block(512);
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(double);
   switch (it) {
     case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
     case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;

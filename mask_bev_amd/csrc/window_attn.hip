@@ -176,7 +176,7 @@ __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& 
                                                const __bf16* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                const __bf16* __restrict__ out, const __bf16* __restrict__ grad_out,
                                                int col, __bf16* q_img, __bf16* qt_img, __bf16* k_img, __bf16* kt_img,
-                                               __bf16* v_img, __bf16* do_img, __bf16* dot_img, float* delta_s) {
+                                               __bf16* v_img, __bf16* do_img, __bf16* dot_img, double* delta_s) {
   constexpr int CH = D / 8;
   const int C3 = 3 * g.C;
 #pragma unroll 2
@@ -213,7 +213,7 @@ __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& 
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += (float)o.h[j] * (float)d.h[j];
-      atomicAdd(&delta_s[t], acc);
+      atomicAdd(&delta_s[t], (double)acc);
     }
   }
 }
@@ -376,16 +376,16 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   __shared__ __attribute__((aligned(16))) T qt_img[BF16 ? L::T_IMG : 1];
   __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
   __shared__ float tbl[21 * 21];
-  __shared__ float dtbl[21 * 21];
+  __shared__ double dtbl[21 * 21];     // f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   __shared__ int kinfo[NPAD];
   __shared__ int pix[NPAD];
   __shared__ float lse_s[NPAD];
-  __shared__ float delta_s[NPAD];
+  __shared__ double delta_s[NPAD];
   const BlockId id = decode_block(g);
   const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
   for (int i = threadIdx.x; i < tsz; i += blockDim.x) {
     tbl[i] = bias_table[i * g.heads + id.head];
-    dtbl[i] = 0.f;
+    dtbl[i] = 0.0;
   }
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     if (t < g.N) {
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
       pix[t] = -1;
       lse_s[t] = 0.f;
     }
-    delta_s[t] = 0.f;
+    delta_s[t] = 0.0;
   }
   __syncthreads();
   const int C3 = 3 * g.C, col = id.head * D;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += to_f(out[o + j]) * to_f(grad_out[o + j]);
-      atomicAdd(&delta_s[t], acc);
+      atomicAdd(&delta_s[t], (double)acc);
     }
   }
   __syncthreads();
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   if (wave < nblk && part == 0) {
     // ---- part 1: lane = query.  dS^T tiles, relative-position-bias gradient, dQ
     const int q = 32 * wave + r;
-    const float my_lse = lse_s[q], my_delta = delta_s[q];
+    const float my_lse = lse_s[q], my_delta = (float)delta_s[q];
     f32x16 dq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
           const float bm = bias_mask(tbl, kinfo, g.ws, q, k, &idx);
           const float p = __expf(s[i] * scale + bm - my_lse);
           ds = p * (dp[i] - my_delta);
-          atomicAdd(&dtbl[idx], ds);
+          atomicAdd(&dtbl[idx], (double)ds);
         }
         s[i] = ds * scale;                       // dQ = scale * dS K
       }
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
         float p = 0.f, d = 0.f;
         if (qq < g.N && k < g.N) {
           p = __expf(s[i] * scale + bias_mask(tbl, kinfo, g.ws, qq, k, nullptr) - lse_s[qq]);
-          d = p * (dp[i] - delta_s[qq]) * scale;
+          d = p * (dp[i] - (float)delta_s[qq]) * scale;
         }
         s[i] = p;
         ds[i] = d;
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < tsz; i += blockDim.x) atomicAdd(&grad_table[i * g.heads + id.head], dtbl[i]);
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) atomicAdd(&grad_table[i * g.heads + id.head], (float)dtbl[i]);
 }
 
 bool make_geom(int batch, int H, int W, int C, int heads, int ws, int shift, WinGeom& g) {
