@@ -159,7 +159,10 @@ int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats,
  * (B, Nq, H, L, P, 2) f32 in [0, 1] (x, y); attn_weight (B, Nq, H, L, P) f32; out (B, Nq, H*D) f32.
  * Bilinear sampling at loc*size - 0.5 with zero padding (grid_sample align_corners=False).
  * head_dim must be a power of two <= 64.  Backward zero-fills grad_value itself, then accumulates with
- * f32 atomics (sums may differ in the last bits from run to run).
+ * f32 atomics (sums may differ in the last bits from run to run).  spatial_shapes_host (nullable): the same (L, 2)
+ * shapes in HOST memory; when given and num_query == num_value (self-attention over the multi-scale map, queries
+ * in level-major raster order), the backward accumulates bands of every level's map in LDS (f64) and only the
+ * flushed bands and out-of-band corners reach grad_value as global atomics.
  */
 int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
                            const float* sampling_loc, const float* attn_weight,
@@ -171,7 +174,8 @@ int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int6
                            const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
                            int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
                            int32_t num_levels, int32_t num_query, int32_t num_points,
-                           float* grad_value, float* grad_loc, float* grad_attn, void* stream);
+                           const int64_t* spatial_shapes_host, float* grad_value, float* grad_loc, float* grad_attn,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4 — fused shifted-window multi-head attention (between the qkv and the output projection).

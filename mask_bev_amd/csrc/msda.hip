@@ -142,6 +142,170 @@ __global__ void __launch_bounds__(256) k_msda_bwd(const float* __restrict__ grad
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward, banded form (self-attention over the multi-scale token map: num_query == num_value, queries in the
+// same level-major raster order as the values).  One workgroup owns a BAND of rows of one level's (h, w) map of
+// one (batch, head) as f64 accumulators in LDS (128 KB: 16 rows of a 32-wide level, 8 rows of a 64-wide one) and
+// processes the queries whose reference row falls into that band (contiguous query ranges, one per query level).
+// A bilinear corner inside the band is a ds_add_f64 (≈ 10 cycles per wave instruction; ds_add_f32 would be ≈ 190,
+// scratch/ubench/lds_atomic.hip); a corner that a large offset carries outside the band is a direct global f32
+// atomic.  Every (query, point) is handled exactly once, so the result does not depend on how well the
+// reference-row heuristic matches the learned offsets — only the share of global atomics does.  The band leaves as
+// one flush in the full-rate atomic shape.  Global float atomics drop from 1.06 GB per launch to the flushes
+// (≈ 100 MB) plus the out-of-band corners.
+// sum over each aligned group of 32 lanes on the DPP network (no LDS crossbar traffic next to the LDS atomics):
+// row_shr 1/2/4/8 inside the 16-lane rows, row_bcast:15 into the odd rows; lanes 31 and 63 hold the group sums.
+__device__ __forceinline__ float group32_sum_dpp(float v) {
+#define MBV_DPP_ADD(ctrl, rmask)                                                                              \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true));
+  MBV_DPP_ADD(0x111, 0xf)   // row_shr:1
+  MBV_DPP_ADD(0x112, 0xf)   // row_shr:2
+  MBV_DPP_ADD(0x114, 0xf)   // row_shr:4
+  MBV_DPP_ADD(0x118, 0xf)   // row_shr:8
+  MBV_DPP_ADD(0x142, 0xa)   // row_bcast:15 (rows 1 and 3 receive lane 15 of rows 0 and 2)
+#undef MBV_DPP_ADD
+  return v;
+}
+
+struct MsdaBands {
+  int levels;
+  int h[8], w[8], lstart[8], band_rows[8], bands[8], chunks[8], block_begin[9];
+};
+
+__global__ void __launch_bounds__(1024) k_msda_bwd_banded(const float* __restrict__ grad_out,
+                                                         const float* __restrict__ value,
+                                                         const float* __restrict__ loc, const float* __restrict__ attn,
+                                                         MsdaBands cfg, int num_value, int heads, int dim, int points,
+                                                         float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                                         float* __restrict__ grad_attn) {
+  __shared__ double map[16384];
+  int level = 0;
+  while (level + 1 < cfg.levels && (int)blockIdx.x >= cfg.block_begin[level + 1]) ++level;
+  const int local = blockIdx.x - cfg.block_begin[level];
+  const int chunks = cfg.chunks[level], bands = cfg.bands[level];
+  const int chunk = local % chunks, band = (local / chunks) % bands, bh = local / (chunks * bands);
+  const int hd = bh % heads, b = bh / heads;
+  const int h = cfg.h[level], w = cfg.w[level], lstart = cfg.lstart[level], levels = cfg.levels;
+  const int R0 = band * cfg.band_rows[level], R1 = min(h, R0 + cfg.band_rows[level]);
+  const int map_n = (R1 - R0) * w * dim;
+  for (int i = threadIdx.x; i < map_n; i += 1024) map[i] = 0.0;
+  // queries whose reference row ((2 y + 1) h_l) / (2 h_q) lies in [R0, R1): one contiguous range per query level
+  int rbeg[8], rend[8], total = 0;
+#pragma unroll
+  for (int lq = 0; lq < 8; ++lq) {
+    rbeg[lq] = rend[lq] = 0;
+    if (lq < levels) {
+      const int hq = cfg.h[lq], wq = cfg.w[lq];
+      auto first_row = [&](int R) {          // smallest y with reference row >= R
+        const int num = 2 * hq * R - h;
+        int y = num <= 0 ? 0 : (num + 2 * h - 1) / (2 * h);
+        return y > hq ? hq : y;
+      };
+      rbeg[lq] = cfg.lstart[lq] + first_row(R0) * wq;
+      rend[lq] = cfg.lstart[lq] + (R1 >= h ? hq : first_row(R1)) * wq;
+      total += rend[lq] - rbeg[lq];
+    }
+  }
+  const int per = (total + chunks - 1) / chunks;
+  const int i0 = min(total, chunk * per), i1 = min(total, i0 + per);
+  const int d = threadIdx.x % dim, slot = threadIdx.x / dim, slots = 1024 / dim;
+  const int stride_pix = heads * dim;
+  const int64_t slab = ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + d;     // value / grad_value base
+  __syncthreads();
+  // one query per slot and iteration, its points U at a time: the loads of all U points, then their 4U value
+  // gathers, are issued together (16 waves per CU have to hide two dependent L2 round trips per query)
+  constexpr int U = 4;
+  const int nq_mine = i1 - i0;
+  for (int n0 = 0; n0 < nq_mine; n0 += slots) {              // wave-uniform trip count
+    const int n = n0 + slot;
+    const bool qlive = n < nq_mine;
+    int qi = i0 + (qlive ? n : nq_mine - 1);
+    int q = 0;
+#pragma unroll
+    for (int lq = 0; lq < 8; ++lq) {         // position qi of the concatenated ranges -> query index
+      const int cnt = rend[lq] - rbeg[lq];
+      if (qi >= 0 && qi < cnt) q = rbeg[lq] + qi;
+      qi -= cnt;
+    }
+    const int64_t qh = ((int64_t)b * num_value + q) * heads + hd;
+    const float go = grad_out[qh * dim + d];
+    for (int p0 = 0; p0 < points; p0 += U) {
+      bool live[U];
+      int64_t kk[U];
+      float lx[U], ly[U], aw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        live[u] = qlive && p0 + u < points;
+        kk[u] = (qh * levels + level) * points + (p0 + u < points ? p0 + u : points - 1);
+        lx[u] = loc[kk[u] * 2];
+        ly[u] = loc[kk[u] * 2 + 1];
+        aw[u] = attn[kk[u]];
+      }
+      Corner c[U];
+      bool inside[U];
+      float v[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        inside[u] = bilinear_setup(lx[u], ly[u], h, w, 1, c[u]);              // offsets in pixels
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[u][j] = 0.f;
+          if (inside[u] && c[u].off[j] >= 0) v[u][j] = value[slab + (int64_t)c[u].off[j] * stride_pix];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+        if (inside[u]) {
+          const float tg = go * aw[u];
+          if (live[u]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int off = c[u].off[j];
+              if (off >= 0) {
+                const int rel = off - R0 * w;
+                if (rel >= 0 && rel < (R1 - R0) * w) atomicAdd(&map[rel * dim + d], (double)(c[u].wgt[j] * tg));
+                else atomicAdd(grad_value + slab + (int64_t)off * stride_pix, c[u].wgt[j] * tg);
+              }
+            }
+          }
+          const float uh = 1.f - c[u].lh, uw = 1.f - c[u].lw;
+          const float val = c[u].wgt[0] * v[u][0] + c[u].wgt[1] * v[u][1] + c[u].wgt[2] * v[u][2] + c[u].wgt[3] * v[u][3];
+          const float gh = -uw * v[u][0] - c[u].lw * v[u][1] + uw * v[u][2] + c[u].lw * v[u][3];
+          const float gw = -uh * v[u][0] + uh * v[u][1] - c[u].lh * v[u][2] + c[u].lh * v[u][3];
+          g_w = go * val;
+          g_x = (float)w * gw * tg;
+          g_y = (float)h * gh * tg;
+        }
+        int writer = 0;                      // lane of the dim-group that ends up holding the sums
+        if (dim == 32) {
+          g_w = group32_sum_dpp(g_w);
+          g_x = group32_sum_dpp(g_x);
+          g_y = group32_sum_dpp(g_y);
+          writer = 31;
+        } else {
+          for (int o = dim >> 1; o > 0; o >>= 1) {
+            g_w += __shfl_xor(g_w, o, 64);
+            g_x += __shfl_xor(g_x, o, 64);
+            g_y += __shfl_xor(g_y, o, 64);
+          }
+        }
+        if (live[u] && d == writer) {
+          grad_attn[kk[u]] = g_w;
+          grad_loc[kk[u] * 2] = g_x;
+          grad_loc[kk[u] * 2 + 1] = g_y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t gbase = ((int64_t)b * num_value + lstart + R0 * w) * stride_pix + hd * dim;
+  for (int i = threadIdx.x; i < map_n; i += 1024) {
+    const double v = map[i];
+    if (v != 0.0) atomicAdd(grad_value + gbase + (int64_t)(i / dim) * stride_pix + (i % dim), (float)v);
+  }
+}
+
 bool pow2_le64(int d) { return d > 0 && d <= 64 && (d & (d - 1)) == 0; }
 
 }  // namespace
@@ -167,7 +331,8 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
                                       const int64_t* level_start, const float* sampling_loc,
                                       const float* attn_weight, int32_t batch, int32_t num_value, int32_t num_heads,
                                       int32_t head_dim, int32_t num_levels, int32_t num_query, int32_t num_points,
-                                      float* grad_value, float* grad_loc, float* grad_attn, void* stream_) {
+                                      const int64_t* spatial_shapes_host, float* grad_value, float* grad_loc,
+                                      float* grad_attn, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0 || num_points <= 0)
     return MBV_ERR_BAD_ARG;
@@ -176,6 +341,34 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
       !grad_loc || !grad_attn)
     return MBV_ERR_BAD_ARG;
   MBV_CHECK_HIP(mbv_fill_async(grad_value, 0, sizeof(float) * (size_t)batch * num_value * num_heads * head_dim, stream));
+  if (spatial_shapes_host && num_query == num_value && num_levels <= 8) {
+    // banded form: needs the level shapes on the host to size the bands, and the self-attention query order
+    MsdaBands cfg;
+    cfg.levels = num_levels;
+    const int bh = batch * num_heads;
+    int lstart = 0, blocks = 0;
+    bool ok = true;
+    for (int l = 0; l < num_levels; ++l) {
+      const int h = (int)spatial_shapes_host[2 * l], w = (int)spatial_shapes_host[2 * l + 1];
+      const int rows = 16384 / (w * head_dim);
+      if (h <= 0 || w <= 0 || rows < 1) { ok = false; break; }
+      cfg.h[l] = h; cfg.w[l] = w; cfg.lstart[l] = lstart;
+      cfg.band_rows[l] = rows < h ? rows : h;
+      cfg.bands[l] = (h + cfg.band_rows[l] - 1) / cfg.band_rows[l];
+      int chunks = 256 / (bh * cfg.bands[l]);
+      cfg.chunks[l] = chunks < 1 ? 1 : chunks;
+      cfg.block_begin[l] = blocks;
+      blocks += bh * cfg.bands[l] * cfg.chunks[l];
+      lstart += h * w;
+    }
+    if (ok && lstart == num_value) {
+      cfg.block_begin[num_levels] = blocks;
+      hipLaunchKernelGGL(k_msda_bwd_banded, dim3((unsigned)blocks), dim3(1024), 0, stream, grad_out, value, sampling_loc,
+                         attn_weight, cfg, num_value, num_heads, head_dim, num_points, grad_value, grad_loc, grad_attn);
+      MBV_CHECK_LAUNCH();
+      return MBV_OK;
+    }
+  }
   const int64_t total = (int64_t)batch * num_query * num_heads * head_dim;
   hipLaunchKernelGGL(k_msda_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, grad_out, value,
                      spatial_shapes, level_start, sampling_loc, attn_weight, total, num_value, num_heads, head_dim,

@@ -428,9 +428,10 @@ def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torc
 class _MSDeformAttn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, value, shapes_t, level_start, loc, attn):
+    def forward(ctx, value, shapes_t, level_start, loc, attn, shapes_host):
         lib = _lib.load()
         _need_gpu(value, shapes_t, level_start, loc, attn)
+        ctx.shapes_host = shapes_host
         value, loc, attn = value.contiguous(), loc.contiguous(), attn.contiguous()
         b, nv, nh, d = value.shape
         _, nq, _, nl, npnt, _ = loc.shape
@@ -452,19 +453,23 @@ class _MSDeformAttn(torch.autograd.Function):
         g_value = torch.empty_like(value)
         g_loc = torch.empty_like(loc)
         g_attn = torch.empty_like(attn)
+        host = None
+        if ctx.shapes_host is not None and len(ctx.shapes_host) == nl:       # banded LDS accumulation (K5)
+            host = (ctypes.c_int64 * (2 * nl))(*[int(v) for hw in ctx.shapes_host for v in hw])
         rc = lib.mbv_ms_deform_attn_bwd(_ptr(grad_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
-                                        _ptr(attn), b, nv, nh, d, nl, nq, npnt, _ptr(g_value), _ptr(g_loc),
+                                        _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(g_value), _ptr(g_loc),
                                         _ptr(g_attn), _stream())
         check(rc, 'mbv_ms_deform_attn_bwd')
-        return g_value, None, None, g_loc, g_attn
+        return g_value, None, None, g_loc, g_attn, None
 
 
 def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, level_start: torch.Tensor,
                    sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
     """value (B, N, H, D); sampling_locations (B, Nq, H, L, P, 2) in [0,1]; weights (B, Nq, H, L, P)
     → (B, Nq, H*D) f32.  Bilinear, zero padding, align_corners=False (K5, include/maskbev_hip.h)."""
+    host = None if spatial_shapes is None else tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDeformAttn.apply(value.float(), shapes_t, level_start, sampling_locations.float(),
-                               attention_weights.float())
+                               attention_weights.float(), host)
 
 
 # --------------------------------------------------------------------------------------
