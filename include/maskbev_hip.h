@@ -343,12 +343,14 @@ int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t nu
  * (mask_bev/models/networks/mask2former_head/mask2former_head.py:459) and :460-470 + :538-539
  * (F.interpolate bilinear → sigmoid() < 0.5 → repeat over heads; a row that would block every key is unblocked).
  * mask_embed (B, Q, C), mask_feature (B, C, pixels), logits (B, Q, pixels): all f32 (is_bf16 = 0, exact-f32 MFMA,
- * C even) or all bf16 (is_bf16 = 1, C % 16 == 0).
+ * C even) or all bf16 (is_bf16 = 1, C % 16 == 0); with bf16 inputs, logits_f32 != 0 stores the f32 accumulators
+ * as f32 logits (the loss consumes f32; saves the cast pass).
  * mbv_attn_mask_from_logits: logits (rows, H, W) → blocked (rows, h*w) u8 (1 = may not attend), kept once per
  * query (the reference materialises it 8x, once per head).
  */
 int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feature, int32_t is_bf16, int32_t batch,
-                        int32_t num_queries, int32_t channels, int64_t pixels, void* logits, void* stream);
+                        int32_t num_queries, int32_t channels, int64_t pixels, void* logits, int32_t logits_f32,
+                        void* stream);
 
 int mbv_attn_mask_from_logits(const void* logits, int32_t is_bf16, int64_t rows, int32_t H, int32_t W,
                               int32_t h, int32_t w, uint8_t* blocked, void* stream);

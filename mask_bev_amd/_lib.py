@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class MaskBevHipError(RuntimeError):
@@ -66,7 +66,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_packed_mask_words': (_L, [_I, _I]),
     'mbv_pack_binary_masks': (ctypes.c_int, [_P, _L, _I, _I, _P, _P]),
     'mbv_point_sample_packed_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    'mbv_mask_logits_fwd': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _L, _P, _P]),
+    'mbv_mask_logits_fwd': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _L, _P, _I, _P]),
     'mbv_attn_mask_from_logits': (ctypes.c_int, [_P, _I, _L, _I, _I, _I, _I, _P, _P]),
     'mbv_attn_workspace_bytes': (c_size_t, [_I, _I, _I, _I, _I]),
     'mbv_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, c_size_t, _P]),

@@ -26,9 +26,9 @@ constexpr int QB = 128;    // queries per workgroup (4 waves x 32)
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 // ---- bf16 --------------------------------------------------------------------------------------------
-template <int KC>   // channels staged per pass
+template <int KC, typename TOut>   // channels staged per pass; logits stored as bf16 or (the f32 accumulators) f32
 __global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restrict__ E, const __bf16* __restrict__ F,
-                                                          int Q, int C, int64_t HW, __bf16* __restrict__ out) {
+                                                          int Q, int C, int64_t HW, TOut* __restrict__ out) {
   constexpr int LD = KC + 8;
   __shared__ __attribute__((aligned(16))) __bf16 ft[PT * LD];      // [pixel][c]
   const int b = blockIdx.y, q0 = blockIdx.z * QB;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int qq = q0 + 32 * wave + acc_row(i, h);
-      if (qq < Q) out[((int64_t)b * Q + qq) * HW + p] = (__bf16)acc[pb][i];
+      if (qq < Q) out[((int64_t)b * Q + qq) * HW + p] = (TOut)acc[pb][i];
     }
   }
 }
@@ -182,16 +182,21 @@ __global__ void __launch_bounds__(256) k_attn_mask(const T* __restrict__ logits,
 
 extern "C" int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feature, int32_t is_bf16, int32_t batch,
                                    int32_t num_queries, int32_t channels, int64_t pixels, void* logits,
-                                   void* stream_) {
+                                   int32_t logits_f32, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || num_queries <= 0 || channels <= 0 || pixels <= 0) return MBV_ERR_BAD_ARG;
   if (!mask_embed || !mask_feature || !logits) return MBV_ERR_BAD_ARG;
   const dim3 grid((unsigned)((pixels + PT - 1) / PT), batch, (num_queries + QB - 1) / QB), block(256);
   if (is_bf16) {
     if (channels % 16 != 0) return MBV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_mask_logits_bf16<256>, grid, block, 0, stream, reinterpret_cast<const __bf16*>(mask_embed),
-                       reinterpret_cast<const __bf16*>(mask_feature), num_queries, channels, pixels,
-                       reinterpret_cast<__bf16*>(logits));
+    if (logits_f32)
+      hipLaunchKernelGGL((k_mask_logits_bf16<256, float>), grid, block, 0, stream,
+                         reinterpret_cast<const __bf16*>(mask_embed), reinterpret_cast<const __bf16*>(mask_feature),
+                         num_queries, channels, pixels, reinterpret_cast<float*>(logits));
+    else
+      hipLaunchKernelGGL((k_mask_logits_bf16<256, __bf16>), grid, block, 0, stream,
+                         reinterpret_cast<const __bf16*>(mask_embed), reinterpret_cast<const __bf16*>(mask_feature),
+                         num_queries, channels, pixels, reinterpret_cast<__bf16*>(logits));
   } else {
     if (channels % 2 != 0) return MBV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_mask_logits_f32<128>, grid, block, 0, stream, reinterpret_cast<const float*>(mask_embed),

@@ -256,14 +256,14 @@ class Mask2FormerHead(nn.Module):
                 nn.init.xavier_normal_(p)
 
     # ------------------------------------------------------------------ forward
-    def _forward_head(self, decoder_out, mask_feature, target_size):
+    def _forward_head(self, decoder_out, mask_feature, target_size, out=None):
         """mask2former_head.py:428-472 → cls (B,Q,K+1), mask logits (B,Q,H,W), blocked (B,1,Q,h*w) bool.
         The boolean mask is kept once per query (broadcast over heads) instead of being repeated 8x, and
         the 'row fully blocked → unblock the row' rule of :538-539 is applied here."""
         x = self.transformer_decoder.post_norm(decoder_out)
         cls_pred = self.cls_embed(x)
         mask_embed = self.mask_embed(x)
-        mask_pred, blocked = ops.mask_logits(mask_embed, mask_feature, target_size)
+        mask_pred, blocked = ops.mask_logits(mask_embed, mask_feature, target_size, out)
         return cls_pred, mask_pred, blocked
 
     def forward(self, x: List[torch.Tensor], batch_data_samples=None):
@@ -280,7 +280,13 @@ class Mask2FormerHead(nn.Module):
         query_feat = self.query_feat.weight.unsqueeze(0).expand(bs, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(bs, -1, -1)
         cls_list, mask_list = [], []
-        cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features, memories[0].shape[-2:])
+        # the 10 mask predictions are written as f32 straight into one stacked buffer: the loss reads it as is
+        nd = len(self.transformer_decoder.layers) + 1
+        stack = torch.empty((nd, bs, self.num_queries) + tuple(mask_features.shape[-2:]), dtype=torch.float32,
+                            device=mask_features.device) if mask_features.is_cuda else None
+        self._mask_stack = stack
+        cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features, memories[0].shape[-2:],
+                                                          None if stack is None else stack[0])
         cls_list.append(cls_pred)
         mask_list.append(mask_pred)
         nl = self.num_transformer_feat_level
@@ -288,7 +294,8 @@ class Mask2FormerHead(nn.Module):
             lvl = i % nl
             query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl])
             cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features,
-                                                              memories[(i + 1) % nl].shape[-2:])
+                                                              memories[(i + 1) % nl].shape[-2:],
+                                                              None if stack is None else stack[i + 1])
             cls_list.append(cls_pred)
             mask_list.append(mask_pred)
         return cls_list, mask_list, [None for _ in cls_list]
@@ -397,7 +404,10 @@ class Mask2FormerHead(nn.Module):
         p = self.num_points
         eps = torch.finfo(torch.float32).eps
         cls = torch.stack([c.float() for c in all_cls_scores], 0)                                # (D, B, Q, K+1)
-        masks_flat = torch.stack([mk.float() for mk in all_mask_preds], 0).flatten(0, 2)         # (D*B*Q, H, W)
+        stacked = ops.stack_slices(getattr(self, '_mask_stack', None), list(all_mask_preds))
+        if stacked is None:
+            stacked = torch.stack([mk.float() for mk in all_mask_preds], 0)
+        masks_flat = stacked.flatten(0, 2)                                                       # (D*B*Q, H, W)
         gt_flat = masks_gt.float().flatten(0, 1)                                                 # (B*G, ny, nx)
         if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
             gt_flat = ops.pack_binary_masks(gt_flat)      # {0,1} by the batch contract: 32 KB per 512x512 mask

@@ -687,9 +687,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, blocked: Option
 # --------------------------------------------------------------------------------------
 # K7 per-query mask logits + attention mask of the next decoder layer
 # --------------------------------------------------------------------------------------
+class OutSlot:
+    """A caller-provided output buffer handed to an op as a plain Python object (autograd does not see it as an
+    input): ``mask_logits`` writes decoder output i straight into slice i of the stacked (D, B, Q, H, W) tensor the
+    loss consumes, so neither the per-output f32 cast nor the stack copy exists."""
+
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor = tensor
+
+
 class _MaskLogits(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mask_embed, mask_feature):
+    def forward(ctx, mask_embed, mask_feature, out_slot):
         lib = _lib.load()
         _need_gpu(mask_embed, mask_feature)
         dt = mask_feature.dtype
@@ -699,9 +708,14 @@ class _MaskLogits(torch.autograd.Function):
         f = mask_feature.contiguous()
         b, q, c = e.shape
         h, w = f.shape[-2:]
-        out = torch.empty((b, q, h, w), dtype=dt, device=f.device)
+        if out_slot is not None:
+            out = out_slot.tensor
+            if out.shape != (b, q, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise MaskBevHipError('mask_logits: the output slot must be a contiguous f32 (B, Q, H, W) tensor')
+        else:
+            out = torch.empty((b, q, h, w), dtype=dt, device=f.device)
         rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), 1 if dt == torch.bfloat16 else 0, b, q, c, h * w, _ptr(out),
-                                     _stream())
+                                     1 if out.dtype == torch.float32 else 0, _stream())
         check(rc, 'mbv_mask_logits_fwd')
         ctx.save_for_backward(e, f)
         ctx.embed_dtype = mask_embed.dtype
@@ -717,16 +731,42 @@ class _MaskLogits(torch.autograd.Function):
         ff = f.reshape(b, c, h * w)
         g_e = torch.matmul(dl, ff.transpose(1, 2)).to(ctx.embed_dtype)
         g_f = torch.matmul(e.transpose(1, 2), dl).reshape(b, c, h, w)
-        return g_e, g_f
+        return g_e, g_f, None
 
 
-def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_size):
+class _StackSlices(torch.autograd.Function):
+    """``torch.stack(parts)`` when the parts already ARE the consecutive slices of ``buffer``: returns the buffer (no
+    copy); the gradient of part i is the view grad[i]."""
+
+    @staticmethod
+    def forward(ctx, buffer, *parts):
+        ctx.n = len(parts)
+        return buffer.view_as(buffer)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (None,) + tuple(grad[i] for i in range(ctx.n))
+
+
+def stack_slices(buffer: torch.Tensor, parts) -> Optional[torch.Tensor]:
+    """The stacked tensor of ``parts`` without copying, if every part i is exactly ``buffer[i]``; else None."""
+    if buffer is None or len(parts) != buffer.shape[0]:
+        return None
+    step = buffer.stride(0) * buffer.element_size()
+    for i, p in enumerate(parts):
+        if (p.dtype != buffer.dtype or p.shape != buffer.shape[1:] or not p.is_contiguous()
+                or p.data_ptr() != buffer.data_ptr() + i * step):
+            return None
+    return _StackSlices.apply(buffer, *parts)
+
+
+def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_size, out: Optional[torch.Tensor] = None):
     """mask_embed (B, Q, C) · mask_feature (B, C, H, W) → logits (B, Q, H, W) (MFMA contraction, K7) and the
     boolean cross-attention mask of the next layer, (B, 1, Q, h*w), True = blocked:
     bilinear resize (align_corners=False) → sigmoid < 0.5, rows that would block every key unblocked
     (mask2former_head.py:459-470 and :538-539).  Kept once per query and broadcast over heads."""
     lib = _lib.load()
-    logits = _MaskLogits.apply(mask_embed, mask_feature)
+    logits = _MaskLogits.apply(mask_embed, mask_feature, None if out is None else OutSlot(out))
     b, q, h, w = logits.shape
     th, tw = int(target_size[0]), int(target_size[1])
     blocked = torch.empty((b, 1, q, th * tw), dtype=torch.bool, device=logits.device)
