@@ -234,6 +234,8 @@ class MultiScaleDeformableAttention(nn.Module):
         b, n, e = query.shape
         h, l, p = self.num_heads, self.num_levels, self.num_points
         q = query + query_pos
+        if torch.is_autocast_enabled('cuda') and q.is_cuda:
+            q = q.to(torch.get_autocast_dtype('cuda'))       # one cast for both projections of q
         value = self.value_proj(query).view(b, n, h, e // h)
         off = self.sampling_offsets(q).view(b, n, h, l, p, 2)
         aw = self.attention_weights(q).view(b, n, h, l * p).softmax(-1).view(b, n, h, l, p)

@@ -277,6 +277,11 @@ class Mask2FormerHead(nn.Module):
             dec_pos.append(sine_positional_encoding(h, w, self.decoder_embed_dims // 2, m.device)
                            .flatten(2).transpose(1, 2))
         dec_key = [a + b for a, b in zip(dec_in, dec_pos)]     # key = memory + pos, shared by the 3 layers of a level
+        if torch.is_autocast_enabled('cuda') and dec_in[0].is_cuda:
+            # one cast per level instead of one per (layer, projection): the K / V GEMMs read these copies
+            adt = torch.get_autocast_dtype('cuda')
+            dec_in = [t.to(adt) for t in dec_in]
+            dec_key = [t.to(adt) for t in dec_key]
         query_feat = self.query_feat.weight.unsqueeze(0).expand(bs, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(bs, -1, -1)
         cls_list, mask_list = [], []

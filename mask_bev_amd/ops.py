@@ -561,7 +561,7 @@ _SMALL_F32_MACS = 1 << 30          # … and only while the f32 GEMM itself stay
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, rows):
+    def forward(ctx, x, weight, bias, rows, f32_out=False):
         if torch.is_autocast_enabled('cuda') and not (
                 x.dtype == torch.float32 and weight.dtype == torch.float32
                 and x.numel() <= _SMALL_F32_ROWS * x.shape[-1] and x.numel() * weight.shape[0] <= _SMALL_F32_MACS):
@@ -573,7 +573,17 @@ class _Linear(torch.autograd.Function):
             w = w[rows[0]:rows[1]]
             b = None if b is None else b[rows[0]:rows[1]]
         with torch.autocast('cuda', enabled=False):
-            y = torch.nn.functional.linear(x, w, b)
+            if f32_out and x.dtype == torch.bfloat16 and x.is_cuda:
+                # bf16 GEMM with the f32 accumulators stored as f32 (the consumer wants f32: no cast pass)
+                x2 = x.reshape(-1, x.shape[-1])
+                if bias is not None:
+                    bf = bias if rows is None else bias[rows[0]:rows[1]]
+                    y = torch.addmm(bf.float(), x2, w.t(), out_dtype=torch.float32)
+                else:
+                    y = torch.mm(x2, w.t(), out_dtype=torch.float32)
+                y = y.view(x.shape[:-1] + (w.shape[0],))
+            else:
+                y = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
         ctx.weight, ctx.bias, ctx.rows = weight, bias, rows
         return y
@@ -615,17 +625,17 @@ class _Linear(torch.autograd.Function):
             else:
                 gb = torch.zeros_like(bias)
                 gb[rows[0]:rows[1]] = g2.sum(0, dtype=torch.float32)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           rows: Optional[tuple] = None) -> torch.Tensor:
+           rows: Optional[tuple] = None, f32_out: bool = False) -> torch.Tensor:
     """y = x W^T + b on the library GEMM (hipBLASLt) honouring autocast, with the split-K weight gradient.
     ``rows=(r0, r1)`` uses rows r0:r1 of the parameters (the q / k / v blocks of a packed ``in_proj_weight``)
     without materialising slices or zero-padded slice gradients.  Parameters that live in a
     :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
     direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
-    return _Linear.apply(x, weight, bias, rows)
+    return _Linear.apply(x, weight, bias, rows, f32_out)
 
 
 # --------------------------------------------------------------------------------------
