@@ -328,6 +328,25 @@ int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K14 — batch producer: instance-id map → instance ids → per-instance binary masks.
+ * Replaces: FilterSmallMasks + MaskToLabelInstanceMasks of the reference's data pipeline
+ * (mask_bev/datasets/semantic_kitti/semantic_kitti_transforms.py:11-26, 66-81) and the host→device copy of the
+ * dense (B, Q, ny, nx) f32 masks they produce.
+ * instance_map (B, nx, ny) i32, 0 = background (the layout of the reference's mask cache; the transform's `.T` is
+ * applied here).  mbv_instance_ids: ids (B, Q) i32 = the ids with >= min_pixels pixels in ascending order, -1
+ * padded (the reference enumerates a Python set: same set, unspecified order — the Hungarian matcher makes the
+ * loss independent of it); counts (B) i32; *status (device i32) bit 0 = a scan had more than Q instances (the
+ * reference raises IndexError; here the Q smallest ids are kept), bit 1 = more than 4096 distinct ids.
+ * mbv_expand_instance_masks: masks_f32 (B, Q, ny, nx) f32 {0,1} and / or masks_packed (B*Q, words) u32 in the
+ * bit-packed layout of mbv_pack_binary_masks (either may be NULL): masks[b, q, y, x] = (map[b, x, y] == ids[b, q]).
+ */
+int mbv_instance_ids(const int32_t* instance_map, int32_t batch, int32_t nx, int32_t ny, int32_t num_queries,
+                     int32_t min_pixels, int32_t* ids, int32_t* counts, int32_t* status, void* stream);
+
+int mbv_expand_instance_masks(const int32_t* instance_map, const int32_t* ids, int32_t batch, int32_t nx, int32_t ny,
+                              int32_t num_queries, float* masks_f32, uint32_t* masks_packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

@@ -28,6 +28,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import ops
 from .mask_bev_module import MaskBevModule
 
 
@@ -49,7 +50,9 @@ class GraphedTrainStep:
             x = module._encoder(scans)
         self.x_static = torch.zeros_like(x).requires_grad_()
         self.labels = labels.clone()
-        self.masks = masks.clone()
+        # dense (B, Q, ny, nx) masks or the bit-packed targets of batch.instance_targets (K14)
+        self.masks = (ops.PackedMasks(masks.words.clone(), masks.h, masks.w) if isinstance(masks, ops.PackedMasks)
+                      else masks.clone())
         self._graph_params = list(module._backbone.parameters()) + list(module._panoptic_head.parameters())
         # warm-up on a side stream (allocator / library workspaces / autotuning settle before capture)
         side = torch.cuda.Stream(device=dev)
@@ -93,7 +96,10 @@ class GraphedTrainStep:
         self.x_static.data.copy_(x.detach())
         if labels.data_ptr() != self.labels.data_ptr():
             self.labels.copy_(labels)
-        if masks.data_ptr() != self.masks.data_ptr():
+        if isinstance(masks, ops.PackedMasks):
+            if masks.words.data_ptr() != self.masks.words.data_ptr():
+                self.masks.words.copy_(masks.words)
+        elif masks.data_ptr() != self.masks.data_ptr():
             self.masks.copy_(masks)
         self.graph.replay()                                # backbone, head, loss and their backward
         handles = None

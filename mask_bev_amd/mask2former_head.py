@@ -399,7 +399,10 @@ class Mask2FormerHead(nn.Module):
         the (B, G, ny, nx) GT masks (no gathered copies), the assignments come from K9 on the device, and
         nothing synchronises with the host."""
         labels_gt = gt_labels_list if torch.is_tensor(gt_labels_list) else torch.stack(list(gt_labels_list), 0)
-        masks_gt = gt_masks_list if torch.is_tensor(gt_masks_list) else torch.stack(list(gt_masks_list), 0)
+        packed_gt = gt_masks_list if isinstance(gt_masks_list, ops.PackedMasks) else None
+        masks_gt = None
+        if packed_gt is None:
+            masks_gt = gt_masks_list if torch.is_tensor(gt_masks_list) else torch.stack(list(gt_masks_list), 0)
         dev = all_cls_scores[0].device
         d = len(all_cls_scores)
         b, nq = all_cls_scores[0].shape[:2]
@@ -413,9 +416,12 @@ class Mask2FormerHead(nn.Module):
         if stacked is None:
             stacked = torch.stack([mk.float() for mk in all_mask_preds], 0)
         masks_flat = stacked.flatten(0, 2)                                                       # (D*B*Q, H, W)
-        gt_flat = masks_gt.float().flatten(0, 1)                                                 # (B*G, ny, nx)
-        if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
-            gt_flat = ops.pack_binary_masks(gt_flat)      # {0,1} by the batch contract: 32 KB per 512x512 mask
+        if packed_gt is not None:                         # K14 produced the bit-packed targets directly (batch.py)
+            gt_flat = packed_gt
+        else:
+            gt_flat = masks_gt.float().flatten(0, 1)                                             # (B*G, ny, nx)
+            if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
+                gt_flat = ops.pack_binary_masks(gt_flat)  # {0,1} by the batch contract: 32 KB per 512x512 mask
         pts = PointSource(dev, self.point_seed)
         match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
         cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)
