@@ -88,12 +88,18 @@ def main():
         sys.exit(subprocess.call(cmd))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)      # one rank per GPU; wraps only in the single-GPU smoke test of the N > 1 path
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('MBV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; gloo only for smoke tests
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mask_bev_amd import ops, synthetic
     from mask_bev_amd.mask_bev_module import MaskBevModule
@@ -110,6 +116,8 @@ def main():
     if world > 1:
         from mask_bev_amd.ddp import GradientAllReducer
         reducer = GradientAllReducer(model, bucket_mb=64.0)
+        if getattr(model, '_arena', None) is not None:
+            model._arena.refresh_shadow()       # the construction-time parameter broadcast wrote the f32 arena
 
     pool = [synthetic.make_batch(args.workload, args.batch, rank, s, device) for s in range(args.pool)]
     torch.cuda.synchronize()
