@@ -347,6 +347,18 @@ int mbv_expand_instance_masks(const int32_t* instance_map, const int32_t* ids, i
                               int32_t num_queries, float* masks_f32, uint32_t* masks_packed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K15 — mask IoU of matched (prediction, ground truth) pairs at ground-truth resolution.
+ * Replaces: the upsample → sigmoid > 0.5 → batched_mask_iou chain of MaskBevPanopticHead.update_mAP_metrics
+ * (mask_bev/models/head/mask_bev_panoptic_head.py:74-85; mask_bev/evaluation/average_precision.py:78-81).
+ * logits (N, h, w) f32 with h*w <= 16384; pred_row / gt_row (pairs) i32: rows of `logits` and of the bit-packed
+ * ground truth (mbv_pack_binary_masks layout, maps of H x W pixels); gt_row < 0 marks an unmatched prediction.
+ * inter / uni (pairs) i32 pixel counts; IoU = inter / (uni + 1e-12) like the reference.
+ */
+int mbv_matched_mask_iou(const float* logits, const int32_t* pred_row, const uint32_t* gt_packed,
+                         const int32_t* gt_row, int32_t num_pairs, int32_t h, int32_t w, int32_t H, int32_t W,
+                         int32_t* inter, int32_t* uni, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9 — batched linear-sum assignment on the device (one wavefront per cost matrix).
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).

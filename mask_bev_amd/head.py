@@ -26,6 +26,15 @@ class MaskBevPanopticHead(nn.Module):
     def loss(self, cls, masks, label_gt, masks_gt, heights_pred=None, heights_gt=None):
         return self._panoptic_head.loss(cls, masks, label_gt, masks_gt, None, heights_pred, heights_gt)
 
+    def update_mAP_metrics(self, layer_index: int, pred_cls, pred_masks, labels_gt, masks_gt, cls_metric=None,
+                           map_metric=None, mIoU_metric=None):
+        """mask_bev_panoptic_head.py:34-96 for the classification and mIoU metrics (mask_bev_amd/metrics.py): the
+        assignment of the loss just evaluated is reused and the mask IoU runs on K15.  ``map_metric`` (torchmetrics'
+        MeanAveragePrecision in the reference) is not fed — torchmetrics is outside this path."""
+        from . import metrics
+        metrics.update_metrics(self._panoptic_head, layer_index, pred_cls, pred_masks, labels_gt, masks_gt, cls_metric,
+                               mIoU_metric)
+
     @staticmethod
     def _get_config(num_things_classes, num_stuff_classes, num_queries, in_channels, head_feat_channels,
                     head_out_channels, reverse_class_weights):

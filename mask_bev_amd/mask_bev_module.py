@@ -257,6 +257,11 @@ class MaskBevModule(_Base):
         cls, masks, heights = self.forward(x)
         loss_dict = self.compute_loss(cls, masks, labels_gt, masks_gt, heights, None)
         loss = self.loss(loss_dict)
+        # metrics (mask_bev_module.py:273-275 / :330-332): per configured decoder layer, from the loss's own assignment
+        per_layer = self._train_metric_per_layer if mode == 'train' else self._val_metric_per_layer
+        for layer_index, (cls_metric, map_metric, miou_metric) in per_layer.items():
+            self._panoptic_head.update_mAP_metrics(layer_index, cls, masks, labels_gt, masks_gt, cls_metric, map_metric,
+                                                   miou_metric)
         if getattr(self, 'log_scalars', True):
             self.log(f'{mode}_loss', loss, batch_size=batch_size, prog_bar=True, sync_dist=True)
             self.log('hp_metric' if mode == 'train' else 'hp_val_metric', loss, on_step=False, on_epoch=True,
@@ -270,8 +275,28 @@ class MaskBevModule(_Base):
     def validation_step(self, val_batch, batch_idx):
         return self._step(val_batch, batch_idx, 'val')
 
+    def enable_metrics(self, layers=(9,), train: bool = True, val: bool = True):
+        """Build extension: attach the GPU-native classification / mIoU metrics (mask_bev_amd/metrics.py) to the
+        given decoder layers, in the reference's ``{layer: (cls_metric, map_metric, miou_metric)}`` layout
+        (mask_bev_module.py:85-98; the torchmetrics mask-mAP slot stays ``None``)."""
+        from .metrics import BinaryClassifScores, MeanIoU
+        for flag, store in ((train, self._train_metric_per_layer), (val, self._val_metric_per_layer)):
+            if flag:
+                for layer in layers:
+                    store[int(layer)] = (BinaryClassifScores(), None, MeanIoU())
+
+    def log_metrics(self, mode: str, per_layer):
+        """mask_bev_module.py:209-224: log and reset the per-layer metrics at the end of an epoch."""
+        for layer_index, (cls_metric, _map_metric, miou_metric) in per_layer.items():
+            if cls_metric is not None:
+                self.log(f'{mode}_cls_mAP_layer_{layer_index}', float(cls_metric.compute()), sync_dist=True)
+                cls_metric.reset()
+            if miou_metric is not None:
+                self.log(f'{mode}_mIoU_layer_{layer_index}', float(miou_metric.compute()), sync_dist=True)
+                miou_metric.reset()
+
     def on_train_epoch_end(self):
-        pass
+        self.log_metrics('train', self._train_metric_per_layer)
 
     def on_validation_epoch_end(self):
-        pass
+        self.log_metrics('val', self._val_metric_per_layer)

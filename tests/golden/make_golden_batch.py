@@ -25,6 +25,21 @@ from mask_bev.datasets.semantic_kitti.semantic_kitti_transforms import (FilterSm
                                                                          MaskToLabelInstanceMasks)
 
 
+def make_iou_golden():
+    """mask_bev/evaluation/average_precision.py:78-81 run unmodified (its module imports cv2: stand-in above)."""
+    from mask_bev.evaluation.average_precision import batched_mask_iou
+    g = torch.Generator().manual_seed(5)
+    m1 = (torch.rand(6, 40, 36, generator=g) > 0.6).float()
+    m2 = torch.rand(6, 40, 36, generator=g) > 0.5
+    m1[2] = 0
+    m2[3] = False
+    m1[4] = 0
+    m2[4] = False
+    np.savez_compressed(os.path.join(HERE, 'mask_iou.npz'), masks1=m1.numpy().astype(np.uint8),
+                        masks2=m2.numpy().astype(np.uint8), iou=batched_mask_iou(m1, m2).numpy())
+    print('wrote mask_iou.npz')
+
+
 def make_map(rng, nx, ny, ids, sizes):
     m = np.zeros((nx, ny), dtype=np.int64)
     for inst, (sx, sy) in zip(ids, sizes):
@@ -60,3 +75,4 @@ def main():
 
 if __name__ == '__main__':
     main()
+    make_iou_golden()
