@@ -363,10 +363,15 @@ int mbv_matched_mask_iou(const float* logits, const int32_t* pred_row, const uin
  * Replaces: mmdet HungarianAssigner → scipy.optimize.linear_sum_assignment on the host, reached from
  * Mask2FormerHead._get_targets_single (mask_bev/models/networks/mask2former_head/mask2former_head.py:207-210).
  * cost (batch, num_rows, num_cols) f32 (finite); row_to_col (batch, num_rows) i32 = assigned column of each
- * row, -1 for rows left unassigned when num_rows > num_cols.  num_rows, num_cols <= 128.
+ * row, -1 for rows left unassigned when num_rows > num_cols.  Up to 128 x 128 the cost matrix lives in LDS (the
+ * 100-query configurations); up to 320 x 320 (200 / 300 queries) it is read from global memory one coalesced row
+ * per search step, which needs num_rows <= num_cols: for num_rows > num_cols > 128 call mbv_hungarian_wide_t with
+ * the materialised transpose cost_t (batch, num_cols, num_rows) — same row_to_col (batch, num_rows) output.
  */
 int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
                   int32_t* row_to_col, void* stream);
+int mbv_hungarian_wide_t(const float* cost_t, int32_t batch, int32_t num_rows, int32_t num_cols,
+                         int32_t* row_to_col, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7 — per-query mask logits on MFMA, and the boolean cross-attention mask of the next decoder layer.

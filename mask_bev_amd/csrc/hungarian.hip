@@ -203,23 +203,202 @@ __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Wide problems (128 < columns <= 320: the 200-query KITTI and 300-query Waymo configurations).  Same algorithm and
+// register-resident state with CPL columns per lane; the cost matrix (up to 360 KB) does not fit LDS and is read
+// from global memory / L2, one coalesced row per search step — latency-bound, a supported path rather than a fast
+// one (the 100-query configuration never takes it).  rows <= cols, row-major (rows, cols) input.
+template <int CPL>
+__device__ __forceinline__ int pick_i(const int (&x)[CPL], int c) {
+  int r = x[0];
+#pragma unroll
+  for (int k = 1; k < CPL; ++k) r = c == k ? x[k] : r;
+  return r;
+}
+template <int CPL>
+__device__ __forceinline__ double pick_d(const double (&x)[CPL], int c) {
+  double r = x[0];
+#pragma unroll
+  for (int k = 1; k < CPL; ++k) r = c == k ? x[k] : r;
+  return r;
+}
+
+template <int CPL>
+__global__ void __launch_bounds__(64) k_hungarian_wide(const float* __restrict__ cost_all, int rows, int cols,
+                                                       int transposed_out, int32_t* __restrict__ out_all, int out_len) {
+  constexpr int MAXD = 64 * CPL;
+  __shared__ double u_row[MAXD];
+  __shared__ int row_matched[MAXD];
+  const int lane = threadIdx.x;
+  const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
+  int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
+  const double INF = 1e300;
+  int jc[CPL];
+  bool has[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { jc[c] = lane + 1 + 64 * c; has[c] = jc[c] <= cols; }
+  // row reduction (coalesced: the lanes of the wave read one row)
+  for (int i = 0; i < rows; ++i) {
+    float m = INFINITY;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      if (has[c]) m = fminf(m, cost[(int64_t)i * cols + jc[c] - 1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) { u_row[i] = (double)m; row_matched[i] = 0; }
+  }
+  __syncthreads();
+  double v[CPL], uu[CPL], minv[CPL];
+  int p[CPL], way[CPL];
+  bool used[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { v[c] = 0.0; uu[c] = 0.0; p[c] = 0; }
+  if (rows == cols) {                     // column reduction (square problems only, see k_hungarian)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) v[c] = INF;
+    for (int i = 0; i < rows; ++i) {
+      const double ui = u_row[i];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if (has[c]) v[c] = fmin(v[c], (double)cost[(int64_t)i * cols + jc[c] - 1] - ui);
+    }
+  }
+  for (int i = 0; i < rows; ++i) {        // greedy matching on zero reduced costs
+    const double ui = u_row[i];
+    unsigned cand = 0xffffffffu;
+#pragma unroll
+    for (int c = CPL - 1; c >= 0; --c)
+      if (has[c] && p[c] == 0 && ((double)cost[(int64_t)i * cols + jc[c] - 1] - ui) - v[c] == 0.0) cand = (unsigned)jc[c];
+    const unsigned j = wave_min_u32(cand);
+    if (j != 0xffffffffu) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if ((int)j == jc[c]) { p[c] = i + 1; uu[c] = ui; }
+      if (lane == 0) row_matched[i] = 1;
+    }
+  }
+  __syncthreads();
+  for (int i = 1; i <= rows; ++i) {
+    if (row_matched[i - 1]) continue;
+    double ui = u_row[i - 1];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { minv[c] = INF; used[c] = false; way[c] = 0; }
+    int j0 = 0;
+    while (true) {
+      int i0;
+      double ui0;
+      if (j0 == 0) {
+        i0 = i;
+        ui0 = ui;
+      } else {
+        const int owner = (j0 - 1) & 63, cc = (j0 - 1) >> 6;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (j0 == jc[c]) used[c] = true;
+        i0 = __builtin_amdgcn_readlane(pick_i<CPL>(p, cc), owner);
+        ui0 = readlane_f64(pick_d<CPL>(uu, cc), owner);
+      }
+      const float* arow = cost + (int64_t)(i0 - 1) * cols;
+      double best = INF;
+      int bestj = 0x7fffffff;
+      bool best_taken = true;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        if (has[c] && !used[c]) {
+          const double cur = (double)arow[jc[c] - 1] - ui0 - v[c];
+          if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
+          const bool taken = p[c] != 0;
+          if (minv[c] < best || (minv[c] == best && best_taken && !taken)) { best = minv[c]; bestj = jc[c]; best_taken = taken; }
+        }
+      }
+      // key = orderable reduced cost (10 low mantissa bits cleared) | matched? | column (9 bits); free columns win ties
+      const unsigned long long key =
+          bestj == 0x7fffffff ? ~0ull
+                              : ((orderable(best) & ~0x3ffull) | ((unsigned long long)(best_taken ? 1 : 0) << 9) |
+                                 (unsigned long long)bestj);
+      const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+      const unsigned mhi = wave_min_u32(hi);
+      const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+      const int j1 = (int)(mlo & 0x1ffu);
+      const int owner1 = (j1 - 1) & 63, c1 = (j1 - 1) >> 6;
+      const double delta = readlane_f64(pick_d<CPL>(minv, c1), owner1);
+      ui += delta;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        if (has[c]) { if (used[c]) { uu[c] += delta; v[c] -= delta; } else minv[c] -= delta; }
+      }
+      j0 = j1;
+      if (__builtin_amdgcn_readlane(pick_i<CPL>(p, c1), owner1) == 0) break;
+    }
+    int j = j0;
+    while (j != 0) {                      // augment
+      const int owner = (j - 1) & 63, cc = (j - 1) >> 6;
+      const int jp = __builtin_amdgcn_readlane(pick_i<CPL>(way, cc), owner);
+      int row;
+      double urow;
+      if (jp == 0) {
+        row = i;
+        urow = ui;
+      } else {
+        const int ownp = (jp - 1) & 63, cp = (jp - 1) >> 6;
+        row = __builtin_amdgcn_readlane(pick_i<CPL>(p, cp), ownp);
+        urow = readlane_f64(pick_d<CPL>(uu, cp), ownp);
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c)
+        if (j == jc[c]) { p[c] = row; uu[c] = urow; }
+      j = jp;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    if (!has[c]) continue;
+    if (!transposed_out) {
+      if (p[c] > 0) out[p[c] - 1] = jc[c] - 1;       // out[row] = col
+    } else {
+      out[jc[c] - 1] = p[c] > 0 ? p[c] - 1 : -1;     // the caller's rows are this problem's columns
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
                              int32_t* row_to_col, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch < 0 || num_rows <= 0 || num_cols <= 0) return MBV_ERR_BAD_ARG;
-  if (num_rows > kMaxDim || num_cols > kMaxDim) return MBV_ERR_UNSUPPORTED;
+  if (num_rows > 320 || num_cols > 320) return MBV_ERR_UNSUPPORTED;
   if (batch == 0) return MBV_OK;
   if (!cost || !row_to_col) return MBV_ERR_BAD_ARG;
-  if (num_rows <= num_cols) {
-    hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
-                       num_rows);
+  if (num_rows <= kMaxDim && num_cols <= kMaxDim) {
+    if (num_rows <= num_cols) {
+      hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
+                         num_rows);
+    } else {
+      // more rows than columns: solve the transposed problem; unmatched rows get -1
+      hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_cols, num_rows, 1, row_to_col,
+                         num_rows);
+    }
   } else {
-    // more rows than columns: solve the transposed problem; unmatched rows get -1
-    hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_cols, num_rows, 1, row_to_col,
+    // wide problems read the matrix from global memory and need it in (rows <= cols) orientation:
+    // mbv_hungarian_wide_t takes the materialised transpose for num_rows > num_cols
+    if (num_rows > num_cols) return MBV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
                        num_rows);
   }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_hungarian_wide_t(const float* cost_t, int32_t batch, int32_t num_rows, int32_t num_cols,
+                                    int32_t* row_to_col, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch < 0 || num_rows <= 0 || num_cols <= 0 || num_rows <= num_cols) return MBV_ERR_BAD_ARG;
+  if (num_rows > 320) return MBV_ERR_UNSUPPORTED;
+  if (batch == 0) return MBV_OK;
+  if (!cost_t || !row_to_col) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), 0, stream, cost_t, num_cols, num_rows, 1, row_to_col,
+                     num_rows);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -887,6 +887,11 @@ def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     if out is None:
         out = torch.empty((n, r), dtype=torch.int32, device=cost.device)
     out.fill_(-1)
+    if max(r, c) > 128 and r > c:         # wide problems are solved from global memory in (rows <= cols) orientation
+        cost_t = cost.transpose(1, 2).contiguous()
+        rc = lib.mbv_hungarian_wide_t(_ptr(cost_t), n, r, c, _ptr(out), _stream())
+        check(rc, 'mbv_hungarian_wide_t')
+        return out
     rc = lib.mbv_hungarian(_ptr(cost), n, r, c, _ptr(out), _stream())
     check(rc, 'mbv_hungarian')
     return out

@@ -8,7 +8,9 @@ from scipy.optimize import linear_sum_assignment
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('n,r,c', [(6, 100, 100), (3, 8, 8), (4, 20, 50), (4, 50, 20), (2, 128, 128), (5, 1, 7)])
+@pytest.mark.parametrize('n,r,c', [(6, 100, 100), (3, 8, 8), (4, 20, 50), (4, 50, 20), (2, 128, 128), (5, 1, 7),
+                                   (3, 200, 200), (2, 300, 300), (2, 150, 260), (2, 260, 150), (2, 129, 129),
+                                   (1, 320, 320)])
 def test_hungarian_matches_scipy(device, n, r, c):
     from mask_bev_amd import ops
     g = torch.Generator().manual_seed(r * 131 + c)
