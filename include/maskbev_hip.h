@@ -315,7 +315,9 @@ int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const floa
  * bwd: dy (rows, C) f32/bf16, ds nullable (gradient reaching the sum from the residual path), s = the saved sum;
  * writes dx (rows, C) f32 (the gradient of a and of b), optionally the same in bf16 (dx_bf16), and
  * dgamma / dbeta (C) f32 — overwritten, or accumulated into when accumulate != 0 (parameter-arena gradients).
- * partial_ws: mbv_add_layernorm_bwd_blocks(rows, C) * 2 * C floats.
+ * dbranch_bias (C) f32, nullable: += the column sums of dx — the bias gradient of the Linear that produced the
+ * residual branch b (its output gradient IS dx), saving that layer a pass over dx.
+ * partial_ws: mbv_add_layernorm_bwd_blocks(rows, C) * 3 * C floats.
  */
 int mbv_add_layernorm_supported(int32_t C);
 int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C);
@@ -324,8 +326,8 @@ int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t 
                           float* mean, float* rstd, void* stream);
 int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
-                          void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate, float* partial_ws,
-                          void* stream);
+                          void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate, float* dbranch_bias,
+                          float* partial_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K14 — batch producer: instance-id map → instance ids → per-instance binary masks.

@@ -114,19 +114,22 @@ struct LnBwdIo {
   const float* s; const float* mean; const float* rstd; const float* gamma;
   float* dx;                         // f32 gradient of the sum (= of a and of b)
   void* dx_lo;                       // optional bf16 copy of dx for a bf16 branch input (nullable)
-  float* partial;                    // (gridDim.x, 2, C) per-block Σ dy*xhat, Σ dy
+  float* partial;                    // (gridDim.x, NP, C) per-block Σ dy*xhat, Σ dy [, Σ dx]
+  int np;                            // 2, or 3 when the column sums of dx are wanted too (the bias gradient of
+                                     // the Linear that produced the residual branch: d(branch) = dx)
 };
 
 template <int ITERS>
 __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C) {
-  extern __shared__ double red[];    // [2][C]; f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
+  extern __shared__ double red[];    // [np][C]; f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
-  for (int i = threadIdx.x; i < 2 * C; i += 512) red[i] = 0.0;
+  const int np = io.np;
+  for (int i = threadIdx.x; i < np * C; i += 512) red[i] = 0.0;
   __syncthreads();
-  float4 dg[ITERS], db[ITERS];
+  float4 dg[ITERS], db[ITERS], dxs[ITERS];
 #pragma unroll
-  for (int i = 0; i < ITERS; ++i) dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < ITERS; ++i) dg[i] = db[i] = dxs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 gam[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
@@ -170,6 +173,7 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
         }
         *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
         if (io.dx_lo) store4(io.dx_lo, 1, base + 4 * v, d);
+        dxs[i].x += d.x; dxs[i].y += d.y; dxs[i].z += d.z; dxs[i].w += d.w;
       }
     }
   }
@@ -182,38 +186,45 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
       atomicAdd(&red[4 * v + 2], (double)dg[i].z); atomicAdd(&red[4 * v + 3], (double)dg[i].w);
       atomicAdd(&red[C + 4 * v + 0], (double)db[i].x); atomicAdd(&red[C + 4 * v + 1], (double)db[i].y);
       atomicAdd(&red[C + 4 * v + 2], (double)db[i].z); atomicAdd(&red[C + 4 * v + 3], (double)db[i].w);
+      if (np == 3) {
+        atomicAdd(&red[2 * C + 4 * v + 0], (double)dxs[i].x); atomicAdd(&red[2 * C + 4 * v + 1], (double)dxs[i].y);
+        atomicAdd(&red[2 * C + 4 * v + 2], (double)dxs[i].z); atomicAdd(&red[2 * C + 4 * v + 3], (double)dxs[i].w);
+      }
     }
   }
   __syncthreads();
-  float* prow = io.partial + (long)blockIdx.x * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 512) prow[i] = (float)red[i];
+  float* prow = io.partial + (long)blockIdx.x * np * C;
+  for (int i = threadIdx.x; i < np * C; i += 512) prow[i] = (float)red[i];
 }
 
-// dgamma[c] += Σ_blocks partial[blk][0][c], dbeta likewise.  Block = 64 columns x 4 slices over one chunk of 64
+// dgamma[c] += Σ_blocks partial[blk][0][c], dbeta likewise (and the branch-bias gradient when np == 3).  Block = 64 columns x 4 slices over one chunk of 64
 // partial rows (blockIdx.y); chunks meet through f32 atomics (≤ 16 adds per address), the destination is cleared
 // by the caller when it is not accumulated into.
-__global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nblk, int C,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void __launch_bounds__(256) k_ln_param_reduce(const float* __restrict__ partial, int nblk, int C, int np,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ dbranch) {
   __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);     // over 2C columns: [0, C) gamma, [C, 2C) beta
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);     // over np*C columns: gamma | beta | branch bias
   const int slice = threadIdx.x >> 6;
   const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
+  const int ncol = np * C;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  if (col < 2 * C) {
+  if (col < ncol) {
     int b = b0 + slice;
     for (; b + 12 < b1; b += 16) {
-      acc0 += partial[(long)b * 2 * C + col];
-      acc1 += partial[(long)(b + 4) * 2 * C + col];
-      acc2 += partial[(long)(b + 8) * 2 * C + col];
-      acc3 += partial[(long)(b + 12) * 2 * C + col];
+      acc0 += partial[(long)b * ncol + col];
+      acc1 += partial[(long)(b + 4) * ncol + col];
+      acc2 += partial[(long)(b + 8) * ncol + col];
+      acc3 += partial[(long)(b + 12) * ncol + col];
     }
-    for (; b < b1; b += 4) acc0 += partial[(long)b * 2 * C + col];
+    for (; b < b1; b += 4) acc0 += partial[(long)b * ncol + col];
   }
   red[slice][threadIdx.x & 63] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
-  if (slice == 0 && col < 2 * C) {
+  if (slice == 0 && col < ncol) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    atomicAdd(col < C ? dgamma + col : dbeta + (col - C), t);
+    float* dst = col < C ? dgamma + col : (col < 2 * C ? dbeta + (col - C) : dbranch + (col - 2 * C));
+    atomicAdd(dst, t);
   }
 }
 
@@ -262,7 +273,7 @@ extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* 
 extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                                      const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
                                      float* dx, void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate,
-                                     float* partial_ws, void* stream) {
+                                     float* dbranch_bias, float* partial_ws, void* stream) {
   const int it = iters_for(C);
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
@@ -276,10 +287,11 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
     return MBV_OK;
   }
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
-  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, partial_ws};
+  const int np = dbranch_bias ? 3 : 2;
+  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, partial_ws, np};
   const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
   const dim3 grid(nblk), block(512);
-  const size_t lds = (size_t)2 * C * sizeof(double);
+  const size_t lds = (size_t)np * C * sizeof(double);
   switch (it) {
     case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
     case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;
@@ -291,8 +303,8 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
     MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
     MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
   }
-  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((2 * C + 63) / 64), (unsigned)((nblk + 63) / 64)), dim3(256), 0,
-                     st, partial_ws, nblk, C, dgamma, dbeta);
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((np * C + 63) / 64), (unsigned)((nblk + 63) / 64)), dim3(256), 0,
+                     st, partial_ws, nblk, C, np, dgamma, dbeta, dbranch_bias);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

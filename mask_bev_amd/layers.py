@@ -21,10 +21,12 @@ def trunc_normal_(t: torch.Tensor, std: float = 0.02) -> torch.Tensor:
 
 
 class Linear(nn.Linear):
-    """``nn.Linear`` (same parameters / checkpoint keys) routed through :func:`ops.linear`."""
+    """``nn.Linear`` (same parameters / checkpoint keys) routed through :func:`ops.linear`.
+    ``skip_bias_grad=True``: the caller guarantees that the op consuming the output accumulates the bias gradient
+    (K12 with ``branch_bias``)."""
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x: torch.Tensor, skip_bias_grad: bool = False) -> torch.Tensor:
+        return ops.linear(x, self.weight, self.bias, skip_bias_grad=skip_bias_grad)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -36,7 +38,9 @@ class LayerNorm(nn.LayerNorm):
     the autocast dtype (what the GEMM would cast it to anyway); ``return_sum`` also returns the f32 sum."""
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, gemm_input: bool = False,
-                return_sum: bool = False):
+                return_sum: bool = False, residual_bias: Optional[torch.Tensor] = None):
+        """``residual_bias``: the bias Parameter of the Linear that produced ``residual`` when that layer was run with
+        ``skip_bias_grad=True`` — its gradient (the column sums of d(residual)) is accumulated by this op."""
         c = x.shape[-1]
         if (x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
                 and ops.add_layernorm_supported(c) and x.dtype in (torch.float32, torch.bfloat16)
@@ -44,7 +48,10 @@ class LayerNorm(nn.LayerNorm):
             out_dtype = torch.float32
             if gemm_input and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
                 out_dtype = torch.bfloat16
-            return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum)
+            return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum,
+                                     branch_bias=residual_bias)
+        if residual_bias is not None:
+            residual = ops.accumulate_bias_grad(residual, residual_bias)      # the deferred gradient must not be lost
         s = x if residual is None else x + residual
         y = super().forward(s.float() if s.dtype != torch.float32 and not torch.is_autocast_enabled('cuda') else s)
         return (y, s) if return_sum else y
@@ -60,11 +67,13 @@ class FFN(nn.Module):
             nn.Sequential(Linear(embed_dims, feedforward_channels), nn.GELU() if act == 'gelu' else nn.ReLU()),
             Linear(feedforward_channels, embed_dims))
 
-    def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None, add_identity: bool = True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, identity: Optional[torch.Tensor] = None, add_identity: bool = True,
+                defer_out_bias: bool = False) -> torch.Tensor:
         """``add_identity=False`` returns the branch alone: the caller fuses the residual add into the LayerNorm
-        that follows (K12)."""
+        that follows (K12); with ``defer_out_bias`` that LayerNorm also accumulates the output layer's bias gradient
+        (pass ``self.layers[1].bias`` as its ``residual_bias``)."""
         if not add_identity:
-            return self.layers(x)
+            return self.layers[1](self.layers[0](x), skip_bias_grad=defer_out_bias)
         return (x if identity is None else identity) + self.layers(x)
 
 
@@ -181,7 +190,7 @@ class MultiheadAttention(nn.Module):
         self.attn = _AttnParams(embed_dims)
 
     def forward(self, query, key, value, query_pos=None, key_pos=None, blocked: Optional[torch.Tensor] = None,
-                add_identity: bool = True):
+                add_identity: bool = True, defer_out_bias: bool = False):
         """query (B, Q, E), key/value (B, L, E); ``blocked`` (B, 1|H, Q, L) bool, True = may NOT attend.
         ``add_identity=False`` returns the attention branch alone (residual add fused into the next LayerNorm)."""
         e, h = self.embed_dims, self.num_heads
@@ -192,7 +201,7 @@ class MultiheadAttention(nn.Module):
         k = ops.linear(k, w, bias, rows=(e, 2 * e))
         v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
         o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
-        o = self.attn.out_proj(o)
+        o = self.attn.out_proj(o, skip_bias_grad=defer_out_bias and not add_identity)
         return query + o if add_identity else o
 
 
@@ -229,7 +238,7 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, query_pos: torch.Tensor, reference_points: torch.Tensor,
                 spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor,
-                add_identity: bool = True):
+                add_identity: bool = True, defer_out_bias: bool = False):
         """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y)."""
         b, n, e = query.shape
         h, l, p = self.num_heads, self.num_levels, self.num_points
@@ -242,5 +251,5 @@ class MultiScaleDeformableAttention(nn.Module):
         normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(off.dtype)          # (L, 2) = (w, h)
         loc = reference_points.view(1, n, 1, 1, 1, 2) + off / normalizer.view(1, 1, 1, l, 1, 2)
         out = ops.ms_deform_attn(value, spatial_shapes, shapes_t, level_start, loc, aw)
-        out = self.output_proj(out)
+        out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)
         return out + query if add_identity else out

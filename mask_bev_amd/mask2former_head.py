@@ -31,8 +31,12 @@ class _DeformEncoderLayer(nn.Module):
 
     def forward(self, q, pos, ref, shapes, shapes_t, level_start):
         # post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12)
-        q = self.norms[0](q, self.self_attn(q, pos, ref, shapes, shapes_t, level_start, add_identity=False))
-        return self.norms[1](q, self.ffn(q, add_identity=False))
+        c = q.shape[-1]
+        ob, fb = self.self_attn.output_proj.bias, self.ffn.layers[1].bias
+        d1, d2 = ops.bias_grad_deferrable(ob, c), ops.bias_grad_deferrable(fb, c)
+        q = self.norms[0](q, self.self_attn(q, pos, ref, shapes, shapes_t, level_start, add_identity=False,
+                                            defer_out_bias=d1), residual_bias=ob if d1 else None)
+        return self.norms[1](q, self.ffn(q, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None)
 
 
 class _DeformEncoder(nn.Module):

@@ -561,7 +561,7 @@ _SMALL_F32_MACS = 1 << 30          # … and only while the f32 GEMM itself stay
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, rows, f32_out=False):
+    def forward(ctx, x, weight, bias, rows, f32_out=False, skip_bias_grad=False):
         if torch.is_autocast_enabled('cuda') and not (
                 x.dtype == torch.float32 and weight.dtype == torch.float32
                 and x.numel() <= _SMALL_F32_ROWS * x.shape[-1] and x.numel() * weight.shape[0] <= _SMALL_F32_MACS):
@@ -586,6 +586,7 @@ class _Linear(torch.autograd.Function):
                 y = torch.nn.functional.linear(x, w, b)
         ctx.save_for_backward(x, w)
         ctx.weight, ctx.bias, ctx.rows = weight, bias, rows
+        ctx.skip_bias_grad = skip_bias_grad
         return y
 
     @staticmethod
@@ -600,14 +601,16 @@ class _Linear(torch.autograd.Function):
             gx = g2.mm(w).view_as(x)
         bias_direct = (bias is not None and ctx.needs_input_grad[2] and getattr(bias, '_mbv_arena', False)
                        and bias.grad is not None and bias.grad.dtype == torch.float32)
-        bias_done = False
+        bias_done = ctx.skip_bias_grad        # the consumer of this layer's output accumulates db (K12 / activation op)
+        if bias_done:
+            bias_direct = False
         if ctx.needs_input_grad[1]:
             if getattr(weight, '_mbv_arena', False) and weight.grad is not None and weight.grad.dtype == torch.float32:
                 acc = weight.grad if rows is None else weight.grad[rows[0]:rows[1]]
                 bacc = None
                 if bias_direct:
                     bacc = bias.grad if rows is None else bias.grad[rows[0]:rows[1]]
-                bias_done = _wgrad_into(acc, g2, x2, bacc)  # straight into the arena gradient
+                bias_done = _wgrad_into(acc, g2, x2, bacc) or bias_done    # straight into the arena gradient
                 _fire_grad_hooks(weight)
                 if bias_done:
                     _fire_grad_hooks(bias)
@@ -625,17 +628,17 @@ class _Linear(torch.autograd.Function):
             else:
                 gb = torch.zeros_like(bias)
                 gb[rows[0]:rows[1]] = g2.sum(0, dtype=torch.float32)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           rows: Optional[tuple] = None, f32_out: bool = False) -> torch.Tensor:
+           rows: Optional[tuple] = None, f32_out: bool = False, skip_bias_grad: bool = False) -> torch.Tensor:
     """y = x W^T + b on the library GEMM (hipBLASLt) honouring autocast, with the split-K weight gradient.
     ``rows=(r0, r1)`` uses rows r0:r1 of the parameters (the q / k / v blocks of a packed ``in_proj_weight``)
     without materialising slices or zero-padded slice gradients.  Parameters that live in a
     :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
     direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
-    return _Linear.apply(x, weight, bias, rows, f32_out)
+    return _Linear.apply(x, weight, bias, rows, f32_out, skip_bias_grad)
 
 
 # --------------------------------------------------------------------------------------
@@ -1015,9 +1018,10 @@ def add_layernorm_supported(channels: int) -> bool:
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, weight, bias, eps, out_dtype):
+    def forward(ctx, a, b, weight, bias, eps, out_dtype, branch_bias=None):
         lib = _lib.load()
         _need_gpu(a, b, weight, bias)
+        ctx.branch_bias = branch_bias
         c = a.shape[-1]
         ok = (torch.float32, torch.bfloat16)
         if a.dtype not in ok or (b is not None and b.dtype not in ok) or out_dtype not in ok:
@@ -1054,7 +1058,7 @@ class _AddLayerNorm(torch.autograd.Function):
         if gy is None:                                    # only the residual path carries gradient
             ga = None if gs is None else gs.to(da)
             gb = None if (gs is None or db is None) else gs.to(db)
-            return ga, gb, None, None, None, None
+            return ga, gb, None, None, None, None, None
         c = s.shape[-1]
         rows = s.numel() // c
         gy = gy.contiguous()
@@ -1076,11 +1080,14 @@ class _AddLayerNorm(torch.autograd.Function):
             dgamma = torch.empty(c, dtype=torch.float32, device=s.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=s.device)
         nblk = lib.mbv_add_layernorm_bwd_blocks(rows, c)
-        ws = torch.empty(max(1, nblk * 2 * c), dtype=torch.float32, device=s.device)
+        bb = ctx.branch_bias             # arena gradient of the Linear bias that produced b: += colsum(dx)
+        ws = torch.empty(max(1, nblk * 3 * c), dtype=torch.float32, device=s.device)
         check(lib.mbv_add_layernorm_bwd(_ptr(gy), int(gy.dtype == torch.bfloat16), _ptr(gs),
                                         int(gs is not None and gs.dtype == torch.bfloat16), _ptr(s), _ptr(mean),
                                         _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo), _ptr(dgamma), _ptr(dbeta),
-                                        1 if direct else 0, _ptr(ws), _stream()), 'mbv_add_layernorm_bwd')
+                                        1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws), _stream()),
+              'mbv_add_layernorm_bwd')
+        # (the branch Linear's own backward, which runs after this one, announces its bias gradient to the hooks)
         if direct:
             _fire_grad_hooks(weight)
             _fire_grad_hooks(bias)
@@ -1089,16 +1096,48 @@ class _AddLayerNorm(torch.autograd.Function):
             dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
         ga = dx_lo if da == torch.bfloat16 else dx
         gb = None if db is None else (dx_lo if db == torch.bfloat16 else dx)
-        return ga, gb, dgamma, dbeta, None, None
+        return ga, gb, dgamma, dbeta, None, None, None
+
+
+class _AccumulateBiasGrad(torch.autograd.Function):
+    """Identity whose backward adds the column sums of the gradient to ``bias.grad`` (the safety net for a bias
+    gradient that was deferred to a K12 call which then took the non-fused path)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.bias = bias
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.reshape(-1, g.shape[-1])
+        if g2.dtype not in (torch.float32, torch.bfloat16):
+            g2 = g2.float()
+        colsum_accum(g2, ctx.bias.grad)
+        _fire_grad_hooks(ctx.bias)
+        return g, None
+
+
+def accumulate_bias_grad(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    return _AccumulateBiasGrad.apply(x, bias)
+
+
+def bias_grad_deferrable(bias: Optional[torch.Tensor], channels: int) -> bool:
+    """True when a Linear may leave its bias gradient to the K12 op that consumes its output as the residual branch:
+    the bias lives in a parameter arena (so K12 can accumulate into its gradient) and K12 supports the width."""
+    return (bias is not None and getattr(bias, '_mbv_arena', False) and bias.grad is not None
+            and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous() and bias.is_cuda
+            and add_layernorm_supported(channels) and torch.is_grad_enabled())
 
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
-                  eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, return_sum: bool = False):
+                  eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, return_sum: bool = False,
+                  branch_bias: Optional[torch.Tensor] = None):
     """``y = LayerNorm_C(a + b)`` over the last axis in one pass (K12); ``b=None`` is a plain LayerNorm.
     ``out_dtype`` (default: the autocast dtype when autocast is on and the consumer is a GEMM — pass it explicitly —
     else f32) is the storage type of y; statistics and the sum are f32.  With ``return_sum`` the f32 sum ``a + b``
     (the new residual stream of a pre-LN block) is returned as well: ``(y, s)``."""
     if out_dtype is None:
         out_dtype = torch.float32
-    y, s = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype)
+    y, s = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias)
     return (y, a if s is None else s) if return_sum else y

@@ -46,12 +46,12 @@ class ShiftWindowMSA(nn.Module):
         self.window_size, self.shift_size = window_size, shift_size
         self.w_msa = WindowMSA(embed_dims, num_heads, window_size)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:           # (B, H, W, C) → (B, H, W, C)
+    def forward(self, x: torch.Tensor, defer_out_bias: bool = False) -> torch.Tensor:   # (B, H, W, C) → (B, H, W, C)
         m = self.w_msa
         qkv = m.qkv(x)
         o = ops.window_attention(qkv, m.qkv.bias, m.relative_position_bias_table, m.num_heads, self.window_size,
                                  self.shift_size)
-        return m.proj(o)
+        return m.proj(o, skip_bias_grad=defer_out_bias)
 
 
 class SwinBlock(nn.Module):
@@ -62,13 +62,23 @@ class SwinBlock(nn.Module):
         self.norm2 = LayerNorm(embed_dims)
         self.ffn = FFN(embed_dims, feedforward_channels, act='gelu')
 
-    def forward(self, x: torch.Tensor, pending: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, pending: Optional[torch.Tensor] = None,
+                pending_bias: Optional[torch.Tensor] = None, defer_ffn_bias: bool = True):
         """Pre-LN block (swin.py:357-377): x ← x + attn(LN1(x)); x ← x + ffn(LN2(x)).  The residual adds are fused
         into the LayerNorm that reads their result (K12): the block takes the not-yet-added output ``pending`` of
-        the previous block's FFN and returns ``(x, pending)`` with the stream's value being ``x + pending``."""
-        y, x = self.norm1(x, pending, gemm_input=True, return_sum=True)
-        y, x = self.norm2(x, self.attn(y), gemm_input=True, return_sum=True)
-        return x, self.ffn(y, add_identity=False)
+        the previous block's FFN and returns ``(x, pending, pending_bias)`` with the stream's value being
+        ``x + pending``.  The bias gradients of the two output projections (proj, fc2) are column sums of exactly
+        the gradient K12 computes for its residual input, so K12 accumulates them (``pending_bias`` names the bias
+        whose gradient the consumer of ``pending`` owes; ``defer_ffn_bias=False`` when that consumer is not K12)."""
+        c = x.shape[-1]
+        y, x = self.norm1(x, pending, gemm_input=True, return_sum=True, residual_bias=pending_bias)
+        proj_b = self.attn.w_msa.proj.bias
+        d1 = ops.bias_grad_deferrable(proj_b, c)
+        y, x = self.norm2(x, self.attn(y, defer_out_bias=d1), gemm_input=True, return_sum=True,
+                          residual_bias=proj_b if d1 else None)
+        fc2_b = self.ffn.layers[1].bias
+        d2 = defer_ffn_bias and ops.bias_grad_deferrable(fc2_b, c)
+        return x, self.ffn(y, add_identity=False, defer_out_bias=d2), (fc2_b if d2 else None)
 
 
 class SwinBlockSequence(nn.Module):
@@ -83,11 +93,12 @@ class SwinBlockSequence(nn.Module):
     def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None):
         """→ (input of the next stage, this stage's output — normalised by ``out_norm`` when given; the last
         residual add of the stage is fused into that LayerNorm)."""
-        pending = None
-        for blk in self.blocks:
-            x, pending = blk(x, pending)
+        pending = pending_bias = None
+        last = len(self.blocks) - 1
+        for i, blk in enumerate(self.blocks):
+            x, pending, pending_bias = blk(x, pending, pending_bias, defer_ffn_bias=(i < last or out_norm is not None))
         if out_norm is not None:
-            out, x = out_norm(x, pending, return_sum=True)
+            out, x = out_norm(x, pending, return_sum=True, residual_bias=pending_bias)
         else:
             x = x if pending is None else x + pending
             out = x

@@ -176,3 +176,43 @@ def test_wgrad_small_f32(device, T, O, I):
     assert rc == 0
     assert torch.allclose(acc.double(), want, rtol=1e-5, atol=2e-5 * T ** 0.5)
     assert torch.allclose(bacc.double(), bwant, rtol=1e-5, atol=2e-5 * T ** 0.5)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_arena_gradients_equal_plain_autograd(device, dtype):
+    """Every direct-accumulation path at once (Linear dW / db incl. the small-token kernel, the bias gradients
+    deferred to K12, K12's and K3's affine gradients): a flattened module and a plain one with the same weights,
+    batch and sampling points produce the same loss and the same gradient for every parameter."""
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    kw = tiny_kwargs(nx=96, ny=96, q=8)
+    kw['compute_dtype'] = dtype
+    torch.manual_seed(0)
+    plain = MaskBevModule(**kw).to(device).train()
+    torch.manual_seed(0)
+    flat = MaskBevModule(**kw).to(device).train()
+    flat.load_state_dict(plain.state_dict())
+    arena = flat.flatten_parameters()
+    for m in (plain, flat):
+        m.log_scalars = False
+        h = m._panoptic_head._panoptic_head
+        h.num_points = 600
+        h.point_seed = 5                              # same sampling points in both evaluations
+    scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
+    labels, gt = random_gt(kw, 2, 3, seed=10)
+    batch = (scans, (labels.to(device), gt.to(device)))
+    l0 = plain.training_step(batch, 0)
+    l0.backward()
+    l1 = flat.training_step(batch, 0)
+    l1.backward()
+    tol = 2e-4 if dtype == 'fp32' else 4e-2
+    assert abs(float(l0) - float(l1)) <= tol * abs(float(l0))
+    worst = []
+    for (n, p), (_, q) in zip(plain.named_parameters(), flat.named_parameters()):
+        assert (p.grad is None) == (q.grad is None or float(q.grad.abs().max()) == 0.0 and p.grad is None), n
+        if p.grad is None:
+            continue
+        scale = float(p.grad.abs().max()) + 1e-9
+        err = float((p.grad.float() - q.grad).abs().max()) / scale
+        worst.append((err, n))
+        assert err <= (5e-3 if dtype == 'fp32' else 0.15), (n, err)
+    assert max(worst)[0] < (5e-3 if dtype == 'fp32' else 0.15)
