@@ -283,6 +283,13 @@ int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* s
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
 
+/* Activation backward fused with the bias gradient of the Linear in front of it (the fc1 layers of mmcv FFN,
+ * mask_bev/models/networks/swin/swin.py:347-355, mask_bev_panoptic_head.py:137-142): grad_pre = grad_act * act'(pre_act)
+ * with act = ReLU (kind 0) or erf-GELU (kind 1), all (rows, n) f32 or bf16, n % 4 == 0;
+ * bias_acc (n) f32 (nullable) += column sums of grad_pre. */
+int mbv_act_bwd_colsum(const void* grad_act, const void* pre_act, int32_t is_bf16, int32_t kind, int64_t rows, int32_t n,
+                       void* grad_pre, float* bias_acc, void* stream);
+
 /* Weight (and bias) gradient of a Linear applied to few tokens (the decoder's B*Q query rows), exact f32:
  * acc (O, I) += g^T x with g (T, O), x (T, I) row-major f32; bias_acc (O) += column sums of g when not NULL;
  * f32 MFMA, f32 atomics into acc / bias_acc. */

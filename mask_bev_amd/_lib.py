@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class MaskBevHipError(RuntimeError):
@@ -55,6 +55,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P]),
     'mbv_refresh_shadow': (ctypes.c_int, [_P, _P, _L, _P]),
     'mbv_colsum_accum': (ctypes.c_int, [_P, _I, _L, _I, _P, _P]),
+    'mbv_act_bwd_colsum': (ctypes.c_int, [_P, _P, _I, _I, _L, _I, _P, _P, _P]),
     'mbv_wgrad_small_f32': (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
     'mbv_mask_loss_rows_fwd': (ctypes.c_int, [_P, _P, _L, _I, _P, _P]),
     'mbv_mask_loss_rows_bwd': (ctypes.c_int, [_P, _P, _P, _L, _I, _P, _P]),

@@ -161,6 +161,66 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long ro
   }
 }
 
+// Activation backward fused with the bias gradient of the Linear in front of it:
+//   gz = ga * act'(z)   (GELU, erf form, or ReLU)      bias_acc[c] += Σ_rows gz[r, c]
+// — the column sums are taken from the values the kernel has just computed instead of by a second pass over gz
+// (the fc1 layers of the FFNs have the widest outputs of the model: 4C columns).  Same tiling as k_colsum.
+template <typename T>
+__device__ __forceinline__ void store4t(T* p, float4 v);
+template <>
+__device__ __forceinline__ void store4t<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <>
+__device__ __forceinline__ void store4t<unsigned short>(unsigned short* p, float4 v) {
+  uint2 u;
+  u.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
+  u.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <int KIND>   // 0 = ReLU, 1 = GELU (erf)
+__device__ __forceinline__ float act_grad(float z, float g) {
+  if (KIND == 0) return z > 0.f ? g : 0.f;
+  const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+  return g * (cdf + z * pdf);
+}
+
+template <typename T, int KIND>
+__global__ void __launch_bounds__(256) k_act_bwd_colsum(const T* __restrict__ ga, const T* __restrict__ z, long rows,
+                                                        int n, T* __restrict__ gz, float* __restrict__ bias_acc,
+                                                        const int W) {
+  __shared__ float4 part[256];
+  const int tid = threadIdx.x;
+  const int cg = tid & (W - 1), ro = tid / W, rpi = 256 / W;
+  const int c0 = (blockIdx.x * W + cg) * 4;
+  const long rows_per_block = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < n) {
+    for (long r = r0 + ro; r < r1; r += rpi) {
+      const float4 g = load4<T>(ga + r * n + c0);
+      const float4 x = load4<T>(z + r * n + c0);
+      float4 d;
+      d.x = act_grad<KIND>(x.x, g.x); d.y = act_grad<KIND>(x.y, g.y);
+      d.z = act_grad<KIND>(x.z, g.z); d.w = act_grad<KIND>(x.w, g.w);
+      store4t<T>(gz + r * n + c0, d);
+      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (ro == 0 && c0 < n && bias_acc) {
+    float4 s = acc;
+    for (int w = 1; w < rpi; ++w) {
+      const float4 q = part[w * W + cg];
+      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    atomicAdd(bias_acc + c0, s.x); atomicAdd(bias_acc + c0 + 1, s.y);
+    atomicAdd(bias_acc + c0 + 2, s.z); atomicAdd(bias_acc + c0 + 3, s.w);
+  }
+}
+
 // Small-token weight gradient in exact f32: acc (O, I) += g^T x for g (T, O), x (T, I), T = the decoder's B*Q rows.
 // The library's f32 GEMM heuristics pick one 256x256 macro-tile for this shape (measured 98 us per call); here one
 // wave owns a 32 x 32 output tile and a slice of T, multiplies with v_mfma_f32_32x32x2_f32 straight from global
@@ -295,6 +355,34 @@ extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, in
   const long waves = (long)ntiles * slices;
   hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, x, T, O,
                      I, tiles_i, ntiles, rows_per_slice, acc, bias_acc);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_act_bwd_colsum(const void* grad_act, const void* pre_act, int32_t is_bf16, int32_t kind, int64_t rows,
+                                  int32_t n, void* grad_pre, float* bias_acc, void* stream) {
+  if (rows < 0 || n <= 0 || (n & 3) || kind < 0 || kind > 1) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!grad_act || !pre_act || !grad_pre) return MBV_ERR_BAD_ARG;
+  const size_t al = is_bf16 ? 7 : 15;
+  if ((reinterpret_cast<size_t>(grad_act) | reinterpret_cast<size_t>(pre_act) | reinterpret_cast<size_t>(grad_pre)) & al)
+    return MBV_ERR_BAD_ARG;
+  int W = 1;
+  while (W < 256 && W * 4 < n) W <<= 1;
+  const int rpi = 256 / W;
+  const unsigned gx = (unsigned)((n + W * 4 - 1) / (W * 4));
+  long gy = (2048 + gx - 1) / gx;                      // elementwise work: fill the chip; ≤ 256 atomics per column
+  if (gy > 256) gy = 256;
+  if (gy > rows / (4L * rpi)) gy = rows / (4L * rpi);
+  if (gy < 1) gy = 1;
+  const dim3 grid(gx, (unsigned)gy), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MBV_ACT(T, K)                                                                                              \
+  hipLaunchKernelGGL((k_act_bwd_colsum<T, K>), grid, block, 0, st, reinterpret_cast<const T*>(grad_act),           \
+                     reinterpret_cast<const T*>(pre_act), (long)rows, n, reinterpret_cast<T*>(grad_pre), bias_acc, W)
+  if (is_bf16) { if (kind) MBV_ACT(unsigned short, 1); else MBV_ACT(unsigned short, 0); }
+  else { if (kind) MBV_ACT(float, 1); else MBV_ACT(float, 0); }
+#undef MBV_ACT
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -73,8 +73,17 @@ class FFN(nn.Module):
         that follows (K12); with ``defer_out_bias`` that LayerNorm also accumulates the output layer's bias gradient
         (pass ``self.layers[1].bias`` as its ``residual_bias``)."""
         if not add_identity:
-            return self.layers[1](self.layers[0](x), skip_bias_grad=defer_out_bias)
-        return (x if identity is None else identity) + self.layers(x)
+            return self.layers[1](self._hidden(x), skip_bias_grad=defer_out_bias)
+        return (x if identity is None else identity) + self.layers[1](self._hidden(x))
+
+    def _hidden(self, x: torch.Tensor) -> torch.Tensor:
+        """act(fc1(x)); for token-major activations beyond the small-token path the bias gradient of fc1 is taken
+        inside the activation's backward kernel (ops.bias_act) instead of by a separate pass over d(fc1 output)."""
+        fc1, act = self.layers[0][0], self.layers[0][1]
+        kind = 'gelu' if isinstance(act, nn.GELU) else 'relu'
+        rows = x.numel() // max(1, x.shape[-1])
+        d = (rows > 2048 and fc1.out_features % 4 == 0 and ops.bias_grad_deferrable(fc1.bias, 4))
+        return ops.bias_act(fc1(x, skip_bias_grad=d), fc1.bias if d else None, kind)
 
 
 def corner_pad(x: torch.Tensor, k: int, s: int) -> torch.Tensor:

@@ -1099,6 +1099,44 @@ class _AddLayerNorm(torch.autograd.Function):
         return ga, gb, dgamma, dbeta, None, None, None
 
 
+class _BiasAct(torch.autograd.Function):
+    """act(z) (ReLU / erf-GELU) whose backward also accumulates the bias gradient of the Linear that produced z
+    (K11 ``mbv_act_bwd_colsum``): one pass computes dz and its column sums."""
+
+    @staticmethod
+    def forward(ctx, z, bias, kind):
+        ctx.bias, ctx.kind = bias, kind
+        ctx.save_for_backward(z)
+        return torch.nn.functional.gelu(z) if kind == 1 else torch.relu(z)
+
+    @staticmethod
+    def backward(ctx, ga):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        n = z.shape[-1]
+        zc = z.contiguous()
+        ga = ga.to(zc.dtype).contiguous()
+        gz = torch.empty_like(zc)
+        bias = ctx.bias
+        check(lib.mbv_act_bwd_colsum(_ptr(ga), _ptr(zc), int(zc.dtype == torch.bfloat16), ctx.kind, zc.numel() // n, n,
+                                     _ptr(gz), _ptr(None if bias is None else bias.grad), _stream()),
+              'mbv_act_bwd_colsum')
+        return gz, None, None
+
+
+def bias_act(z: torch.Tensor, bias: Optional[torch.Tensor], kind: str) -> torch.Tensor:
+    """``relu`` / ``gelu`` of a Linear output ``z``.  When ``bias`` (that Linear's arena-resident bias, the layer
+    having been run with ``skip_bias_grad=True``) is given, the backward accumulates its gradient while it computes
+    dz.  Falls back to the torch activation for shapes / dtypes the kernel does not take."""
+    k = 1 if kind == 'gelu' else 0
+    ok = (z.is_cuda and z.dtype in (torch.float32, torch.bfloat16) and z.shape[-1] % 4 == 0 and z.requires_grad)
+    if not ok:
+        if bias is not None and z.requires_grad:
+            z = accumulate_bias_grad(z, bias)          # the deferred bias gradient must not be lost: dz reaches it here
+        return torch.nn.functional.gelu(z) if k == 1 else torch.relu(z)
+    return _BiasAct.apply(z, bias, k)
+
+
 class _AccumulateBiasGrad(torch.autograd.Function):
     """Identity whose backward adds the column sums of the gradient to ``bias.grad`` (the safety net for a bias
     gradient that was deferred to a K12 call which then took the non-fused path)."""

@@ -216,3 +216,28 @@ def test_arena_gradients_equal_plain_autograd(device, dtype):
         worst.append((err, n))
         assert err <= (5e-3 if dtype == 'fp32' else 0.15), (n, err)
     assert max(worst)[0] < (5e-3 if dtype == 'fp32' else 0.15)
+
+
+@pytest.mark.parametrize('kind', ['gelu', 'relu'])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_bias_act_backward(device, kind, dt):
+    """Fused activation backward + bias column sums vs torch."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(3000, 96, generator=g) * 2).to(device).to(dt).requires_grad_()
+    bias = torch.nn.Parameter(torch.zeros(96, device=device))
+    bias.grad = torch.randn(96, generator=g).to(device)
+    b0 = bias.grad.clone()
+    go = torch.randn(3000, 96, generator=g).to(device).to(dt)
+    y = ops.bias_act(z, bias, kind)
+    y.backward(go)
+    zr = z.detach().double().requires_grad_()
+    yr = torch.nn.functional.gelu(zr) if kind == 'gelu' else torch.relu(zr)
+    yr.backward(go.double())
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert torch.allclose(y.double(), yr, rtol=tol, atol=tol)
+    assert torch.allclose(z.grad.double(), zr.grad, rtol=tol, atol=tol)
+    # column sums of the f64 reference gradient (the kernel sums its f32 values before they are rounded to bf16)
+    want = b0.double() + zr.grad.sum(0)
+    assert torch.allclose(bias.grad.double(), want, rtol=1e-4 if dt == torch.float32 else 5e-3,
+                          atol=2e-3 if dt == torch.float32 else 0.3)
