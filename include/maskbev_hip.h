@@ -187,7 +187,8 @@ int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int6
  * as qkv; lse: mbv_window_attn_lse_elems(...) f32, saved for backward.  head_dim = C / heads must be
  * 16, 32 or 64 and ws <= 11.
  * Backward zero-fills grad_table ((2ws-1)^2, heads) and grad_qkv_bias (3C: gradient reaching the bias
- * through padded tokens) itself, then accumulates them with f32 atomics; grad_qkv (B, H, W, 3C) is
+ * through padded tokens; with full_bias_grad != 0 also the column sums of grad_qkv over the real tokens, i.e.
+ * the whole bias gradient of the qkv Linear, which then skips its own pass over grad_qkv) itself, then accumulates them with f32 atomics; grad_qkv (B, H, W, 3C) is
  * written in full.
  */
 int64_t mbv_window_attn_lse_elems(int32_t batch, int32_t H, int32_t W, int32_t heads, int32_t ws);
@@ -199,7 +200,8 @@ int mbv_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bia
 int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
                         const void* grad_out, const float* lse, int32_t is_bf16,
                         int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
-                        void* grad_qkv, float* grad_table, float* grad_qkv_bias, void* stream);
+                        void* grad_qkv, float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8 — indexed bilinear point sampling of mask maps (loss and Hungarian targets).

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
                                                          const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
                                                          const float* __restrict__ lse, WinGeom g, float scale,
                                                          TIn* __restrict__ grad_qkv, float* __restrict__ grad_table,
-                                                         float* __restrict__ grad_pad /* (3C) */) {
+                                                         float* __restrict__ grad_pad /* (3C) */, int full_bias) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
   __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
@@ -381,12 +381,17 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   __shared__ int pix[NPAD];
   __shared__ float lse_s[NPAD];
   __shared__ double delta_s[NPAD];
+  // column sums of dQ / dK / dV of this (window, head): the qkv-bias gradient.  Padded tokens always contribute (their
+  // q, k, v ARE the bias); with full_bias the real tokens do too, which is the bias gradient of the qkv Linear itself
+  // — that layer then skips its own pass over grad_qkv.
+  __shared__ double colacc[3 * D];
   const BlockId id = decode_block(g);
   const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
   for (int i = threadIdx.x; i < tsz; i += blockDim.x) {
     tbl[i] = bias_table[i * g.heads + id.head];
     dtbl[i] = 0.0;
   }
+  for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) colacc[i] = 0.0;
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     if (t < g.N) {
       const int ty = t / g.ws, tx = t - ty * g.ws;
@@ -478,14 +483,17 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
     for (int cb = 0; cb < NCB; ++cb) {
       const int dcol = r + 32 * cb;
       if (dcol >= D) continue;
+      float csum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qq = 32 * wave + acc_row(i, h);
         if (qq >= g.N) continue;
         const int px = pix[qq];
         if (px >= 0) grad_qkv[(row0 + px) * C3 + col + dcol] = (TIn)dq[cb][i];
-        else atomicAdd(&grad_pad[col + dcol], dq[cb][i]);
+        if (px < 0 || full_bias) csum += dq[cb][i];
       }
+      csum += __shfl_xor(csum, 32, 64);
+      if (h == 0 && csum != 0.f) atomicAdd(&colacc[dcol], (double)csum);
     }
   }
   if (wave < nblk && part == 1) {
@@ -523,6 +531,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
     for (int cb = 0; cb < NCB; ++cb) {
       const int dcol = r + 32 * cb;
       if (dcol >= D) continue;
+      float ksum = 0.f, vsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int kk = 32 * kb + acc_row(i, h);
@@ -531,15 +540,21 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
         if (px >= 0) {
           grad_qkv[(row0 + px) * C3 + g.C + col + dcol] = (TIn)dk[cb][i];
           grad_qkv[(row0 + px) * C3 + 2 * g.C + col + dcol] = (TIn)dv[cb][i];
-        } else {
-          atomicAdd(&grad_pad[g.C + col + dcol], dk[cb][i]);
-          atomicAdd(&grad_pad[2 * g.C + col + dcol], dv[cb][i]);
         }
+        if (px < 0 || full_bias) { ksum += dk[cb][i]; vsum += dv[cb][i]; }
       }
+      ksum += __shfl_xor(ksum, 32, 64);
+      vsum += __shfl_xor(vsum, 32, 64);
+      if (h == 0 && ksum != 0.f) atomicAdd(&colacc[D + dcol], (double)ksum);
+      if (h == 0 && vsum != 0.f) atomicAdd(&colacc[2 * D + dcol], (double)vsum);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < tsz; i += blockDim.x) atomicAdd(&grad_table[i * g.heads + id.head], (float)dtbl[i]);
+  for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) {
+    const double v = colacc[i];
+    if (v != 0.0) atomicAdd(&grad_pad[(i / D) * g.C + col + (i % D)], (float)v);
+  }
 }
 
 bool make_geom(int batch, int H, int W, int C, int heads, int ws, int shift, WinGeom& g) {
@@ -577,7 +592,7 @@ int launch_fwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
 template <bool BF16, typename TIn>
 int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, const float* table, const void* out,
                const void* grad_out, const float* lse, void* grad_qkv, float* grad_table, float* grad_pad,
-               hipStream_t stream) {
+               int full_bias, hipStream_t stream) {
   const float scale = 1.0f / sqrtf((float)D);
   const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(512);
   const TIn* q = reinterpret_cast<const TIn*>(qkv);
@@ -588,9 +603,9 @@ int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
   gv.vec_ok = BF16 && g.C % 8 == 0 &&
               ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(grad_out)) & 15) == 0;
   switch (D) {
-    case 16: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
-    case 32: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
-    case 64: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad); break;
+    case 16: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad, full_bias); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 32, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad, full_bias); break;
+    case 64: hipLaunchKernelGGL((k_window_attn_bwd<BF16, 64, TIn>), grid, block, 0, stream, q, qkv_bias, table, o, go, lse, gv, scale, gq, grad_table, grad_pad, full_bias); break;
     default: return MBV_ERR_UNSUPPORTED;
   }
   MBV_CHECK_LAUNCH();
@@ -621,7 +636,7 @@ extern "C" int mbv_window_attn_fwd(const void* qkv, const float* qkv_bias, const
 extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
                                    const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch, int32_t H,
                                    int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, void* grad_qkv,
-                                   float* grad_table, float* grad_qkv_bias, void* stream_) {
+                                   float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WinGeom g;
   if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
@@ -633,7 +648,7 @@ extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const
   MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
   MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
   return is_bf16 ? launch_bwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
-                                            grad_qkv_bias, stream)
+                                            grad_qkv_bias, full_bias_grad, stream)
                  : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
-                                            grad_qkv_bias, stream);
+                                            grad_qkv_bias, full_bias_grad, stream);
 }

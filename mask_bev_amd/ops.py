@@ -372,9 +372,10 @@ def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
 # --------------------------------------------------------------------------------------
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, qkv_bias, bias_table, num_heads, ws, shift):
+    def forward(ctx, qkv, qkv_bias, bias_table, num_heads, ws, shift, full_bias_grad=False):
         lib = _lib.load()
         _need_gpu(qkv, qkv_bias, bias_table)
+        ctx.full_bias_grad = full_bias_grad
         if qkv.dtype not in (torch.float32, torch.bfloat16):
             raise MaskBevHipError(f'window_attention supports f32 and bf16 qkv, got {qkv.dtype}')
         qkv = qkv.contiguous()
@@ -407,19 +408,21 @@ class _WindowAttention(torch.autograd.Function):
         is_bf16 = 1 if qkv.dtype == torch.bfloat16 else 0
         rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
                                      is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
-                                     _ptr(g_bias), _stream())
+                                     _ptr(g_bias), 1 if ctx.full_bias_grad else 0, _stream())
         check(rc, 'mbv_window_attn_bwd')
-        return g_qkv, g_bias.to(bias_dtype), g_table.to(table_dtype), None, None, None
+        return g_qkv, g_bias.to(bias_dtype), g_table.to(table_dtype), None, None, None, None
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torch.Tensor, num_heads: int, ws: int,
-                     shift: int) -> torch.Tensor:
+                     shift: int, full_bias_grad: bool = False) -> torch.Tensor:
     """Shifted-window multi-head attention on a channels-last map (K4, include/maskbev_hip.h).
 
     qkv (B, H, W, 3C) is the fused projection of the *un-padded* tokens; tokens that the reference pads in
     (swin.py:185-188: zeros after LayerNorm) have qkv == bias, which the kernel substitutes while staging.
-    Returns (B, H, W, C) (before the output projection), same dtype as qkv (f32 or bf16)."""
-    return _WindowAttention.apply(qkv, qkv_bias, bias_table, num_heads, ws, shift)
+    Returns (B, H, W, C) (before the output projection), same dtype as qkv (f32 or bf16).
+    ``full_bias_grad``: the gradient returned for ``qkv_bias`` is the WHOLE bias gradient of the qkv projection
+    (column sums of d(qkv) over all tokens) — run that Linear with ``skip_bias_grad=True``."""
+    return _WindowAttention.apply(qkv, qkv_bias, bias_table, num_heads, ws, shift, full_bias_grad)
 
 
 # --------------------------------------------------------------------------------------

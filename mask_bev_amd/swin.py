@@ -48,9 +48,12 @@ class ShiftWindowMSA(nn.Module):
 
     def forward(self, x: torch.Tensor, defer_out_bias: bool = False) -> torch.Tensor:   # (B, H, W, C) → (B, H, W, C)
         m = self.w_msa
-        qkv = m.qkv(x)
+        # the bias gradient of the qkv projection is the column sums of d(qkv): K4's backward has those tiles in
+        # registers anyway (and already collects the padded tokens' share), so it accumulates them and the Linear skips
+        fb = torch.is_grad_enabled() and x.is_cuda and m.qkv.bias is not None
+        qkv = m.qkv(x, skip_bias_grad=fb)
         o = ops.window_attention(qkv, m.qkv.bias, m.relative_position_bias_table, m.num_heads, self.window_size,
-                                 self.shift_size)
+                                 self.shift_size, full_bias_grad=fb)
         return m.proj(o, skip_bias_grad=defer_out_bias)
 
 
