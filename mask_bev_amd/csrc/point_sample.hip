@@ -83,13 +83,16 @@ __global__ void __launch_bounds__(256) k_pack_binary(const float* __restrict__ s
 
 constexpr int kPackedWords = 32768;   // 128 KB LDS: up to 1024 x 1024 binary pixels
 
+// WORDS = LDS words reserved for the packed map: 8192 (32 KB, a 512 x 512 mask: four workgroups per CU) or 32768
+// (128 KB, up to 1024 x 1024: one per CU) — the occupancy, not the arithmetic, sets this kernel's time.
+template <int WORDS>
 __global__ void __launch_bounds__(512) k_point_sample_packed(const uint32_t* __restrict__ packed,
                                                              int64_t words_per_map,
                                                              const int32_t* __restrict__ src_index,
                                                              const float* __restrict__ coords,
                                                              const int32_t* __restrict__ coord_index, int P, int H,
                                                              int W, float* __restrict__ out) {
-  __shared__ uint32_t bits[kPackedWords];
+  __shared__ uint32_t bits[WORDS];
   const int g = blockIdx.x;
   const uint32_t* s = packed + (int64_t)src_index[g] * words_per_map;
   for (int i = threadIdx.x; i < (int)words_per_map; i += blockDim.x) bits[i] = s[i];
@@ -203,8 +206,12 @@ extern "C" int mbv_point_sample_packed_fwd(const uint32_t* packed, const int32_t
   if (!packed || !src_index || !coords || !coord_index || !out) return MBV_ERR_BAD_ARG;
   const int64_t words = mbv_packed_mask_words(H, W);
   if (words > kPackedWords) return MBV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_point_sample_packed, dim3(num_rows), dim3(512), 0, stream, packed, words, src_index, coords,
-                     coord_index, num_points, H, W, out);
+  if (words <= 8192)
+    hipLaunchKernelGGL(k_point_sample_packed<8192>, dim3(num_rows), dim3(512), 0, stream, packed, words, src_index,
+                       coords, coord_index, num_points, H, W, out);
+  else
+    hipLaunchKernelGGL(k_point_sample_packed<kPackedWords>, dim3(num_rows), dim3(512), 0, stream, packed, words,
+                       src_index, coords, coord_index, num_points, H, W, out);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
