@@ -18,7 +18,8 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kBlocks = 1024;     // persistent-style grid: one set of channel atomics per workgroup
+constexpr int kBlocks = 2048;     // persistent-style grid: one set of channel atomics per workgroup
+constexpr int kChunk = 8;         // rows of a pillar in flight per wave
 
 // CPL = channels per lane (1 for 64 channels, 2 for 128)
 template <int CPL>
@@ -36,25 +37,56 @@ __global__ void __launch_bounds__(256) k_pfn_stats(float* __restrict__ Y, const 
 #pragma unroll
   for (int k = 0; k < CPL; ++k) { ds[k] = 0.0; dq[k] = 0.0; }
   int since_flush = 0;
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < V; v += gridDim.x * kWavesPerBlock) {
-    const int n = num_points[v];
-    const int64_t rs = row_start[v];
+  // Rows are read in chunks of kChunk with all their loads issued before the first use (and before the stores
+  // that follow, which the compiler must otherwise order against later loads of Y): a pillar holds ≈ 5 rows, so
+  // the walk costs about one memory round trip per pillar instead of one per row and channel half.  The header
+  // (n, row_start) of the wave's next pillar is fetched while the current one is processed.
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  int n_next = v < V ? num_points[v] : 0;
+  int64_t rs_next = v < V ? (int64_t)row_start[v] : 0;
+  for (; v < V; v += vstride) {
+    const int n = n_next;
+    const int64_t rs = rs_next;
+    if (v + vstride < V) { n_next = num_points[v + vstride]; rs_next = row_start[v + vstride]; }
     const float mult = (float)(P - n);
+    float t[CPL], yp[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      t[k] = (T && c < U) ? T[(int64_t)v * U + c] : 0.f;
+      yp[k] = c < U ? Ypad[(int64_t)v * U + c] : 0.f;
+    }
+    for (int j0 = 0; j0 < n; j0 += kChunk) {
+      float y[kChunk][CPL];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          y[j][k] = (j0 + j < n && c < U) ? Y[(rs + j0 + j) * U + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          if (j0 + j < n && c < U) {
+            float yy = y[j][k];
+            if (T) { yy += t[k]; Y[(rs + j0 + j) * U + c] = yy; }
+            s[k] += yy;
+            q[k] += yy * yy;
+          }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
       if (c >= U) continue;
-      const float t = T ? T[(int64_t)v * U + c] : 0.f;
-      for (int j = 0; j < n; ++j) {
-        float y = Y[(rs + j) * U + c];
-        if (T) { y += t; Y[(rs + j) * U + c] = y; }
-        s[k] += y;
-        q[k] += y * y;
-      }
-      float yp = Ypad[(int64_t)v * U + c];
-      if (T) { yp += t; Ypad[(int64_t)v * U + c] = yp; }
-      s[k] += mult * yp;
-      q[k] += mult * yp * yp;
+      float ypp = yp[k];
+      if (T) { ypp += t[k]; Ypad[(int64_t)v * U + c] = ypp; }
+      s[k] += mult * ypp;
+      q[k] += mult * ypp * ypp;
     }
     if (++since_flush == 64) {      // bound the f32 partial sums: fold into f64 every 64 pillars
 #pragma unroll
@@ -120,22 +152,48 @@ __global__ void __launch_bounds__(256) k_pfn_apply_max(const float* __restrict__
     sc[k] = c < U ? scale[c] : 0.f;
     sh[k] = c < U ? shift[c] : 0.f;
   }
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < V; v += gridDim.x * kWavesPerBlock) {
-    const int n = num_points[v];
-    const int64_t rs = row_start[v];
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  int n_next = v < V ? num_points[v] : 0;
+  int64_t rs_next = v < V ? (int64_t)row_start[v] : 0;
+  for (; v < V; v += vstride) {
+    const int n = n_next;
+    const int64_t rs = rs_next;
+    if (v + vstride < V) { n_next = num_points[v + vstride]; rs_next = row_start[v + vstride]; }
+    float ap[CPL], mx[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      ap[k] = c < U ? fmaxf(Ypad[(int64_t)v * U + c] * sc[k] + sh[k], 0.f) : 0.f;
+      mx[k] = n < P ? ap[k] : -INFINITY;
+    }
+    for (int j0 = 0; j0 < n; j0 += kChunk) {
+      float y[kChunk][CPL];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          y[j][k] = (j0 + j < n && c < U) ? Y[(rs + j0 + j) * U + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          if (j0 + j < n && c < U) {
+            const float a = fmaxf(y[j][k] * sc[k] + sh[k], 0.f);
+            if (A) A[(rs + j0 + j) * U + c] = a;
+            mx[k] = fmaxf(mx[k], a);
+          }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
       if (c >= U) continue;
-      const float ap = fmaxf(Ypad[(int64_t)v * U + c] * sc[k] + sh[k], 0.f);
-      float mx = n < P ? ap : -INFINITY;
-      for (int j = 0; j < n; ++j) {
-        const float a = fmaxf(Y[(rs + j) * U + c] * sc[k] + sh[k], 0.f);
-        if (A) A[(rs + j) * U + c] = a;
-        mx = fmaxf(mx, a);
-      }
-      if (Apad) Apad[(int64_t)v * U + c] = ap;
-      M[(int64_t)v * U + c] = mx;
+      if (Apad) Apad[(int64_t)v * U + c] = ap[k];
+      M[(int64_t)v * U + c] = mx[k];
     }
   }
 }
@@ -166,43 +224,95 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route(const float* __restrict__
     sc[k] = ok ? scale[c] : 0.f; sh[k] = ok ? shift[c] : 0.f; mu[k] = ok ? mean[c] : 0.f; rs_[k] = ok ? rstd[c] : 0.f;
     s1[k] = 0.0; s2[k] = 0.0;
   }
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < V; v += gridDim.x * kWavesPerBlock) {
-    const int n = num_points[v];
-    const int64_t rs = row_start[v];
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  int n_next = v < V ? num_points[v] : 0;
+  int64_t rs_next = v < V ? (int64_t)row_start[v] : 0;
+  for (; v < V; v += vstride) {
+    const int n = n_next;
+    const int64_t rs = rs_next;
+    if (v + vstride < V) { n_next = num_points[v + vstride]; rs_next = row_start[v + vstride]; }
+    float yp[CPL], ap[CPL], dm[CPL], gp[CPL], mx[CPL];
+    int arg[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      const bool ok = c < U;
+      yp[k] = ok ? Ypad[(int64_t)v * U + c] : 0.f;
+      dm[k] = ok ? dM[(int64_t)v * U + c] : 0.f;
+      gp[k] = (ok && SApad) ? SApad[(int64_t)v * U + c] : 0.f;
+      ap[k] = fmaxf(yp[k] * sc[k] + sh[k], 0.f);
+      mx[k] = -INFINITY;
+      arg[k] = -1;
+    }
+    // pass 1: arg-max (first maximal real row; the padded rows sit after the real rows in the dense tensor).
+    // Pillars of up to kChunk rows (almost all of them) keep their rows in registers for pass 2.
+    float y0[kChunk][CPL];
+    for (int j0 = 0; j0 < n; j0 += kChunk) {
+      float y[kChunk][CPL];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          y[j][k] = (j0 + j < n && c < U) ? Y[(rs + j0 + j) * U + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          if (j0 == 0) y0[j][k] = y[j][k];
+          if (j0 + j < n) {
+            const float a = fmaxf(y[j][k] * sc[k] + sh[k], 0.f);
+            if (a > mx[k]) { mx[k] = a; arg[k] = j0 + j; }
+          }
+        }
+    }
+    bool pad_wins[CPL];
+    float f1[CPL], f2[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { pad_wins[k] = (n < P) && (ap[k] > mx[k]); f1[k] = 0.f; f2[k] = 0.f; }
+    // pass 2: dz = relu'(a) * (dA + routed dM), BatchNorm-backward sums
+    for (int j0 = 0; j0 < n; j0 += kChunk) {
+      float y[kChunk][CPL], g[kChunk][CPL];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          const bool ok = j0 + j < n && c < U;
+          y[j][k] = j0 == 0 ? y0[j][k] : (ok ? Y[(rs + j0 + j) * U + c] : 0.f);
+          g[j][k] = (ok && has_dA) ? DZ[(rs + j0 + j) * U + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          if (j0 + j < n && c < U) {
+            const float yy = y[j][k];
+            const float a = yy * sc[k] + sh[k];
+            float gg = g[j][k];
+            if (!pad_wins[k] && j0 + j == arg[k]) gg += dm[k];
+            const float dz = a > 0.f ? gg : 0.f;
+            DZ[(rs + j0 + j) * U + c] = dz;
+            f1[k] += dz;
+            f2[k] += dz * (yy - mu[k]) * rs_[k];
+          }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
       if (c >= U) continue;
-      const float yp = Ypad[(int64_t)v * U + c];
-      const float ap = fmaxf(yp * sc[k] + sh[k], 0.f);
-      // arg-max (first maximal real row; the padded rows sit after the real rows in the dense tensor)
-      float mx = -INFINITY;
-      int arg = -1;
-      for (int j = 0; j < n; ++j) {
-        const float a = fmaxf(Y[(rs + j) * U + c] * sc[k] + sh[k], 0.f);
-        if (a > mx) { mx = a; arg = j; }
-      }
-      const bool pad_wins = (n < P) && (ap > mx);
-      const float dm = dM[(int64_t)v * U + c];
-      float f1 = 0.f, f2 = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const float y = Y[(rs + j) * U + c];
-        const float a = y * sc[k] + sh[k];
-        float g = has_dA ? DZ[(rs + j) * U + c] : 0.f;
-        if (!pad_wins && j == arg) g += dm;
-        const float dz = a > 0.f ? g : 0.f;
-        DZ[(rs + j) * U + c] = dz;
-        f1 += dz;
-        f2 += dz * (y - mu[k]) * rs_[k];
-      }
-      float gp = SApad ? SApad[(int64_t)v * U + c] : 0.f;
-      if (pad_wins) gp += dm;
-      const float dzp = (yp * sc[k] + sh[k]) > 0.f ? gp : 0.f;
+      float gpp = gp[k];
+      if (pad_wins[k]) gpp += dm[k];
+      const float dzp = (yp[k] * sc[k] + sh[k]) > 0.f ? gpp : 0.f;
       DZpad[(int64_t)v * U + c] = dzp;
-      f1 += dzp;
-      f2 += dzp * (yp - mu[k]) * rs_[k];
-      s1[k] += f1;
-      s2[k] += f2;
+      f1[k] += dzp;
+      f2[k] += dzp * (yp[k] - mu[k]) * rs_[k];
+      s1[k] += f1[k];
+      s2[k] += f2[k];
     }
   }
 #pragma unroll
@@ -237,25 +347,55 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn(const float* __restrict__ Y,
     c1[k] = (training && ok) ? (float)(sums[c] / count) : 0.f;
     c2[k] = (training && ok) ? (float)(sums[U + c] / count) : 0.f;
   }
-  for (int v = blockIdx.x * kWavesPerBlock + wave; v < V; v += gridDim.x * kWavesPerBlock) {
-    const int n = num_points[v];
-    const int64_t rs = row_start[v];
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  int n_next = v < V ? num_points[v] : 0;
+  int64_t rs_next = v < V ? (int64_t)row_start[v] : 0;
+  for (; v < V; v += vstride) {
+    const int n = n_next;
+    const int64_t rs = rs_next;
+    if (v + vstride < V) { n_next = num_points[v + vstride]; rs_next = row_start[v + vstride]; }
     const float mult = (float)(P - n);
+    float acc[CPL], ypv[CPL], dzpv[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      acc[k] = 0.f;
+      ypv[k] = c < U ? Ypad[(int64_t)v * U + c] : 0.f;
+      dzpv[k] = c < U ? DZpad[(int64_t)v * U + c] : 0.f;
+    }
+    for (int j0 = 0; j0 < n; j0 += kChunk) {
+      float y[kChunk][CPL], dz[kChunk][CPL];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          const bool ok = j0 + j < n && c < U;
+          y[j][k] = ok ? Y[(rs + j0 + j) * U + c] : 0.f;
+          dz[j][k] = ok ? DZ[(rs + j0 + j) * U + c] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+          const int c = lane + 64 * k;
+          if (j0 + j < n && c < U) {
+            const float xh = (y[j][k] - mu[k]) * rs_[k];
+            const float dy = gs[k] * (dz[j][k] - c1[k] - xh * c2[k]);
+            DZ[(rs + j0 + j) * U + c] = dy;
+            acc[k] += dy;
+          }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int c = lane + 64 * k;
       if (c >= U) continue;
-      float acc = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const float xh = (Y[(rs + j) * U + c] - mu[k]) * rs_[k];
-        const float dy = gs[k] * (DZ[(rs + j) * U + c] - c1[k] - xh * c2[k]);
-        DZ[(rs + j) * U + c] = dy;
-        acc += dy;
-      }
-      const float xhp = (Ypad[(int64_t)v * U + c] - mu[k]) * rs_[k];
-      const float dyp = gs[k] * (DZpad[(int64_t)v * U + c] - mult * c1[k] - mult * xhp * c2[k]);
+      const float xhp = (ypv[k] - mu[k]) * rs_[k];
+      const float dyp = gs[k] * (dzpv[k] - mult * c1[k] - mult * xhp * c2[k]);
       DZpad[(int64_t)v * U + c] = dyp;
-      if (dT) dT[(int64_t)v * U + c] = acc + dyp;
+      if (dT) dT[(int64_t)v * U + c] = acc[k] + dyp;
     }
   }
 }
