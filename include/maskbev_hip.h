@@ -312,6 +312,13 @@ int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t ro
 int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const float* grad_sums, int64_t rows,
                            int32_t points, float* grad_logits, void* stream);
 
+/* Matching-cost terms (mmdet CrossEntropyLossCost(use_sigmoid) + DiceCost on the sampled points,
+ * mask2former_head.py:199-205): logits (groups, queries, points) f32 → terms (groups, 3, queries, points) f32 =
+ * [softplus(-x), softplus(x), sigmoid(x)] — one batched GEMM against the sampled ground truth then gives all three
+ * cost matrices — and row_sums (groups*queries, 2) = [sum softplus(x), sum sigmoid(x)]. */
+int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points, float* terms,
+                         float* row_sums, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K12 — fused residual-add + LayerNorm over the last (channel) axis of token-major activations.
  * Replaces: the `x + f(x)` → nn.LayerNorm(C) pairs of SwinBlock.forward (mask_bev/models/networks/swin/swin.py:

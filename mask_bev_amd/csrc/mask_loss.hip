@@ -88,6 +88,47 @@ __global__ void __launch_bounds__(kThreads) k_mask_loss_rows_bwd(const float* __
   }
 }
 
+// Matching-cost terms of the point-sampled mask logits x (rows, P), one pass:
+//   terms[0] = softplus(-x)  (BCE against 1),  terms[1] = softplus(-x) + x  (BCE against 0),  terms[2] = sigmoid(x)
+// laid out (groups, 3, Q, P) so that one batched GEMM against the sampled ground truth (groups, P, G) yields all three
+// cost matrices, plus the row sums of terms[1] and terms[2] (the "against 0" constant and the dice denominator).
+// Replaces five elementwise passes and two reductions of mmdet's CrossEntropyLossCost / DiceCost as used at
+// mask2former_head.py:199-205.
+__global__ void __launch_bounds__(kThreads) k_match_terms(const float* __restrict__ x, int q, int p,
+                                                          float* __restrict__ terms, float* __restrict__ sums) {
+  __shared__ float red[2][kThreads / 64];
+  const long row = blockIdx.x;                      // = group * q + query
+  const long group = row / q, query = row - group * q;
+  const float* xr = x + row * p;
+  float* t0 = terms + ((group * 3 + 0) * q + query) * p;
+  float* t1 = terms + ((group * 3 + 1) * q + query) * p;
+  float* t2 = terms + ((group * 3 + 2) * q + query) * p;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < p; i += kThreads) {
+    const float v = xr[i];
+    const float e = __expf(-fabsf(v));
+    const float inv = 1.0f / (1.0f + e);
+    const float sig = v >= 0.f ? inv : e * inv;
+    const float pos = fmaxf(-v, 0.f) + log1pf(e);   // softplus(-x)
+    const float neg = pos + v;                      // softplus(x)
+    t0[i] = pos;
+    t1[i] = neg;
+    t2[i] = sig;
+    s1 += neg;
+    s2 += sig;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float s = 0.f;
+    for (int w = 0; w < kThreads / 64; ++w) s += red[threadIdx.x][w];
+    sums[row * 2 + threadIdx.x] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t rows, int32_t points,
@@ -110,6 +151,18 @@ extern "C" int mbv_mask_loss_rows_bwd(const float* logits, const float* targets,
   if (rows > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_mask_loss_rows_bwd, dim3((unsigned)rows), dim3(kThreads), 0, (hipStream_t)stream, logits, targets,
                      grad_sums, points, grad_logits);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points, float* terms,
+                                    float* row_sums, void* stream) {
+  if (groups < 0 || queries <= 0 || points <= 0) return MBV_ERR_BAD_ARG;
+  if (groups == 0) return MBV_OK;
+  if (!logits || !terms || !row_sums) return MBV_ERR_BAD_ARG;
+  if (groups * queries > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_match_terms, dim3((unsigned)(groups * queries)), dim3(kThreads), 0, (hipStream_t)stream, logits,
+                     queries, points, terms, row_sums);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

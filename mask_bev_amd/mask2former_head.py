@@ -385,14 +385,17 @@ class Mask2FormerHead(nn.Module):
         prob = cls.softmax(-1)
         lab = labels_gt.view(1, b, 1, ng).expand(d, b, nq, ng)
         cls_cost = -torch.gather(prob, 3, lab) * 2.0                                            # (D, B, Q, G)
-        pos = F.softplus(-mp)                    # BCE-with-logits against 1
-        neg = pos + mp                           # against 0: softplus(x) = softplus(-x) + x
-        gpt = gp.transpose(2, 3)
-        bce = (torch.matmul(pos, gpt) + torch.matmul(neg, 1 - gpt)) / self.num_points
-        ps = mp.sigmoid()
-        num = 2 * torch.matmul(ps, gpt)
-        den = ps.sum(-1)[..., :, None] + gp.sum(-1)[..., None, :]
-        dice = 1 - (num + 1.0) / (den + 1.0)
+        # K13: softplus(-x), softplus(x), sigmoid(x) and two row sums in one pass over the sampled logits; the three
+        # cost matrices come from ONE batched GEMM against the sampled ground truth
+        terms, sums = ops.match_cost_terms(mp.reshape(d * b, nq, -1))                         # (DB, 3Q, P), (DB, Q, 2)
+        gpt = gp.reshape(d * b, ng, -1).transpose(1, 2)                                       # (DB, P, G)
+        prod = torch.matmul(terms, gpt).view(d, b, 3, nq, ng)
+        pos_gp, neg_gp, sig_gp = prod[:, :, 0], prod[:, :, 1], prod[:, :, 2]
+        sums = sums.view(d, b, nq, 2)
+        # BCE against 1 on the GT pixels + against 0 elsewhere: neg·(1 - gp) = Σ neg - neg·gp
+        bce = (pos_gp + sums[..., 0:1] - neg_gp) / self.num_points
+        den = sums[..., 1:2] + gp.sum(-1)[..., None, :]
+        dice = 1 - (2 * sig_gp + 1.0) / (den + 1.0)
         return (cls_cost + 5.0 * bce + 5.0 * dice).flatten(0, 1)                               # (D*B, Q, G)
 
     def loss(self, all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, img_metas=None, heights_pred=None,

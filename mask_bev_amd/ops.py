@@ -1182,3 +1182,17 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
         out_dtype = torch.float32
     y, s = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias)
     return (y, a if s is None else s) if return_sum else y
+
+
+@torch.no_grad()
+def match_cost_terms(logits: torch.Tensor):
+    """logits (G, Q, P) f32 sampled mask logits → (terms (G, 3Q, P) f32 = [softplus(-x); softplus(x); sigmoid(x)]
+    stacked along the query axis, row_sums (G, Q, 2) = [Σ softplus(x), Σ sigmoid(x)]) in one pass (K13)."""
+    lib = _lib.load()
+    _need_gpu(logits)
+    x = logits.float().contiguous()
+    g, q, p = x.shape
+    terms = torch.empty((g, 3 * q, p), dtype=torch.float32, device=x.device)
+    sums = torch.empty((g, q, 2), dtype=torch.float32, device=x.device)
+    check(lib.mbv_match_cost_terms(_ptr(x), g, q, p, _ptr(terms), _ptr(sums), _stream()), 'mbv_match_cost_terms')
+    return terms, sums

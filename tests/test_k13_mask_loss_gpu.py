@@ -24,3 +24,16 @@ def test_mask_loss_rows(device, R, P):
     (got * w).sum().backward()
     (want * w.double()).sum().backward()
     assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_match_cost_terms(device):
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(5, 7, 1003, generator=g) * 5).to(device)
+    terms, sums = ops.match_cost_terms(x)
+    xd = x.double()
+    want = torch.cat([F.softplus(-xd), F.softplus(xd), xd.sigmoid()], dim=1)
+    assert terms.shape == (5, 21, 1003)
+    assert torch.allclose(terms.double(), want, rtol=2e-6, atol=2e-6)
+    assert torch.allclose(sums[..., 0].double(), F.softplus(xd).sum(-1), rtol=1e-5)
+    assert torch.allclose(sums[..., 1].double(), xd.sigmoid().sum(-1), rtol=1e-5)
