@@ -79,6 +79,51 @@ __global__ void __launch_bounds__(256) k_msda_fwd(const float* __restrict__ valu
   out[idx] = acc;   // (B, Nq, H*D): idx already is ((b*Nq+q)*H+hd)*D+d
 }
 
+// Forward, 4 channels per lane: the bilinear set-up of a (query, head, level, point) sample is the same for every
+// channel, so with one channel per lane it is recomputed by 32 lanes; here a lane owns 4 adjacent channels (one
+// 16-byte piece of the 128-byte pixel row) and 8 lanes cover a head — a quarter of the threads and of the
+// set-up instructions for the same gathers, issued as 16-byte loads.
+__global__ void __launch_bounds__(256) k_msda_fwd_v4(const float* __restrict__ value,
+                                                     const int64_t* __restrict__ shapes,
+                                                     const int64_t* __restrict__ level_start,
+                                                     const float* __restrict__ loc, const float* __restrict__ attn,
+                                                     int64_t total4, int num_value, int heads, int dim, int levels,
+                                                     int num_query, int points, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int d4n = dim >> 2;
+  const int d4 = (int)(idx % d4n);
+  int64_t t = idx / d4n;
+  const int hd = (int)(t % heads);
+  t /= heads;                       // t = b * num_query + q
+  const int b = (int)(t / num_query);
+  const int stride_pix = heads * dim;
+  const float* vb = value + (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t lw_base = (t * heads + hd) * levels * points;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int l = 0; l < levels; ++l) {
+    const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
+    const float* vl = vb + level_start[l] * stride_pix;
+    for (int p = 0; p < points; ++p) {
+      const int64_t k = lw_base + l * points + p;
+      const float lx = loc[k * 2], ly = loc[k * 2 + 1], aw = attn[k];
+      Corner c;
+      if (bilinear_setup(lx, ly, h, w, stride_pix, c)) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c.off[j] >= 0) {
+            const float4 x = *reinterpret_cast<const float4*>(vl + c.off[j]);
+            v.x += c.wgt[j] * x.x; v.y += c.wgt[j] * x.y; v.z += c.wgt[j] * x.z; v.w += c.wgt[j] * x.w;
+          }
+        }
+        acc.x += aw * v.x; acc.y += aw * v.y; acc.z += aw * v.z; acc.w += aw * v.w;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(out + ((t * heads + hd) * dim + d4 * 4)) = acc;
+}
+
 __global__ void __launch_bounds__(256) k_msda_bwd(const float* __restrict__ grad_out,
                                                   const float* __restrict__ value,
                                                   const int64_t* __restrict__ shapes,
@@ -320,6 +365,14 @@ extern "C" int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial
   if (!pow2_le64(head_dim)) return MBV_ERR_UNSUPPORTED;
   if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !out) return MBV_ERR_BAD_ARG;
   const int64_t total = (int64_t)batch * num_query * num_heads * head_dim;
+  if ((head_dim & 3) == 0 && ((reinterpret_cast<size_t>(value) | reinterpret_cast<size_t>(out)) & 15) == 0) {
+    const int64_t total4 = total / 4;
+    hipLaunchKernelGGL(k_msda_fwd_v4, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, value,
+                       spatial_shapes, level_start, sampling_loc, attn_weight, total4, num_value, num_heads, head_dim,
+                       num_levels, num_query, num_points, out);
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
   hipLaunchKernelGGL(k_msda_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, value, spatial_shapes,
                      level_start, sampling_loc, attn_weight, total, num_value, num_heads, head_dim, num_levels,
                      num_query, num_points, out);
