@@ -114,7 +114,9 @@ struct LnBwdIo {
   const float* s; const float* mean; const float* rstd; const float* gamma;
   float* dx;                         // f32 gradient of the sum (= of a and of b)
   void* dx_lo;                       // optional bf16 copy of dx for a bf16 branch input (nullable)
-  float* partial;                    // (gridDim.x, NP, C) per-block Σ dy*xhat, Σ dy [, Σ dx]
+  float* partial;                    // (gridDim.x, NP, C) per-block Σ dy*xhat, Σ dy [, Σ dx]; NULL = few blocks:
+                                     // add straight into dgamma / dbeta / dbranch (no reduction launch)
+  float* dgamma; float* dbeta; float* dbranch;
   int np;                            // 2, or 3 when the column sums of dx are wanted too (the bias gradient of
                                      // the Linear that produced the residual branch: d(branch) = dx)
 };
@@ -193,8 +195,15 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
     }
   }
   __syncthreads();
-  float* prow = io.partial + (long)blockIdx.x * np * C;
-  for (int i = threadIdx.x; i < np * C; i += 512) prow[i] = (float)red[i];
+  if (io.partial) {
+    float* prow = io.partial + (long)blockIdx.x * np * C;
+    for (int i = threadIdx.x; i < np * C; i += 512) prow[i] = (float)red[i];
+  } else {
+    for (int i = threadIdx.x; i < np * C; i += 512) {
+      float* dst = i < C ? io.dgamma + i : (i < 2 * C ? io.dbeta + (i - C) : io.dbranch + (i - 2 * C));
+      atomicAdd(dst, (float)red[i]);
+    }
+  }
 }
 
 // dgamma[c] += Σ_blocks partial[blk][0][c], dbeta likewise (and the branch-bias gradient when np == 3).  Block = 64 columns x 4 slices over one chunk of 64
@@ -288,8 +297,14 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
   }
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
   const int np = dbranch_bias ? 3 : 2;
-  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, partial_ws, np};
   const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
+  const bool direct = nblk <= 64;          // few rows (the decoder's B*Q tokens): ≤ 64 adds per address, one launch
+  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, direct ? nullptr : partial_ws,
+             dgamma, dbeta, dbranch_bias, np};
+  if (direct && !accumulate) {
+    MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
+    MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
+  }
   const dim3 grid(nblk), block(512);
   const size_t lds = (size_t)np * C * sizeof(double);
   switch (it) {
@@ -299,6 +314,7 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
     default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
   }
   MBV_CHECK_LAUNCH();
+  if (direct) return MBV_OK;
   if (!accumulate) {
     MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
     MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
