@@ -177,8 +177,10 @@ def main():
         cells = nx * ny
         acc = 0 if args.no_arena else 2 * c * cells          # arena: d(weight), d(bias) are read and accumulated into
         n_params = sum(p.numel() for p in model.parameters())
-        algo = {'k_ln_apply': (2 * c * cells + args.batch * c * cells) * 4.0,
-                'k_ln_bwd_dense': (args.batch * c * cells + c * cells + 2 * c * cells + acc) * 4.0,
+        # bf16 compute: the map leaves K3 (and its gradient comes back) as the backbone's bf16 patch rows
+        io = 2.0 if model._patch_handoff() else 4.0
+        algo = {'k_ln_apply': 2 * c * cells * 4.0 + args.batch * c * cells * io,
+                'k_ln_bwd_dense': args.batch * c * cells * io + (c * cells + 2 * c * cells + acc) * 4.0,
                 # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
                 'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
         # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of

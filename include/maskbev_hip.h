@@ -134,15 +134,23 @@ int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, float* dz_pad,
  */
 size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch);
 
+/* `patch` selects the layout of `out` (forward) and `grad_out` (backward):
+ *   0  (batch, C, ny, nx) f32 — the reference's NCHW pseudo-image;
+ *   4  (batch, ny/4, nx/4, 16*C) bf16 patch tokens, element (y%4)*4C + c*4 + x%4 of row (b, y/4, x/4): the input
+ *      rows of the backbone's 4 x 4 non-overlapping patch projection (mmdet PatchEmbed built at
+ *      mask_bev/models/backbones/swin.py:579-586), which then is one GEMM with no layout or cast pass.
+ *      Needs mbv_scatter_layernorm_patch_supported(C, ny, nx, 4) (C % 32 == 0, ny % 4 == 0, nx % 4 == 0). */
+int mbv_scatter_layernorm_patch_supported(int32_t channels, int32_t ny, int32_t nx, int32_t patch);
+
 int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                               const int32_t* cell_to_pillar, const float* weight, const float* bias,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
-                              float* out, float* stats, void* workspace, size_t workspace_bytes,
+                              int32_t patch, void* out, float* stats, void* workspace, size_t workspace_bytes,
                               void* stream, void* ev_start, void* ev_stop);
 
-/* Backward: grad_out (batch, C, cells) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
+/* Backward: grad_out (layout per `patch`) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
  * `accumulate` != 0 adds into grad_weight / grad_bias instead of overwriting them. */
-int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats,
+int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, const float* feats,
                               const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
                               const float* weight, const float* stats,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,

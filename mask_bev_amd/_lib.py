@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 class MaskBevHipError(RuntimeError):
@@ -38,9 +38,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_pfn_bwd_route': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     'mbv_pfn_bwd_bn': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, _I, _P, _P, _L, _I, _I, _P, _P]),
     'mbv_scatter_layernorm_workspace_bytes': (c_size_t, [_I]),
-    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, c_size_t, _P, _P,
-                                                 _P]),
-    'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
+    'mbv_scatter_layernorm_patch_supported': (ctypes.c_int, [_I, _I, _I, _I]),
+    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, c_size_t, _P,
+                                                 _P, _P]),
+    'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
                                                  c_size_t, _P, _P, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

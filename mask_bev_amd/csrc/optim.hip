@@ -31,13 +31,6 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p -= (a.lr / a.bias_correction1) * (m / denom);
 }
 
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-
 // 4 elements per thread per iteration (float4 loads: 16 B/lane, fully coalesced), grid-stride.
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float* __restrict__ grad,
                                                float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,

@@ -121,28 +121,55 @@ __device__ __forceinline__ void store_vec(float* p, const float (&r)[VEC]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Patch-token layout (PATCH = true, VEC = 4, patch = 4): the consumer of the BEV map is the backbone's
+// non-overlapping 4 x 4 patch projection (mmdet PatchEmbed, swin.py:579-586), a GEMM over 16*C values per token.
+// Writing the map as bf16 rows  tokens[b][y/4][x/4][(y%4)*4C + c*4 + x%4]  makes that projection (and its data
+// gradient) one plain GEMM with no layout transform, no cast pass and half the bytes; the gradient comes back in
+// the same layout.  A thread then owns NCH consecutive channels of one token column (4 cells): its NCH*4 values
+// are contiguous in the row, and the lanes of a wave that share a token cover a full 256 B run of it.
+// ---------------------------------------------------------------------------------------------
+template <bool PATCH, int NCH>
+struct Map {
+  // first channel (within the tile) and first cell (within the tile) of this thread
+  static __device__ __forceinline__ int chan0(int wave, int lane) {
+    return PATCH ? (lane & (kCT / NCH - 1)) * NCH : wave * NCH;
+  }
+  static __device__ __forceinline__ int cell0(int wave, int lane, int vec) {
+    constexpr int LPT = kCT / NCH;                  // lanes per token
+    return PATCH ? (wave * (64 / LPT) + lane / LPT) * 4 : lane * vec;
+  }
+};
+
+__device__ __forceinline__ int64_t patch_row_offset(int b, int channels, int ny, int nx, int y, int xv, int c) {
+  const int64_t token = ((int64_t)b * (ny >> 2) + (y >> 2)) * (nx >> 2) + (xv >> 2);
+  return token * (16 * (int64_t)channels) + (int64_t)(y & 3) * 4 * channels + (int64_t)c * 4;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward apply
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool PATCH>
 __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feats,
                                                   const int32_t* __restrict__ cell_to_pillar,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ stats, int batch, int channels, int ny,
-                                                  int nx, int xtiles, float* __restrict__ out) {
+                                                  int nx, int xtiles, void* __restrict__ out_) {
   using T = Tile<VEC>;
+  using M = Map<PATCH, 8>;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
   const int y = blockIdx.x / xtiles;
   const int x0 = (blockIdx.x % xtiles) * T::XT;
   const int c0 = blockIdx.y * kCT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t cells = (int64_t)ny * nx;
-  const int xv = x0 + lane * VEC;            // first x of this lane in the apply phase
+  const int ch0 = M::chan0(wave, lane), cv = M::cell0(wave, lane, VEC);
+  const int xv = x0 + cv;                     // first x of this lane in the apply phase
   const bool x_ok = xv < nx;                  // nx % VEC == 0 → the whole vector is in range
   // affine parameters: read once, reused for every scan of the batch
   float w[8][VEC], bz[8][VEC];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int c = c0 + wave * 8 + k;
+    const int c = c0 + ch0 + k;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; bz[k][e] = 0.f; }
     if (x_ok && c < channels) {
@@ -159,16 +186,40 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
     gather_tile<VEC>(feats, channels, c0, pid, lds);
     __syncthreads();
     if (x_ok) {
+      if constexpr (PATCH) {
+        // channels % kCT == 0 in this mode: 8 channels x 4 cells = 32 bf16 = 64 contiguous bytes per thread
+        unsigned short* orow = reinterpret_cast<unsigned short*>(out_) +
+                               patch_row_offset(b, channels, ny, nx, y, xv, c0 + ch0);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int cl = wave * 8 + k;
-        const int c = c0 + cl;
-        if (c < channels) {
-          float f[VEC], r[VEC];
-          load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
+        for (int k = 0; k < 8; k += 2) {
+          float f0[VEC], f1[VEC];
+          load_vec<VEC>(&lds[(ch0 + k) * T::LD + cv], f0);
+          load_vec<VEC>(&lds[(ch0 + k + 1) * T::LD + cv], f1);
+          unsigned u[4];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) r[e] = (f[e] - mean) * rstd * w[k][e] + bz[k][e];
-          store_vec<VEC>(out + (((int64_t)b * channels + c) * ny + y) * nx + xv, r);
+          for (int e = 0; e < 2; ++e) {
+            const float a0 = (f0[2 * e] - mean) * rstd * w[k][2 * e] + bz[k][2 * e];
+            const float a1 = (f0[2 * e + 1] - mean) * rstd * w[k][2 * e + 1] + bz[k][2 * e + 1];
+            const float b0 = (f1[2 * e] - mean) * rstd * w[k + 1][2 * e] + bz[k + 1][2 * e];
+            const float b1 = (f1[2 * e + 1] - mean) * rstd * w[k + 1][2 * e + 1] + bz[k + 1][2 * e + 1];
+            u[e] = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
+            u[2 + e] = (unsigned)f32_to_bf16_rne(b0) | ((unsigned)f32_to_bf16_rne(b1) << 16);
+          }
+          *reinterpret_cast<uint4*>(orow + k * 4) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+      } else {
+        float* out = reinterpret_cast<float*>(out_);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cl = ch0 + k;
+          const int c = c0 + cl;
+          if (c < channels) {
+            float f[VEC], r[VEC];
+            load_vec<VEC>(&lds[cl * T::LD + cv], f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[e] = (f[e] - mean) * rstd * w[k][e] + bz[k][e];
+            store_vec<VEC>(out + (((int64_t)b * channels + c) * ny + y) * nx + xv, r);
+          }
         }
       }
     }
@@ -180,8 +231,8 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
 // backward, pass 1: grad_weight / grad_bias, per-scan sums of (g*w) and (g*w*xhat), and g*w at the
 // occupied cells scattered back into (pillar, channel) rows.
 // ---------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ grad_out,
+template <int VEC, bool PATCH>
+__global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ grad_out_,
                                                       const float* __restrict__ feats,
                                                       const int32_t* __restrict__ cell_to_pillar,
                                                       const float* __restrict__ weight,
@@ -198,6 +249,7 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
   // its dependent, divergent loads sit on every wave's critical path.)
   constexpr int THREADS = 512, WAVES = THREADS / 64, CPW = kCT / WAVES;
   using T = Tile<VEC, THREADS>;
+  using M = Map<PATCH, CPW>;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
   constexpr int MAXB = 16;
   __shared__ double acc[MAXB][2][WAVES];
@@ -206,12 +258,13 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
   const int c0 = blockIdx.y * kCT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t cells = (int64_t)ny * nx;
-  const int xv = x0 + lane * VEC;
+  const int ch0 = M::chan0(wave, lane), cv = M::cell0(wave, lane, VEC);
+  const int xv = x0 + cv;
   const bool x_ok = xv < nx;
   float w[CPW][VEC], dw[CPW][VEC], db[CPW][VEC];
 #pragma unroll
   for (int k = 0; k < CPW; ++k) {
-    const int c = c0 + wave * CPW + k;
+    const int c = c0 + ch0 + k;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; dw[k][e] = 0.f; db[k][e] = 0.f; }
     if (x_ok && c < channels) load_vec<VEC>(weight + ((int64_t)c * ny + y) * nx + xv, w[k]);
@@ -227,12 +280,32 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
       const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
       const int32_t pid = pid_next;
       float g[CPW][VEC];
+      if constexpr (PATCH) {
+        // CPW channels x 4 cells = 16 bf16 = 32 contiguous bytes of the token's gradient row
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+        if (x_ok) {
+          const unsigned short* grow = reinterpret_cast<const unsigned short*>(grad_out_) +
+                                       patch_row_offset(b, channels, ny, nx, y, xv, c0 + ch0);
+          q0 = *reinterpret_cast<const uint4*>(grow);
+          q1 = *reinterpret_cast<const uint4*>(grow + 8);
+        }
+        const unsigned u[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-      for (int k = 0; k < CPW; ++k) {
-        const int c = c0 + wave * CPW + k;
+        for (int k = 0; k < CPW; ++k) {
+          g[k][0] = __uint_as_float(u[2 * k] << 16);
+          g[k][1] = __uint_as_float(u[2 * k] & 0xffff0000u);
+          g[k][2] = __uint_as_float(u[2 * k + 1] << 16);
+          g[k][3] = __uint_as_float(u[2 * k + 1] & 0xffff0000u);
+        }
+      } else {
+        const float* grad_out = reinterpret_cast<const float*>(grad_out_);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) g[k][e] = 0.f;
-        if (x_ok && c < channels) load_vec<VEC>(grad_out + (((int64_t)b * channels + c) * ny + y) * nx + xv, g[k]);
+        for (int k = 0; k < CPW; ++k) {
+          const int c = c0 + ch0 + k;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) g[k][e] = 0.f;
+          if (x_ok && c < channels) load_vec<VEC>(grad_out + (((int64_t)b * channels + c) * ny + y) * nx + xv, g[k]);
+        }
       }
       pid_next = -1;
       if (b + 1 < bend && x0 + gcell < nx)
@@ -243,11 +316,11 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
       if (x_ok) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-          const int cl = wave * CPW + k;
+          const int cl = ch0 + k;
           const int c = c0 + cl;
           if (c < channels) {
             float f[VEC], gw[VEC];
-            load_vec<VEC>(&lds[cl * T::LD + lane * VEC], f);
+            load_vec<VEC>(&lds[cl * T::LD + cv], f);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               const float xhat = (f[e] - mean) * rstd;
@@ -257,7 +330,7 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
               s1f += gw[e];
               s2f += gw[e] * xhat;
             }
-            store_vec<VEC>(&lds[cl * T::LD + lane * VEC], gw);
+            store_vec<VEC>(&lds[cl * T::LD + cv], gw);
           }
         }
       }
@@ -291,7 +364,7 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const float* __restrict__ 
   if (x_ok) {
 #pragma unroll
     for (int k = 0; k < CPW; ++k) {
-      const int c = c0 + wave * CPW + k;
+      const int c = c0 + ch0 + k;
       if (c < channels) {
         const int64_t o = ((int64_t)c * ny + y) * nx + xv;
         if (accumulate) {
@@ -338,14 +411,20 @@ extern "C" size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch) {
   return mbv_align_up(sizeof(double) * 2 * (size_t)batch, 256);
 }
 
+// patch-token output (bf16 rows of 16*C per 4 x 4 patch): whole patches and whole channel tiles only
+extern "C" int mbv_scatter_layernorm_patch_supported(int32_t channels, int32_t ny, int32_t nx, int32_t patch) {
+  return patch == 4 && channels > 0 && channels % kCT == 0 && ny > 0 && nx > 0 && ny % 4 == 0 && nx % 4 == 0;
+}
+
 extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
-                                         int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps, float* out,
-                                         float* stats, void* workspace, size_t workspace_bytes, void* stream_,
-                                         void* ev_start, void* ev_stop) {
+                                         int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
+                                         int32_t patch, void* out, float* stats, void* workspace,
+                                         size_t workspace_bytes, void* stream_, void* ev_start, void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
+  if (patch != 0 && !mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch)) return MBV_ERR_UNSUPPORTED;
   if (!feats || !pillar_batch_start || !cell_to_pillar || !weight || !bias || !out || !stats) return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
   double* sums = reinterpret_cast<double*>(workspace);
@@ -357,29 +436,34 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
   MBV_CHECK_LAUNCH();
   const int ctiles = (channels + kCT - 1) / kCT;
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
-  if (nx % 4 == 0) {
+  if (patch) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL(k_ln_apply<4>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar, weight,
-                       bias, stats, batch, channels, ny, nx, xtiles, out);
+    hipLaunchKernelGGL((k_ln_apply<4, true>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
+                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+  } else if (nx % 4 == 0) {
+    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
+    hipLaunchKernelGGL((k_ln_apply<4, false>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
+                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL(k_ln_apply<1>, dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar, weight,
-                       bias, stats, batch, channels, ny, nx, xtiles, out);
+    hipLaunchKernelGGL((k_ln_apply<1, false>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
+                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
   }
   MBV_CHECK_LAUNCH();
   if (ev_stop) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_stop), stream));
   return MBV_OK;
 }
 
-extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* feats, const int32_t* pillar_batch_start,
-                                         const int32_t* cell_to_pillar, const float* weight, const float* stats,
-                                         int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
-                                         float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
+extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, const float* feats,
+                                         const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
+                                         const float* weight, const float* stats, int32_t batch, int32_t channels,
+                                         int32_t ny, int32_t nx, int64_t num_pillars, float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
                                          void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
                                          void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
+  if (patch != 0 && !mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch)) return MBV_ERR_UNSUPPORTED;
   if (!grad_out || !feats || !pillar_batch_start || !cell_to_pillar || !weight || !stats || !grad_feats ||
       !grad_weight || !grad_bias)
     return MBV_ERR_BAD_ARG;
@@ -388,14 +472,19 @@ extern "C" int mbv_scatter_layernorm_bwd(const float* grad_out, const float* fea
   MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * batch, stream));
   const int ctiles = (channels + kCT - 1) / kCT;
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
-  if (nx % 4 == 0) {
+  if (patch) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL(k_ln_bwd_dense<4>, dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL((k_ln_bwd_dense<4, true>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
+                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
+                       grad_bias, accumulate, sums);
+  } else if (nx % 4 == 0) {
+    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
+    hipLaunchKernelGGL((k_ln_bwd_dense<4, false>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL(k_ln_bwd_dense<1>, dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL((k_ln_bwd_dense<1, false>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   }

@@ -138,14 +138,19 @@ class MaskBevEncoder(nn.Module):
         self._middle_encoder = PointPillarsScatter(in_channels=self._out_features, output_shape=out_shape)
         self._layer_norm = nn.LayerNorm([self._out_features, *out_shape], eps=1e-3)
 
-    def forward(self, point_clouds: Sequence[torch.Tensor]) -> torch.Tensor:
-        """list of (Ni, pc_dim) device tensors → (B, C, ny, nx)."""
+    def forward(self, point_clouds: Sequence[torch.Tensor], patch: int = 0, out: Optional[torch.Tensor] = None):
+        """list of (Ni, pc_dim) device tensors → (B, C, ny, nx); with ``patch`` = 4 the same values as bf16
+        ``ops.PatchTokens`` for a backbone whose first layer is a 4 x 4 patch projection.  ``out``: optional
+        destination buffer for the result."""
         batch = len(point_clouds)
         pillars = self._voxel_layer.pillars(point_clouds, prefilter=True)
         feats = self._voxel_encoder(pillars)
         ln = self._layer_norm
         return ops.scatter_layernorm(feats, ln.weight, ln.bias, pillars, batch, self._num_voxel_y, self._num_voxel_x,
-                                     ln.eps)
+                                     ln.eps, patch, out)
+
+    def patch_layout(self, patch: int) -> bool:
+        return ops.patch_layout_supported(self._out_features, self._num_voxel_y, self._num_voxel_x, patch)
 
     # --- staged API of the reference (mask_bev_encoders.py:95-123) -------------------------------
     def voxelize(self, point_clouds: Sequence[torch.Tensor]):

@@ -46,9 +46,15 @@ class GraphedTrainStep:
         self._overlap_prev = head.overlap_matcher
         # the matcher's side-stream fork / join is captured as a parallel branch of the graph
         head.overlap_matcher = overlap_matcher
+        # the encoder writes its result (the (B, C, ny, nx) map, or the backbone's bf16 patch rows) straight into the
+        # graph's static input buffer
+        self._patch = module._patch_handoff()
         with torch.no_grad(), module._autocast():
-            x = module._encoder(scans)
-        self.x_static = torch.zeros_like(x).requires_grad_()
+            x = module._encoder(scans, patch=self._patch)
+        self.x_static = torch.zeros_like(self._rows(x)).requires_grad_()
+        self._x_in = (ops.PatchTokens(self.x_static, x.channels, x.patch) if isinstance(x, ops.PatchTokens)
+                      else self.x_static)
+        x = self._rows(x)
         self.labels = labels.clone()
         # dense (B, Q, ny, nx) masks or the bit-packed targets of batch.instance_targets (K14)
         self.masks = (ops.PackedMasks(masks.words.clone(), masks.h, masks.w) if isinstance(masks, ops.PackedMasks)
@@ -76,11 +82,15 @@ class GraphedTrainStep:
             self.loss_static = self._forward_backward()
         torch.cuda.synchronize()
 
+    @staticmethod
+    def _rows(x):
+        return x.rows if isinstance(x, ops.PatchTokens) else x
+
     def _forward_backward(self) -> torch.Tensor:
         m = self.m
         dt = m._compute_dtype
         with torch.autocast('cuda', dtype=dt or torch.bfloat16, enabled=dt is not None, cache_enabled=False):
-            feats = m._backbone(self.x_static)
+            feats = m._backbone(self._x_in)
             cls, masks, heights = m._panoptic_head(feats)
         loss = m.loss(m.compute_loss(cls, masks, self.labels, self.masks, heights, None))
         loss.backward()
@@ -91,9 +101,8 @@ class GraphedTrainStep:
         scans, labels, masks, _ = m._unpack(batch)
         if self.reducer is not None:
             self.reducer.sync_buffers()
-        with m._autocast():
-            x = m._encoder(scans)                          # eager: K1 → K2 → K3
-        self.x_static.data.copy_(x.detach())
+        with m._autocast():                                # eager: K1 → K2 → K3 (into the static buffer)
+            x = self._rows(m._encoder(scans, patch=self._patch, out=self.x_static.detach()))
         if labels.data_ptr() != self.labels.data_ptr():
             self.labels.copy_(labels)
         if isinstance(masks, ops.PackedMasks):

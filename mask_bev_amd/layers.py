@@ -104,7 +104,14 @@ class PatchEmbed(nn.Module):
         self.projection = nn.Conv2d(in_channels, embed_dims, kernel_size=patch, stride=patch)
         self.norm = LayerNorm(embed_dims)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x) -> torch.Tensor:
+        if isinstance(x, ops.PatchTokens):
+            # K3 already wrote the projection's input rows (bf16, (dy, c, dx) order): one GEMM, no layout pass
+            if x.patch != self.patch or x.channels != self.projection.in_channels:
+                raise ValueError('PatchTokens do not match this projection')
+            w = self.projection.weight                                   # (E, C, p, p) → (E, p, C, p)
+            w2 = w.permute(0, 2, 1, 3).reshape(w.shape[0], -1)
+            return self.norm(ops.linear(x.rows, w2, self.projection.bias))
         x = self.projection(corner_pad(x, self.patch, self.patch))
         return self.norm(x.permute(0, 2, 3, 1))
 

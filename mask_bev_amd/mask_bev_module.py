@@ -200,9 +200,16 @@ class MaskBevModule(_Base):
 
     def forward(self, x):
         with self._autocast():
-            x = self._encoder(x)
+            x = self._encoder(x, patch=self._patch_handoff())
             x = self._backbone(x)
             return self._panoptic_head(x)
+
+    def _patch_handoff(self) -> int:
+        """bf16 compute: the encoder writes the backbone's 4 x 4 patch rows directly (K3 patch-token layout)."""
+        if self._compute_dtype != torch.bfloat16:
+            return 0
+        pe = self._backbone._backbone.patch_embed
+        return pe.patch if self._encoder.patch_layout(pe.patch) else 0
 
     def forward_encode(self, pc):
         with self._autocast():

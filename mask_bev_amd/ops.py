@@ -309,8 +309,8 @@ def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torc
 # --------------------------------------------------------------------------------------
 class _ScatterLayerNorm(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, feats, weight, bias, cell_to_pillar, pillar_batch_start, batch, ny, nx, eps):
+    @torch.amp.custom_fwd(device_type='cuda')          # inputs are cast by scatter_layernorm(); `out` keeps its dtype
+    def forward(ctx, feats, weight, bias, cell_to_pillar, pillar_batch_start, batch, ny, nx, eps, patch=0, out=None):
         lib = _lib.load()
         _need_gpu(feats, weight, bias, cell_to_pillar, pillar_batch_start)
         feats = feats.contiguous()
@@ -318,16 +318,28 @@ class _ScatterLayerNorm(torch.autograd.Function):
         bias = bias.contiguous()
         c = int(weight.shape[0])
         dev = feats.device
-        out = torch.empty((batch, c, ny, nx), dtype=torch.float32, device=dev)
+        if patch:
+            if not lib.mbv_scatter_layernorm_patch_supported(c, ny, nx, patch):
+                raise MaskBevHipError(f'scatter_layernorm: no patch-token layout for C={c}, {ny}x{nx}, patch {patch}')
+            shape, dt = (batch, ny // patch, nx // patch, patch * patch * c), torch.bfloat16
+        else:
+            shape, dt = (batch, c, ny, nx), torch.float32
+        if out is None:
+            out = torch.empty(shape, dtype=dt, device=dev)
+        else:                      # caller-owned destination (the static input buffer of a captured graph)
+            if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != dev:
+                raise MaskBevHipError(f'scatter_layernorm: out must be a contiguous {dt} tensor of shape {shape}')
+            ctx.mark_dirty(out)
         stats = torch.empty((batch, 2), dtype=torch.float32, device=dev)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         rc = lib.mbv_scatter_layernorm_fwd(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
-                                           _ptr(bias), batch, c, ny, nx, float(eps), _ptr(out), _ptr(stats), _ptr(ws),
-                                           ws.numel(), _stream(), *TIMER.events('k_ln_apply')[2:])
+                                           _ptr(bias), batch, c, ny, nx, float(eps), int(patch), _ptr(out), _ptr(stats),
+                                           _ptr(ws), ws.numel(), _stream(), *TIMER.events('k_ln_apply')[2:])
         check(rc, 'mbv_scatter_layernorm_fwd')
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
         ctx.params = (weight, bias)
+        ctx.patch = int(patch)
         return out
 
     @staticmethod
@@ -336,7 +348,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         lib = _lib.load()
         feats, weight, stats, cell_to_pillar, pillar_batch_start = ctx.saved_tensors
         batch, c, ny, nx = ctx.dims
-        grad_out = grad_out.to(torch.float32).contiguous()
+        grad_out = grad_out.to(torch.bfloat16 if ctx.patch else torch.float32).contiguous()
         dev = feats.device
         g_feats = torch.empty_like(feats)
         wp, bp = ctx.params
@@ -348,7 +360,8 @@ class _ScatterLayerNorm(torch.autograd.Function):
             g_w = torch.empty_like(weight)
             g_b = torch.empty_like(weight)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
-        rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), _ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar),
+        rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), ctx.patch, _ptr(feats), _ptr(pillar_batch_start),
+                                           _ptr(cell_to_pillar),
                                            _ptr(weight), _ptr(stats), batch, c, ny, nx, int(feats.shape[0]),
                                            _ptr(g_feats), _ptr(g_w), _ptr(g_b), 1 if direct else 0, _ptr(ws),
                                            ws.numel(), _stream(), *TIMER.events('k_ln_bwd_dense')[2:])
@@ -356,15 +369,36 @@ class _ScatterLayerNorm(torch.autograd.Function):
         if direct:
             _fire_grad_hooks(wp)
             _fire_grad_hooks(bp)
-            return g_feats, None, None, None, None, None, None, None, None
-        return g_feats, g_w, g_b, None, None, None, None, None, None
+            return g_feats, None, None, None, None, None, None, None, None, None, None
+        return g_feats, g_w, g_b, None, None, None, None, None, None, None, None
+
+
+class PatchTokens:
+    """The BEV pseudo-image handed over as the input rows of a ``patch`` x ``patch`` non-overlapping projection:
+    ``rows`` (B, ny/p, nx/p, p*p*C) bf16 with element ``(y%p)*p*C + c*p + x%p`` (K3's patch-token layout)."""
+
+    def __init__(self, rows: torch.Tensor, channels: int, patch: int):
+        self.rows, self.channels, self.patch = rows, channels, patch
+
+    def to_image(self) -> torch.Tensor:
+        """(B, C, ny, nx) view of the same values (tests / staged callers)."""
+        b, ty, tx, _ = self.rows.shape
+        p, c = self.patch, self.channels
+        return self.rows.view(b, ty, tx, p, c, p).permute(0, 4, 1, 3, 2, 5).reshape(b, c, ty * p, tx * p)
+
+
+def patch_layout_supported(channels: int, ny: int, nx: int, patch: int) -> bool:
+    return bool(_lib.load().mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch))
 
 
 def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, p: Pillars, batch: int, ny: int,
-                      nx: int, eps: float) -> torch.Tensor:
-    """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3)."""
-    return _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
-                                   p.pillar_batch_start, batch, ny, nx, eps)
+                      nx: int, eps: float, patch: int = 0, out: Optional[torch.Tensor] = None):
+    """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3).
+    ``patch`` = 4 returns :class:`PatchTokens` (bf16) instead of the (B, C, ny, nx) f32 map; ``out`` is an optional
+    destination buffer (no grad) of the result's shape and dtype."""
+    out = _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
+                                  p.pillar_batch_start, batch, ny, nx, eps, patch, out)
+    return PatchTokens(out, int(weight.shape[0]), patch) if patch else out
 
 
 # --------------------------------------------------------------------------------------
@@ -552,7 +586,10 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     part = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1), **od)
     if s * c < t:
         torch.addmm(acc, g2[s * c:].t(), x2[s * c:], out=acc, **od)
-    acc.add_(part.sum(0))
+    if acc.is_contiguous() and part.is_cuda:
+        colsum_accum(part.view(s, -1), acc.view(-1))         # Σ over the K-chunks, added in the same launch
+    else:
+        acc.add_(part.sum(0))
     return False
 
 

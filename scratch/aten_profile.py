@@ -1,5 +1,5 @@
 """Which aten ops produce the step's kernels (eager step under torch.profiler, grouped by op + input shapes)."""
-import torch, collections
+import torch, collections, sys
 from torch.profiler import profile, ProfilerActivity
 from mask_bev_amd import synthetic
 from mask_bev_amd.mask_bev_module import MaskBevModule
@@ -23,8 +23,9 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print('total self device time ms', tot / 1e3)
-rows=[r for r in rows if r[2].startswith('aten::')]
+filt = sys.argv[1].split(',') if len(sys.argv) > 1 else None
+rows=[r for r in rows if r[2].startswith('aten::') and (filt is None or r[2][6:] in filt)]
 rows.sort(key=lambda r:-r[1])
 print('aten ops by count')
-for t, n, k, sh in rows[:60]:
+for t, n, k, sh in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 60]:
     print(f'{t/1e3:7.2f} ms n={n:4d} {k[:34]:34s} {sh}')

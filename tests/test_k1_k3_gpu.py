@@ -143,3 +143,87 @@ def test_scatter_layernorm_fwd_bwd(device, nx, ny, C, sizes):
     torch.testing.assert_close(w_d.grad.cpu(), w_ref.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(b_d.grad.cpu(), b_ref.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(f_d.grad.cpu(), f_ref.grad, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nx,ny,C,sizes', [(64, 64, 32, [3000, 2000]), (52, 40, 64, [500]), (512, 8, 32, [900, 10, 0]),
+                                           (300, 12, 32, [2000, 1500])])
+def test_scatter_layernorm_patch_tokens(device, nx, ny, C, sizes):
+    """K3 patch-token layout (bf16 rows of the backbone's 4 x 4 patch projection) vs the oracle's dense scatter +
+    F.layer_norm: the forward values are the bf16 rounding of the f32 map (<= 1 bf16 ulp of the f32 reference), and
+    a gradient arriving in the same layout gives the gradients of the NCHW path (rtol 1e-4 / atol 2e-5)."""
+    from mask_bev_amd import ops
+    cfg = _cfg(nx=nx, ny=ny, C=C)
+    scans = _scans(cfg, sizes, seed=nx + 1)
+    pil, (rv, rn, rc) = _check_voxelize(cfg, scans, device)
+    B = len(scans)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(pil.num_pillars, C, generator=g)
+    w = 1 + 0.1 * torch.randn(C, ny, nx, generator=g)
+    b = 0.1 * torch.randn(C, ny, nx, generator=g)
+    go = torch.randn(B, C, ny, nx, generator=g).bfloat16()                     # what the bf16 dgrad GEMM would hand back
+    f_ref, w_ref, b_ref = feats.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    canvas = O.scatter_to_canvas(cfg, f_ref, rc, B)
+    out_ref = torch.nn.functional.layer_norm(canvas, [C, ny, nx], w_ref, b_ref, 1e-3)
+    out_ref.backward(go.float())
+    f_d, w_d, b_d = (t.clone().to(device).requires_grad_() for t in (feats, w, b))
+    assert ops.patch_layout_supported(C, ny, nx, 4)
+    tok = ops.scatter_layernorm(f_d, w_d, b_d, pil, B, ny, nx, 1e-3, patch=4)
+    assert isinstance(tok, ops.PatchTokens) and tok.rows.dtype == torch.bfloat16
+    assert tuple(tok.rows.shape) == (B, ny // 4, nx // 4, 16 * C)
+    # forward: identical to rounding the f32 NCHW result of the same kernel family, and within bf16 of the oracle
+    with torch.no_grad():
+        img32 = ops.scatter_layernorm(f_d, w_d, b_d, pil, B, ny, nx, 1e-3)
+    assert torch.equal(tok.to_image(), img32.bfloat16())
+    torch.testing.assert_close(tok.to_image().float().cpu(), out_ref.detach(), rtol=8e-3, atol=1e-5)
+    # backward: the gradient in patch layout, element (y%4)*4C + c*4 + x%4 of row (b, y/4, x/4)
+    go_rows = go.view(B, C, ny // 4, 4, nx // 4, 4).permute(0, 2, 4, 3, 1, 5).reshape(B, ny // 4, nx // 4, 16 * C)
+    tok.rows.backward(go_rows.contiguous().to(device))
+    torch.testing.assert_close(w_d.grad.cpu(), w_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(b_d.grad.cpu(), b_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(f_d.grad.cpu(), f_ref.grad, rtol=1e-4, atol=2e-5)
+    # destination buffer variant writes the same bytes
+    buf = torch.zeros_like(tok.rows)
+    tok2 = ops.scatter_layernorm(f_d.detach(), w_d.detach(), b_d.detach(), pil, B, ny, nx, 1e-3, patch=4, out=buf)
+    assert tok2.rows.data_ptr() == buf.data_ptr() and torch.equal(buf, tok.rows)
+
+
+@pytest.mark.gpu
+def test_scatter_layernorm_patch_unsupported_shapes(device):
+    from mask_bev_amd import ops
+    assert not ops.patch_layout_supported(32, 62, 64, 4)       # ny not a multiple of the patch
+    assert not ops.patch_layout_supported(24, 64, 64, 4)       # partial channel tile
+    assert not ops.patch_layout_supported(32, 64, 64, 2)       # only the 4 x 4 projection of the MaskBEV backbone
+
+
+@pytest.mark.gpu
+def test_patch_embed_tokens_equal_conv(device):
+    """PatchEmbed fed K3's patch rows (one GEMM) vs the same values through the reference's Conv2d route
+    (swin.py:579-586): outputs and all parameter / input gradients agree to bf16 accuracy."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.layers import PatchEmbed
+    torch.manual_seed(3)
+    B, C, ny, nx, E = 2, 32, 32, 48, 96
+    pe = PatchEmbed(C, E, 4).to(device)
+    img = torch.randn(B, C, ny, nx, device=device).bfloat16()
+    rows = img.view(B, C, ny // 4, 4, nx // 4, 4).permute(0, 2, 4, 3, 1, 5).reshape(B, ny // 4, nx // 4, 16 * C)
+    rows = rows.contiguous().requires_grad_()
+    tok = ops.PatchTokens(rows, C, 4)
+    assert torch.equal(tok.to_image(), img)
+    go = torch.randn(B, ny // 4, nx // 4, E, device=device)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y_tok = pe(tok)
+    y_tok.float().backward(go)
+    grads_tok = [p.grad.clone() for p in pe.parameters()]
+    g_rows = rows.grad.clone()
+    for p in pe.parameters():
+        p.grad = None
+    img_r = img.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y_conv = pe(img_r)
+    y_conv.float().backward(go)
+    torch.testing.assert_close(y_tok.float(), y_conv.float(), rtol=2e-2, atol=2e-2)
+    for (n, p), gt in zip(pe.named_parameters(), grads_tok):
+        torch.testing.assert_close(gt, p.grad, rtol=2e-2, atol=2e-2 * float(p.grad.abs().max()), msg=lambda m: f'{n}: {m}')
+    g_img = ops.PatchTokens(g_rows, C, 4).to_image()
+    torch.testing.assert_close(g_img.float(), img_r.grad.float(), rtol=2e-2, atol=2e-2 * float(img_r.grad.abs().max()))
