@@ -101,11 +101,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from mask_bev_amd import ops, synthetic
+    from mask_bev_amd import ops, synthetic, tuning
     from mask_bev_amd.mask_bev_module import MaskBevModule
 
     torch.manual_seed(420)
     kw = synthetic.module_kwargs(args.workload, args.batch, compute_dtype=args.dtype)
+    tuned = tuning.use_tuned_gemms()     # hipBLASLt solution table for this step's GEMM shapes (look-up only)
     model = MaskBevModule(**kw).to(device)
     model.train()
     model.log_scalars = False           # scalar logging is host-side bookkeeping, not the path
@@ -202,7 +203,7 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph',
+                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned,
                         final_loss=final_loss),
             roofline=dominant, roofline_all=list(roof.values()))
         if not args.no_cpu_baseline and world == 1:

@@ -148,3 +148,18 @@ def test_window_partition_roundtrip_and_all_masked_rule():
     _, _, blocked = O.forward_head(cfg, sd, q, mf, (4, 4))
     blocked[torch.where(blocked.sum(-1) == blocked.shape[-1])] = False
     assert not blocked.all(-1).any()
+
+
+def test_tuned_gemm_table_is_lookup_only_and_cpu_safe():
+    """The hipBLASLt solution table ships with validator lines and is never applied without a GPU."""
+    from mask_bev_amd import tuning
+    assert os.path.isfile(tuning.DEFAULT_TABLE)
+    lines = open(tuning.DEFAULT_TABLE).read().splitlines()
+    validators = [l for l in lines if l.startswith('Validator,')]
+    assert {v.split(',')[1] for v in validators} >= {'PT_VERSION', 'HIPBLASLT_VERSION', 'GCN_ARCH_NAME'}
+    assert any('gfx950' in v for v in validators)
+    entries = [l for l in lines if l and not l.startswith('Validator,')]
+    assert len(entries) > 50 and all(len(e.split(',')) == 4 for e in entries)
+    assert not any('Rocblas' in e for e in entries)           # hipBLASLt solutions or Default only
+    if not torch.cuda.is_available():
+        assert tuning.use_tuned_gemms() is False

@@ -151,3 +151,24 @@ def test_other_reference_configurations_train(device, workload, batch):
     assert bool(torch.isfinite(arena.grad).all()) and float(arena.grad.abs().sum()) > 0
     opt.step()
     assert bool(torch.isfinite(arena.param).all())
+
+
+@pytest.mark.gpu
+def test_tuned_gemm_table_accepted_and_numerically_neutral(device):
+    """use_tuned_gemms(): the committed table matches this stack, and a tuned GEMM equals the default one to bf16
+    accumulation-order accuracy (only the hipBLASLt solution index changes)."""
+    from torch.cuda import tunable
+    from mask_bev_amd import tuning
+    g = torch.Generator(device='cpu').manual_seed(1)
+    a = torch.randn(4096, 768, generator=g).to(device).bfloat16()
+    w = torch.randn(3072, 768, generator=g).to(device).bfloat16()
+    b = torch.randn(3072, generator=g).to(device).bfloat16()
+    ref = torch.nn.functional.linear(a, w, b).float()
+    was = tunable.is_enabled()
+    try:
+        assert tuning.use_tuned_gemms() is True
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        got = torch.nn.functional.linear(a, w, b).float()
+    finally:
+        tunable.enable(was)
+    torch.testing.assert_close(got, ref, rtol=2e-2, atol=0.5)
