@@ -185,6 +185,26 @@ int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int6
                            const int64_t* spatial_shapes_host, float* grad_value, float* grad_loc, float* grad_attn,
                            void* stream);
 
+/* K16 — the element-wise chain in front of K5, fused (mmcv MultiScaleDeformableAttention.forward:
+ * `attention_weights.softmax(-1)`, `offset_normalizer = stack([W_l, H_l])`, `sampling_locations =
+ * reference_points + sampling_offsets / offset_normalizer`; same call site as K5).
+ * offsets (B, Nq, H, L, P, 2) and logits (B, Nq, H, L*P): both f32 (is_bf16 = 0) or both bf16 (is_bf16 = 1, the
+ * autocast projections; the quotient is then rounded to bf16 before the f32 add, as torch's type promotion does);
+ * ref_points (Nq, 2) f32 (x, y) in [0, 1]; spatial_shapes_host (L, 2) int64 (h, w) in HOST memory.
+ * Outputs loc (B, Nq, H, L, P, 2) f32 and attn (B, Nq, H, L*P) f32 = softmax over the L*P samples of a head.
+ * Backward: grad_loc / grad_attn (f32, from K5) and attn → grad_offsets / grad_logits in the input dtype.
+ * Supported: L <= 8, L*P <= 16 (mbv_msda_prepare_supported); the caller composes torch ops otherwise. */
+int mbv_msda_prepare_supported(int32_t num_levels, int32_t num_points);
+
+int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int32_t is_bf16, const float* ref_points,
+                         const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
+                         int32_t num_levels, int32_t num_points, float* loc, float* attn, void* stream);
+
+int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
+                         const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
+                         int32_t num_levels, int32_t num_points, int32_t out_bf16, void* grad_offsets,
+                         void* grad_logits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4 — fused shifted-window multi-head attention (between the qkv and the output projection).
  * Replaces: ShiftWindowMSA.forward (mask_bev/models/networks/swin/swin.py:179-253: pad, roll, window

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class MaskBevHipError(RuntimeError):
@@ -43,6 +43,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                                  _P, _P]),
     'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
                                                  c_size_t, _P, _P, _P]),
+    'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
+    'mbv_msda_prepare_fwd': (ctypes.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'mbv_msda_prepare_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),

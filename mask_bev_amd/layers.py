@@ -263,9 +263,13 @@ class MultiScaleDeformableAttention(nn.Module):
             q = q.to(torch.get_autocast_dtype('cuda'))       # one cast for both projections of q
         value = self.value_proj(query).view(b, n, h, e // h)
         off = self.sampling_offsets(q).view(b, n, h, l, p, 2)
-        aw = self.attention_weights(q).view(b, n, h, l * p).softmax(-1).view(b, n, h, l, p)
-        normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(off.dtype)          # (L, 2) = (w, h)
-        loc = reference_points.view(1, n, 1, 1, 1, 2) + off / normalizer.view(1, 1, 1, l, 1, 2)
+        aw = self.attention_weights(q).view(b, n, h, l * p)
+        if spatial_shapes is not None and off.is_cuda and ops.msda_prepare_supported(l, p):
+            loc, aw = ops.msda_prepare(off, aw, reference_points, spatial_shapes)              # K16: one launch
+        else:
+            aw = aw.softmax(-1).view(b, n, h, l, p)
+            normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(off.dtype)      # (L, 2) = (w, h)
+            loc = reference_points.view(1, n, 1, 1, 1, 2) + off / normalizer.view(1, 1, 1, l, 1, 2)
         out = ops.ms_deform_attn(value, spatial_shapes, shapes_t, level_start, loc, aw)
         out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)
         return out + query if add_identity else out

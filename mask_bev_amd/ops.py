@@ -500,6 +500,54 @@ class _MSDeformAttn(torch.autograd.Function):
         return g_value, None, None, g_loc, g_attn, None
 
 
+class _MSDAPrepare(torch.autograd.Function):
+    """K16: (offsets, logits) → (sampling locations, softmaxed weights), f32 out; gradients in the input dtype."""
+
+    @staticmethod
+    def forward(ctx, off, logits, ref, shapes_host):
+        lib = _lib.load()
+        _need_gpu(off, logits, ref)
+        if off.dtype != logits.dtype or off.dtype not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError('msda_prepare: offsets and logits must both be f32 or both bf16')
+        off, logits = off.contiguous(), logits.contiguous()
+        ref = ref.to(torch.float32).contiguous()
+        b, n, h, l, p, _ = off.shape
+        host = (ctypes.c_int64 * (2 * l))(*[int(v) for hw in shapes_host for v in hw])
+        loc = torch.empty((b, n, h, l, p, 2), dtype=torch.float32, device=off.device)
+        attn = torch.empty((b, n, h, l, p), dtype=torch.float32, device=off.device)
+        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logits), 1 if off.dtype == torch.bfloat16 else 0, _ptr(ref), host,
+                                       b, n, h, l, p, _ptr(loc), _ptr(attn), _stream()), 'mbv_msda_prepare_fwd')
+        ctx.save_for_backward(attn)
+        ctx.meta = (host, off.dtype, (b, n, h, l, p), logits.shape)
+        return loc, attn
+
+    @staticmethod
+    def backward(ctx, g_loc, g_attn):
+        lib = _lib.load()
+        attn, = ctx.saved_tensors
+        host, dt, (b, n, h, l, p), lshape = ctx.meta
+        g_loc = g_loc.to(torch.float32).contiguous()
+        g_attn = g_attn.to(torch.float32).contiguous()
+        g_off = torch.empty((b, n, h, l, p, 2), dtype=dt, device=attn.device)
+        g_logit = torch.empty(lshape, dtype=dt, device=attn.device)
+        check(lib.mbv_msda_prepare_bwd(_ptr(g_loc), _ptr(g_attn), _ptr(attn), host, b, n, h, l, p,
+                                       1 if dt == torch.bfloat16 else 0, _ptr(g_off), _ptr(g_logit), _stream()),
+              'mbv_msda_prepare_bwd')
+        return g_off, g_logit, None, None
+
+
+def msda_prepare_supported(num_levels: int, num_points: int) -> bool:
+    return bool(_lib.load().mbv_msda_prepare_supported(num_levels, num_points))
+
+
+def msda_prepare(offsets: torch.Tensor, logits: torch.Tensor, reference_points: torch.Tensor, spatial_shapes):
+    """offsets (B, Nq, H, L, P, 2), logits (B, Nq, H, L*P) (both f32 or both bf16), reference_points (Nq, 2) in
+    [0, 1], spatial_shapes [(h, w)] * L  →  sampling locations (B, Nq, H, L, P, 2) f32 and attention weights
+    (B, Nq, H, L, P) f32 (softmax over L*P) — K16, include/maskbev_hip.h."""
+    host = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    return _MSDAPrepare.apply(offsets, logits, reference_points, host)
+
+
 def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, level_start: torch.Tensor,
                    sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
     """value (B, N, H, D); sampling_locations (B, Nq, H, L, P, 2) in [0,1]; weights (B, Nq, H, L, P)

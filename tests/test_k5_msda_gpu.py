@@ -39,3 +39,47 @@ def test_msda_fwd_bwd(device, B, H, D, shapes, P):
     torch.testing.assert_close(v_d.grad.cpu(), v_r.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(a_d.grad.cpu(), a_r.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(l_d.grad.cpu(), l_r.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shapes,points', [([(16, 16), (8, 8), (4, 4)], 4), ([(12, 20)], 3), ([(8, 8), (4, 6)], 8)])
+def test_msda_prepare_matches_torch_composition(device, dt, shapes, points):
+    """K16 vs the torch ops it replaces (softmax over L*P, offsets / (W, H), + reference points), including the
+    dtype of the quotient under bf16 projections; forward and both gradients."""
+    from mask_bev_amd import ops
+    torch.manual_seed(7)
+    B, H, L, P = 2, 4, len(shapes), points
+    N = sum(h * w for h, w in shapes)
+    assert ops.msda_prepare_supported(L, P)
+    off = (torch.randn(B, N, H, L, P, 2, device=device) * 3).to(dt).requires_grad_()
+    logit = torch.randn(B, N, H, L * P, device=device).to(dt).requires_grad_()
+    ref = torch.rand(N, 2, device=device)
+    g_loc = torch.randn(B, N, H, L, P, 2, device=device)
+    g_aw = torch.randn(B, N, H, L, P, device=device)
+    loc, aw = ops.msda_prepare(off, logit, ref, shapes)
+    assert loc.dtype == torch.float32 and aw.dtype == torch.float32
+    (loc * g_loc).sum().add((aw * g_aw).sum()).backward()
+    off_r, logit_r = off.detach().clone().requires_grad_(), logit.detach().clone().requires_grad_()
+    shapes_t = torch.tensor(shapes, device=device)
+    normalizer = torch.stack([shapes_t[:, 1], shapes_t[:, 0]], -1).to(dt)
+    aw_r = logit_r.float().softmax(-1).view(B, N, H, L, P)           # autocast evaluates softmax in f32
+    loc_r = ref.view(1, N, 1, 1, 1, 2) + off_r / normalizer.view(1, 1, 1, L, 1, 2)
+    (loc_r * g_loc).sum().add((aw_r * g_aw).sum()).backward()
+    assert loc_r.dtype == torch.float32
+    torch.testing.assert_close(aw, aw_r, rtol=1e-5, atol=1e-6)
+    if dt == torch.float32:
+        torch.testing.assert_close(loc, loc_r, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(off.grad, off_r.grad, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(logit.grad, logit_r.grad, rtol=1e-4, atol=1e-6)
+    else:
+        assert torch.equal(loc, loc_r)                               # same bf16 quotient, same f32 add
+        assert torch.equal(off.grad, off_r.grad)
+        torch.testing.assert_close(logit.grad.float(), logit_r.grad.float(), rtol=1.6e-2, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_msda_prepare_limits(device):
+    from mask_bev_amd import ops
+    assert ops.msda_prepare_supported(3, 4) and ops.msda_prepare_supported(4, 4)
+    assert not ops.msda_prepare_supported(5, 4) and not ops.msda_prepare_supported(9, 1)
