@@ -175,8 +175,7 @@ __device__ __forceinline__ float act_grad(float z, float g) {
   if (KIND == 0) return z > 0.f ? g : 0.f;
   // Phi(z) = 0.5 (1 + erf(z / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 in erf): the rational form needs
   // exp(-(z / sqrt 2)^2) = exp(-z^2 / 2) — the very exponential the density term uses — so the whole derivative
-  // costs one exp, one rcp and a degree-5 Horner chain instead of libm's erff (the kernel was VALU-bound on it:
-  // 79 us per 50 M elements against 60 us of HBM time).
+  // costs one exp, one rcp and a degree-5 Horner chain instead of libm's erff.
   const float e = __expf(-0.5f * z * z);
   const float az = fabsf(z) * 0.70710678118654752f;
   const float t = __frcp_rn(1.f + 0.3275911f * az);
@@ -199,7 +198,26 @@ __global__ void __launch_bounds__(256) k_act_bwd_colsum(const T* __restrict__ ga
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c0 < n) {
-    for (long r = r0 + ro; r < r1; r += rpi) {
+    long r = r0 + ro;
+    // 4 rows per iteration: 8 loads in flight per thread (one row at a time left the kernel on load latency —
+    // 3.9 TB/s — whatever the arithmetic cost)
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {
+      float4 g[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = load4<T>(ga + (r + u * rpi) * n + c0);
+        x[u] = load4<T>(z + (r + u * rpi) * n + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float4 d;
+        d.x = act_grad<KIND>(x[u].x, g[u].x); d.y = act_grad<KIND>(x[u].y, g[u].y);
+        d.z = act_grad<KIND>(x[u].z, g[u].z); d.w = act_grad<KIND>(x[u].w, g[u].w);
+        store4t<T>(gz + (r + u * rpi) * n + c0, d);
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+      }
+    }
+    for (; r < r1; r += rpi) {
       const float4 g = load4<T>(ga + r * n + c0);
       const float4 x = load4<T>(z + r * n + c0);
       float4 d;
