@@ -81,6 +81,32 @@ __global__ void __launch_bounds__(256) k_pack_binary(const float* __restrict__ s
   if (lane == 32 && w0 < words_per_map) packed[map * words_per_map + w0] = (uint32_t)(m >> 32);
 }
 
+// Same packing, 16 pixels per thread: a lane reads four float4 (4 x 16 B, each wave instruction one contiguous KiB),
+// turns each into a nibble, and the 8 lanes that share a word OR their nibbles together with three xor-shuffles.
+// (One pixel per thread ran at 1.9 TB/s: 105 M threads for 420 MB.)  hw % 1024 == 0 (whole wave tiles per map).
+__global__ void __launch_bounds__(256) k_pack_binary_v4(const float* __restrict__ src, int64_t hw, int64_t words_per_map,
+                                                        uint32_t* __restrict__ packed) {
+  const int64_t map = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // 1024 pixels per wave
+  const int64_t p0 = wave * 1024;
+  if (p0 >= hw) return;
+  const float* s = src + map * hw + p0;
+  float4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(s + u * 256 + lane * 4);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    uint32_t w = ((v[u].x != 0.f) ? 1u : 0u) | ((v[u].y != 0.f) ? 2u : 0u) | ((v[u].z != 0.f) ? 4u : 0u) |
+                 ((v[u].w != 0.f) ? 8u : 0u);
+    w <<= 4 * (lane & 7);
+    w |= __shfl_xor(w, 1, 64);
+    w |= __shfl_xor(w, 2, 64);
+    w |= __shfl_xor(w, 4, 64);
+    if ((lane & 7) == 0) packed[map * words_per_map + (p0 + u * 256) / 32 + (lane >> 3)] = w;
+  }
+}
+
 constexpr int kPackedWords = 32768;   // 128 KB LDS: up to 1024 x 1024 binary pixels
 
 // WORDS = LDS words reserved for the packed map: 8192 (32 KB, a 512 x 512 mask: four workgroups per CU) or 32768
@@ -191,8 +217,12 @@ extern "C" int mbv_pack_binary_masks(const float* src, int64_t num_maps, int32_t
   if (!src || !packed) return MBV_ERR_BAD_ARG;
   if (num_maps > 65535) return MBV_ERR_UNSUPPORTED;
   const int64_t hw = (int64_t)H * W, words = mbv_packed_mask_words(H, W);
-  hipLaunchKernelGGL(k_pack_binary, dim3((unsigned)((words * 32 + 255) / 256), (unsigned)num_maps), dim3(256), 0, stream,
-                     src, hw, words, packed);
+  if (hw % 1024 == 0 && (reinterpret_cast<size_t>(src) & 15) == 0)
+    hipLaunchKernelGGL(k_pack_binary_v4, dim3((unsigned)((hw / 1024 + 3) / 4), (unsigned)num_maps), dim3(256), 0, stream,
+                       src, hw, words, packed);
+  else
+    hipLaunchKernelGGL(k_pack_binary, dim3((unsigned)((words * 32 + 255) / 256), (unsigned)num_maps), dim3(256), 0,
+                       stream, src, hw, words, packed);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

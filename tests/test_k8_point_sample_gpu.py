@@ -1,4 +1,5 @@
 """K8 indexed bilinear point sampling: forward/backward vs F.grid_sample on gathered maps (f32, rtol 1e-5)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -56,3 +57,21 @@ def test_point_sample_bf16_source_outside_autocast(device):
     out = ops.point_sample(src.to(device), idx, coords.to(device), idx)
     ref = F.grid_sample(src.float().unsqueeze(1), 2.0 * coords.unsqueeze(2) - 1.0, align_corners=False).squeeze(3).squeeze(1)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('H,W', [(64, 64), (512, 512), (37, 29), (32, 48), (128, 24)])
+def test_pack_binary_masks_bits(device, H, W):
+    """bit i of word k = (pixel 32 k + i != 0), both packing kernels (whole 1024-pixel tiles / ragged)."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    src = (torch.rand(5, H, W, generator=g) > 0.5).float() * torch.randn(5, H, W, generator=g).sign()
+    src[1] = 0
+    src[2] = 1
+    pm = ops.pack_binary_masks(src.to(device))
+    words = pm.words.cpu().numpy().astype(np.uint32).reshape(5, -1)
+    bits = (src.flatten(1).numpy() != 0)
+    nw = words.shape[1]
+    padded = np.zeros((5, nw * 32), dtype=bool)
+    padded[:, :H * W] = bits
+    want = (padded.reshape(5, nw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+    assert np.array_equal(words, want)
