@@ -165,6 +165,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    replica_spread = None
+    if world > 1:
+        # data-parallel sanity, outside the timed region: every rank must hold the same parameters after the run
+        cs = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replica_spread = float((hi - lo).item())
 
     if rank == 0:
         w = synthetic.WORKLOADS[args.workload]
@@ -203,7 +211,7 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned,
+                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss),
             roofline=dominant, roofline_all=list(roof.values()))
         if not args.no_cpu_baseline and world == 1:

@@ -88,6 +88,19 @@ class ParameterArena:
         ab = [self.segments[n] for n in names]
         return min(a for a, _ in ab), max(b for _, b in ab)
 
+    def range_of(self, module_or_params) -> Tuple[int, int]:
+        """Arena range [lo, hi) holding exactly the parameters of a sub-module (they are laid out in registration
+        order, so a sub-module's parameters are contiguous); raises if other parameters are interleaved."""
+        params = list(module_or_params.parameters()) if isinstance(module_or_params, nn.Module) else list(module_or_params)
+        ids = {id(p) for p in params}
+        inside = [(o, o + _round_up(p.numel(), _ALIGN)) for p, o in self.layout if id(p) in ids]
+        if len(inside) != len(ids):
+            raise ValueError('parameters outside the arena')
+        lo, hi = min(a for a, _ in inside), max(b for _, b in inside)
+        if any(lo <= o < hi and id(p) not in ids for p, o in self.layout):
+            raise ValueError('the parameters are not contiguous in the arena')
+        return lo, hi
+
     # -- maintenance ------------------------------------------------------------------------------------
     def refresh_shadow(self):
         """Re-derive the bf16 shadow from the f32 parameters (after load_state_dict / broadcast / manual edits)."""

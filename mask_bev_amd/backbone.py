@@ -18,9 +18,9 @@ class MaskBevBackbone(nn.Module):
         self._backbone = CustomSwinTransformer(**config)
         self._backbone.init_weights()
 
-    def forward(self, x):
-        """(B, C, ny, nx) → 4 maps (B, C_i, ny/S_i, nx/S_i)."""
-        return self._backbone(x)
+    def forward(self, x, cut=None):
+        """(B, C, ny, nx) → 4 maps (B, C_i, ny/S_i, nx/S_i).  ``cut``: see ``CustomSwinTransformer.forward``."""
+        return self._backbone(x) if cut is None else self._backbone(x, cut=cut)
 
     @staticmethod
     def _get_config(pretrain_img_size, in_channels, embed_dims, patch_size, window_size, strides, use_abs_pos_embed,

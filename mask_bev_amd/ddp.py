@@ -153,6 +153,17 @@ class GradientAllReducer:
                                                group=self.group, async_op=True))
         return handles
 
+    def start_ranges(self, arena, ranges, chunk_mb: float = 256.0) -> list:
+        """Like :meth:`start_arena` for explicit element ranges [(lo, hi), ...] of the arena gradient — the parts
+        of a segment whose backward has already finished (graph.py launches them while the rest still runs)."""
+        handles = []
+        step = max(1, int(chunk_mb * 1024 * 1024) // 4)
+        for a, b in ranges:
+            for lo in range(a, b, step):
+                handles.append(dist.all_reduce(arena.grad[lo:min(b, lo + step)], op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
+        return handles
+
     def finish_arena(self, arena, handles: list, optimizer=None):
         """Wait for :meth:`start_arena`; the mean is applied by the optimizer kernel (``grad_scale = 1/world``)
         when it supports it, else by one in-place division."""

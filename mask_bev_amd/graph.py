@@ -7,8 +7,13 @@ a HIP graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) — Swin backbone, pix
 decoder, the sync-free loss (K8/K9/K10) and their whole backward — and replayed every step:
 
     eager   K1 voxelise → K2 PFN → K3 scatter+LayerNorm          (pillar counts differ per batch: dynamic shapes)
-    replay  backbone → head → loss → backward                     (one graph launch)
+    replay  backbone → head → loss → backward of head + last Swin stage        (graph 1)
+    replay  backward of Swin stages 1-3 and the patch projection               (graph 2, same memory pool)
     eager   backward of K3 / K2 from the graph's d(loss)/d(pseudo-image), optimizer step
+
+Data-parallel runs launch the gradient all-reduce in four pieces as their gradients complete — head + last stage
+after graph 1 (underneath graph 2), the rest of the backbone after graph 2 and the encoder's LayerNorm affine from
+its gradient hook (both underneath the encoder backward), the PFN last — so that only the tail is exposed.
 
 With a parameter arena (``module.flatten_parameters()``, arena.py) the graph accumulates into the arena's static
 gradient buffer, the optimizer step is one K11 launch that also clears the gradient and refreshes the bf16 weight
@@ -77,24 +82,59 @@ class GraphedTrainStep:
             for p in self._graph_params:
                 p.grad = None
         self.x_static.grad = None
+        # Two graphs sharing one memory pool: (1) forward, loss, backward of the head and of the LAST backbone stage;
+        # (2) backward of the earlier stages.  Between the two replays a data-parallel step launches the all-reduce
+        # of the gradients graph 1 completed (head + last stage = 38 % of the bytes), which then runs on RCCL's
+        # stream underneath graph 2; on one GPU the two replays are simply back to back.
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss_static = self._forward_backward()
+            self.loss_static = self._forward_backward_head()
+        self.graph_late = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_late, pool=self.graph.pool()):
+            self._backward_early_stages()
         torch.cuda.synchronize()
+        self._ranges_head, self._ranges_late = self._arena_ranges()
 
     @staticmethod
     def _rows(x):
         return x.rows if isinstance(x, ops.PatchTokens) else x
 
-    def _forward_backward(self) -> torch.Tensor:
+    def _forward_backward_head(self) -> torch.Tensor:
+        """Forward of backbone + head + loss, then the backward of the head and of the last backbone stage (the
+        autograd graph is cut in front of that stage and at the three earlier feature maps)."""
         m = self.m
         dt = m._compute_dtype
+        swin = m._backbone._backbone
+        cut = {'stage': len(swin.stages) - 1}
         with torch.autocast('cuda', dtype=dt or torch.bfloat16, enabled=dt is not None, cache_enabled=False):
-            feats = m._backbone(self._x_in)
-            cls, masks, heights = m._panoptic_head(feats)
+            feats = m._backbone(self._x_in, cut=cut)
+            early = list(feats[:cut['stage']])
+            leaves = [f.detach().requires_grad_() for f in early]
+            cls, masks, heights = m._panoptic_head(leaves + list(feats[cut['stage']:]))
         loss = m.loss(m.compute_loss(cls, masks, self.labels, self.masks, heights, None))
         loss.backward()
+        self._late_roots = early + [cut['x_in']]
+        self._late_grads = [l.grad for l in leaves] + [cut['x_leaf'].grad]
         return loss.detach()
+
+    def _backward_early_stages(self):
+        torch.autograd.backward(self._late_roots, self._late_grads)
+        self._late_roots = self._late_grads = None
+
+    def _forward_backward(self) -> torch.Tensor:
+        loss = self._forward_backward_head()
+        self._backward_early_stages()
+        return loss
+
+    def _arena_ranges(self):
+        """Arena ranges whose gradients are complete after graph 1 / only after graph 2."""
+        if self.arena is None:
+            return None, None
+        swin = self.m._backbone._backbone
+        last = len(swin.stages) - 1
+        a, b = self.arena.segments['backbone']
+        lo, hi = self.arena.range_of(swin.stages[last])
+        return [self.arena.segments['head'], (lo, hi)], [(a, lo), (hi, b)]
 
     def step(self, batch) -> torch.Tensor:
         m = self.m
@@ -110,16 +150,34 @@ class GraphedTrainStep:
                 self.masks.words.copy_(masks.words)
         elif masks.data_ptr() != self.masks.data_ptr():
             self.masks.copy_(masks)
-        self.graph.replay()                                # backbone, head, loss and their backward
+        overlap = self.reducer is not None and self.arena is not None
+        self.graph.replay()                                # backbone, head, loss; backward of head + last stage
         handles = None
-        if self.reducer is not None and self.arena is not None:
-            handles = self.reducer.start_arena(self.arena, ('head', 'backbone'))   # overlaps the encoder backward
-        x.backward(self.x_static.grad)                     # eager: backward of K3 / K2
-        if handles is not None:
-            handles += self.reducer.start_arena(self.arena, ('encoder',))
+        if overlap:                                        # their all-reduce runs underneath the second graph
+            handles = self.reducer.start_ranges(self.arena, self._ranges_head)
+        self.graph_late.replay()                           # backward of the earlier backbone stages
+        if overlap:
+            handles += self.reducer.start_ranges(self.arena, self._ranges_late)
+            # K3's backward is the FIRST kernel of the encoder backward and produces the two largest gradients of
+            # the model (the (C, ny, nx) LayerNorm affine, 268 MB): their all-reduce starts from the gradient hook,
+            # underneath the PFN backward that follows
+            ln = self.m._encoder._layer_norm
+            ln_range = self.arena.range_of(ln)
+            early = []
+            hook = ln.bias.register_post_accumulate_grad_hook(
+                lambda p: early.extend(self.reducer.start_ranges(self.arena, [ln_range])))
+            try:
+                x.backward(self.x_static.grad)             # eager: backward of K3 / K2
+            finally:
+                hook.remove()
+            a, b = self.arena.segments['encoder']
+            rest = [(a, b)] if not early else [(a, ln_range[0]), (ln_range[1], b)]
+            handles += early + self.reducer.start_ranges(self.arena, [r for r in rest if r[1] > r[0]])
             self.reducer.finish_arena(self.arena, handles, self.opt)
-        elif self.reducer is not None:
-            self.reducer.reduce_all()
+        else:
+            x.backward(self.x_static.grad)                 # eager: backward of K3 / K2
+            if self.reducer is not None:
+                self.reducer.reduce_all()
         self.opt.step()
         if self.arena is None:
             for p in self.m._encoder.parameters():         # graph-owned gradients are overwritten by the replay

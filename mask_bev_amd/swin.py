@@ -158,7 +158,11 @@ class CustomSwinTransformer(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
-    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+    def forward(self, x: torch.Tensor, cut: Optional[dict] = None) -> List[torch.Tensor]:
+        """``cut = {'stage': i}`` severs the autograd graph in front of stage ``i`` (graph.py runs the backward of
+        the head and the last stage, then of the earlier stages, as two HIP graphs with a gradient all-reduce
+        launched in between): on return ``cut['x_in']`` is the attached input of that stage and ``cut['x_leaf']``
+        the detached leaf the stage actually consumed (its ``.grad`` is the gradient to continue with)."""
         x = self.patch_embed(x)                                    # (B, H, W, E)
         b, h, w, e = x.shape
         if self.use_abs_pos_embed:
@@ -170,6 +174,9 @@ class CustomSwinTransformer(nn.Module):
             x = x + ape.flatten(2).transpose(1, 2).reshape(1, h, w, e)
         outs = []
         for i, stage in enumerate(self.stages):
+            if cut is not None and i == cut['stage']:
+                cut['x_in'] = x
+                x = cut['x_leaf'] = x.detach().requires_grad_()
             x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None)
             if i in self.out_indices:
                 outs.append(out.permute(0, 3, 1, 2).contiguous())

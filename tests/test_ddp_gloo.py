@@ -132,3 +132,80 @@ def test_arena_allreduce_world2_matches_single_process():
     from mask_bev_amd.arena import ParameterArena
     want = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None).param
     assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-6)
+
+
+def _ranges_worker(rank, world, port, out):
+    """The staged exchange of graph.py: sub-module ranges reduced as their gradients complete, one of them from a
+    post-accumulate hook fired inside backward."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mask_bev_amd.arena import ParameterArena
+    from mask_bev_amd.ddp import GradientAllReducer
+    torch.manual_seed(100 + rank)
+    enc = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 32))
+    bb = nn.Sequential(nn.Linear(32, 24), nn.ReLU(), nn.Linear(24, 16))
+    head = nn.Linear(16, 1)
+    m = nn.Sequential(enc, nn.ReLU(), bb, nn.ReLU(), head)
+    red = GradientAllReducer(m, bucket_mb=0.001)
+    red.no_sync(True)
+    arena = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None)
+    last = arena.range_of(bb[2])                            # "last stage" of the backbone
+    a, b = arena.segments['backbone']
+    assert a <= last[0] < last[1] == b and arena.range_of(bb) == (a, b)
+    first_enc = arena.range_of(enc[2])                      # the encoder layer whose backward runs first
+    ea, eb = arena.segments['encoder']
+    torch.manual_seed(7)
+    x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
+    idx = list(range(rank, 8, world))
+    for _ in range(2):
+        early = []
+        hook = enc[2].bias.register_post_accumulate_grad_hook(lambda p: early.extend(red.start_ranges(arena, [first_enc])))
+        ((m(x_all[idx]) - y_all[idx]) ** 2).mean().backward()
+        hook.remove()
+        assert early, 'the hook did not fire'
+        handles = red.start_ranges(arena, [arena.segments['head'], last], chunk_mb=0.0005)
+        handles += red.start_ranges(arena, [(a, last[0]), (last[1], b)])
+        handles += early + red.start_ranges(arena, [(ea, first_enc[0]), (first_enc[1], eb)])
+        red.finish_arena(arena, handles)
+        with torch.no_grad():
+            arena.param.sub_(0.1 * arena.grad)
+        arena.zero_grad()
+    out[rank] = arena.param.clone()
+    dist.destroy_process_group()
+
+
+def test_staged_range_allreduce_world2_matches_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ranges_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0], out[1])
+    torch.manual_seed(100)
+    enc = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 32))
+    bb = nn.Sequential(nn.Linear(32, 24), nn.ReLU(), nn.Linear(24, 16))
+    head = nn.Linear(16, 1)
+    ref = nn.Sequential(enc, nn.ReLU(), bb, nn.ReLU(), head)
+    torch.manual_seed(7)
+    x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
+    for _ in range(2):
+        gs = []
+        for r in range(2):
+            idx = list(range(r, 8, 2))
+            gs.append(torch.autograd.grad(((ref(x_all[idx]) - y_all[idx]) ** 2).mean(), list(ref.parameters())))
+        with torch.no_grad():
+            for p, g0, g1 in zip(ref.parameters(), *gs):
+                p.sub_(0.1 * (g0 + g1) / 2)
+    from mask_bev_amd.arena import ParameterArena
+    want = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None).param
+    assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-6)
+
+
+def test_arena_range_of_rejects_interleaved_parameters():
+    from mask_bev_amd.arena import ParameterArena
+    a, b, c = nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 4)
+    arena = ParameterArena([('s', nn.Sequential(a, b, c))], shadow_dtype=None)
+    assert arena.range_of(b)[0] == arena.range_of(a)[1]
+    with pytest.raises(ValueError):
+        arena.range_of([a.weight, c.weight])
+    with pytest.raises(ValueError):
+        arena.range_of(nn.Linear(2, 2))
