@@ -192,6 +192,80 @@ def _point_sample(inp: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
     return F.grid_sample(inp, 2.0 * pts.unsqueeze(2) - 1.0, align_corners=False).squeeze(3)
 
 
+class _DeferredHeads(torch.autograd.Function):
+    """The prediction heads of all D = layers + 1 decoder outputs, backward in ONE batched pass.
+
+    The forward values (class scores, mask logits in the stacked buffer, the next layer's attention mask) are needed
+    layer by layer and are computed there without a graph.  Their backward does not have that dependency: the loss
+    gradient of all D outputs is available before the decoder's backward starts.  Run per layer it costs ≈ 16 launches
+    on B*Q = 400 rows each, ten times (two batched GEMMs against the mask features, nine accumulations of the 16 MB
+    feature gradient, the three-layer MLP, the class head, the LayerNorm); here it is one cast + permute of the
+    stacked logit gradient, two GEMMs with D*Q rows per sample, and one re-evaluation + backward of the small head
+    on D*B*Q rows (the re-evaluation uses the precision the per-layer forward used).  mask2former_head.py:428-472."""
+
+    @staticmethod
+    def forward(ctx, head, cls_all, mask_feature, *query_feats):
+        ctx.head = head
+        ctx.nd = len(query_feats)
+        ctx.save_for_backward(mask_feature, *query_feats)
+        # the D mask predictions leave as the D slices of the stacked buffer the per-layer passes filled (views: the
+        # loss re-assembles them without a copy, ops.stack_slices); the buffer itself is not an autograd input
+        stack = head._mask_stack
+        return (cls_all.view_as(cls_all),) + tuple(stack[i] for i in range(ctx.nd))
+
+    @staticmethod
+    def backward(ctx, d_cls, *d_masks):
+        head, nd = ctx.head, ctx.nd
+        mask_feature, *query_feats = ctx.saved_tensors
+        b, q, c = query_feats[0].shape
+        hh, ww = mask_feature.shape[-2:]
+        hw = hh * ww
+        dt = mask_feature.dtype
+        # stacked logit gradient (D, B, Q, H, W): the slices handed back by ops.stack_slices are views of one buffer
+        g0 = d_masks[0]
+        full = None
+        if g0 is not None and all(g is not None and g.is_contiguous() and g.dtype == g0.dtype for g in d_masks):
+            step = g0.numel() * g0.element_size()
+            if all(g.data_ptr() == g0.data_ptr() + i * step for i, g in enumerate(d_masks)):
+                full = torch.as_strided(g0, (nd, b, q, hw), (b * q * hw, q * hw, hw, 1))
+        if full is None:
+            zero = None
+            parts = []
+            for g in d_masks:
+                if g is None:
+                    zero = zero if zero is not None else torch.zeros((b, q, hh, ww), dtype=torch.float32,
+                                                                     device=mask_feature.device)
+                    g = zero
+                parts.append(g.float())
+            full = torch.stack(parts, 0).view(nd, b, q, hw)
+        dl = torch.empty((b, nd, q, hw), dtype=dt, device=full.device)       # per sample: D*Q rows, one cast+permute
+        dl.copy_(full.permute(1, 0, 2, 3))
+        dl = dl.view(b, nd * q, hw)
+        # re-evaluate the small head on all D*B*Q rows with a graph, in the per-layer forward's precision
+        small = b * q * c <= ops._SMALL_F32_ROWS * c
+        adt = head._deferred_autocast
+        with torch.enable_grad(), torch.autocast('cuda', dtype=adt or torch.bfloat16,
+                                                 enabled=(adt is not None) and not small, cache_enabled=False):
+            q_all = torch.stack([t.detach() for t in query_feats], 0).requires_grad_()      # (D, B, Q, C)
+            y = head.transformer_decoder.post_norm(q_all)
+            cls_re = head.cls_embed(y)
+            e_re = head.mask_embed(y)                                                      # (D, B, Q, C)
+        e_b = torch.empty((b, nd, q, c), dtype=dt, device=full.device)
+        e_b.copy_(e_re.detach().permute(1, 0, 2, 3))
+        e_b = e_b.view(b, nd * q, c)
+        ff = mask_feature.reshape(b, c, hw)
+        d_e = torch.bmm(dl, ff.transpose(1, 2))                                            # (B, D*Q, C)
+        d_f = torch.bmm(e_b.transpose(1, 2), dl).view(b, c, hh, ww)                        # (B, C, H, W)
+        d_e = d_e.view(b, nd, q, c).permute(1, 0, 2, 3).to(e_re.dtype)
+        roots, grads = [e_re], [d_e]
+        if d_cls is not None:
+            roots.append(cls_re)
+            grads.append(d_cls.to(cls_re.dtype))
+        torch.autograd.backward(roots, grads)                # parameter gradients accumulate where they always do
+        gq = q_all.grad
+        return (None, None, d_f) + tuple(gq[i] for i in range(nd))
+
+
 class Mask2FormerHead(nn.Module):
     def __init__(self, in_channels, feat_channels, out_channels, num_things_classes=80, num_stuff_classes=53,
                  num_queries=100, num_transformer_feat_level=3, pixel_decoder=None, enforce_decoder_input_project=False,
@@ -294,19 +368,33 @@ class Mask2FormerHead(nn.Module):
         stack = torch.empty((nd, bs, self.num_queries) + tuple(mask_features.shape[-2:]), dtype=torch.float32,
                             device=mask_features.device) if mask_features.is_cuda else None
         self._mask_stack = stack
-        cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features, memories[0].shape[-2:],
-                                                          None if stack is None else stack[0])
+        # training on the GPU: the heads run layer by layer WITHOUT a graph and get one batched backward (_DeferredHeads)
+        deferred = (stack is not None and self.training and torch.is_grad_enabled()
+                    and os.environ.get('MBV_DEFERRED_HEADS', '1') != '0')
+        feats_q = [query_feat]
+
+        def heads(qf, size, slot):
+            if not deferred:
+                return self._forward_head(qf, mask_features, size, slot)
+            with torch.no_grad():
+                return self._forward_head(qf, mask_features, size, slot)
+
+        cls_pred, mask_pred, blocked = heads(query_feat, memories[0].shape[-2:], None if stack is None else stack[0])
         cls_list.append(cls_pred)
         mask_list.append(mask_pred)
         nl = self.num_transformer_feat_level
         for i, layer in enumerate(self.transformer_decoder.layers):
             lvl = i % nl
             query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl])
-            cls_pred, mask_pred, blocked = self._forward_head(query_feat, mask_features,
-                                                              memories[(i + 1) % nl].shape[-2:],
-                                                              None if stack is None else stack[i + 1])
+            feats_q.append(query_feat)
+            cls_pred, mask_pred, blocked = heads(query_feat, memories[(i + 1) % nl].shape[-2:],
+                                                 None if stack is None else stack[i + 1])
             cls_list.append(cls_pred)
             mask_list.append(mask_pred)
+        if deferred:
+            self._deferred_autocast = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None
+            outs = _DeferredHeads.apply(self, torch.stack(cls_list, 0), mask_features, *feats_q)
+            cls_list, mask_list = list(outs[0].unbind(0)), list(outs[1:])
         return cls_list, mask_list, [None for _ in cls_list]
 
     # ------------------------------------------------------------------ loss

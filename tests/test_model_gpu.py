@@ -172,3 +172,34 @@ def test_tuned_gemm_table_accepted_and_numerically_neutral(device):
     finally:
         tunable.enable(was)
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_deferred_heads_backward_equals_per_layer_backward(device, dtype, monkeypatch):
+    """_DeferredHeads (one batched backward of the 10 prediction heads) vs the per-layer autograd path: same loss,
+    same gradients for every parameter (fp32: 1e-4 of the largest entry; bf16: the per-layer path sums the mask
+    feature gradient in bf16, the batched one in f32 — 3e-2)."""
+    kw = tiny_kwargs()
+    kw['compute_dtype'] = dtype
+    grads, losses = {}, {}
+    scans = random_scans(kw, [3000, 2000], seed=2)
+    labels, gt = random_gt(kw, 2, 3, seed=4)
+    for mode in ('1', '0'):
+        monkeypatch.setenv('MBV_DEFERRED_HEADS', mode)
+        m, cfg, sd = _build(kw, device, seed=7)
+        head = m._panoptic_head._panoptic_head
+        head.num_points = 256
+        head.point_seed = 11
+        m.train()
+        loss = m.training_step(([s.to(device) for s in scans], (labels.to(device), gt.to(device))), 1)
+        loss.backward()
+        losses[mode] = float(loss.detach())
+        grads[mode] = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert abs(losses['1'] - losses['0']) <= 1e-6 * abs(losses['0'])          # forward values are the same tensors
+    assert grads['1'].keys() == grads['0'].keys()
+    tol = 1e-4 if dtype == 'fp32' else 3e-2
+    for k in grads['0']:
+        scale = float(grads['0'][k].abs().max()) + 1e-12
+        err = float((grads['1'][k] - grads['0'][k]).abs().max()) / scale
+        assert err <= tol, (k, err)
