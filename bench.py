@@ -35,6 +35,9 @@ def parse():
     ap.add_argument('--workload', default='semantic_kitti_512')
     ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (YAML batch_size)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'])
+    ap.add_argument('--distribution', default='lidar', choices=['lidar', 'uniform'],
+                    help="synthetic point distribution: 64-beam LiDAR-shaped scans (headline) or uniform x/y "
+                         "(worst case for the pillar count)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-budget-s', type=float, default=90.0)
     ap.add_argument('--pool', type=int, default=2, help='distinct synthetic batches kept resident in HBM')
@@ -120,7 +123,8 @@ def main():
         if getattr(model, '_arena', None) is not None:
             model._arena.refresh_shadow()       # the construction-time parameter broadcast wrote the f32 arena
 
-    pool = [synthetic.make_batch(args.workload, args.batch, rank, s, device) for s in range(args.pool)]
+    pool = [synthetic.make_batch(args.workload, args.batch, rank, s, device, args.distribution)
+            for s in range(args.pool)]
     torch.cuda.synchronize()
 
     graphed = None
@@ -195,7 +199,8 @@ def main():
         # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
         # MI355X_MICROARCH.md); same workload, same build
         traffic = {'k_ln_apply': 576.8e6, 'k_ln_bwd_dense': 993.6e6, 'k_adamw': 6511.5e6} \
-            if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0) else {}
+            if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
+                and args.distribution == 'lidar') else {}
         roof = {}
         for name, ms in times.items():
             if not ms or name not in algo:
@@ -205,15 +210,25 @@ def main():
                               frac=algo[name] / (avg * 1e-3) / 1e9 / 8000.0, traffic=traffic.get(name),
                               kernel=name, avg_ms=avg, launches=len(ms), algorithmic_bytes=algo[name])
         dominant = max(roof.values(), key=lambda r: r['avg_ms']) if roof else None
+        # whole-step figure: algorithmic work per scan of the S2 configuration — 0.97 TFLOP and 4.5 GB
+        # forward + backward, plus the optimizer pass shared by the scans of a step — against the chip peaks
+        step_roof = None
+        if args.workload == 'semantic_kitti_512':
+            sps = args.batch * args.steps / dt                        # scans per second on this GPU
+            bytes_scan = 4.5e9 + algo['k_adamw'] / args.batch
+            step_roof = dict(flops_per_scan=0.97e12, achieved_tflops=0.97 * sps, mfma_peak_tflops=2500.0,
+                             frac_mfma=0.97 * sps / 2500.0, bytes_per_scan=bytes_scan,
+                             achieved_gbs=bytes_scan * sps / 1e9, hbm_peak_gbs=8000.0,
+                             frac_hbm=bytes_scan * sps / 1e9 / 8000.0)
         line = dict(
             metric='LiDAR scans/sec fwd+bwd, 120k-pt 512x512 BEV 100q', value=args.batch * world * args.steps / dt,
             unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-            higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
+            higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic' if args.distribution == 'lidar' else 'synthetic (uniform x/y points)',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
                         step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss),
-            roofline=dominant, roofline_all=list(roof.values()))
+            roofline=dominant, roofline_all=list(roof.values()), step_roofline=step_roof)
         if not args.no_cpu_baseline and world == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.workload, model, args.cpu_baseline_budget_s)

@@ -99,18 +99,34 @@ def gt_masks(batch: int, num_queries: int, ny: int, nx: int, gen: torch.Generato
     return labels, masks
 
 
-def make_batch(workload: str, batch: int, rank: int, step: int, device):
+def uniform_scan(n_points: int, pc_dim: int, gen: torch.Generator, device, x_range, y_range) -> torch.Tensor:
+    """x, y ~ U(range), z ~ U(-3, 1), remaining channels U(0, 1): the worst case for the pillar count
+    (≈ 96 k non-empty pillars per 120 k-point scan on the 512 x 512 grid; SURVEY.md §8d distribution (ii))."""
+    pts = torch.rand(n_points, pc_dim, generator=gen, device=device)
+    pts[:, 0] = pts[:, 0] * (x_range[1] - x_range[0]) + x_range[0]
+    pts[:, 1] = pts[:, 1] * (y_range[1] - y_range[0]) + y_range[0]
+    pts[:, 2] = pts[:, 2] * 4.0 - 3.0
+    return pts.contiguous()
+
+
+def make_batch(workload: str, batch: int, rank: int, step: int, device, distribution: str = 'lidar'):
     """One training batch in the reference's batch contract:
-    (list of (Ni, pc_dim) tensors, (labels (B, Q) int64, masks (B, Q, ny, nx) f32))."""
+    (list of (Ni, pc_dim) tensors, (labels (B, Q) int64, masks (B, Q, ny, nx) f32)).
+    ``distribution``: 'lidar' (64-beam scan over a flat ground, the headline input) or 'uniform'."""
     w = WORKLOADS[workload]
     gen = torch.Generator(device=device).manual_seed(420 + 1000 * rank + step)
     nx = int((w['x_range'][1] - w['x_range'][0]) / w['voxel_size'])
     ny = int((w['y_range'][1] - w['y_range'][0]) / w['voxel_size'])
     scans = []
     for _ in range(batch):
-        s = lidar_scan(w['points'], w['pc_point_dim'], gen, device)
-        if w['x_range'][0] >= 0:                 # forward-facing range (KITTI): fold the scan into x >= 0
-            s[:, 0] = s[:, 0].abs()
+        if distribution == 'uniform':
+            s = uniform_scan(w['points'], w['pc_point_dim'], gen, device, w['x_range'], w['y_range'])
+        elif distribution == 'lidar':
+            s = lidar_scan(w['points'], w['pc_point_dim'], gen, device)
+            if w['x_range'][0] >= 0:             # forward-facing range (KITTI): fold the scan into x >= 0
+                s[:, 0] = s[:, 0].abs()
+        else:
+            raise ValueError(f'unknown point distribution {distribution!r}')
         scans.append(s)
     labels, masks = gt_masks(batch, w['num_queries'], ny, nx, gen, device, cell=w['voxel_size'])
     return scans, (labels, masks)
