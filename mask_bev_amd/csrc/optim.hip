@@ -364,7 +364,7 @@ extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, in
   if (T == 0) return MBV_OK;
   const int tiles_o = (O + 31) / 32, tiles_i = (I + 31) / 32;
   const int ntiles = tiles_o * tiles_i;
-  int slices = (1024 + ntiles - 1) / ntiles;            // ≈ 1024 waves = 4 per CU
+  int slices = (2048 + ntiles - 1) / ntiles;            // ≈ 2048 waves = 8 per CU (1024: the 2048-wide FFN layers ran 200-row chains, 21 us)
   const int max_slices = (T + 31) / 32;                 // at least 32 rows per slice
   if (slices > max_slices) slices = max_slices;
   if (slices < 1) slices = 1;
