@@ -122,6 +122,10 @@ def main():
         reducer = GradientAllReducer(model, bucket_mb=64.0)
         if getattr(model, '_arena', None) is not None:
             model._arena.refresh_shadow()       # the construction-time parameter broadcast wrote the f32 arena
+            # arena gradients are accumulated in place, once per USE of a parameter (a packed in_proj weight is used
+            # by three projections): the per-parameter ready-hooks of the bucketed reducer do not apply — the arena
+            # is reduced in contiguous ranges after (graph step: during) the backward
+            reducer.no_sync(True)
 
     pool = [synthetic.make_batch(args.workload, args.batch, rank, s, device, args.distribution)
             for s in range(args.pool)]
@@ -143,7 +147,10 @@ def main():
         loss = model.training_step((scans, gt), i)
         loss.backward()
         if reducer is not None:
-            reducer.finish()
+            if getattr(model, '_arena', None) is not None:
+                reducer.reduce_arena(model._arena, opt)
+            else:
+                reducer.finish()
         opt.step()
         opt.zero_grad(set_to_none=args.no_arena)
         return loss

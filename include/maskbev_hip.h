@@ -460,6 +460,21 @@ int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blo
                  int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
                  float* grad_q, float* grad_k, float* grad_v, void* stream);
 
+/* Same kernels with strided key / value operands: k and v point at columns of a wider row-major matrix whose rows are
+ * `ld_kv` elements apart (the key / value projections of SEVERAL decoder layers that attend to the same memory are
+ * then produced side by side by one GEMM — the three layers of a level in mask2former_head.py:535-560 — and the
+ * gradient of that matrix is assembled in place: grad_k / grad_v rows are `ld_grad_kv` apart, optionally stored as
+ * bf16, ready to be the operand of the batched data / weight-gradient GEMMs).  Strided or bf16 key / value gradients
+ * need num_queries <= 128. */
+int mbv_attn_fwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+                    int32_t is_bf16, int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads,
+                    int32_t head_dim, void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream);
+
+int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+                    const void* out, const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
+                    int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
+                    void* grad_k, void* grad_v, int32_t ld_grad_kv, int32_t grad_kv_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

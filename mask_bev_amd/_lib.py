@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class MaskBevHipError(RuntimeError):
@@ -81,6 +81,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_attn_workspace_bytes': (c_size_t, [_I, _I, _I, _I, _I]),
     'mbv_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, c_size_t, _P]),
     'mbv_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'mbv_attn_fwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, c_size_t, _P]),
+    'mbv_attn_bwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
 }
 
 _lib = None

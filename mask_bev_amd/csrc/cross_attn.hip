@@ -21,6 +21,10 @@ using namespace mbv_tiles;
 
 struct AttnGeom {
   int B, Q, L, heads, E, nsplit, nsuper;
+  int ldkv;      // row stride (elements) of the key / value inputs: E, or wider when several layers' projections of the
+                 // same memory are written side by side by one GEMM (the pointers then carry the column offset)
+  int ldg;       // row stride of grad_k / grad_v
+  int gkv_bf16;  // grad_k / grad_v stored as bf16 (single query super-block only: plain stores)
 };
 
 struct AttnBlock {
@@ -111,12 +115,12 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
   const AttnBlock blk = decode(g);
   const int col = blk.head * D;
   stage_rows<BF16, D, TIn>(q, (int64_t)blk.b * g.Q * g.E, g.E, blk.q0, blk.nq, col, q_img, nullptr);
-  stage_rows<BF16, D, TIn>(k, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, k_img, nullptr);
+  stage_rows<BF16, D, TIn>(k, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, k_img, nullptr);
   if constexpr (BF16) {
-    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, nullptr, v_img);
+    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, nullptr, v_img);
     zero_tail<BF16, D>(v_img);
   } else {
-    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.E, g.E, blk.k0, blk.nk, col, v_img, nullptr);
+    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, v_img, nullptr);
   }
   stage_mask(mask, g, blk, m_lds);
   __syncthreads();
@@ -228,14 +232,15 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
   __shared__ double delta_s[NPAD];     // f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   const AttnBlock blk = decode(g);
   const int col = blk.head * D;
-  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.E;
+  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.ldkv;
+  const int64_t goff = (int64_t)blk.b * g.L * g.ldg;
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     lse_s[t] = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
     delta_s[t] = 0.0;
   }
   stage_rows<BF16, D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, BF16 ? qt_img : nullptr);
-  stage_rows<BF16, D, TIn>(k, koff, g.E, blk.k0, blk.nk, col, k_img, BF16 ? kt_img : nullptr);
-  stage_rows<BF16, D, TIn>(v, koff, g.E, blk.k0, blk.nk, col, v_img, nullptr);
+  stage_rows<BF16, D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img, BF16 ? kt_img : nullptr);
+  stage_rows<BF16, D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img, nullptr);
   stage_rows<BF16, D, TIn>(grad_out, qoff, g.E, blk.q0, blk.nq, col, do_img, BF16 ? dot_img : nullptr);
   if constexpr (BF16) {
     zero_tail<BF16, D>(qt_img);
@@ -339,8 +344,11 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
       for (int i = 0; i < 16; ++i) {
         const int kk = 32 * kb + acc_row(i, h);
         if (kk < blk.nk) {
-          const int64_t o = koff + (int64_t)(blk.k0 + kk) * g.E + col + dcol;
-          if (g.nsuper > 1) { atomicAdd(grad_k + o, dk[cb][i]); atomicAdd(grad_v + o, dv[cb][i]); }
+          const int64_t o = goff + (int64_t)(blk.k0 + kk) * g.ldg + col + dcol;
+          if (g.gkv_bf16) {
+            reinterpret_cast<unsigned short*>(grad_k)[o] = f32_to_bf16_rne(dk[cb][i]);
+            reinterpret_cast<unsigned short*>(grad_v)[o] = f32_to_bf16_rne(dv[cb][i]);
+          } else if (g.nsuper > 1) { atomicAdd(grad_k + o, dk[cb][i]); atomicAdd(grad_v + o, dv[cb][i]); }
           else { grad_k[o] = dk[cb][i]; grad_v[o] = dv[cb][i]; }
         }
       }
@@ -351,6 +359,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
 bool make_attn_geom(int B, int Q, int L, int heads, int D, AttnGeom& g) {
   if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || D <= 0) return false;
   g.B = B; g.Q = Q; g.L = L; g.heads = heads; g.E = heads * D;
+  g.ldkv = g.ldg = g.E; g.gkv_bf16 = 0;
   g.nsplit = (L + NPAD - 1) / NPAD;
   g.nsuper = (Q + NPAD - 1) / NPAD;
   return true;
@@ -409,12 +418,15 @@ extern "C" size_t mbv_attn_workspace_bytes(int32_t batch, int32_t num_queries, i
   return mbv_align_up(attn_ws_floats(g, head_dim) * sizeof(float), 256);
 }
 
-extern "C" int mbv_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* blocked, int32_t is_bf16,
-                            int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
-                            void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int mbv_attn_fwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+                               int32_t is_bf16, int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads,
+                               int32_t head_dim, void* out, float* lse, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnGeom g;
   if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
+  if (ld_kv < g.E) return MBV_ERR_BAD_ARG;
+  g.ldkv = ld_kv;
   if (!q || !k || !v || !out || !lse) return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_attn_workspace_bytes(batch, num_queries, num_keys, heads, head_dim))
     return MBV_ERR_WORKSPACE;
@@ -423,22 +435,43 @@ extern "C" int mbv_attn_fwd(const void* q, const void* k, const void* v, const u
                  : attn_fwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, lse, ws, stream);
 }
 
-extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blocked, const void* out,
-                            const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
-                            int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
-                            float* grad_k, float* grad_v, void* stream_) {
+extern "C" int mbv_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* blocked, int32_t is_bf16,
+                            int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
+                            void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream_) {
+  return mbv_attn_fwd_ld(q, k, v, heads * head_dim, blocked, is_bf16, batch, num_queries, num_keys, heads, head_dim,
+                         out, lse, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+                               const void* out, const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
+                               int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
+                               void* grad_k, void* grad_v, int32_t ld_grad_kv, int32_t grad_kv_bf16, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnGeom g;
   if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
   if (!q || !k || !v || !out || !grad_out || !lse || !grad_q || !grad_k || !grad_v) return MBV_ERR_BAD_ARG;
+  if (ld_kv < g.E || ld_grad_kv < g.E) return MBV_ERR_BAD_ARG;
+  // strided or bf16 key / value gradients are plain stores of whole rows: one query super-block only
+  if ((ld_grad_kv != g.E || grad_kv_bf16) && g.nsuper > 1) return MBV_ERR_UNSUPPORTED;
+  g.ldkv = ld_kv; g.ldg = ld_grad_kv; g.gkv_bf16 = grad_kv_bf16 ? 1 : 0;
   if (g.nsplit > 1)
     MBV_CHECK_HIP(mbv_fill_async(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
   if (g.nsuper > 1) {
     MBV_CHECK_HIP(mbv_fill_async(grad_k, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
     MBV_CHECK_HIP(mbv_fill_async(grad_v, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
   }
-  return is_bf16 ? attn_bwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, grad_k,
-                                                 grad_v, stream)
-                 : attn_bwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, grad_k,
-                                                 grad_v, stream);
+  float* gk32 = reinterpret_cast<float*>(grad_k);
+  float* gv32 = reinterpret_cast<float*>(grad_v);
+  return is_bf16 ? attn_bwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, gk32,
+                                                 gv32, stream)
+                 : attn_bwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, gk32,
+                                                 gv32, stream);
+}
+
+extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blocked, const void* out,
+                            const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
+                            int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
+                            float* grad_k, float* grad_v, void* stream_) {
+  return mbv_attn_bwd_ld(q, k, v, heads * head_dim, blocked, out, grad_out, lse, is_bf16, batch, num_queries, num_keys,
+                         heads, head_dim, grad_q, grad_k, grad_v, heads * head_dim, 0, stream_);
 }

@@ -175,7 +175,10 @@ class GradientAllReducer:
             arena.grad.div_(self.world)
 
     def reduce_arena(self, arena, optimizer=None, order=('head', 'backbone', 'encoder')):
-        """Segments are reduced in the order their gradients complete (head first, encoder last)."""
+        """Segments are reduced in the order their gradients complete (head first, encoder last).  With a
+        :class:`ParameterArena` use this (after ``no_sync(True)``) instead of the hook-driven buckets also in the eager
+        step: arena gradients are accumulated once per use of a parameter, so a per-parameter ready-hook would fire
+        before the last use has added its part."""
         self.finish_arena(arena, self.start_arena(arena, order), optimizer)
 
     def no_sync(self, flag: bool = True):

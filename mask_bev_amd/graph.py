@@ -25,7 +25,10 @@ the design: no kernel is changed, only how they are launched.
 
 Construct :class:`GraphedTrainStep` before running any eager backward of the module on the default stream (or run
 such eager code inside ``torch.cuda.stream(side)``): like PyTorch's whole-network capture, the warm-up iterations
-here run on a side stream because autograd state created on the legacy default stream cannot be captured.
+here run on a side stream because autograd state created on the legacy default stream cannot be captured.  Do not
+keep the loss (or anything else that holds the autograd graph) of an earlier eager step alive across the
+construction: its AccumulateGrad nodes stay bound to the stream they were created on and would accumulate outside
+the capture (PyTorch emits its "AccumulateGrad node's stream does not match" warning in that case).
 """
 from __future__ import annotations
 

@@ -206,17 +206,23 @@ class MultiheadAttention(nn.Module):
         self.attn = _AttnParams(embed_dims)
 
     def forward(self, query, key, value, query_pos=None, key_pos=None, blocked: Optional[torch.Tensor] = None,
-                add_identity: bool = True, defer_out_bias: bool = False):
+                add_identity: bool = True, defer_out_bias: bool = False, shared_kv=None):
         """query (B, Q, E), key/value (B, L, E); ``blocked`` (B, 1|H, Q, L) bool, True = may NOT attend.
-        ``add_identity=False`` returns the attention branch alone (residual add fused into the next LayerNorm)."""
+        ``add_identity=False`` returns the attention branch alone (residual add fused into the next LayerNorm).
+        ``shared_kv`` = (holder, token, slot): keys / values were projected for this layer by
+        ``ops.shared_kv_project`` together with the other layers of the same memory (key / value are ignored)."""
         e, h = self.embed_dims, self.num_heads
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
         q = query + query_pos if query_pos is not None else query
-        k = key + key_pos if key_pos is not None else key
         q = ops.linear(q, w, bias, rows=(0, e))
-        k = ops.linear(k, w, bias, rows=(e, 2 * e))
-        v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
-        o = ops.attention(q, k, v, blocked, h)                     # K6: heads split by addressing, mask per query
+        if shared_kv is not None:
+            holder, token, slot = shared_kv
+            o = ops.attention_shared_kv(q, token, blocked, h, holder, slot)
+        else:
+            k = key + key_pos if key_pos is not None else key
+            k = ops.linear(k, w, bias, rows=(e, 2 * e))
+            v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
+            o = ops.attention(q, k, v, blocked, h)                 # K6: heads split by addressing, mask per query
         o = self.attn.out_proj(o, skip_bias_grad=defer_out_bias and not add_identity)
         return query + o if add_identity else o
 

@@ -142,10 +142,12 @@ class _DecoderLayer(nn.Module):
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
         self.norms = nn.ModuleList([LayerNorm(embed_dims) for _ in range(3)])
 
-    def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None):
+    def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None, shared_kv=None):
         """``memory_key`` = memory + memory_pos when the caller has it (it is the same for every layer that reads
-        this level)."""
-        if memory_key is None:
+        this level); ``shared_kv``: this layer's slot of the level's batched key / value projection."""
+        if shared_kv is not None:
+            r = self.cross_attn(query, None, None, query_pos, None, blocked, add_identity=False, shared_kv=shared_kv)
+        elif memory_key is None:
             r = self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked, add_identity=False)
         else:
             r = self.cross_attn(query, memory_key, memory, query_pos, None, blocked, add_identity=False)
@@ -383,9 +385,22 @@ class Mask2FormerHead(nn.Module):
         cls_list.append(cls_pred)
         mask_list.append(mask_pred)
         nl = self.num_transformer_feat_level
-        for i, layer in enumerate(self.transformer_decoder.layers):
+        # the three layers that read a memory level share ONE key and ONE value GEMM (and one data-gradient GEMM each
+        # in backward): ops.SharedKV
+        layers = self.transformer_decoder.layers
+        shared = [None] * len(layers)
+        if (ops.shared_kv_supported(self.num_queries, mask_features.device)
+                and os.environ.get('MBV_SHARED_KV', '1') != '0'):
+            for lvl in range(nl):
+                idx = [i for i in range(len(layers)) if i % nl == lvl]
+                holder, token = ops.shared_kv_project(
+                    dec_key[lvl], dec_in[lvl],
+                    [(layers[i].cross_attn.attn.in_proj_weight, layers[i].cross_attn.attn.in_proj_bias) for i in idx])
+                for slot, i in enumerate(idx):
+                    shared[i] = (holder, token, slot)
+        for i, layer in enumerate(layers):
             lvl = i % nl
-            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl])
+            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl], shared[i])
             feats_q.append(query_feat)
             cls_pred, mask_pred, blocked = heads(query_feat, memories[(i + 1) % nl].shape[-2:],
                                                  None if stack is None else stack[i + 1])

@@ -785,6 +785,168 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, blocked: Option
     return _Attention.apply(q, k, v, blocked, num_heads)
 
 
+class SharedKV:
+    """Key / value projections of ONE memory level for the n decoder layers that attend to it (layers l, l+3, l+6 of
+    the Mask2Former decoder read the same level, mask2former_head.py:535-560), written side by side by one GEMM each:
+    ``k_cat`` / ``v_cat`` (B, L, n*E).  Layer slot j reads columns [j*E, (j+1)*E) in place (K6 with a row stride)
+    and its backward writes its dK / dV into the same columns of ``dk_cat`` / ``dv_cat``, so that the gradient of the
+    memory is ONE data-gradient GEMM per operand with no accumulation passes.  Plain Python object: autograd sees
+    only the scalar ``token`` that orders the backward."""
+
+    def __init__(self):
+        self.k_cat = self.v_cat = self.dk_cat = self.dv_cat = None
+        self.n = self.e = 0
+        self.written = set()
+
+
+class _SharedKVProject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, key_in, val_in, *wb):
+        n = len(wb) // 2
+        e = key_in.shape[-1]
+        dt = key_in.dtype
+        ws, bs = wb[0::2], wb[1::2]
+        wk = torch.cat([_compute_copy(w, dt)[e:2 * e] for w in ws], 0)           # (n*E, E)
+        wv = torch.cat([_compute_copy(w, dt)[2 * e:3 * e] for w in ws], 0)
+        bk = torch.cat([_compute_copy(b_, dt)[e:2 * e] for b_ in bs], 0)
+        bv = torch.cat([_compute_copy(b_, dt)[2 * e:3 * e] for b_ in bs], 0)
+        with torch.autocast('cuda', enabled=False):
+            holder.k_cat = torch.nn.functional.linear(key_in, wk, bk)
+            holder.v_cat = torch.nn.functional.linear(val_in.to(dt), wv, bv)
+        holder.n, holder.e = n, e
+        holder.dk_cat = holder.dv_cat = None
+        holder.written = set()
+        ctx.holder, ctx.params, ctx.n, ctx.e = holder, wb, n, e
+        ctx.save_for_backward(key_in, val_in, wk, wv)
+        return key_in.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _g_token):
+        holder, n, e = ctx.holder, ctx.n, ctx.e
+        key_in, val_in, wk, wv = ctx.saved_tensors
+        dk, dv = holder.dk_cat, holder.dv_cat
+        holder.k_cat = holder.v_cat = holder.dk_cat = holder.dv_cat = None
+        grads = [None] * (3 + 2 * n)
+        if dk is None:                                   # no layer attended to this level
+            return tuple(grads)
+        for j in range(n):                               # a slot whose layer did not run contributes nothing
+            if j not in holder.written:
+                dk[..., j * e:(j + 1) * e].zero_()
+                dv[..., j * e:(j + 1) * e].zero_()
+        t = key_in.numel() // e
+        dk2, dv2 = dk.view(t, n * e), dv.view(t, n * e)
+        key2, val2 = key_in.reshape(t, e), val_in.reshape(t, e).to(dk.dtype)
+        if ctx.needs_input_grad[1]:
+            grads[1] = dk2.mm(wk).view_as(key_in)
+        if ctx.needs_input_grad[2]:
+            grads[2] = dv2.mm(wv).view_as(val_in).to(val_in.dtype)
+        # weight / bias gradients of all n layers: one f32-accumulating GEMM and one column-sum pass per operand ...
+        gw = torch.zeros((2, n * e, e), dtype=torch.float32, device=dk.device)
+        gb = torch.zeros((2, n * e), dtype=torch.float32, device=dk.device)
+        _wgrad_into(gw[0], dk2, key2)
+        _wgrad_into(gw[1], dv2, val2)
+        colsum_accum(dk2, gb[0])
+        colsum_accum(dv2, gb[1])
+        # ... then added to the k / v rows of each layer's packed in_proj parameters in one multi-tensor launch
+        dst, src = [], []
+        for j in range(n):
+            w, b_ = ctx.params[2 * j], ctx.params[2 * j + 1]
+            rows = slice(j * e, (j + 1) * e)
+            for p, g, slot in ((w, gw, 3 + 2 * j), (b_, gb, 4 + 2 * j)):
+                if not ctx.needs_input_grad[slot]:
+                    continue
+                if getattr(p, '_mbv_arena', False) and p.grad is not None and p.grad.dtype == torch.float32:
+                    dst += [p.grad[e:2 * e], p.grad[2 * e:3 * e]]
+                    src += [g[0][rows], g[1][rows]]
+                else:
+                    full = torch.zeros_like(p)
+                    full[e:2 * e] = g[0][rows]
+                    full[2 * e:3 * e] = g[1][rows]
+                    grads[slot] = full
+        if dst:
+            torch._foreach_add_(dst, src)
+            for j in range(n):
+                _fire_grad_hooks(ctx.params[2 * j])
+                _fire_grad_hooks(ctx.params[2 * j + 1])
+        return tuple(grads)
+
+
+def shared_kv_project(key_in: torch.Tensor, val_in: torch.Tensor, packed_params) -> tuple:
+    """``packed_params``: [(in_proj_weight (3E, E), in_proj_bias (3E,)), ...] of the layers that attend to this memory.
+    Returns (holder, token) for :func:`attention_shared_kv`."""
+    holder = SharedKV()
+    flat = [t for wb in packed_params for t in wb]
+    token = _SharedKVProject.apply(holder, key_in, val_in, *flat)
+    return holder, token
+
+
+def shared_kv_supported(num_queries: int, device) -> bool:
+    """Strided key / value gradients are plain row stores: one 128-query super-block (K6)."""
+    return device.type == 'cuda' and num_queries <= 128
+
+
+class _AttentionSharedKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, token, blocked, num_heads, holder, slot):
+        lib = _lib.load()
+        k_cat, v_cat = holder.k_cat, holder.v_cat
+        _need_gpu(q, k_cat, v_cat, blocked)
+        dt = k_cat.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError(f'attention supports f32 and bf16, got {dt}')
+        ctx.q_dtype = q.dtype
+        q = q.to(dt).contiguous()
+        b, nq, e = q.shape
+        nl = k_cat.shape[1]
+        d = e // num_heads
+        ld = holder.n * e
+        off = slot * e * k_cat.element_size()
+        mask = None
+        if blocked is not None:
+            mask = blocked.reshape(b, nq, nl).contiguous()
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        out = torch.empty_like(q)
+        lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
+        ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
+        rc = lib.mbv_attn_fwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
+                                 ld, _ptr(mask), 1 if dt == torch.bfloat16 else 0, b, nq, nl, num_heads, d, _ptr(out),
+                                 _ptr(lse), _ptr(ws), ws.numel(), _stream())
+        check(rc, 'mbv_attn_fwd_ld')
+        ctx.save_for_backward(q, mask, out, lse)
+        ctx.holder, ctx.slot, ctx.num_heads = holder, slot, num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        q, mask, out, lse = ctx.saved_tensors
+        holder, slot, h = ctx.holder, ctx.slot, ctx.num_heads
+        k_cat, v_cat = holder.k_cat, holder.v_cat
+        b, nq, e = q.shape
+        nl = k_cat.shape[1]
+        ld = holder.n * e
+        if holder.dk_cat is None:                         # first of the n layers to run backward allocates
+            holder.dk_cat = torch.empty_like(k_cat)
+            holder.dv_cat = torch.empty_like(v_cat)
+        off = slot * e * k_cat.element_size()
+        grad_out = grad_out.to(q.dtype).contiguous()
+        g_q = torch.empty((b, nq, e), dtype=torch.float32, device=q.device)
+        bf = q.dtype == torch.bfloat16
+        rc = lib.mbv_attn_bwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
+                                 ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), 1 if bf else 0, b, nq, nl, h,
+                                 e // h, _ptr(g_q), ctypes.c_void_p(holder.dk_cat.data_ptr() + off),
+                                 ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ld, 1 if bf else 0, _stream())
+        check(rc, 'mbv_attn_bwd_ld')
+        holder.written.add(slot)
+        return g_q.to(ctx.q_dtype), None, None, None, None, None
+
+
+def attention_shared_kv(q: torch.Tensor, token: torch.Tensor, blocked: Optional[torch.Tensor], num_heads: int,
+                        holder: SharedKV, slot: int) -> torch.Tensor:
+    """:func:`attention` against slot ``slot`` of a :class:`SharedKV` (keys / values already projected)."""
+    return _AttentionSharedKV.apply(q, token, blocked, num_heads, holder, slot)
+
+
 # --------------------------------------------------------------------------------------
 # K7 per-query mask logits + attention mask of the next decoder layer
 # --------------------------------------------------------------------------------------

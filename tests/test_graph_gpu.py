@@ -42,6 +42,9 @@ def test_graph_replay_matches_eager(device):
     with torch.cuda.stream(side):
         loss_e = m.training_step(batches[1], 0)
         loss_e.backward()
+        # drop the eager autograd graph: AccumulateGrad nodes it keeps alive are bound to this side stream and would
+        # run their accumulations outside the capture (PyTorch warns about exactly this)
+        loss_e = loss_e.detach()
         g_eager, g_enc_eager = _flat_grads(graph_params).clone(), _flat_grads(enc_params).clone()
         m.zero_grad(set_to_none=True)
     torch.cuda.current_stream().wait_stream(side)

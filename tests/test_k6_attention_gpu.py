@@ -54,3 +54,55 @@ def test_attention_fwd_bwd(device, B, Q, L, heads, D, masked, dtype):
     torch.testing.assert_close(qd.grad.float().cpu(), qr.grad, **gtol)
     torch.testing.assert_close(kd.grad.float().cpu(), kr.grad, **gtol)
     torch.testing.assert_close(vd.grad.float().cpu(), vr.grad, **gtol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_shared_kv_attention_equals_separate_projections(device, dt):
+    """ops.shared_kv_project + attention_shared_kv (one key GEMM and one value GEMM for three layers, K6 reading and
+    writing columns of the shared matrices in place) vs three independent linear → attention chains: outputs and the
+    gradients of the memory, the queries and the packed in_proj parameters."""
+    from mask_bev_amd import ops
+    torch.manual_seed(11)
+    B, Q, L, E, H, n = 2, 100, 300, 64, 4, 3
+    key_in = torch.randn(B, L, E, device=device).to(dt)
+    val_in = torch.randn(B, L, E, device=device).to(dt)
+    ws = [(0.2 * torch.randn(3 * E, E, device=device)).requires_grad_() for _ in range(n)]
+    bs = [(0.1 * torch.randn(3 * E, device=device)).requires_grad_() for _ in range(n)]
+    qs = [torch.randn(B, Q, E, device=device) for _ in range(n)]
+    blocked = torch.rand(B, 1, Q, L, device=device) > 0.7
+    blocked[:, :, :, 0] = False
+    gos = [torch.randn(B, Q, E, device=device) for _ in range(n)]
+
+    def run(shared):
+        k_in, v_in = key_in.clone().requires_grad_(), val_in.clone().requires_grad_()
+        q_l = [q.clone().requires_grad_() for q in qs]
+        for p in ws + bs:
+            p.grad = None
+        outs = []
+        if shared:
+            holder, token = ops.shared_kv_project(k_in, v_in, list(zip(ws, bs)))
+            for j in range(n):
+                outs.append(ops.attention_shared_kv(q_l[j], token, blocked, H, holder, j))
+        else:
+            for j in range(n):
+                k = torch.nn.functional.linear(k_in, ws[j][E:2 * E].to(dt), bs[j][E:2 * E].to(dt))
+                v = torch.nn.functional.linear(v_in, ws[j][2 * E:].to(dt), bs[j][2 * E:].to(dt))
+                outs.append(ops.attention(q_l[j], k, v, blocked, H))
+        torch.autograd.backward(outs, [g.to(o.dtype) for g, o in zip(gos, outs)])
+        return ([o.detach().float() for o in outs], k_in.grad.float(), v_in.grad.float(), [q.grad.float() for q in q_l],
+                [w.grad.clone() for w in ws], [b.grad.clone() for b in bs])
+
+    a, b = run(True), run(False)
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    for x, y in zip(a[0], b[0]):
+        torch.testing.assert_close(x, y, **tol)
+    for idx in (1, 2):
+        scale = float(b[idx].abs().max())
+        torch.testing.assert_close(a[idx] / scale, b[idx] / scale, **tol)
+    for idx in (3, 4, 5):
+        for x, y in zip(a[idx], b[idx]):
+            scale = float(y.abs().max()) + 1e-12
+            torch.testing.assert_close(x / scale, y / scale, **tol)
+    # the q rows of the packed parameters receive nothing from this path
+    assert all(float(w[:E].abs().max()) == 0.0 for w in a[4])
