@@ -227,3 +227,43 @@ def test_patch_embed_tokens_equal_conv(device):
         torch.testing.assert_close(gt, p.grad, rtol=2e-2, atol=2e-2 * float(p.grad.abs().max()), msg=lambda m: f'{n}: {m}')
     g_img = ops.PatchTokens(g_rows, C, 4).to_image()
     torch.testing.assert_close(g_img.float(), img_r.grad.float(), rtol=2e-2, atol=2e-2 * float(img_r.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_scatter_layernorm_full_size_properties(device):
+    """K3 at the bench size (B 4, C 128, 512 x 512, 120 k-point scans): size-independent properties instead of a dense
+    oracle — per-scan statistics of the un-affined output, the closed form of every empty cell, and agreement of
+    the bf16 patch rows with the f32 image."""
+    from mask_bev_amd import ops
+    cfg = _cfg(nx=512, ny=512, vs=0.15625, P=32, C=128)
+    scans = _scans(cfg, [120000, 120000, 90000, 120000], seed=3, spread=1.0)
+    pil = ops.voxelize([s.to(device) for s in scans], _geom(cfg), cfg.max_num_points, cfg.max_voxels)
+    B, C, ny, nx = 4, 128, 512, 512
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(pil.num_pillars, C, generator=g).to(device)
+    w = torch.ones(C, ny, nx, device=device)
+    b = torch.zeros(C, ny, nx, device=device)
+    out = ops.scatter_layernorm(feats, w, b, pil, B, ny, nx, 1e-3)                     # identity affine: x-hat itself
+    flat = out.view(B, -1).double()
+    assert float(flat.mean(1).abs().max()) < 1e-4
+    # eps = 1e-3 inside the rsqrt: var(out) = v / (v + eps) with v the variance of the scattered canvas, which is
+    # known from the pillar rows alone (every empty cell is 0)
+    starts = pil.pillar_batch_start.cpu().tolist()
+    for s in range(B):
+        rows = feats[starts[s]:starts[s + 1]].double()
+        n_el = C * ny * nx
+        mean = float(rows.sum()) / n_el
+        v = float((rows * rows).sum()) / n_el - mean * mean
+        assert abs(float(flat[s].var(unbiased=False)) - v / (v + 1e-3)) < 1e-5
+    # every empty cell holds the same value per scan: (0 - mean) * rstd
+    occ = (pil.cell_to_pillar.view(B, ny, nx) >= 0)
+    for s in range(B):
+        empty = out[s][:, ~occ[s]]
+        assert float(empty.max() - empty.min()) == 0.0
+    # affine + patch rows: equal to the bf16 rounding of the f32 image of the same kernel family
+    w2 = 1 + 0.1 * torch.randn(C, ny, nx, generator=g).to(device)
+    b2 = 0.1 * torch.randn(C, ny, nx, generator=g).to(device)
+    img = ops.scatter_layernorm(feats, w2, b2, pil, B, ny, nx, 1e-3)
+    tok = ops.scatter_layernorm(feats, w2, b2, pil, B, ny, nx, 1e-3, patch=4)
+    assert torch.equal(tok.to_image(), img.bfloat16())
+    torch.testing.assert_close(img, out * w2 + b2, rtol=1e-5, atol=1e-5)

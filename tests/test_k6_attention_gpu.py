@@ -106,3 +106,37 @@ def test_shared_kv_attention_equals_separate_projections(device, dt):
             torch.testing.assert_close(x / scale, y / scale, **tol)
     # the q rows of the packed parameters receive nothing from this path
     assert all(float(w[:E].abs().max()) == 0.0 for w in a[4])
+
+
+@pytest.mark.gpu
+def test_shared_kv_attention_bench_shape_bf16(device):
+    """The bench's level-0 cross-attention (B 4, Q 100, L 16 384, E 256, 8 heads, bf16): slot reads / slot-wise bf16
+    gradient stores of the shared key / value matrices vs the contiguous path, on the same projected values."""
+    from mask_bev_amd import ops
+    torch.manual_seed(5)
+    B, Q, L, E, H, n = 4, 100, 16384, 256, 8, 3
+    k_cat = torch.randn(B, L, n * E, device=device).bfloat16()
+    v_cat = torch.randn(B, L, n * E, device=device).bfloat16()
+    blocked = torch.rand(B, 1, Q, L, device=device) > 0.5
+    blocked[..., :4] = False
+    holder = ops.SharedKV()
+    holder.k_cat, holder.v_cat, holder.n, holder.e = k_cat, v_cat, n, E
+    token = torch.zeros((), device=device, requires_grad=True)
+    for slot in (0, 2):
+        q = torch.randn(B, Q, E, device=device, requires_grad=True)
+        go = torch.randn(B, Q, E, device=device)
+        out = ops.attention_shared_kv(q, token, blocked, H, holder, slot)
+        out.backward(go.to(out.dtype))
+        k = k_cat[..., slot * E:(slot + 1) * E].contiguous().requires_grad_()
+        v = v_cat[..., slot * E:(slot + 1) * E].contiguous().requires_grad_()
+        q2 = q.detach().clone().requires_grad_()
+        ref = ops.attention(q2, k, v, blocked, H)
+        ref.backward(go.to(ref.dtype))
+        assert torch.equal(out, ref)                                   # same kernel, same values: bit-identical
+        torch.testing.assert_close(q.grad, q2.grad, rtol=1e-4, atol=1e-6)   # split-L partial sums meet in f32 atomics
+        dk = holder.dk_cat[..., slot * E:(slot + 1) * E].float()
+        dv = holder.dv_cat[..., slot * E:(slot + 1) * E].float()
+        assert torch.equal(dk, k.grad.float().bfloat16().float())      # the f32 gradient rounded to bf16 once
+        assert torch.equal(dv, v.grad.float().bfloat16().float())
+    # the untouched slot of the shared gradient matrices was never written by slots 0 and 2
+    assert holder.written == {0, 2}
