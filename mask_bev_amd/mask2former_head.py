@@ -7,6 +7,7 @@ mask_bev/models/head/mask_bev_panoptic_head.py:98-215.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -72,6 +73,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.mask_feature = nn.Conv2d(feat_channels, out_channels, kernel_size=1)
         self.num_outs = num_outs
         self._geom_cache: Dict[Tuple, Tuple] = {}
+        self._tail_streams: Dict = {}
 
     def init_weights(self):
         for m in self.input_convs:
@@ -122,11 +124,35 @@ class MSDeformAttnPixelDecoder(nn.Module):
             q = layer(q, qpos, ref, shapes, shapes_t, level_start)
         outs = [t.transpose(1, 2).reshape(bs, -1, h, w) for t, (h, w) in
                 zip(torch.split(q, [h * w for h, w in shapes], dim=1), shapes)]
-        for j, i in enumerate(range(n - nl - 1, -1, -1)):
-            cur = self.lateral_convs[j](feats[i])
-            y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
-            outs.append(self.output_convs[j](y))
-        return self.mask_feature(outs[-1]), outs[:self.num_outs]
+        # The FPN tail (lateral / output convolutions, mask-feature projection) runs on a second stream and is joined
+        # at once.  Forward gains nothing from it; BACKWARD does: autograd replays a node on the stream its forward ran
+        # on, so the tail's backward — which needs only d(mask_features), the first gradient the head produces — becomes
+        # a parallel branch underneath the decoder layers' backward (400-row kernels that leave the chip idle).
+        side = self._tail_stream(feats[0].device)
+        if side is not None:
+            main = torch.cuda.current_stream(feats[0].device)
+            side.wait_stream(main)
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            tail = list(outs)
+            for j, i in enumerate(range(n - nl - 1, -1, -1)):
+                cur = self.lateral_convs[j](feats[i])
+                y = cur + F.interpolate(tail[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
+                tail.append(self.output_convs[j](y))
+            mask_feature = self.mask_feature(tail[-1])
+        if side is not None:
+            main.wait_stream(side)
+        return mask_feature, tail[:self.num_outs]
+
+    def _tail_stream(self, device):
+        if device.type != 'cuda' or not torch.is_grad_enabled() or os.environ.get('MBV_TAIL_STREAM', '1') == '0':
+            return None
+        st = self._tail_streams.get(device)
+        if st is None:
+            st = self._tail_streams[device] = torch.cuda.Stream(device=device)
+        return st
 
 
 # --------------------------------------------------------------------------------------
