@@ -205,6 +205,13 @@ int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_attn, const fl
                          int32_t num_levels, int32_t num_points, int32_t out_bf16, void* grad_offsets,
                          void* grad_logits, void* stream);
 
+/* Same with (batch, query) row strides for the two outputs (elements): they can then be columns of one wider gradient
+ * matrix — next to the gradient of the value projection — that a single data-gradient GEMM consumes. */
+int mbv_msda_prepare_bwd_ld(const float* grad_loc, const float* grad_attn, const float* attn,
+                            const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
+                            int32_t num_levels, int32_t num_points, int32_t out_bf16, void* grad_offsets,
+                            int64_t ld_offsets, void* grad_logits, int64_t ld_logits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4 — fused shifted-window multi-head attention (between the qkv and the output projection).
  * Replaces: ShiftWindowMSA.forward (mask_bev/models/networks/swin/swin.py:179-253: pad, roll, window

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 class MaskBevHipError(RuntimeError):
@@ -46,6 +46,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
     'mbv_msda_prepare_fwd': (ctypes.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_msda_prepare_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'mbv_msda_prepare_bwd_ld': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),

@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(256) k_msda_prepare_bwd(const float* __restric
                                                           const float* __restrict__ g_attn,
                                                           const float* __restrict__ attn, Norm nrm, long rows,
                                                           int levels, int points, T* __restrict__ g_off,
-                                                          T* __restrict__ g_logit) {
+                                                          T* __restrict__ g_logit, int heads, long ld_off,
+                                                          long ld_logit) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const int lp = levels * points;
@@ -171,8 +172,11 @@ __global__ void __launch_bounds__(256) k_msda_prepare_bwd(const float* __restric
   }
 #pragma unroll
   for (int k = 0; k < kMaxLP; ++k) dot += a[k] * g[k];
-  T* go = g_off + i * lp * 2;
-  T* gq = g_logit + i * lp;
+  // (batch, query) row strides: the two gradients may be columns of one wider matrix; the heads stay packed in a row
+  const long bn = i / heads;
+  const int hh = (int)(i - bn * heads);
+  T* go = g_off + bn * ld_off + (long)hh * lp * 2;
+  T* gq = g_logit + bn * ld_logit + (long)hh * lp;
   if (vec) {
 #pragma unroll
     for (int k = 0; k < kMaxLP; k += 4) {
@@ -247,11 +251,15 @@ extern "C" int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int
   return MBV_OK;
 }
 
-extern "C" int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
-                                    const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query,
-                                    int32_t num_heads, int32_t num_levels, int32_t num_points, int32_t out_bf16,
-                                    void* grad_offsets, void* grad_logits, void* stream) {
+extern "C" int mbv_msda_prepare_bwd_ld(const float* grad_loc, const float* grad_attn, const float* attn,
+                                       const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query,
+                                       int32_t num_heads, int32_t num_levels, int32_t num_points, int32_t out_bf16,
+                                       void* grad_offsets, int64_t ld_offsets, void* grad_logits, int64_t ld_logits,
+                                       void* stream) {
   if (batch <= 0 || num_query <= 0 || num_heads <= 0) return MBV_ERR_BAD_ARG;
+  // row strides are given per (batch, query) row of H*L*P*2 / H*L*P elements; inside a row the heads stay packed
+  if (ld_offsets < (int64_t)num_heads * num_levels * num_points * 2 || ld_logits < (int64_t)num_heads * num_levels * num_points)
+    return MBV_ERR_BAD_ARG;
   if (!mbv_msda_prepare_supported(num_levels, num_points)) return MBV_ERR_UNSUPPORTED;
   if (!grad_loc || !grad_attn || !attn || !grad_offsets || !grad_logits) return MBV_ERR_BAD_ARG;
   Norm n;
@@ -261,11 +269,21 @@ extern "C" int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_att
   if (out_bf16)
     hipLaunchKernelGGL(k_msda_prepare_bwd<unsigned short>, grid, block, 0, (hipStream_t)stream, grad_loc, grad_attn,
                        attn, n, rows, num_levels, num_points, reinterpret_cast<unsigned short*>(grad_offsets),
-                       reinterpret_cast<unsigned short*>(grad_logits));
+                       reinterpret_cast<unsigned short*>(grad_logits), num_heads, (long)ld_offsets, (long)ld_logits);
   else
     hipLaunchKernelGGL(k_msda_prepare_bwd<float>, grid, block, 0, (hipStream_t)stream, grad_loc, grad_attn, attn, n,
                        rows, num_levels, num_points, reinterpret_cast<float*>(grad_offsets),
-                       reinterpret_cast<float*>(grad_logits));
+                       reinterpret_cast<float*>(grad_logits), num_heads, (long)ld_offsets, (long)ld_logits);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
+}
+
+extern "C" int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
+                                    const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query,
+                                    int32_t num_heads, int32_t num_levels, int32_t num_points, int32_t out_bf16,
+                                    void* grad_offsets, void* grad_logits, void* stream) {
+  const int64_t lp = (int64_t)num_levels * num_points;
+  return mbv_msda_prepare_bwd_ld(grad_loc, grad_attn, attn, spatial_shapes_host, batch, num_query, num_heads,
+                                 num_levels, num_points, out_bf16, grad_offsets, num_heads * lp * 2, grad_logits,
+                                 num_heads * lp, stream);
 }

@@ -338,7 +338,7 @@ extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, in
   if (rows < 0 || n <= 0 || !g || !out) return MBV_ERR_BAD_ARG;
   if (rows == 0) return MBV_OK;
   int W = 1;
-  while (W < 256 && W * 4 < n) W <<= 1;
+  while (W < 64 && W * 4 < n) W <<= 1;          // a wave per 256 columns: wide matrices get column blocks (gridDim.x), not idle lanes
   const int rpi = 256 / W;
   const unsigned gx = (unsigned)((n + W * 4 - 1) / (W * 4));
   // ≈ 2 blocks per CU, at most 64 row slices per column, at least 8 iterations per block

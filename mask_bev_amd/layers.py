@@ -7,6 +7,7 @@ are organised around channels-last (B, H, W, C) token maps, which is what the gf
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -264,6 +265,13 @@ class MultiScaleDeformableAttention(nn.Module):
         """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y)."""
         b, n, e = query.shape
         h, l, p = self.num_heads, self.num_levels, self.num_points
+        if (spatial_shapes is not None and query.is_cuda and query.dtype == torch.float32
+                and query_pos.shape[0] == 1 and sum(hh * ww for hh, ww in spatial_shapes) == n
+                and ops.msda_prepare_supported(l, p) and os.environ.get('MBV_MSDA_FUSED', '1') != '0'):
+            out = ops.msda_query_side(query, query_pos, reference_points, self.value_proj, self.sampling_offsets,
+                                      self.attention_weights, h, l, p, spatial_shapes, shapes_t, level_start)
+            out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)
+            return out + query if add_identity else out
         q = query + query_pos
         if torch.is_autocast_enabled('cuda') and q.is_cuda:
             q = q.to(torch.get_autocast_dtype('cuda'))       # one cast for both projections of q

@@ -557,6 +557,128 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, 
                                attention_weights.float(), host)
 
 
+class _MSDAQuerySide(torch.autograd.Function):
+    """The query side of the pixel decoder's deformable self-attention as ONE autograd node:
+
+        value = value_proj(x);  q = x + pos;  off = sampling_offsets(q);  logits = attention_weights(q)
+        loc, attn = K16(off, logits);  out = K5(value, loc, attn)                      (before output_proj)
+
+    Forward is the same sequence of launches as the composed ops.  Backward assembles the gradients of the three
+    projections side by side in one (B*N, E + 2HLP + HLP) matrix G — K5's value gradient cast into the first E columns,
+    K16's backward writing the other two blocks in place (row strides) — so that d(x) is ONE data-gradient GEMM
+    G · [Wv; Wo; Wa] with no casts or accumulation passes, the bias gradients one column-sum pass, and d(pos) a
+    batch-sum of the offset / weight columns times [Wo; Wa].  mmcv MultiScaleDeformableAttention.forward
+    (mask_bev_panoptic_head.py:127-136); replaces 3 GEMMs + 3 column sums + 9 element-wise launches per layer."""
+
+    @staticmethod
+    def forward(ctx, x, pos, ref, wv, bv, wo, bo, wa, ba, heads, levels, points, shapes_host, shapes_t, level_start):
+        lib = _lib.load()
+        _need_gpu(x, pos, ref, wv, wo, wa)
+        b, n, e = x.shape
+        d = e // heads
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise MaskBevHipError('msda_query_side supports f32 and bf16 compute')
+        with torch.autocast('cuda', enabled=False):
+            xb = x.to(dt)
+            qb = (x + pos).to(dt)
+            wvc, woc, wac = _compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)
+            value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
+            off = torch.nn.functional.linear(qb, woc, _compute_copy(bo, dt)).contiguous()
+            logit = torch.nn.functional.linear(qb, wac, _compute_copy(ba, dt)).contiguous()
+        host = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
+        ref32 = ref.to(torch.float32).contiguous()
+        loc = torch.empty((b, n, heads, levels, points, 2), dtype=torch.float32, device=x.device)
+        attn = torch.empty((b, n, heads, levels, points), dtype=torch.float32, device=x.device)
+        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logit), 1 if dt == torch.bfloat16 else 0, _ptr(ref32), host, b, n,
+                                       heads, levels, points, _ptr(loc), _ptr(attn), _stream()), 'mbv_msda_prepare_fwd')
+        out = torch.empty((b, n, e), dtype=torch.float32, device=x.device)
+        check(lib.mbv_ms_deform_attn_fwd(_ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, n,
+                                         heads, d, levels, n, points, _ptr(out), _stream()), 'mbv_ms_deform_attn_fwd')
+        ctx.save_for_backward(xb, qb, value, loc, attn, shapes_t, level_start, wvc, woc, wac)
+        ctx.params = (wv, bv, wo, bo, wa, ba)
+        ctx.meta = (heads, levels, points, host, tuple(shapes_host), dt, x.dtype, pos.dtype, tuple(pos.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        xb, qb, value, loc, attn, shapes_t, level_start, wvc, woc, wac = ctx.saved_tensors
+        wv, bv, wo, bo, wa, ba = ctx.params
+        heads, levels, points, host, shapes_host, dt, x_dtype, pos_dtype, pos_shape = ctx.meta
+        b, n, e = xb.shape
+        d = e // heads
+        lo, la = heads * levels * points * 2, heads * levels * points
+        width = e + lo + la
+        t = b * n
+        dev = xb.device
+        g_out = g_out.to(torch.float32).contiguous()
+        g_value = torch.empty_like(value)
+        g_loc = torch.empty_like(loc)
+        g_attn = torch.empty_like(attn)
+        host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
+        check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn),
+                                         b, n, heads, d, levels, n, points, host_b, _ptr(g_value), _ptr(g_loc),
+                                         _ptr(g_attn), _stream()), 'mbv_ms_deform_attn_bwd')
+        g = torch.empty((t, width), dtype=dt, device=dev)                 # [d value | d offsets | d logits]
+        g[:, :e].copy_(g_value.view(t, e))
+        esz = g.element_size()
+        check(lib.mbv_msda_prepare_bwd_ld(_ptr(g_loc), _ptr(g_attn), _ptr(attn), host, b, n, heads, levels, points,
+                                          1 if dt == torch.bfloat16 else 0, ctypes.c_void_p(g.data_ptr() + e * esz), width,
+                                          ctypes.c_void_p(g.data_ptr() + (e + lo) * esz), width, _stream()),
+              'mbv_msda_prepare_bwd_ld')
+        wcat = torch.cat([wvc, woc, wac], 0)                              # (width, E)
+        od = {} if dt == torch.float32 else dict(out_dtype=torch.float32)
+        gx = gpos = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g, wcat, **od).view(b, n, e).to(x_dtype)
+        if ctx.needs_input_grad[1]:                                       # pos is broadcast over the batch
+            gq_sum = g.view(b, n, width)[:, :, e:].sum(0, dtype=torch.float32).to(dt)
+            gpos = torch.mm(gq_sum, wcat[e:], **od).view(1, n, e)
+            if tuple(pos_shape) != (1, n, e):
+                gpos = gpos.sum_to_size(pos_shape) if len(pos_shape) == 3 else gpos.reshape(pos_shape)
+            gpos = gpos.to(pos_dtype)
+        x2, q2 = xb.view(t, e), qb.view(t, e)
+        cols = ((0, e, x2), (e, e + lo, q2), (e + lo, width, q2))
+        grads = [None] * 6
+        bias_tmp = None
+        if any(ctx.needs_input_grad[4 + 2 * j] for j in range(3)):
+            bias_tmp = torch.zeros(width, dtype=torch.float32, device=dev)
+            colsum_accum(g, bias_tmp)
+        dst, src = [], []
+        for j, ((c0, c1, inp), w, bia) in enumerate(zip(cols, (wv, wo, wa), (bv, bo, ba))):
+            gj = g[:, c0:c1]                                              # column block: a GEMM operand with lda = width
+            if ctx.needs_input_grad[3 + 2 * j]:
+                if getattr(w, '_mbv_arena', False) and w.grad is not None and w.grad.dtype == torch.float32:
+                    _wgrad_into(w.grad, gj, inp)
+                    _fire_grad_hooks(w)
+                else:
+                    acc = torch.zeros(w.shape, dtype=torch.float32, device=dev)
+                    _wgrad_into(acc, gj, inp)
+                    grads[2 * j] = acc.to(w.dtype)
+            if ctx.needs_input_grad[4 + 2 * j]:
+                if getattr(bia, '_mbv_arena', False) and bia.grad is not None and bia.grad.dtype == torch.float32:
+                    dst.append(bia.grad)
+                    src.append(bias_tmp[c0:c1])
+                else:
+                    grads[2 * j + 1] = bias_tmp[c0:c1].to(bia.dtype)
+        if dst:
+            torch._foreach_add_(dst, src)
+            for bia in (bv, bo, ba):
+                _fire_grad_hooks(bia)
+        return (gx, gpos, None) + tuple(grads) + (None,) * 6
+
+
+def msda_query_side(x, pos, ref, value_proj, sampling_offsets, attention_weights, heads, levels, points, spatial_shapes,
+                    shapes_t, level_start):
+    """x (B, N, E) f32, pos (1, N, E) → the deformable-attention output (B, N, E) f32 before ``output_proj``; the three
+    ``nn.Linear`` modules supply the parameters (checkpoint keys unchanged).  See :class:`_MSDAQuerySide`."""
+    host = tuple((int(h), int(w)) for h, w in spatial_shapes)
+    return _MSDAQuerySide.apply(x, pos, ref, value_proj.weight, value_proj.bias, sampling_offsets.weight,
+                                sampling_offsets.bias, attention_weights.weight, attention_weights.bias, heads, levels,
+                                points, host, shapes_t, level_start)
+
+
 # --------------------------------------------------------------------------------------
 # Linear layers: library GEMMs, with a split-K weight gradient for token-major activations
 # --------------------------------------------------------------------------------------
