@@ -581,7 +581,8 @@ class _MSDAQuerySide(torch.autograd.Function):
             raise MaskBevHipError('msda_query_side supports f32 and bf16 compute')
         with torch.autocast('cuda', enabled=False):
             xb = x.to(dt)
-            qb = (x + pos).to(dt)
+            qb = torch.empty(x.shape, dtype=dt, device=x.device)
+            torch.add(x, pos, out=qb)                     # the sum, stored in the compute dtype by the same launch
             wvc, woc, wac = _compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)
             value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
             off = torch.nn.functional.linear(qb, woc, _compute_copy(bo, dt)).contiguous()
