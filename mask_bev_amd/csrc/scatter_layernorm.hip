@@ -91,6 +91,37 @@ __device__ __forceinline__ void gather_tile(const float* __restrict__ feats, int
   }
 }
 
+// the same gather in two halves: the loads of the NEXT scan's rows are issued before the current scan's outputs are
+// computed and stored, so that the (cell -> pillar id -> pillar row) chain of scan b+1 overlaps the store phase of b
+template <int VEC, int THREADS = 256>
+__device__ __forceinline__ void gather_load(const float* __restrict__ feats, int channels, int c0, int32_t pid,
+                                            float4 (&r)[Tile<VEC, THREADS>::CH_PER_THREAD / 4]) {
+  using T = Tile<VEC, THREADS>;
+  const int grp = threadIdx.x / T::XT;
+  const int cbeg = grp * T::CH_PER_THREAD;
+#pragma unroll
+  for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
+    const int c = c0 + cbeg + k;
+    r[k / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pid >= 0 && c < channels) r[k / 4] = *reinterpret_cast<const float4*>(feats + (int64_t)pid * channels + c);
+  }
+}
+template <int VEC, int THREADS = 256>
+__device__ __forceinline__ void gather_store(const float4 (&r)[Tile<VEC, THREADS>::CH_PER_THREAD / 4],
+                                             float* __restrict__ lds) {
+  using T = Tile<VEC, THREADS>;
+  const int cell = threadIdx.x % T::XT;
+  const int grp = threadIdx.x / T::XT;
+  const int cbeg = grp * T::CH_PER_THREAD;
+#pragma unroll
+  for (int k = 0; k < T::CH_PER_THREAD; k += 4) {
+    lds[(cbeg + k + 0) * T::LD + cell] = r[k / 4].x;
+    lds[(cbeg + k + 1) * T::LD + cell] = r[k / 4].y;
+    lds[(cbeg + k + 2) * T::LD + cell] = r[k / 4].z;
+    lds[(cbeg + k + 3) * T::LD + cell] = r[k / 4].w;
+  }
+}
+
 template <int VEC>
 struct VecT;
 template <>
@@ -155,65 +186,85 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
                                                   const float* __restrict__ stats, int batch, int channels, int ny,
                                                   int nx, int xtiles, void* __restrict__ out_) {
   using T = Tile<VEC>;
-  using M = Map<PATCH, 8>;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
   const int y = blockIdx.x / xtiles;
   const int x0 = (blockIdx.x % xtiles) * T::XT;
   const int c0 = blockIdx.y * kCT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t cells = (int64_t)ny * nx;
-  const int ch0 = M::chan0(wave, lane), cv = M::cell0(wave, lane, VEC);
-  const int xv = x0 + cv;                     // first x of this lane in the apply phase
-  const bool x_ok = xv < nx;                  // nx % VEC == 0 → the whole vector is in range
+  // apply-phase ownership.  NCHW: a wave owns 8 channels, a lane VEC consecutive cells of each (512 B per wave store).
+  // Patch rows: 16 lanes share a token, each owning a channel PAIR (2 x 4 cells = 8 bf16 = 16 B), in 4 token sets —
+  // one store instruction then writes whole 256-byte runs of 4 token rows (a lane owning 8 consecutive channels of
+  // one token wrote 16-byte pieces 64 bytes apart: the same bytes in four times the write transactions)
+  const int ch0 = PATCH ? 2 * (lane & 15) : wave * 8;
+  const int cv = PATCH ? 0 : lane * VEC;
+  const int tq = lane >> 4;
+  auto chan_of = [&](int k) { return PATCH ? ch0 + (k & 1) : ch0 + k; };
+  auto cell_of = [&](int k) { return PATCH ? (wave * 16 + (k >> 1) * 4 + tq) * 4 : cv; };
   // affine parameters: read once, reused for every scan of the batch
   float w[8][VEC], bz[8][VEC];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int c = c0 + ch0 + k;
+    const int c = c0 + chan_of(k);
+    const int xk = x0 + cell_of(k);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { w[k][e] = 0.f; bz[k][e] = 0.f; }
-    if (x_ok && c < channels) {
-      const int64_t o = ((int64_t)c * ny + y) * nx + xv;
+    if (xk < nx && c < channels) {             // nx % VEC == 0 → the whole vector is in range
+      const int64_t o = ((int64_t)c * ny + y) * nx + xk;
       load_vec<VEC>(weight + o, w[k]);
       load_vec<VEC>(bias + o, bz[k]);
     }
   }
   const int gcell = threadIdx.x % T::XT;
+  const bool g_ok = x0 + gcell < nx;
+  const int64_t cell_off = (int64_t)y * nx + x0 + gcell;
+  float4 rows[T::CH_PER_THREAD / 4];
+  {
+    const int32_t pid0 = g_ok ? cell_to_pillar[cell_off] : -1;
+    gather_load<VEC>(feats, channels, c0, pid0, rows);
+  }
+  int32_t pid_next = (g_ok && batch > 1) ? cell_to_pillar[cells + cell_off] : -1;
   for (int b = 0; b < batch; ++b) {
     const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
-    int32_t pid = -1;
-    if (x0 + gcell < nx) pid = cell_to_pillar[(int64_t)b * cells + (int64_t)y * nx + x0 + gcell];
-    gather_tile<VEC>(feats, channels, c0, pid, lds);
+    gather_store<VEC>(rows, lds);
     __syncthreads();
-    if (x_ok) {
+    if (b + 1 < batch) {                       // scan b+1: rows requested now, its successor's pillar id too
+      gather_load<VEC>(feats, channels, c0, pid_next, rows);
+      pid_next = (g_ok && b + 2 < batch) ? cell_to_pillar[(int64_t)(b + 2) * cells + cell_off] : -1;
+    }
+    {
       if constexpr (PATCH) {
-        // channels % kCT == 0 in this mode: 8 channels x 4 cells = 32 bf16 = 64 contiguous bytes per thread
-        unsigned short* orow = reinterpret_cast<unsigned short*>(out_) +
-                               patch_row_offset(b, channels, ny, nx, y, xv, c0 + ch0);
+        // channels % kCT == 0 in this mode; per token set: 2 channels x 4 cells = 8 bf16 = one 16-byte store
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-          float f0[VEC], f1[VEC];
-          load_vec<VEC>(&lds[(ch0 + k) * T::LD + cv], f0);
-          load_vec<VEC>(&lds[(ch0 + k + 1) * T::LD + cv], f1);
-          unsigned u[4];
+          const int cj = cell_of(k), xj = x0 + cj;
+          if (xj < nx) {
+            float f0[VEC], f1[VEC];
+            load_vec<VEC>(&lds[ch0 * T::LD + cj], f0);
+            load_vec<VEC>(&lds[(ch0 + 1) * T::LD + cj], f1);
+            unsigned u[4];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float a0 = (f0[2 * e] - mean) * rstd * w[k][2 * e] + bz[k][2 * e];
-            const float a1 = (f0[2 * e + 1] - mean) * rstd * w[k][2 * e + 1] + bz[k][2 * e + 1];
-            const float b0 = (f1[2 * e] - mean) * rstd * w[k + 1][2 * e] + bz[k + 1][2 * e];
-            const float b1 = (f1[2 * e + 1] - mean) * rstd * w[k + 1][2 * e + 1] + bz[k + 1][2 * e + 1];
-            u[e] = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
-            u[2 + e] = (unsigned)f32_to_bf16_rne(b0) | ((unsigned)f32_to_bf16_rne(b1) << 16);
+            for (int e = 0; e < 2; ++e) {
+              const float a0 = (f0[2 * e] - mean) * rstd * w[k][2 * e] + bz[k][2 * e];
+              const float a1 = (f0[2 * e + 1] - mean) * rstd * w[k][2 * e + 1] + bz[k][2 * e + 1];
+              const float b0 = (f1[2 * e] - mean) * rstd * w[k + 1][2 * e] + bz[k + 1][2 * e];
+              const float b1 = (f1[2 * e + 1] - mean) * rstd * w[k + 1][2 * e + 1] + bz[k + 1][2 * e + 1];
+              u[e] = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
+              u[2 + e] = (unsigned)f32_to_bf16_rne(b0) | ((unsigned)f32_to_bf16_rne(b1) << 16);
+            }
+            unsigned short* orow = reinterpret_cast<unsigned short*>(out_) +
+                                   patch_row_offset(b, channels, ny, nx, y, xj, c0 + ch0);
+            *reinterpret_cast<uint4*>(orow) = make_uint4(u[0], u[1], u[2], u[3]);
           }
-          *reinterpret_cast<uint4*>(orow + k * 4) = make_uint4(u[0], u[1], u[2], u[3]);
         }
       } else {
         float* out = reinterpret_cast<float*>(out_);
+        const int xv = x0 + cv;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int cl = ch0 + k;
           const int c = c0 + cl;
-          if (c < channels) {
+          if (xv < nx && c < channels) {
             float f[VEC], r[VEC];
             load_vec<VEC>(&lds[cl * T::LD + cv], f);
 #pragma unroll
