@@ -187,20 +187,20 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
                                                   int nx, int xtiles, void* __restrict__ out_) {
   using T = Tile<VEC>;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
+  constexpr int kTokDw = kCT * 2 + 2;                         // dwords per token in the turn tile (64 data + 2 pad)
+  __shared__ __attribute__((aligned(8))) uint32_t olds[PATCH ? 64 * kTokDw : 2];
   const int y = blockIdx.x / xtiles;
   const int x0 = (blockIdx.x % xtiles) * T::XT;
   const int c0 = blockIdx.y * kCT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t cells = (int64_t)ny * nx;
-  // apply-phase ownership.  NCHW: a wave owns 8 channels, a lane VEC consecutive cells of each (512 B per wave store).
-  // Patch rows: 16 lanes share a token, each owning a channel PAIR (2 x 4 cells = 8 bf16 = 16 B), in 4 token sets —
-  // one store instruction then writes whole 256-byte runs of 4 token rows (a lane owning 8 consecutive channels of
-  // one token wrote 16-byte pieces 64 bytes apart: the same bytes in four times the write transactions)
-  const int ch0 = PATCH ? 2 * (lane & 15) : wave * 8;
-  const int cv = PATCH ? 0 : lane * VEC;
-  const int tq = lane >> 4;
-  auto chan_of = [&](int k) { return PATCH ? ch0 + (k & 1) : ch0 + k; };
-  auto cell_of = [&](int k) { return PATCH ? (wave * 16 + (k >> 1) * 4 + tq) * 4 : cv; };
+  // apply-phase ownership: a wave owns 8 channels, a lane VEC consecutive cells of each, so the affine parameters are
+  // read as whole KiB rows.  For patch rows the results are turned through a second LDS tile (token-major, padded to
+  // 66 dwords per token: conflict-free 8-byte writes and reads) and leave as whole 256-byte runs of the token rows.
+  const int ch0 = wave * 8;
+  const int cv = lane * VEC;
+  auto chan_of = [&](int k) { return ch0 + k; };
+  auto cell_of = [&](int) { return cv; };
   // affine parameters: read once, reused for every scan of the batch
   float w[8][VEC], bz[8][VEC];
 #pragma unroll
@@ -234,27 +234,32 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
     }
     {
       if constexpr (PATCH) {
-        // channels % kCT == 0 in this mode; per token set: 2 channels x 4 cells = 8 bf16 = one 16-byte store
+        // channels % kCT == 0 in this mode.  token = lane (4 cells), channel cl = ch0 + k: 4 bf16 = 2 dwords
 #pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-          const int cj = cell_of(k), xj = x0 + cj;
-          if (xj < nx) {
-            float f0[VEC], f1[VEC];
-            load_vec<VEC>(&lds[ch0 * T::LD + cj], f0);
-            load_vec<VEC>(&lds[(ch0 + 1) * T::LD + cj], f1);
-            unsigned u[4];
+        for (int k = 0; k < 8; ++k) {
+          float f[VEC];
+          load_vec<VEC>(&lds[(ch0 + k) * T::LD + cv], f);
+          const float a0 = (f[0] - mean) * rstd * w[k][0] + bz[k][0];
+          const float a1 = (f[1] - mean) * rstd * w[k][1] + bz[k][1];
+          const float a2 = (f[2] - mean) * rstd * w[k][2] + bz[k][2];
+          const float a3 = (f[3] - mean) * rstd * w[k][3] + bz[k][3];
+          uint2 u;
+          u.x = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
+          u.y = (unsigned)f32_to_bf16_rne(a2) | ((unsigned)f32_to_bf16_rne(a3) << 16);
+          *reinterpret_cast<uint2*>(&olds[lane * kTokDw + (ch0 + k) * 2]) = u;
+        }
+        __syncthreads();
+        // 64 tokens x 256 B: a wave instruction stores two whole token runs (32 lanes x 8 B each)
+        unsigned short* obase = reinterpret_cast<unsigned short*>(out_);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const float a0 = (f0[2 * e] - mean) * rstd * w[k][2 * e] + bz[k][2 * e];
-              const float a1 = (f0[2 * e + 1] - mean) * rstd * w[k][2 * e + 1] + bz[k][2 * e + 1];
-              const float b0 = (f1[2 * e] - mean) * rstd * w[k + 1][2 * e] + bz[k + 1][2 * e];
-              const float b1 = (f1[2 * e + 1] - mean) * rstd * w[k + 1][2 * e + 1] + bz[k + 1][2 * e + 1];
-              u[e] = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
-              u[2 + e] = (unsigned)f32_to_bf16_rne(b0) | ((unsigned)f32_to_bf16_rne(b1) << 16);
-            }
-            unsigned short* orow = reinterpret_cast<unsigned short*>(out_) +
-                                   patch_row_offset(b, channels, ny, nx, y, xj, c0 + ch0);
-            *reinterpret_cast<uint4*>(orow) = make_uint4(u[0], u[1], u[2], u[3]);
+        for (int it = 0; it < (64 * kCT * 2) / (256 * 2); ++it) {
+          const int idx = it * 256 + threadIdx.x;
+          const int tok = idx >> 5, piece = idx & 31;             // 32 pieces of 8 bytes per token
+          const int xt = x0 + tok * 4;
+          if (xt < nx) {
+            const uint2 u = *reinterpret_cast<const uint2*>(&olds[tok * kTokDw + piece * 2]);
+            unsigned short* orow = obase + patch_row_offset(b, channels, ny, nx, y, xt, c0) + piece * 4;
+            *reinterpret_cast<uint2*>(orow) = u;
           }
         }
       } else {
@@ -274,7 +279,9 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
         }
       }
     }
-    __syncthreads();
+    // NCHW: the f32 tile is about to be overwritten by the next scan's rows.  Patch rows: every read of the f32 tile
+    // precedes the barrier above, and the turn tile is rewritten only after the next scan's first barrier.
+    if constexpr (!PATCH) __syncthreads();
   }
 }
 
