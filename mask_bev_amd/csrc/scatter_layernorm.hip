@@ -307,8 +307,12 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
   // its dependent, divergent loads sit on every wave's critical path.)
   constexpr int THREADS = 512, WAVES = THREADS / 64, CPW = kCT / WAVES;
   using T = Tile<VEC, THREADS>;
-  using M = Map<PATCH, CPW>;
+  using M = Map<false, CPW>;           // a wave owns CPW channels, a lane VEC cells: parameters move as whole KiB rows
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
+  // patch rows: the token-major gradient is read in whole 256-byte runs and turned through this tile (66 dwords per
+  // token, as in the forward) into the (channel, cell) ownership above
+  constexpr int kTokDw = kCT * 2 + 2;
+  __shared__ __attribute__((aligned(8))) uint32_t gtile[PATCH ? 64 * kTokDw : 2];
   constexpr int MAXB = 16;
   __shared__ double acc[MAXB][2][WAVES];
   const int y = blockIdx.x / xtiles;
@@ -338,22 +342,15 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
       const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
       const int32_t pid = pid_next;
       float g[CPW][VEC];
+      uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+      const int g_tok = wave * 8 + (lane >> 3), g_piece = lane & 7;     // 8 lanes x 32 B = one token's 256-byte run
       if constexpr (PATCH) {
-        // CPW channels x 4 cells = 16 bf16 = 32 contiguous bytes of the token's gradient row
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-        if (x_ok) {
+        const int xt = x0 + g_tok * 4;
+        if (xt < nx) {
           const unsigned short* grow = reinterpret_cast<const unsigned short*>(grad_out_) +
-                                       patch_row_offset(b, channels, ny, nx, y, xv, c0 + ch0);
+                                       patch_row_offset(b, channels, ny, nx, y, xt, c0 + g_piece * 4);
           q0 = *reinterpret_cast<const uint4*>(grow);
           q1 = *reinterpret_cast<const uint4*>(grow + 8);
-        }
-        const unsigned u[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-          g[k][0] = __uint_as_float(u[2 * k] << 16);
-          g[k][1] = __uint_as_float(u[2 * k] & 0xffff0000u);
-          g[k][2] = __uint_as_float(u[2 * k + 1] << 16);
-          g[k][3] = __uint_as_float(u[2 * k + 1] & 0xffff0000u);
         }
       } else {
         const float* grad_out = reinterpret_cast<const float*>(grad_out_);
@@ -369,7 +366,24 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
       if (b + 1 < bend && x0 + gcell < nx)
         pid_next = cell_to_pillar[(int64_t)(b + 1) * cells + (int64_t)y * nx + x0 + gcell];
       gather_tile<VEC, THREADS>(feats, channels, c0, pid, lds);
+      if constexpr (PATCH) {
+        uint32_t* gt = &gtile[g_tok * kTokDw + g_piece * 8];
+        *reinterpret_cast<uint2*>(gt) = make_uint2(q0.x, q0.y);
+        *reinterpret_cast<uint2*>(gt + 2) = make_uint2(q0.z, q0.w);
+        *reinterpret_cast<uint2*>(gt + 4) = make_uint2(q1.x, q1.y);
+        *reinterpret_cast<uint2*>(gt + 6) = make_uint2(q1.z, q1.w);
+      }
       __syncthreads();
+      if constexpr (PATCH) {                     // token = lane, channels ch0 .. ch0 + CPW - 1
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const uint2 u = *reinterpret_cast<const uint2*>(&gtile[lane * kTokDw + (ch0 + k) * 2]);
+          g[k][0] = __uint_as_float(u.x << 16);
+          g[k][1] = __uint_as_float(u.x & 0xffff0000u);
+          g[k][2] = __uint_as_float(u.y << 16);
+          g[k][3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+      }
       float s1f = 0.f, s2f = 0.f;   // <= 16 terms per thread and scan: f32 partials, f64 across threads
       if (x_ok) {
 #pragma unroll
