@@ -205,7 +205,7 @@ def main():
                 'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
         # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
         # MI355X_MICROARCH.md); same workload, same build
-        traffic = {'k_ln_apply': 576.8e6, 'k_ln_bwd_dense': 993.6e6, 'k_adamw': 6511.5e6} \
+        traffic = {'k_ln_apply': 568.8e6, 'k_ln_bwd_dense': 993.7e6, 'k_adamw': 6511.5e6} \
             if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
                 and args.distribution == 'lidar') else {}
         roof = {}
