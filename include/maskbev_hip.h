@@ -482,6 +482,44 @@ int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, 
                     int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
                     void* grad_k, void* grad_v, int32_t ld_grad_kv, int32_t grad_kv_bf16, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K17 — 16-bit (bf16 / fp16) MFMA GEMMs of the token-major Linear layers, with the element-wise work around them
+ * fused into the epilogue.  dtype: 0 = bf16, 1 = fp16 (inputs; accumulation is f32).
+ * Replaces the cuBLAS/ATen GEMMs behind nn.Linear in WindowMSA.qkv / .proj (mask_bev/models/networks/swin/swin.py:
+ * 89-116), the mmcv FFN of SwinBlock (swin.py:347-377: Linear -> GELU -> Linear), PatchEmbed / PatchMerging
+ * (swin.py:579-586, 611), the Linears of the pixel decoder and the transformer decoder
+ * (mask_bev/models/head/mask_bev_panoptic_head.py:119-175) and their autograd backward.
+ * Every matrix is row-major with leading dimension ld* (elements, multiples of 8; pointers 16-byte aligned);
+ * `batch` independent problems are `stride_*` elements apart.  Shapes the kernels do not take return
+ * MBV_ERR_UNSUPPORTED (callers use the library GEMM for those).
+ *
+ *   mbv_gemm16_nt   out (m, n) = act(x (m, k) . w (n, k)^T + bias);  act: 0 none, 1 ReLU, 2 GELU (erf form);
+ *                   out_pre (optional, act != 0) receives the pre-activation; out / out_pre are 16-bit or f32.
+ *   mbv_gemm16_nn   out (m, k) = act'(aux) * (g (m, n) . w (n, k));  act: 0 none, 1 ReLU' with aux = the activation
+ *                   output, 2 GELU' with aux = the pre-activation (aux (m, k) 16-bit, ld = ldaux, batch stride of
+ *                   out); colsum (k) f32 (optional) += column sums of the stored out (the bias gradient of the
+ *                   Linear in front of the activation; needs `workspace` of mbv_gemm16_nn_workspace_bytes).
+ *   mbv_gemm16_tn   accumulate != 0: dw (n, k) f32 += g (m, n)^T . x (m, k), the sum over m split over `splits`
+ *                   workgroups per tile (0 = choose) that add with f32 atomics (dw is the parameter arena's gradient);
+ *                   accumulate == 0: dw = g^T . x stored once (16-bit or f32).
+ */
+int mbv_gemm16_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
+
+int mbv_gemm16_nt(const void* x, const void* w, const float* bias, void* out, void* out_pre, int64_t m, int64_t n,
+                  int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, int32_t dtype, int32_t out_f32, int32_t act,
+                  int32_t batch, int64_t stride_x, int64_t stride_w, int64_t stride_o, void* stream);
+
+size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch);
+
+int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, float* colsum, int64_t m, int64_t n,
+                  int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux, int32_t dtype, int32_t out_f32,
+                  int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w, int64_t stride_o, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldx,
+                  int64_t lddw, int32_t dtype, int32_t accumulate, int32_t out_f32, int32_t splits, int32_t batch,
+                  int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

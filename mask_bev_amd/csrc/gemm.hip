@@ -1,0 +1,657 @@
+// K17 — 16-bit (bf16 / fp16) MFMA GEMM family for the token-major Linear layers of the path: the Swin qkv / proj /
+// fc1 / fc2 projections, patch projection and patch merging (/root/reference: mask_bev/models/networks/swin/swin.py:
+// 89-116, 357-377, 579-586, 611; mmcv FFN), the pixel decoder's and the decoder's Linears
+// (mask_bev/models/head/mask_bev_panoptic_head.py:119-175) and the backward of the mask-logit contraction
+// (mask_bev/models/networks/mask2former_head/mask2former_head.py:459).  One kernel template, three operand layouts:
+//
+//   NT  C[m][n] = sum_k X[m][k] W[n][k]          forward Linear              (both operands contraction-contiguous)
+//   NN  C[m][k] = sum_n G[m][n] W[n][k]          data gradient               (W read with transposing LDS reads)
+//   TN  C[n][k] = sum_m G[m][n] X[m][k]          weight gradient, split over m (both operands transposed reads)
+//
+// Structure (cdna_hip_programming.md §5, "minimum 2-phase" recipe): 256 threads = 4 waves as 2 x 2, block tile
+// 128 x 128 x KB (KB = 32: 35 KB of LDS, four workgroups per CU hide each other's load latency; KB = 64: two), wave
+// tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16; both operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds`
+// (no staging registers; out-of-range rows / columns read as zero through the buffer range check, so every edge is
+// handled by the descriptor), double buffered, one barrier per K-step; LDS images are XOR-swizzled on the SOURCE
+// address (the LDS side of an LDS-DMA is lane-linear) so that both the ds_read_b128 row reads and the
+// ds_read_b64_tr_b16 transposed reads are bank-conflict free.
+// Epilogue: STORE — the wave's accumulators (computed as C^T so that a lane holds 4 consecutive columns) are turned
+// through a private LDS tile and leave as whole 128-byte (16-bit) / 256-byte (f32) row segments, with bias,
+// ReLU / GELU (optionally also storing the pre-activation), the activation-backward products ReLU' / GELU' against
+// a saved tensor and the column sums of the result (the bias gradient of the layer in front; per-wave partial rows
+// in the workspace, then one small reduction launch) applied in f32 on the way; ATOMIC — f32 atomic adds of the
+// accumulators straight into the destination (weight gradients accumulate in the parameter arena; each
+// wave-instruction adds two 128-byte row segments, the full-rate shape of MI355X_MICROARCH.md §Global float atomics).
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int STG_LD = 68;                        // f32 row stride of a wave's 32 x 64 epilogue tile
+constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;    // four waves
+constexpr unsigned OOB = 0x80000000u;             // byte offset beyond any descriptor: the load returns zero
+
+template <int KB, int NS = 2>
+struct Geo {
+  static constexpr int IMG = 128 * KB * 2;        // one operand tile
+  static constexpr int STAGE = 2 * IMG;           // A + B
+  static constexpr int PW = KB / 16;              // 1-KiB LDS-DMA pieces per wave and operand tile
+  static constexpr int LDS = NS * STAGE > STG_BYTES ? NS * STAGE : STG_BYTES;
+  static constexpr int WPS = LDS <= 40960 ? 4 : (LDS <= 53248 ? 3 : (LDS <= 81920 ? 2 : 1));   // workgroups per CU
+};
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_DRELU = 3, EPI_DGELU = 4 };
+
+struct GemmArgs {
+  const void* a;
+  const void* b;
+  void* c;              // STORE: (gm, gn) row-major, 16-bit or f32; ATOMIC: f32, accumulated into
+  void* c2;             // STORE + EPI_GELU / EPI_RELU: optional pre-activation output (same type as c)
+  const void* aux;      // EPI_DRELU / EPI_DGELU: saved activation output / pre-activation, (gm, gn) 16-bit, ld = ldx
+  const float* bias;    // STORE: optional, (gn)
+  float* colsum_rows;   // STORE: optional, (2 ntm, gn) f32: column sums of the stored values per wave row
+  int gm, gn, gk;       // GEMM dims: C (gm x gn) = A (gm x gk) . B (gk x gn)
+  int lda, ldb, ldc, ldx;
+  long long sa, sb, sc; // batch strides (elements)
+  unsigned a_bytes, b_bytes;   // extent of one batch item of A / B for the buffer descriptors
+  int ntm, ntn, splits, ksteps;  // tiles, split-K parts, K-steps of KB per part
+  int out_f32;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<__bf16> {
+  static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  }
+  static __device__ __forceinline__ float to_f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+  // a plain cast: v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN — MI355X_MICROARCH.md §Correctness)
+  static __device__ __forceinline__ unsigned short from_f(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+  }
+};
+template <>
+struct Mma<_Float16> {
+  static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+  static __device__ __forceinline__ float to_f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ unsigned short from_f(float f) {
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+  }
+};
+
+// Raw buffer descriptor (stride 0, range-checked: a byte offset at or beyond `bytes` reads as zero).
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r[0] = (int)(unsigned)b;
+  r[1] = (int)(unsigned)((b >> 32) & 0xffffu);
+  r[2] = (int)bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at byte offset voff + soff of the buffer land at LDS byte address
+// lds_addr + 16 l.  Written in asm so that hipcc does not count it: the compiler otherwise waits vmcnt(0) in front of
+// the next ds_read of the same __shared__ array (it cannot tell the two halves of the double buffer apart), which
+// serialises the prefetch with the MFMAs it is meant to run under.  Completion is this kernel's own
+// `s_waitcnt vmcnt(0)` in front of the barrier that publishes the tile; M0 is written in the statement that reads it
+// (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void glds16(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(rs), "s"(soff), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+               : "memory", "m0");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)p);
+}
+
+// ---- LDS images ---------------------------------------------------------------------------------------------------
+// KC image (contraction index contiguous): [128 rows][KB k] 16-bit.  KB = 64: 128-byte rows of 8 chunks of 16 B, chunk
+// c of row r at physical chunk c ^ ((r >> 1) & 7) (two rows share a 256-byte bank row); KB = 32: 64-byte rows of 4
+// chunks, chunk c at c ^ ((r >> 2) & 3) (four rows per bank row).  Either way the 16 rows x one chunk column that a
+// ds_read_b128 lane group touches land in 16 different 16-byte slots.  One wave-instruction (1 KiB) fills 8 / 16 rows.
+template <int KB>
+__device__ __forceinline__ void kc_lane(int piece, int lane, int& r, int& c) {
+  if (KB == 64) {
+    r = 8 * piece + (lane >> 3);
+    c = (lane & 7) ^ ((r >> 1) & 7);
+  } else {
+    r = 16 * piece + (lane >> 2);
+    c = (lane & 3) ^ ((r >> 2) & 3);
+  }
+}
+
+// KS image (contraction index strided): [KB k rows][128 cols] 16-bit, 256-byte rows of 16 chunks; chunk c of row r
+// at physical chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3))  (cdna_hip_programming.md T10, image (b): conflict-free
+// for the 32x32x16 transposed reads).  One wave-instruction fills 4 rows.
+__device__ __forceinline__ int ks_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__device__ __forceinline__ void ks_lane(int piece, int lane, int& r, int& c) {
+  r = 4 * piece + (lane >> 4);
+  c = (lane & 15) ^ ks_swz(r);
+}
+
+// Per-lane byte offsets of a wave's pieces for the K-step that starts at k0 (every bound checked per lane:
+// out-of-range elements get the OOB offset and arrive as zeros).
+template <int KB, bool KS>
+__device__ __forceinline__ void piece_offsets(unsigned (&off)[Geo<KB>::PW], int x0, int x_total, int ld_bytes, int k0,
+                                              int k_end, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < Geo<KB>::PW; ++j) {
+    int r, c;
+    if (KS) {
+      ks_lane(wave * Geo<KB>::PW + j, lane, r, c);
+      const int gk = k0 + r, gx = x0 + 8 * c;
+      off[j] = (gk < k_end && gx < x_total) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gx * 2u : OOB;
+    } else {
+      kc_lane<KB>(wave * Geo<KB>::PW + j, lane, r, c);
+      const int gx = x0 + r, gk = k0 + 8 * c;
+      off[j] = (gx < x_total && gk < k_end) ? (unsigned)gx * (unsigned)ld_bytes + (unsigned)gk * 2u : OOB;
+    }
+  }
+}
+
+// ---- LDS -> MFMA fragments ---------------------------------------------------------------------------------------
+// 32x32x16 operand of k-step ks (16 k's): lane l (r = l & 31, h = l >> 5) holds element (row / col r, k = 8h + j).
+template <int KB>
+__device__ __forceinline__ uint4 frag_kc(const char* img, int r0, int ks, int lane) {
+  const int row = r0 + (lane & 31), c = 2 * ks + (lane >> 5);
+  if (KB == 64) return *reinterpret_cast<const uint4*>(img + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const uint4*>(img + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+}
+
+__device__ __forceinline__ uint4 frag_ks(const char* img, int c0, int ks, int lane) {
+  // 16-lane group g: columns c0 + 16 (g & 1) .. + 15, k rows 16 ks + 8 (g >> 1) + 4 s .. + 3 for s = 0, 1;
+  // lane 4q + p of the group addresses row q, columns 4p .. 4p + 3 of the 4 x 16 block
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  const int col = c0 + 16 * ((lane >> 4) & 1);
+  const int ch = (col >> 3) + (p >> 1);
+  const int rr = 16 * ks + 8 * (lane >> 5) + q;
+  const char* p0 = img + rr * 256 + ((ch ^ ks_swz(rr)) << 4) + 8 * (p & 1);
+  const int rr1 = rr + 4;
+  const char* p1 = img + rr1 * 256 + ((ch ^ ks_swz(rr1)) << 4) + 8 * (p & 1);
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p0);
+  const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p1);
+  const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(uint4, t);
+}
+
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ float gelu_cdf_parts(float z, float& dens) {
+  // Phi(z) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 in erf), sharing exp(-z^2/2) with the density
+  const float e = __expf(-0.5f * z * z);
+  const float az = fabsf(z) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.f + 0.3275911f * az);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float half_tail = 0.5f * poly * e;
+  dens = 0.3989422804014327f * e;
+  return z >= 0.f ? 1.f - half_tail : half_tail;
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(void* base, size_t o, const float (&v)[8], int out_f32) {
+  if (out_f32) {
+    float* d = reinterpret_cast<float*>(base) + o;
+    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 u;
+    u.x = Mma<T>::from_f(v[0]) | ((unsigned)Mma<T>::from_f(v[1]) << 16);
+    u.y = Mma<T>::from_f(v[2]) | ((unsigned)Mma<T>::from_f(v[3]) << 16);
+    u.z = Mma<T>::from_f(v[4]) | ((unsigned)Mma<T>::from_f(v[5]) << 16);
+    u.w = Mma<T>::from_f(v[6]) | ((unsigned)Mma<T>::from_f(v[7]) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + o) = u;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void round8(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = Mma<T>::to_f(Mma<T>::from_f(v[e]));
+}
+
+// OUT: 0 = STORE (C^T accumulators, row-major store through LDS with the epilogue), 1 = ATOMIC (f32 adds)
+template <int KB, int NS, bool A_KS, bool B_KS, int OUT, int EPI, typename T>
+__global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmArgs p) {
+  using G = Geo<KB, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware block order (blocks b and b + 8 share an XCD): every XCD walks a contiguous range of the
+  // (batch, split, tile_m, tile_n) index, tile_n fastest, so the blocks that share an A panel share an L2.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, s = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+  }
+  const int tiles = p.ntm * p.ntn;
+  const int z = bid / tiles, t = bid - z * tiles;
+  const int tile_m = t / p.ntn, tile_n = t - tile_m * p.ntn;
+  const int bz = z / p.splits, sp = z - bz * p.splits;
+  const int k_begin = sp * p.ksteps * KB;
+  int k_end = k_begin + p.ksteps * KB;
+  if (k_end > p.gk) k_end = p.gk;
+  const int nk = (k_end - k_begin + KB - 1) / KB;
+  if (nk <= 0) return;
+
+  const char* abase = reinterpret_cast<const char*>(p.a) + (size_t)bz * (size_t)p.sa * 2;
+  const char* bbase = reinterpret_cast<const char*>(p.b) + (size_t)bz * (size_t)p.sb * 2;
+  const i32x4 ra = make_rsrc(abase, p.a_bytes), rb = make_rsrc(bbase, p.b_bytes);
+  const unsigned smem_addr = lds_addr_of(smem);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // loop-invariant offsets of this lane's pieces at the first K-step; a full K-step s adds the scalar s * step
+  const bool ragged = ((k_end - k_begin) & (KB - 1)) != 0;
+  unsigned offa[G::PW], offb[G::PW];
+  piece_offsets<KB, A_KS>(offa, m0, p.gm, p.lda * 2, k_begin, k_begin + KB, wave, lane);
+  piece_offsets<KB, B_KS>(offb, n0, p.gn, p.ldb * 2, k_begin, k_begin + KB, wave, lane);
+  const unsigned stepa = A_KS ? (unsigned)(KB * 2) * (unsigned)p.lda : (unsigned)(KB * 2);
+  const unsigned stepb = B_KS ? (unsigned)(KB * 2) * (unsigned)p.ldb : (unsigned)(KB * 2);
+
+  // K-step kt of this workgroup goes into ring slot kt % NS; a step beyond the range is issued as zero fills (no
+  // memory traffic) so that every step leaves the same number of loads on the wave's counter
+  auto stage = [&](int kt) {
+    const unsigned aimg = smem_addr + (kt % NS) * G::STAGE + wave * (G::PW * 1024), bimg = aimg + G::IMG;
+    if (kt >= nk) {
+#pragma unroll
+      for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, OOB, 0u);
+#pragma unroll
+      for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, OOB, 0u);
+      return;
+    }
+    if (ragged && kt == nk - 1) {                        // the only K-step with k's beyond the range: checked per lane
+      unsigned ta[G::PW], tb[G::PW];
+      piece_offsets<KB, A_KS>(ta, m0, p.gm, p.lda * 2, k_begin + kt * KB, k_end, wave, lane);
+      piece_offsets<KB, B_KS>(tb, n0, p.gn, p.ldb * 2, k_begin + kt * KB, k_end, wave, lane);
+#pragma unroll
+      for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, ta[j], 0u);
+#pragma unroll
+      for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, tb[j], 0u);
+      return;
+    }
+    const unsigned sa = (unsigned)kt * stepa, sb = (unsigned)kt * stepb;
+#pragma unroll
+    for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, offa[j], sa);
+#pragma unroll
+    for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, offb[j], sb);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // NS - 1 steps in flight.  Per step: wait for the oldest (the wave's own pieces: counted vmcnt, the younger
+  // NS - 2 steps stay in flight), barrier (everybody's pieces of that step are in LDS, and everybody is done reading
+  // the slot of the step before), refill that slot with step kt + NS - 1, multiply.
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) stage(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * G::PW) : "memory");
+    __syncthreads();
+    stage(kt + NS - 1);
+    const char* aimg = smem + (kt % NS) * G::STAGE;
+    const char* bimg = aimg + G::IMG;
+    uint4 af[KB / 16][2], bf[KB / 16][2];
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[ks][i] = A_KS ? frag_ks(aimg, 64 * wm + 32 * i, ks, lane) : frag_kc<KB>(aimg, 64 * wm + 32 * i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[ks][j] = B_KS ? frag_ks(bimg, 64 * wn + 32 * j, ks, lane) : frag_kc<KB>(bimg, 64 * wn + 32 * j, ks, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = OUT == 0 ? Mma<T>::run(bf[ks][j], af[ks][i], acc[i][j]) : Mma<T>::run(af[ks][i], bf[ks][j], acc[i][j]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero fills of the tail: nothing may land in LDS later
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  if (OUT == 1) {
+    // acc[i][j][e]: row m = acc_row(e, h) of tile i, column n = r of tile j
+    float* c = reinterpret_cast<float*>(p.c) + (size_t)bz * (size_t)p.sc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int gn = n0 + 64 * wn + 32 * j + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int gm = m0 + 64 * wm + 32 * i + acc_row(e, h);
+          if (gm < p.gm && gn < p.gn) atomicAdd(c + (size_t)gm * p.ldc + gn, acc[i][j][e]);
+        }
+      }
+    return;
+  }
+
+  // ---- STORE: acc[i][j][e] = C[m = 64 wm + 32 i + r][n = 64 wn + 32 j + acc_row(e, h)] -------------------------------
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
+  const int prow = lane >> 3, cg = lane & 7;
+  const int gn = n0 + 64 * wn + 8 * cg;
+  const bool col_ok = gn < p.gn;                      // gn % 8 == 0 is required: a column group is all in or all out
+  const size_t cbase = (size_t)bz * (size_t)p.sc;
+  const int mrow0 = m0 + 64 * wm + prow;              // this lane's rows: mrow0 + 32 i + 8 ps
+  constexpr bool HAS_AUX = EPI == EPI_DRELU || EPI == EPI_DGELU;
+  uint4 auxv[2][4];
+  if (HAS_AUX) {                                      // all eight rows requested before the accumulators are turned
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int gm = mrow0 + 32 * i + 8 * ps;
+        auxv[i][ps] = make_uint4(0, 0, 0, 0);
+        if (gm < p.gm && col_ok)
+          auxv[i][ps] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.aux) + cbase +
+                                                        (size_t)gm * p.ldx + gn);
+      }
+  }
+  float bias8[8], csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; csum[e] = 0.f; }
+  if (p.bias && col_ok) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * g]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+        *reinterpret_cast<f32x4*>(stg + r * STG_LD + 32 * j + 8 * g + 4 * h) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = 8 * ps + prow;
+      const int gm = mrow0 + 32 * i + 8 * ps;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * STG_LD + 8 * cg);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * STG_LD + 8 * cg + 4);
+      if (gm >= p.gm || !col_ok) continue;
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+      const size_t o = cbase + (size_t)gm * p.ldc + gn;
+      if (EPI == EPI_RELU || EPI == EPI_GELU) {
+        if (p.c2) store8<T>(p.c2, o, v, p.out_f32);        // the pre-activation as the backward wants it
+        if (!p.out_f32) round8<T>(v);                     // the activation sees what the unfused path reads back
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (EPI == EPI_RELU) {
+            v[e] = v[e] > 0.f ? v[e] : 0.f;
+          } else {
+            float dens;
+            v[e] *= gelu_cdf_parts(v[e], dens);
+          }
+        }
+      } else if (HAS_AUX) {
+        const unsigned w[4] = {auxv[i][ps].x, auxv[i][ps].y, auxv[i][ps].z, auxv[i][ps].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float zz = Mma<T>::to_f((unsigned short)(w[e >> 1] >> (16 * (e & 1))));
+          if (EPI == EPI_DRELU) {
+            v[e] = zz > 0.f ? v[e] : 0.f;
+          } else {
+            float dens;
+            const float cdf = gelu_cdf_parts(zz, dens);
+            v[e] *= cdf + zz * dens;
+          }
+        }
+      }
+      store8<T>(p.c, o, v, p.out_f32);
+      if (p.colsum_rows) {
+        if (!p.out_f32) round8<T>(v);                     // sum what was stored
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+      }
+    }
+  }
+  if (p.colsum_rows) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = csum[e];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      csum[e] = s;
+    }
+    if (prow == 0 && col_ok) {                        // one partial row per (tile_m, wave row): no atomics, no contention
+      float* d = p.colsum_rows + ((size_t)bz * 2 * p.ntm + 2 * tile_m + wm) * (size_t)p.gn + gn;
+      *reinterpret_cast<float4*>(d) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+    }
+  }
+}
+
+// out (n) += sum over rows of part (rows, n)
+__global__ void __launch_bounds__(256) k_sum_rows(const float* __restrict__ part, int rows, int n, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float s = 0.f;
+  if (col < n)
+    for (int r = r0 + sub; r < r1; r += 4) s += part[(size_t)r * n + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && col < n)
+    atomicAdd(out + col, (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]));
+}
+
+}  // namespace
+
+// dtype: 0 = bf16, 1 = fp16.  layout: 0 = NT, 1 = NN, 2 = TN (see the header).
+template <int KB, int NS, bool AKS, bool BKS, int OUT, int EPI>
+static int gemm16_launch_t(int dtype, const GemmArgs& a, unsigned nblk, hipStream_t st) {
+  constexpr int lds = Geo<KB, NS>::LDS;
+  if (dtype == 0) {
+    if (lds > 65536) {
+      static bool done = false;       // idempotent attribute of the code object, not library state
+      if (!done) {
+        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<KB, NS, AKS, BKS, OUT, EPI, __bf16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = true;
+      }
+    }
+    hipLaunchKernelGGL((k_gemm16<KB, NS, AKS, BKS, OUT, EPI, __bf16>), dim3(nblk), dim3(256), lds, st, a);
+  } else {
+    if (lds > 65536) {
+      static bool done = false;
+      if (!done) {
+        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<KB, NS, AKS, BKS, OUT, EPI, _Float16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = true;
+      }
+    }
+    hipLaunchKernelGGL((k_gemm16<KB, NS, AKS, BKS, OUT, EPI, _Float16>), dim3(nblk), dim3(256), lds, st, a);
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+template <int KB, int NS>
+static int gemm16_launch_k(int layout, int atomic, int epi, int dtype, const GemmArgs& a, unsigned n, hipStream_t st) {
+  if (layout == 0) {
+    if (atomic) return gemm16_launch_t<KB, NS, false, false, 1, EPI_NONE>(dtype, a, n, st);
+    if (epi == EPI_RELU) return gemm16_launch_t<KB, NS, false, false, 0, EPI_RELU>(dtype, a, n, st);
+    if (epi == EPI_GELU) return gemm16_launch_t<KB, NS, false, false, 0, EPI_GELU>(dtype, a, n, st);
+    return gemm16_launch_t<KB, NS, false, false, 0, EPI_NONE>(dtype, a, n, st);
+  }
+  if (layout == 1) {
+    if (epi == EPI_DRELU) return gemm16_launch_t<KB, NS, false, true, 0, EPI_DRELU>(dtype, a, n, st);
+    if (epi == EPI_DGELU) return gemm16_launch_t<KB, NS, false, true, 0, EPI_DGELU>(dtype, a, n, st);
+    return gemm16_launch_t<KB, NS, false, true, 0, EPI_NONE>(dtype, a, n, st);
+  }
+  if (atomic) return gemm16_launch_t<KB, NS, true, true, 1, EPI_NONE>(dtype, a, n, st);
+  return gemm16_launch_t<KB, NS, true, true, 0, EPI_NONE>(dtype, a, n, st);
+}
+
+// Pipeline shape "KBxNS" (K-step depth x ring slots); MBV_GEMM_CFG overrides the default for A/B runs.
+static int gemm16_cfg() {
+  const char* e = getenv("MBV_GEMM_CFG");
+  if (!e) return 323;
+  return atoi(e);
+}
+
+static int gemm16_kb() { return gemm16_cfg() / 10; }
+
+static int gemm16_launch(int layout, int atomic, int epi, int dtype, GemmArgs a, int kb, int batch, hipStream_t st) {
+  const long long nblk = (long long)a.ntm * a.ntn * a.splits * batch;
+  if (nblk <= 0) return MBV_OK;
+  if (nblk > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+  const unsigned n = (unsigned)nblk;
+  switch (gemm16_cfg()) {
+    case 322: return gemm16_launch_k<32, 2>(layout, atomic, epi, dtype, a, n, st);
+    case 642: return gemm16_launch_k<64, 2>(layout, atomic, epi, dtype, a, n, st);
+    default: return gemm16_launch_k<32, 3>(layout, atomic, epi, dtype, a, n, st);
+  }
+}
+
+static bool fits_2g(long long rows, long long ld) { return rows * ld * 2 < 0x7fff0000LL; }
+
+extern "C" int mbv_gemm16_supported(int32_t layout, int64_t m, int64_t n, int64_t k) {
+  if (layout < 0 || layout > 2 || m <= 0 || n <= 0 || k <= 0) return 0;
+  if ((n & 7) || (k & 7)) return 0;          // 16-byte chunks; every other edge is handled by the range check
+  return m * (n > k ? n : k) * 2 < 0x7fff0000LL ? 1 : 0;
+}
+
+// out (m, n) = epi(x (m, k) . w (n, k)^T + bias)
+extern "C" int mbv_gemm16_nt(const void* x, const void* w, const float* bias, void* out, void* out_pre, int64_t m,
+                             int64_t n, int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, int32_t dtype,
+                             int32_t out_f32, int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w,
+                             int64_t stride_o, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !x || !w || !out) return MBV_ERR_BAD_ARG;
+  if (dtype < 0 || dtype > 1 || act < 0 || act > 2) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldx & 7) || (ldw & 7) || (ldo & 7) || ldx < k || ldw < k || ldo < n) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out) |
+       reinterpret_cast<size_t>(out_pre) | reinterpret_cast<size_t>(bias)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  if (!fits_2g(m, ldx) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
+  if (m == 0 || batch == 0) return MBV_OK;
+  const int kb = gemm16_kb();
+  GemmArgs a = {};
+  a.a = x; a.b = w; a.c = out; a.c2 = out_pre; a.bias = bias;
+  a.gm = (int)m; a.gn = (int)n; a.gk = (int)k;
+  a.lda = (int)ldx; a.ldb = (int)ldw; a.ldc = (int)ldo;
+  a.sa = stride_x; a.sb = stride_w; a.sc = stride_o;
+  a.a_bytes = (unsigned)(((m - 1) * ldx + k) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
+  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((n + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((k + kb - 1) / kb);
+  a.out_f32 = out_f32;
+  return gemm16_launch(0, 0, act, dtype, a, kb, batch, (hipStream_t)stream);
+}
+
+extern "C" size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch) {
+  return (size_t)((m + BM - 1) / BM) * 2 * (size_t)k * 4 * (size_t)(batch > 0 ? batch : 1);
+}
+
+// out (m, k) = act'(aux) * (g (m, n) . w (n, k));  colsum (k) += column sums of out
+extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, float* colsum, int64_t m,
+                             int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux, int32_t dtype,
+                             int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w,
+                             int64_t stride_o, void* workspace, size_t workspace_bytes, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !w || !out) return MBV_ERR_BAD_ARG;
+  if (dtype < 0 || dtype > 1 || act < 0 || act > 2 || (act && !aux)) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldg & 7) || (ldw & 7) || (ldo & 7) || (ldaux & 7) || ldg < n || ldw < k || ldo < k)
+    return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out) |
+       reinterpret_cast<size_t>(aux) | reinterpret_cast<size_t>(workspace)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  if (!fits_2g(m, ldg) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
+  if (colsum && (!workspace || workspace_bytes < mbv_gemm16_nn_workspace_bytes(m, k, batch))) return MBV_ERR_WORKSPACE;
+  if (m == 0 || batch == 0) return MBV_OK;
+  const int kb = gemm16_kb();
+  GemmArgs a = {};
+  a.a = g; a.b = w; a.c = out; a.aux = aux; a.colsum_rows = colsum ? reinterpret_cast<float*>(workspace) : nullptr;
+  a.gm = (int)m; a.gn = (int)k; a.gk = (int)n;
+  a.lda = (int)ldg; a.ldb = (int)ldw; a.ldc = (int)ldo; a.ldx = (int)ldaux;
+  a.sa = stride_g; a.sb = stride_w; a.sc = stride_o;
+  a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
+  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((k + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((n + kb - 1) / kb);
+  a.out_f32 = out_f32;
+  const int rc = gemm16_launch(1, 0, act == 0 ? EPI_NONE : (act == 1 ? EPI_DRELU : EPI_DGELU), dtype, a, kb, batch,
+                               (hipStream_t)stream);
+  if (rc != MBV_OK || !colsum) return rc;
+  const int rows = 2 * a.ntm * batch;
+  int gy = rows / 16;
+  if (gy < 1) gy = 1;
+  if (gy > 32) gy = 32;
+  hipLaunchKernelGGL(k_sum_rows, dim3((unsigned)((k + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float*>(workspace), rows, (int)k, colsum);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// accumulate != 0:  dw (n, k) f32 += g (m, n)^T . x (m, k), the sum over m split over workgroups (f32 atomic adds)
+// accumulate == 0:  dw (n, k) = g^T . x stored (16-bit or f32), one workgroup per tile
+extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, int64_t k, int64_t ldg,
+                             int64_t ldx, int64_t lddw, int32_t dtype, int32_t accumulate, int32_t out_f32,
+                             int32_t splits, int32_t batch, int64_t stride_g, int64_t stride_x, int64_t stride_dw,
+                             void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !x || !dw) return MBV_ERR_BAD_ARG;
+  if (dtype < 0 || dtype > 1) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldg & 7) || (ldx & 7) || ldg < n || ldx < k || lddw < k) return MBV_ERR_UNSUPPORTED;
+  if (!accumulate && (lddw & 7)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dw)) & 15) return MBV_ERR_UNSUPPORTED;
+  if (!fits_2g(m, ldg) || !fits_2g(m, ldx)) return MBV_ERR_UNSUPPORTED;
+  if (m == 0 || batch == 0) return MBV_OK;
+  const int kb = gemm16_kb();
+  GemmArgs a = {};
+  a.a = g; a.b = x; a.c = dw;
+  a.gm = (int)n; a.gn = (int)k; a.gk = (int)m;
+  a.lda = (int)ldg; a.ldb = (int)ldx; a.ldc = (int)lddw;
+  a.sa = stride_g; a.sb = stride_x; a.sc = stride_dw;
+  a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 2); a.b_bytes = (unsigned)(((m - 1) * ldx + k) * 2);
+  a.ntm = (int)((n + BM - 1) / BM); a.ntn = (int)((k + BN - 1) / BN);
+  const int total_steps = (int)((m + kb - 1) / kb);
+  int s = 1;
+  if (accumulate) {
+    s = splits;
+    if (s <= 0) {                 // about two workgroups per CU, at least 256 rows of m each
+      const long long tiles = (long long)a.ntm * a.ntn * batch;
+      s = (int)((512 + tiles - 1) / tiles);
+      if (s > total_steps * kb / 256) s = total_steps * kb / 256;
+    }
+    if (s < 1) s = 1;
+    if (s > total_steps) s = total_steps;
+  }
+  a.ksteps = (total_steps + s - 1) / s;
+  a.splits = (total_steps + a.ksteps - 1) / a.ksteps;
+  a.out_f32 = accumulate ? 1 : out_f32;
+  return gemm16_launch(2, accumulate ? 1 : 0, EPI_NONE, dtype, a, kb, batch, (hipStream_t)stream);
+}

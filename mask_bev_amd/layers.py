@@ -73,6 +73,13 @@ class FFN(nn.Module):
         """``add_identity=False`` returns the branch alone: the caller fuses the residual add into the LayerNorm
         that follows (K12); with ``defer_out_bias`` that LayerNorm also accumulates the output layer's bias gradient
         (pass ``self.layers[1].bias`` as its ``residual_bias``)."""
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        kind = 'gelu' if isinstance(self.layers[0][1], nn.GELU) else 'relu'
+        if ops.ffn_fused_ok(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+            # K17: fc1 + bias + activation, and fc2's data gradient + activation backward + d bias, as single launches
+            y = ops.ffn(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, kind,
+                        defer_out_bias=defer_out_bias and not add_identity)
+            return y if not add_identity else (x if identity is None else identity) + y
         if not add_identity:
             return self.layers[1](self._hidden(x), skip_bias_grad=defer_out_bias)
         return (x if identity is None else identity) + self.layers[1](self._hidden(x))

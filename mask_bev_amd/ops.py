@@ -681,6 +681,126 @@ def msda_query_side(x, pos, ref, value_proj, sampling_offsets, attention_weights
 
 
 # --------------------------------------------------------------------------------------
+# K17 16-bit MFMA GEMMs (csrc/gemm.hip)
+# --------------------------------------------------------------------------------------
+_GEMM16_DT = {torch.bfloat16: 0, torch.float16: 1}
+_ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
+
+
+def gemm16_enabled() -> bool:
+    """A/B switch: MBV_GEMM16=0 sends every Linear back to the library GEMM."""
+    import os
+    return os.environ.get('MBV_GEMM16', '1') != '0'
+
+
+def gemm16_policy() -> str:
+    """Which Linear work runs on K17 (csrc/gemm.hip) instead of the library GEMM.  MBV_GEMM16 =
+    ``auto`` (default): the fused forms — FFN input layer + activation, FFN output layer's data gradient + activation
+    backward + bias gradient — and the arena-accumulating weight gradient, for token counts where K17 measured at or
+    above the library (scratch/bench_gemm.py, profiles/r02); ``all``: every eligible Linear, forward and backward;
+    ``0``: none (the round-1 path)."""
+    import os
+    v = os.environ.get('MBV_GEMM16', 'auto')
+    return {'1': 'auto', '0': 'none'}.get(v, v)
+
+
+_K17_MIN_TOKENS = 8192        # below this the 128 x 128 tiles under-fill the chip and the library's split / stream-K wins
+
+
+def _k17_wants(kind: str, tokens: int) -> bool:
+    pol = gemm16_policy()
+    if pol == 'none':
+        return False
+    if pol == 'all':
+        return True
+    return kind in ('fused', 'wgrad') and tokens >= _K17_MIN_TOKENS
+
+
+def _gemm16_ok(*ts: torch.Tensor) -> bool:
+    dt = ts[0].dtype
+    return (dt in _GEMM16_DT and all(t.is_cuda and t.dtype == dt and t.dim() == 2 and t.stride(1) == 1
+                                     and t.stride(0) % 8 == 0 and t.shape[1] % 8 == 0 and t.data_ptr() % 16 == 0
+                                     and t.shape[0] * t.stride(0) * 2 < 0x7fff0000 for t in ts))
+
+
+def gemm16_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+              out_dtype: Optional[torch.dtype] = None, want_pre: bool = False):
+    """``act(x (M, K) @ w (N, K)^T + bias)`` on K17 (bf16 / fp16 inputs, f32 accumulation).  Returns ``out`` or
+    ``(out, pre_activation)`` with ``want_pre``.  ``bias`` f32 (N,).  Raises MaskBevHipError for shapes K17 does not take
+    (check with :func:`gemm16_nt_ok`)."""
+    lib = _lib.load()
+    if not _gemm16_ok(x, w) or x.shape[1] != w.shape[1]:
+        raise MaskBevHipError('gemm16_nt: unsupported operands')
+    m, k = x.shape
+    n = w.shape[0]
+    od = out_dtype or x.dtype
+    if od not in (x.dtype, torch.float32):
+        raise MaskBevHipError('gemm16_nt: out dtype must be the input dtype or f32')
+    out = torch.empty((m, n), dtype=od, device=x.device)
+    pre = torch.empty((m, n), dtype=od, device=x.device) if (want_pre and _ACT[act]) else None
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16):
+        raise MaskBevHipError('gemm16_nt: bias must be contiguous f32, 16-byte aligned')
+    check(lib.mbv_gemm16_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pre), m, n, k, x.stride(0), w.stride(0), n,
+                            _GEMM16_DT[x.dtype], int(od == torch.float32), _ACT[act], 1, 0, 0, 0, _stream()),
+          'mbv_gemm16_nt')
+    return (out, pre) if want_pre else out
+
+
+def gemm16_nn(g: torch.Tensor, w: torch.Tensor, act: Optional[str] = None, aux: Optional[torch.Tensor] = None,
+              colsum: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``act'(aux) * (g (M, N) @ w (N, K))`` on K17: the data gradient of a Linear, optionally multiplied by the
+    derivative of the activation in front of it (``aux``: ReLU output / GELU pre-activation, (M, K)) with the column
+    sums of the result added to ``colsum`` (K,) f32."""
+    lib = _lib.load()
+    if not _gemm16_ok(g, w) or g.shape[1] != w.shape[0]:
+        raise MaskBevHipError('gemm16_nn: unsupported operands')
+    m, n = g.shape
+    k = w.shape[1]
+    a = _ACT[act]
+    if a and (aux is None or not _gemm16_ok(aux) or aux.dtype != g.dtype or tuple(aux.shape) != (m, k)):
+        raise MaskBevHipError('gemm16_nn: aux must be a (M, K) tensor of the input dtype')
+    od = out_dtype or g.dtype
+    out = torch.empty((m, k), dtype=od, device=g.device)
+    if colsum is not None and (colsum.dtype != torch.float32 or not colsum.is_contiguous()):
+        raise MaskBevHipError('gemm16_nn: colsum must be contiguous f32')
+    ws = _workspace(lib.mbv_gemm16_nn_workspace_bytes(m, k, 1), g.device) if colsum is not None else None
+    check(lib.mbv_gemm16_nn(_ptr(g), _ptr(w), _ptr(out), _ptr(aux if a else None), _ptr(colsum), m, n, k, g.stride(0),
+                            w.stride(0), k, aux.stride(0) if a else 0, _GEMM16_DT[g.dtype],
+                            int(od == torch.float32), a, 1, 0, 0, 0, _ptr(ws), 0 if ws is None else ws.numel(),
+                            _stream()), 'mbv_gemm16_nn')
+    return out
+
+
+def gemm16_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, splits: int = 0) -> None:
+    """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` on K17 (split over M, f32 atomic adds): the weight gradient of a
+    Linear accumulated straight into the arena."""
+    lib = _lib.load()
+    if (not _gemm16_ok(g, x) or g.shape[0] != x.shape[0] or acc.dtype != torch.float32 or acc.stride(1) != 1
+            or tuple(acc.shape) != (g.shape[1], x.shape[1]) or acc.data_ptr() % 16):
+        raise MaskBevHipError('gemm16_tn_acc: unsupported operands')
+    m, n = g.shape
+    k = x.shape[1]
+    check(lib.mbv_gemm16_tn(_ptr(g), _ptr(x), _ptr(acc), m, n, k, g.stride(0), x.stride(0), acc.stride(0),
+                            _GEMM16_DT[g.dtype], 1, 1, int(splits), 1, 0, 0, 0, _stream()), 'mbv_gemm16_tn')
+
+
+def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``g (B, M, N)^T @ x (B, M, K)`` → (B, N, K), stored once per tile (no split over M)."""
+    lib = _lib.load()
+    if g.dim() != 3 or x.dim() != 3 or g.shape[:2] != x.shape[:2] or not g.is_contiguous() or not x.is_contiguous():
+        raise MaskBevHipError('gemm16_tn: (B, M, N) and (B, M, K) contiguous operands')
+    if not _gemm16_ok(g[0], x[0]):
+        raise MaskBevHipError('gemm16_tn: unsupported operands')
+    b, m, n = g.shape
+    k = x.shape[2]
+    od = out_dtype or g.dtype
+    out = torch.empty((b, n, k), dtype=od, device=g.device)
+    check(lib.mbv_gemm16_tn(_ptr(g), _ptr(x), _ptr(out), m, n, k, n, k, k, _GEMM16_DT[g.dtype], 0,
+                            int(od == torch.float32), 1, b, m * n, m * k, n * k, _stream()), 'mbv_gemm16_tn')
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # Linear layers: library GEMMs, with a split-K weight gradient for token-major activations
 # --------------------------------------------------------------------------------------
 def _wgrad_splits(tokens: int) -> int:
@@ -739,6 +859,10 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add).
     Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch."""
     t = g2.shape[0]
+    if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and _k17_wants('wgrad', t) and acc.stride(-1) == 1
+            and _gemm16_ok(g2, x2) and acc.data_ptr() % 16 == 0):
+        gemm16_tn_acc(acc, g2, x2)               # K17: split over the tokens, f32 atomic adds into the arena
+        return False
     if (g2.dtype == torch.float32 and x2.dtype == torch.float32 and t <= _SMALL_F32_ROWS and g2.is_cuda
             and acc.is_contiguous()):
         lib = _lib.load()
@@ -783,8 +907,14 @@ class _Linear(torch.autograd.Function):
         if rows is not None:
             w = w[rows[0]:rows[1]]
             b = None if b is None else b[rows[0]:rows[1]]
+        x2k = x.reshape(-1, x.shape[-1]) if x.is_cuda and x.dtype in _GEMM16_DT else None
         with torch.autocast('cuda', enabled=False):
-            if f32_out and x.dtype == torch.bfloat16 and x.is_cuda:
+            if (x2k is not None and gemm16_policy() == 'all' and _gemm16_ok(x2k, w)
+                    and (bias is None or bias.dtype == torch.float32)):
+                bf = None if bias is None else (bias if rows is None else bias[rows[0]:rows[1]])
+                y = gemm16_nt(x2k, w, bf, out_dtype=torch.float32 if f32_out else None)
+                y = y.view(x.shape[:-1] + (w.shape[0],))
+            elif f32_out and x.dtype == torch.bfloat16 and x.is_cuda:
                 # bf16 GEMM with the f32 accumulators stored as f32 (the consumer wants f32: no cast pass)
                 x2 = x.reshape(-1, x.shape[-1])
                 if bias is not None:
@@ -809,7 +939,10 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = g2.mm(w).view_as(x)
+            if gemm16_policy() == 'all' and g2.is_cuda and _gemm16_ok(g2, w):
+                gx = gemm16_nn(g2, w).view_as(x)
+            else:
+                gx = g2.mm(w).view_as(x)
         bias_direct = (bias is not None and ctx.needs_input_grad[2] and getattr(bias, '_mbv_arena', False)
                        and bias.grad is not None and bias.grad.dtype == torch.float32)
         bias_done = ctx.skip_bias_grad        # the consumer of this layer's output accumulates db (K12 / activation op)
@@ -850,6 +983,82 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
     direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
     return _Linear.apply(x, weight, bias, rows, f32_out, skip_bias_grad)
+
+
+class _FFN(torch.autograd.Function):
+    """``fc2(act(fc1(x)))`` of an mmcv FFN (/root/reference: mask_bev/models/networks/swin/swin.py:347-377) with the
+    element-wise work folded into K17's epilogues: forward, fc1 + bias + activation in one launch (stores the
+    pre-activation for GELU); backward, the data gradient of fc2 times the activation derivative with the column sums
+    of the result (= d bias of fc1) in one launch, the two weight gradients accumulated straight into the arena, and no
+    separate activation / bias kernels.  Parameters must live in a parameter arena (bf16 shadow, f32 gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, kind, defer_out_bias):
+        dt = torch.get_autocast_dtype('cuda')
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != dt:
+            x2 = x2.to(dt)
+        w1c, w2c = _compute_copy(w1, dt), _compute_copy(w2, dt)
+        if kind == 'gelu':
+            a, h = gemm16_nt(x2, w1c, b1, act='gelu', want_pre=True)
+        else:
+            a, h = gemm16_nt(x2, w1c, b1, act='relu'), None
+        if gemm16_policy() == 'all':
+            out = gemm16_nt(a, w2c, b2)
+        else:
+            out = torch.nn.functional.linear(a, w2c, _compute_copy(b2, dt))
+        ctx.save_for_backward(x2, a if h is None else h, a, w1c, w2c)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.kind, ctx.defer_out_bias, ctx.xshape = kind, defer_out_bias, x.shape
+        return out.view(x.shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, aux, a, w1c, w2c = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        g2 = gout.reshape(-1, gout.shape[-1])
+        if g2.dtype != x2.dtype:
+            g2 = g2.to(x2.dtype)
+        g2 = g2.contiguous()
+        t = g2.shape[0]
+        # d hidden = (g . W2) * act'(.), column sums -> d b1
+        dh = gemm16_nn(g2, w2c, act=ctx.kind, aux=aux, colsum=b1.grad)
+        _fire_grad_hooks(b1)
+        _wgrad_into(w2.grad, g2, a)
+        _fire_grad_hooks(w2)
+        if not ctx.defer_out_bias:
+            colsum_accum(g2, b2.grad)
+            _fire_grad_hooks(b2)
+        _wgrad_into(w1.grad, dh, x2)
+        _fire_grad_hooks(w1)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (gemm16_nn(dh, w1c) if gemm16_policy() == 'all' else dh.mm(w1c)).view(ctx.xshape)
+        return gx, None, None, None, None, None, None
+
+
+def ffn_fused_ok(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b) -> bool:
+    """The fused FFN (K17 epilogues) applies: 16-bit autocast on a ROCm device, arena-resident parameters with f32
+    gradients, token count in K17's range, 16-byte-chunk shapes."""
+    if not (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.is_grad_enabled()):
+        return False
+    dt = torch.get_autocast_dtype('cuda')
+    rows = x.numel() // max(1, x.shape[-1])
+    if dt not in _GEMM16_DT or not _k17_wants('fused', rows):
+        return False
+    for p in (fc1_w, fc1_b, fc2_w, fc2_b):
+        if p is None or not getattr(p, '_mbv_arena', False) or p.grad is None or p.grad.dtype != torch.float32:
+            return False
+        sh = getattr(p, '_mbv_shadow', None)
+        if p.dim() == 2 and (sh is None or sh.dtype != dt):
+            return False
+    return fc1_w.shape[0] % 8 == 0 and fc1_w.shape[1] % 8 == 0 and fc2_w.shape[0] % 8 == 0
+
+
+def ffn(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b, kind: str, defer_out_bias: bool = False) -> torch.Tensor:
+    """``fc2(act(fc1(x)))`` through :class:`_FFN` (check :func:`ffn_fused_ok` first).  ``defer_out_bias``: the
+    consumer of the result (K12 with ``branch_bias``) accumulates d b2."""
+    return _FFN.apply(x, fc1_w, fc1_b, fc2_w, fc2_b, kind, defer_out_bias)
 
 
 # --------------------------------------------------------------------------------------
