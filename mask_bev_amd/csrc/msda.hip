@@ -10,6 +10,8 @@
 // Forward is a gather (L2-resident value maps); backward scatters grad_value with f32 atomics
 // (1.06 GB of adds per layer at B=4 → bounded by the ≈1.3 TB/s chip-wide atomic rate)
 // and reduces grad_location / grad_weight over the D lanes with in-wave shuffles.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -351,6 +353,164 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_banded(const float* __restric
   }
 }
 
+// Banded backward, 4 channels per lane (head_dim = 32): 8 lanes share a (query, head) and a lane owns one 16-byte
+// piece of the 128-byte pixel rows, exactly as in k_msda_fwd_v4.  Against one channel per lane this divides the
+// bilinear set-up, the header loads and the cross-lane reductions of the location / weight gradients by four and puts
+// 128 queries instead of 32 in flight per workgroup (a workgroup's queries take a quarter of the dependent
+// memory round trips); the LDS atomics stay one ds_add_f64 per (corner, channel).
+__device__ __forceinline__ float group8_sum_dpp(float v) {
+#define MBV_DPP_ADD(ctrl, bmask)                                                                              \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, bmask, true));
+  MBV_DPP_ADD(0xB1, 0xf)    // quad_perm [1,0,3,2]: + lane ^ 1
+  MBV_DPP_ADD(0x4E, 0xf)    // quad_perm [2,3,0,1]: + lane ^ 2   (every lane holds its quad's sum)
+  MBV_DPP_ADD(0x114, 0xa)   // row_shr:4 into banks 1 and 3: lanes 4-7 (12-15) += lanes 0-3 (8-11)
+#undef MBV_DPP_ADD
+  return v;                 // lanes 4..7 of every aligned group of 8 hold the group's sum
+}
+
+__global__ void __launch_bounds__(1024) k_msda_bwd_banded4(const float* __restrict__ grad_out,
+                                                          const float* __restrict__ value,
+                                                          const float* __restrict__ loc, const float* __restrict__ attn,
+                                                          MsdaBands cfg, int num_value, int heads, int points, int ablate,
+                                                          float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                                          float* __restrict__ grad_attn) {
+  constexpr int dim = 32;
+  __shared__ double map[16384];
+  int level = 0;
+  while (level + 1 < cfg.levels && (int)blockIdx.x >= cfg.block_begin[level + 1]) ++level;
+  const int local = blockIdx.x - cfg.block_begin[level];
+  const int chunks = cfg.chunks[level], bands = cfg.bands[level];
+  const int chunk = local % chunks, band = (local / chunks) % bands, bh = local / (chunks * bands);
+  const int hd = bh % heads, b = bh / heads;
+  const int h = cfg.h[level], w = cfg.w[level], lstart = cfg.lstart[level], levels = cfg.levels;
+  const int R0 = band * cfg.band_rows[level], R1 = min(h, R0 + cfg.band_rows[level]);
+  const int map_n = (R1 - R0) * w * dim;
+  for (int i = threadIdx.x; i < map_n; i += 1024) map[i] = 0.0;
+  int rbeg[8], rend[8], total = 0;
+#pragma unroll
+  for (int lq = 0; lq < 8; ++lq) {
+    rbeg[lq] = rend[lq] = 0;
+    if (lq < levels) {
+      const int hq = cfg.h[lq], wq = cfg.w[lq];
+      auto first_row = [&](int R) {          // smallest y with reference row >= R
+        const int num = 2 * hq * R - h;
+        int y = num <= 0 ? 0 : (num + 2 * h - 1) / (2 * h);
+        return y > hq ? hq : y;
+      };
+      rbeg[lq] = cfg.lstart[lq] + first_row(R0) * wq;
+      rend[lq] = cfg.lstart[lq] + (R1 >= h ? hq : first_row(R1)) * wq;
+      total += rend[lq] - rbeg[lq];
+    }
+  }
+  const int per = (total + chunks - 1) / chunks;
+  const int i0 = min(total, chunk * per), i1 = min(total, i0 + per);
+  const int d4 = threadIdx.x & 7, slot = threadIdx.x >> 3;      // 128 query slots of 8 lanes
+  const int stride_pix = heads * dim;
+  const int64_t slab = ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + d4 * 4;
+  const int band_px = (R1 - R0) * w;
+  __syncthreads();
+  constexpr int U = 2;     // 16-byte gathers: 2 points x 4 corners x 4 registers in flight per lane
+  const int nq_mine = i1 - i0;
+  for (int n0 = 0; n0 < nq_mine; n0 += 128) {                  // wave-uniform trip count
+    const int n = n0 + slot;
+    const bool qlive = n < nq_mine;
+    int qi = i0 + (qlive ? n : nq_mine - 1);
+    int q = 0;
+#pragma unroll
+    for (int lq = 0; lq < 8; ++lq) {
+      const int cnt = rend[lq] - rbeg[lq];
+      if (qi >= 0 && qi < cnt) q = rbeg[lq] + qi;
+      qi -= cnt;
+    }
+    const int64_t qh = ((int64_t)b * num_value + q) * heads + hd;
+    const float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + d4 * 4);
+    for (int p0 = 0; p0 < points; p0 += U) {
+      bool live[U];
+      int64_t kk[U];
+      float lx[U], ly[U], aw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        live[u] = qlive && p0 + u < points;
+        kk[u] = (qh * levels + level) * points + (p0 + u < points ? p0 + u : points - 1);
+        lx[u] = loc[kk[u] * 2];
+        ly[u] = loc[kk[u] * 2 + 1];
+        aw[u] = attn[kk[u]];
+      }
+      Corner c[U];
+      bool inside[U];
+      float4 v[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        inside[u] = bilinear_setup(lx[u], ly[u], h, w, 1, c[u]);              // offsets in pixels
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (inside[u] && c[u].off[j] >= 0 && !(ablate & 4))
+            v[u][j] = *reinterpret_cast<const float4*>(value + slab + (int64_t)c[u].off[j] * stride_pix);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+        if (inside[u]) {
+          const float a = aw[u];
+          if (live[u]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int off = c[u].off[j];
+              if (off >= 0) {
+                const float wj = c[u].wgt[j] * a;
+                const int rel = off - R0 * w;
+                if (rel >= 0 && rel < band_px) {
+                  if (ablate & 1) continue;
+                  double* m = &map[rel * dim + d4 * 4];
+                  atomicAdd(m, (double)(wj * go.x));
+                  atomicAdd(m + 1, (double)(wj * go.y));
+                  atomicAdd(m + 2, (double)(wj * go.z));
+                  atomicAdd(m + 3, (double)(wj * go.w));
+                } else {
+                  if (ablate & 2) continue;
+                  float* gv = grad_value + slab + (int64_t)off * stride_pix;
+                  atomicAdd(gv, wj * go.x);
+                  atomicAdd(gv + 1, wj * go.y);
+                  atomicAdd(gv + 2, wj * go.z);
+                  atomicAdd(gv + 3, wj * go.w);
+                }
+              }
+            }
+          }
+          // sum over this lane's 4 channels of go . v_j for each corner, then the bilinear combinations
+          float s[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            s[j] = go.x * v[u][j].x + go.y * v[u][j].y + go.z * v[u][j].z + go.w * v[u][j].w;
+          const float uh = 1.f - c[u].lh, uw = 1.f - c[u].lw;
+          g_w = c[u].wgt[0] * s[0] + c[u].wgt[1] * s[1] + c[u].wgt[2] * s[2] + c[u].wgt[3] * s[3];
+          const float gh = -uw * s[0] - c[u].lw * s[1] + uw * s[2] + c[u].lw * s[3];
+          const float gw = -uh * s[0] + uh * s[1] - c[u].lh * s[2] + c[u].lh * s[3];
+          g_x = (float)w * gw * a;
+          g_y = (float)h * gh * a;
+        }
+        if (ablate & 8) continue;
+        g_w = group8_sum_dpp(g_w);
+        g_x = group8_sum_dpp(g_x);
+        g_y = group8_sum_dpp(g_y);
+        if (live[u] && d4 == 7) {
+          grad_attn[kk[u]] = g_w;
+          grad_loc[kk[u] * 2] = g_x;
+          grad_loc[kk[u] * 2 + 1] = g_y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t gbase = ((int64_t)b * num_value + lstart + R0 * w) * stride_pix + hd * dim;
+  for (int i = threadIdx.x; i < map_n; i += 1024) {
+    const double v = map[i];
+    if (v != 0.0) atomicAdd(grad_value + gbase + (int64_t)(i / dim) * stride_pix + (i % dim), (float)v);
+  }
+}
+
 bool pow2_le64(int d) { return d > 0 && d <= 64 && (d & (d - 1)) == 0; }
 
 }  // namespace
@@ -416,6 +576,17 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
     }
     if (ok && lstart == num_value) {
       cfg.block_begin[num_levels] = blocks;
+      // A/B switch: the four-channels-per-lane form (measured equal, 0.40 ms: cheaper set-up and LDS adds, but its
+      // out-of-band global atomics are 16-byte pieces instead of whole 128-byte rows — see DESIGN.md K5)
+      const char* four = getenv("MBV_MSDA_BWD_4CH");
+      if (head_dim == 32 && four && four[0] == '1' &&
+          ((reinterpret_cast<size_t>(grad_out) | reinterpret_cast<size_t>(value)) & 15) == 0) {
+        hipLaunchKernelGGL(k_msda_bwd_banded4, dim3((unsigned)blocks), dim3(1024), 0, stream, grad_out, value,
+                           sampling_loc, attn_weight, cfg, num_value, num_heads, num_points,
+                           getenv("MBV_MSDA_ABLATE") ? atoi(getenv("MBV_MSDA_ABLATE")) : 0, grad_value, grad_loc, grad_attn);
+        MBV_CHECK_LAUNCH();
+        return MBV_OK;
+      }
       hipLaunchKernelGGL(k_msda_bwd_banded, dim3((unsigned)blocks), dim3(1024), 0, stream, grad_out, value, sampling_loc,
                          attn_weight, cfg, num_value, num_heads, head_dim, num_points, grad_value, grad_loc, grad_attn);
       MBV_CHECK_LAUNCH();
