@@ -9,9 +9,16 @@ scans already resident in HBM: voxelise → PFN → scatter+LN → Swin → pixe
 Rank 0 prints ONE JSON line (metric of BASELINE.json: LiDAR scans/s fwd+bwd, whole job).
 
 Extra objects on the line:
-  roofline      HBM roofline of the dominant hand-written kernel, timed with HIP events recorded by the library
-                on its launch stream inside the timed region.
-  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample.
+  roofline      roofline of the kernel of this repository that costs the most time per step (launches x average
+                duration): algorithmic bytes (HBM-bound) or flops (MFMA-bound) of one launch over its average launch
+                duration, measured live with HIP events on the stream the kernel is launched on.  K3's kernels and
+                the optimizer kernel run eagerly inside the timed region and are timed there; the kernels inside the
+                replayed HIP graphs cannot carry events, so every C-ABI call of two eager steps run right AFTER the
+                timed region is bracketed by events instead (mask_bev_amd/workmodel.py holds the work of each call).
+                `roofline_all` lists every instrumented kernel, ranked by time per step; `traffic` is the measured HBM
+                bytes per launch from the PMC passes kept in `roofline_traffic_source` (null when not measured).
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample:
+                1 warm-up + 3 iterations, forward and forward+backward, at os.cpu_count() and at 6 threads.
 """
 from __future__ import annotations
 
@@ -30,8 +37,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=150)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='semantic_kitti_512')
     ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (YAML batch_size)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'])
@@ -39,46 +46,174 @@ def parse():
                     help="synthetic point distribution: 64-beam LiDAR-shaped scans (headline) or uniform x/y "
                          "(worst case for the pillar count)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-budget-s', type=float, default=90.0)
+    ap.add_argument('--cpu-baseline-budget-s', type=float, default=120.0)
+    ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-threads', type=int, default=6, help=argparse.SUPPRESS)
+    ap.add_argument('--no-kernel-profile', action='store_true', help='skip the instrumented eager step behind roofline_all')
     ap.add_argument('--pool', type=int, default=2, help='distinct synthetic batches kept resident in HBM')
     ap.add_argument('--no-arena', action='store_true', help='per-tensor parameters and torch.optim.AdamW')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the HIP graph')
     return ap.parse_args()
 
 
-def cpu_baseline(workload: str, module, budget_s: float):
-    """Oracle forward + loss + backward on the host cores, batch of 1 scan of the same workload, fp32.
-    ORACLE USE: checker/baseline only — never on the measured GPU path.
-    Threads: 6, the value the reference pins (``OMP_NUM_THREADS=6``, /root/reference: train_mask_bev.py:14);
-    oversubscribing a many-core host with tiny torch ops is an order of magnitude slower."""
+def cpu_baseline_worker(state_file: str, workload: str, threads: int, budget_s: float):
+    """One thread setting of the CPU baseline, in a process of its own (so that a pathological setting can be cut off):
+    1 warm-up + up to 3 timed iterations of forward+loss+backward and of forward+loss of the oracle on 1 scan."""
     from oracle import maskbev_oracle as O
     from mask_bev_amd import synthetic
+    torch.set_num_threads(threads)
     kw = synthetic.module_kwargs(workload, 1)
     cfg = O.make_cfg(**kw)
-    sd = {k: v.detach().float().cpu() for k, v in module.state_dict().items()}
-    sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
-            for k, v in sd.items()}
-    cores = min(6, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    sd = torch.load(state_file)
     scans, (labels, masks) = synthetic.make_batch(workload, 1, 0, 10_000, torch.device('cpu'))
-    t0 = time.perf_counter()
-    cls, mk, _ = O.model_forward(cfg, sd_g, scans, training=True)
-    loss = O.total_loss(O.loss_dict(cfg, cls, mk, labels, masks, O.PointSource(0)))
-    t_fwd = time.perf_counter() - t0
-    if t_fwd > budget_s / 3.0:      # keep the default run within minutes: do not start the backward
-        return dict(value=1.0 / (3.0 * t_fwd), unit='scans/s', cores=cores, kind='port',
-                    sample=f'1 scan of {workload}, fp32, oracle forward+loss only ({t_fwd:.1f} s, over budget); '
-                           f'value assumes backward = 2x forward; torch threads = {cores}')
-    loss.backward()
-    t_all = time.perf_counter() - t0
-    return dict(value=1.0 / t_all, unit='scans/s', cores=cores, kind='port',
-                sample=f'1 scan of {workload}, fp32, oracle forward+loss+backward, 1 iteration '
-                       f'(forward+loss {t_fwd:.1f} s, total {t_all:.1f} s), torch threads = {cores} '
-                       f'(the reference pins OMP_NUM_THREADS=6)')
+
+    def one(backward: bool) -> float:
+        sd_g = {k: (v.clone().requires_grad_(backward) if v.is_floating_point() and 'running_' not in k else v.clone())
+                for k, v in sd.items()}
+        t0 = time.perf_counter()
+        with torch.set_grad_enabled(backward):
+            cls, mk, _ = O.model_forward(cfg, sd_g, scans, training=True)
+            loss = O.total_loss(O.loss_dict(cfg, cls, mk, labels, masks, O.PointSource(0)))
+        if backward:
+            loss.backward()
+        return time.perf_counter() - t0
+
+    t_warm = one(True)                                        # warm-up (allocator, thread pools)
+    print(json.dumps(dict(stage='warmup', s=t_warm)), flush=True)
+    iters = 3 if t_warm * 5.0 <= budget_s else (1 if t_warm * 2.5 <= budget_s else 0)
+    fb = [one(True) for _ in range(iters)]
+    fw = [one(False) for _ in range(iters)]
+    print(json.dumps(dict(stage='done', iterations=iters, warmup_s=t_warm, fwd_bwd_s=fb, fwd_s=fw)), flush=True)
+
+
+def cpu_baseline(workload: str, module, budget_s: float):
+    """The oracle (CPU restatement of the reference's dense algorithm, kind "port") on the host cores of this box, on
+    a bounded sample: 1 scan of the same workload per iteration, fp32.  ORACLE USE: checker / baseline only — never
+    on the measured GPU path.  Protocol of SURVEY.md §8d / BASELINE.md §3: 1 warm-up + 3 timed iterations, forward(+loss)
+    and forward+backward timed separately, at 6 threads (the reference pins ``OMP_NUM_THREADS=6``,
+    /root/reference: train_mask_bev.py:14) and at ``os.cpu_count()`` threads.  Each thread setting runs in a child
+    process with a share of the time budget: a many-core host oversubscribed with the oracle's tiny torch ops can be
+    an order of magnitude slower, and the default bench run must still end within minutes — a setting that exceeds its
+    share is cut off and says so.  ``value`` is the best forward+backward rate; every row is kept."""
+    import subprocess
+    import tempfile
+    sd = {k: v.detach().float().cpu() for k, v in module.state_dict().items()}
+    settings = sorted({min(6, os.cpu_count() or 1), os.cpu_count() or 1})
+    share = budget_s / len(settings)
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        state_file = os.path.join(tmp, 'state.pt')
+        torch.save(sd, state_file)
+        for threads in settings:
+            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', state_file, '--workload', workload,
+                   '--cpu-threads', str(threads), '--cpu-baseline-budget-s', str(share)]
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+            t0, out, timed_out = time.perf_counter(), '', False
+            try:
+                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=share * 1.5 + 30).stdout
+            except subprocess.TimeoutExpired as e:
+                out, timed_out = (e.stdout or b'').decode() if isinstance(e.stdout, bytes) else (e.stdout or ''), True
+            recs = [json.loads(l) for l in out.splitlines() if l.startswith('{')]
+            done = next((r for r in recs if r.get('stage') == 'done'), None)
+            warm = next((r for r in recs if r.get('stage') == 'warmup'), None)
+            row = dict(threads=threads, wall_s=round(time.perf_counter() - t0, 1))
+            if done and done['iterations'] > 0:
+                fb, fw = done['fwd_bwd_s'], done['fwd_s']
+                row.update(iterations=done['iterations'], warmup_s=round(done['warmup_s'], 2),
+                           fwd_bwd_s=[round(t, 2) for t in fb], fwd_s=[round(t, 2) for t in fw],
+                           fwd_bwd_scans_per_s=len(fb) / sum(fb), fwd_scans_per_s=len(fw) / sum(fw),
+                           note=None if done['iterations'] == 3 else 'iteration count cut to fit the time budget')
+            elif warm or done:
+                t = (done or warm).get('warmup_s', (warm or {}).get('s'))
+                row.update(iterations=0, warmup_s=round(t, 2), fwd_bwd_s=[round(t, 2)], fwd_s=[],
+                           fwd_bwd_scans_per_s=1.0 / t, fwd_scans_per_s=None,
+                           note='too slow for the time budget: the warm-up iteration is the only sample'
+                                + (' (cut off)' if timed_out else ''))
+            else:
+                row.update(iterations=0, fwd_bwd_scans_per_s=None, fwd_scans_per_s=None,
+                           note='cut off before the warm-up iteration finished' if timed_out else 'failed')
+            rows.append(row)
+    ok = [r for r in rows if r.get('fwd_bwd_scans_per_s')]
+    if not ok:
+        return dict(value=None, unit='scans/s', cores=None, kind='port', sample='no thread setting finished', rows=rows)
+    best = max(ok, key=lambda r: r['fwd_bwd_scans_per_s'])
+    return dict(value=best['fwd_bwd_scans_per_s'], unit='scans/s', cores=best['threads'], kind='port',
+                sample=f'1 scan of {workload} per iteration, fp32, oracle forward+loss+backward; 1 warm-up + '
+                       f'{best["iterations"]} timed iterations; thread settings {settings} '
+                       f'(host has {os.cpu_count()} logical cores; the reference pins OMP_NUM_THREADS=6)',
+                rows=rows)
+
+
+def kernel_profile(model, opt, batch, steps: int = 2):
+    """HIP-event duration of every C-ABI call of `steps` eager training steps (after one untimed eager step), on the
+    stream the kernels are launched on, with the algorithmic work of each call (mask_bev_amd/workmodel.py).
+    Runs AFTER the timed region: the timed steps replay HIP graphs, which cannot carry per-kernel events.
+    Returns {kernel: dict(launches_per_step, avg_ms, total_ms_per_step, bytes, flops, bound)}."""
+    from mask_bev_amd import _lib, workmodel
+    lib = _lib.load()
+    records = []
+
+    def hook(name, fn, args):
+        model_fn = workmodel.MODELS.get(name)
+        if model_fn is None:
+            return fn(*args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        records.append((model_fn(args), a, b))
+        return rc
+
+    def one(i):
+        loss = model.training_step(batch, i)
+        loss.backward()
+        opt.step()
+        if not getattr(opt, 'zero_grad_in_step', False):
+            opt.zero_grad(set_to_none=False)
+
+    one(0)
+    torch.cuda.synchronize()
+    lib.hook = hook
+    try:
+        for i in range(steps):
+            one(1 + i)
+        torch.cuda.synchronize()
+    finally:
+        lib.hook = None
+    agg = {}
+    for (kernel, bound, nbytes, flops), a, b in records:
+        e = agg.setdefault(kernel, dict(kernel=kernel, bound=bound, launches=0, ms=0.0, bytes=0.0, flops=0.0))
+        e['launches'] += 1
+        e['ms'] += a.elapsed_time(b)
+        e['bytes'] += nbytes
+        e['flops'] += flops
+    out = {}
+    for k, e in agg.items():
+        n = e['launches']
+        out[k] = dict(kernel=k, bound=e['bound'], launches_per_step=n / steps, avg_ms=e['ms'] / n,
+                      total_ms_per_step=e['ms'] / steps, algorithmic_bytes=e['bytes'] / n,
+                      algorithmic_flops=e['flops'] / n)
+    return out
+
+
+def roofline_entry(kernel, bound, avg_ms, launches_per_step, nbytes, flops, traffic, source):
+    """One `roofline` object: achieved = algorithmic bytes (HBM-bound kernels) or flops (MFMA-bound) of one launch
+    over its average duration, against the chip peak of MI355X_MICROARCH.md."""
+    from mask_bev_amd import workmodel
+    peak, unit = workmodel.peak_of(bound)
+    work = flops if bound.startswith('mfma') else nbytes
+    achieved = work / (avg_ms * 1e-3) / (1e12 if bound.startswith('mfma') else 1e9)
+    return dict(bound='mfma' if bound.startswith('mfma') else 'hbm', achieved=achieved, peak=peak, unit=unit,
+                frac=achieved / peak, traffic=traffic, kernel=kernel, avg_ms=avg_ms,
+                launches_per_step=launches_per_step, total_ms_per_step=avg_ms * launches_per_step,
+                algorithmic_bytes=nbytes, algorithmic_flops=flops, timing=source)
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.cpu_baseline_worker, args.workload, args.cpu_threads, args.cpu_baseline_budget_s)
+        return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,6 +311,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    profile = {}
+    if world == 1 and not args.no_kernel_profile:
+        profile = kernel_profile(model, opt, pool[0])
     replica_spread = None
     if world > 1:
         # data-parallel sanity, outside the timed region: every rank must hold the same parameters after the run
@@ -203,20 +341,28 @@ def main():
                 'k_ln_bwd_dense': args.batch * c * cells * io + (c * cells + 2 * c * cells + acc) * 4.0,
                 # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
                 'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
-        # HBM bytes per launch from the PMC passes of profiles/r01 (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of
-        # MI355X_MICROARCH.md); same workload, same build
-        traffic = {'k_ln_apply': 568.8e6, 'k_ln_bwd_dense': 993.7e6, 'k_adamw': 6511.5e6} \
-            if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
-                and args.distribution == 'lidar') else {}
+        # HBM bytes per launch measured with the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+        # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload and build: profiles/r02/pmc_hbm_traffic.json
+        traffic, traffic_file = {}, os.path.join('profiles', 'r02', 'pmc_hbm_traffic.json')
+        if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
+                and args.distribution == 'lidar' and os.path.exists(os.path.join(ROOT, traffic_file))):
+            with open(os.path.join(ROOT, traffic_file)) as fh:
+                traffic = {k: v for k, v in json.load(fh).items() if not k.startswith('_')}
         roof = {}
-        for name, ms in times.items():
+        for name, ms in times.items():          # in-library / in-stream events recorded inside the timed region
             if not ms or name not in algo:
                 continue
             avg = sum(ms) / len(ms)
-            roof[name] = dict(bound='hbm', achieved=algo[name] / (avg * 1e-3) / 1e9, peak=8000.0, unit='GB/s',
-                              frac=algo[name] / (avg * 1e-3) / 1e9 / 8000.0, traffic=traffic.get(name),
-                              kernel=name, avg_ms=avg, launches=len(ms), algorithmic_bytes=algo[name])
-        dominant = max(roof.values(), key=lambda r: r['avg_ms']) if roof else None
+            roof[name] = roofline_entry(name, 'hbm', avg, len(ms) / args.steps, algo[name], 0.0, traffic.get(name),
+                                        'HIP events inside the timed region')
+        for name, e in profile.items():         # the instrumented eager step after the timed region
+            if name in roof:
+                continue
+            roof[name] = roofline_entry(name, e['bound'], e['avg_ms'], e['launches_per_step'], e['algorithmic_bytes'],
+                                        e['algorithmic_flops'], traffic.get(name),
+                                        'HIP events around the C-ABI call, eager step after the timed region')
+        ranked = sorted(roof.values(), key=lambda r: -r['total_ms_per_step'])
+        dominant = ranked[0] if ranked else None      # the kernel that costs the most time per step
         # whole-step figure: algorithmic work per scan of the S2 configuration — 0.97 TFLOP and 4.5 GB
         # forward + backward, plus the optimizer pass shared by the scans of a step — against the chip peaks
         step_roof = None
@@ -235,7 +381,8 @@ def main():
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
                         step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss),
-            roofline=dominant, roofline_all=list(roof.values()), step_roofline=step_roof)
+            roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,
+            step_roofline=step_roof)
         if not args.no_cpu_baseline and world == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.workload, model, args.cpu_baseline_budget_s)

@@ -166,11 +166,15 @@ int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, const float* 
  * value (B, Nv, H, D) f32; spatial_shapes (L, 2) i64 (h, w); level_start (L) i64; sampling_loc
  * (B, Nq, H, L, P, 2) f32 in [0, 1] (x, y); attn_weight (B, Nq, H, L, P) f32; out (B, Nq, H*D) f32.
  * Bilinear sampling at loc*size - 0.5 with zero padding (grid_sample align_corners=False).
- * head_dim must be a power of two <= 64.  Backward zero-fills grad_value itself, then accumulates with
- * f32 atomics (sums may differ in the last bits from run to run).  spatial_shapes_host (nullable): the same (L, 2)
- * shapes in HOST memory; when given and num_query == num_value (self-attention over the multi-scale map, queries
- * in level-major raster order), the backward accumulates bands of every level's map in LDS (f64) and only the
- * flushed bands and out-of-band corners reach grad_value as global atomics.
+ * head_dim must be a power of two <= 64.  spatial_shapes_host (nullable): the same (L, 2) shapes in HOST memory.
+ * Backward, three forms: (a) head_dim == 32, host shapes given, every level map <= 4096 pixels — no global atomics:
+ * d(value) is accumulated per (batch, head, 4-channel group) in a whole-map f64 LDS image and stored once (bitwise
+ * reproducible up to the order of the LDS adds), d(location) / d(weight) are a separate gather; mbv_ms_deform_attn_bwd_split
+ * says whether that form applies, and `part` (1 = the value part, 2 = the location / weight part, 3 = both) lets a
+ * caller enqueue the two independent parts on two streams.  (b) host shapes given and num_query == num_value
+ * (self-attention over the multi-scale map): bands of every level's map in LDS (f64), flushed bands and out-of-band
+ * corners as global f32 atomics.  (c) otherwise: global f32 atomics.  (b) and (c) zero-fill grad_value themselves and
+ * take only part == 3.
  */
 int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
                            const float* sampling_loc, const float* attn_weight,
@@ -178,12 +182,14 @@ int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, co
                            int32_t num_levels, int32_t num_query, int32_t num_points,
                            float* out, void* stream);
 
+int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int64_t* spatial_shapes_host);
+
 int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
                            int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
                            int32_t num_levels, int32_t num_query, int32_t num_points,
                            const int64_t* spatial_shapes_host, float* grad_value, float* grad_loc, float* grad_attn,
-                           void* stream);
+                           int32_t part, void* stream);
 
 /* K16 — the element-wise chain in front of K5, fused (mmcv MultiScaleDeformableAttention.forward:
  * `attention_weights.softmax(-1)`, `offset_normalizer = stack([W_l, H_l])`, `sampling_locations =
@@ -508,6 +514,14 @@ int mbv_gemm16_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
 int mbv_gemm16_nt(const void* x, const void* w, const float* bias, void* out, void* out_pre, int64_t m, int64_t n,
                   int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, int32_t dtype, int32_t out_f32, int32_t act,
                   int32_t batch, int64_t stride_x, int64_t stride_w, int64_t stride_o, void* stream);
+
+/* acc (m, n) f32 += x (m, k) . w (n, k)^T with the sum over k split over `splits` workgroups per tile (0 = choose)
+ * that add with f32 atomics: few-row products with a long contraction — d(mask_embed) = d(logits) . mask_feature^T of
+ * torch.einsum('bqc,bchw->bqhw') (mask_bev/models/networks/mask2former_head/mask2former_head.py:459), 1000 x 256
+ * outputs over 16 384 pixels per sample. */
+int mbv_gemm16_nt_acc(const void* x, const void* w, float* acc, int64_t m, int64_t n, int64_t k, int64_t ldx,
+                      int64_t ldw, int64_t ldacc, int32_t dtype, int32_t splits, int32_t batch, int64_t stride_x,
+                      int64_t stride_w, int64_t stride_acc, void* stream);
 
 size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch);
 

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 class MaskBevHipError(RuntimeError):
@@ -48,7 +48,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_msda_prepare_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_msda_prepare_bwd_ld': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'mbv_ms_deform_attn_bwd_split': (ctypes.c_int, [_I, _I, _P]),
+    'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I,
+                                              _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),
     'mbv_window_attn_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
@@ -85,6 +87,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_attn_fwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, c_size_t, _P]),
     'mbv_gemm16_supported': (ctypes.c_int, [_I, _L, _L, _L]),
     'mbv_gemm16_nt': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _L, _L, _L, _P]),
+    'mbv_gemm16_nt_acc': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _L, _L, _L, _P]),
     'mbv_gemm16_nn_workspace_bytes': (c_size_t, [_L, _L, _I]),
     'mbv_gemm16_nn': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _L, _L, _L, _P,
                                      c_size_t, _P]),
@@ -95,7 +98,23 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
 _lib = None
 
 
-def load() -> ctypes.CDLL:
+class _LibProxy:
+    """The bound library.  ``hook`` (None in normal operation) lets bench.py time every C-ABI call of one eager step
+    with HIP events on the launch stream: ``hook(name, fn, args)`` must return ``fn(*args)``."""
+
+    def __init__(self, lib: ctypes.CDLL):
+        self._lib = lib
+        self.hook = None
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        hook = self.__dict__.get('hook')
+        if hook is None or not name.startswith('mbv_'):
+            return fn
+        return lambda *args: hook(name, fn, args)
+
+
+def load() -> '_LibProxy':
     """Load the shared library, binding every declared symbol; raises if anything is missing."""
     global _lib
     if _lib is not None:
@@ -115,8 +134,8 @@ def load() -> ctypes.CDLL:
     v = lib.mbv_abi_version()
     if v != ABI_VERSION:
         raise MaskBevHipError(f'libmaskbev_hip.so ABI {v} != expected {ABI_VERSION}; rebuild it')
-    _lib = lib
-    return lib
+    _lib = _LibProxy(lib)
+    return _lib
 
 
 def check(rc: int, what: str) -> None:

@@ -144,6 +144,10 @@ class FlatAdam(torch.optim.Optimizer):
         self.decoupled = decoupled
         self.zero_grad_in_step = zero_grad
         self.grad_scale = 1.0
+        frozen = [tuple(p.shape) for p, _ in arena.layout if not p.requires_grad]
+        if frozen:          # the single launch updates (and decays) every element of a segment; torch skips frozen ones
+            raise ValueError(f'FlatAdam updates whole arena segments: {len(frozen)} frozen parameter(s) in the arena '
+                             f'(first shape {frozen[0]}); keep frozen parameters out of the arena')
         pgs = []
         for g in groups:
             a, b = arena.segments[g['segment']]
@@ -208,6 +212,25 @@ class FlatAdam(torch.optim.Optimizer):
             self.exp_avg.copy_(flat['exp_avg'])
             self.exp_avg_sq.copy_(flat['exp_avg_sq'])
             self.steps = int(flat['steps'])
+        elif sd.get('state'):
+            # a torch.optim.Adam / AdamW state_dict (the reference's checkpoints, or a run saved without the arena):
+            # its parameters are numbered in module.parameters() order = the order of the arena layout
+            state = sd['state']
+            if len(state) != len(self.arena.layout):
+                raise ValueError(f'optimizer state has {len(state)} parameters, the arena {len(self.arena.layout)}: '
+                                 'cannot map a per-parameter Adam state onto the arena')
+            steps = 0
+            with torch.no_grad():
+                for idx, (p, o) in enumerate(self.arena.layout):
+                    st = state[idx] if idx in state else state[str(idx)]
+                    if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError(f'optimizer state {idx} has shape {tuple(st["exp_avg"].shape)}, '
+                                         f'parameter {tuple(p.shape)}')
+                    n = p.numel()
+                    self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                    self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    steps = max(steps, int(st['step']))
+            self.steps = steps
         for pg, saved in zip(self.param_groups, sd.get('param_groups', [])):
             for k in ('lr', 'betas', 'eps', 'weight_decay'):
                 if k in saved:

@@ -576,6 +576,40 @@ extern "C" int mbv_gemm16_nt(const void* x, const void* w, const float* bias, vo
   return gemm16_launch(0, 0, act, dtype, a, kb, batch, (hipStream_t)stream);
 }
 
+// acc (m, n) f32 += x (m, k) . w (n, k)^T, the sum over k split over workgroups (f32 atomic adds): for few-row
+// products with a long contraction (the mask-logit backward: 1000 x 256 outputs over 16 384 pixels)
+extern "C" int mbv_gemm16_nt_acc(const void* x, const void* w, float* acc, int64_t m, int64_t n, int64_t k, int64_t ldx,
+                                 int64_t ldw, int64_t ldacc, int32_t dtype, int32_t splits, int32_t batch,
+                                 int64_t stride_x, int64_t stride_w, int64_t stride_acc, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !x || !w || !acc) return MBV_ERR_BAD_ARG;
+  if (dtype < 0 || dtype > 1) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldx & 7) || (ldw & 7) || ldx < k || ldw < k || ldacc < n) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(acc)) & 15) return MBV_ERR_UNSUPPORTED;
+  if (!fits_2g(m, ldx) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
+  if (m == 0 || batch == 0) return MBV_OK;
+  const int kb = gemm16_kb();
+  GemmArgs a = {};
+  a.a = x; a.b = w; a.c = acc;
+  a.gm = (int)m; a.gn = (int)n; a.gk = (int)k;
+  a.lda = (int)ldx; a.ldb = (int)ldw; a.ldc = (int)ldacc;
+  a.sa = stride_x; a.sb = stride_w; a.sc = stride_acc;
+  a.a_bytes = (unsigned)(((m - 1) * ldx + k) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
+  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((n + BN - 1) / BN);
+  const int total_steps = (int)((k + kb - 1) / kb);
+  int s = splits;
+  if (s <= 0) {
+    const long long tiles = (long long)a.ntm * a.ntn * batch;
+    s = (int)((512 + tiles - 1) / tiles);
+    if (s > total_steps * kb / 256) s = total_steps * kb / 256;
+  }
+  if (s < 1) s = 1;
+  if (s > total_steps) s = total_steps;
+  a.ksteps = (total_steps + s - 1) / s;
+  a.splits = (total_steps + a.ksteps - 1) / a.ksteps;
+  a.out_f32 = 1;
+  return gemm16_launch(0, 1, EPI_NONE, dtype, a, kb, batch, (hipStream_t)stream);
+}
+
 extern "C" size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch) {
   return (size_t)((m + BM - 1) / BM) * 2 * (size_t)k * 4 * (size_t)(batch > 0 ? batch : 1);
 }

@@ -511,6 +511,149 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_banded4(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward with no global atomics at all (head_dim = 32, every level map <= 4096 pixels), two independent parts:
+//
+//  location / weight part — d(sampling location), d(attention weight): a pure gather like the forward.  8 lanes share a
+//      (query, head), a lane owns 4 adjacent channels (16-byte gathers of the value rows), the two reductions over the
+//      32 channels are three DPP steps.
+//  value part — d(value): one workgroup owns the WHOLE (h, w) map of one level for 4 of the 32 channels of
+//      one (batch, head) as f64 LDS accumulators in planar [channel][pixel] order (64 x 64 x 4 x 8 B = 128 KB at the
+//      finest level), one lane per query: a corner is four ds_add_f64 whose 64 lanes (64 consecutive queries, so
+//      mostly consecutive pixels) fall on consecutive 8-byte slots.  Nothing can land outside the map, so there are
+//      no out-of-band global atomics (160 us of the banded kernel's 400), every element of grad_value is written
+//      exactly once by plain stores (no zero fill, no flush atomics), and the value map is not read here at all.
+//      The price is that the 8 channel groups each redo the bilinear set-up of every sample (ALU the banded kernel
+//      left idle).
+// d(value) of ONE level: workgroup = (batch, head, 4-channel group); see the comment above.  Launched once per level so
+// that the dynamic LDS is that level's map (128 KB only at the finest level; the coarser levels' workgroups then share
+// CUs).  P = 4: the four sampling points of a (query, head, level) are one 32-byte + one 16-byte load.
+template <int P>
+__global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict__ grad_out,
+                                                        const float* __restrict__ loc, const float* __restrict__ attn,
+                                                        int level, int levels, int h, int w, int lstart, int num_value,
+                                                        int num_query, int heads, int points_rt,
+                                                        float* __restrict__ grad_value) {
+  constexpr int dim = 32, CG = 4;
+  const int points = P > 0 ? P : points_rt;
+  extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
+  int id = blockIdx.x;
+  const int split = id & 7;
+  id >>= 3;
+  const int hd = id % heads, b = id / heads;
+  const int npix = h * w, stride_pix = heads * dim;
+  for (int i = threadIdx.x; i < CG * npix; i += 1024) map[i] = 0.0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < num_query; q += 1024) {
+    const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
+    const float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + split * CG);
+    const int64_t kb = (qh * levels + level) * points;
+    constexpr int U = P > 0 ? P : 1;
+    for (int p0 = 0; p0 < points; p0 += U) {
+      float lx[U], ly[U], aw[U];
+      if constexpr (P == 4) {
+        const float4 l01 = *reinterpret_cast<const float4*>(loc + kb * 2);
+        const float4 l23 = *reinterpret_cast<const float4*>(loc + kb * 2 + 4);
+        const float4 a4 = *reinterpret_cast<const float4*>(attn + kb);
+        lx[0] = l01.x; ly[0] = l01.y; lx[1] = l01.z; ly[1] = l01.w;
+        lx[2] = l23.x; ly[2] = l23.y; lx[3] = l23.z; ly[3] = l23.w;
+        aw[0] = a4.x; aw[1] = a4.y; aw[2] = a4.z; aw[3] = a4.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          lx[u] = loc[(kb + p0 + u) * 2];
+          ly[u] = loc[(kb + p0 + u) * 2 + 1];
+          aw[u] = attn[kb + p0 + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Corner c;
+        if (!bilinear_setup(lx[u], ly[u], h, w, 1, c)) continue;          // offsets in pixels
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int off = c.off[j];
+          if (off < 0) continue;
+          const float wj = c.wgt[j] * aw[u];
+          atomicAdd(&map[off], (double)(wj * go.x));
+          atomicAdd(&map[npix + off], (double)(wj * go.y));
+          atomicAdd(&map[2 * npix + off], (double)(wj * go.z));
+          atomicAdd(&map[3 * npix + off], (double)(wj * go.w));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* gv = grad_value + ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + split * CG;
+  for (int i = threadIdx.x; i < npix; i += 1024)
+    *reinterpret_cast<float4*>(gv + (int64_t)i * stride_pix) =
+        make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
+}
+
+// d(location), d(weight): 8 lanes per (query, head), 4 channels per lane
+__global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restrict__ grad_out,
+                                                          const float* __restrict__ value,
+                                                          const int64_t* __restrict__ shapes,
+                                                          const int64_t* __restrict__ level_start,
+                                                          const float* __restrict__ loc, const float* __restrict__ attn,
+                                                          int64_t total8, int num_value, int heads, int levels,
+                                                          int num_query, int points, float* __restrict__ grad_loc,
+                                                          float* __restrict__ grad_attn) {
+  constexpr int dim = 32;
+  const int stride_pix = heads * dim;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < total8;                     // total8 is a multiple of 8: a group of 8 lanes is all in or out
+  const int64_t sidx = live ? idx : total8 - 1;
+  const int d4 = (int)(sidx & 7);
+  int64_t t = sidx >> 3;
+  const int hd = (int)(t % heads);
+  t /= heads;                                         // t = b * num_query + q
+  const int b = (int)(t / num_query);
+  const float* vb = value + (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t lw_base = (t * heads + hd) * levels * points;
+  const float4 go = *reinterpret_cast<const float4*>(grad_out + (t * heads + hd) * dim + d4 * 4);
+  for (int l = 0; l < levels; ++l) {
+    const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
+    const float* vl = vb + level_start[l] * stride_pix;
+    for (int p = 0; p < points; ++p) {
+      const int64_t k = lw_base + l * points + p;
+      const float lx = loc[k * 2], ly = loc[k * 2 + 1], aw = attn[k];
+      float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+      Corner c;
+      if (bilinear_setup(lx, ly, h, w, stride_pix, c)) {
+        float s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s4[j] = 0.f;
+          if (c.off[j] >= 0) {
+            const float4 x = *reinterpret_cast<const float4*>(vl + c.off[j]);
+            s4[j] = go.x * x.x + go.y * x.y + go.z * x.z + go.w * x.w;
+          }
+        }
+        const float uh = 1.f - c.lh, uw = 1.f - c.lw;
+        g_w = c.wgt[0] * s4[0] + c.wgt[1] * s4[1] + c.wgt[2] * s4[2] + c.wgt[3] * s4[3];
+        const float gh = -uw * s4[0] - c.lw * s4[1] + uw * s4[2] + c.lw * s4[3];
+        const float gw = -uh * s4[0] + uh * s4[1] - c.lh * s4[2] + c.lh * s4[3];
+        g_x = (float)w * gw * aw;
+        g_y = (float)h * gh * aw;
+      }
+      g_w = group8_sum_dpp(g_w);
+      g_x = group8_sum_dpp(g_x);
+      g_y = group8_sum_dpp(g_y);
+      if (live && d4 == 7) {
+        grad_attn[k] = g_w;
+        grad_loc[k * 2] = g_x;
+        grad_loc[k * 2 + 1] = g_y;
+      }
+    }
+  }
+}
+
+struct MsdaLevels {
+  int levels;
+  int h[8], w[8], lstart[8];
+};
+
 bool pow2_le64(int d) { return d > 0 && d <= 64 && (d & (d - 1)) == 0; }
 
 }  // namespace
@@ -540,12 +683,22 @@ extern "C" int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial
   return MBV_OK;
 }
 
+extern "C" int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int64_t* spatial_shapes_host) {
+  const char* banded = getenv("MBV_MSDA_BWD_BANDED");
+  if (!spatial_shapes_host || head_dim != 32 || num_levels <= 0 || num_levels > 8 || (banded && banded[0] == '1')) return 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const int64_t h = spatial_shapes_host[2 * l], w = spatial_shapes_host[2 * l + 1];
+    if (h <= 0 || w <= 0 || h * w > 4096) return 0;
+  }
+  return 1;
+}
+
 extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int64_t* spatial_shapes,
                                       const int64_t* level_start, const float* sampling_loc,
                                       const float* attn_weight, int32_t batch, int32_t num_value, int32_t num_heads,
                                       int32_t head_dim, int32_t num_levels, int32_t num_query, int32_t num_points,
                                       const int64_t* spatial_shapes_host, float* grad_value, float* grad_loc,
-                                      float* grad_attn, void* stream_) {
+                                      float* grad_attn, int32_t part, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0 || num_points <= 0)
     return MBV_ERR_BAD_ARG;
@@ -553,6 +706,57 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_value ||
       !grad_loc || !grad_attn)
     return MBV_ERR_BAD_ARG;
+  if (part < 1 || part > 3) return MBV_ERR_BAD_ARG;
+  {
+    // no global atomics (see k_msda_bwd_value); MBV_MSDA_BWD_BANDED=1 keeps the banded form (A/B switch)
+    bool fits = mbv_ms_deform_attn_bwd_split(head_dim, num_levels, spatial_shapes_host) != 0 &&
+                ((reinterpret_cast<size_t>(grad_out) | reinterpret_cast<size_t>(value) |
+                  reinterpret_cast<size_t>(grad_value) | reinterpret_cast<size_t>(sampling_loc) |
+                  reinterpret_cast<size_t>(attn_weight)) & 15) == 0;
+    MsdaLevels lv;
+    lv.levels = num_levels;
+    int lstart = 0, max_pix = 0;
+    for (int l = 0; fits && l < num_levels; ++l) {
+      const int h = (int)spatial_shapes_host[2 * l], w = (int)spatial_shapes_host[2 * l + 1];
+      if (h <= 0 || w <= 0 || h * w > 4096) { fits = false; break; }
+      lv.h[l] = h; lv.w[l] = w; lv.lstart[l] = lstart;
+      lstart += h * w;
+      if (h * w > max_pix) max_pix = h * w;
+    }
+    if (fits && lstart == num_value) {
+      static bool attr_done = false;      // idempotent attribute of the code objects, not library state
+      if (!attr_done && max_pix * 32 > 65536) {
+        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_done = true;
+      }
+      const int which = part;
+      for (int l = num_levels - 1; l >= 0 && (which & 1); --l) {      // finest (longest) level first
+        const dim3 grid((unsigned)(batch * num_heads * 8)), block(1024);
+        const size_t lds = (size_t)lv.h[l] * lv.w[l] * 4 * sizeof(double);
+        if (num_points == 4)
+          hipLaunchKernelGGL(k_msda_bwd_value<4>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
+                             num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
+                             grad_value);
+        else
+          hipLaunchKernelGGL(k_msda_bwd_value<0>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
+                             num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
+                             grad_value);
+        MBV_CHECK_LAUNCH();
+      }
+      if (which & 2) {
+        const int64_t total8 = (int64_t)batch * num_query * num_heads * 8;
+        hipLaunchKernelGGL(k_msda_bwd_locattn, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream, grad_out,
+                           value, spatial_shapes, level_start, sampling_loc, attn_weight, total8, num_value, num_heads,
+                           num_levels, num_query, num_points, grad_loc, grad_attn);
+        MBV_CHECK_LAUNCH();
+      }
+      return MBV_OK;
+    }
+  }
+  if (part != 3) return MBV_ERR_UNSUPPORTED;
   MBV_CHECK_HIP(mbv_fill_async(grad_value, 0, sizeof(float) * (size_t)batch * num_value * num_heads * head_dim, stream));
   if (spatial_shapes_host && num_query == num_value && num_levels <= 8) {
     // banded form: needs the level shapes on the host to size the bands, and the self-attention query order

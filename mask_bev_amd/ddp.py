@@ -29,13 +29,13 @@ from torch import nn
 
 
 class _Bucket:
-    __slots__ = ('params', 'numel', 'flat', 'pending', 'handle', 'offsets')
+    __slots__ = ('params', 'numel', 'flat', 'seen', 'handle', 'offsets')
 
     def __init__(self):
         self.params: List[nn.Parameter] = []
         self.numel = 0
         self.flat: Optional[torch.Tensor] = None
-        self.pending = 0
+        self.seen = set()                   # ids of the parameters whose gradient has been announced this step
         self.handle = None
         self.offsets: List[int] = []
 
@@ -69,11 +69,21 @@ class GradientAllReducer:
             self.buckets.append(cur)
         self._bucket_of: Dict[int, _Bucket] = {}
         self._hooks = []
-        for b in self.buckets:
-            for p in b.params:
-                self._bucket_of[id(p)] = b
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
-        self._active = True
+        # Parameters that live in a ParameterArena (arena.py) receive their gradients by in-place accumulation, once
+        # per USE of the parameter (a packed in_proj weight announces itself three times): a per-parameter ready-hook
+        # cannot tell the last use from the first, so the hook-driven buckets are refused for them — the arena's
+        # gradient is reduced in contiguous ranges after the backward instead (finish() -> reduce_arena()).
+        self.arena = getattr(module, '_arena', None)
+        if self.arena is None and any(getattr(p, '_mbv_arena', False) for p in params):
+            raise RuntimeError('parameters live in a ParameterArena the module does not expose as `_arena`: '
+                               'reduce it with reduce_arena() / start_ranges()')
+        if self.arena is None:
+            for b in self.buckets:
+                for p in b.params:
+                    self._bucket_of[id(p)] = b
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        self._active = self.arena is None
+        self._next = 0                      # buckets are launched in index order on every rank
         self.sync_parameters()
         self._reset()
 
@@ -82,6 +92,9 @@ class GradientAllReducer:
     def sync_parameters(self):
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=0, group=self.group)
+        arena = getattr(self.module, '_arena', None)
+        if arena is not None:               # the broadcast wrote the f32 arena: the bf16 shadow the GEMMs read follows
+            arena.refresh_shadow()
 
     @torch.no_grad()
     def sync_buffers(self):
@@ -99,16 +112,23 @@ class GradientAllReducer:
 
     def _reset(self):
         for b in self.buckets:
-            b.pending = len(b.params)
+            b.seen = set()
             b.handle = None
+        self._next = 0
 
     def _on_grad_ready(self, p: nn.Parameter):
         if not self._active:
             return
         b = self._bucket_of[id(p)]
-        b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        b.seen.add(id(p))                   # a set, not a counter: a second announcement of p changes nothing
+        self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch complete buckets strictly in index order: the sequence of collectives is then the same on every
+        rank whatever order (or subset) of gradients each rank produced."""
+        while self._next < len(self.buckets) and len(self.buckets[self._next].seen) == len(self.buckets[self._next].params):
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b: _Bucket):
         dtype = self.grad_dtype or b.params[0].grad.dtype
@@ -119,16 +139,22 @@ class GradientAllReducer:
         b.flat.div_(self.world)
         b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self):
+    def finish(self, optimizer=None):
         """Call after ``loss.backward()``: waits for every bucket and scatters the averaged gradients back.
         Parameters that received no gradient this step (unused) are treated as zero, like DDP's
-        ``find_unused_parameters=True`` default under Lightning 1.9."""
-        for b in self.buckets:
-            if b.handle is None:                      # some parameter of the bucket got no gradient
-                for p in b.params:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                self._launch(b)
+        ``find_unused_parameters=True`` default under Lightning 1.9; the remaining buckets
+        are launched in index order, so ranks whose sets of unused parameters differ still pair their collectives.
+        With a parameter arena the arena gradient is reduced in place, in contiguous ranges (no bucket copies)."""
+        if self.arena is not None:
+            self.reduce_arena(self.arena, optimizer)
+            return
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            for p in b.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self._launch(b)
+            self._next += 1
         for b in self.buckets:
             b.handle.wait()
             for p, off in zip(b.params, b.offsets):
@@ -182,7 +208,9 @@ class GradientAllReducer:
         self.finish_arena(arena, self.start_arena(arena, order), optimizer)
 
     def no_sync(self, flag: bool = True):
-        self._active = not flag
+        """Switch the hook-driven buckets off (gradient accumulation steps, HIP-graph capture / replay).  With a
+        parameter arena they are never on."""
+        self._active = (not flag) and self.arena is None
 
     def remove(self):
         for h in self._hooks:

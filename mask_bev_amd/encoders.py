@@ -33,8 +33,14 @@ class Voxelization(nn.Module):
         self.voxel_size = [float(v) for v in voxel_size]
         self.point_cloud_range = [float(v) for v in point_cloud_range]
         self.max_num_points = int(max_num_points)
-        self.max_voxels = int(max_voxels[0] if isinstance(max_voxels, (tuple, list)) else max_voxels)
+        # mmcv: an int serves both modes, a (train, test) pair is picked by ``self.training``
+        mv = tuple(max_voxels) if isinstance(max_voxels, (tuple, list)) else (max_voxels, max_voxels)
+        self.max_voxels_train_test = (int(mv[0]), int(mv[1]))
         self.geometry = VoxelGeometry.from_ranges(self.point_cloud_range, self.voxel_size)
+
+    @property
+    def max_voxels(self) -> int:
+        return self.max_voxels_train_test[0 if self.training else 1]
 
     def pillars(self, point_clouds: Sequence[torch.Tensor], prefilter: bool) -> Pillars:
         return ops.voxelize(point_clouds, self.geometry, self.max_num_points, self.max_voxels, prefilter)

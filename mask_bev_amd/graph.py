@@ -167,8 +167,12 @@ class GraphedTrainStep:
             ln = self.m._encoder._layer_norm
             ln_range = self.arena.range_of(ln)
             early = []
-            hook = ln.bias.register_post_accumulate_grad_hook(
-                lambda p: early.extend(self.reducer.start_ranges(self.arena, [ln_range])))
+
+            def launch_ln(_p):          # the hook may be announced more than once per backward: launch once
+                if not early:
+                    early.extend(self.reducer.start_ranges(self.arena, [ln_range]))
+
+            hook = ln.bias.register_post_accumulate_grad_hook(launch_ln)
             try:
                 x.backward(self.x_static.grad)             # eager: backward of K3 / K2
             finally:

@@ -282,8 +282,8 @@ class _DeferredHeads(torch.autograd.Function):
         e_b.copy_(e_re.detach().permute(1, 0, 2, 3))
         e_b = e_b.view(b, nd * q, c)
         ff = mask_feature.reshape(b, c, hw)
-        d_e = torch.bmm(dl, ff.transpose(1, 2))                                            # (B, D*Q, C)
-        d_f = torch.bmm(e_b.transpose(1, 2), dl).view(b, c, hh, ww)                        # (B, C, H, W)
+        d_e, d_f = ops.mask_logits_backward(dl, e_b, ff)        # (B, D*Q, C), (B, C, HW): K17 for 16-bit operands
+        d_f = d_f.view(b, c, hh, ww)
         d_e = d_e.view(b, nd, q, c).permute(1, 0, 2, 3).to(e_re.dtype)
         roots, grads = [e_re], [d_e]
         if d_cls is not None:

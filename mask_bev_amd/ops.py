@@ -138,6 +138,13 @@ def voxelize(point_clouds: Sequence[torch.Tensor], geom: VoxelGeometry, max_poin
     points = torch.cat([p.reshape(-1, dim) for p in point_clouds], 0).to(torch.float32).contiguous()
     n = int(points.shape[0])
     batch = len(point_clouds)
+    if n == 0:                            # no points at all: empty pillars, like the reference (no kernel to launch)
+        z = lambda *sh: torch.zeros(sh, dtype=torch.int32, device=dev)
+        return Pillars(points=points, scan_offsets=z(batch + 1), coors=z(0, 4), num_points=z(0),
+                       pillar_points=z(0, int(max_points)), row_start=z(1),
+                       cell_to_pillar=torch.full((batch, geom.cells), -1, dtype=torch.int32, device=dev),
+                       pillar_batch_start=z(batch + 1), pillars_per_scan=[0] * batch, num_pillars=0, num_rows=0,
+                       max_points=int(max_points))
     offs = [0]
     for l in lens:
         offs.append(offs[-1] + l)
@@ -493,11 +500,37 @@ class _MSDeformAttn(torch.autograd.Function):
         host = None
         if ctx.shapes_host is not None and len(ctx.shapes_host) == nl:       # banded LDS accumulation (K5)
             host = (ctypes.c_int64 * (2 * nl))(*[int(v) for hw in ctx.shapes_host for v in hw])
-        rc = lib.mbv_ms_deform_attn_bwd(_ptr(grad_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
-                                        _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(g_value), _ptr(g_loc),
-                                        _ptr(g_attn), _stream())
-        check(rc, 'mbv_ms_deform_attn_bwd')
+        _msda_backward(lib, grad_out, value, shapes_t, level_start, loc, attn, (b, nv, nh, d, nl, nq, npnt), host,
+                       g_value, g_loc, g_attn)
         return g_value, None, None, g_loc, g_attn, None
+
+
+_MSDA_SIDE = {}
+
+
+def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn):
+    """K5 backward.  The no-atomics form has two independent parts — d(value), bound by the LDS f64-atomic rate, and
+    d(location) / d(weight), bound by L2 gathers.  MBV_MSDA_BWD_OVERLAP=1 puts them on two streams; measured inside the
+    HIP-graph step the fork / join edges cost more than the overlap returns (34.17 vs 33.88 ms per step), so the
+    default is one stream.  The side stream only touches buffers that were allocated on the current stream and
+    outlive the join."""
+    import os
+    b, nv, nh, d, nl, nq, npnt = dims
+    args = (_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq,
+            npnt, host, _ptr(g_value), _ptr(g_loc), _ptr(g_attn))
+    split = host is not None and lib.mbv_ms_deform_attn_bwd_split(d, nl, host)
+    if not split or os.environ.get('MBV_MSDA_BWD_OVERLAP', '0') != '1':
+        check(lib.mbv_ms_deform_attn_bwd(*args, 3, _stream()), 'mbv_ms_deform_attn_bwd')
+        return
+    main = torch.cuda.current_stream()
+    side = _MSDA_SIDE.get(g_out.device)
+    if side is None:
+        side = _MSDA_SIDE[g_out.device] = torch.cuda.Stream(device=g_out.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        check(lib.mbv_ms_deform_attn_bwd(*args, 2, _stream()), 'mbv_ms_deform_attn_bwd')      # d(location), d(weight)
+    check(lib.mbv_ms_deform_attn_bwd(*args, 1, _stream()), 'mbv_ms_deform_attn_bwd')          # d(value)
+    main.wait_stream(side)
 
 
 class _MSDAPrepare(torch.autograd.Function):
@@ -618,9 +651,8 @@ class _MSDAQuerySide(torch.autograd.Function):
         g_loc = torch.empty_like(loc)
         g_attn = torch.empty_like(attn)
         host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
-        check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn),
-                                         b, n, heads, d, levels, n, points, host_b, _ptr(g_value), _ptr(g_loc),
-                                         _ptr(g_attn), _stream()), 'mbv_ms_deform_attn_bwd')
+        _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, (b, n, heads, d, levels, n, points), host_b,
+                       g_value, g_loc, g_attn)
         g = torch.empty((t, width), dtype=dt, device=dev)                 # [d value | d offsets | d logits]
         g[:, :e].copy_(g_value.view(t, e))
         esz = g.element_size()
@@ -782,6 +814,36 @@ def gemm16_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, splits: i
     k = x.shape[1]
     check(lib.mbv_gemm16_tn(_ptr(g), _ptr(x), _ptr(acc), m, n, k, g.stride(0), x.stride(0), acc.stride(0),
                             _GEMM16_DT[g.dtype], 1, 1, int(splits), 1, 0, 0, 0, _stream()), 'mbv_gemm16_tn')
+
+
+def gemm16_nt_acc(x: torch.Tensor, w: torch.Tensor, splits: int = 0) -> torch.Tensor:
+    """``x (B, M, K) @ w (B, N, K)^T`` → (B, M, N) f32 on K17 with the contraction split over workgroups (f32 atomic
+    adds into a zeroed result): few rows, long K."""
+    lib = _lib.load()
+    if x.dim() != 3 or w.dim() != 3 or x.shape[0] != w.shape[0] or x.shape[2] != w.shape[2]:
+        raise MaskBevHipError('gemm16_nt_acc: (B, M, K) and (B, N, K) operands')
+    x, w = x.contiguous(), w.contiguous()
+    if not _gemm16_ok(x[0], w[0]):
+        raise MaskBevHipError('gemm16_nt_acc: unsupported operands')
+    b, m, k = x.shape
+    n = w.shape[1]
+    out = torch.zeros((b, m, n), dtype=torch.float32, device=x.device)
+    check(lib.mbv_gemm16_nt_acc(_ptr(x), _ptr(w), _ptr(out), m, n, k, k, k, n, _GEMM16_DT[x.dtype], int(splits), b,
+                                m * k, n * k, m * n, _stream()), 'mbv_gemm16_nt_acc')
+    return out
+
+
+def mask_logits_backward(dl: torch.Tensor, embed: torch.Tensor, feature: torch.Tensor):
+    """Backward of ``einsum('bqc,bcp->bqp', embed, feature)`` (/root/reference: mask_bev/models/networks/
+    mask2former_head/mask2former_head.py:459) for dl (B, R, P), embed (B, R, C), feature (B, C, P):
+    ``d_embed = dl . feature^T`` (B, R, C) f32 and ``d_feature = embed^T . dl`` (B, C, P) in the operands' dtype.  16-bit
+    operands run on K17 (split-K NT with f32 atomics; batched TN stored once); anything else on the library GEMM."""
+    if (dl.is_cuda and dl.dtype in _GEMM16_DT and embed.dtype == dl.dtype and feature.dtype == dl.dtype
+            and gemm16_policy() != 'none' and dl.shape[2] % 8 == 0 and embed.shape[2] % 8 == 0):
+        dl, embed, feature = dl.contiguous(), embed.contiguous(), feature.contiguous()
+        if _gemm16_ok(dl[0], embed[0], feature[0]):
+            return gemm16_nt_acc(dl, feature), gemm16_tn(embed, dl)
+    return torch.bmm(dl, feature.transpose(1, 2)), torch.bmm(embed.transpose(1, 2), dl)
 
 
 def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -1318,15 +1380,13 @@ class _MaskLogits(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_logits):
-        # two plain library GEMMs (hipBLASLt through torch): dE = dL . F^T, dF = E^T . dL
+        # dE = dL . F^T, dF = E^T . dL: K17 for 16-bit operands (ops.mask_logits_backward)
         e, f = ctx.saved_tensors
         b, q, c = e.shape
         h, w = f.shape[-2:]
         dl = grad_logits.to(e.dtype).reshape(b, q, h * w)
-        ff = f.reshape(b, c, h * w)
-        g_e = torch.matmul(dl, ff.transpose(1, 2)).to(ctx.embed_dtype)
-        g_f = torch.matmul(e.transpose(1, 2), dl).reshape(b, c, h, w)
-        return g_e, g_f, None
+        g_e, g_f = mask_logits_backward(dl, e, f.reshape(b, c, h * w))
+        return g_e.to(ctx.embed_dtype), g_f.reshape(b, c, h, w), None
 
 
 class _StackSlices(torch.autograd.Function):
@@ -1638,6 +1698,11 @@ class _AddLayerNorm(torch.autograd.Function):
         weight, bias = ctx.weight, ctx.bias
         da, db = ctx.dtypes
         if gy is None:                                    # only the residual path carries gradient
+            bb = ctx.branch_bias
+            if gs is not None and bb is not None:         # the deferred bias gradient of the branch Linear: colsum(gs)
+                g2 = gs.reshape(-1, gs.shape[-1])
+                colsum_accum(g2 if g2.dtype in (torch.float32, torch.bfloat16) else g2.float(), bb.grad)
+                _fire_grad_hooks(bb)
             ga = None if gs is None else gs.to(da)
             gb = None if (gs is None or db is None) else gs.to(db)
             return ga, gb, None, None, None, None, None
@@ -1703,6 +1768,8 @@ class _BiasAct(torch.autograd.Function):
         check(lib.mbv_act_bwd_colsum(_ptr(ga), _ptr(zc), int(zc.dtype == torch.bfloat16), ctx.kind, zc.numel() // n, n,
                                      _ptr(gz), _ptr(None if bias is None else bias.grad), _stream()),
               'mbv_act_bwd_colsum')
+        if bias is not None:
+            _fire_grad_hooks(bias)
         return gz, None, None
 
 

@@ -1,0 +1,135 @@
+"""Algorithmic work of the C-ABI calls: for a call's argument tuple, the name of the kernel that
+dominates it, the roofline that bounds that kernel and the algorithmic HBM bytes / MFMA flops of ONE call.
+Used by bench.py to turn the HIP-event durations of an instrumented eager step into roofline fractions; the byte
+counts are the operands each kernel must read and write once (no re-reads, no workspace traffic).
+
+``MODELS[symbol](args) -> (kernel, bound, bytes, flops)``; argument positions follow include/maskbev_hip.h.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_TFLOPS = 2500.0        # dense bf16 / fp16 MFMA
+MFMA_F32_TFLOPS = 157.3
+
+Work = Tuple[str, str, float, float]
+
+
+def _i(x) -> int:
+    return int(getattr(x, 'value', x) or 0)
+
+
+def _window_attn(a, bwd: bool) -> Work:
+    if bwd:
+        bf16, b, h, w, c, heads, ws = (_i(a[i]) for i in (6, 7, 8, 9, 10, 11, 12))
+    else:
+        bf16, b, h, w, c, heads, ws = (_i(a[i]) for i in (3, 4, 5, 6, 7, 8, 9))
+    es = 2 if bf16 else 4
+    t = b * h * w
+    nwin = b * ((h + ws - 1) // ws) * ((w + ws - 1) // ws)
+    n, d = ws * ws, c // max(1, heads)
+    if bwd:      # reads qkv, out, grad_out; writes grad_qkv; five n x n x d products per (window, head)
+        return ('k_window_attn_bwd', 'hbm', t * c * es * (3 + 1 + 1 + 3), 10.0 * nwin * heads * n * n * d)
+    return ('k_window_attn_fwd', 'hbm', t * c * es * (3 + 1), 4.0 * nwin * heads * n * n * d)
+
+
+def _msda(a, bwd: bool) -> Work:
+    o = 1 if bwd else 0
+    b, nv, heads, d, levels, nq, pts = (_i(a[i + o]) for i in (5, 6, 7, 8, 9, 10, 11))
+    samples = b * nq * heads * levels * pts
+    vmap, qmap = b * nv * heads * d * 4.0, b * nq * heads * d * 4.0
+    if bwd:      # value, grad_out, loc, attn in; grad_value, grad_loc, grad_attn out
+        part = _i(a[17])
+        if part == 1:    # d(value): grad_out, loc, attn in; grad_value out
+            return ('k_msda_bwd_value', 'hbm', vmap + qmap + samples * 12.0, 0.0)
+        if part == 2:    # d(location), d(weight): value, grad_out, loc, attn in; grad_loc, grad_attn out
+            return ('k_msda_bwd_locattn', 'hbm', vmap + qmap + 2 * samples * 12.0, 0.0)
+        return ('k_msda_bwd', 'hbm', 2 * vmap + qmap + 2 * samples * 12.0, 0.0)
+    return ('k_msda_fwd_v4', 'hbm', vmap + qmap + samples * 12.0, 0.0)
+
+
+def _attn(a, bwd: bool, ld: bool) -> Work:
+    if bwd:
+        i0 = 8 if ld else 7
+    else:
+        i0 = 5 if ld else 4
+    bf16, b, q, k, heads, d = (_i(a[i0 + j]) for j in range(6))
+    es = 2 if bf16 else 4
+    e = heads * d
+    if bwd:
+        return ('k_attn_bwd', 'hbm', b * (2 * q * e * es + 2 * k * e * es + q * k) + b * (q * e * 4 + 2 * k * e * 4),
+                10.0 * b * heads * q * k * d)
+    return ('k_attn_fwd_split', 'hbm', b * (q * e * es * 2 + 2 * k * e * es + q * k), 4.0 * b * heads * q * k * d)
+
+
+def _gemm16(a, layout: str) -> Work:
+    if layout == 'nt':
+        m, n, k, f32 = _i(a[5]), _i(a[6]), _i(a[7]), _i(a[12])
+        by = (m * k + n * k) * 2.0 + m * n * (4 if f32 else 2) * (2 if a[4] is not None and _i(a[4]) else 1)
+        return ('k_gemm16<NT>', 'mfma', by, 2.0 * m * n * k * max(1, _i(a[14])))
+    if layout == 'nn':
+        m, n, k, f32 = _i(a[5]), _i(a[6]), _i(a[7]), _i(a[13])
+        by = (m * n + n * k) * 2.0 + m * k * (4 if f32 else 2) + (m * k * 2.0 if _i(a[14]) else 0.0)
+        return ('k_gemm16<NN>', 'mfma', by, 2.0 * m * n * k * max(1, _i(a[15])))
+    m, n, k = _i(a[3]), _i(a[4]), _i(a[5])
+    return ('k_gemm16<TN>', 'mfma', (m * n + m * k) * 2.0 + n * k * 4.0 * 2, 2.0 * m * n * k * max(1, _i(a[13])))
+
+
+def _add_ln(a, bwd: bool) -> Work:
+    if bwd:
+        rows, c = _i(a[8]), _i(a[9])
+        by = rows * c * ((2 if _i(a[1]) else 4) + (0 if not _i(a[2]) else (2 if _i(a[3]) else 4)) + 4 + 4
+                         + (2 if _i(a[11]) else 0))
+        return ('k_add_ln_bwd', 'hbm', by, 0.0)
+    rows, c = _i(a[6]), _i(a[7])
+    by = rows * c * ((2 if _i(a[1]) else 4) + (0 if not _i(a[2]) else (2 if _i(a[3]) else 4))
+                     + (4 if _i(a[9]) else 0) + (2 if _i(a[11]) else 4))
+    return ('k_add_ln_fwd', 'hbm', by, 0.0)
+
+
+MODELS: Dict[str, Callable[[tuple], Work]] = {
+    'mbv_window_attn_fwd': lambda a: _window_attn(a, False),
+    'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
+    'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
+    'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
+    'mbv_attn_fwd': lambda a: _attn(a, False, False),
+    'mbv_attn_fwd_ld': lambda a: _attn(a, False, True),
+    'mbv_attn_bwd': lambda a: _attn(a, True, False),
+    'mbv_attn_bwd_ld': lambda a: _attn(a, True, True),
+    'mbv_gemm16_nt': lambda a: _gemm16(a, 'nt'),
+    'mbv_gemm16_nn': lambda a: _gemm16(a, 'nn'),
+    'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
+    'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
+    'mbv_add_layernorm_bwd': lambda a: _add_ln(a, True),
+    # importance sampling: every row's (H, W) f32 map is read once; the 3x over-sampled candidates never touch HBM
+    'mbv_sample_select_uncertain': lambda a: ('k_sample_select', 'hbm',
+                                              _i(a[4]) * (_i(a[7]) * _i(a[8]) * 4.0 + _i(a[6]) * 8.0), 0.0),
+    'mbv_hungarian': lambda a: ('k_hungarian', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 4.0 + _i(a[1]) * _i(a[2]) * 4.0, 0.0),
+    'mbv_mask_logits_fwd': lambda a: ('k_mask_logits', 'hbm',
+                                      _i(a[3]) * (_i(a[4]) * _i(a[5]) + _i(a[5]) * _i(a[6])) * (2 if _i(a[2]) else 4)
+                                      + _i(a[3]) * _i(a[4]) * _i(a[6]) * (4 if (_i(a[8]) or not _i(a[2])) else 2),
+                                      2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6])),
+    'mbv_point_sample_fwd': lambda a: ('k_point_sample_fwd_lds', 'hbm',
+                                       _i(a[4]) * (_i(a[6]) * _i(a[7]) * 4.0 + _i(a[5]) * 12.0), 0.0),
+    'mbv_point_sample_bwd': lambda a: ('k_point_sample_bwd_lds', 'hbm',
+                                       _i(a[8]) * _i(a[6]) * _i(a[7]) * 4.0 + _i(a[4]) * _i(a[5]) * 12.0, 0.0),
+    'mbv_point_sample_packed_fwd': lambda a: ('k_point_sample_packed', 'hbm',
+                                              _i(a[4]) * (_i(a[6]) * _i(a[7]) / 8.0 + _i(a[5]) * 12.0), 0.0),
+    'mbv_mask_loss_rows_fwd': lambda a: ('k_mask_loss_rows_fwd', 'hbm', _i(a[2]) * _i(a[3]) * 8.0, 0.0),
+    'mbv_mask_loss_rows_bwd': lambda a: ('k_mask_loss_rows_bwd', 'hbm', _i(a[3]) * _i(a[4]) * 12.0, 0.0),
+    'mbv_act_bwd_colsum': lambda a: ('k_act_bwd_colsum', 'hbm', _i(a[4]) * _i(a[5]) * 3.0 * (2 if _i(a[2]) else 4), 0.0),
+    'mbv_wgrad_small_f32': lambda a: ('k_wgrad_small', 'mfma_f32',
+                                      (_i(a[2]) * (_i(a[3]) + _i(a[4])) + 2 * _i(a[3]) * _i(a[4])) * 4.0,
+                                      2.0 * _i(a[2]) * _i(a[3]) * _i(a[4])),
+    'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
+    'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
+}
+
+
+def peak_of(bound: str) -> Tuple[float, str]:
+    if bound == 'mfma':
+        return MFMA_BF16_TFLOPS, 'TFLOP/s'
+    if bound == 'mfma_f32':
+        return MFMA_F32_TFLOPS, 'TFLOP/s'
+    return HBM_PEAK_GBS, 'GB/s'

@@ -28,10 +28,13 @@ lib = _lib.load()
 host = (ctypes.c_int64 * (2 * L))(*[v for hw in shapes for v in hw])
 gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
 
+PART = [3]
+
+
 def bwd():
     rc = lib.mbv_ms_deform_attn_bwd(go.data_ptr(), value.data_ptr(), shapes_t.data_ptr(), ls.data_ptr(), loc.data_ptr(),
                                     attn.data_ptr(), B, nv, H, D, L, nq, P, ctypes.cast(host, ctypes.c_void_p),
-                                    gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                    gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), PART[0], torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
 def timeit(fn, iters=10, reps=5):
@@ -49,16 +52,13 @@ def timeit(fn, iters=10, reps=5):
         best = min(best, a.elapsed_time(b) / iters * 1e3)
     return best
 
-res = {}
-for mode in ('1', '0'):
-    os.environ['MBV_MSDA_BWD_4CH'] = mode
+for name, env, part in (('no-atomics form (both parts, one stream)', {}, 3), ('  value part only', {}, 1),
+                        ('  location/weight part only', {}, 2), ('banded form', {'MBV_MSDA_BWD_BANDED': '1'}, 3)):
+    os.environ.pop('MBV_MSDA_BWD_BANDED', None)
+    os.environ.update(env)
+    PART[0] = part
     bwd(); torch.cuda.synchronize()
-    res[mode] = (gv.clone(), gl.clone(), ga.clone())
-    print('4ch' if mode == '1' else '1ch', 'us per backward (fill + kernel):', timeit(bwd))
-for a, b, n in zip(res['1'], res['0'], ('grad_value', 'grad_loc', 'grad_attn')):
-    print(n, 'max |4ch - 1ch| =', (a - b).abs().max().item(), 'of', b.abs().max().item())
-
-os.environ['MBV_MSDA_BWD_4CH'] = '1'
-for ab in (0, 1, 2, 3, 4, 8, 15):
-    os.environ['MBV_MSDA_ABLATE'] = str(ab)
-    print('ablate', ab, '(1 no LDS adds, 2 no global adds, 4 no value gathers, 8 no reductions/stores):', timeit(bwd))
+    if not env or 'BANDED' in str(env):
+        print(name, 'us:', timeit(bwd), ' grad_value checksum', float(gv.double().abs().sum()), float(gl.double().abs().sum()))
+    else:
+        print(name, 'us:', timeit(bwd))

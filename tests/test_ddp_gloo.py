@@ -209,3 +209,49 @@ def test_arena_range_of_rejects_interleaved_parameters():
         arena.range_of([a.weight, c.weight])
     with pytest.raises(ValueError):
         arena.range_of(nn.Linear(2, 2))
+
+
+def _worker_unused(rank, world, port, out):
+    """Ranks with DIFFERENT sets of unused parameters: rank 1 never uses the `extra` branch.  The buckets must still be
+    all-reduced in the same order on both ranks (index order), or the collectives pair up wrongly / hang."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mask_bev_amd.ddp import GradientAllReducer
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.extra, self.b = nn.Linear(6, 12), nn.Linear(12, 12), nn.Linear(12, 1)
+
+        def forward(self, x, use_extra):
+            h = torch.relu(self.a(x))
+            if use_extra:
+                h = h + self.extra(h)
+            return self.b(h)
+
+    torch.manual_seed(3)
+    m = Net()
+    red = GradientAllReducer(m, bucket_mb=0.0001)          # (nearly) one bucket per parameter
+    assert len(red.buckets) >= 4
+    torch.manual_seed(11 + rank)
+    x, y = torch.randn(5, 6), torch.randn(5, 1)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    for _ in range(2):
+        ((m(x, use_extra=(rank == 0)) - y) ** 2).mean().backward()
+        # a parameter announced twice (gradient accumulation outside autograd does that) must not launch early
+        red._on_grad_ready(m.b.weight)
+        red.finish()
+        opt.step()
+        opt.zero_grad()
+    out[rank] = [p.detach().clone() for p in m.parameters()]
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_unused_parameters_stay_in_step():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_unused, args=(world, port, out), nprocs=world, join=True)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert out[0][2].abs().sum() > 0                       # the `extra` weight exists and moved (rank 0's half gradient)

@@ -163,3 +163,30 @@ def test_tuned_gemm_table_is_lookup_only_and_cpu_safe():
     assert not any('Rocblas' in e for e in entries)           # hipBLASLt solutions or Default only
     if not torch.cuda.is_available():
         assert tuning.use_tuned_gemms() is False
+
+
+def test_reference_import_path_and_launcher_cpu(tmp_path):
+    """/root/reference: train_mask_bev.py:12 — ``from mask_bev.mask_bev_module import MaskBevModule`` — resolves to
+    this implementation, and so do the module paths the reference's own tests / figure scripts import."""
+    import importlib
+    import yaml
+    from mask_bev.mask_bev_module import MaskBevModule
+    from mask_bev_amd.mask_bev_module import MaskBevModule as Native
+    assert MaskBevModule is Native
+    for mod, name in [('mask_bev.models.encoders.mask_bev_encoders', 'MaskBevEncoder'),
+                      ('mask_bev.models.backbones.mask_bev_backbone', 'MaskBevBackbone'),
+                      ('mask_bev.models.head.mask_bev_panoptic_head', 'MaskBevPanopticHead'),
+                      ('mask_bev.models.networks.swin.swin', 'CustomSwinTransformer'),
+                      ('mask_bev.models.networks.mask2former_head.mask2former_head', 'Mask2FormerHead'),
+                      ('mask_bev.models.training_types', 'OptimizerType')]:
+        assert hasattr(importlib.import_module(mod), name)
+    # the launcher parses the reference's command line and YAML, then refuses to run without an MI355X
+    import train_mask_bev_amd as launcher
+    from mask_bev_amd import synthetic
+    cfg = tmp_path / 'smoke.yml'
+    cfg.write_text(yaml.safe_dump(dict(synthetic.module_kwargs('smoke_96', 2), dataset='synthetic')))
+    with pytest.raises(ValueError, match='Could not find config'):
+        launcher.main(['--config', str(tmp_path / 'missing.yml'), '--train'])
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit, match='MI355X'):
+            launcher.main(['--config', str(cfg), '--train', '--synthetic'])

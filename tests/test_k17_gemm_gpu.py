@@ -185,3 +185,19 @@ def test_fused_ffn_matches_unfused_layers(act, monkeypatch):
             assert (ga - ga0).abs().max() <= 2e-2 * ga0.abs().max()
         assert (gx - gx0).norm() <= 1e-2 * gx0.norm()
         assert (ga - ga0).norm() <= 1e-2 * ga0.norm()
+
+
+@gpu
+def test_mask_logit_backward_products():
+    """ops.mask_logits_backward: d_embed = dl . F^T (split-K NT, f32 atomics) and d_feature = E^T . dl (batched TN)
+    at the deferred-head shape of the bench (rows = 10 outputs x 100 queries, C = 256) on a reduced pixel count."""
+    from mask_bev_amd import ops
+    dt = torch.bfloat16
+    b, r, c, p = 2, 1000, 256, 4096
+    dl, e, f = _rand((b, r, p), dt, 21, 0.05), _rand((b, r, c), dt, 22), _rand((b, c, p), dt, 23)
+    g_e, g_f = ops.mask_logits_backward(dl, e, f)
+    ref_e = dl.double() @ f.double().transpose(1, 2)
+    ref_f = e.double().transpose(1, 2) @ dl.double()
+    assert g_e.dtype == torch.float32 and g_f.dtype == dt
+    assert (g_e.double() - ref_e).abs().max() < 2e-4 * ref_e.abs().max()
+    _close(g_f, ref_f, dt, float(ref_f.abs().max()) * 1e-2)
