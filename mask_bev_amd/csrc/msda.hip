@@ -358,6 +358,18 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_banded(const float* __restric
 // bilinear set-up, the header loads and the cross-lane reductions of the location / weight gradients by four and puts
 // 128 queries instead of 32 in flight per workgroup (a workgroup's queries take a quarter of the dependent
 // memory round trips); the LDS atomics stay one ds_add_f64 per (corner, channel).
+// sum over each aligned group of 8 lanes, result in EVERY lane of the group
+__device__ __forceinline__ float group8_allsum(float v) {
+#define MBV_DPP_ADD(ctrl, bmask)                                                                              \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, bmask, true));
+  MBV_DPP_ADD(0xB1, 0xf)    // + lane ^ 1
+  MBV_DPP_ADD(0x4E, 0xf)    // + lane ^ 2
+#undef MBV_DPP_ADD
+  const float hi = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xa, true));  // row_shr:4
+  const float lo = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, true));  // row_shl:4
+  return v + hi + lo;       // banks 1, 3 receive the quad below, banks 0, 2 the quad above
+}
+
 __device__ __forceinline__ float group8_sum_dpp(float v) {
 #define MBV_DPP_ADD(ctrl, bmask)                                                                              \
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, bmask, true));
@@ -537,10 +549,11 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
   constexpr int dim = 32, CG = 4;
   const int points = P > 0 ? P : points_rt;
   extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
-  int id = blockIdx.x;
-  const int split = id & 7;
-  id >>= 3;
-  const int hd = id % heads, b = id / heads;
+  // blocks b and b + 8 share an XCD: with batch * heads a multiple of 8 the eight channel groups of a (batch, head),
+  // which read the same grad_out rows, locations and weights, land on ONE XCD's L2 (speed only)
+  const int nbh = gridDim.x >> 3;
+  const int split = blockIdx.x / nbh, bhid = blockIdx.x - split * nbh;
+  const int hd = bhid % heads, b = bhid / heads;
   const int npix = h * w, stride_pix = heads * dim;
   for (int i = threadIdx.x; i < CG * npix; i += 1024) map[i] = 0.0;
   __syncthreads();
@@ -612,6 +625,7 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
   const float* vb = value + (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
   const int64_t lw_base = (t * heads + hd) * levels * points;
   const float4 go = *reinterpret_cast<const float4*>(grad_out + (t * heads + hd) * dim + d4 * 4);
+  float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
   for (int l = 0; l < levels; ++l) {
     const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
     const float* vl = vb + level_start[l] * stride_pix;
@@ -637,13 +651,19 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
         g_x = (float)w * gw * aw;
         g_y = (float)h * gh * aw;
       }
-      g_w = group8_sum_dpp(g_w);
-      g_x = group8_sum_dpp(g_x);
-      g_y = group8_sum_dpp(g_y);
-      if (live && d4 == 7) {
-        grad_attn[k] = g_w;
-        grad_loc[k * 2] = g_x;
-        grad_loc[k * 2 + 1] = g_y;
+      g_w = group8_allsum(g_w);
+      g_x = group8_allsum(g_x);
+      g_y = group8_allsum(g_y);
+      // lane d4 of the group keeps sample s when s % 8 == d4: the group's stores are then runs of 8 consecutive
+      // samples (32 B of weights, 64 B of locations) instead of one 4-byte store per sample
+      const int sidx8 = l * points + p;
+      if ((sidx8 & 7) == d4) { keep_w = g_w; keep_x = g_x; keep_y = g_y; }
+      if ((sidx8 & 7) == 7 || (l == levels - 1 && p == points - 1)) {
+        const int first = sidx8 & ~7;
+        if (live && first + d4 <= sidx8) {
+          grad_attn[lw_base + first + d4] = keep_w;
+          *reinterpret_cast<float2*>(grad_loc + (lw_base + first + d4) * 2) = make_float2(keep_x, keep_y);
+        }
       }
     }
   }
