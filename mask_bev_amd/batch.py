@@ -40,6 +40,43 @@ def read_semantic_kitti_label(path) -> Tuple[np.ndarray, np.ndarray]:
     return raw & 0xFFFF, raw >> 16
 
 
+def apply_learning_map(sem: np.ndarray, inst: np.ndarray, learning_map_lut: np.ndarray, unlabeled: int = 0):
+    """Class remap of semantic_kitti_dataset.py:369-372: ``sem`` through the learning-map look-up table, instance ids of
+    points that become UNLABELED cleared."""
+    sem = learning_map_lut[sem]
+    inst = inst.copy()
+    inst[sem == unlabeled] = 0
+    return sem, inst
+
+
+def read_poses(path) -> np.ndarray:
+    """``sequences/SS/poses.txt`` → (N, 4, 4) f64 origin-to-scan transforms: each line holds the upper 3 x 4 block,
+    the omitted last row is (0, 0, 0, 1) (semantic_kitti_dataset.py:336-349)."""
+    reduced = np.loadtxt(str(path), ndmin=2)
+    n = reduced.shape[0]
+    full = np.zeros((n, 4, 4))
+    full[:, :3, :] = reduced.reshape(n, 3, 4)
+    full[:, 3, 3] = 1
+    return full
+
+
+def read_calib(path) -> dict:
+    """``sequences/SS/calib.txt`` → ``{'p0': (3, 4), ..., 'velo_to_cam': (4, 4)}`` (``Tr`` completed with the row
+    (0, 0, 0, 1); the other keys lower-cased — the fields of SemanticKittiCalib, semantic_kitti_dataset.py:374-385)."""
+    calib = {}
+    with open(str(path), 'r') as f:
+        for line in f:
+            if ':' not in line:
+                continue
+            k, v = line.split(':')
+            mat = np.array(v.split(), dtype=np.float64).reshape(3, 4)
+            if k == 'Tr':
+                calib['velo_to_cam'] = np.vstack((mat, [0, 0, 0, 1]))
+            else:
+                calib[k.lower()] = mat
+    return calib
+
+
 def read_mask_cache(path) -> np.ndarray:
     """The reference's per-scan mask cache (``np.save`` of the (nx, ny) instance map,
     semantic_kitti_mask_dataset.py:121-137)."""

@@ -86,6 +86,10 @@ class PillarFeatureNet(nn.Module):
 
     def forward(self, p: Pillars) -> torch.Tensor:
         rows, _ = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)              # K2a: (K, D+7)
+        return self.forward_rows(rows, p)
+
+    def forward_rows(self, rows: torch.Tensor, p: Pillars) -> torch.Tensor:
+        """The PFN layers on already decorated compact rows (K, in_channels + 7)."""
         layers = [(l.linear.weight, l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var, l.norm.eps,
                    l.norm.momentum) for l in self.pfn_layers]
         out = ops.pfn_layers(rows, p, layers, self.training)                                # K2b
@@ -94,6 +98,25 @@ class PillarFeatureNet(nn.Module):
                 for l in self.pfn_layers:
                     l.norm.num_batches_tracked.add_(1)
         return out
+
+
+class LearnableFourierPositionalEncoding(nn.Module):
+    """Per-point learnable Fourier features — same constructor, parameter names (``Wr``, ``mlp.0``, ``mlp.2``) and
+    arithmetic as /root/reference: mask_bev/models/positional_encoding/learnable_fourier_positional_encoding.py:6-59
+    (x (N, G, M) → (N, D)); evaluated on the real points only (see :meth:`MaskBevEncoder._fourier_rows`)."""
+
+    def __init__(self, G: int, M: int, F_dim: int, H_dim: int, D: int, gamma: float):
+        super().__init__()
+        self.G, self.M, self.F_dim, self.H_dim, self.D, self.gamma = G, M, F_dim, H_dim, D, gamma
+        self.Wr = nn.Linear(M, F_dim // 2, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(F_dim, H_dim, bias=True), nn.GELU(), nn.Linear(H_dim, D // G))
+        nn.init.normal_(self.Wr.weight.data, mean=0, std=gamma ** -2)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        n = x.shape[0]
+        projected = self.Wr(x)
+        f = torch.cat([torch.cos(projected), torch.sin(projected)], dim=-1) / (self.F_dim ** 0.5)
+        return self.mlp(f).reshape(n, self.D)
 
 
 class PointPillarsScatter(nn.Module):
@@ -124,20 +147,27 @@ class MaskBevEncoder(nn.Module):
                  encoder_params: Optional[Dict] = None, pc_point_dim: int = 4):
         super().__init__()
         encoder_params = encoder_params or {}
-        if encoding_type != EncodingType.Vanilla:
-            # no shipped config enables the fourier encoder: out of scope for this path
+        if encoding_type == EncodingType.Vanilla:
+            self._pos_encoder = None
+            pc_in_channels = pc_point_dim
+        elif encoding_type == EncodingType.Fourier:                      # mask_bev_encoders.py:51-58
+            pc_in_channels = 128
+            self._pos_encoder_group = fourier_enc_group
+            self._pos_encoder_M = 4 // fourier_enc_group
+            self._pos_encoder = LearnableFourierPositionalEncoding(G=fourier_enc_group, M=self._pos_encoder_M,
+                                                                   F_dim=32, H_dim=32, D=pc_in_channels, gamma=1.0)
+        else:
             raise NotImplementedError(f'{encoding_type}')
         self._feat_channels = list(feat_channels)
         self._out_features = feat_channels[-1]
         self._x_range, self._y_range, self._z_range = x_range, y_range, z_range
-        self._pos_encoder = None
         self._num_voxel_x = int((x_range[1] - x_range[0]) / voxel_size_x)
         self._num_voxel_y = int((y_range[1] - y_range[0]) / voxel_size_y)
         self._num_voxel_z = 1
         point_cloud_range = [x_range[0], y_range[0], z_range[0], x_range[1], y_range[1], z_range[1]]
         voxel_size = [voxel_size_x, voxel_size_y, voxel_size_z]
         self._voxel_layer = Voxelization(voxel_size, point_cloud_range, max_num_points, max_voxels, deterministic)
-        self._voxel_encoder = PillarFeatureNet(in_channels=pc_point_dim, feat_channels=self._feat_channels,
+        self._voxel_encoder = PillarFeatureNet(in_channels=pc_in_channels, feat_channels=self._feat_channels,
                                                voxel_size=voxel_size, point_cloud_range=point_cloud_range,
                                                **encoder_params)
         out_shape = [self._num_voxel_y, self._num_voxel_x]
@@ -150,10 +180,41 @@ class MaskBevEncoder(nn.Module):
         destination buffer for the result."""
         batch = len(point_clouds)
         pillars = self._voxel_layer.pillars(point_clouds, prefilter=True)
-        feats = self._voxel_encoder(pillars)
+        if self._pos_encoder is not None:
+            feats = self._voxel_encoder.forward_rows(self._fourier_rows(pillars), pillars)
+        else:
+            feats = self._voxel_encoder(pillars)
         ln = self._layer_norm
         return ops.scatter_layernorm(feats, ln.weight, ln.bias, pillars, batch, self._num_voxel_y, self._num_voxel_x,
                                      ln.eps, patch, out)
+
+    def _fourier_rows(self, p: Pillars) -> torch.Tensor:
+        """Decorated PFN input rows (K, 128 + 7) of the REAL points under the Fourier per-point encoding
+        (mask_bev_encoders.py:85-89 + mmdet3d PillarFeatureNet, legacy).  The reference encodes every slot of the dense
+        zero-padded (V, P, 4) tensor, so a padded slot carries the constant encoding e0 of the origin; the decoration
+        then zeroes padded rows again, and the only trace e0 leaves is in ``points_mean``, which sums the first three
+        channels over all P slots: mean = (sum over real points + (P - n) e0) / n.  That term is added here, and the
+        PFN layers see exactly the rows of the dense evaluation.  Plain differentiable torch ops (the encoder's MLP is
+        a few hundred parameters on K ~ 10^5 rows); the PFN layers themselves stay on K2b."""
+        enc = self._pos_encoder
+        dev = p.points.device
+        idx = p.pillar_points.reshape(-1)
+        idx = idx[idx >= 0].long()                                  # compact row order: pillar by pillar, slot by slot
+        pts = p.points[idx][:, :4]
+        e = enc(pts.reshape(-1, enc.G, enc.M))                      # (K, 128)
+        e0 = enc(torch.zeros(1, enc.G, enc.M, device=dev, dtype=pts.dtype))[0, :3]
+        n = p.num_points.to(e.dtype)                                # (V,)
+        row_pillar = torch.repeat_interleave(torch.arange(p.num_pillars, device=dev), p.num_points.long())
+        sums = torch.zeros(p.num_pillars, 3, device=dev, dtype=e.dtype).index_add_(0, row_pillar, e[:, :3])
+        mean = (sums + (p.max_points - n).unsqueeze(1) * e0.unsqueeze(0)) / n.unsqueeze(1)
+        vs, rng = self._voxel_encoder.voxel_size, self._voxel_encoder.point_cloud_range
+        c = p.coors.to(e.dtype)
+        center = torch.stack([c[:, 3] * vs[0] + (vs[0] / 2 + rng[0]), c[:, 2] * vs[1] + (vs[1] / 2 + rng[1]),
+                              c[:, 1] * vs[2] + (vs[2] / 2 + rng[2])], 1)
+        f_cluster = e[:, :3] - mean[row_pillar]
+        f_center = e[:, :3] - center[row_pillar]                    # legacy: written over channels 0..2
+        dist = f_center.norm(dim=1, keepdim=True)
+        return torch.cat([f_center, e[:, 3:], f_cluster, f_center, dist], 1)
 
     def patch_layout(self, patch: int) -> bool:
         return ops.patch_layout_supported(self._out_features, self._num_voxel_y, self._num_voxel_x, patch)

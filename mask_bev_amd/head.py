@@ -28,12 +28,12 @@ class MaskBevPanopticHead(nn.Module):
 
     def update_mAP_metrics(self, layer_index: int, pred_cls, pred_masks, labels_gt, masks_gt, cls_metric=None,
                            map_metric=None, mIoU_metric=None):
-        """mask_bev_panoptic_head.py:34-96 for the classification and mIoU metrics (mask_bev_amd/metrics.py): the
-        assignment of the loss just evaluated is reused and the mask IoU runs on K15.  ``map_metric`` (torchmetrics'
-        MeanAveragePrecision in the reference) is not fed — torchmetrics is outside this path."""
+        """mask_bev_panoptic_head.py:34-96 (mask_bev_amd/metrics.py): the assignment of the loss just evaluated is reused,
+        the matched mask IoU runs on K15, and ``map_metric`` (torchmetrics' COCO mask mAP in the reference) is a
+        :class:`~mask_bev_amd.metrics.MaskMeanAveragePrecision` fed with device-side pairwise IoUs."""
         from . import metrics
         metrics.update_metrics(self._panoptic_head, layer_index, pred_cls, pred_masks, labels_gt, masks_gt, cls_metric,
-                               mIoU_metric)
+                               mIoU_metric, map_metric)
 
     @staticmethod
     def _get_config(num_things_classes, num_stuff_classes, num_queries, in_channels, head_feat_channels,

@@ -282,19 +282,25 @@ class MaskBevModule(_Base):
     def validation_step(self, val_batch, batch_idx):
         return self._step(val_batch, batch_idx, 'val')
 
-    def enable_metrics(self, layers=(9,), train: bool = True, val: bool = True):
+    def enable_metrics(self, layers=(9,), train: bool = True, val: bool = True, mask_map: bool = False):
         """Build extension: attach the GPU-native classification / mIoU metrics (mask_bev_amd/metrics.py) to the
         given decoder layers, in the reference's ``{layer: (cls_metric, map_metric, miou_metric)}`` layout
-        (mask_bev_module.py:85-98; the torchmetrics mask-mAP slot stays ``None``)."""
-        from .metrics import BinaryClassifScores, MeanIoU
+        (mask_bev_module.py:85-98).  ``mask_map=True`` also fills the COCO mask-mAP slot (needs dense ground-truth
+        masks in the batch)."""
+        from .metrics import BinaryClassifScores, MaskMeanAveragePrecision, MeanIoU
         for flag, store in ((train, self._train_metric_per_layer), (val, self._val_metric_per_layer)):
             if flag:
                 for layer in layers:
-                    store[int(layer)] = (BinaryClassifScores(), None, MeanIoU())
+                    store[int(layer)] = (BinaryClassifScores(), MaskMeanAveragePrecision() if mask_map else None,
+                                         MeanIoU())
 
     def log_metrics(self, mode: str, per_layer):
         """mask_bev_module.py:209-224: log and reset the per-layer metrics at the end of an epoch."""
-        for layer_index, (cls_metric, _map_metric, miou_metric) in per_layer.items():
+        for layer_index, (cls_metric, map_metric, miou_metric) in per_layer.items():
+            if map_metric is not None:                    # mask_bev_module.py:212-219
+                for name, value in map_metric.compute().items():
+                    self.log(f'{mode}_mAP_{layer_index}_{name}', float(value), sync_dist=True)
+                map_metric.reset()
             if cls_metric is not None:
                 self.log(f'{mode}_cls_mAP_layer_{layer_index}', float(cls_metric.compute()), sync_dist=True)
                 cls_metric.reset()

@@ -266,7 +266,7 @@ class _PillarFeatureNet(torch.autograd.Function):
         grads = [None] * (5 * n_layers)
         with torch.autocast('cuda', enabled=False):
             dm = d_out.float().contiguous()
-            da, sapad = None, None
+            da, sapad, d_rows = None, None, None
             for l in reversed(range(n_layers)):
                 a_prev, apad_prev, m_prev, y, ypad, scale, shift, mean, rstd, w, g = ctx.saved[l]
                 u = int(w.shape[0])
@@ -287,6 +287,8 @@ class _PillarFeatureNet(torch.autograd.Function):
                 dy, dypad = dz, dzpad
                 if l == 0:
                     gw = _wgrad(dy, a_prev)
+                    # d(rows): only a learnable per-point encoding in front of the PFN asks for it (A3, fourier)
+                    d_rows = dy.mm(w) if ctx.needs_input_grad[0] else None
                     da = sapad = dm = None
                 else:
                     ca = int(a_prev.shape[1])
@@ -297,7 +299,7 @@ class _PillarFeatureNet(torch.autograd.Function):
                     dm = dt.mm(wb)
                 grads[5 * l] = gw.to(dtypes[5 * l])
         ctx.saved = None
-        return (None,) * 8 + tuple(grads)
+        return (d_rows,) + (None,) * 7 + tuple(grads)
 
 
 def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torch.Tensor:

@@ -42,7 +42,8 @@ def make_cfg(x_range, y_range, z_range, voxel_size, num_queries, max_num_points,
              depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), mlp_ratio=4,
              pd_layers=6, pd_heads=8, pd_levels=3, pd_points=4, pd_ffn=1024,
              dec_layers=9, dec_heads=8, dec_ffn=2048, num_points=12544,
-             oversample_ratio=3.0, importance_sample_ratio=0.75, **_ignored) -> SimpleNamespace:
+             oversample_ratio=3.0, importance_sample_ratio=0.75, encoder_encoding_type='vanilla',
+             encoder_fourier_enc_group=1, **_ignored) -> SimpleNamespace:
     """Same keyword names as ``MaskBevModule.__init__`` (mask_bev_module.py:35-43).
     The trailing architecture keywords default to the values hard-coded at
     mask_bev_backbone.py:41-64 and mask_bev_panoptic_head.py:105-215 and exist only
@@ -73,6 +74,10 @@ def make_cfg(x_range, y_range, z_range, voxel_size, num_queries, max_num_points,
     c.reverse_class_weights = head_reverse_class_weights
     c.num_classes = head_num_classes
     c.pc_dim = pc_point_dim
+    # mask_bev_encoders.py:51-58: 'fourier' feeds a 128-channel per-point encoding to the PillarFeatureNet
+    c.encoding_type = encoder_encoding_type
+    c.fourier_group = encoder_fourier_enc_group
+    c.pfn_in = 128 if encoder_encoding_type == 'fourier' else pc_point_dim
     c.depths, c.num_heads, c.mlp_ratio = tuple(depths), tuple(num_heads), mlp_ratio
     c.pd_layers, c.pd_heads, c.pd_levels, c.pd_points, c.pd_ffn = pd_layers, pd_heads, pd_levels, pd_points, pd_ffn
     c.dec_layers, c.dec_heads, c.dec_ffn = dec_layers, dec_heads, dec_ffn
@@ -262,9 +267,29 @@ def scatter_to_canvas(cfg, feats: Tensor, coors: Tensor, batch_size: int) -> Ten
     return torch.stack(out, 0).view(batch_size, c, cfg.ny, cfg.nx)
 
 
+def fourier_encode(sd: SD, x: Tensor, p: str = ENC + '_pos_encoder.') -> Tensor:
+    """LearnableFourierPositionalEncoding.forward (mask_bev/models/positional_encoding/
+    learnable_fourier_positional_encoding.py:41-59): x (N, G, M) → (N, D).  PINNED by tests/golden/fourier.npz
+    (the reference class itself, run by tests/golden/make_golden_fourier.py)."""
+    n = x.shape[0]
+    projected = F.linear(x, sd[p + 'Wr.weight'])                                     # (N, G, F/2), no bias
+    f_dim = 2 * projected.shape[-1]
+    feats = torch.cat([torch.cos(projected), torch.sin(projected)], dim=-1) / math.sqrt(f_dim)
+    y = F.linear(F.gelu(F.linear(feats, sd[p + 'mlp.0.weight'], sd[p + 'mlp.0.bias'])),
+                 sd[p + 'mlp.2.weight'], sd[p + 'mlp.2.bias'])
+    return y.reshape(n, -1)
+
+
 def encoder_forward(cfg, sd: SD, point_clouds: Sequence[Tensor], training: bool = True, return_parts: bool = False):
     """MaskBevEncoder.forward, mask_bev_encoders.py:77-93."""
     voxels, nump, coors = voxelize(cfg, point_clouds)
+    if getattr(cfg, 'encoding_type', 'vanilla') == 'fourier':
+        # mask_bev_encoders.py:85-89: EVERY slot of the dense (V, P, 4) tensor is encoded, the zero padding included —
+        # a padded slot becomes the constant encoding of the origin and takes part in the PFN's points_mean
+        v, npts, _ = voxels.shape
+        g = cfg.fourier_group
+        x = voxels.reshape(v * npts, -1).reshape(-1, g, 4 // g)
+        voxels = fourier_encode(sd, x).reshape(v, npts, -1)
     feats = pfn_forward(cfg, sd, voxels, nump, coors, training)
     canvas = scatter_to_canvas(cfg, feats, coors, len(point_clouds))
     w, b = sd[ENC + '_layer_norm.weight'], sd[ENC + '_layer_norm.bias']
@@ -767,7 +792,13 @@ def make_state_dict(cfg, seed: int = 0, scale: float = 1.0) -> SD:
         sd[p + '.bias'] = rn(c, std=0.1)
 
     # encoder
-    cin = cfg.pc_dim + 7
+    if getattr(cfg, 'encoding_type', 'vanilla') == 'fourier':
+        g_, m_ = cfg.fourier_group, 4 // cfg.fourier_group
+        pe = ENC + '_pos_encoder.'
+        sd[pe + 'Wr.weight'] = rn(16, m_, std=1.0)                                   # F_dim 32, gamma 1 (:56-58)
+        lin(pe + 'mlp.0', 32, 32)
+        lin(pe + 'mlp.2', 128 // g_, 32)
+    cin = getattr(cfg, 'pfn_in', cfg.pc_dim) + 7
     chans = [cin] + cfg.feat_channels
     for i in range(len(cfg.feat_channels)):
         last = i == len(cfg.feat_channels) - 1

@@ -71,3 +71,40 @@ def test_module_step_feeds_metrics(device):
     assert 0.0 <= float(miou.compute()) <= 1.0
     m.on_train_epoch_end()
     assert miou.ious == []
+
+
+def test_module_step_feeds_mask_map_metric(device):
+    """The `map_metric` slot (mask_bev_panoptic_head.py:87-96): fed from a training step with device-side pairwise
+    IoUs; the stored IoU matrix equals the oracle's dense pairwise IoU of the upsampled, thresholded masks, and
+    compute() returns the twelve COCO numbers equal to the oracle's plain-loop COCOeval on the same state."""
+    import torch.nn.functional as F
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    from oracle import metrics_oracle as MO
+    torch.manual_seed(0)
+    kw = tiny_kwargs(nx=96, ny=96, q=8)
+    m = MaskBevModule(**kw).to(device).train()
+    m.log_scalars = False
+    m._panoptic_head._panoptic_head.num_points = 500
+    m.enable_metrics(layers=(9,), val=False, mask_map=True)
+    scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
+    labels, gt = random_gt(kw, 2, 3, seed=10)
+    with torch.no_grad():
+        _, masks, _ = m(scans)
+    loss = m.training_step((scans, (labels.to(device), gt.to(device))), 0)
+    assert torch.isfinite(loss)
+    _, map_metric, _ = m._train_metric_per_layer[9]
+    assert len(map_metric.images) == 2
+    for i, im in enumerate(map_metric.images):
+        up = F.interpolate(masks[9][i].float().cpu().unsqueeze(1), gt.shape[-2:], mode='bilinear',
+                           align_corners=False).squeeze(1)
+        ref = MO.pairwise_mask_iou(torch.sigmoid(up) > 0.5, gt[i] > 0.5)
+        # bf16 GEMM inputs can move a logit across 0 only where |logit| is at rounding level: compare loosely there
+        assert np.abs(im['ious'].numpy() - ref).max() < 2e-2
+    got = map_metric.compute()
+    ref = MO.coco_mask_map([{k: v.numpy() for k, v in im.items()} for im in map_metric.images])
+    assert set(got) == {'map', 'map_50', 'map_75', 'map_small', 'map_medium', 'map_large', 'mar_1', 'mar_10',
+                        'mar_100', 'mar_small', 'mar_medium', 'mar_large'}
+    for k in ref:
+        assert got[k] == pytest.approx(ref[k], abs=1e-12), k
+    m.on_train_epoch_end()
+    assert map_metric.images == []

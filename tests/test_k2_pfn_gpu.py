@@ -59,3 +59,36 @@ def test_pfn_matches_dense_oracle(device, chans, P, sizes, training):
             torch.testing.assert_close(buf.cpu(), want, rtol=1e-4, atol=1e-6)
         if 'num_batches_tracked' in name:
             assert int(buf) == (1 if training else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('group', [1, 2])
+def test_fourier_encoder_matches_dense_oracle(device, group):
+    """A3 (mask_bev_encoders.py:85-89): `encoder_encoding_type='fourier'` — the product evaluates the per-point
+    Fourier MLP and the PFN on real points only (padded slots enter through the (P - n) e0 term of points_mean);
+    the oracle encodes the dense zero-padded (V, P, 4) tensor like the reference.  Pseudo-image within 1e-4, and
+    the gradients of the encoding's own parameters and of the first PFN layer within 1e-3."""
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    from oracle import maskbev_oracle as O
+    from tests.util_cfg import random_scans, tiny_kwargs
+    kw = dict(tiny_kwargs(nx=48, ny=48, p=8), encoder_encoding_type='fourier', encoder_fourier_enc_group=group)
+    cfg = O.make_cfg(**kw)
+    sd = O.make_state_dict(cfg, 3)
+    m = MaskBevModule(**kw)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).train()
+    scans = random_scans(kw, [1500, 900], seed=5)
+    out = m.forward_encode([s.to(device) for s in scans])
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    (out * w.to(device)).sum().backward()
+    sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
+            for k, v in sd.items()}
+    ref = O.encoder_forward(cfg, sd_g, scans, training=True)
+    (ref * w).sum().backward()
+    assert float((out.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-4
+    got = dict(m.named_parameters())
+    for k in ['_encoder._pos_encoder.Wr.weight', '_encoder._pos_encoder.mlp.0.weight', '_encoder._pos_encoder.mlp.2.bias',
+              '_encoder._voxel_encoder.pfn_layers.0.linear.weight', '_encoder._voxel_encoder.pfn_layers.1.norm.weight']:
+        g, r = got[k].grad.cpu(), sd_g[k].grad
+        assert float((g - r).abs().max() / r.abs().max().clamp(min=1e-9)) < 1e-3, k
