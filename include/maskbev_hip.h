@@ -506,7 +506,9 @@ int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, 
  *                   out); colsum (k) f32 (optional) += column sums of the stored out (the bias gradient of the
  *                   Linear in front of the activation; needs `workspace` of mbv_gemm16_nn_workspace_bytes).
  *   mbv_gemm16_tn   accumulate != 0: dw (n, k) f32 += g (m, n)^T . x (m, k), the sum over m split over `splits`
- *                   workgroups per tile (0 = choose) that add with f32 atomics (dw is the parameter arena's gradient);
+ *                   workgroups per tile (0 = choose).  With a `workspace` of mbv_gemm16_tn_workspace_bytes (dw
+ *                   contiguous, batch 1) the parts are stored and added by their owner thread (no atomics, bit-
+ *                   reproducible); without it they add with f32 atomics (dw is the parameter arena's gradient);
  *                   accumulate == 0: dw = g^T . x stored once (16-bit or f32).
  */
 int mbv_gemm16_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
@@ -530,9 +532,12 @@ int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, floa
                   int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w, int64_t stride_o, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+size_t mbv_gemm16_tn_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
 int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldx,
                   int64_t lddw, int32_t dtype, int32_t accumulate, int32_t out_f32, int32_t splits, int32_t batch,
-                  int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* stream);
+                  int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,18 +36,28 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 128;
 constexpr int STG_LD = 68;                        // f32 row stride of a wave's 32 x 64 epilogue tile
-constexpr int STG_BYTES = 4 * 32 * STG_LD * 4;    // four waves
 constexpr unsigned OOB = 0x80000000u;             // byte offset beyond any descriptor: the load returns zero
 
-template <int KB, int NS = 2>
+// Block shape: WM x 2 waves, each wave TM x TN MFMA tiles of 32 x 32  =>  BM = 32 TM WM rows, BN = 64 TN columns.
+//   128 x 128 (WM 2, 2 x 2 tiles, 256 threads)  — the default
+//   256 x 128 (WM 4, 2 x 2 tiles, 512 threads)  — twice the rows per B-tile fetch: 85 instead of 64 flop per staged byte
+//   384 x 192 (WM 4, 3 x 3 tiles, 512 threads)  — the weight-gradient shape: 128 flop per byte, one workgroup per CU
+// An operand tile wider than 128 rows / columns is staged as 128-wide sub-images, so the swizzles below never change.
+template <int KB, int NS, int WM = 2, int TM = 2, int TN = 2>
 struct Geo {
-  static constexpr int IMG = 128 * KB * 2;        // one operand tile
-  static constexpr int STAGE = 2 * IMG;           // A + B
-  static constexpr int PW = KB / 16;              // 1-KiB LDS-DMA pieces per wave and operand tile
-  static constexpr int LDS = NS * STAGE > STG_BYTES ? NS * STAGE : STG_BYTES;
-  static constexpr int WPS = LDS <= 40960 ? 4 : (LDS <= 53248 ? 3 : (LDS <= 81920 ? 2 : 1));   // workgroups per CU
+  static constexpr int NW = 2 * WM;                                   // waves
+  static constexpr int BM = 32 * TM * WM, BN = 64 * TN;
+  static constexpr int SA = (BM + 127) / 128, SB = (BN + 127) / 128;  // 128-wide sub-images per operand tile
+  static constexpr int IMG = 128 * KB * 2;                            // one sub-image
+  static constexpr int STAGE = (SA + SB) * IMG;
+  static constexpr int PPS = IMG / 1024;                              // 1-KiB LDS-DMA pieces per sub-image
+  static constexpr int PIECES = (SA + SB) * PPS;
+  static constexpr int NP = (PIECES + NW - 1) / NW;                   // pieces per wave and K-step
+  static constexpr int STG = NW * 32 * STG_LD * 4;                    // epilogue staging (STORE, TN == 2)
+  static constexpr int LDS = NS * STAGE > STG ? NS * STAGE : STG;
+  static constexpr int BLOCKS = LDS <= 40960 ? 4 : (LDS <= 53248 ? 3 : (LDS <= 81920 ? 2 : 1));   // per CU, by LDS
+  static constexpr int WPS = (BLOCKS * NW + 3) / 4 > 8 ? 8 : (BLOCKS * NW + 3) / 4;               // waves per SIMD
 };
 
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_DRELU = 3, EPI_DGELU = 4 };
@@ -59,10 +69,11 @@ struct GemmArgs {
   void* c2;             // STORE + EPI_GELU / EPI_RELU: optional pre-activation output (same type as c)
   const void* aux;      // EPI_DRELU / EPI_DGELU: saved activation output / pre-activation, (gm, gn) 16-bit, ld = ldx
   const float* bias;    // STORE: optional, (gn)
-  float* colsum_rows;   // STORE: optional, (2 ntm, gn) f32: column sums of the stored values per wave row
+  float* colsum_rows;   // STORE: optional, (WM ntm, gn) f32: column sums of the stored values per wave row
   int gm, gn, gk;       // GEMM dims: C (gm x gn) = A (gm x gk) . B (gk x gn)
   int lda, ldb, ldc, ldx;
   long long sa, sb, sc; // batch strides (elements)
+  long long ssplit;     // STORE with splits > 1: element stride between the partial results of the K parts
   unsigned a_bytes, b_bytes;   // extent of one batch item of A / B for the buffer descriptors
   int ntm, ntn, splits, ksteps;  // tiles, split-K parts, K-steps of KB per part
   int out_f32;
@@ -148,24 +159,21 @@ __device__ __forceinline__ void ks_lane(int piece, int lane, int& r, int& c) {
   c = (lane & 15) ^ ks_swz(r);
 }
 
-// Per-lane byte offsets of a wave's pieces for the K-step that starts at k0 (every bound checked per lane:
-// out-of-range elements get the OOB offset and arrive as zeros).
+// Byte offset of lane `lane` of piece `local` (0 .. PPS-1) of sub-image `sub` of an operand tile whose first row /
+// column is x0, for the K-step that starts at k0.  Every bound is checked: out-of-range elements get the OOB offset
+// and arrive as zeros.
 template <int KB, bool KS>
-__device__ __forceinline__ void piece_offsets(unsigned (&off)[Geo<KB>::PW], int x0, int x_total, int ld_bytes, int k0,
-                                              int k_end, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < Geo<KB>::PW; ++j) {
-    int r, c;
-    if (KS) {
-      ks_lane(wave * Geo<KB>::PW + j, lane, r, c);
-      const int gk = k0 + r, gx = x0 + 8 * c;
-      off[j] = (gk < k_end && gx < x_total) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gx * 2u : OOB;
-    } else {
-      kc_lane<KB>(wave * Geo<KB>::PW + j, lane, r, c);
-      const int gx = x0 + r, gk = k0 + 8 * c;
-      off[j] = (gx < x_total && gk < k_end) ? (unsigned)gx * (unsigned)ld_bytes + (unsigned)gk * 2u : OOB;
-    }
+__device__ __forceinline__ unsigned piece_offset(int sub, int local, int x0, int x_total, int ld_bytes, int k0, int k_end,
+                                                 int lane) {
+  int r, c;
+  if (KS) {
+    ks_lane(local, lane, r, c);
+    const int gk = k0 + r, gx = x0 + 128 * sub + 8 * c;
+    return (gk < k_end && gx < x_total) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gx * 2u : OOB;
   }
+  kc_lane<KB>(local, lane, r, c);
+  const int gx = x0 + 128 * sub + r, gk = k0 + 8 * c;
+  return (gx < x_total && gk < k_end) ? (unsigned)gx * (unsigned)ld_bytes + (unsigned)gk * 2u : OOB;
 }
 
 // ---- LDS -> MFMA fragments ---------------------------------------------------------------------------------------
@@ -230,9 +238,11 @@ __device__ __forceinline__ void round8(float (&v)[8]) {
 }
 
 // OUT: 0 = STORE (C^T accumulators, row-major store through LDS with the epilogue), 1 = ATOMIC (f32 adds)
-template <int KB, int NS, bool A_KS, bool B_KS, int OUT, int EPI, typename T>
-__global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmArgs p) {
-  using G = Geo<KB, NS>;
+template <int KB, int NS, int WM, int TM, int TN, bool A_KS, bool B_KS, int OUT, int EPI, typename T>
+__global__ void __launch_bounds__(64 * 2 * WM, (Geo<KB, NS, WM, TM, TN>::WPS)) k_gemm16(const GemmArgs p) {
+  using G = Geo<KB, NS, WM, TM, TN>;
+  static_assert(OUT == 1 || TN == 2, "the STORE epilogue turns 64-column wave tiles");
+  constexpr int BM = G::BM, BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,47 +271,44 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
   const unsigned smem_addr = lds_addr_of(smem);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // loop-invariant offsets of this lane's pieces at the first K-step; a full K-step s adds the scalar s * step
+  // This wave's LDS-DMA pieces: piece pi = wave + NW j of the stage (sub-images of A first, then of B).  Offsets at
+  // the first K-step are loop-invariant; a full K-step s adds the scalar s * step of its operand.
   const bool ragged = ((k_end - k_begin) & (KB - 1)) != 0;
-  unsigned offa[G::PW], offb[G::PW];
-  piece_offsets<KB, A_KS>(offa, m0, p.gm, p.lda * 2, k_begin, k_begin + KB, wave, lane);
-  piece_offsets<KB, B_KS>(offb, n0, p.gn, p.ldb * 2, k_begin, k_begin + KB, wave, lane);
   const unsigned stepa = A_KS ? (unsigned)(KB * 2) * (unsigned)p.lda : (unsigned)(KB * 2);
   const unsigned stepb = B_KS ? (unsigned)(KB * 2) * (unsigned)p.ldb : (unsigned)(KB * 2);
+  auto piece_off = [&](int j, int k0, int kend) -> unsigned {
+    const int pi = wave + G::NW * j;
+    const int sub = pi / G::PPS, local = pi - sub * G::PPS;
+    if (pi >= G::PIECES) return OOB;
+    if (sub < G::SA) return piece_offset<KB, A_KS>(sub, local, m0, p.gm, p.lda * 2, k0, kend, lane);
+    return piece_offset<KB, B_KS>(sub - G::SA, local, n0, p.gn, p.ldb * 2, k0, kend, lane);
+  };
+  unsigned off[G::NP];
+#pragma unroll
+  for (int j = 0; j < G::NP; ++j) off[j] = piece_off(j, k_begin, k_begin + KB);
 
   // K-step kt of this workgroup goes into ring slot kt % NS; a step beyond the range is issued as zero fills (no
   // memory traffic) so that every step leaves the same number of loads on the wave's counter
   auto stage = [&](int kt) {
-    const unsigned aimg = smem_addr + (kt % NS) * G::STAGE + wave * (G::PW * 1024), bimg = aimg + G::IMG;
-    if (kt >= nk) {
+    const unsigned slot = smem_addr + (kt % NS) * G::STAGE;
+    const bool tail = ragged && kt == nk - 1;            // the only K-step with k's beyond the range
 #pragma unroll
-      for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, OOB, 0u);
-#pragma unroll
-      for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, OOB, 0u);
-      return;
+    for (int j = 0; j < G::NP; ++j) {
+      const int pi = wave + G::NW * j;
+      if (G::PIECES % G::NW != 0 && pi >= G::PIECES) continue;       // (wave-uniform) this wave has one piece fewer
+      const bool is_a = pi < G::SA * G::PPS;
+      unsigned v = off[j], sof = (unsigned)kt * (is_a ? stepa : stepb);
+      if (kt >= nk) { v = OOB; sof = 0u; }
+      else if (tail) { v = piece_off(j, k_begin + kt * KB, k_end); sof = 0u; }
+      glds16(is_a ? ra : rb, slot + pi * 1024, v, sof);
     }
-    if (ragged && kt == nk - 1) {                        // the only K-step with k's beyond the range: checked per lane
-      unsigned ta[G::PW], tb[G::PW];
-      piece_offsets<KB, A_KS>(ta, m0, p.gm, p.lda * 2, k_begin + kt * KB, k_end, wave, lane);
-      piece_offsets<KB, B_KS>(tb, n0, p.gn, p.ldb * 2, k_begin + kt * KB, k_end, wave, lane);
-#pragma unroll
-      for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, ta[j], 0u);
-#pragma unroll
-      for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, tb[j], 0u);
-      return;
-    }
-    const unsigned sa = (unsigned)kt * stepa, sb = (unsigned)kt * stepb;
-#pragma unroll
-    for (int j = 0; j < G::PW; ++j) glds16(ra, aimg + j * 1024, offa[j], sa);
-#pragma unroll
-    for (int j = 0; j < G::PW; ++j) glds16(rb, bimg + j * 1024, offb[j], sb);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -311,27 +318,36 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) stage(s);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * G::PW) : "memory");
+    if (G::PIECES % G::NW == 0 || wave < G::PIECES % G::NW)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G::NP) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (G::NP - 1)) : "memory");
     __syncthreads();
     stage(kt + NS - 1);
     const char* aimg = smem + (kt % NS) * G::STAGE;
-    const char* bimg = aimg + G::IMG;
-    uint4 af[KB / 16][2], bf[KB / 16][2];
+    const char* bimg = aimg + G::SA * G::IMG;
+    uint4 af[KB / 16][TM], bf[KB / 16][TN];
 #pragma unroll
     for (int ks = 0; ks < KB / 16; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[ks][i] = A_KS ? frag_ks(aimg, 64 * wm + 32 * i, ks, lane) : frag_kc<KB>(aimg, 64 * wm + 32 * i, ks, lane);
+      for (int i = 0; i < TM; ++i) {
+        const int x = 32 * (wm * TM + i);                 // 32-row tiles never straddle a 128-wide sub-image
+        const char* im = aimg + (x >> 7) * G::IMG;
+        af[ks][i] = A_KS ? frag_ks(im, x & 127, ks, lane) : frag_kc<KB>(im, x & 127, ks, lane);
+      }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bf[ks][j] = B_KS ? frag_ks(bimg, 64 * wn + 32 * j, ks, lane) : frag_kc<KB>(bimg, 64 * wn + 32 * j, ks, lane);
+      for (int j = 0; j < TN; ++j) {
+        const int x = 32 * (wn * TN + j);
+        const char* im = bimg + (x >> 7) * G::IMG;
+        bf[ks][j] = B_KS ? frag_ks(im, x & 127, ks, lane) : frag_kc<KB>(im, x & 127, ks, lane);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < KB / 16; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = OUT == 0 ? Mma<T>::run(bf[ks][j], af[ks][i], acc[i][j]) : Mma<T>::run(af[ks][i], bf[ks][j], acc[i][j]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero fills of the tail: nothing may land in LDS later
@@ -342,13 +358,13 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
     // acc[i][j][e]: row m = acc_row(e, h) of tile i, column n = r of tile j
     float* c = reinterpret_cast<float*>(p.c) + (size_t)bz * (size_t)p.sc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + 64 * wn + 32 * j + r;
+      for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + 32 * (wn * TN + j) + r;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int gm = m0 + 64 * wm + 32 * i + acc_row(e, h);
+          const int gm = m0 + 32 * (wm * TM + i) + acc_row(e, h);
           if (gm < p.gm && gn < p.gn) atomicAdd(c + (size_t)gm * p.ldc + gn, acc[i][j][e]);
         }
       }
@@ -360,13 +376,13 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
   const int prow = lane >> 3, cg = lane & 7;
   const int gn = n0 + 64 * wn + 8 * cg;
   const bool col_ok = gn < p.gn;                      // gn % 8 == 0 is required: a column group is all in or all out
-  const size_t cbase = (size_t)bz * (size_t)p.sc;
-  const int mrow0 = m0 + 64 * wm + prow;              // this lane's rows: mrow0 + 32 i + 8 ps
+  const size_t cbase = (size_t)bz * (size_t)p.sc + (size_t)sp * (size_t)p.ssplit;
+  const int mrow0 = m0 + 32 * TM * wm + prow;         // this lane's rows: mrow0 + 32 i + 8 ps
   constexpr bool HAS_AUX = EPI == EPI_DRELU || EPI == EPI_DGELU;
-  uint4 auxv[2][4];
-  if (HAS_AUX) {                                      // all eight rows requested before the accumulators are turned
+  uint4 auxv[TM][4];
+  if (HAS_AUX) {                                      // every row requested before the accumulators are turned
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const int gm = mrow0 + 32 * i + 8 * ps;
@@ -386,7 +402,7 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
     bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TM; ++i) {
     if (i) __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -452,7 +468,7 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS>::WPS)) k_gemm16(const GemmAr
       csum[e] = s;
     }
     if (prow == 0 && col_ok) {                        // one partial row per (tile_m, wave row): no atomics, no contention
-      float* d = p.colsum_rows + ((size_t)bz * 2 * p.ntm + 2 * tile_m + wm) * (size_t)p.gn + gn;
+      float* d = p.colsum_rows + ((size_t)bz * WM * p.ntm + WM * tile_m + wm) * (size_t)p.gn + gn;
       *reinterpret_cast<float4*>(d) = make_float4(csum[0], csum[1], csum[2], csum[3]);
       *reinterpret_cast<float4*>(d + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
     }
@@ -474,73 +490,142 @@ __global__ void __launch_bounds__(256) k_sum_rows(const float* __restrict__ part
     atomicAdd(out + col, (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]));
 }
 
+// out (n) += sum over the `parts` partial results part (parts, n).  A thread owns 4 consecutive elements and walks its
+// share of the parts 8 at a time (8 independent 16-byte loads in flight).  gridDim.y == 1: the owner adds (no atomics,
+// bit-reproducible); small outputs with many parts are cut into gridDim.y part ranges that finish with f32 atomics.
+__global__ void __launch_bounds__(256) k_add_parts(const float* __restrict__ part, int parts, long long n,
+                                                   float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const int per = (parts + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = p0 + per < parts ? p0 + per : parts;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = p0; p < p1; p += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = p + u < p1 ? *reinterpret_cast<const float4*>(part + (long long)(p + u) * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  if (gridDim.y == 1) {
+    float4 o = *reinterpret_cast<const float4*>(out + i);
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    *reinterpret_cast<float4*>(out + i) = o;
+  } else {
+    atomicAdd(out + i, s.x); atomicAdd(out + i + 1, s.y); atomicAdd(out + i + 2, s.z); atomicAdd(out + i + 3, s.w);
+  }
+}
+
 }  // namespace
 
 // dtype: 0 = bf16, 1 = fp16.  layout: 0 = NT, 1 = NN, 2 = TN (see the header).
-template <int KB, int NS, bool AKS, bool BKS, int OUT, int EPI>
+constexpr int KB = 32, NS = 3;      // K-step depth x ring slots (measured best of 32x2, 32x3, 32x4, 64x2, 64x3)
+
+template <int WM, int TM, int TN, bool AKS, bool BKS, int OUT, int EPI>
 static int gemm16_launch_t(int dtype, const GemmArgs& a, unsigned nblk, hipStream_t st) {
-  constexpr int lds = Geo<KB, NS>::LDS;
+  using G = Geo<KB, NS, WM, TM, TN>;
+  constexpr int lds = G::LDS;
+  const dim3 block(64 * G::NW);
   if (dtype == 0) {
     if (lds > 65536) {
       static bool done = false;       // idempotent attribute of the code object, not library state
       if (!done) {
-        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<KB, NS, AKS, BKS, OUT, EPI, __bf16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MBV_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&k_gemm16<KB, NS, WM, TM, TN, AKS, BKS, OUT, EPI, __bf16>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done = true;
       }
     }
-    hipLaunchKernelGGL((k_gemm16<KB, NS, AKS, BKS, OUT, EPI, __bf16>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_gemm16<KB, NS, WM, TM, TN, AKS, BKS, OUT, EPI, __bf16>), dim3(nblk), block, lds, st, a);
   } else {
     if (lds > 65536) {
       static bool done = false;
       if (!done) {
-        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm16<KB, NS, AKS, BKS, OUT, EPI, _Float16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MBV_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&k_gemm16<KB, NS, WM, TM, TN, AKS, BKS, OUT, EPI, _Float16>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done = true;
       }
     }
-    hipLaunchKernelGGL((k_gemm16<KB, NS, AKS, BKS, OUT, EPI, _Float16>), dim3(nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_gemm16<KB, NS, WM, TM, TN, AKS, BKS, OUT, EPI, _Float16>), dim3(nblk), block, lds, st, a);
   }
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
 
-template <int KB, int NS>
-static int gemm16_launch_k(int layout, int atomic, int epi, int dtype, const GemmArgs& a, unsigned n, hipStream_t st) {
+template <int WM, int TM, int TN>
+static int gemm16_launch_s(int layout, int atomic, int epi, int dtype, const GemmArgs& a, unsigned n, hipStream_t st) {
   if (layout == 0) {
-    if (atomic) return gemm16_launch_t<KB, NS, false, false, 1, EPI_NONE>(dtype, a, n, st);
-    if (epi == EPI_RELU) return gemm16_launch_t<KB, NS, false, false, 0, EPI_RELU>(dtype, a, n, st);
-    if (epi == EPI_GELU) return gemm16_launch_t<KB, NS, false, false, 0, EPI_GELU>(dtype, a, n, st);
-    return gemm16_launch_t<KB, NS, false, false, 0, EPI_NONE>(dtype, a, n, st);
+    if (atomic) return gemm16_launch_t<WM, TM, TN, false, false, 1, EPI_NONE>(dtype, a, n, st);
+    if constexpr (TN == 2) {
+      if (epi == EPI_RELU) return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_RELU>(dtype, a, n, st);
+      if (epi == EPI_GELU) return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_GELU>(dtype, a, n, st);
+      return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_NONE>(dtype, a, n, st);
+    }
+    return MBV_ERR_UNSUPPORTED;
   }
   if (layout == 1) {
-    if (epi == EPI_DRELU) return gemm16_launch_t<KB, NS, false, true, 0, EPI_DRELU>(dtype, a, n, st);
-    if (epi == EPI_DGELU) return gemm16_launch_t<KB, NS, false, true, 0, EPI_DGELU>(dtype, a, n, st);
-    return gemm16_launch_t<KB, NS, false, true, 0, EPI_NONE>(dtype, a, n, st);
+    if constexpr (TN == 2) {
+      if (epi == EPI_DRELU) return gemm16_launch_t<WM, TM, TN, false, true, 0, EPI_DRELU>(dtype, a, n, st);
+      if (epi == EPI_DGELU) return gemm16_launch_t<WM, TM, TN, false, true, 0, EPI_DGELU>(dtype, a, n, st);
+      return gemm16_launch_t<WM, TM, TN, false, true, 0, EPI_NONE>(dtype, a, n, st);
+    }
+    return MBV_ERR_UNSUPPORTED;
   }
-  if (atomic) return gemm16_launch_t<KB, NS, true, true, 1, EPI_NONE>(dtype, a, n, st);
-  return gemm16_launch_t<KB, NS, true, true, 0, EPI_NONE>(dtype, a, n, st);
+  if (atomic) return gemm16_launch_t<WM, TM, TN, true, true, 1, EPI_NONE>(dtype, a, n, st);
+  if constexpr (TN == 2) return gemm16_launch_t<WM, TM, TN, true, true, 0, EPI_NONE>(dtype, a, n, st);
+  return MBV_ERR_UNSUPPORTED;
 }
 
-// Pipeline shape "KBxNS" (K-step depth x ring slots); MBV_GEMM_CFG overrides the default for A/B runs.
-static int gemm16_cfg() {
-  const char* e = getenv("MBV_GEMM_CFG");
-  if (!e) return 323;
-  return atoi(e);
+// Block shapes (Geo): 0 = 128 x 128, 1 = 256 x 128.  (A 384 x 192 weight-gradient shape — 3 x 3 tiles per wave, one
+// workgroup per CU — was built and measured 2-2.6x SLOWER: with ~512 workgroups in flight the atomic traffic is
+// workgroups x tile bytes, 151 MB instead of 33 MB per launch.)
+static const int SHAPE_BM[2] = {128, 256}, SHAPE_BN[2] = {128, 128};
+
+// Which block shape a problem gets.  MBV_GEMM_TILE=0/1/2 forces one (A/B runs).  Otherwise: the largest shape that
+// still (a) wastes little of its tiles on the edges of the (gm x gn) output and (b) leaves at least ~2 workgroup
+// slots per CU busy (the weight gradients make up for small outputs with their split over the tokens).
+static int gemm16_pick_shape(int atomic, long long gm, long long gn, long long work_units) {
+  const char* e = getenv("MBV_GEMM_TILE");
+  if (e && e[0] >= '0' && e[0] <= '1') return e[0] - '0';
+  auto eff = [&](int s) {
+    const long long tm = (gm + SHAPE_BM[s] - 1) / SHAPE_BM[s], tn = (gn + SHAPE_BN[s] - 1) / SHAPE_BN[s];
+    return (double)(gm * gn) / (double)(tm * SHAPE_BM[s] * tn * SHAPE_BN[s]);
+  };
+  auto blocks = [&](int s) {
+    return ((gm + SHAPE_BM[s] - 1) / SHAPE_BM[s]) * ((gn + SHAPE_BN[s] - 1) / SHAPE_BN[s]) * work_units;
+  };
+  // measured (scratch/bench_gemm.py, profiles/r02): 256 x 128 wins 5-13 % on STORE products with >= 128 such tiles;
+  // products that end in atomics pay (workgroups x tile bytes) of atomic traffic, so they keep the smallest tile
+  if (atomic) return 0;
+  if (eff(1) >= 0.9 * eff(0) && blocks(1) >= 128) return 1;
+  return 0;
 }
 
-static int gemm16_kb() { return gemm16_cfg() / 10; }
-
-static int gemm16_launch(int layout, int atomic, int epi, int dtype, GemmArgs a, int kb, int batch, hipStream_t st) {
+static int gemm16_launch(int shape, int layout, int atomic, int epi, int dtype, const GemmArgs& a, int batch,
+                         hipStream_t st) {
   const long long nblk = (long long)a.ntm * a.ntn * a.splits * batch;
   if (nblk <= 0) return MBV_OK;
   if (nblk > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
   const unsigned n = (unsigned)nblk;
-  switch (gemm16_cfg()) {
-    case 322: return gemm16_launch_k<32, 2>(layout, atomic, epi, dtype, a, n, st);
-    case 642: return gemm16_launch_k<64, 2>(layout, atomic, epi, dtype, a, n, st);
-    default: return gemm16_launch_k<32, 3>(layout, atomic, epi, dtype, a, n, st);
+  if (shape == 1) return gemm16_launch_s<4, 2, 2>(layout, atomic, epi, dtype, a, n, st);
+  return gemm16_launch_s<2, 2, 2>(layout, atomic, epi, dtype, a, n, st);
+}
+
+// Split of the contraction of an ATOMIC product over workgroups: about two workgroups per CU, at least 256 deep each.
+static void gemm16_split(GemmArgs& a, int splits, long long contraction, int batch) {
+  const int total_steps = (int)((contraction + KB - 1) / KB);
+  int s = splits;
+  if (s <= 0) {
+    const long long tiles = (long long)a.ntm * a.ntn * batch;
+    s = (int)((512 + tiles - 1) / tiles);
+    if (s > total_steps * KB / 256) s = total_steps * KB / 256;
   }
+  if (s < 1) s = 1;
+  if (s > total_steps) s = total_steps;
+  a.ksteps = (total_steps + s - 1) / s;
+  a.splits = (total_steps + a.ksteps - 1) / a.ksteps;
 }
 
 static bool fits_2g(long long rows, long long ld) { return rows * ld * 2 < 0x7fff0000LL; }
@@ -564,16 +649,17 @@ extern "C" int mbv_gemm16_nt(const void* x, const void* w, const float* bias, vo
     return MBV_ERR_UNSUPPORTED;
   if (!fits_2g(m, ldx) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
   if (m == 0 || batch == 0) return MBV_OK;
-  const int kb = gemm16_kb();
+  const int shape = gemm16_pick_shape(0, m, n, batch);
+  const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
   GemmArgs a = {};
   a.a = x; a.b = w; a.c = out; a.c2 = out_pre; a.bias = bias;
   a.gm = (int)m; a.gn = (int)n; a.gk = (int)k;
   a.lda = (int)ldx; a.ldb = (int)ldw; a.ldc = (int)ldo;
   a.sa = stride_x; a.sb = stride_w; a.sc = stride_o;
   a.a_bytes = (unsigned)(((m - 1) * ldx + k) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
-  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((n + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((k + kb - 1) / kb);
+  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((n + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((k + KB - 1) / KB);
   a.out_f32 = out_f32;
-  return gemm16_launch(0, 0, act, dtype, a, kb, batch, (hipStream_t)stream);
+  return gemm16_launch(shape, 0, 0, act, dtype, a, batch, (hipStream_t)stream);
 }
 
 // acc (m, n) f32 += x (m, k) . w (n, k)^T, the sum over k split over workgroups (f32 atomic adds): for few-row
@@ -587,7 +673,8 @@ extern "C" int mbv_gemm16_nt_acc(const void* x, const void* w, float* acc, int64
   if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(acc)) & 15) return MBV_ERR_UNSUPPORTED;
   if (!fits_2g(m, ldx) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
   if (m == 0 || batch == 0) return MBV_OK;
-  const int kb = gemm16_kb();
+  const int shape = gemm16_pick_shape(1, m, n, (long long)batch * ((k + 511) / 512));
+  const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
   GemmArgs a = {};
   a.a = x; a.b = w; a.c = acc;
   a.gm = (int)m; a.gn = (int)n; a.gk = (int)k;
@@ -595,23 +682,14 @@ extern "C" int mbv_gemm16_nt_acc(const void* x, const void* w, float* acc, int64
   a.sa = stride_x; a.sb = stride_w; a.sc = stride_acc;
   a.a_bytes = (unsigned)(((m - 1) * ldx + k) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
   a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((n + BN - 1) / BN);
-  const int total_steps = (int)((k + kb - 1) / kb);
-  int s = splits;
-  if (s <= 0) {
-    const long long tiles = (long long)a.ntm * a.ntn * batch;
-    s = (int)((512 + tiles - 1) / tiles);
-    if (s > total_steps * kb / 256) s = total_steps * kb / 256;
-  }
-  if (s < 1) s = 1;
-  if (s > total_steps) s = total_steps;
-  a.ksteps = (total_steps + s - 1) / s;
-  a.splits = (total_steps + a.ksteps - 1) / a.ksteps;
+  gemm16_split(a, splits, k, batch);
   a.out_f32 = 1;
-  return gemm16_launch(0, 1, EPI_NONE, dtype, a, kb, batch, (hipStream_t)stream);
+  return gemm16_launch(shape, 0, 1, EPI_NONE, dtype, a, batch, (hipStream_t)stream);
 }
 
 extern "C" size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch) {
-  return (size_t)((m + BM - 1) / BM) * 2 * (size_t)k * 4 * (size_t)(batch > 0 ? batch : 1);
+  // one partial row per 64 output rows (a wave row of any block shape)
+  return (size_t)((m + 63) / 64 + 4) * (size_t)k * 4 * (size_t)(batch > 0 ? batch : 1);
 }
 
 // out (m, k) = act'(aux) * (g (m, n) . w (n, k));  colsum (k) += column sums of out
@@ -629,19 +707,20 @@ extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void
   if (!fits_2g(m, ldg) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
   if (colsum && (!workspace || workspace_bytes < mbv_gemm16_nn_workspace_bytes(m, k, batch))) return MBV_ERR_WORKSPACE;
   if (m == 0 || batch == 0) return MBV_OK;
-  const int kb = gemm16_kb();
+  const int shape = gemm16_pick_shape(0, m, k, batch);
+  const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
   GemmArgs a = {};
   a.a = g; a.b = w; a.c = out; a.aux = aux; a.colsum_rows = colsum ? reinterpret_cast<float*>(workspace) : nullptr;
   a.gm = (int)m; a.gn = (int)k; a.gk = (int)n;
   a.lda = (int)ldg; a.ldb = (int)ldw; a.ldc = (int)ldo; a.ldx = (int)ldaux;
   a.sa = stride_g; a.sb = stride_w; a.sc = stride_o;
   a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 2); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 2);
-  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((k + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((n + kb - 1) / kb);
+  a.ntm = (int)((m + BM - 1) / BM); a.ntn = (int)((k + BN - 1) / BN); a.splits = 1; a.ksteps = (int)((n + KB - 1) / KB);
   a.out_f32 = out_f32;
-  const int rc = gemm16_launch(1, 0, act == 0 ? EPI_NONE : (act == 1 ? EPI_DRELU : EPI_DGELU), dtype, a, kb, batch,
+  const int rc = gemm16_launch(shape, 1, 0, act == 0 ? EPI_NONE : (act == 1 ? EPI_DRELU : EPI_DGELU), dtype, a, batch,
                                (hipStream_t)stream);
   if (rc != MBV_OK || !colsum) return rc;
-  const int rows = 2 * a.ntm * batch;
+  const int rows = (BM / 64) * a.ntm * batch;
   int gy = rows / 16;
   if (gy < 1) gy = 1;
   if (gy > 32) gy = 32;
@@ -653,10 +732,21 @@ extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void
 
 // accumulate != 0:  dw (n, k) f32 += g (m, n)^T . x (m, k), the sum over m split over workgroups (f32 atomic adds)
 // accumulate == 0:  dw (n, k) = g^T . x stored (16-bit or f32), one workgroup per tile
+// Bytes of workspace with which an accumulating mbv_gemm16_tn replaces its f32 atomics by partial results + one
+// owner-adds pass (dw contiguous, batch 1): room for the largest split it may choose.
+extern "C" size_t mbv_gemm16_tn_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  const long long tiles = ((n + 127) / 128) * ((k + 127) / 128);
+  long long s = (512 + tiles - 1) / tiles;
+  const long long cap = (m + 255) / 256;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (size_t)(s + 1) * (size_t)n * (size_t)k * 4;
+}
+
 extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, int64_t k, int64_t ldg,
                              int64_t ldx, int64_t lddw, int32_t dtype, int32_t accumulate, int32_t out_f32,
                              int32_t splits, int32_t batch, int64_t stride_g, int64_t stride_x, int64_t stride_dw,
-                             void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !x || !dw) return MBV_ERR_BAD_ARG;
   if (dtype < 0 || dtype > 1) return MBV_ERR_BAD_ARG;
   if ((n & 7) || (k & 7) || (ldg & 7) || (ldx & 7) || ldg < n || ldx < k || lddw < k) return MBV_ERR_UNSUPPORTED;
@@ -664,7 +754,8 @@ extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, 
   if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dw)) & 15) return MBV_ERR_UNSUPPORTED;
   if (!fits_2g(m, ldg) || !fits_2g(m, ldx)) return MBV_ERR_UNSUPPORTED;
   if (m == 0 || batch == 0) return MBV_OK;
-  const int kb = gemm16_kb();
+  const int shape = gemm16_pick_shape(accumulate ? 1 : 0, n, k, accumulate ? (long long)batch * ((m + 511) / 512) : batch);
+  const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
   GemmArgs a = {};
   a.a = g; a.b = x; a.c = dw;
   a.gm = (int)n; a.gn = (int)k; a.gk = (int)m;
@@ -672,20 +763,31 @@ extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, 
   a.sa = stride_g; a.sb = stride_x; a.sc = stride_dw;
   a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 2); a.b_bytes = (unsigned)(((m - 1) * ldx + k) * 2);
   a.ntm = (int)((n + BM - 1) / BM); a.ntn = (int)((k + BN - 1) / BN);
-  const int total_steps = (int)((m + kb - 1) / kb);
-  int s = 1;
   if (accumulate) {
-    s = splits;
-    if (s <= 0) {                 // about two workgroups per CU, at least 256 rows of m each
-      const long long tiles = (long long)a.ntm * a.ntn * batch;
-      s = (int)((512 + tiles - 1) / tiles);
-      if (s > total_steps * kb / 256) s = total_steps * kb / 256;
-    }
-    if (s < 1) s = 1;
-    if (s > total_steps) s = total_steps;
+    gemm16_split(a, splits, m, batch);
+  } else {
+    a.splits = 1;
+    a.ksteps = (int)((m + KB - 1) / KB);
   }
-  a.ksteps = (total_steps + s - 1) / s;
-  a.splits = (total_steps + a.ksteps - 1) / a.ksteps;
   a.out_f32 = accumulate ? 1 : out_f32;
-  return gemm16_launch(2, accumulate ? 1 : 0, EPI_NONE, dtype, a, kb, batch, (hipStream_t)stream);
+  // partial results + owner-adds instead of atomics: plain full-line stores (~6 TB/s against ~1.3 for atomics) and
+  // a bit-reproducible sum; needs a contiguous dw, 16-byte alignment and a workspace for the parts
+  if (accumulate && a.splits > 1 && batch == 1 && workspace && lddw == k && (n * k) % 4 == 0 &&
+      (reinterpret_cast<size_t>(workspace) & 15) == 0 &&
+      workspace_bytes >= (size_t)a.splits * (size_t)n * (size_t)k * 4 && !getenv("MBV_GEMM_TN_ATOMIC")) {
+    GemmArgs b = a;
+    b.c = workspace;
+    b.ssplit = n * k;
+    b.ldc = (int)k;
+    const int rc = gemm16_launch(shape, 2, 0, EPI_NONE, dtype, b, batch, (hipStream_t)stream);
+    if (rc != MBV_OK) return rc;
+    const long long total = n * k;
+    // outputs of fewer than 64 k elements with many parts: a few part ranges per element keep the chip busy
+    const unsigned gy = (total < 65536 && a.splits >= 32) ? (unsigned)((a.splits + 15) / 16) : 1u;
+    hipLaunchKernelGGL(k_add_parts, dim3((unsigned)((total / 4 + 255) / 256), gy), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(workspace), a.splits, total, reinterpret_cast<float*>(dw));
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
+  return gemm16_launch(shape, 2, accumulate ? 1 : 0, EPI_NONE, dtype, a, batch, (hipStream_t)stream);
 }

@@ -738,7 +738,9 @@ def gemm16_policy() -> str:
     return {'1': 'auto', '0': 'none'}.get(v, v)
 
 
-_K17_MIN_TOKENS = 8192        # below this the 128 x 128 tiles under-fill the chip and the library's split / stream-K wins
+# below these token counts the 128 x 128 tiles under-fill the chip and the library's split / stream-K kernels win
+# (scratch/bench_gemm.py on the bench shapes, profiles/r02/c_gemm_shapes.txt)
+_K17_MIN_TOKENS = {'fused': 8192, 'wgrad': 4096}
 
 
 def _k17_wants(kind: str, tokens: int) -> bool:
@@ -747,7 +749,7 @@ def _k17_wants(kind: str, tokens: int) -> bool:
         return False
     if pol == 'all':
         return True
-    return kind in ('fused', 'wgrad') and tokens >= _K17_MIN_TOKENS
+    return kind in _K17_MIN_TOKENS and tokens >= _K17_MIN_TOKENS[kind]
 
 
 def _gemm16_ok(*ts: torch.Tensor) -> bool:
@@ -814,8 +816,12 @@ def gemm16_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, splits: i
         raise MaskBevHipError('gemm16_tn_acc: unsupported operands')
     m, n = g.shape
     k = x.shape[1]
+    ws = None
+    if acc.is_contiguous():               # partial results + owner-adds instead of atomics
+        ws = _workspace(lib.mbv_gemm16_tn_workspace_bytes(m, n, k), g.device)
     check(lib.mbv_gemm16_tn(_ptr(g), _ptr(x), _ptr(acc), m, n, k, g.stride(0), x.stride(0), acc.stride(0),
-                            _GEMM16_DT[g.dtype], 1, 1, int(splits), 1, 0, 0, 0, _stream()), 'mbv_gemm16_tn')
+                            _GEMM16_DT[g.dtype], 1, 1, int(splits), 1, 0, 0, 0, _ptr(ws),
+                            0 if ws is None else ws.numel(), _stream()), 'mbv_gemm16_tn')
 
 
 def gemm16_nt_acc(x: torch.Tensor, w: torch.Tensor, splits: int = 0) -> torch.Tensor:
@@ -860,7 +866,7 @@ def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype]
     od = out_dtype or g.dtype
     out = torch.empty((b, n, k), dtype=od, device=g.device)
     check(lib.mbv_gemm16_tn(_ptr(g), _ptr(x), _ptr(out), m, n, k, n, k, k, _GEMM16_DT[g.dtype], 0,
-                            int(od == torch.float32), 1, b, m * n, m * k, n * k, _stream()), 'mbv_gemm16_tn')
+                            int(od == torch.float32), 1, b, m * n, m * k, n * k, None, 0, _stream()), 'mbv_gemm16_tn')
     return out
 
 
@@ -924,7 +930,8 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch."""
     t = g2.shape[0]
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and _k17_wants('wgrad', t) and acc.stride(-1) == 1
-            and _gemm16_ok(g2, x2) and acc.data_ptr() % 16 == 0):
+            and _gemm16_ok(g2, x2) and acc.data_ptr() % 16 == 0
+            and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')):     # 2048-wide patch rows: the library wins (77 vs 95 us)
         gemm16_tn_acc(acc, g2, x2)               # K17: split over the tokens, f32 atomic adds into the arena
         return False
     if (g2.dtype == torch.float32 and x2.dtype == torch.float32 and t <= _SMALL_F32_ROWS and g2.is_cuda

@@ -66,7 +66,9 @@ for name, m, k, n in SHAPES:
     t_f_k = timeit(lambda: ops.gemm16_nt(x, w, b32))
     t_d_lib = timeit(lambda: g.mm(w))
     t_d_k = timeit(lambda: ops.gemm16_nn(g, w))
-    t_w_lib = timeit(lambda: ops._wgrad_into(acc, g, x))
+    os.environ['MBV_GEMM16'] = '0'
+    t_w_lib = timeit(lambda: ops._wgrad_into(acc, g, x))          # library path: batched split-K GEMM + column sums
+    os.environ['MBV_GEMM16'] = 'auto'
     t_w_k = timeit(lambda: ops.gemm16_tn_acc(acc, g, x))
     for key, a, b in (('fwd', t_f_lib, t_f_k), ('dgrad', t_d_lib, t_d_k), ('wgrad', t_w_lib, t_w_k)):
         tot[key][0] += a

@@ -1,5 +1,6 @@
 """K15 matched mask IoU (metrics path) vs the oracle's F.interpolate → sigmoid > 0.5 → batched_mask_iou chain, and the
 metric objects fed from the loss's own assignment."""
+import numpy as np
 import pytest
 import torch
 
