@@ -166,7 +166,7 @@ def kernel_profile(model, opt, batch, steps: int = 2):
 
     def one(i):
         loss = model.training_step(batch, i)
-        loss.backward()
+        model.scale_loss(loss).backward()
         opt.step()
         if not getattr(opt, 'zero_grad_in_step', False):
             opt.zero_grad(set_to_none=False)
@@ -280,7 +280,7 @@ def main():
         if reducer is not None:
             reducer.sync_buffers()
         loss = model.training_step((scans, gt), i)
-        loss.backward()
+        model.scale_loss(loss).backward()
         if reducer is not None:
             if getattr(model, '_arena', None) is not None:
                 reducer.reduce_arena(model._arena, opt)

@@ -31,6 +31,14 @@ typedef enum {
 /* Library/ABI version; bumped whenever a signature below changes. */
 int mbv_abi_version(void);
 
+/* Storage type of an activation tensor.  Every `is_bf16` / `*_bf16` / `*_dtype` flag below takes one of these (the
+ * flags were 0 / 1 before fp16 existed, hence their names): 2 selects IEEE half, computed by the same kernels
+ * instantiated for `_Float16` (v_mfma_f32_32x32x16_f16; conversions round to nearest even, overflow -> inf).
+ * Accumulation, softmax, LayerNorm statistics and every gradient of a parameter stay f32 for all three. */
+#define MBV_DT_F32 0
+#define MBV_DT_BF16 1
+#define MBV_DT_F16 2
+
 /* ------------------------------------------------------------------------------------------------
  * K1 — range filter + hard voxelisation of a batch of scans.
  * Replaces: MaskBevEncoder._filter_in_range (mask_bev/models/encoders/mask_bev_encoders.py:113-117)
@@ -136,7 +144,7 @@ size_t mbv_scatter_layernorm_workspace_bytes(int32_t batch);
 
 /* `patch` selects the layout of `out` (forward) and `grad_out` (backward):
  *   0  (batch, C, ny, nx) f32 — the reference's NCHW pseudo-image;
- *   4  (batch, ny/4, nx/4, 16*C) bf16 patch tokens, element (y%4)*4C + c*4 + x%4 of row (b, y/4, x/4): the input
+ *   4  (batch, ny/4, nx/4, 16*C) patch tokens in bf16 or half (`patch_dtype` = MBV_DT_BF16 / MBV_DT_F16), element (y%4)*4C + c*4 + x%4 of row (b, y/4, x/4): the input
  *      rows of the backbone's 4 x 4 non-overlapping patch projection (mmdet PatchEmbed built at
  *      mask_bev/models/backbones/swin.py:579-586), which then is one GEMM with no layout or cast pass.
  *      Needs mbv_scatter_layernorm_patch_supported(C, ny, nx, 4) (C % 32 == 0, ny % 4 == 0, nx % 4 == 0). */
@@ -145,12 +153,12 @@ int mbv_scatter_layernorm_patch_supported(int32_t channels, int32_t ny, int32_t 
 int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                               const int32_t* cell_to_pillar, const float* weight, const float* bias,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
-                              int32_t patch, void* out, float* stats, void* workspace, size_t workspace_bytes,
-                              void* stream, void* ev_start, void* ev_stop);
+                              int32_t patch, int32_t patch_dtype, void* out, float* stats, void* workspace,
+                              size_t workspace_bytes, void* stream, void* ev_start, void* ev_stop);
 
 /* Backward: grad_out (layout per `patch`) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
  * `accumulate` != 0 adds into grad_weight / grad_bias instead of overwriting them. */
-int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, const float* feats,
+int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
                               const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
                               const float* weight, const float* stats,
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
@@ -313,16 +321,28 @@ int mbv_uniform_points(const int64_t* seed, int64_t rows, int32_t n, float* out_
  *   aligned, n elements).  step >= 1 is the 1-based update count (bias corrections are computed on the host in
  *   f64).  decoupled=1 → AdamW (param *= 1 - lr*wd), 0 → Adam (grad += wd*param).  grad is multiplied by
  *   grad_scale first (1/world_size after a SUM all-reduce).  shadow_bf16 (nullable, 8-byte aligned) receives the
- *   updated parameters rounded to nearest-even bf16 — the copy the bf16 GEMMs read.  zero_grad=1 clears grad in
- *   the same pass.
- * mbv_refresh_shadow: shadow_bf16[i] = bf16(param[i]) (after load_state_dict / broadcast).
+ *   updated parameters rounded to nearest-even bf16 or half (shadow_dtype = MBV_DT_BF16 / MBV_DT_F16) — the copy the
+ *   16-bit GEMMs read.  zero_grad=1 clears grad in the same pass.
+ *   fp16 loss scaling, without a host round trip: loss_scale (device f32 scalar, nullable) is the factor the loss was
+ *   multiplied by — grad is divided by it on the fly; skip_flag (device i32, nullable) non-zero = the gradient held
+ *   inf / nan: parameters, moments and shadow are left as they are and only zero_grad is honoured.
+ * mbv_grad_nonfinite: *flag |= 1 if any of grad[0..n) is inf or nan (torch.amp.GradScaler's found_inf).
+ * mbv_loss_scale_update: GradScaler.update() on the device — flag set: scale = max(scale * backoff, 1), streak = 0;
+ *   else streak += 1 and scale *= growth every growth_interval clean steps; clears the flag.
+ * mbv_refresh_shadow: shadow[i] = bf16 / half (param[i]) (after load_state_dict / broadcast).
  * mbv_colsum_accum: out[c] += sum_r g[r, c] for row-major g (rows, n), bf16 (is_bf16=1) or f32; f32 atomics.
  */
-int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                   float grad_scale, int32_t decoupled, int32_t zero_grad, void* stream);
+int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int32_t shadow_dtype,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   float grad_scale, int32_t decoupled, int32_t zero_grad, const float* loss_scale,
+                   const int32_t* skip_flag, void* stream);
 
-int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* stream);
+int mbv_grad_nonfinite(const float* grad, int64_t n, int32_t* flag, void* stream);
+
+int mbv_loss_scale_update(float* loss_scale, int32_t* clean_steps, int32_t* flag, float growth, float backoff,
+                          int32_t growth_interval, void* stream);
+
+int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t shadow_dtype, int64_t n, void* stream);
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
 
@@ -370,7 +390,7 @@ int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, i
  * C <= 2048 (mbv_add_layernorm_supported).  fwd writes sum_out = a + b (f32, the tensor the backward needs; may be
  * NULL only for a lone f32 `a`, which then serves as the saved input), y in f32 or bf16, mean / rstd (rows) f32.
  * bwd: dy (rows, C) f32/bf16, ds nullable (gradient reaching the sum from the residual path), s = the saved sum;
- * writes dx (rows, C) f32 (the gradient of a and of b), optionally the same in bf16 (dx_bf16), and
+ * writes dx (rows, C) f32 (the gradient of a and of b), optionally the same in 16 bits (dx_lo, of dx_lo_dtype), and
  * dgamma / dbeta (C) f32 — overwritten, or accumulated into when accumulate != 0 (parameter-arena gradients).
  * dbranch_bias (C) f32, nullable: += the column sums of dx — the bias gradient of the Linear that produced the
  * residual branch b (its output gradient IS dx), saving that layer a pass over dx.
@@ -383,8 +403,8 @@ int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t 
                           float* mean, float* rstd, void* stream);
 int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
-                          void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate, float* dbranch_bias,
-                          float* partial_ws, void* stream);
+                          void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
+                          float* dbranch_bias, float* partial_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K14 — batch producer: instance-id map → instance ids → per-instance binary masks.

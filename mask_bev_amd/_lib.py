@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 
 class MaskBevHipError(RuntimeError):
@@ -39,9 +39,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_pfn_bwd_bn': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_double, _I, _P, _P, _L, _I, _I, _P, _P]),
     'mbv_scatter_layernorm_workspace_bytes': (c_size_t, [_I]),
     'mbv_scatter_layernorm_patch_supported': (ctypes.c_int, [_I, _I, _I, _I]),
-    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, c_size_t, _P,
-                                                 _P, _P]),
-    'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
+    'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, c_size_t,
+                                                 _P, _P, _P]),
+    'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
                                                  c_size_t, _P, _P, _P]),
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
     'mbv_msda_prepare_fwd': (ctypes.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -59,8 +59,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_hungarian': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
     'mbv_hungarian_wide_t': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
     'mbv_select_uncertain_points': (ctypes.c_int, [_P, _P, _L, _I, _I, _P, _P]),
-    'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P]),
-    'mbv_refresh_shadow': (ctypes.c_int, [_P, _P, _L, _P]),
+    'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P, _P, _P]),
+    'mbv_grad_nonfinite': (ctypes.c_int, [_P, _L, _P, _P]),
+    'mbv_loss_scale_update': (ctypes.c_int, [_P, _P, _P, _F, _F, _I, _P]),
+    'mbv_refresh_shadow': (ctypes.c_int, [_P, _P, _I, _L, _P]),
     'mbv_colsum_accum': (ctypes.c_int, [_P, _I, _L, _I, _P, _P]),
     'mbv_act_bwd_colsum': (ctypes.c_int, [_P, _P, _I, _I, _L, _I, _P, _P, _P]),
     'mbv_wgrad_small_f32': (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
@@ -71,7 +73,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_add_layernorm_supported': (ctypes.c_int, [_I]),
     'mbv_add_layernorm_bwd_blocks': (_L, [_L, _I]),
     'mbv_add_layernorm_fwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P, _P, _I, _P, _P, _P]),
-    'mbv_add_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'mbv_add_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P, _P,
+                                             _P]),
     'mbv_instance_ids': (ctypes.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_expand_instance_masks': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_matched_mask_iou': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -63,9 +63,9 @@ class ParameterArena:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.shadow = None
         if shadow_dtype is not None:
-            if shadow_dtype != torch.bfloat16:
-                raise TypeError('the shadow copy is bf16')
-            self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
+            if shadow_dtype not in (torch.bfloat16, torch.float16):
+                raise TypeError('the shadow copy is bf16 or fp16')
+            self.shadow = torch.zeros(off, dtype=shadow_dtype, device=device)
         with torch.no_grad():
             for p, o in self.layout:
                 n = p.numel()
@@ -102,15 +102,20 @@ class ParameterArena:
         return lo, hi
 
     # -- maintenance ------------------------------------------------------------------------------------
+    @property
+    def shadow_flag(self) -> int:
+        """MBV_DT_BF16 / MBV_DT_F16 (maskbev_hip.h); 0 without a shadow."""
+        return 0 if self.shadow is None else (2 if self.shadow.dtype == torch.float16 else 1)
+
     def refresh_shadow(self):
-        """Re-derive the bf16 shadow from the f32 parameters (after load_state_dict / broadcast / manual edits)."""
+        """Re-derive the 16-bit shadow from the f32 parameters (after load_state_dict / broadcast / manual edits)."""
         if self.shadow is None or self.numel == 0:
             return
         if self.device.type != 'cuda':
             self.shadow.copy_(self.param)
             return
         lib = _lib.load()
-        check(lib.mbv_refresh_shadow(self.param.data_ptr(), self.shadow.data_ptr(), self.numel,
+        check(lib.mbv_refresh_shadow(self.param.data_ptr(), self.shadow.data_ptr(), self.shadow_flag, self.numel,
                                      torch.cuda.current_stream(self.device).cuda_stream), 'mbv_refresh_shadow')
 
     def zero_grad(self, names: Optional[Iterable[str]] = None):
@@ -130,17 +135,69 @@ class ParameterArena:
         return all(p.data.untyped_storage().data_ptr() == base for p, _ in self.layout)
 
 
+class LossScaler:
+    """Dynamic loss scaling for fp16 compute with ``torch.amp.GradScaler``'s rules (start at 2**16, halve on a
+    non-finite gradient and skip that update, double after ``growth_interval`` clean steps) — but with the scale, the
+    overflow flag and the clean-step count held on the device and read / updated by kernels (K11:
+    ``mbv_grad_nonfinite``, ``mbv_adamw_step(loss_scale, skip_flag)``, ``mbv_loss_scale_update``), so that a step
+    neither synchronises with the host nor changes shape: ``scale_loss`` is captured in the HIP graph like any other
+    multiply.  Gradients are left scaled in the arena; the optimizer kernel divides on the fly."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.device = torch.device(device)
+        self.scale = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.clean_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval = int(growth_interval)
+
+    def scale_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self.scale.view(())
+
+    def check(self, grad: torch.Tensor):
+        """flag |= any non-finite element of ``grad`` (the all-reduced arena gradient)."""
+        lib = _lib.load()
+        check(lib.mbv_grad_nonfinite(grad.data_ptr(), grad.numel(), self.flag.data_ptr(),
+                                     torch.cuda.current_stream(self.device).cuda_stream), 'mbv_grad_nonfinite')
+
+    def update(self):
+        lib = _lib.load()
+        check(lib.mbv_loss_scale_update(self.scale.data_ptr(), self.clean_steps.data_ptr(), self.flag.data_ptr(),
+                                        self.growth_factor, self.backoff_factor, self.growth_interval,
+                                        torch.cuda.current_stream(self.device).cuda_stream), 'mbv_loss_scale_update')
+
+    def get_scale(self) -> float:
+        return float(self.scale.item())
+
+    def state_dict(self):
+        return dict(scale=self.get_scale(), clean_steps=int(self.clean_steps.item()),
+                    growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
+                    growth_interval=self.growth_interval)
+
+    def load_state_dict(self, sd):
+        self.scale.fill_(float(sd['scale']))
+        self.clean_steps.fill_(int(sd.get('clean_steps', 0)))
+        self.growth_factor = float(sd.get('growth_factor', self.growth_factor))
+        self.backoff_factor = float(sd.get('backoff_factor', self.backoff_factor))
+        self.growth_interval = int(sd.get('growth_interval', self.growth_interval))
+
+
 class FlatAdam(torch.optim.Optimizer):
     """Adam / AdamW over a :class:`ParameterArena`: one ``mbv_adamw_step`` launch per parameter group.
 
     ``param_groups`` carry ``lr`` / ``weight_decay`` / ``betas`` / ``eps`` like torch's optimizers, so the
     reference's schedulers (ReduceLROnPlateau, CosineAnnealingLR — mask_bev_module.py:153-159) drive it unchanged.
-    Adjacent groups with identical hyper-parameters are fused into one launch.  ``step()`` also refreshes the bf16
-    shadow and clears the gradient in the same pass (``zero_grad=True``)."""
+    Adjacent groups with identical hyper-parameters are fused into one launch.  ``step()`` also refreshes the 16-bit
+    shadow and clears the gradient in the same pass (``zero_grad=True``).  With a :class:`LossScaler` (fp16 compute) the
+    gradient is checked for inf / nan first, un-scaled inside the update kernel, and an overflowed step leaves
+    parameters and moments untouched (the bias-correction count still advances: it is a host integer)."""
 
     def __init__(self, arena: ParameterArena, groups: List[dict], lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 1e-2, decoupled: bool = True, zero_grad: bool = True):
+                 eps: float = 1e-8, weight_decay: float = 1e-2, decoupled: bool = True, zero_grad: bool = True,
+                 scaler: Optional[LossScaler] = None):
         self.arena = arena
+        self.scaler = scaler
         self.decoupled = decoupled
         self.zero_grad_in_step = zero_grad
         self.grad_scale = 1.0
@@ -184,6 +241,9 @@ class FlatAdam(torch.optim.Optimizer):
                 runs[-1][1] = b
             else:
                 runs.append([a, b, hp])
+        sc = self.scaler
+        if sc is not None:
+            sc.check(ar.grad)
         for a, b, (lr, b1, b2, eps, wd) in runs:
             if b == a:
                 continue
@@ -191,9 +251,14 @@ class FlatAdam(torch.optim.Optimizer):
             with ops.TIMER.span('k_adamw'):
                 check(lib.mbv_adamw_step(ar.param.data_ptr() + 4 * a, ar.grad.data_ptr() + 4 * a,
                                          self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, sh,
-                                         b - a, lr, b1, b2, eps, wd, self.steps, float(self.grad_scale),
-                                         1 if self.decoupled else 0, 1 if self.zero_grad_in_step else 0, stream),
+                                         ar.shadow_flag, b - a, lr, b1, b2, eps, wd, self.steps,
+                                         float(self.grad_scale), 1 if self.decoupled else 0,
+                                         1 if self.zero_grad_in_step else 0,
+                                         0 if sc is None else sc.scale.data_ptr(),
+                                         0 if sc is None else sc.flag.data_ptr(), stream),
                       'mbv_adamw_step')
+        if sc is not None:
+            sc.update()
         return loss
 
     def zero_grad(self, set_to_none: bool = False):
@@ -204,9 +269,13 @@ class FlatAdam(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()
         sd['flat_state'] = dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, steps=self.steps)
+        if self.scaler is not None:
+            sd['loss_scaler'] = self.scaler.state_dict()
         return sd
 
     def load_state_dict(self, sd):
+        if self.scaler is not None and sd.get('loss_scaler') is not None:
+            self.scaler.load_state_dict(sd['loss_scaler'])
         flat = sd.get('flat_state')
         if flat is not None:
             self.exp_avg.copy_(flat['exp_avg'])

@@ -46,14 +46,17 @@ def sources() -> List[str]:
 def _stamp(src: str, flags: List[str]) -> str:
     h = hashlib.sha1()
     h.update(' '.join(flags).encode())
-    for name in [src] + sorted(f for f in os.listdir(CSRC) if f.endswith('.hpp')) + ['../../include/maskbev_hip.h']:
+    # `<name>_f16.hip` = the half instantiation of `<name>.hip` (it defines MBV_H16 and includes that file)
+    twin = [src.replace('_f16.hip', '.hip')] if src.endswith('_f16.hip') else []
+    for name in [src] + twin + sorted(f for f in os.listdir(CSRC) if f.endswith('.hpp')) + \
+            ['../../include/maskbev_hip.h']:
         with open(os.path.join(CSRC, name), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
 
 
 def _compile_one(src: str, verbose: bool) -> str:
-    flags = COMMON_FLAGS + FILE_FLAGS.get(src, [])
+    flags = COMMON_FLAGS + FILE_FLAGS.get(src.replace('_f16.hip', '.hip'), [])
     obj = os.path.join(BUILD_DIR, src.replace('.hip', '.o'))
     stamp_file = obj + '.stamp'
     stamp = _stamp(src, flags)

@@ -7,6 +7,29 @@
 
 #define MBV_WAVE 64
 
+// ---- the 16-bit storage type of this translation unit ----------------------------------------------------------
+// Every kernel file that touches 16-bit activations (K3, K4, K6, K7, K12, K13, the optimizer's weight shadow) is
+// compiled twice: as it stands for bf16, and once more through its `<name>_f16.hip` companion, which defines MBV_H16
+// and includes it, for IEEE half (`v_mfma_f32_32x32x16_f16`, `v_cvt_f16_f32`).  Kernels live in anonymous namespaces,
+// so the two instantiations do not collide; the C entry points of the half build get an `_f16` suffix and hidden
+// visibility, and the public entry point forwards to them when its dtype argument is MBV_DT_F16.
+#define MBV_DT_F32 0
+#define MBV_DT_BF16 1
+#define MBV_DT_F16 2
+#ifdef MBV_H16
+typedef _Float16 lo16_t;
+#define MBV_SYM(name) name##_f16
+#define MBV_ENTRY extern "C" __attribute__((visibility("hidden")))
+#else
+typedef __bf16 lo16_t;
+#define MBV_SYM(name) name
+#define MBV_ENTRY extern "C"
+#endif
+// declaration of the half build's twin of an entry point (same signature), visible to the bf16 build only
+#define MBV_F16_TWIN extern "C" __attribute__((visibility("hidden")))
+// a dtype flag as the half build sees it: its own 16-bit type is "1"
+#define MBV_LO_FLAG(x) ((x) == MBV_DT_F16 ? 1 : (x))
+
 // Launch check: a failed launch is returned to the caller as a positive hipError_t.
 #define MBV_CHECK_LAUNCH()                         \
   do {                                             \
@@ -74,10 +97,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// f32 ↔ the bits of this build's 16-bit type (round to nearest even; half: overflow goes to ±inf)
+__device__ __forceinline__ float lo16_to_f32(unsigned short h) {
+#ifdef MBV_H16
+  return (float)__builtin_bit_cast(_Float16, h);
+#else
+  return __uint_as_float((unsigned)h << 16);
+#endif
+}
+
 // f32 → bf16 bits, round to nearest even (what a torch `.to(bfloat16)` does); NaN stays NaN
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned short f32_to_lo16(float f) {
+#ifdef MBV_H16
+  return __builtin_bit_cast(unsigned short, (_Float16)f);
+#else
+  return f32_to_bf16_rne(f);
+#endif
 }

@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
         if (kk < blk.nk) {
           const int64_t o = goff + (int64_t)(blk.k0 + kk) * g.ldg + col + dcol;
           if (g.gkv_bf16) {
-            reinterpret_cast<unsigned short*>(grad_k)[o] = f32_to_bf16_rne(dk[cb][i]);
-            reinterpret_cast<unsigned short*>(grad_v)[o] = f32_to_bf16_rne(dv[cb][i]);
+            reinterpret_cast<unsigned short*>(grad_k)[o] = f32_to_lo16(dk[cb][i]);
+            reinterpret_cast<unsigned short*>(grad_v)[o] = f32_to_lo16(dv[cb][i]);
           } else if (g.nsuper > 1) { atomicAdd(grad_k + o, dk[cb][i]); atomicAdd(grad_v + o, dv[cb][i]); }
           else { grad_k[o] = dk[cb][i]; grad_v[o] = dv[cb][i]; }
         }
@@ -411,6 +411,7 @@ int attn_bwd_launch(const AttnGeom& g, int D, const void* q, const void* k, cons
 
 }  // namespace
 
+#ifndef MBV_H16
 extern "C" size_t mbv_attn_workspace_bytes(int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads,
                                            int32_t head_dim) {
   AttnGeom g;
@@ -418,10 +419,23 @@ extern "C" size_t mbv_attn_workspace_bytes(int32_t batch, int32_t num_queries, i
   return mbv_align_up(attn_ws_floats(g, head_dim) * sizeof(float), 256);
 }
 
-extern "C" int mbv_attn_fwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+// the half build of this file (cross_attn_f16.hip); a dtype flag of MBV_DT_F16 forwards there
+MBV_F16_TWIN int mbv_attn_fwd_ld_f16(const void*, const void*, const void*, int32_t, const uint8_t*, int32_t, int32_t,
+                                     int32_t, int32_t, int32_t, int32_t, void*, float*, void*, size_t, void*);
+MBV_F16_TWIN int mbv_attn_bwd_ld_f16(const void*, const void*, const void*, int32_t, const uint8_t*, const void*,
+                                     const void*, const float*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t,
+                                     float*, void*, void*, int32_t, int32_t, void*);
+#endif
+
+MBV_ENTRY int MBV_SYM(mbv_attn_fwd_ld)(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
                                int32_t is_bf16, int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads,
                                int32_t head_dim, void* out, float* lse, void* workspace, size_t workspace_bytes,
                                void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16)
+    return mbv_attn_fwd_ld_f16(q, k, v, ld_kv, blocked, 1, batch, num_queries, num_keys, heads, head_dim, out, lse,
+                               workspace, workspace_bytes, stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnGeom g;
   if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
@@ -431,21 +445,29 @@ extern "C" int mbv_attn_fwd_ld(const void* q, const void* k, const void* v, int3
   if (!workspace || workspace_bytes < mbv_attn_workspace_bytes(batch, num_queries, num_keys, heads, head_dim))
     return MBV_ERR_WORKSPACE;
   float* ws = reinterpret_cast<float*>(workspace);
-  return is_bf16 ? attn_fwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, lse, ws, stream)
+  return is_bf16 ? attn_fwd_launch<true, lo16_t>(g, head_dim, q, k, v, blocked, out, lse, ws, stream)
                  : attn_fwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, lse, ws, stream);
 }
 
+#ifndef MBV_H16
 extern "C" int mbv_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* blocked, int32_t is_bf16,
                             int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
                             void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream_) {
   return mbv_attn_fwd_ld(q, k, v, heads * head_dim, blocked, is_bf16, batch, num_queries, num_keys, heads, head_dim,
                          out, lse, workspace, workspace_bytes, stream_);
 }
+#endif
 
-extern "C" int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
+MBV_ENTRY int MBV_SYM(mbv_attn_bwd_ld)(const void* q, const void* k, const void* v, int32_t ld_kv, const uint8_t* blocked,
                                const void* out, const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
                                int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
                                void* grad_k, void* grad_v, int32_t ld_grad_kv, int32_t grad_kv_bf16, void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16 || grad_kv_bf16 == MBV_DT_F16)
+    return mbv_attn_bwd_ld_f16(q, k, v, ld_kv, blocked, out, grad_out, lse, MBV_LO_FLAG(is_bf16), batch, num_queries,
+                               num_keys, heads, head_dim, grad_q, grad_k, grad_v, ld_grad_kv,
+                               MBV_LO_FLAG(grad_kv_bf16), stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   AttnGeom g;
   if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
@@ -462,12 +484,13 @@ extern "C" int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int3
   }
   float* gk32 = reinterpret_cast<float*>(grad_k);
   float* gv32 = reinterpret_cast<float*>(grad_v);
-  return is_bf16 ? attn_bwd_launch<true, __bf16>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, gk32,
+  return is_bf16 ? attn_bwd_launch<true, lo16_t>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, gk32,
                                                  gv32, stream)
                  : attn_bwd_launch<false, float>(g, head_dim, q, k, v, blocked, out, grad_out, lse, grad_q, gk32,
                                                  gv32, stream);
 }
 
+#ifndef MBV_H16
 extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const uint8_t* blocked, const void* out,
                             const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch,
                             int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
@@ -475,3 +498,4 @@ extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const u
   return mbv_attn_bwd_ld(q, k, v, heads * head_dim, blocked, out, grad_out, lse, is_bf16, batch, num_queries, num_keys,
                          heads, head_dim, grad_q, grad_k, grad_v, heads * head_dim, 0, stream_);
 }
+#endif

@@ -16,32 +16,32 @@
 
 namespace {
 
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ float f16_to_f32(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+__device__ __forceinline__ unsigned f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 
-// 4 consecutive channels of a row, f32 or bf16 storage
-__device__ __forceinline__ float4 load4(const void* base, bool bf16, long elem) {
-  if (bf16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+// 4 consecutive channels of a row; `kind` = MBV_DT_F32 / MBV_DT_BF16 / MBV_DT_F16 storage (wave-uniform)
+__device__ __forceinline__ float4 load4(const void* base, int kind, long elem) {
+  if (kind == MBV_DT_F32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+  const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+  if (kind == MBV_DT_BF16)
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                        __uint_as_float(u.y & 0xffff0000u));
-  }
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+  return make_float4(f16_to_f32(u.x & 0xffffu), f16_to_f32(u.x >> 16), f16_to_f32(u.y & 0xffffu), f16_to_f32(u.y >> 16));
 }
-__device__ __forceinline__ void store4(void* base, bool bf16, long elem, float4 v) {
-  if (bf16) {
-    uint2 u;
-    u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-    u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = u;
-  } else {
+__device__ __forceinline__ void store4(void* base, int kind, long elem, float4 v) {
+  if (kind == MBV_DT_F32) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
+    return;
   }
+  uint2 u;
+  if (kind == MBV_DT_BF16) {
+    u.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
+    u.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+  } else {
+    u.x = f32_to_f16(v.x) | (f32_to_f16(v.y) << 16);
+    u.y = f32_to_f16(v.z) | (f32_to_f16(v.w) << 16);
+  }
+  *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = u;
 }
 
 struct LnIo {
@@ -113,7 +113,7 @@ struct LnBwdIo {
   const void* ds; int ds_bf16;       // gradient arriving at the sum from the residual path (nullable)
   const float* s; const float* mean; const float* rstd; const float* gamma;
   float* dx;                         // f32 gradient of the sum (= of a and of b)
-  void* dx_lo;                       // optional bf16 copy of dx for a bf16 branch input (nullable)
+  void* dx_lo; int dx_lo_kind;       // optional 16-bit copy of dx for a 16-bit branch input (nullable), its storage kind
   float* partial;                    // (gridDim.x, NP, C) per-block Σ dy*xhat, Σ dy [, Σ dx]; NULL = few blocks:
                                      // add straight into dgamma / dbeta / dbranch (no reduction launch)
   float* dgamma; float* dbeta; float* dbranch;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
           d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
         }
         *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
-        if (io.dx_lo) store4(io.dx_lo, 1, base + 4 * v, d);
+        if (io.dx_lo) store4(io.dx_lo, io.dx_lo_kind, base + 4 * v, d);
         dxs[i].x += d.x; dxs[i].y += d.y; dxs[i].z += d.z; dxs[i].w += d.w;
       }
     }
@@ -281,8 +281,8 @@ extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* 
 
 extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                                      const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
-                                     float* dx, void* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate,
-                                     float* dbranch_bias, float* partial_ws, void* stream) {
+                                     float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta,
+                                     int32_t accumulate, float* dbranch_bias, float* partial_ws, void* stream) {
   const int it = iters_for(C);
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
@@ -296,10 +296,11 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
     return MBV_OK;
   }
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
+  if (dx_lo && dx_lo_dtype != MBV_DT_BF16 && dx_lo_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   const int np = dbranch_bias ? 3 : 2;
   const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
   const bool direct = nblk <= 64;          // few rows (the decoder's B*Q tokens): ≤ 64 adds per address, one launch
-  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_bf16, direct ? nullptr : partial_ws,
+  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, direct ? nullptr : partial_ws,
              dgamma, dbeta, dbranch_bias, np};
   if (direct && !accumulate) {
     MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));

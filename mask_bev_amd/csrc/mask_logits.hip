@@ -17,26 +17,35 @@
 
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(lo16_t)))) lo16_t bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 constexpr int PT = 128;    // pixels per workgroup
 constexpr int QB = 128;    // queries per workgroup (4 waves x 32)
 
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef MBV_H16
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 // ---- bf16 --------------------------------------------------------------------------------------------
 template <int KC, typename TOut>   // channels staged per pass; logits stored as bf16 or (the f32 accumulators) f32
-__global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restrict__ E, const __bf16* __restrict__ F,
+__global__ void __launch_bounds__(256) k_mask_logits_bf16(const lo16_t* __restrict__ E, const lo16_t* __restrict__ F,
                                                           int Q, int C, int64_t HW, TOut* __restrict__ out) {
   constexpr int LD = KC + 8;
-  __shared__ __attribute__((aligned(16))) __bf16 ft[PT * LD];      // [pixel][c]
+  __shared__ __attribute__((aligned(16))) lo16_t ft[PT * LD];      // [pixel][c]
   const int b = blockIdx.y, q0 = blockIdx.z * QB;
   const int64_t p0 = (int64_t)blockIdx.x * PT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const __bf16* Fb = F + (int64_t)b * C * HW;
+  const lo16_t* Fb = F + (int64_t)b * C * HW;
   const int q = q0 + 32 * wave + r;
-  const __bf16* Eq = E + ((int64_t)b * Q + (q < Q ? q : 0)) * C;
+  const lo16_t* Eq = E + ((int64_t)b * Q + (q < Q ? q : 0)) * C;
   f32x16 acc[4];
 #pragma unroll
   for (int pb = 0; pb < 4; ++pb)
@@ -47,7 +56,7 @@ __global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restri
     // stage F[kc .. kc+KC)[p0 .. p0+PT) transposed: 8 consecutive pixels of one channel per thread-iteration
     for (int idx = threadIdx.x; idx < KC * (PT / 8); idx += blockDim.x) {
       const int c = idx / (PT / 8), px = (idx - c * (PT / 8)) * 8;
-      __bf16 v[8];
+      lo16_t v[8];
       const bool c_ok = kc + c < C;
       if (c_ok && p0 + px + 7 < HW && (HW & 7) == 0) {
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(Fb + (int64_t)(kc + c) * HW + p0 + px);
@@ -56,7 +65,7 @@ __global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restri
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          v[j] = (c_ok && p0 + px + j < HW) ? Fb[(int64_t)(kc + c) * HW + p0 + px + j] : (__bf16)0.f;
+          v[j] = (c_ok && p0 + px + j < HW) ? Fb[(int64_t)(kc + c) * HW + p0 + px + j] : (lo16_t)0.f;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ft[(px + j) * LD + c] = v[j];
@@ -69,12 +78,12 @@ __global__ void __launch_bounds__(256) k_mask_logits_bf16(const __bf16* __restri
         a = *reinterpret_cast<const bf16x8*>(Eq + kc + 16 * ks + 8 * h);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = (__bf16)0.f;
+        for (int j = 0; j < 8; ++j) a[j] = (lo16_t)0.f;
       }
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) {
         const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(&ft[(32 * pb + r) * LD + 16 * ks + 8 * h]);
-        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[pb], 0, 0, 0);
+        acc[pb] = mfma16(a, bfrag, acc[pb]);
       }
     }
   }
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(256) k_mask_logits_f32(const float* __restrict
 
 // ---- attention mask ----------------------------------------------------------------------------------
 __device__ __forceinline__ float ld(const float* p) { return *p; }
-__device__ __forceinline__ float ld(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ float ld(const lo16_t* p) { return (float)*p; }
 
 // one workgroup per (b, q): bilinear resize (align_corners=False) of the (H, W) logits to (h, w),
 // blocked = sigmoid(v) < 0.5, and if every key would be blocked the row is un-blocked.
@@ -180,9 +189,22 @@ __global__ void __launch_bounds__(256) k_attn_mask(const T* __restrict__ logits,
 
 }  // namespace
 
-extern "C" int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feature, int32_t is_bf16, int32_t batch,
-                                   int32_t num_queries, int32_t channels, int64_t pixels, void* logits,
-                                   int32_t logits_f32, void* stream_) {
+#ifndef MBV_H16
+// the half build of this file (mask_logits_f16.hip); `is_bf16` = MBV_DT_F16 forwards there
+MBV_F16_TWIN int mbv_mask_logits_fwd_f16(const void*, const void*, int32_t, int32_t, int32_t, int32_t, int64_t, void*,
+                                         int32_t, void*);
+MBV_F16_TWIN int mbv_attn_mask_from_logits_f16(const void*, int32_t, int64_t, int32_t, int32_t, int32_t, int32_t, uint8_t*,
+                                               void*);
+#endif
+
+MBV_ENTRY int MBV_SYM(mbv_mask_logits_fwd)(const void* mask_embed, const void* mask_feature, int32_t is_bf16,
+                                           int32_t batch, int32_t num_queries, int32_t channels, int64_t pixels,
+                                           void* logits, int32_t logits_f32, void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16)
+    return mbv_mask_logits_fwd_f16(mask_embed, mask_feature, 1, batch, num_queries, channels, pixels, logits, logits_f32,
+                                   stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || num_queries <= 0 || channels <= 0 || pixels <= 0) return MBV_ERR_BAD_ARG;
   if (!mask_embed || !mask_feature || !logits) return MBV_ERR_BAD_ARG;
@@ -191,12 +213,12 @@ extern "C" int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feat
     if (channels % 16 != 0) return MBV_ERR_UNSUPPORTED;
     if (logits_f32)
       hipLaunchKernelGGL((k_mask_logits_bf16<256, float>), grid, block, 0, stream,
-                         reinterpret_cast<const __bf16*>(mask_embed), reinterpret_cast<const __bf16*>(mask_feature),
+                         reinterpret_cast<const lo16_t*>(mask_embed), reinterpret_cast<const lo16_t*>(mask_feature),
                          num_queries, channels, pixels, reinterpret_cast<float*>(logits));
     else
-      hipLaunchKernelGGL((k_mask_logits_bf16<256, __bf16>), grid, block, 0, stream,
-                         reinterpret_cast<const __bf16*>(mask_embed), reinterpret_cast<const __bf16*>(mask_feature),
-                         num_queries, channels, pixels, reinterpret_cast<__bf16*>(logits));
+      hipLaunchKernelGGL((k_mask_logits_bf16<256, lo16_t>), grid, block, 0, stream,
+                         reinterpret_cast<const lo16_t*>(mask_embed), reinterpret_cast<const lo16_t*>(mask_feature),
+                         num_queries, channels, pixels, reinterpret_cast<lo16_t*>(logits));
   } else {
     if (channels % 2 != 0) return MBV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_mask_logits_f32<128>, grid, block, 0, stream, reinterpret_cast<const float*>(mask_embed),
@@ -207,15 +229,18 @@ extern "C" int mbv_mask_logits_fwd(const void* mask_embed, const void* mask_feat
   return MBV_OK;
 }
 
-extern "C" int mbv_attn_mask_from_logits(const void* logits, int32_t is_bf16, int64_t rows, int32_t H, int32_t W,
-                                         int32_t h, int32_t w, uint8_t* blocked, void* stream_) {
+MBV_ENTRY int MBV_SYM(mbv_attn_mask_from_logits)(const void* logits, int32_t is_bf16, int64_t rows, int32_t H,
+                                                 int32_t W, int32_t h, int32_t w, uint8_t* blocked, void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16) return mbv_attn_mask_from_logits_f16(logits, 1, rows, H, W, h, w, blocked, stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (rows < 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return MBV_ERR_BAD_ARG;
   if (rows == 0) return MBV_OK;
   if (!logits || !blocked) return MBV_ERR_BAD_ARG;
   if (is_bf16)
-    hipLaunchKernelGGL(k_attn_mask<__bf16>, dim3((unsigned)rows), dim3(256), 0, stream,
-                       reinterpret_cast<const __bf16*>(logits), H, W, h, w, blocked);
+    hipLaunchKernelGGL(k_attn_mask<lo16_t>, dim3((unsigned)rows), dim3(256), 0, stream,
+                       reinterpret_cast<const lo16_t*>(logits), H, W, h, w, blocked);
   else
     hipLaunchKernelGGL(k_attn_mask<float>, dim3((unsigned)rows), dim3(256), 0, stream,
                        reinterpret_cast<const float*>(logits), H, W, h, w, blocked);

@@ -66,6 +66,27 @@ __device__ __forceinline__ void st4<unsigned short>(unsigned short* p, const flo
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// IEEE half storage (dtype flag MBV_DT_F16)
+template <>
+__device__ __forceinline__ float ldf<_Float16>(const _Float16* p) { return (float)*p; }
+template <>
+__device__ __forceinline__ void stf<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
+template <>
+__device__ __forceinline__ float round_like<_Float16>(float v) { return (float)(_Float16)v; }
+template <>
+__device__ __forceinline__ void ld4<_Float16>(const _Float16* p, float* v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 q = *reinterpret_cast<const h4*>(p);
+  v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+}
+template <>
+__device__ __forceinline__ void st4<_Float16>(_Float16* p, const float* v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 q;
+  q[0] = (_Float16)v[0]; q[1] = (_Float16)v[1]; q[2] = (_Float16)v[2]; q[3] = (_Float16)v[3];
+  *reinterpret_cast<h4*>(p) = q;
+}
+
 struct Norm { float w[8], h[8]; };
 
 template <typename T>
@@ -239,7 +260,11 @@ extern "C" int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int
   if (!fill_norm(spatial_shapes_host, num_levels, n)) return MBV_ERR_BAD_ARG;
   const long rows = (long)batch * num_query * num_heads;
   const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
-  if (is_bf16)
+  if (is_bf16 == MBV_DT_F16)
+    hipLaunchKernelGGL(k_msda_prepare_fwd<_Float16>, grid, block, 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(offsets), reinterpret_cast<const _Float16*>(logits),
+                       ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn);
+  else if (is_bf16)
     hipLaunchKernelGGL(k_msda_prepare_fwd<unsigned short>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned short*>(offsets), reinterpret_cast<const unsigned short*>(logits),
                        ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn);
@@ -266,7 +291,11 @@ extern "C" int mbv_msda_prepare_bwd_ld(const float* grad_loc, const float* grad_
   if (!fill_norm(spatial_shapes_host, num_levels, n)) return MBV_ERR_BAD_ARG;
   const long rows = (long)batch * num_query * num_heads;
   const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
-  if (out_bf16)
+  if (out_bf16 == MBV_DT_F16)
+    hipLaunchKernelGGL(k_msda_prepare_bwd<_Float16>, grid, block, 0, (hipStream_t)stream, grad_loc, grad_attn, attn, n,
+                       rows, num_levels, num_points, reinterpret_cast<_Float16*>(grad_offsets),
+                       reinterpret_cast<_Float16*>(grad_logits), num_heads, (long)ld_offsets, (long)ld_logits);
+  else if (out_bf16)
     hipLaunchKernelGGL(k_msda_prepare_bwd<unsigned short>, grid, block, 0, (hipStream_t)stream, grad_loc, grad_attn,
                        attn, n, rows, num_levels, num_points, reinterpret_cast<unsigned short*>(grad_offsets),
                        reinterpret_cast<unsigned short*>(grad_logits), num_heads, (long)ld_offsets, (long)ld_logits);

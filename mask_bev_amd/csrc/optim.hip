@@ -16,7 +16,14 @@ namespace {
 struct AdamArgs {
   float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale;
   int decoupled, zero_grad;
+  int shadow_kind;                 // MBV_DT_BF16 / MBV_DT_F16: storage of the weight shadow
+  const float* loss_scale;         // device scalar (nullable): gradients arrive multiplied by it (fp16 loss scaling)
+  const int* skip;                 // device flag (nullable): non-zero = the gradient held inf / nan, skip the update
 };
+
+__device__ __forceinline__ unsigned short shadow_bits(float p, int kind) {
+  return kind == MBV_DT_F16 ? __builtin_bit_cast(unsigned short, (_Float16)p) : f32_to_bf16_rne(p);
+}
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
   g *= a.grad_scale;
@@ -37,6 +44,16 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float*
                                                unsigned short* __restrict__ shadow, long n, AdamArgs a) {
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
+  if (a.loss_scale) a.grad_scale /= *a.loss_scale;
+  if (a.skip && *a.skip) {         // overflowed step: parameters, moments and the shadow stay; the gradient is dropped
+    if (a.zero_grad) {
+      for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const long t = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (t < n) grad[t] = 0.f;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 p = reinterpret_cast<float4*>(param)[i];
     const float4 g = reinterpret_cast<const float4*>(grad)[i];
@@ -51,7 +68,8 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float*
     reinterpret_cast<float4*>(exp_avg_sq)[i] = v;
     if (shadow) {
       ushort4 s;
-      s.x = f32_to_bf16_rne(p.x); s.y = f32_to_bf16_rne(p.y); s.z = f32_to_bf16_rne(p.z); s.w = f32_to_bf16_rne(p.w);
+      s.x = shadow_bits(p.x, a.shadow_kind); s.y = shadow_bits(p.y, a.shadow_kind);
+      s.z = shadow_bits(p.z, a.shadow_kind); s.w = shadow_bits(p.w, a.shadow_kind);
       reinterpret_cast<ushort4*>(shadow)[i] = s;
     }
     if (a.zero_grad) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -62,16 +80,48 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float*
     float p = param[t], m = exp_avg[t], v = exp_avg_sq[t];
     adam_one(p, grad[t], m, v, a);
     param[t] = p; exp_avg[t] = m; exp_avg_sq[t] = v;
-    if (shadow) shadow[t] = f32_to_bf16_rne(p);
+    if (shadow) shadow[t] = shadow_bits(p, a.shadow_kind);
     if (a.zero_grad) grad[t] = 0.f;
   }
 }
 
-// f32 -> bf16 shadow refresh of an arena (after load_state_dict / parameter broadcast).
+// f32 -> 16-bit shadow refresh of an arena (after load_state_dict / parameter broadcast).
 __global__ void __launch_bounds__(256) k_shadow(const float* __restrict__ param, unsigned short* __restrict__ shadow,
-                                                long n) {
+                                                long n, int kind) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) shadow[i] = f32_to_bf16_rne(param[i]);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) shadow[i] = shadow_bits(param[i], kind);
+}
+
+// ---- fp16 loss scaling, all on the device (no host synchronisation, replayable) ---------------------------------
+// flag |= "some gradient element is inf or nan" (what torch.amp.GradScaler's unscale_ reports as found_inf)
+__global__ void __launch_bounds__(256) k_grad_nonfinite(const float* __restrict__ grad, long n, int* __restrict__ flag) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const uint4 u = reinterpret_cast<const uint4*>(grad)[i];
+    bad |= ((u.x & 0x7f800000u) == 0x7f800000u) | ((u.y & 0x7f800000u) == 0x7f800000u) |
+           ((u.z & 0x7f800000u) == 0x7f800000u) | ((u.w & 0x7f800000u) == 0x7f800000u);
+  }
+  const long t = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) bad |= (__float_as_uint(grad[t]) & 0x7f800000u) == 0x7f800000u;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// GradScaler.update(): overflow -> scale *= backoff, streak = 0; else streak += 1 and every `interval` clean steps
+// scale *= growth.  Clears the flag for the next step.
+__global__ void k_loss_scale_update(float* __restrict__ scale, int* __restrict__ streak, int* __restrict__ flag,
+                                    float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*flag) {
+    *scale = fmaxf(*scale * backoff, 1.f);
+    *streak = 0;
+  } else if (++*streak >= interval) {
+    const float s = *scale * growth;
+    if (s <= 3.0e38f && s == s) *scale = s;
+    *streak = 0;
+  }
+  *flag = 0;
 }
 
 // Column sums of a row-major (T, N) matrix accumulated into out (N,) f32.
@@ -94,6 +144,15 @@ template <>
 __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return __uint_as_float((unsigned)*p << 16); }
+
+template <>
+__device__ __forceinline__ float4 load4<_Float16>(const _Float16* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 q = *reinterpret_cast<const h4*>(p);
+  return make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+}
+template <>
+__device__ __forceinline__ float load1<_Float16>(const _Float16* p) { return (float)*p; }
 
 // W = threads per row (power of two ≤ 256, each owning 4 adjacent columns); 256 / W rows are read per iteration,
 // 4 iterations in flight.  Row slices (gridDim.y) are kept few (≤ 64 per column) — f32 atomics onto the same
@@ -168,6 +227,14 @@ __device__ __forceinline__ void store4t<unsigned short>(unsigned short* p, float
   u.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
   u.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
   *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <>
+__device__ __forceinline__ void store4t<_Float16>(_Float16* p, float4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 q;
+  q[0] = (_Float16)v.x; q[1] = (_Float16)v.y; q[2] = (_Float16)v.z; q[3] = (_Float16)v.w;
+  *reinterpret_cast<h4*>(p) = q;
 }
 
 template <int KIND>   // 0 = ReLU, 1 = GELU (erf)
@@ -300,15 +367,18 @@ __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g
 }  // namespace
 
 extern "C" int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
-                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              int64_t step, float grad_scale, int32_t decoupled, int32_t zero_grad, void* stream) {
+                              int32_t shadow_dtype, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int64_t step, float grad_scale, int32_t decoupled, int32_t zero_grad,
+                              const float* loss_scale, const int32_t* skip_flag, void* stream) {
   if (n < 0 || step < 1 || !param || !grad || !exp_avg || !exp_avg_sq) return MBV_ERR_BAD_ARG;
   if (n == 0) return MBV_OK;
   if ((reinterpret_cast<size_t>(param) | reinterpret_cast<size_t>(grad) | reinterpret_cast<size_t>(exp_avg) |
        reinterpret_cast<size_t>(exp_avg_sq)) & 15)
     return MBV_ERR_BAD_ARG;
   if (shadow_bf16 && (reinterpret_cast<size_t>(shadow_bf16) & 7)) return MBV_ERR_BAD_ARG;
+  if (shadow_bf16 && shadow_dtype != MBV_DT_BF16 && shadow_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   AdamArgs a;
+  a.shadow_kind = shadow_dtype; a.loss_scale = loss_scale; a.skip = skip_flag;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
   a.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -323,13 +393,35 @@ extern "C" int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* 
   return MBV_OK;
 }
 
-extern "C" int mbv_refresh_shadow(const float* param, void* shadow_bf16, int64_t n, void* stream) {
+extern "C" int mbv_grad_nonfinite(const float* grad, int64_t n, int32_t* flag, void* stream) {
+  if (n < 0 || !grad || !flag || (reinterpret_cast<size_t>(grad) & 15)) return MBV_ERR_BAD_ARG;
+  if (n == 0) return MBV_OK;
+  long blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_grad_nonfinite, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, (long)n, flag);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_loss_scale_update(float* loss_scale, int32_t* clean_steps, int32_t* flag, float growth, float backoff,
+                                     int32_t growth_interval, void* stream) {
+  if (!loss_scale || !clean_steps || !flag || growth < 1.f || backoff <= 0.f || backoff > 1.f || growth_interval < 1)
+    return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_loss_scale_update, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_scale, clean_steps, flag,
+                     growth, backoff, growth_interval);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t shadow_dtype, int64_t n, void* stream) {
   if (n < 0 || !param || !shadow_bf16) return MBV_ERR_BAD_ARG;
+  if (shadow_dtype != MBV_DT_BF16 && shadow_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   if (n == 0) return MBV_OK;
   long blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(k_shadow, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                     reinterpret_cast<unsigned short*>(shadow_bf16), (long)n);
+                     reinterpret_cast<unsigned short*>(shadow_bf16), (long)n, shadow_dtype);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -348,7 +440,10 @@ extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, in
   if (gy > rows / (8L * rpi)) gy = rows / (8L * rpi);
   if (gy < 1) gy = 1;
   const bool vec = (n & 3) == 0 && (reinterpret_cast<size_t>(g) & (is_bf16 ? 7 : 15)) == 0;
-  if (is_bf16)
+  if (is_bf16 == MBV_DT_F16)
+    hipLaunchKernelGGL(k_colsum<_Float16>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(g), (long)rows, n, out, vec, W);
+  else if (is_bf16)
     hipLaunchKernelGGL(k_colsum<unsigned short>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned short*>(g), (long)rows, n, out, vec, W);
   else
@@ -399,7 +494,8 @@ extern "C" int mbv_act_bwd_colsum(const void* grad_act, const void* pre_act, int
 #define MBV_ACT(T, K)                                                                                              \
   hipLaunchKernelGGL((k_act_bwd_colsum<T, K>), grid, block, 0, st, reinterpret_cast<const T*>(grad_act),           \
                      reinterpret_cast<const T*>(pre_act), (long)rows, n, reinterpret_cast<T*>(grad_pre), bias_acc, W)
-  if (is_bf16) { if (kind) MBV_ACT(unsigned short, 1); else MBV_ACT(unsigned short, 0); }
+  if (is_bf16 == MBV_DT_F16) { if (kind) MBV_ACT(_Float16, 1); else MBV_ACT(_Float16, 0); }
+  else if (is_bf16) { if (kind) MBV_ACT(unsigned short, 1); else MBV_ACT(unsigned short, 0); }
   else { if (kind) MBV_ACT(float, 1); else MBV_ACT(float, 0); }
 #undef MBV_ACT
   MBV_CHECK_LAUNCH();

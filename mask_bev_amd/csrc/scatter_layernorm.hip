@@ -179,7 +179,27 @@ __device__ __forceinline__ int64_t patch_row_offset(int b, int channels, int ny,
 // ---------------------------------------------------------------------------------------------
 // forward apply
 // ---------------------------------------------------------------------------------------------
-template <int VEC, bool PATCH>
+// two values <-> one dword of 16-bit storage (KIND = MBV_DT_BF16 or MBV_DT_F16)
+template <int KIND>
+__device__ __forceinline__ unsigned pack_lo2(float a, float b) {
+  if constexpr (KIND == MBV_DT_F16)
+    return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) |
+           ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+  else
+    return (unsigned)f32_to_bf16_rne(a) | ((unsigned)f32_to_bf16_rne(b) << 16);
+}
+template <int KIND>
+__device__ __forceinline__ void unpack_lo2(unsigned u, float& a, float& b) {
+  if constexpr (KIND == MBV_DT_F16) {
+    a = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+    b = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+  } else {
+    a = __uint_as_float(u << 16);
+    b = __uint_as_float(u & 0xffff0000u);
+  }
+}
+
+template <int VEC, int PATCH>     // PATCH: 0 = (B, C, ny, nx) f32 map, MBV_DT_BF16 / MBV_DT_F16 = 4 x 4 patch rows
 __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feats,
                                                   const int32_t* __restrict__ cell_to_pillar,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
@@ -244,8 +264,8 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
           const float a2 = (f[2] - mean) * rstd * w[k][2] + bz[k][2];
           const float a3 = (f[3] - mean) * rstd * w[k][3] + bz[k][3];
           uint2 u;
-          u.x = (unsigned)f32_to_bf16_rne(a0) | ((unsigned)f32_to_bf16_rne(a1) << 16);
-          u.y = (unsigned)f32_to_bf16_rne(a2) | ((unsigned)f32_to_bf16_rne(a3) << 16);
+          u.x = pack_lo2<PATCH>(a0, a1);
+          u.y = pack_lo2<PATCH>(a2, a3);
           *reinterpret_cast<uint2*>(&olds[lane * kTokDw + (ch0 + k) * 2]) = u;
         }
         __syncthreads();
@@ -289,7 +309,7 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
 // backward, pass 1: grad_weight / grad_bias, per-scan sums of (g*w) and (g*w*xhat), and g*w at the
 // occupied cells scattered back into (pillar, channel) rows.
 // ---------------------------------------------------------------------------------------------
-template <int VEC, bool PATCH>
+template <int VEC, int PATCH>
 __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ grad_out_,
                                                       const float* __restrict__ feats,
                                                       const int32_t* __restrict__ cell_to_pillar,
@@ -378,10 +398,8 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
           const uint2 u = *reinterpret_cast<const uint2*>(&gtile[lane * kTokDw + (ch0 + k) * 2]);
-          g[k][0] = __uint_as_float(u.x << 16);
-          g[k][1] = __uint_as_float(u.x & 0xffff0000u);
-          g[k][2] = __uint_as_float(u.y << 16);
-          g[k][3] = __uint_as_float(u.y & 0xffff0000u);
+          unpack_lo2<PATCH>(u.x, g[k][0], g[k][1]);
+          unpack_lo2<PATCH>(u.y, g[k][2], g[k][3]);
         }
       }
       float s1f = 0.f, s2f = 0.f;   // <= 16 terms per thread and scan: f32 partials, f64 across threads
@@ -491,12 +509,14 @@ extern "C" int mbv_scatter_layernorm_patch_supported(int32_t channels, int32_t n
 extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
-                                         int32_t patch, void* out, float* stats, void* workspace,
-                                         size_t workspace_bytes, void* stream_, void* ev_start, void* ev_stop) {
+                                         int32_t patch, int32_t patch_dtype, void* out, float* stats,
+                                         void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
+                                         void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
   if (patch != 0 && !mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch)) return MBV_ERR_UNSUPPORTED;
+  if (patch != 0 && patch_dtype != MBV_DT_BF16 && patch_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   if (!feats || !pillar_batch_start || !cell_to_pillar || !weight || !bias || !out || !stats) return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
   double* sums = reinterpret_cast<double*>(workspace);
@@ -510,15 +530,19 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (patch) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL((k_ln_apply<4, true>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
-                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+    if (patch_dtype == MBV_DT_F16)
+      hipLaunchKernelGGL((k_ln_apply<4, MBV_DT_F16>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats,
+                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+    else
+      hipLaunchKernelGGL((k_ln_apply<4, MBV_DT_BF16>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats,
+                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out);
   } else if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL((k_ln_apply<4, false>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
+    hipLaunchKernelGGL((k_ln_apply<4, 0>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
                        weight, bias, stats, batch, channels, ny, nx, xtiles, out);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL((k_ln_apply<1, false>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
+    hipLaunchKernelGGL((k_ln_apply<1, 0>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
                        weight, bias, stats, batch, channels, ny, nx, xtiles, out);
   }
   MBV_CHECK_LAUNCH();
@@ -526,7 +550,7 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
   return MBV_OK;
 }
 
-extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, const float* feats,
+extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
                                          const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
                                          const float* weight, const float* stats, int32_t batch, int32_t channels,
                                          int32_t ny, int32_t nx, int64_t num_pillars, float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
@@ -536,6 +560,7 @@ extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, co
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
   if (patch != 0 && !mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch)) return MBV_ERR_UNSUPPORTED;
+  if (patch != 0 && patch_dtype != MBV_DT_BF16 && patch_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   if (!grad_out || !feats || !pillar_batch_start || !cell_to_pillar || !weight || !stats || !grad_feats ||
       !grad_weight || !grad_bias)
     return MBV_ERR_BAD_ARG;
@@ -546,17 +571,22 @@ extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, co
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
   if (patch) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL((k_ln_bwd_dense<4, true>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
-                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
-                       grad_bias, accumulate, sums);
+    if (patch_dtype == MBV_DT_F16)
+      hipLaunchKernelGGL((k_ln_bwd_dense<4, MBV_DT_F16>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out,
+                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
+                         grad_bias, accumulate, sums);
+    else
+      hipLaunchKernelGGL((k_ln_bwd_dense<4, MBV_DT_BF16>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out,
+                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
+                         grad_bias, accumulate, sums);
   } else if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL((k_ln_bwd_dense<4, false>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL((k_ln_bwd_dense<4, 0>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL((k_ln_bwd_dense<1, false>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
+    hipLaunchKernelGGL((k_ln_bwd_dense<1, 0>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
                        cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
                        grad_bias, accumulate, sums);
   }

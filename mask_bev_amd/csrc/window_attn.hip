@@ -122,30 +122,30 @@ __device__ __forceinline__ void zero_t_tail(typename Lay<BF16, D>::T* t_img) {
 // loop iteration (≈ 9 in the backward); this is one or two.  Requires C % 8 == 0 and 16-byte aligned tensors.
 union Pack8 {
   uint4 u;
-  __bf16 h[8];
+  lo16_t h[8];
 };
 
 __device__ __forceinline__ Pack8 pad_pack(const float* __restrict__ vec, int c) {
   Pack8 p;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p.h[j] = (__bf16)(vec ? vec[c + j] : 0.f);
+  for (int j = 0; j < 8; ++j) p.h[j] = (lo16_t)(vec ? vec[c + j] : 0.f);
   return p;
 }
 
 template <int D>
-__device__ __forceinline__ void put_row(__bf16* img, int t, int c8, const Pack8& p) {
+__device__ __forceinline__ void put_row(lo16_t* img, int t, int c8, const Pack8& p) {
   *reinterpret_cast<uint4*>(img + t * Lay<true, D>::RS + c8) = p.u;
 }
 template <int D>
-__device__ __forceinline__ void put_t(__bf16* img, int t, int c8, const Pack8& p) {
+__device__ __forceinline__ void put_t(lo16_t* img, int t, int c8, const Pack8& p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) img[(c8 + j) * Lay<true, D>::TS + t] = p.h[j];
 }
 
 template <int D>
 __device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
-                                               const __bf16* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                               int col, __bf16* q_img, __bf16* k_img, __bf16* vt_img) {
+                                               const lo16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                               int col, lo16_t* q_img, lo16_t* k_img, lo16_t* vt_img) {
   constexpr int CH = D / 8;
   const int C3 = 3 * g.C;
   for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& 
     if (t < g.N) {
       const int pix = pix_lds[t];
       if (pix >= 0) {
-        const __bf16* p = qkv + ((int64_t)id.b * g.H * g.W + pix) * C3 + col + c8;
+        const lo16_t* p = qkv + ((int64_t)id.b * g.H * g.W + pix) * C3 + col + c8;
         q.u = *reinterpret_cast<const uint4*>(p);
         k.u = *reinterpret_cast<const uint4*>(p + g.C);
         v.u = *reinterpret_cast<const uint4*>(p + 2 * g.C);
@@ -173,10 +173,10 @@ __device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& 
 
 template <int D>
 __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
-                                               const __bf16* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                               const __bf16* __restrict__ out, const __bf16* __restrict__ grad_out,
-                                               int col, __bf16* q_img, __bf16* qt_img, __bf16* k_img, __bf16* kt_img,
-                                               __bf16* v_img, __bf16* do_img, __bf16* dot_img, double* delta_s) {
+                                               const lo16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                               const lo16_t* __restrict__ out, const lo16_t* __restrict__ grad_out,
+                                               int col, lo16_t* q_img, lo16_t* qt_img, lo16_t* k_img, lo16_t* kt_img,
+                                               lo16_t* v_img, lo16_t* do_img, lo16_t* dot_img, double* delta_s) {
   constexpr int CH = D / 8;
   const int C3 = 3 * g.C;
 #pragma unroll 2
@@ -190,7 +190,7 @@ __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& 
       if (pix >= 0) {
         real = true;
         const int64_t row = (int64_t)id.b * g.H * g.W + pix;
-        const __bf16* p = qkv + row * C3 + col + c8;
+        const lo16_t* p = qkv + row * C3 + col + c8;
         q.u = *reinterpret_cast<const uint4*>(p);
         k.u = *reinterpret_cast<const uint4*>(p + g.C);
         v.u = *reinterpret_cast<const uint4*>(p + 2 * g.C);
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
   const int C3 = 3 * g.C, col = id.head * D;
   const bool vec_ok = g.vec_ok != 0;
   bool fused = false;
-  if constexpr (BF16 && std::is_same_v<TIn, __bf16>) {
+  if constexpr (BF16 && std::is_same_v<TIn, lo16_t>) {
     if (vec_ok) {
       fused = true;
       stage_fwd_bf16<D>(g, id, pix, qkv, qkv_bias, col, q_img, k_img, v_img);
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   __syncthreads();
   const int C3 = 3 * g.C, col = id.head * D;
   bool fused = false;
-  if constexpr (BF16 && std::is_same_v<TIn, __bf16>) {
+  if constexpr (BF16 && std::is_same_v<TIn, lo16_t>) {
     if (g.vec_ok) {
       fused = true;
       stage_bwd_bf16<D>(g, id, pix, qkv, qkv_bias, out, grad_out, col, q_img, qt_img, k_img, kt_img, v_img, do_img,
@@ -614,29 +614,47 @@ int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
 
 }  // namespace
 
+#ifndef MBV_H16
 extern "C" int64_t mbv_window_attn_lse_elems(int32_t batch, int32_t H, int32_t W, int32_t heads, int32_t ws) {
   if (batch <= 0 || H <= 0 || W <= 0 || heads <= 0 || ws <= 0) return 0;
   const int64_t nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws;
   return (int64_t)batch * nWh * nWw * heads * NPAD;
 }
 
-extern "C" int mbv_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_table, int32_t is_bf16,
+// the half build of this file (window_attn_f16.hip); `is_bf16` = MBV_DT_F16 forwards there
+MBV_F16_TWIN int mbv_window_attn_fwd_f16(const void*, const float*, const float*, int32_t, int32_t, int32_t, int32_t, int32_t,
+                                         int32_t, int32_t, int32_t, void*, float*, void*);
+MBV_F16_TWIN int mbv_window_attn_bwd_f16(const void*, const float*, const float*, const void*, const void*, const float*,
+                                         int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*,
+                                         float*, float*, int32_t, void*);
+#endif
+
+MBV_ENTRY int MBV_SYM(mbv_window_attn_fwd)(const void* qkv, const float* qkv_bias, const float* bias_table, int32_t is_bf16,
                                    int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws,
                                    int32_t shift, void* out, float* lse, void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16)
+    return mbv_window_attn_fwd_f16(qkv, qkv_bias, bias_table, 1, batch, H, W, C, heads, ws, shift, out, lse, stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WinGeom g;
   if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
   if (g.N > NPAD || ws > 11) return MBV_ERR_UNSUPPORTED;
   if (!qkv || !qkv_bias || !bias_table || !out || !lse) return MBV_ERR_BAD_ARG;
   const int D = C / heads;
-  return is_bf16 ? launch_fwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, lse, stream)
+  return is_bf16 ? launch_fwd<true, lo16_t>(g, D, qkv, qkv_bias, bias_table, out, lse, stream)
                  : launch_fwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, lse, stream);
 }
 
-extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
+MBV_ENTRY int MBV_SYM(mbv_window_attn_bwd)(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
                                    const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch, int32_t H,
                                    int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, void* grad_qkv,
                                    float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad, void* stream_) {
+#ifndef MBV_H16
+  if (is_bf16 == MBV_DT_F16)
+    return mbv_window_attn_bwd_f16(qkv, qkv_bias, bias_table, out, grad_out, lse, 1, batch, H, W, C, heads, ws, shift,
+                                   grad_qkv, grad_table, grad_qkv_bias, full_bias_grad, stream_);
+#endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WinGeom g;
   if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
@@ -647,7 +665,7 @@ extern "C" int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
   MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
   MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
-  return is_bf16 ? launch_bwd<true, __bf16>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
+  return is_bf16 ? launch_bwd<true, lo16_t>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
                                             grad_qkv_bias, full_bias_grad, stream)
                  : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
                                             grad_qkv_bias, full_bias_grad, stream);

@@ -115,7 +115,7 @@ class GraphedTrainStep:
             leaves = [f.detach().requires_grad_() for f in early]
             cls, masks, heights = m._panoptic_head(leaves + list(feats[cut['stage']:]))
         loss = m.loss(m.compute_loss(cls, masks, self.labels, self.masks, heights, None))
-        loss.backward()
+        m.scale_loss(loss).backward()          # fp16: times the device-side loss scale (a captured multiply)
         self._late_roots = early + [cut['x_in']]
         self._late_grads = [l.grad for l in leaves] + [cut['x_leaf'].grad]
         return loss.detach()

@@ -44,11 +44,12 @@ class LayerNorm(nn.LayerNorm):
         ``skip_bias_grad=True`` — its gradient (the column sums of d(residual)) is accumulated by this op."""
         c = x.shape[-1]
         if (x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
-                and ops.add_layernorm_supported(c) and x.dtype in (torch.float32, torch.bfloat16)
-                and (residual is None or residual.dtype in (torch.float32, torch.bfloat16))):
+                and ops.add_layernorm_supported(c) and x.dtype in ops._ACT_DTYPES
+                and (residual is None or residual.dtype in ops._ACT_DTYPES)):
             out_dtype = torch.float32
-            if gemm_input and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
-                out_dtype = torch.bfloat16
+            if (gemm_input and torch.is_autocast_enabled('cuda')
+                    and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES):
+                out_dtype = torch.get_autocast_dtype('cuda')
             return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum,
                                      branch_bias=residual_bias)
         if residual_bias is not None:
@@ -150,6 +151,22 @@ class PatchMerging(nn.Module):
         return self.reduction(self.norm(x, gemm_input=True))
 
 
+def conv1x1(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A 1 x 1 ``nn.Conv2d`` (its parameters, its state-dict keys) evaluated as ONE strided-batched GEMM
+    ``W (Cout, Cin) @ x[b] (Cin, H*W)`` instead of a MIOpen implicit-GEMM convolution: no NCHW<->NHWC transposes around
+    it (0.11 ms per step of `batched_transpose` kernels in profiles/r02/b_kernel_stats.csv), and bit-reproducible in
+    fp16 (MIOpen's fp16 solver for the mask-feature projection was measured to change its result from call to call,
+    which made every decoder layer after it — and the gradients — irreproducible)."""
+    b, c, h, w = x.shape
+    w2 = conv.weight.view(conv.weight.shape[0], c).unsqueeze(0).expand(b, -1, -1)
+    x2 = x.flatten(2)
+    if conv.bias is None:
+        y = torch.bmm(w2, x2)
+    else:
+        y = torch.baddbmm(conv.bias.view(1, -1, 1), w2, x2)
+    return y.view(b, -1, h, w)
+
+
 class ConvGN(nn.Module):
     """conv → GroupNorm(32) [→ ReLU]; keys ``conv.*`` / ``gn.*`` (mmcv ``ConvModule`` layout used by the
     pixel decoder configured at mask_bev_panoptic_head.py:119-123)."""
@@ -161,7 +178,7 @@ class ConvGN(nn.Module):
         self.relu = relu
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.gn(self.conv(x))
+        x = self.gn(conv1x1(self.conv, x) if self.conv.kernel_size == (1, 1) and x.is_cuda else self.conv(x))
         return F.relu(x) if self.relu else x
 
 

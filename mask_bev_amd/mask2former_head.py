@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import ConvGN, FFN, LayerNorm, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
+from .layers import ConvGN, FFN, conv1x1, LayerNorm, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
 
 
 # --------------------------------------------------------------------------------------
@@ -141,7 +141,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 cur = self.lateral_convs[j](feats[i])
                 y = cur + F.interpolate(tail[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
                 tail.append(self.output_convs[j](y))
-            mask_feature = self.mask_feature(tail[-1])
+            mask_feature = (conv1x1(self.mask_feature, tail[-1]) if tail[-1].is_cuda
+                            else self.mask_feature(tail[-1]))
         if side is not None:
             main.wait_stream(side)
         return mask_feature, tail[:self.num_outs]

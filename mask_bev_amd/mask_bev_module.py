@@ -87,6 +87,7 @@ class MaskBevModule(_Base):
         self._differential_lr_scaling = differential_lr_scaling
         self._predict_heights = predict_heights
         self._arena = None
+        self._loss_scaler = None
         # build extension (not a reference key): arithmetic type of the GEMM-shaped layers
         self._compute_dtype = {'fp32': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[
             kwargs.get('compute_dtype', 'fp32')]
@@ -144,20 +145,30 @@ class MaskBevModule(_Base):
         """Build extension: move parameters / gradients into one :class:`~mask_bev_amd.arena.ParameterArena`
         (call after ``.to(device)``).  ``configure_optimizers`` then returns the single-launch ``FlatAdam`` for
         Adam / AdamW; checkpoint keys and shapes are unchanged."""
-        from .arena import ParameterArena
+        from .arena import LossScaler, ParameterArena
         self._arena = ParameterArena([('encoder', self._encoder), ('backbone', self._backbone),
-                                      ('head', self._panoptic_head)],
-                                     shadow_dtype=torch.bfloat16 if self._compute_dtype == torch.bfloat16 else None)
+                                      ('head', self._panoptic_head)], shadow_dtype=self._compute_dtype)
+        # fp16 compute: dynamic loss scaling with its state on the device (arena.LossScaler); bf16 / fp32 need none
+        self._loss_scaler = LossScaler(self._arena.device) if self._compute_dtype == torch.float16 else None
         return self._arena
+
+    def scale_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """``loss`` times the current fp16 loss scale (the value to call ``backward()`` on); ``loss`` itself for
+        bf16 / fp32 compute.  The matching un-scaling happens inside ``FlatAdam.step()``."""
+        scaler = getattr(self, '_loss_scaler', None)
+        return loss if scaler is None else scaler.scale_loss(loss)
 
     def _flat_optimizer(self):
         from .arena import FlatAdam
         scale = self._differential_lr_scaling if self._differential_lr else 1.0
         groups = [dict(segment='encoder', lr=self._lr * scale), dict(segment='backbone', lr=self._lr * scale),
                   dict(segment='head', lr=self._lr)]
+        scaler = getattr(self, '_loss_scaler', None)
         if self._optimiser_type == OptimizerType.ADAM_W:      # torch defaults: betas (0.9, 0.999), eps 1e-8
-            return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=True)
-        return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=False)
+            return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=True,
+                            scaler=scaler)
+        return FlatAdam(self._arena, groups, lr=self._lr, weight_decay=self._weight_decay, decoupled=False,
+                        scaler=scaler)
 
     def configure_optimizers(self):
         if getattr(self, '_arena', None) is not None and self._optimiser_type in (OptimizerType.ADAM,
@@ -205,8 +216,8 @@ class MaskBevModule(_Base):
             return self._panoptic_head(x)
 
     def _patch_handoff(self) -> int:
-        """bf16 compute: the encoder writes the backbone's 4 x 4 patch rows directly (K3 patch-token layout)."""
-        if self._compute_dtype != torch.bfloat16:
+        """16-bit compute: the encoder writes the backbone's 4 x 4 patch rows directly (K3 patch-token layout)."""
+        if self._compute_dtype is None:
             return 0
         pe = self._backbone._backbone.patch_embed
         return pe.patch if self._encoder.patch_layout(pe.patch) else 0

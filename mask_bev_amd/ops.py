@@ -24,6 +24,28 @@ def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# storage types of activations and their flag in the C ABI (MBV_DT_F32 / MBV_DT_BF16 / MBV_DT_F16, maskbev_hip.h)
+_ACT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+_LO_DTYPES = (torch.bfloat16, torch.float16)
+_DT_FLAG = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _dt_flag(dtype: torch.dtype) -> int:
+    try:
+        return _DT_FLAG[dtype]
+    except KeyError:
+        raise MaskBevHipError(f'mask_bev_amd kernels take f32, bf16 or fp16 activations, got {dtype}') from None
+
+
+def lo_dtype() -> torch.dtype:
+    """The 16-bit type of the current autocast region (bf16 outside one)."""
+    if torch.is_autocast_enabled('cuda'):
+        dt = torch.get_autocast_dtype('cuda')
+        if dt in _LO_DTYPES:
+            return dt
+    return torch.bfloat16
+
+
 def _need_gpu(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -319,7 +341,8 @@ def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torc
 class _ScatterLayerNorm(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # inputs are cast by scatter_layernorm(); `out` keeps its dtype
-    def forward(ctx, feats, weight, bias, cell_to_pillar, pillar_batch_start, batch, ny, nx, eps, patch=0, out=None):
+    def forward(ctx, feats, weight, bias, cell_to_pillar, pillar_batch_start, batch, ny, nx, eps, patch=0, out=None,
+                patch_dtype=torch.bfloat16):
         lib = _lib.load()
         _need_gpu(feats, weight, bias, cell_to_pillar, pillar_batch_start)
         feats = feats.contiguous()
@@ -330,7 +353,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         if patch:
             if not lib.mbv_scatter_layernorm_patch_supported(c, ny, nx, patch):
                 raise MaskBevHipError(f'scatter_layernorm: no patch-token layout for C={c}, {ny}x{nx}, patch {patch}')
-            shape, dt = (batch, ny // patch, nx // patch, patch * patch * c), torch.bfloat16
+            shape, dt = (batch, ny // patch, nx // patch, patch * patch * c), patch_dtype
         else:
             shape, dt = (batch, c, ny, nx), torch.float32
         if out is None:
@@ -342,13 +365,14 @@ class _ScatterLayerNorm(torch.autograd.Function):
         stats = torch.empty((batch, 2), dtype=torch.float32, device=dev)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         rc = lib.mbv_scatter_layernorm_fwd(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
-                                           _ptr(bias), batch, c, ny, nx, float(eps), int(patch), _ptr(out), _ptr(stats),
-                                           _ptr(ws), ws.numel(), _stream(), *TIMER.events('k_ln_apply')[2:])
+                                           _ptr(bias), batch, c, ny, nx, float(eps), int(patch),
+                                           _dt_flag(dt) if patch else 0, _ptr(out), _ptr(stats), _ptr(ws), ws.numel(),
+                                           _stream(), *TIMER.events('k_ln_apply')[2:])
         check(rc, 'mbv_scatter_layernorm_fwd')
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
         ctx.params = (weight, bias)
-        ctx.patch = int(patch)
+        ctx.patch, ctx.patch_dtype = int(patch), dt
         return out
 
     @staticmethod
@@ -357,7 +381,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         lib = _lib.load()
         feats, weight, stats, cell_to_pillar, pillar_batch_start = ctx.saved_tensors
         batch, c, ny, nx = ctx.dims
-        grad_out = grad_out.to(torch.bfloat16 if ctx.patch else torch.float32).contiguous()
+        grad_out = grad_out.to(ctx.patch_dtype if ctx.patch else torch.float32).contiguous()
         dev = feats.device
         g_feats = torch.empty_like(feats)
         wp, bp = ctx.params
@@ -369,7 +393,8 @@ class _ScatterLayerNorm(torch.autograd.Function):
             g_w = torch.empty_like(weight)
             g_b = torch.empty_like(weight)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
-        rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), ctx.patch, _ptr(feats), _ptr(pillar_batch_start),
+        rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), ctx.patch, _dt_flag(ctx.patch_dtype) if ctx.patch else 0,
+                                           _ptr(feats), _ptr(pillar_batch_start),
                                            _ptr(cell_to_pillar),
                                            _ptr(weight), _ptr(stats), batch, c, ny, nx, int(feats.shape[0]),
                                            _ptr(g_feats), _ptr(g_w), _ptr(g_b), 1 if direct else 0, _ptr(ws),
@@ -378,13 +403,13 @@ class _ScatterLayerNorm(torch.autograd.Function):
         if direct:
             _fire_grad_hooks(wp)
             _fire_grad_hooks(bp)
-            return g_feats, None, None, None, None, None, None, None, None, None, None
-        return g_feats, g_w, g_b, None, None, None, None, None, None, None, None
+            return (g_feats,) + (None,) * 11
+        return (g_feats, g_w, g_b) + (None,) * 9
 
 
 class PatchTokens:
     """The BEV pseudo-image handed over as the input rows of a ``patch`` x ``patch`` non-overlapping projection:
-    ``rows`` (B, ny/p, nx/p, p*p*C) bf16 with element ``(y%p)*p*C + c*p + x%p`` (K3's patch-token layout)."""
+    ``rows`` (B, ny/p, nx/p, p*p*C) bf16 / fp16 with element ``(y%p)*p*C + c*p + x%p`` (K3's patch-token layout)."""
 
     def __init__(self, rows: torch.Tensor, channels: int, patch: int):
         self.rows, self.channels, self.patch = rows, channels, patch
@@ -403,10 +428,11 @@ def patch_layout_supported(channels: int, ny: int, nx: int, patch: int) -> bool:
 def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, p: Pillars, batch: int, ny: int,
                       nx: int, eps: float, patch: int = 0, out: Optional[torch.Tensor] = None):
     """``LayerNorm([C, ny, nx])(PointPillarsScatter(feats, coors))`` without building the canvas (K3).
-    ``patch`` = 4 returns :class:`PatchTokens` (bf16) instead of the (B, C, ny, nx) f32 map; ``out`` is an optional
-    destination buffer (no grad) of the result's shape and dtype."""
+    ``patch`` = 4 returns :class:`PatchTokens` (the 16-bit type of the autocast region, or of ``out``) instead of the
+    (B, C, ny, nx) f32 map; ``out`` is an optional destination buffer (no grad) of the result's shape and dtype."""
+    patch_dtype = out.dtype if (out is not None and patch) else lo_dtype()
     out = _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
-                                  p.pillar_batch_start, batch, ny, nx, eps, patch, out)
+                                  p.pillar_batch_start, batch, ny, nx, eps, patch, out, patch_dtype)
     return PatchTokens(out, int(weight.shape[0]), patch) if patch else out
 
 
@@ -419,8 +445,8 @@ class _WindowAttention(torch.autograd.Function):
         lib = _lib.load()
         _need_gpu(qkv, qkv_bias, bias_table)
         ctx.full_bias_grad = full_bias_grad
-        if qkv.dtype not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError(f'window_attention supports f32 and bf16 qkv, got {qkv.dtype}')
+        if qkv.dtype not in _ACT_DTYPES:
+            raise MaskBevHipError(f'window_attention supports f32, bf16 and fp16 qkv, got {qkv.dtype}')
         qkv = qkv.contiguous()
         b, h, w, c3 = qkv.shape
         c = c3 // 3
@@ -429,7 +455,7 @@ class _WindowAttention(torch.autograd.Function):
         out = torch.empty((b, h, w, c), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((lib.mbv_window_attn_lse_elems(b, h, w, num_heads, ws),), dtype=torch.float32,
                           device=qkv.device)
-        is_bf16 = 1 if qkv.dtype == torch.bfloat16 else 0
+        is_bf16 = _dt_flag(qkv.dtype)
         rc = lib.mbv_window_attn_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), is_bf16, b, h, w, c, num_heads, ws, shift,
                                      _ptr(out), _ptr(lse), _stream())
         check(rc, 'mbv_window_attn_fwd')
@@ -448,7 +474,7 @@ class _WindowAttention(torch.autograd.Function):
         g_qkv = torch.empty_like(qkv)
         g_table = torch.empty_like(table32)
         g_bias = torch.empty_like(bias32)
-        is_bf16 = 1 if qkv.dtype == torch.bfloat16 else 0
+        is_bf16 = _dt_flag(qkv.dtype)
         rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
                                      is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
                                      _ptr(g_bias), 1 if ctx.full_bias_grad else 0, _stream())
@@ -542,15 +568,15 @@ class _MSDAPrepare(torch.autograd.Function):
     def forward(ctx, off, logits, ref, shapes_host):
         lib = _lib.load()
         _need_gpu(off, logits, ref)
-        if off.dtype != logits.dtype or off.dtype not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError('msda_prepare: offsets and logits must both be f32 or both bf16')
+        if off.dtype != logits.dtype or off.dtype not in _ACT_DTYPES:
+            raise MaskBevHipError('msda_prepare: offsets and logits must share one of f32, bf16, fp16')
         off, logits = off.contiguous(), logits.contiguous()
         ref = ref.to(torch.float32).contiguous()
         b, n, h, l, p, _ = off.shape
         host = (ctypes.c_int64 * (2 * l))(*[int(v) for hw in shapes_host for v in hw])
         loc = torch.empty((b, n, h, l, p, 2), dtype=torch.float32, device=off.device)
         attn = torch.empty((b, n, h, l, p), dtype=torch.float32, device=off.device)
-        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logits), 1 if off.dtype == torch.bfloat16 else 0, _ptr(ref), host,
+        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logits), _dt_flag(off.dtype), _ptr(ref), host,
                                        b, n, h, l, p, _ptr(loc), _ptr(attn), _stream()), 'mbv_msda_prepare_fwd')
         ctx.save_for_backward(attn)
         ctx.meta = (host, off.dtype, (b, n, h, l, p), logits.shape)
@@ -566,7 +592,7 @@ class _MSDAPrepare(torch.autograd.Function):
         g_off = torch.empty((b, n, h, l, p, 2), dtype=dt, device=attn.device)
         g_logit = torch.empty(lshape, dtype=dt, device=attn.device)
         check(lib.mbv_msda_prepare_bwd(_ptr(g_loc), _ptr(g_attn), _ptr(attn), host, b, n, h, l, p,
-                                       1 if dt == torch.bfloat16 else 0, _ptr(g_off), _ptr(g_logit), _stream()),
+                                       _dt_flag(dt), _ptr(g_off), _ptr(g_logit), _stream()),
               'mbv_msda_prepare_bwd')
         return g_off, g_logit, None, None
 
@@ -576,7 +602,7 @@ def msda_prepare_supported(num_levels: int, num_points: int) -> bool:
 
 
 def msda_prepare(offsets: torch.Tensor, logits: torch.Tensor, reference_points: torch.Tensor, spatial_shapes):
-    """offsets (B, Nq, H, L, P, 2), logits (B, Nq, H, L*P) (both f32 or both bf16), reference_points (Nq, 2) in
+    """offsets (B, Nq, H, L, P, 2), logits (B, Nq, H, L*P) (one dtype: f32, bf16 or fp16), reference_points (Nq, 2) in
     [0, 1], spatial_shapes [(h, w)] * L  →  sampling locations (B, Nq, H, L, P, 2) f32 and attention weights
     (B, Nq, H, L, P) f32 (softmax over L*P) — K16, include/maskbev_hip.h."""
     host = tuple((int(h), int(w)) for h, w in spatial_shapes)
@@ -612,8 +638,8 @@ class _MSDAQuerySide(torch.autograd.Function):
         b, n, e = x.shape
         d = e // heads
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
-        if dt not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError('msda_query_side supports f32 and bf16 compute')
+        if dt not in _ACT_DTYPES:
+            raise MaskBevHipError('msda_query_side supports f32, bf16 and fp16 compute')
         with torch.autocast('cuda', enabled=False):
             xb = x.to(dt)
             qb = torch.empty(x.shape, dtype=dt, device=x.device)
@@ -626,7 +652,7 @@ class _MSDAQuerySide(torch.autograd.Function):
         ref32 = ref.to(torch.float32).contiguous()
         loc = torch.empty((b, n, heads, levels, points, 2), dtype=torch.float32, device=x.device)
         attn = torch.empty((b, n, heads, levels, points), dtype=torch.float32, device=x.device)
-        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logit), 1 if dt == torch.bfloat16 else 0, _ptr(ref32), host, b, n,
+        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logit), _dt_flag(dt), _ptr(ref32), host, b, n,
                                        heads, levels, points, _ptr(loc), _ptr(attn), _stream()), 'mbv_msda_prepare_fwd')
         out = torch.empty((b, n, e), dtype=torch.float32, device=x.device)
         check(lib.mbv_ms_deform_attn_fwd(_ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, n,
@@ -659,7 +685,7 @@ class _MSDAQuerySide(torch.autograd.Function):
         g[:, :e].copy_(g_value.view(t, e))
         esz = g.element_size()
         check(lib.mbv_msda_prepare_bwd_ld(_ptr(g_loc), _ptr(g_attn), _ptr(attn), host, b, n, heads, levels, points,
-                                          1 if dt == torch.bfloat16 else 0, ctypes.c_void_p(g.data_ptr() + e * esz), width,
+                                          _dt_flag(dt), ctypes.c_void_p(g.data_ptr() + e * esz), width,
                                           ctypes.c_void_p(g.data_ptr() + (e + lo) * esz), width, _stream()),
               'mbv_msda_prepare_bwd_ld')
         wcat = torch.cat([wvc, woc, wac], 0)                              # (width, E)
@@ -918,10 +944,10 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
     """out (N,) f32 += column sums of g2 (T, N) (bf16 or f32) — the bias gradient, in one launch."""
     lib = _lib.load()
     _need_gpu(g2, out)
-    if g2.dtype not in (torch.float32, torch.bfloat16) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise MaskBevHipError('colsum_accum: g2 must be f32/bf16 and out contiguous f32')
+    if g2.dtype not in _ACT_DTYPES or out.dtype != torch.float32 or not out.is_contiguous():
+        raise MaskBevHipError('colsum_accum: g2 must be f32, bf16 or fp16 and out contiguous f32')
     g2 = g2.contiguous()
-    check(lib.mbv_colsum_accum(_ptr(g2), 1 if g2.dtype == torch.bfloat16 else 0, g2.shape[0], g2.shape[1], _ptr(out),
+    check(lib.mbv_colsum_accum(_ptr(g2), _dt_flag(g2.dtype), g2.shape[0], g2.shape[1], _ptr(out),
                                _stream()), 'mbv_colsum_accum')
 
 
@@ -985,8 +1011,8 @@ class _Linear(torch.autograd.Function):
                 bf = None if bias is None else (bias if rows is None else bias[rows[0]:rows[1]])
                 y = gemm16_nt(x2k, w, bf, out_dtype=torch.float32 if f32_out else None)
                 y = y.view(x.shape[:-1] + (w.shape[0],))
-            elif f32_out and x.dtype == torch.bfloat16 and x.is_cuda:
-                # bf16 GEMM with the f32 accumulators stored as f32 (the consumer wants f32: no cast pass)
+            elif f32_out and x.dtype in _LO_DTYPES and x.is_cuda:
+                # 16-bit GEMM with the f32 accumulators stored as f32 (the consumer wants f32: no cast pass)
                 x2 = x.reshape(-1, x.shape[-1])
                 if bias is not None:
                     bf = bias if rows is None else bias[rows[0]:rows[1]]
@@ -1141,8 +1167,8 @@ class _Attention(torch.autograd.Function):
         lib = _lib.load()
         _need_gpu(q, k, v, blocked)
         dt = k.dtype                     # the (large) key / value side decides; q (B*Q rows) is cast to it
-        if dt not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError(f'attention supports f32 and bf16, got {dt}')
+        if dt not in _ACT_DTYPES:
+            raise MaskBevHipError(f'attention supports f32, bf16 and fp16, got {dt}')
         ctx.in_dtypes = (q.dtype, k.dtype, v.dtype)
         q, k, v = q.to(dt).contiguous(), k.contiguous(), v.to(dt).contiguous()
         b, nq, e = q.shape
@@ -1155,7 +1181,7 @@ class _Attention(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
         ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
-        rc = lib.mbv_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), 1 if dt == torch.bfloat16 else 0, b, nq, nl,
+        rc = lib.mbv_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _dt_flag(dt), b, nq, nl,
                               num_heads, d, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
         check(rc, 'mbv_attn_fwd')
         ctx.save_for_backward(q, k, v, mask, out, lse)
@@ -1174,7 +1200,7 @@ class _Attention(torch.autograd.Function):
         g_k = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
         g_v = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
         rc = lib.mbv_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse),
-                              1 if q.dtype == torch.bfloat16 else 0, b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
+                              _dt_flag(q.dtype), b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
                               _ptr(g_v), _stream())
         check(rc, 'mbv_attn_bwd')
         dq, dk, dv = ctx.in_dtypes
@@ -1295,8 +1321,8 @@ class _AttentionSharedKV(torch.autograd.Function):
         k_cat, v_cat = holder.k_cat, holder.v_cat
         _need_gpu(q, k_cat, v_cat, blocked)
         dt = k_cat.dtype
-        if dt not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError(f'attention supports f32 and bf16, got {dt}')
+        if dt not in _ACT_DTYPES:
+            raise MaskBevHipError(f'attention supports f32, bf16 and fp16, got {dt}')
         ctx.q_dtype = q.dtype
         q = q.to(dt).contiguous()
         b, nq, e = q.shape
@@ -1312,7 +1338,7 @@ class _AttentionSharedKV(torch.autograd.Function):
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
         ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
         rc = lib.mbv_attn_fwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
-                                 ld, _ptr(mask), 1 if dt == torch.bfloat16 else 0, b, nq, nl, num_heads, d, _ptr(out),
+                                 ld, _ptr(mask), _dt_flag(dt), b, nq, nl, num_heads, d, _ptr(out),
                                  _ptr(lse), _ptr(ws), ws.numel(), _stream())
         check(rc, 'mbv_attn_fwd_ld')
         ctx.save_for_backward(q, mask, out, lse)
@@ -1334,11 +1360,11 @@ class _AttentionSharedKV(torch.autograd.Function):
         off = slot * e * k_cat.element_size()
         grad_out = grad_out.to(q.dtype).contiguous()
         g_q = torch.empty((b, nq, e), dtype=torch.float32, device=q.device)
-        bf = q.dtype == torch.bfloat16
+        bf = _dt_flag(q.dtype)
         rc = lib.mbv_attn_bwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
-                                 ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), 1 if bf else 0, b, nq, nl, h,
+                                 ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), bf, b, nq, nl, h,
                                  e // h, _ptr(g_q), ctypes.c_void_p(holder.dk_cat.data_ptr() + off),
-                                 ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ld, 1 if bf else 0, _stream())
+                                 ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ld, bf, _stream())
         check(rc, 'mbv_attn_bwd_ld')
         holder.written.add(slot)
         return g_q.to(ctx.q_dtype), None, None, None, None, None
@@ -1368,8 +1394,8 @@ class _MaskLogits(torch.autograd.Function):
         lib = _lib.load()
         _need_gpu(mask_embed, mask_feature)
         dt = mask_feature.dtype
-        if dt not in (torch.float32, torch.bfloat16):
-            raise MaskBevHipError(f'mask_logits supports f32 and bf16, got {dt}')
+        if dt not in _ACT_DTYPES:
+            raise MaskBevHipError(f'mask_logits supports f32, bf16 and fp16, got {dt}')
         e = mask_embed.to(dt).contiguous()
         f = mask_feature.contiguous()
         b, q, c = e.shape
@@ -1380,7 +1406,7 @@ class _MaskLogits(torch.autograd.Function):
                 raise MaskBevHipError('mask_logits: the output slot must be a contiguous f32 (B, Q, H, W) tensor')
         else:
             out = torch.empty((b, q, h, w), dtype=dt, device=f.device)
-        rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), 1 if dt == torch.bfloat16 else 0, b, q, c, h * w, _ptr(out),
+        rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), _dt_flag(dt), b, q, c, h * w, _ptr(out),
                                      1 if out.dtype == torch.float32 else 0, _stream())
         check(rc, 'mbv_mask_logits_fwd')
         ctx.save_for_backward(e, f)
@@ -1435,7 +1461,7 @@ def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_siz
     th, tw = int(target_size[0]), int(target_size[1])
     blocked = torch.empty((b, 1, q, th * tw), dtype=torch.bool, device=logits.device)
     src = logits.detach()
-    rc = lib.mbv_attn_mask_from_logits(_ptr(src), 1 if src.dtype == torch.bfloat16 else 0, b * q, h, w, th, tw,
+    rc = lib.mbv_attn_mask_from_logits(_ptr(src), _dt_flag(src.dtype), b * q, h, w, th, tw,
                                        _ptr(blocked), _stream())
     check(rc, 'mbv_attn_mask_from_logits')
     return logits, blocked
@@ -1674,9 +1700,9 @@ class _AddLayerNorm(torch.autograd.Function):
         _need_gpu(a, b, weight, bias)
         ctx.branch_bias = branch_bias
         c = a.shape[-1]
-        ok = (torch.float32, torch.bfloat16)
+        ok = _ACT_DTYPES
         if a.dtype not in ok or (b is not None and b.dtype not in ok) or out_dtype not in ok:
-            raise MaskBevHipError('add_layernorm supports f32 and bf16 activations')
+            raise MaskBevHipError('add_layernorm supports f32, bf16 and fp16 activations')
         if weight.dtype != torch.float32 or bias.dtype != torch.float32:
             raise MaskBevHipError('add_layernorm: f32 affine parameters')
         a2 = a.contiguous()
@@ -1690,9 +1716,9 @@ class _AddLayerNorm(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=a.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
         w, bb = weight.contiguous(), bias.contiguous()
-        check(lib.mbv_add_layernorm_fwd(_ptr(a2), int(a2.dtype == torch.bfloat16), _ptr(b2),
-                                        int(b2 is not None and b2.dtype == torch.bfloat16), _ptr(w), _ptr(bb), rows, c,
-                                        float(eps), _ptr(s), _ptr(y), int(out_dtype == torch.bfloat16), _ptr(mean),
+        check(lib.mbv_add_layernorm_fwd(_ptr(a2), _dt_flag(a2.dtype), _ptr(b2),
+                                        (_dt_flag(b2.dtype) if b2 is not None else 0), _ptr(w), _ptr(bb), rows, c,
+                                        float(eps), _ptr(s), _ptr(y), _dt_flag(out_dtype), _ptr(mean),
                                         _ptr(rstd), _stream()), 'mbv_add_layernorm_fwd')
         ctx.save_for_backward(a2 if s is None else s, mean, rstd, w)
         ctx.weight, ctx.bias = weight, bias
@@ -1710,7 +1736,7 @@ class _AddLayerNorm(torch.autograd.Function):
             bb = ctx.branch_bias
             if gs is not None and bb is not None:         # the deferred bias gradient of the branch Linear: colsum(gs)
                 g2 = gs.reshape(-1, gs.shape[-1])
-                colsum_accum(g2 if g2.dtype in (torch.float32, torch.bfloat16) else g2.float(), bb.grad)
+                colsum_accum(g2 if g2.dtype in _ACT_DTYPES else g2.float(), bb.grad)
                 _fire_grad_hooks(bb)
             ga = None if gs is None else gs.to(da)
             gb = None if (gs is None or db is None) else gs.to(db)
@@ -1718,15 +1744,15 @@ class _AddLayerNorm(torch.autograd.Function):
         c = s.shape[-1]
         rows = s.numel() // c
         gy = gy.contiguous()
-        if gy.dtype not in (torch.float32, torch.bfloat16):
+        if gy.dtype not in _ACT_DTYPES:
             gy = gy.float()
         if gs is not None:
             gs = gs.contiguous()
-            if gs.dtype not in (torch.float32, torch.bfloat16):
+            if gs.dtype not in _ACT_DTYPES:
                 gs = gs.float()
         dx = torch.empty(s.shape, dtype=torch.float32, device=s.device)
-        want_lo = da == torch.bfloat16 or db == torch.bfloat16
-        dx_lo = torch.empty(s.shape, dtype=torch.bfloat16, device=s.device) if want_lo else None
+        lo = da if da in _LO_DTYPES else (db if db in _LO_DTYPES else None)      # a and b share their 16-bit type
+        dx_lo = torch.empty(s.shape, dtype=lo, device=s.device) if lo is not None else None
         direct = (getattr(weight, '_mbv_arena', False) and getattr(bias, '_mbv_arena', False)
                   and weight.grad is not None and bias.grad is not None
                   and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32)
@@ -1738,9 +1764,10 @@ class _AddLayerNorm(torch.autograd.Function):
         nblk = lib.mbv_add_layernorm_bwd_blocks(rows, c)
         bb = ctx.branch_bias             # arena gradient of the Linear bias that produced b: += colsum(dx)
         ws = torch.empty(max(1, nblk * 3 * c), dtype=torch.float32, device=s.device)
-        check(lib.mbv_add_layernorm_bwd(_ptr(gy), int(gy.dtype == torch.bfloat16), _ptr(gs),
-                                        int(gs is not None and gs.dtype == torch.bfloat16), _ptr(s), _ptr(mean),
-                                        _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo), _ptr(dgamma), _ptr(dbeta),
+        check(lib.mbv_add_layernorm_bwd(_ptr(gy), _dt_flag(gy.dtype), _ptr(gs),
+                                        (_dt_flag(gs.dtype) if gs is not None else 0), _ptr(s), _ptr(mean),
+                                        _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo),
+                                        _dt_flag(lo) if lo is not None else 0, _ptr(dgamma), _ptr(dbeta),
                                         1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws), _stream()),
               'mbv_add_layernorm_bwd')
         # (the branch Linear's own backward, which runs after this one, announces its bias gradient to the hooks)
@@ -1750,8 +1777,8 @@ class _AddLayerNorm(torch.autograd.Function):
             dgamma = dbeta = None
         else:
             dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
-        ga = dx_lo if da == torch.bfloat16 else dx
-        gb = None if db is None else (dx_lo if db == torch.bfloat16 else dx)
+        ga = dx_lo if da in _LO_DTYPES else dx
+        gb = None if db is None else (dx_lo if db in _LO_DTYPES else dx)
         return ga, gb, dgamma, dbeta, None, None, None
 
 
@@ -1774,7 +1801,7 @@ class _BiasAct(torch.autograd.Function):
         ga = ga.to(zc.dtype).contiguous()
         gz = torch.empty_like(zc)
         bias = ctx.bias
-        check(lib.mbv_act_bwd_colsum(_ptr(ga), _ptr(zc), int(zc.dtype == torch.bfloat16), ctx.kind, zc.numel() // n, n,
+        check(lib.mbv_act_bwd_colsum(_ptr(ga), _ptr(zc), _dt_flag(zc.dtype), ctx.kind, zc.numel() // n, n,
                                      _ptr(gz), _ptr(None if bias is None else bias.grad), _stream()),
               'mbv_act_bwd_colsum')
         if bias is not None:
@@ -1787,7 +1814,7 @@ def bias_act(z: torch.Tensor, bias: Optional[torch.Tensor], kind: str) -> torch.
     having been run with ``skip_bias_grad=True``) is given, the backward accumulates its gradient while it computes
     dz.  Falls back to the torch activation for shapes / dtypes the kernel does not take."""
     k = 1 if kind == 'gelu' else 0
-    ok = (z.is_cuda and z.dtype in (torch.float32, torch.bfloat16) and z.shape[-1] % 4 == 0 and z.requires_grad)
+    ok = (z.is_cuda and z.dtype in _ACT_DTYPES and z.shape[-1] % 4 == 0 and z.requires_grad)
     if not ok:
         if bias is not None and z.requires_grad:
             z = accumulate_bias_grad(z, bias)          # the deferred bias gradient must not be lost: dz reaches it here
@@ -1807,7 +1834,7 @@ class _AccumulateBiasGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g2 = g.reshape(-1, g.shape[-1])
-        if g2.dtype not in (torch.float32, torch.bfloat16):
+        if g2.dtype not in _ACT_DTYPES:
             g2 = g2.float()
         colsum_accum(g2, ctx.bias.grad)
         _fire_grad_hooks(ctx.bias)

@@ -45,7 +45,8 @@ def test_flat_adam_matches_torch(device, decoupled):
 
 
 @pytest.mark.parametrize('T,N,dt', [(400, 256, torch.bfloat16), (65536, 384, torch.bfloat16), (1000, 2, torch.float32),
-                                    (777, 131, torch.bfloat16), (5000, 1024, torch.float32)])
+                                    (777, 131, torch.bfloat16), (5000, 1024, torch.float32), (65536, 384, torch.float16),
+                                    (777, 131, torch.float16)])
 def test_colsum_accum(device, T, N, dt):
     from mask_bev_amd import ops
     g = torch.randn(T, N, device=device).to(dt)
@@ -178,7 +179,7 @@ def test_wgrad_small_f32(device, T, O, I):
     assert torch.allclose(bacc.double(), bwant, rtol=1e-5, atol=2e-5 * T ** 0.5)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
 def test_arena_gradients_equal_plain_autograd(device, dtype):
     """Every direct-accumulation path at once (Linear dW / db incl. the small-token kernel, the bias gradients
     deferred to K12, K12's and K3's affine gradients): a flattened module and a plain one with the same weights,
@@ -200,10 +201,11 @@ def test_arena_gradients_equal_plain_autograd(device, dtype):
     scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
     labels, gt = random_gt(kw, 2, 3, seed=10)
     batch = (scans, (labels.to(device), gt.to(device)))
+    ls = 1024.0 if dtype == 'fp16' else 1.0           # fp16: a fixed loss scale on both sides keeps gradients normal
     l0 = plain.training_step(batch, 0)
-    l0.backward()
+    (l0 * ls).backward()
     l1 = flat.training_step(batch, 0)
-    l1.backward()
+    (l1 * ls).backward()
     tol = 2e-4 if dtype == 'fp32' else 4e-2
     assert abs(float(l0) - float(l1)) <= tol * abs(float(l0))
     worst = []
@@ -219,7 +221,7 @@ def test_arena_gradients_equal_plain_autograd(device, dtype):
 
 
 @pytest.mark.parametrize('kind', ['gelu', 'relu'])
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 def test_bias_act_backward(device, kind, dt):
     """Fused activation backward + bias column sums vs torch."""
     from mask_bev_amd import ops
@@ -234,7 +236,7 @@ def test_bias_act_backward(device, kind, dt):
     zr = z.detach().double().requires_grad_()
     yr = torch.nn.functional.gelu(zr) if kind == 'gelu' else torch.relu(zr)
     yr.backward(go.double())
-    tol = 1e-5 if dt == torch.float32 else 2e-2
+    tol = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dt]
     assert torch.allclose(y.double(), yr, rtol=tol, atol=tol)
     assert torch.allclose(z.grad.double(), zr.grad, rtol=tol, atol=tol)
     # column sums of the f64 reference gradient (the kernel sums its f32 values before they are rounded to bf16)

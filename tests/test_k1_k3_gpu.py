@@ -148,7 +148,8 @@ def test_scatter_layernorm_fwd_bwd(device, nx, ny, C, sizes):
 @pytest.mark.gpu
 @pytest.mark.parametrize('nx,ny,C,sizes', [(64, 64, 32, [3000, 2000]), (52, 40, 64, [500]), (512, 8, 32, [900, 10, 0]),
                                            (300, 12, 32, [2000, 1500])])
-def test_scatter_layernorm_patch_tokens(device, nx, ny, C, sizes):
+@pytest.mark.parametrize('lo', [torch.bfloat16, torch.float16])
+def test_scatter_layernorm_patch_tokens(device, nx, ny, C, sizes, lo):
     """K3 patch-token layout (bf16 rows of the backbone's 4 x 4 patch projection) vs the oracle's dense scatter +
     F.layer_norm: the forward values are the bf16 rounding of the f32 map (<= 1 bf16 ulp of the f32 reference), and
     a gradient arriving in the same layout gives the gradients of the NCHW path (rtol 1e-4 / atol 2e-5)."""
@@ -161,21 +162,23 @@ def test_scatter_layernorm_patch_tokens(device, nx, ny, C, sizes):
     feats = torch.randn(pil.num_pillars, C, generator=g)
     w = 1 + 0.1 * torch.randn(C, ny, nx, generator=g)
     b = 0.1 * torch.randn(C, ny, nx, generator=g)
-    go = torch.randn(B, C, ny, nx, generator=g).bfloat16()                     # what the bf16 dgrad GEMM would hand back
+    go = torch.randn(B, C, ny, nx, generator=g).to(lo)                         # what the 16-bit dgrad GEMM would hand back
     f_ref, w_ref, b_ref = feats.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
     canvas = O.scatter_to_canvas(cfg, f_ref, rc, B)
     out_ref = torch.nn.functional.layer_norm(canvas, [C, ny, nx], w_ref, b_ref, 1e-3)
     out_ref.backward(go.float())
     f_d, w_d, b_d = (t.clone().to(device).requires_grad_() for t in (feats, w, b))
     assert ops.patch_layout_supported(C, ny, nx, 4)
-    tok = ops.scatter_layernorm(f_d, w_d, b_d, pil, B, ny, nx, 1e-3, patch=4)
-    assert isinstance(tok, ops.PatchTokens) and tok.rows.dtype == torch.bfloat16
+    with torch.autocast('cuda', dtype=lo):               # the patch rows take the 16-bit type of the autocast region
+        tok = ops.scatter_layernorm(f_d, w_d, b_d, pil, B, ny, nx, 1e-3, patch=4)
+    assert isinstance(tok, ops.PatchTokens) and tok.rows.dtype == lo
     assert tuple(tok.rows.shape) == (B, ny // 4, nx // 4, 16 * C)
     # forward: identical to rounding the f32 NCHW result of the same kernel family, and within bf16 of the oracle
     with torch.no_grad():
         img32 = ops.scatter_layernorm(f_d, w_d, b_d, pil, B, ny, nx, 1e-3)
-    assert torch.equal(tok.to_image(), img32.bfloat16())
-    torch.testing.assert_close(tok.to_image().float().cpu(), out_ref.detach(), rtol=8e-3, atol=1e-5)
+    assert torch.equal(tok.to_image(), img32.to(lo))
+    torch.testing.assert_close(tok.to_image().float().cpu(), out_ref.detach(),
+                               rtol=8e-3 if lo == torch.bfloat16 else 1e-3, atol=1e-5)
     # backward: the gradient in patch layout, element (y%4)*4C + c*4 + x%4 of row (b, y/4, x/4)
     go_rows = go.view(B, C, ny // 4, 4, nx // 4, 4).permute(0, 2, 4, 3, 1, 5).reshape(B, ny // 4, nx // 4, 16 * C)
     tok.rows.backward(go_rows.contiguous().to(device))

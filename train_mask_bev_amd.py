@@ -175,8 +175,7 @@ def main(argv=None):
 
     model = MaskBevModule.from_config(config, checkpoint_folder_path).to(device)
     model.log_scalars = False
-    if config.get('compute_dtype', 'fp32') != 'fp16':
-        model.flatten_parameters()
+    model.flatten_parameters()         # fp16 compute: this also creates the device-side loss scaler
     opt_cfg = model.configure_optimizers()
     optimizer, scheduler = opt_cfg['optimizer'], opt_cfg['lr_scheduler']
 
@@ -232,7 +231,7 @@ def main(argv=None):
                     if reducer is not None:
                         reducer.sync_buffers()
                     loss = model.training_step(batch, i)
-                    loss.backward()
+                    model.scale_loss(loss).backward()
                     if reducer is not None:
                         reducer.finish(optimizer)
                     optimizer.step()
