@@ -190,7 +190,14 @@ def kernel_profile(model, opt, batch, steps: int = 2):
     out = {}
     for k, e in agg.items():
         n = e['launches']
-        out[k] = dict(kernel=k, bound=e['bound'], launches_per_step=n / steps, avg_ms=e['ms'] / n,
+        bound = e['bound']
+        if bound == 'mfma':
+            # a GEMM family spans shapes on both sides of the ridge (the 65 536-token weight gradients stream 100 MB
+            # for 14 GFLOP): the family is priced against the roofline that bounds MORE of its launches' ideal time
+            t_hbm = e['bytes'] / (workmodel.HBM_PEAK_GBS * 1e9)
+            t_mfma = e['flops'] / (workmodel.MFMA_BF16_TFLOPS * 1e12)
+            bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
+        out[k] = dict(kernel=k, bound=bound, launches_per_step=n / steps, avg_ms=e['ms'] / n,
                       total_ms_per_step=e['ms'] / steps, algorithmic_bytes=e['bytes'] / n,
                       algorithmic_flops=e['flops'] / n)
     return out

@@ -68,13 +68,13 @@ __device__ __forceinline__ BlockId decode_block(const WinGeom& g) {
   return r;
 }
 
-// Stage `part` (0 q, 1 k, 2 v) of this (window, head) into a [token][d] image and/or a [d][token] image.
+// Stage one operand (q, k, v or dO) of this (window, head) into a padded-row [token][d] image (the f32 path).
 // Padded tokens take the qkv bias (swin.py:185-188 pads zeros after LayerNorm => qkv == bias).
 template <bool BF16, int D, typename TIn>
 __device__ __forceinline__ void stage_part(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
                                            const TIn* __restrict__ src, int src_row_stride, int src_col,
                                            const float* __restrict__ pad_vec /* may be null -> zeros */,
-                                           typename Lay<BF16, D>::T* row_img, typename Lay<BF16, D>::T* t_img) {
+                                           typename Lay<BF16, D>::T* row_img) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
   constexpr int CH = D / 8;   // 8-element chunks per token
@@ -95,31 +95,100 @@ __device__ __forceinline__ void stage_part(const WinGeom& g, const BlockId& id, 
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
-    if (row_img) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) row_img[t * L::RS + c8 + j] = (T)v[j];
-    }
-    if (t_img) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t_img[(c8 + j) * L::TS + t] = (T)v[j];
-    }
+    for (int j = 0; j < 8; ++j) row_img[t * L::RS + c8 + j] = (T)v[j];
   }
 }
 
-template <bool BF16, int D>
-__device__ __forceinline__ void zero_t_tail(typename Lay<BF16, D>::T* t_img) {
-  using L = Lay<BF16, D>;
-  if constexpr (L::TROWS > D) {
-    for (int idx = threadIdx.x; idx < (L::TROWS - D) * L::TS; idx += blockDim.x)
-      t_img[D * L::TS + idx] = (typename L::T)0.f;
+// ---- 16-bit LDS images without padding or transposed copies -----------------------------------------------------
+// A [token][d] image of a 16-bit operand is NPAD rows of exactly D elements; the 16-byte chunk c of row r sits at
+// chunk c ^ ((r >> SH) & (D/8 - 1)), which makes the 16-byte MFMA operand reads of 16 consecutive rows hit 16
+// different bank groups (the padded rows of mfma_tiles.hpp did the same at 12 % more LDS).  The [d][token] operand
+// of the `X^T . M` products (P V, dS K, P^T dO, dS^T Q) is read from the SAME image with gfx950's transposing LDS
+// read (`ds_read_b64_tr_b16`: a 16-lane group fetches a 4 x 16 block row-wise and receives it column-wise), so the
+// transposed copies that the staging pass used to scatter into LDS two bytes at a time are gone: the backward's LDS
+// footprint drops from 135 KB to 76 KB at D = 64 — two workgroups per CU instead of one — and the forward's to 52 KB
+// (three instead of two).
+template <int D>
+struct Swz {
+  static constexpr int CH = D / 8;                                  // 16-byte chunks per row
+  static constexpr int SH = D >= 64 ? 1 : (D == 32 ? 2 : 3);        // rows that share a swizzle value
+  static constexpr int IMG = NPAD * D + 64;                         // + slack: at D = 16 a transposed read of the last
+                                                                    //   rows runs 16 (discarded) columns past the image
+  static __device__ __forceinline__ int chunk_off(int row, int c) {  // element offset of chunk c of `row`
+    return row * D + ((c ^ ((row >> SH) & (CH - 1))) << 3);
+  }
+};
+
+// acc(32x32) += A[a0 + r][:] . B[b0 + r][:]^T over d, both swizzled [token][d] images (cf. mbv_tiles::mma_rows)
+template <int D>
+__device__ __forceinline__ void mma_rows_swz(const lo16_t* __restrict__ a_img, int a0, const lo16_t* __restrict__ b_img,
+                                             int b0, f32x16& acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_img + Swz<D>::chunk_off(a0 + r, 2 * ks + h));
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(b_img + Swz<D>::chunk_off(b0 + r, 2 * ks + h));
+    acc = mfma16(a, b, acc);
+  }
+}
+
+// out(32 x 32 cols [cb]) += X^T . M  (cf. mbv_tiles::mma_acc_operand): X an accumulator tile whose rows are the
+// contraction index k0 + acc_row(i, h); M the swizzled [token][d] image, read column-wise by the transposing load.
+// Lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p + 3 of a 4 x 16 block and receives column
+// (lane & 15) of it; the groups cover column halves ((lane >> 4) & 1) and row halves (h) of the MFMA B operand, whose
+// element j of half h is contraction index 16 s + 8 (j >> 2) + 4 h + (j & 3) — two reads, rows +0..3 and +8..11.
+template <int D>
+__device__ __forceinline__ void mma_acc_tr(const f32x16& x, const lo16_t* __restrict__ m_img, int k0, int cb,
+                                           f32x16& out) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  const int c = 4 * cb + 2 * ((lane >> 4) & 1) + (p >> 1);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (lo16_t)x[8 * s + j];
+    const int row0 = k0 + 16 * s + 4 * h + q;
+    const lo16_t* p0 = m_img + Swz<D>::chunk_off(row0, c) + 4 * (p & 1);
+    const lo16_t* p1 = m_img + Swz<D>::chunk_off(row0 + 8, c) + 4 * (p & 1);
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p0);
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p1);
+    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    out = mfma16(a, __builtin_bit_cast(bf16x8, t), out);
+  }
+}
+
+// scalar staging of one operand into a swizzled image (tensors that are not 16-byte aligned or C % 8 != 0)
+template <int D, typename TIn>
+__device__ __forceinline__ void stage_part_swz(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
+                                               const TIn* __restrict__ src, int src_row_stride, int src_col,
+                                               const float* __restrict__ pad_vec, lo16_t* img) {
+  constexpr int CH = D / 8;
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c = idx - t * CH;
+    lo16_t* dst = img + Swz<D>::chunk_off(t, c);
+    const int pix = t < g.N ? pix_lds[t] : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (t < g.N) {
+        if (pix >= 0) v = to_f(src[((int64_t)id.b * g.H * g.W + pix) * src_row_stride + src_col + 8 * c + j]);
+        else if (pad_vec) v = pad_vec[src_col + 8 * c + j];
+      }
+      dst[j] = (lo16_t)v;
+    }
   }
 }
 
 // ---- fused staging for bf16 activations -------------------------------------------------------------------
 // One pass over the (token, 8-channel chunk) items of a window: ALL the 16-byte global loads an item needs (q, k, v
-// and, in the backward, dO and O) are issued together, then written to the LDS images with 16-byte row stores and
-// scattered 2-byte transposed stores.  The per-part form above pays one dependent HBM round trip per part and
-// loop iteration (≈ 9 in the backward); this is one or two.  Requires C % 8 == 0 and 16-byte aligned tensors.
+// and, in the backward, dO and O) are issued together, then written to the swizzled LDS images with 16-byte stores.
+// The per-part form pays one dependent HBM round trip per part and loop iteration (≈ 9 in the backward); this is
+// one or two.  Requires C % 8 == 0 and 16-byte aligned tensors.
 union Pack8 {
   uint4 u;
   lo16_t h[8];
@@ -134,18 +203,13 @@ __device__ __forceinline__ Pack8 pad_pack(const float* __restrict__ vec, int c) 
 
 template <int D>
 __device__ __forceinline__ void put_row(lo16_t* img, int t, int c8, const Pack8& p) {
-  *reinterpret_cast<uint4*>(img + t * Lay<true, D>::RS + c8) = p.u;
-}
-template <int D>
-__device__ __forceinline__ void put_t(lo16_t* img, int t, int c8, const Pack8& p) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) img[(c8 + j) * Lay<true, D>::TS + t] = p.h[j];
+  *reinterpret_cast<uint4*>(img + Swz<D>::chunk_off(t, c8 >> 3)) = p.u;
 }
 
 template <int D>
 __device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
                                                const lo16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                               int col, lo16_t* q_img, lo16_t* k_img, lo16_t* vt_img) {
+                                               int col, lo16_t* q_img, lo16_t* k_img, lo16_t* v_img) {
   constexpr int CH = D / 8;
   const int C3 = 3 * g.C;
   for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
@@ -167,7 +231,7 @@ __device__ __forceinline__ void stage_fwd_bf16(const WinGeom& g, const BlockId& 
     }
     put_row<D>(q_img, t, c8, q);
     put_row<D>(k_img, t, c8, k);
-    put_t<D>(vt_img, t, c8, v);
+    put_row<D>(v_img, t, c8, v);
   }
 }
 
@@ -175,8 +239,8 @@ template <int D>
 __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
                                                const lo16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                const lo16_t* __restrict__ out, const lo16_t* __restrict__ grad_out,
-                                               int col, lo16_t* q_img, lo16_t* qt_img, lo16_t* k_img, lo16_t* kt_img,
-                                               lo16_t* v_img, lo16_t* do_img, lo16_t* dot_img, double* delta_s) {
+                                               int col, lo16_t* q_img, lo16_t* k_img, lo16_t* v_img, lo16_t* do_img,
+                                               double* delta_s) {
   constexpr int CH = D / 8;
   const int C3 = 3 * g.C;
 #pragma unroll 2
@@ -206,9 +270,6 @@ __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& 
     put_row<D>(k_img, t, c8, k);
     put_row<D>(v_img, t, c8, v);
     put_row<D>(do_img, t, c8, d);
-    put_t<D>(qt_img, t, c8, q);
-    put_t<D>(kt_img, t, c8, k);
-    put_t<D>(dot_img, t, c8, d);
     if (real) {                     // delta[q] = sum_d dO[q][d] * O[q][d]
       float acc = 0.f;
 #pragma unroll
@@ -218,16 +279,22 @@ __device__ __forceinline__ void stage_bwd_bf16(const WinGeom& g, const BlockId& 
   }
 }
 
-// additive bias + shift mask for (query q, key k); kinfo packs (ty | tx << 8 | label << 16) per token
-__device__ __forceinline__ float bias_mask(const float* __restrict__ tbl, const int* __restrict__ kinfo, int ws,
-                                           int q, int k, int* idx_out) {
-  const int qi = kinfo[q], ki = kinfo[k];
-  const int dy = (qi & 0xff) - (ki & 0xff) + ws - 1;
-  const int dx = ((qi >> 8) & 0xff) - ((ki >> 8) & 0xff) + ws - 1;
-  const int idx = dy * (2 * ws - 1) + dx;
+// Additive relative-position bias + shift mask of (query, key), in log2 units.  Per token the LDS table `kinfo` holds
+// lin = ty (2 ws - 1) + tx in its low half and the shifted-window region label in its high half: the bias-table index
+// of a pair is lin(q) - lin(k) + (ws - 1) 2 ws — one subtraction per element instead of unpacking both coordinates —
+// and the labels differ iff (qi ^ ki) has a high bit.  `tbl` is staged pre-multiplied by log2(e), so that a
+// probability is ONE v_exp_f32 of an FMA: p = exp2(s * (scale log2 e) + bias2 - lse2).
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+constexpr float kMask2 = -100.0f * kLog2e;                     // swin.py:216: masked pairs get -100
+__device__ __forceinline__ int token_info(const WinGeom& g, const BlockId& id, int t) {
+  const int ty = t / g.ws, tx = t - ty * g.ws;
+  return (ty * (2 * g.ws - 1) + tx) | (region_label(g, id.wy, id.wx, t) << 16);
+}
+__device__ __forceinline__ float bias_mask2(const float* __restrict__ tbl, int qi, int ki, int idx0, int* idx_out) {
+  const int idx = (qi & 0xffff) - (ki & 0xffff) + idx0;
   if (idx_out) *idx_out = idx;
   float v = tbl[idx];
-  if ((qi >> 16) != (ki >> 16)) v += -100.0f;
+  if ((qi ^ ki) >> 16) v += kMask2;
   return v;
 }
 
@@ -241,19 +308,19 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
                                                          TIn* __restrict__ out, float* __restrict__ lse) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
-  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T v_img[BF16 ? L::T_IMG : L::ROW_IMG];
+  constexpr int IMG = BF16 ? Swz<D>::IMG : L::ROW_IMG;      // 16-bit: swizzled, unpadded; f32: padded rows
+  __shared__ __attribute__((aligned(16))) T k_img[IMG];
+  __shared__ __attribute__((aligned(16))) T q_img[IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[IMG];
   __shared__ float tbl[21 * 21];
   __shared__ int kinfo[NPAD];
   __shared__ int pix[NPAD];
   const BlockId id = decode_block(g);
   const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
-  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tbl[i] = bias_table[i * g.heads + id.head];
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tbl[i] = bias_table[i * g.heads + id.head] * kLog2e;
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     if (t < g.N) {
-      const int ty = t / g.ws, tx = t - ty * g.ws;
-      kinfo[t] = ty | (tx << 8) | (region_label(g, id.wy, id.wx, t) << 16);
+      kinfo[t] = token_info(g, id, t);
       pix[t] = token_pixel(g, id.wy, id.wx, t);
     } else {
       kinfo[t] = 0;
@@ -268,19 +335,17 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
     if (vec_ok) {
       fused = true;
       stage_fwd_bf16<D>(g, id, pix, qkv, qkv_bias, col, q_img, k_img, v_img);
-      zero_t_tail<BF16, D>(v_img);
     }
   }
   if (fused) {
   } else if constexpr (BF16) {
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, nullptr, v_img);
-    zero_t_tail<BF16, D>(v_img);
+    stage_part_swz<D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img);
+    stage_part_swz<D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img);
+    stage_part_swz<D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img);
   } else {
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img);
+    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img);
   }
   __syncthreads();
 
@@ -293,16 +358,27 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
 #pragma unroll
   for (int kb = 0; kb < NBLK; ++kb) {
     s[kb] = zero16();
-    if (kb < nblk) mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+    if (kb < nblk) {
+      if constexpr (BF16) mma_rows_swz<D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+      else mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+    }
   }
+  // scores in log2 units: v = s (scale log2 e) + bias2
+  const float sl2 = scale * kLog2e;
+  const int idx0 = (g.ws - 1) * 2 * g.ws;
+  const int qi = kinfo[q];
   float m = -INFINITY;
 #pragma unroll
   for (int kb = 0; kb < NBLK; ++kb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      // branch-free: every lane evaluates its element (kinfo / tbl hold valid entries for all NPAD tokens), padded
+      // keys are then set to -inf — the 16 elements' LDS reads of a tile are issued together, not one dependent
+      // chain per exec-masked block
       const int k = 32 * kb + acc_row(i, h);
-      float v = -INFINITY;
-      if (kb < nblk && k < g.N) v = (q < g.N) ? s[kb][i] * scale + bias_mask(tbl, kinfo, g.ws, q, k, nullptr) : 0.f;
+      float v = fmaf(s[kb][i], sl2, bias_mask2(tbl, qi, kinfo[k], idx0, nullptr));
+      v = (q < g.N) ? v : 0.f;
+      v = (kb < nblk && k < g.N) ? v : -INFINITY;
       s[kb][i] = v;
       m = fmaxf(m, v);
     }
@@ -313,7 +389,7 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
   for (int kb = 0; kb < NBLK; ++kb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float p = __expf(s[kb][i] - m);     // exp(-inf) = 0 for padded keys
+      const float p = __builtin_amdgcn_exp2f(s[kb][i] - m);     // exp2(-inf) = 0 for padded keys
       s[kb][i] = p;
       sum += p;
     }
@@ -324,7 +400,7 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
   for (int kb = 0; kb < NBLK; ++kb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[kb][i] *= inv;
-  if (h == 0 && q < g.N) lse[(int64_t)blockIdx.x * NPAD + q] = m + __logf(sum);
+  if (h == 0 && q < g.N) lse[(int64_t)blockIdx.x * NPAD + q] = (m + __log2f(sum)) * kLn2;     // natural-log units
 
   // O = P V : rows = queries (accumulator registers), cols = d (lanes)
   constexpr int NCB = (D + 31) / 32;
@@ -334,7 +410,10 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
     o[cb] = zero16();
 #pragma unroll
     for (int kb = 0; kb < NBLK; ++kb)
-      if (kb < nblk) mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o[cb]);
+      if (kb < nblk) {
+        if constexpr (BF16) mma_acc_tr<D>(s[kb], v_img, 32 * kb, cb, o[cb]);
+        else mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o[cb]);
+      }
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
@@ -355,11 +434,11 @@ __global__ void __launch_bounds__(256) k_window_attn_fwd(const TIn* __restrict__
 // backward
 // ---------------------------------------------------------------------------------------------
 // 512 threads: waves 0-3 own the query blocks (dS^T tiles → bias-table gradient, dQ) while waves 4-7 own the key
-// blocks (dK, dV) — the two halves of the backward share the staged LDS images and run side by side (the LDS
-// footprint, ≈ 125 KB in bf16 at D = 64, allows one workgroup per CU, so the second half would otherwise wait for
-// the first with four waves on the CU).
+// blocks (dK, dV) — the two halves of the backward share the staged LDS images and run side by side.  16-bit: four
+// swizzled images (q, k, v, dO; 76 KB at D = 64) and ≤ 128 VGPRs, so two workgroups share a CU and one's staging
+// overlaps the other's MFMA phase.
 template <bool BF16, int D, typename TIn>
-__global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__ qkv,
+__global__ void __launch_bounds__(512, (BF16 ? 4 : 2)) k_window_attn_bwd(const TIn* __restrict__ qkv,
                                                          const float* __restrict__ qkv_bias,
                                                          const float* __restrict__ bias_table,
                                                          const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
@@ -368,19 +447,18 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
                                                          float* __restrict__ grad_pad /* (3C) */, int full_bias) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
-  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T v_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T do_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T kt_img[BF16 ? L::T_IMG : 1];
-  __shared__ __attribute__((aligned(16))) T qt_img[BF16 ? L::T_IMG : 1];
-  __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
+  constexpr int IMG = BF16 ? Swz<D>::IMG : L::ROW_IMG;
+  __shared__ __attribute__((aligned(16))) T q_img[IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[IMG];
+  __shared__ __attribute__((aligned(16))) T do_img[IMG];
   __shared__ float tbl[21 * 21];
   __shared__ double dtbl[21 * 21];     // f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   __shared__ int kinfo[NPAD];
   __shared__ int pix[NPAD];
   __shared__ float lse_s[NPAD];
   __shared__ double delta_s[NPAD];
+  __shared__ float2 ld_s[NPAD];        // (lse log2 e, delta) per query, f32: what the element loops read
   // column sums of dQ / dK / dV of this (window, head): the qkv-bias gradient.  Padded tokens always contribute (their
   // q, k, v ARE the bias); with full_bias the real tokens do too, which is the bias gradient of the qkv Linear itself
   // — that layer then skips its own pass over grad_qkv.
@@ -388,14 +466,13 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   const BlockId id = decode_block(g);
   const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
   for (int i = threadIdx.x; i < tsz; i += blockDim.x) {
-    tbl[i] = bias_table[i * g.heads + id.head];
+    tbl[i] = bias_table[i * g.heads + id.head] * kLog2e;
     dtbl[i] = 0.0;
   }
   for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) colacc[i] = 0.0;
   for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
     if (t < g.N) {
-      const int ty = t / g.ws, tx = t - ty * g.ws;
-      kinfo[t] = ty | (tx << 8) | (region_label(g, id.wy, id.wx, t) << 16);
+      kinfo[t] = token_info(g, id, t);
       pix[t] = token_pixel(g, id.wy, id.wx, t);
       lse_s[t] = lse[(int64_t)blockIdx.x * NPAD + t];
     } else {
@@ -411,23 +488,21 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
   if constexpr (BF16 && std::is_same_v<TIn, lo16_t>) {
     if (g.vec_ok) {
       fused = true;
-      stage_bwd_bf16<D>(g, id, pix, qkv, qkv_bias, out, grad_out, col, q_img, qt_img, k_img, kt_img, v_img, do_img,
-                        dot_img, delta_s);
-      zero_t_tail<BF16, D>(qt_img);
-      zero_t_tail<BF16, D>(kt_img);
-      zero_t_tail<BF16, D>(dot_img);
+      stage_bwd_bf16<D>(g, id, pix, qkv, qkv_bias, out, grad_out, col, q_img, k_img, v_img, do_img, delta_s);
     }
   }
   if (!fused) {
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img, BF16 ? qt_img : nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img, BF16 ? kt_img : nullptr);
-    stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img, nullptr);
     // dO is zero on padded tokens (the reference crops them away, swin.py:247-248)
-    stage_part<BF16, D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img, BF16 ? dot_img : nullptr);
     if constexpr (BF16) {
-      zero_t_tail<BF16, D>(qt_img);
-      zero_t_tail<BF16, D>(kt_img);
-      zero_t_tail<BF16, D>(dot_img);
+      stage_part_swz<D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img);
+      stage_part_swz<D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img);
+      stage_part_swz<D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img);
+      stage_part_swz<D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img);
+    } else {
+      stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, col, qkv_bias, q_img);
+      stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, g.C + col, qkv_bias, k_img);
+      stage_part<BF16, D, TIn>(g, id, pix, qkv, C3, 2 * g.C + col, qkv_bias, v_img);
+      stage_part<BF16, D, TIn>(g, id, pix, grad_out, g.C, col, nullptr, do_img);
     }
     // delta[q] = sum_d dO[q][d] * O[q][d]
     constexpr int CH = D / 8;
@@ -443,17 +518,22 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
     }
   }
   __syncthreads();
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) ld_s[t] = make_float2(lse_s[t] * kLog2e, (float)delta_s[t]);
+  __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = threadIdx.x >> 8;
   const int r = lane & 31, h = lane >> 5;
   const int nblk = (g.N + 31) / 32;
   constexpr int NCB = (D + 31) / 32;
   const int64_t row0 = (int64_t)id.b * g.H * g.W;
+  const float sl2 = scale * kLog2e;
+  const int idx0 = (g.ws - 1) * 2 * g.ws;
 
   if (wave < nblk && part == 0) {
     // ---- part 1: lane = query.  dS^T tiles, relative-position-bias gradient, dQ
     const int q = 32 * wave + r;
-    const float my_lse = lse_s[q], my_delta = (float)delta_s[q];
+    const float my_lse2 = ld_s[q].x, my_delta = ld_s[q].y;
+    const int qi = kinfo[q];
     f32x16 dq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
@@ -461,23 +541,33 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
     for (int kb = 0; kb < NBLK; ++kb) {
       if (kb >= nblk) continue;
       f32x16 s = zero16(), dp = zero16();
-      mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
-      mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = 32 * kb + acc_row(i, h);
-        float ds = 0.f;
-        if (q < g.N && k < g.N) {
-          int idx;
-          const float bm = bias_mask(tbl, kinfo, g.ws, q, k, &idx);
-          const float p = __expf(s[i] * scale + bm - my_lse);
-          ds = p * (dp[i] - my_delta);
-          atomicAdd(&dtbl[idx], (double)ds);
-        }
-        s[i] = ds * scale;                       // dQ = scale * dS K
+      if constexpr (BF16) {
+        mma_rows_swz<D>(k_img, 32 * kb, q_img, 32 * wave, s);
+        mma_rows_swz<D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+      } else {
+        mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
+        mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
       }
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) mma_acc_operand<BF16, D>(s, BF16 ? kt_img : k_img, 32 * kb, cb, dq[cb]);
+      for (int i = 0; i < 16; ++i) {
+        // branch-free up to the atomic (see the forward): padded pairs contribute ds = 0
+        const int k = 32 * kb + acc_row(i, h);
+        int idx;
+        const float bm = bias_mask2(tbl, qi, kinfo[k], idx0, &idx);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, bm - my_lse2));
+        const bool valid = q < g.N && k < g.N;
+        const float ds = valid ? p * (dp[i] - my_delta) : 0.f;
+        if (valid) atomicAdd(&dtbl[idx], (double)ds);      // 100 x 100 of the 128 x 128 pairs: the LDS-atomic pipe is the
+                                                           // busiest unit of this kernel, padded pairs stay off it
+        s[i] = ds * scale;                       // dQ = scale * dS K
+        // four elements' LDS chains in flight are enough; without the fence the scheduler hoists all 16 and spills
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        if constexpr (BF16) mma_acc_tr<D>(s, k_img, 32 * kb, cb, dq[cb]);
+        else mma_acc_operand<BF16, D>(s, k_img, 32 * kb, cb, dq[cb]);
+      }
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -503,28 +593,38 @@ __global__ void __launch_bounds__(512) k_window_attn_bwd(const TIn* __restrict__
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
     const int k = 32 * kb + r;                   // this lane's key (column of the un-swapped tiles)
+    const int ki = kinfo[k];
 #pragma unroll
     for (int qb = 0; qb < NBLK; ++qb) {
       if (qb >= nblk) continue;
       f32x16 s = zero16(), dp = zero16();
-      mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);       // rows = queries, cols = keys
-      mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      if constexpr (BF16) {
+        mma_rows_swz<D>(q_img, 32 * qb, k_img, 32 * kb, s);       // rows = queries, cols = keys
+        mma_rows_swz<D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      } else {
+        mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);
+        mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      }
       f32x16 ds;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qq = 32 * qb + acc_row(i, h);
-        float p = 0.f, d = 0.f;
-        if (qq < g.N && k < g.N) {
-          p = __expf(s[i] * scale + bias_mask(tbl, kinfo, g.ws, qq, k, nullptr) - lse_s[qq]);
-          d = p * (dp[i] - (float)delta_s[qq]) * scale;
-        }
+        const float2 ld = ld_s[qq];
+        float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, bias_mask2(tbl, kinfo[qq], ki, idx0, nullptr) - ld.x));
+        p = (qq < g.N && k < g.N) ? p : 0.f;
         s[i] = p;
-        ds[i] = d;
+        ds[i] = p * (dp[i] - ld.y) * scale;
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        mma_acc_operand<BF16, D>(s, BF16 ? dot_img : do_img, 32 * qb, cb, dv[cb]);    // dV = P^T dO
-        mma_acc_operand<BF16, D>(ds, BF16 ? qt_img : q_img, 32 * qb, cb, dk[cb]);     // dK = scale dS^T Q
+        if constexpr (BF16) {
+          mma_acc_tr<D>(s, do_img, 32 * qb, cb, dv[cb]);                              // dV = P^T dO
+          mma_acc_tr<D>(ds, q_img, 32 * qb, cb, dk[cb]);                              // dK = scale dS^T Q
+        } else {
+          mma_acc_operand<BF16, D>(s, do_img, 32 * qb, cb, dv[cb]);
+          mma_acc_operand<BF16, D>(ds, q_img, 32 * qb, cb, dk[cb]);
+        }
       }
     }
 #pragma unroll

@@ -10,10 +10,11 @@ import yaml
 pytestmark = pytest.mark.gpu
 
 
-def test_launcher_trains_two_steps_on_synthetic_data(tmp_path, capsys):
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_launcher_trains_two_steps_on_synthetic_data(tmp_path, capsys, dtype):
     import train_mask_bev_amd as launcher
     from mask_bev_amd import synthetic
-    kw = dict(synthetic.module_kwargs('smoke_96', 2, compute_dtype='bf16'), dataset='synthetic',
+    kw = dict(synthetic.module_kwargs('smoke_96', 2, compute_dtype=dtype), dataset='synthetic',
               synthetic_points=6000, limit_val_batches=0.0, x_range=[-12, 12], y_range=[-12, 12], z_range=[-3, 1])
     cfg = tmp_path / 'smoke_96.yml'
     cfg.write_text(yaml.safe_dump(kw))
@@ -28,6 +29,8 @@ def test_launcher_trains_two_steps_on_synthetic_data(tmp_path, capsys):
     assert 'last.ckpt' in files and any(re.match(r'smoke_96-epoch=\d\d-train_loss=[0-9.]+\.ckpt', f) for f in files)
     sd = torch.load(ck / 'smoke_96' / 'last.ckpt', weights_only=False)
     assert set(sd) >= {'state_dict', 'hyper_parameters', 'optimizer_states', 'epoch'}
+    if dtype == 'fp16':                    # the loss-scaler state travels with the optimizer state
+        assert sd['optimizer_states'][0]['loss_scaler']['scale'] >= 1.0
     # --test picks the best checkpoint by the loss in its file name (train_mask_bev.py:57-64) and reloads it
     rc = launcher.main(['--config', str(cfg), '--test', '--synthetic', '--checkpoint-root', str(ck)])
     assert rc == 0 and 'Testing from' in capsys.readouterr().out
