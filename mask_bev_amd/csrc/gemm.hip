@@ -619,7 +619,8 @@ static void gemm16_split(GemmArgs& a, int splits, long long contraction, int bat
   int s = splits;
   if (s <= 0) {
     const long long tiles = (long long)a.ntm * a.ntn * batch;
-    s = (int)((512 + tiles - 1) / tiles);
+    static const int target = [] { const char* e = getenv("MBV_GEMM_SPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    s = (int)((target + tiles - 1) / tiles);
     if (s > total_steps * KB / 256) s = total_steps * KB / 256;
   }
   if (s < 1) s = 1;

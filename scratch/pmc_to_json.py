@@ -1,0 +1,77 @@
+"""HBM bytes per C-ABI call from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch).
+gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 128-byte read requests at 64 bytes,
+so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores and float atomics.
+Output: a JSON {bench kernel name: bytes per call} (what bench.py's `roofline.traffic` reads) and a CSV with the split.
+A "call" is one launch of the family's primary kernel; kernels the same C entry point launches with it (split-K part
+adds, the LayerNorm parameter reduction, the attention combine) are charged to that call."""
+import collections
+import csv
+import json
+import re
+import sys
+
+FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged to the same call)
+    ('k_gemm16<TN>', r'k_gemm16I.*Lb1ELb1ELi0E', [r'k_add_parts']),
+    ('k_gemm16<NN>', r'k_gemm16I.*Lb0ELb1ELi0E', [r'k_sum_rows']),
+    ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0E', []),
+    ('k_adamw', r'k_adamw', []),
+    ('k_sample_select', r'k_sample_select', []),
+    ('k_window_attn_bwd', r'k_window_attn_bwd', []),
+    ('k_window_attn_fwd', r'k_window_attn_fwd', []),
+    ('k_msda_bwd', r'k_msda_bwd_locattn', [r'k_msda_bwd_value']),
+    ('k_msda_fwd_v4', r'k_msda_fwd', []),
+    ('k_add_ln_bwd', r'k_add_ln_bwd', [r'k_ln_param_reduce']),
+    ('k_add_ln_fwd', r'k_add_ln_fwd', []),
+    ('k_attn_bwd', r'k_attn_bwd', []),
+    ('k_attn_fwd_split', r'k_attn_fwd_split', [r'k_attn_fwd_combine', r'k_attn_combine']),
+    ('k_wgrad_small', r'k_wgrad_small', []),
+    ('k_hungarian', r'k_hungarian', []),
+    ('k_mask_logits', r'k_mask_logits', []),
+    ('k_point_sample_fwd_lds', r'k_point_sample_fwd', []),
+    ('k_point_sample_bwd_lds', r'k_point_sample_bwd', []),
+    ('k_point_sample_packed', r'k_point_sample_packed', []),
+    ('k_mask_loss_rows_fwd', r'k_mask_loss_rows_fwd', []),
+    ('k_mask_loss_rows_bwd', r'k_mask_loss_rows_bwd', []),
+    ('k_match_cost_terms', r'k_match_cost_terms', []),
+    ('k_act_bwd_colsum', r'k_act_bwd_colsum', []),
+    ('k_colsum', r'k_colsum', []),
+    ('k_ln_apply', r'k_ln_apply', []),
+    ('k_ln_bwd_dense', r'k_ln_bwd_dense', []),
+]
+
+
+def load(path, counter):
+    acc = collections.defaultdict(list)
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r['Counter_Name'] == counter:
+                acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+def main():
+    fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+    out, rows = {}, []
+    for name, primary, extra in FAMILIES:
+        def total(acc, pats):
+            return sum(sum(v) for k, v in acc.items() if any(re.search(p, k) for p in pats))
+        calls = sum(len(v) for k, v in fetch.items() if re.search(primary, k))
+        if not calls:
+            continue
+        f = 2.0 * total(fetch, [primary] + extra) * 1024 / calls
+        w = total(write, [primary] + extra) * 1024 / calls
+        out[name] = f + w
+        rows.append((name, calls, f / 1e6, w / 1e6, (f + w) / 1e6))
+    out['_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py '
+                      'semantic_kitti_512 B=4 bf16; FETCH_SIZE doubled (gfx950 128-byte requests counted at 64); '
+                      'bytes per C-ABI call, averaged over the calls of the run')
+    with open(sys.argv[3], 'w') as fh:
+        json.dump(out, fh, indent=1)
+    with open(sys.argv[4], 'w') as fh:
+        fh.write('kernel_family,calls,fetch_MB_per_call(x2 corrected),write_MB_per_call,total_MB_per_call\n')
+        for r in rows:
+            fh.write(f'"{r[0]}",{r[1]},{r[2]:.2f},{r[3]:.2f},{r[4]:.2f}\n')
+
+
+if __name__ == '__main__':
+    main()
