@@ -24,7 +24,9 @@ struct AttnGeom {
   int ldkv;      // row stride (elements) of the key / value inputs: E, or wider when several layers' projections of the
                  // same memory are written side by side by one GEMM (the pointers then carry the column offset)
   int ldg;       // row stride of grad_k / grad_v
-  int gkv_bf16;  // grad_k / grad_v stored as bf16 (single query super-block only: plain stores)
+  int gkv_bf16;  // grad_k / grad_v stored in the 16-bit type (single query super-block only: plain stores)
+  int vec_ok;    // 16-bit tensors 16-byte aligned, E / ldkv / D multiples of 8: fused 16-byte staging
+  int mask_vec;  // mask rows 16-byte aligned (L % 16 == 0): 16-byte mask loads
 };
 
 struct AttnBlock {
@@ -48,58 +50,91 @@ __device__ __forceinline__ AttnBlock decode(const AttnGeom& g) {
   return r;
 }
 
-// rows [r0, r0 + n) of src (B, R, E), columns [col, col + D) -> [row][d] and/or [d][row] images (zero padded)
-template <bool BF16, int D, typename TIn>
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+// rows [r0, r0 + n) of src (B, R, E), columns [col, col + D) -> padded-row [row][d] image (the f32 path);
+// `vec`: 16-byte loads (f32 tensors 16-byte aligned, E % 4 == 0)
+template <int D, typename TIn>
 __device__ __forceinline__ void stage_rows(const TIn* __restrict__ src, int64_t batch_off, int E, int r0, int n,
-                                           int col, typename Lay<BF16, D>::T* row_img,
-                                           typename Lay<BF16, D>::T* t_img) {
-  using L = Lay<BF16, D>;
-  using T = typename L::T;
+                                           int col, float* row_img, bool vec) {
+  using L = Lay<false, D>;
+  constexpr int CH = D / 4;
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c4 = (idx - t * CH) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < n) {
+      const TIn* p = src + batch_off + (int64_t)(r0 + t) * E + col + c4;
+      if constexpr (std::is_same_v<TIn, float>) {
+        if (vec) {
+          const float4 f = *reinterpret_cast<const float4*>(p);
+          v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = p[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = to_f(p[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_img[t * L::RS + c4 + j] = v[j];
+  }
+}
+
+// the same into a swizzled 16-bit image, element by element (tensors that miss the alignment of the fused path)
+template <int D, typename TIn>
+__device__ __forceinline__ void stage_rows_swz(const TIn* __restrict__ src, int64_t batch_off, int E, int r0, int n,
+                                               int col, lo16_t* img) {
   constexpr int CH = D / 8;
   for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
-    const int t = idx / CH, c8 = (idx - t * CH) * 8;
-    float v[8];
-    if (t < n) {
-      const TIn* p = src + batch_off + (int64_t)(r0 + t) * E + col + c8;
+    const int t = idx / CH, c = idx - t * CH;
+    lo16_t* dst = img + Swz<D>::chunk_off(t, c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = to_f(p[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    }
-    if (row_img) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) row_img[t * L::RS + c8 + j] = (T)v[j];
-    }
-    if (t_img) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t_img[(c8 + j) * L::TS + t] = (T)v[j];
-    }
+    for (int j = 0; j < 8; ++j)
+      dst[j] = (lo16_t)(t < n ? to_f(src[batch_off + (int64_t)(r0 + t) * E + col + 8 * c + j]) : 0.f);
   }
 }
 
-template <bool BF16, int D>
-__device__ __forceinline__ void zero_tail(typename Lay<BF16, D>::T* t_img) {
-  using L = Lay<BF16, D>;
-  if constexpr (L::TROWS > D) {
-    for (int idx = threadIdx.x; idx < (L::TROWS - D) * L::TS; idx += blockDim.x)
-      t_img[D * L::TS + idx] = (typename L::T)0.f;
-  }
+// 16-byte chunk c of row r0 + t (zeros beyond n)
+__device__ __forceinline__ uint4 row_chunk(const lo16_t* __restrict__ src, int64_t batch_off, int E, int r0, int n,
+                                           int col, int t, int c) {
+  return t < n ? *reinterpret_cast<const uint4*>(src + batch_off + (int64_t)(r0 + t) * E + col + 8 * c)
+               : make_uint4(0, 0, 0, 0);
 }
 
-// mask tile [query][key] (1 = blocked) of this block into LDS; keys / queries out of range are blocked
-__device__ __forceinline__ void stage_mask(const uint8_t* __restrict__ mask, const AttnGeom& g, const AttnBlock& k,
-                                           uint8_t* __restrict__ m_lds) {
-  for (int idx = threadIdx.x; idx < NPAD * NPAD; idx += blockDim.x) {
-    const int q = idx / NPAD, kk = idx - q * NPAD;
-    uint8_t v = 1;
-    if (q < k.nq && kk < k.nk) v = mask ? mask[((int64_t)k.b * g.Q + k.q0 + q) * g.L + k.k0 + kk] : 0;
-    m_lds[idx] = v;
+// Blocked-pair bits of this block: word[q][kb] holds keys 32 kb .. 32 kb + 31 of query q (bit set = blocked: masked by
+// the byte map, or a key / query beyond the range).  2 KB instead of a 16 KB byte tile; a lane that owns a query
+// keeps its four words in registers, a lane that owns a key reads the query's word as an LDS broadcast.
+__device__ __forceinline__ unsigned pack_bytes4(unsigned w) { return (((w & 0x01010101u) * 0x01020408u) >> 24) & 0xfu; }
+
+__device__ __forceinline__ void stage_mask_bits(const uint8_t* __restrict__ mask, const AttnGeom& g, const AttnBlock& k,
+                                                unsigned* __restrict__ words) {
+  for (int idx = threadIdx.x; idx < NPAD * NBLK; idx += blockDim.x) {
+    const int q = idx / NBLK, kb = idx - q * NBLK;
+    unsigned w = 0xffffffffu;
+    if (q < k.nq && 32 * kb < k.nk) {
+      const int nvalid = min(32, k.nk - 32 * kb);
+      w = 0;
+      if (mask) {
+        const uint8_t* row = mask + ((int64_t)k.b * g.Q + k.q0 + q) * g.L + k.k0 + 32 * kb;
+        if (g.mask_vec && nvalid == 32) {
+          const uint4 lo = *reinterpret_cast<const uint4*>(row), hi = *reinterpret_cast<const uint4*>(row + 16);
+          w = pack_bytes4(lo.x) | (pack_bytes4(lo.y) << 4) | (pack_bytes4(lo.z) << 8) | (pack_bytes4(lo.w) << 12) |
+              (pack_bytes4(hi.x) << 16) | (pack_bytes4(hi.y) << 20) | (pack_bytes4(hi.z) << 24) | (pack_bytes4(hi.w) << 28);
+        } else {
+          for (int j = 0; j < nvalid; ++j) w |= (row[j] ? 1u : 0u) << j;
+        }
+      }
+      if (nvalid < 32) w |= 0xffffffffu << nvalid;
+    }
+    words[idx] = w;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: per-split partials
+// forward: per-split partials (m, l in log2 units)
 // ---------------------------------------------------------------------------------------------
 template <bool BF16, int D, typename TIn>
 __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ q, const TIn* __restrict__ k,
@@ -108,21 +143,44 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
                                                         float* __restrict__ ws_l, float* __restrict__ ws_o) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
-  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T v_img[BF16 ? L::T_IMG : L::ROW_IMG];
-  __shared__ uint8_t m_lds[NPAD * NPAD];
+  constexpr int IMG = BF16 ? Swz<D>::IMG : L::ROW_IMG;      // 16-bit: swizzled, unpadded (mfma_tiles.hpp); f32: padded rows
+  __shared__ __attribute__((aligned(16))) T q_img[IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[IMG];
+  __shared__ unsigned mbits[NPAD * NBLK];
   const AttnBlock blk = decode(g);
   const int col = blk.head * D;
-  stage_rows<BF16, D, TIn>(q, (int64_t)blk.b * g.Q * g.E, g.E, blk.q0, blk.nq, col, q_img, nullptr);
-  stage_rows<BF16, D, TIn>(k, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, k_img, nullptr);
+  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.ldkv;
   if constexpr (BF16) {
-    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, nullptr, v_img);
-    zero_tail<BF16, D>(v_img);
+    bool fused = false;
+    if constexpr (std::is_same_v<TIn, lo16_t>) {
+      if (g.vec_ok) {      // every 16-byte load of the block is issued before the first LDS store: one memory round trip
+        fused = true;
+        constexpr int CH = D / 8;
+#pragma unroll 2
+        for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+          const int t = idx / CH, c = idx - t * CH;
+          const uint4 a = row_chunk(q, qoff, g.E, blk.q0, blk.nq, col, t, c);
+          const uint4 b = row_chunk(k, koff, g.ldkv, blk.k0, blk.nk, col, t, c);
+          const uint4 d = row_chunk(v, koff, g.ldkv, blk.k0, blk.nk, col, t, c);
+          const int o = Swz<D>::chunk_off(t, c);
+          *reinterpret_cast<uint4*>(q_img + o) = a;
+          *reinterpret_cast<uint4*>(k_img + o) = b;
+          *reinterpret_cast<uint4*>(v_img + o) = d;
+        }
+      }
+    }
+    if (!fused) {
+      stage_rows_swz<D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img);
+      stage_rows_swz<D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img);
+      stage_rows_swz<D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img);
+    }
   } else {
-    stage_rows<BF16, D, TIn>(v, (int64_t)blk.b * g.L * g.ldkv, g.ldkv, blk.k0, blk.nk, col, v_img, nullptr);
+    stage_rows<D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, g.vec_ok);
+    stage_rows<D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img, g.vec_ok);
+    stage_rows<D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img, g.vec_ok);
   }
-  stage_mask(mask, g, blk, m_lds);
+  stage_mask_bits(mask, g, blk, mbits);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -133,19 +191,26 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
 #pragma unroll
   for (int kb = 0; kb < NBLK; ++kb) {
     s[kb] = zero16();
-    if (kb < nkb) mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+    if (kb < nkb) {
+      if constexpr (BF16) mma_rows_swz<D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+      else mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s[kb]);
+    }
   }
+  // scores in log2 units; blocked pairs -> -inf.  This lane's query owns one mask word per key block; element i of
+  // lane half h is key 32 kb + acc_row(i, h) = bit (i & 3) + 8 (i >> 2) of the word shifted by 4 h.
+  const float sl2 = scale * kLog2e;
   float m = -INFINITY;
 #pragma unroll
-  for (int kb = 0; kb < NBLK; ++kb)
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const unsigned w = mbits[ql * NBLK + kb] >> (4 * h);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int kk = 32 * kb + acc_row(i, h);
-      const bool ok = kb < nkb && !m_lds[ql * NPAD + kk];
-      const float val = ok ? s[kb][i] * scale : -INFINITY;
+      const bool ok = kb < nkb && !((w >> ((i & 3) + 8 * (i >> 2))) & 1u);
+      const float val = ok ? s[kb][i] * sl2 : -INFINITY;
       s[kb][i] = val;
       m = fmaxf(m, val);
     }
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   const float m_use = (m == -INFINITY) ? 0.f : m;
   float sum = 0.f;
@@ -153,7 +218,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
   for (int kb = 0; kb < NBLK; ++kb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float p = __expf(s[kb][i] - m_use);
+      const float p = __builtin_amdgcn_exp2f(s[kb][i] - m_use);
       s[kb][i] = p;
       sum += p;
     }
@@ -169,7 +234,10 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
     f32x16 o = zero16();
 #pragma unroll
     for (int kb = 0; kb < NBLK; ++kb)
-      if (kb < nkb) mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o);
+      if (kb < nkb) {
+        if constexpr (BF16) mma_acc_tr<D>(s[kb], v_img, 32 * kb, cb, o);
+        else mma_acc_operand<BF16, D>(s[kb], v_img, 32 * kb, cb, o);
+      }
     const int dcol = r + 32 * cb;
     if (dcol < D) {
 #pragma unroll
@@ -178,7 +246,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
   }
 }
 
-// merge the splits: out[b][q][head*D + d], lse[b][head][q]
+// merge the splits: out[b][q][head*D + d], lse[b][head][q] (natural-log units; the partials are in log2 units)
 template <typename TOut>
 __global__ void __launch_bounds__(256) k_attn_combine(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
                                                       const float* __restrict__ ws_o, AttnGeom g, int D,
@@ -195,80 +263,125 @@ __global__ void __launch_bounds__(256) k_attn_combine(const float* __restrict__ 
   const int su = qq / NPAD, ql = qq - su * NPAD;
   const int64_t base = (((int64_t)b * g.heads + head) * g.nsuper + su) * g.nsplit;
   float M = -INFINITY;
+#pragma unroll 8
   for (int s = 0; s < g.nsplit; ++s) M = fmaxf(M, ws_m[(base + s) * NPAD + ql]);
   float den = 0.f, num = 0.f;
-  for (int s = 0; s < g.nsplit; ++s) {
+#pragma unroll 8
+  for (int s = 0; s < g.nsplit; ++s) {      // independent loads, 8 splits in flight
     const float ms = ws_m[(base + s) * NPAD + ql];
-    if (ms == -INFINITY) continue;
-    const float w = __expf(ms - M);
-    den += w * ws_l[(base + s) * NPAD + ql];
-    num += w * ws_o[((base + s) * NPAD + ql) * D + d];
+    const float ls = ws_l[(base + s) * NPAD + ql];
+    const float os = ws_o[((base + s) * NPAD + ql) * D + d];
+    const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+    den += w * ls;
+    num += w * os;
   }
   out[((int64_t)b * g.Q + qq) * g.E + head * D + d] = (TOut)(num / den);
-  if (d == 0) lse[((int64_t)b * g.heads + head) * g.Q + qq] = M + __logf(den);
+  if (d == 0) lse[((int64_t)b * g.heads + head) * g.Q + qq] = (M + __log2f(den)) * kLn2;
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+// 512 threads: waves 0-3 own the query blocks (dQ partial of this key split), waves 4-7 the key blocks (dK, dV) —
+// side by side on the same staged images, like K4's backward.
 template <bool BF16, int D, typename TIn>
-__global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, const TIn* __restrict__ k,
-                                                  const TIn* __restrict__ v, const uint8_t* __restrict__ mask,
-                                                  const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
-                                                  const float* __restrict__ lse, AttnGeom g, float scale,
-                                                  float* __restrict__ grad_q, float* __restrict__ grad_k,
-                                                  float* __restrict__ grad_v) {
+__global__ void __launch_bounds__(512, 2) k_attn_bwd(const TIn* __restrict__ q, const TIn* __restrict__ k,
+                                                     const TIn* __restrict__ v, const uint8_t* __restrict__ mask,
+                                                     const TIn* __restrict__ out, const TIn* __restrict__ grad_out,
+                                                     const float* __restrict__ lse, AttnGeom g, float scale,
+                                                     float* __restrict__ grad_q, float* __restrict__ grad_k,
+                                                     float* __restrict__ grad_v) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
-  __shared__ __attribute__((aligned(16))) T q_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T k_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T v_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T do_img[L::ROW_IMG];
-  __shared__ __attribute__((aligned(16))) T kt_img[BF16 ? L::T_IMG : 1];
-  __shared__ __attribute__((aligned(16))) T qt_img[BF16 ? L::T_IMG : 1];
-  __shared__ __attribute__((aligned(16))) T dot_img[BF16 ? L::T_IMG : 1];
-  __shared__ uint8_t m_lds[NPAD * NPAD];
-  __shared__ float lse_s[NPAD];
+  constexpr int IMG = BF16 ? Swz<D>::IMG : L::ROW_IMG;
+  __shared__ __attribute__((aligned(16))) T q_img[IMG];
+  __shared__ __attribute__((aligned(16))) T k_img[IMG];
+  __shared__ __attribute__((aligned(16))) T v_img[IMG];
+  __shared__ __attribute__((aligned(16))) T do_img[IMG];
+  __shared__ unsigned mbits[NPAD * NBLK];
   __shared__ double delta_s[NPAD];     // f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
+  __shared__ float2 ld_s[NPAD];        // (lse log2 e, delta) per query
   const AttnBlock blk = decode(g);
   const int col = blk.head * D;
   const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.ldkv;
   const int64_t goff = (int64_t)blk.b * g.L * g.ldg;
-  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
-    lse_s[t] = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
-    delta_s[t] = 0.0;
-  }
-  stage_rows<BF16, D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, BF16 ? qt_img : nullptr);
-  stage_rows<BF16, D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img, BF16 ? kt_img : nullptr);
-  stage_rows<BF16, D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img, nullptr);
-  stage_rows<BF16, D, TIn>(grad_out, qoff, g.E, blk.q0, blk.nq, col, do_img, BF16 ? dot_img : nullptr);
-  if constexpr (BF16) {
-    zero_tail<BF16, D>(qt_img);
-    zero_tail<BF16, D>(kt_img);
-    zero_tail<BF16, D>(dot_img);
-  }
-  stage_mask(mask, g, blk, m_lds);
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) delta_s[t] = 0.0;
   __syncthreads();
-  {
+  bool fused = false;
+  if constexpr (BF16 && std::is_same_v<TIn, lo16_t>) {
+    if (g.vec_ok) {
+      fused = true;
+      constexpr int CH = D / 8;
+      for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+        const int t = idx / CH, c = idx - t * CH;
+        union { uint4 u; lo16_t e[8]; } a, b, d, go, o;
+        a.u = row_chunk(q, qoff, g.E, blk.q0, blk.nq, col, t, c);
+        go.u = row_chunk(grad_out, qoff, g.E, blk.q0, blk.nq, col, t, c);
+        o.u = row_chunk(out, qoff, g.E, blk.q0, blk.nq, col, t, c);
+        b.u = row_chunk(k, koff, g.ldkv, blk.k0, blk.nk, col, t, c);
+        d.u = row_chunk(v, koff, g.ldkv, blk.k0, blk.nk, col, t, c);
+        const int off = Swz<D>::chunk_off(t, c);
+        *reinterpret_cast<uint4*>(q_img + off) = a.u;
+        *reinterpret_cast<uint4*>(do_img + off) = go.u;
+        *reinterpret_cast<uint4*>(k_img + off) = b.u;
+        *reinterpret_cast<uint4*>(v_img + off) = d.u;
+        if (t < blk.nq) {                 // delta[q] = sum_d dO[q][d] * O[q][d]
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += (float)o.e[j] * (float)go.e[j];
+          atomicAdd(&delta_s[t], (double)acc);
+        }
+      }
+    }
+  }
+  if (!fused) {
+    if constexpr (BF16) {
+      stage_rows_swz<D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img);
+      stage_rows_swz<D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img);
+      stage_rows_swz<D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img);
+      stage_rows_swz<D, TIn>(grad_out, qoff, g.E, blk.q0, blk.nq, col, do_img);
+    } else {
+      stage_rows<D, TIn>(q, qoff, g.E, blk.q0, blk.nq, col, q_img, g.vec_ok);
+      stage_rows<D, TIn>(k, koff, g.ldkv, blk.k0, blk.nk, col, k_img, g.vec_ok);
+      stage_rows<D, TIn>(v, koff, g.ldkv, blk.k0, blk.nk, col, v_img, g.vec_ok);
+      stage_rows<D, TIn>(grad_out, qoff, g.E, blk.q0, blk.nq, col, do_img, g.vec_ok);
+    }
     constexpr int CH = D / 8;
     for (int idx = threadIdx.x; idx < blk.nq * CH; idx += blockDim.x) {
       const int t = idx / CH, c8 = (idx - t * CH) * 8;
       const int64_t o = qoff + (int64_t)(blk.q0 + t) * g.E + col + c8;
       float acc = 0.f;
+      if constexpr (std::is_same_v<TIn, float>) {
+        if (g.vec_ok) {
+          const float4 a0 = *reinterpret_cast<const float4*>(out + o), a1 = *reinterpret_cast<const float4*>(out + o + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(grad_out + o), b1 = *reinterpret_cast<const float4*>(grad_out + o + 4);
+          acc = a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+          atomicAdd(&delta_s[t], (double)acc);
+          continue;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += to_f(out[o + j]) * to_f(grad_out[o + j]);
       atomicAdd(&delta_s[t], (double)acc);
     }
   }
+  stage_mask_bits(mask, g, blk, mbits);
+  __syncthreads();
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    const float l = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
+    ld_s[t] = make_float2(l * kLog2e, (float)delta_s[t]);
+  }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = threadIdx.x >> 8;
+  const int r = lane & 31, h = lane >> 5;
   const int nqb = (blk.nq + 31) / 32, nkb = (blk.nk + 31) / 32;
   constexpr int NCB = (D + 31) / 32;
+  const float sl2 = scale * kLog2e;
 
-  if (wave < nqb) {   // ---- part 1: lane = query → dQ partial of this key split
+  if (part == 0 && wave < nqb) {   // ---- part 1: lane = query → dQ partial of this key split
     const int ql = 32 * wave + r;
-    const float my_lse = lse_s[ql], my_delta = (float)delta_s[ql];
+    const float my_lse2 = ld_s[ql].x, my_delta = ld_s[ql].y;
     f32x16 dq[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
@@ -276,20 +389,25 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
     for (int kb = 0; kb < NBLK; ++kb) {
       if (kb >= nkb) continue;
       f32x16 s = zero16(), dp = zero16();
-      mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
-      mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+      if constexpr (BF16) {
+        mma_rows_swz<D>(k_img, 32 * kb, q_img, 32 * wave, s);
+        mma_rows_swz<D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+      } else {
+        mma_rows<BF16, D>(k_img, 32 * kb, q_img, 32 * wave, s);
+        mma_rows<BF16, D>(v_img, 32 * kb, do_img, 32 * wave, dp);
+      }
+      const unsigned w = mbits[ql * NBLK + kb] >> (4 * h);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int kk = 32 * kb + acc_row(i, h);
-        float ds = 0.f;
-        if (!m_lds[ql * NPAD + kk]) {
-          const float p = __expf(s[i] * scale - my_lse);
-          ds = p * (dp[i] - my_delta) * scale;
-        }
-        s[i] = ds;
+        const bool blocked = (w >> ((i & 3) + 8 * (i >> 2))) & 1u;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -my_lse2));
+        s[i] = blocked ? 0.f : p * (dp[i] - my_delta) * scale;
       }
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) mma_acc_operand<BF16, D>(s, BF16 ? kt_img : k_img, 32 * kb, cb, dq[cb]);
+      for (int cb = 0; cb < NCB; ++cb) {
+        if constexpr (BF16) mma_acc_tr<D>(s, k_img, 32 * kb, cb, dq[cb]);
+        else mma_acc_operand<BF16, D>(s, k_img, 32 * kb, cb, dq[cb]);
+      }
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -306,7 +424,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
       }
     }
   }
-  if (wave < nkb) {   // ---- part 2: wave = key block → dK, dV of this split's keys
+  if (part == 1 && wave < nkb) {   // ---- part 2: wave = key block → dK, dV of this split's keys
     const int kb = wave;
     const int kl = 32 * kb + r;
     f32x16 dk[NCB], dv[NCB];
@@ -316,24 +434,33 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
     for (int qb = 0; qb < NBLK; ++qb) {
       if (qb >= nqb) continue;
       f32x16 s = zero16(), dp = zero16();
-      mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);
-      mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      if constexpr (BF16) {
+        mma_rows_swz<D>(q_img, 32 * qb, k_img, 32 * kb, s);
+        mma_rows_swz<D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      } else {
+        mma_rows<BF16, D>(q_img, 32 * qb, k_img, 32 * kb, s);
+        mma_rows<BF16, D>(do_img, 32 * qb, v_img, 32 * kb, dp);
+      }
       f32x16 ds;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qq = 32 * qb + acc_row(i, h);
-        float p = 0.f, d = 0.f;
-        if (!m_lds[qq * NPAD + kl]) {
-          p = __expf(s[i] * scale - lse_s[qq]);
-          d = p * (dp[i] - (float)delta_s[qq]) * scale;
-        }
+        const float2 ld = ld_s[qq];                                        // LDS broadcasts: one address per lane half
+        const bool blocked = (mbits[qq * NBLK + kb] >> r) & 1u;            // this lane's key inside the query's word
+        float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -ld.x));
+        p = blocked ? 0.f : p;
         s[i] = p;
-        ds[i] = d;
+        ds[i] = p * (dp[i] - ld.y) * scale;
       }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        mma_acc_operand<BF16, D>(s, BF16 ? dot_img : do_img, 32 * qb, cb, dv[cb]);
-        mma_acc_operand<BF16, D>(ds, BF16 ? qt_img : q_img, 32 * qb, cb, dk[cb]);
+        if constexpr (BF16) {
+          mma_acc_tr<D>(s, do_img, 32 * qb, cb, dv[cb]);
+          mma_acc_tr<D>(ds, q_img, 32 * qb, cb, dk[cb]);
+        } else {
+          mma_acc_operand<BF16, D>(s, do_img, 32 * qb, cb, dv[cb]);
+          mma_acc_operand<BF16, D>(ds, q_img, 32 * qb, cb, dk[cb]);
+        }
       }
     }
 #pragma unroll
@@ -356,10 +483,16 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const TIn* __restrict__ q, con
   }
 }
 
+bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+               const void* e = nullptr) {
+  return ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c) |
+           reinterpret_cast<size_t>(d) | reinterpret_cast<size_t>(e)) & 15) == 0;
+}
+
 bool make_attn_geom(int B, int Q, int L, int heads, int D, AttnGeom& g) {
   if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || D <= 0) return false;
   g.B = B; g.Q = Q; g.L = L; g.heads = heads; g.E = heads * D;
-  g.ldkv = g.ldg = g.E; g.gkv_bf16 = 0;
+  g.ldkv = g.ldg = g.E; g.gkv_bf16 = 0; g.vec_ok = 0; g.mask_vec = 0;
   g.nsplit = (L + NPAD - 1) / NPAD;
   g.nsuper = (Q + NPAD - 1) / NPAD;
   return true;
@@ -397,7 +530,7 @@ int attn_bwd_launch(const AttnGeom& g, int D, const void* q, const void* k, cons
                     const void* out, const void* grad_out, const float* lse, float* gq, float* gk, float* gv,
                     hipStream_t stream) {
   const float scale = 1.0f / sqrtf((float)D);
-  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(256);
+  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(512);
   const TIn *qq = (const TIn*)q, *kk = (const TIn*)k, *vv = (const TIn*)v, *oo = (const TIn*)out, *go = (const TIn*)grad_out;
   switch (D) {
     case 16: hipLaunchKernelGGL((k_attn_bwd<BF16, 16, TIn>), grid, block, 0, stream, qq, kk, vv, mask, oo, go, lse, g, scale, gq, gk, gv); break;
@@ -442,6 +575,10 @@ MBV_ENTRY int MBV_SYM(mbv_attn_fwd_ld)(const void* q, const void* k, const void*
   if (ld_kv < g.E) return MBV_ERR_BAD_ARG;
   g.ldkv = ld_kv;
   if (!q || !k || !v || !out || !lse) return MBV_ERR_BAD_ARG;
+  // fused 16-byte staging: 8-element chunks of the 16-bit types, 4-element chunks of f32
+  g.vec_ok = is_bf16 ? ((g.E & 7) == 0 && (ld_kv & 7) == 0 && (head_dim & 7) == 0 && aligned16(q, k, v))
+                     : ((g.E & 3) == 0 && (ld_kv & 3) == 0 && (head_dim & 3) == 0 && aligned16(q, k, v));
+  g.mask_vec = blocked && (num_keys & 15) == 0 && aligned16(blocked);
   if (!workspace || workspace_bytes < mbv_attn_workspace_bytes(batch, num_queries, num_keys, heads, head_dim))
     return MBV_ERR_WORKSPACE;
   float* ws = reinterpret_cast<float*>(workspace);
@@ -476,6 +613,9 @@ MBV_ENTRY int MBV_SYM(mbv_attn_bwd_ld)(const void* q, const void* k, const void*
   // strided or bf16 key / value gradients are plain stores of whole rows: one query super-block only
   if ((ld_grad_kv != g.E || grad_kv_bf16) && g.nsuper > 1) return MBV_ERR_UNSUPPORTED;
   g.ldkv = ld_kv; g.ldg = ld_grad_kv; g.gkv_bf16 = grad_kv_bf16 ? 1 : 0;
+  g.vec_ok = is_bf16 ? ((g.E & 7) == 0 && (ld_kv & 7) == 0 && (head_dim & 7) == 0 && aligned16(q, k, v, out, grad_out))
+                     : ((g.E & 3) == 0 && (ld_kv & 3) == 0 && (head_dim & 3) == 0 && aligned16(q, k, v, out, grad_out));
+  g.mask_vec = blocked && (num_keys & 15) == 0 && aligned16(blocked);
   if (g.nsplit > 1)
     MBV_CHECK_HIP(mbv_fill_async(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
   if (g.nsuper > 1) {

@@ -100,68 +100,6 @@ __device__ __forceinline__ void stage_part(const WinGeom& g, const BlockId& id, 
   }
 }
 
-// ---- 16-bit LDS images without padding or transposed copies -----------------------------------------------------
-// A [token][d] image of a 16-bit operand is NPAD rows of exactly D elements; the 16-byte chunk c of row r sits at
-// chunk c ^ ((r >> SH) & (D/8 - 1)), which makes the 16-byte MFMA operand reads of 16 consecutive rows hit 16
-// different bank groups (the padded rows of mfma_tiles.hpp did the same at 12 % more LDS).  The [d][token] operand
-// of the `X^T . M` products (P V, dS K, P^T dO, dS^T Q) is read from the SAME image with gfx950's transposing LDS
-// read (`ds_read_b64_tr_b16`: a 16-lane group fetches a 4 x 16 block row-wise and receives it column-wise), so the
-// transposed copies that the staging pass used to scatter into LDS two bytes at a time are gone: the backward's LDS
-// footprint drops from 135 KB to 76 KB at D = 64 — two workgroups per CU instead of one — and the forward's to 52 KB
-// (three instead of two).
-template <int D>
-struct Swz {
-  static constexpr int CH = D / 8;                                  // 16-byte chunks per row
-  static constexpr int SH = D >= 64 ? 1 : (D == 32 ? 2 : 3);        // rows that share a swizzle value
-  static constexpr int IMG = NPAD * D + 64;                         // + slack: at D = 16 a transposed read of the last
-                                                                    //   rows runs 16 (discarded) columns past the image
-  static __device__ __forceinline__ int chunk_off(int row, int c) {  // element offset of chunk c of `row`
-    return row * D + ((c ^ ((row >> SH) & (CH - 1))) << 3);
-  }
-};
-
-// acc(32x32) += A[a0 + r][:] . B[b0 + r][:]^T over d, both swizzled [token][d] images (cf. mbv_tiles::mma_rows)
-template <int D>
-__device__ __forceinline__ void mma_rows_swz(const lo16_t* __restrict__ a_img, int a0, const lo16_t* __restrict__ b_img,
-                                             int b0, f32x16& acc) {
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_img + Swz<D>::chunk_off(a0 + r, 2 * ks + h));
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(b_img + Swz<D>::chunk_off(b0 + r, 2 * ks + h));
-    acc = mfma16(a, b, acc);
-  }
-}
-
-// out(32 x 32 cols [cb]) += X^T . M  (cf. mbv_tiles::mma_acc_operand): X an accumulator tile whose rows are the
-// contraction index k0 + acc_row(i, h); M the swizzled [token][d] image, read column-wise by the transposing load.
-// Lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p + 3 of a 4 x 16 block and receives column
-// (lane & 15) of it; the groups cover column halves ((lane >> 4) & 1) and row halves (h) of the MFMA B operand, whose
-// element j of half h is contraction index 16 s + 8 (j >> 2) + 4 h + (j & 3) — two reads, rows +0..3 and +8..11.
-template <int D>
-__device__ __forceinline__ void mma_acc_tr(const f32x16& x, const lo16_t* __restrict__ m_img, int k0, int cb,
-                                           f32x16& out) {
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int i = lane & 15, q = i >> 2, p = i & 3;
-  const int c = 4 * cb + 2 * ((lane >> 4) & 1) + (p >> 1);
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    bf16x8 a;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (lo16_t)x[8 * s + j];
-    const int row0 = k0 + 16 * s + 4 * h + q;
-    const lo16_t* p0 = m_img + Swz<D>::chunk_off(row0, c) + 4 * (p & 1);
-    const lo16_t* p1 = m_img + Swz<D>::chunk_off(row0 + 8, c) + 4 * (p & 1);
-    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p0);
-    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)p1);
-    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-    out = mfma16(a, __builtin_bit_cast(bf16x8, t), out);
-  }
-}
-
 // scalar staging of one operand into a swizzled image (tensors that are not 16-byte aligned or C % 8 != 0)
 template <int D, typename TIn>
 __device__ __forceinline__ void stage_part_swz(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
