@@ -701,8 +701,12 @@ MBV_ENTRY int MBV_SYM(mbv_window_attn_bwd)(const void* qkv, const float* qkv_bia
     return MBV_ERR_BAD_ARG;
   const int D = C / heads;
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
-  MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
-  MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
+  if (grad_qkv_bias == grad_table + (size_t)tsz * heads) {      // one allocation (ops.py): one fill launch
+    MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * ((size_t)tsz * heads + 3 * (size_t)C), stream));
+  } else {
+    MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
+  }
   return is_bf16 ? launch_bwd<true, lo16_t>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
                                             grad_qkv_bias, full_bias_grad, stream)
                  : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,

@@ -472,8 +472,10 @@ class _WindowAttention(torch.autograd.Function):
         c = c3 // 3
         grad_out = grad_out.to(qkv.dtype).contiguous()
         g_qkv = torch.empty_like(qkv)
-        g_table = torch.empty_like(table32)
-        g_bias = torch.empty_like(bias32)
+        # the two small f32 gradients share one allocation: the library clears them with one fill launch
+        small = torch.empty(table32.numel() + bias32.numel(), dtype=torch.float32, device=qkv.device)
+        g_table = small[:table32.numel()].view(table32.shape)
+        g_bias = small[table32.numel():]
         is_bf16 = _dt_flag(qkv.dtype)
         rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
                                      is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
