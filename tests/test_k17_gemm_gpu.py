@@ -201,3 +201,27 @@ def test_mask_logit_backward_products():
     assert g_e.dtype == torch.float32 and g_f.dtype == dt
     assert (g_e.double() - ref_e).abs().max() < 2e-4 * ref_e.abs().max()
     _close(g_f, ref_f, dt, float(ref_f.abs().max()) * 1e-2)
+
+
+@gpu
+@pytest.mark.parametrize('bias', [True, False])
+def test_conv1x1_as_batched_gemm_equals_conv2d(bias):
+    """layers.conv1x1 (the pixel decoder's 1 x 1 projections as one strided-batched GEMM,
+    mask_bev_panoptic_head.py:119-123 / mmdet MSDeformAttnPixelDecoder's ConvModules) against nn.Conv2d itself in fp32:
+    output, input gradient, weight and bias gradients."""
+    from mask_bev_amd.layers import conv1x1
+    device = _dev()
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(96, 64, 1, bias=bias).to(device)
+    x = torch.randn(3, 96, 20, 28, device=device, requires_grad=True)
+    go = torch.randn(3, 64, 20, 28, device=device)
+    y_ref = conv(x)
+    y_ref.backward(go)
+    want = [y_ref.detach(), x.grad.clone(), conv.weight.grad.clone()] + ([conv.bias.grad.clone()] if bias else [])
+    x.grad = None
+    conv.zero_grad()
+    y = conv1x1(conv, x)
+    y.backward(go)
+    got = [y.detach(), x.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
