@@ -346,6 +346,14 @@ int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t shadow_dty
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
 
+/* Exact-f32 weight gradient of a few-row Linear (the decoder's B*Q tokens): acc (O, I) += g (T, O)^T x (T, I) with
+ * v_mfma_f32_32x32x2_f32 from global memory, f32 atomics into the (arena) gradient; bias_acc (O) nullable += column
+ * sums of g.  mbv_wgrad_small_f32_group: n such products in one launch per 48 — every array argument is a HOST array
+ * of length n (device pointers / sizes per product; bias_acc may be NULL or hold NULL entries).  These gradients are
+ * nobody's input, so a caller may collect them during the backward and issue them together at its end. */
+int mbv_wgrad_small_f32_group(const float* const* g, const float* const* x, float* const* acc, float* const* bias_acc,
+                              const int32_t* T, const int32_t* O, const int32_t* I, int32_t n, void* stream);
+
 /* Activation backward fused with the bias gradient of the Linear in front of it (the fc1 layers of mmcv FFN,
  * mask_bev/models/networks/swin/swin.py:347-355, mask_bev_panoptic_head.py:137-142): grad_pre = grad_act * act'(pre_act)
  * with act = ReLU (kind 0) or erf-GELU (kind 1), all (rows, n) f32 or bf16, n % 4 == 0;

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 
 class MaskBevHipError(RuntimeError):
@@ -66,6 +66,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_colsum_accum': (ctypes.c_int, [_P, _I, _L, _I, _P, _P]),
     'mbv_act_bwd_colsum': (ctypes.c_int, [_P, _P, _I, _I, _L, _I, _P, _P, _P]),
     'mbv_wgrad_small_f32': (ctypes.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    'mbv_wgrad_small_f32_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_mask_loss_rows_fwd': (ctypes.c_int, [_P, _P, _L, _I, _P, _P]),
     'mbv_mask_loss_rows_bwd': (ctypes.c_int, [_P, _P, _P, _L, _I, _P, _P]),
     'mbv_sample_select_uncertain': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P]),

@@ -314,11 +314,10 @@ __global__ void __launch_bounds__(256) k_act_bwd_colsum(const T* __restrict__ ga
 // and adds its tile into the arena gradient with f32 atomics.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g, const float* __restrict__ x, int T,
-                                                     int O, int I, int tiles_i, int ntiles, int rows_per_slice,
-                                                     float* __restrict__ acc, float* __restrict__ bias_acc) {
+__device__ __forceinline__ void wgrad_small_wave(const float* __restrict__ g, const float* __restrict__ x, int T,
+                                                 int O, int I, int tiles_i, int ntiles, int rows_per_slice,
+                                                 float* __restrict__ acc, float* __restrict__ bias_acc, int wg) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tile = wg % ntiles, slice = wg / ntiles;
   const int o0 = (tile / tiles_i) * 32, i0 = (tile % tiles_i) * 32;
   const int t0 = slice * rows_per_slice;
@@ -362,6 +361,35 @@ __global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g
       if (o < O) atomicAdd(acc + (long)o * I + i0 + r, c[k]);
     }
   }
+}
+
+
+__global__ void __launch_bounds__(256) k_wgrad_small(const float* __restrict__ g, const float* __restrict__ x, int T,
+                                                     int O, int I, int tiles_i, int ntiles, int rows_per_slice,
+                                                     float* __restrict__ acc, float* __restrict__ bias_acc) {
+  wgrad_small_wave(g, x, T, O, I, tiles_i, ntiles, rows_per_slice, acc, bias_acc, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// The same for up to kWgradGroup Linears in ONE launch.  The weight gradients of the decoder's 400-row layers are
+// nobody's input: issued one by one between the data-gradient kernels they cost 63 launches of ≈ 10 µs with the chip
+// mostly idle; collected during the backward and launched together at its end they fill it once.
+constexpr int kWgradGroup = 48;
+struct WgradEntry {
+  const float* g; const float* x; float* acc; float* bias_acc;
+  int T, O, I, tiles_i, ntiles, rows_per_slice, wave_begin;
+};
+struct WgradGroupArgs {
+  WgradEntry e[kWgradGroup];
+  int n, total_waves;
+};
+
+__global__ void __launch_bounds__(256) k_wgrad_small_group(const WgradGroupArgs a) {
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= a.total_waves) return;
+  int i = 0;
+  while (i + 1 < a.n && wg >= a.e[i + 1].wave_begin) ++i;       // wave-uniform: a scalar loop over <= 48 entries
+  const WgradEntry& e = a.e[i];
+  wgrad_small_wave(e.g, e.x, e.T, e.O, e.I, e.tiles_i, e.ntiles, e.rows_per_slice, e.acc, e.bias_acc, wg - e.wave_begin);
 }
 
 }  // namespace
@@ -470,6 +498,48 @@ extern "C" int mbv_wgrad_small_f32(const float* g, const float* x, int32_t T, in
   hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, x, T, O,
                      I, tiles_i, ntiles, rows_per_slice, acc, bias_acc);
   MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// n independent products acc[i] (O[i], I[i]) += g[i]^T x[i] (and bias_acc[i] += column sums of g[i] where given) in as
+// few launches as the kernel-argument size allows (48 per launch).  All arrays are HOST arrays of length n.
+extern "C" int mbv_wgrad_small_f32_group(const float* const* g, const float* const* x, float* const* acc,
+                                         float* const* bias_acc, const int32_t* T, const int32_t* O, const int32_t* I,
+                                         int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!g || !x || !acc || !T || !O || !I))) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < n; base += kWgradGroup) {
+    const int cnt = n - base < kWgradGroup ? n - base : kWgradGroup;
+    WgradGroupArgs a;
+    a.n = 0;
+    int waves = 0;
+    // ≈ 16 waves per CU over the whole group, at least 128 waves per product, at least 32 rows per slice
+    const int per_entry = 4096 / cnt > 128 ? 4096 / cnt : 128;
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      if (T[i] < 0 || O[i] <= 0 || I[i] <= 0 || !g[i] || !x[i] || !acc[i]) return MBV_ERR_BAD_ARG;
+      if (T[i] == 0) continue;
+      WgradEntry& e = a.e[a.n++];
+      e.g = g[i]; e.x = x[i]; e.acc = acc[i]; e.bias_acc = bias_acc ? bias_acc[i] : nullptr;
+      e.T = T[i]; e.O = O[i]; e.I = I[i];
+      const int tiles_o = (O[i] + 31) / 32;
+      e.tiles_i = (I[i] + 31) / 32;
+      e.ntiles = tiles_o * e.tiles_i;
+      int slices = (per_entry + e.ntiles - 1) / e.ntiles;
+      const int max_slices = (T[i] + 31) / 32;
+      if (slices > max_slices) slices = max_slices;
+      if (slices < 1) slices = 1;
+      int rps = (T[i] + slices - 1) / slices;
+      rps = (rps + 1) & ~1;
+      slices = (T[i] + rps - 1) / rps;
+      e.rows_per_slice = rps;
+      e.wave_begin = waves;
+      waves += e.ntiles * slices;
+    }
+    if (a.n == 0) continue;
+    a.total_waves = waves;
+    hipLaunchKernelGGL(k_wgrad_small_group, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+  }
   return MBV_OK;
 }
 

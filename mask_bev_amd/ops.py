@@ -7,6 +7,7 @@ There is no CPU fallback — tensors must live on a ROCm device.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -713,7 +714,7 @@ class _MSDAQuerySide(torch.autograd.Function):
             gj = g[:, c0:c1]                                              # column block: a GEMM operand with lda = width
             if ctx.needs_input_grad[3 + 2 * j]:
                 if getattr(w, '_mbv_arena', False) and w.grad is not None and w.grad.dtype == torch.float32:
-                    _wgrad_into(w.grad, gj, inp)
+                    _wgrad_into(w.grad, gj, inp, persistent=True)
                     _fire_grad_hooks(w)
                 else:
                     acc = torch.zeros(w.shape, dtype=torch.float32, device=dev)
@@ -953,9 +954,57 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
                                _stream()), 'mbv_colsum_accum')
 
 
-def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc: Optional[torch.Tensor] = None) -> bool:
+# Small-token weight gradients are nobody's input.  During a backward pass they are collected and issued as ONE grouped
+# launch (mbv_wgrad_small_f32_group) from an autograd-engine callback at the end of that pass — 63 launches of ≈ 10 us
+# with the chip mostly idle become one that fills it.  `MBV_WGRAD_GROUP=0` keeps the per-layer launches (A/B).
+_PENDING_WGRADS: list = []
+
+
+def _defer_small_wgrad(g2, x2, acc, bias_acc) -> bool:
+    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
+        return False
+    if not _PENDING_WGRADS:
+        try:        # only inside a running backward pass; the callback runs when that pass has executed every node
+            torch.autograd.Variable._execution_engine.queue_callback(flush_small_wgrads)
+        except RuntimeError:
+            return False
+    _PENDING_WGRADS.append((g2, x2, acc, bias_acc, torch.cuda.current_stream()))
+    return True
+
+
+def flush_small_wgrads() -> None:
+    """Issue the collected small-token weight gradients (also callable directly; a no-op when nothing is pending)."""
+    if not _PENDING_WGRADS:
+        return
+    items = list(_PENDING_WGRADS)
+    _PENDING_WGRADS.clear()
+    lib = _lib.load()
+    cur = torch.cuda.current_stream()
+    for s in {it[4] for it in items}:
+        if s != cur:
+            cur.wait_stream(s)
+    n = len(items)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+    g = PA(*[it[0].data_ptr() for it in items])
+    x = PA(*[it[1].data_ptr() for it in items])
+    acc = PA(*[it[2].data_ptr() for it in items])
+    bias = PA(*[(it[3].data_ptr() if it[3] is not None else 0) for it in items])
+    t = IA(*[it[0].shape[0] for it in items])
+    o = IA(*[it[0].shape[1] for it in items])
+    i = IA(*[it[1].shape[1] for it in items])
+    check(lib.mbv_wgrad_small_f32_group(g, x, acc, bias, t, o, i, n, _stream()), 'mbv_wgrad_small_f32_group')
+    for it in items:                 # the producers' memory may be reused by later work on other streams
+        for tns in it[:2]:
+            if it[4] != cur:
+                tns.record_stream(cur)
+
+
+def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc: Optional[torch.Tensor] = None,
+                persistent: bool = False) -> bool:
     """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add).
-    Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch."""
+    Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch.
+    ``persistent``: ``acc`` / ``bias_acc`` are arena gradients nobody reads before the backward pass ends — the
+    small-token form may then be deferred to the grouped launch at the end of the pass."""
     t = g2.shape[0]
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and _k17_wants('wgrad', t) and acc.stride(-1) == 1
             and _gemm16_ok(g2, x2) and acc.data_ptr() % 16 == 0
@@ -967,6 +1016,8 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
         lib = _lib.load()
         g2, x2 = g2.contiguous(), x2.contiguous()
         fuse = bias_acc is not None and bias_acc.is_contiguous() and bias_acc.dtype == torch.float32
+        if persistent and _defer_small_wgrad(g2, x2, acc, bias_acc if fuse else None):
+            return fuse
         check(lib.mbv_wgrad_small_f32(_ptr(g2), _ptr(x2), t, g2.shape[1], x2.shape[1], _ptr(acc),
                                       _ptr(bias_acc) if fuse else ctypes.c_void_p(0), _stream()),
               'mbv_wgrad_small_f32')
@@ -1053,7 +1104,7 @@ class _Linear(torch.autograd.Function):
                 bacc = None
                 if bias_direct:
                     bacc = bias.grad if rows is None else bias.grad[rows[0]:rows[1]]
-                bias_done = _wgrad_into(acc, g2, x2, bacc) or bias_done    # straight into the arena gradient
+                bias_done = _wgrad_into(acc, g2, x2, bacc, persistent=True) or bias_done    # straight into the arena
                 _fire_grad_hooks(weight)
                 if bias_done:
                     _fire_grad_hooks(bias)
@@ -1123,12 +1174,12 @@ class _FFN(torch.autograd.Function):
         # d hidden = (g . W2) * act'(.), column sums -> d b1
         dh = gemm16_nn(g2, w2c, act=ctx.kind, aux=aux, colsum=b1.grad)
         _fire_grad_hooks(b1)
-        _wgrad_into(w2.grad, g2, a)
+        _wgrad_into(w2.grad, g2, a, persistent=True)
         _fire_grad_hooks(w2)
         if not ctx.defer_out_bias:
             colsum_accum(g2, b2.grad)
             _fire_grad_hooks(b2)
-        _wgrad_into(w1.grad, dh, x2)
+        _wgrad_into(w1.grad, dh, x2, persistent=True)
         _fire_grad_hooks(w1)
         gx = None
         if ctx.needs_input_grad[0]:

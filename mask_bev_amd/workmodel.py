@@ -88,6 +88,14 @@ def _add_ln(a, bwd: bool) -> Work:
     return ('k_add_ln_fwd', 'hbm', by, 0.0)
 
 
+def _wgrad_group(a) -> Work:
+    n = _i(a[7])
+    t, o, i = a[4], a[5], a[6]
+    by = sum((t[j] * (o[j] + i[j]) + 2 * o[j] * i[j]) * 4.0 for j in range(n))
+    fl = sum(2.0 * t[j] * o[j] * i[j] for j in range(n))
+    return ('k_wgrad_small_group', 'mfma_f32', by, fl)
+
+
 MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_window_attn_fwd': lambda a: _window_attn(a, False),
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
@@ -122,6 +130,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_wgrad_small_f32': lambda a: ('k_wgrad_small', 'mfma_f32',
                                       (_i(a[2]) * (_i(a[3]) + _i(a[4])) + 2 * _i(a[3]) * _i(a[4])) * 4.0,
                                       2.0 * _i(a[2]) * _i(a[3]) * _i(a[4])),
+    'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
     'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
 }
