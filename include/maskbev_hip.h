@@ -345,6 +345,12 @@ int mbv_loss_scale_update(float* loss_scale, int32_t* clean_steps, int32_t* flag
 int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t shadow_dtype, int64_t n, void* stream);
 
 int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream);
+/* count independent column sums out[i] (n[i]) += sum_r g[i][r, 0:n[i]] with row stride ld[i] (elements) and storage
+ * dtype[i] (MBV_DT_*), one launch per 64.  All array arguments are HOST arrays of length count.  Bias gradients and
+ * LayerNorm-parameter partials are nobody's input: a caller may collect them during the backward and issue them
+ * together at its end. */
+int mbv_colsum_accum_group(const void* const* g, const int32_t* dtype, const int64_t* rows, const int32_t* n,
+                           const int64_t* ld, float* const* out, int32_t count, void* stream);
 
 /* Exact-f32 weight gradient of a few-row Linear (the decoder's B*Q tokens): acc (O, I) += g (T, O)^T x (T, I) with
  * v_mfma_f32_32x32x2_f32 from global memory, f32 atomics into the (arena) gradient; bias_acc (O) nullable += column
@@ -412,7 +418,12 @@ int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t 
 int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
                           void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
-                          float* dbranch_bias, float* partial_ws, void* stream);
+                          float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream);
+/* 1 = the backward of (rows, C) adds the parameter gradients from inside its one kernel; 0 = it writes per-block
+ * partial rows (nblk = mbv_add_layernorm_bwd_blocks, layout [nblk][np][C], np = 3 with dbranch_bias else 2) and reduces
+ * them with a second launch — unless defer_reduce != 0 (accumulating callers only), in which case the caller adds
+ * the partials' column sums itself, typically for many layers at once with mbv_colsum_accum_group. */
+int mbv_add_layernorm_bwd_direct(int64_t rows, int32_t C);
 
 /* ------------------------------------------------------------------------------------------------
  * K14 — batch producer: instance-id map → instance ids → per-instance binary masks.

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 class MaskBevHipError(RuntimeError):
@@ -75,7 +75,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_add_layernorm_bwd_blocks': (_L, [_L, _I]),
     'mbv_add_layernorm_fwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P, _P, _I, _P, _P, _P]),
     'mbv_add_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P, _P,
-                                             _P]),
+                                             _I, _P]),
+    'mbv_add_layernorm_bwd_direct': (ctypes.c_int, [_L, _I]),
+    'mbv_colsum_accum_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_instance_ids': (ctypes.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_expand_instance_masks': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_matched_mask_iou': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

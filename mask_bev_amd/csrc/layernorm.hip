@@ -257,6 +257,11 @@ extern "C" int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C) {
   return b < 1 ? 1 : (b > cap ? cap : b);
 }
 
+// 1 = the backward adds dgamma / dbeta from inside its one kernel (few rows); 0 = it leaves per-block partial rows
+extern "C" int mbv_add_layernorm_bwd_direct(int64_t rows, int32_t C) {
+  return mbv_add_layernorm_bwd_blocks(rows, C) <= 64 ? 1 : 0;
+}
+
 extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
                                      int32_t y_bf16, float* mean, float* rstd, void* stream) {
@@ -282,7 +287,8 @@ extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* 
 extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                                      const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
                                      float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta,
-                                     int32_t accumulate, float* dbranch_bias, float* partial_ws, void* stream) {
+                                     int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce,
+                                     void* stream) {
   const int it = iters_for(C);
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
@@ -316,6 +322,9 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
   }
   MBV_CHECK_LAUNCH();
   if (direct) return MBV_OK;
+  // defer_reduce (accumulating callers only): the (nblk, np, C) partial rows stay in partial_ws and the caller adds
+  // their column sums later — mbv_colsum_accum_group with rows = nblk, ld = np * C, one entry per parameter
+  if (defer_reduce && accumulate) return MBV_OK;
   if (!accumulate) {
     MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
     MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));

@@ -158,14 +158,13 @@ __device__ __forceinline__ float load1<_Float16>(const _Float16* p) { return (fl
 // 4 iterations in flight.  Row slices (gridDim.y) are kept few (≤ 64 per column) — f32 atomics onto the same
 // few hundred addresses serialise in L2, measured 58 us at 672 slices vs the 12 us of a two-pass reduction.
 template <typename T>
-__global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long rows, int n, float* __restrict__ out,
-                                                const bool vec, const int W) {
-  __shared__ float4 part[256];
+__device__ __forceinline__ void colsum_block(const T* __restrict__ g, long rows, int n, long ld, float* __restrict__ out,
+                                             const bool vec, const int W, int bx, int by, int ny, float4* part) {
   const int tid = threadIdx.x;
   const int cg = tid & (W - 1), ro = tid / W, rpi = 256 / W;
-  const int c0 = (blockIdx.x * W + cg) * 4;
-  const long rows_per_block = (rows + gridDim.y - 1) / gridDim.y;
-  const long r0 = (long)blockIdx.y * rows_per_block;
+  const int c0 = (bx * W + cg) * 4;
+  const long rows_per_block = (rows + ny - 1) / ny;
+  const long r0 = (long)by * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c0 < n) {
@@ -173,24 +172,24 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long ro
       float4 a1 = acc, a2 = acc, a3 = acc;
       long r = r0 + ro;
       for (; r + 3 * rpi < r1; r += 4 * rpi) {
-        const float4 x0 = load4<T>(g + r * n + c0);
-        const float4 x1 = load4<T>(g + (r + rpi) * n + c0);
-        const float4 x2 = load4<T>(g + (r + 2 * rpi) * n + c0);
-        const float4 x3 = load4<T>(g + (r + 3 * rpi) * n + c0);
+        const float4 x0 = load4<T>(g + r * ld + c0);
+        const float4 x1 = load4<T>(g + (r + rpi) * ld + c0);
+        const float4 x2 = load4<T>(g + (r + 2 * rpi) * ld + c0);
+        const float4 x3 = load4<T>(g + (r + 3 * rpi) * ld + c0);
         acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
         a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
         a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
         a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
       }
       for (; r < r1; r += rpi) {
-        const float4 x0 = load4<T>(g + r * n + c0);
+        const float4 x0 = load4<T>(g + r * ld + c0);
         acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
       }
       acc.x += a1.x + a2.x + a3.x; acc.y += a1.y + a2.y + a3.y;
       acc.z += a1.z + a2.z + a3.z; acc.w += a1.w + a2.w + a3.w;
     } else {
       for (long r = r0 + ro; r < r1; r += rpi) {
-        const T* row = g + r * n + c0;
+        const T* row = g + r * ld + c0;
         acc.x += load1<T>(row);
         if (c0 + 1 < n) acc.y += load1<T>(row + 1);
         if (c0 + 2 < n) acc.z += load1<T>(row + 2);
@@ -211,6 +210,40 @@ __global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long ro
     if (c0 + 2 < n) atomicAdd(out + c0 + 2, s.z);
     if (c0 + 3 < n) atomicAdd(out + c0 + 3, s.w);
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum(const T* __restrict__ g, long rows, int n, float* __restrict__ out,
+                                                const bool vec, const int W) {
+  __shared__ float4 part[256];
+  colsum_block<T>(g, rows, n, (long)n, out, vec, W, blockIdx.x, blockIdx.y, gridDim.y, part);
+}
+
+// Up to kColsumGroup column sums in ONE launch: bias gradients and LayerNorm-parameter partials (rows of per-block
+// partial sums, row stride ld > n) are nobody's input — collected during the backward, issued together at its end.
+constexpr int kColsumGroup = 64;
+struct ColsumEntry {
+  const void* g; float* out;
+  int rows, n, ld, kind, W, gx, gy, block_begin, vec;
+};
+struct ColsumGroupArgs {
+  ColsumEntry e[kColsumGroup];
+  int n, total_blocks;
+};
+
+__global__ void __launch_bounds__(256) k_colsum_group(const ColsumGroupArgs a) {
+  __shared__ float4 part[256];
+  const int blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < a.n && blk >= a.e[i + 1].block_begin) ++i;
+  const ColsumEntry& e = a.e[i];
+  const int local = blk - e.block_begin, bx = local % e.gx, by = local / e.gx;
+  if (e.kind == MBV_DT_F16)
+    colsum_block<_Float16>(reinterpret_cast<const _Float16*>(e.g), e.rows, e.n, e.ld, e.out, e.vec != 0, e.W, bx, by, e.gy, part);
+  else if (e.kind == MBV_DT_BF16)
+    colsum_block<unsigned short>(reinterpret_cast<const unsigned short*>(e.g), e.rows, e.n, e.ld, e.out, e.vec != 0, e.W, bx, by, e.gy, part);
+  else
+    colsum_block<float>(reinterpret_cast<const float*>(e.g), e.rows, e.n, e.ld, e.out, e.vec != 0, e.W, bx, by, e.gy, part);
 }
 
 // Activation backward fused with the bias gradient of the Linear in front of it:
@@ -454,19 +487,58 @@ extern "C" int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t
   return MBV_OK;
 }
 
-extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream) {
-  if (rows < 0 || n <= 0 || !g || !out) return MBV_ERR_BAD_ARG;
-  if (rows == 0) return MBV_OK;
-  int W = 1;
+// launch geometry of a column sum: W threads per row, gx column blocks, gy row slices
+static void colsum_geometry(int64_t rows, int32_t n, int target_blocks, int& W, unsigned& gx, long& gy) {
+  W = 1;
   while (W < 64 && W * 4 < n) W <<= 1;          // a wave per 256 columns: wide matrices get column blocks (gridDim.x), not idle lanes
   const int rpi = 256 / W;
-  const unsigned gx = (unsigned)((n + W * 4 - 1) / (W * 4));
+  gx = (unsigned)((n + W * 4 - 1) / (W * 4));
   // ≈ 2 blocks per CU, at most 64 row slices per column, at least 8 iterations per block
-  long gy = (512 + gx - 1) / gx;
+  gy = (target_blocks + gx - 1) / gx;
   const long cap = (long)rows * n >= (16L << 20) ? 128 : 64;     // big inputs: bandwidth outweighs contention
   if (gy > cap) gy = cap;
   if (gy > rows / (8L * rpi)) gy = rows / (8L * rpi);
   if (gy < 1) gy = 1;
+}
+
+// count independent column sums out[i] (n[i]) += Σ_r g[i][r, :n[i]] (row stride ld[i] elements, dtype[i] an MBV_DT_*
+// code) in one launch per 64.  Every array argument is a HOST array of length count.
+extern "C" int mbv_colsum_accum_group(const void* const* g, const int32_t* dtype, const int64_t* rows, const int32_t* n,
+                                      const int64_t* ld, float* const* out, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && (!g || !dtype || !rows || !n || !ld || !out))) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < count; base += kColsumGroup) {
+    const int cnt = count - base < kColsumGroup ? count - base : kColsumGroup;
+    ColsumGroupArgs a;
+    a.n = 0;
+    int blocks = 0;
+    const int target = 2048 / cnt > 16 ? 2048 / cnt : 16;          // ≈ 8 blocks per CU over the group
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      if (rows[i] < 0 || n[i] <= 0 || ld[i] < n[i] || !g[i] || !out[i] || dtype[i] < 0 || dtype[i] > 2) return MBV_ERR_BAD_ARG;
+      if (rows[i] == 0) continue;
+      ColsumEntry& e = a.e[a.n++];
+      unsigned gx; long gy;
+      colsum_geometry(rows[i], n[i], target, e.W, gx, gy);
+      e.g = g[i]; e.out = out[i]; e.rows = (int)rows[i]; e.n = n[i]; e.ld = (int)ld[i]; e.kind = dtype[i];
+      e.gx = (int)gx; e.gy = (int)gy; e.block_begin = blocks;
+      e.vec = ((n[i] & 3) == 0 && (ld[i] & 3) == 0 && (reinterpret_cast<size_t>(g[i]) & (dtype[i] ? 7 : 15)) == 0) ? 1 : 0;
+      blocks += e.gx * e.gy;
+    }
+    if (a.n == 0) continue;
+    a.total_blocks = blocks;
+    hipLaunchKernelGGL(k_colsum_group, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+  }
+  return MBV_OK;
+}
+
+extern "C" int mbv_colsum_accum(const void* g, int32_t is_bf16, int64_t rows, int32_t n, float* out, void* stream) {
+  if (rows < 0 || n <= 0 || !g || !out) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  int W;
+  unsigned gx;
+  long gy;
+  colsum_geometry(rows, n, 512, W, gx, gy);
   const bool vec = (n & 3) == 0 && (reinterpret_cast<size_t>(g) & (is_bf16 ? 7 : 15)) == 0;
   if (is_bf16 == MBV_DT_F16)
     hipLaunchKernelGGL(k_colsum<_Float16>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream,

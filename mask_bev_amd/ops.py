@@ -943,60 +943,95 @@ def _fire_grad_hooks(p: torch.Tensor):
             h(p)
 
 
-def colsum_accum(g2: torch.Tensor, out: torch.Tensor):
-    """out (N,) f32 += column sums of g2 (T, N) (bf16 or f32) — the bias gradient, in one launch."""
+def colsum_accum(g2: torch.Tensor, out: torch.Tensor, persistent: bool = False):
+    """out (N,) f32 += column sums of g2 (T, N) (bf16 or f32) — the bias gradient, in one launch.
+    ``persistent``: ``out`` is an arena gradient — inside a backward pass the sum joins the grouped launch at its end."""
     lib = _lib.load()
     _need_gpu(g2, out)
     if g2.dtype not in _ACT_DTYPES or out.dtype != torch.float32 or not out.is_contiguous():
         raise MaskBevHipError('colsum_accum: g2 must be f32, bf16 or fp16 and out contiguous f32')
     g2 = g2.contiguous()
+    if persistent and _defer_colsum(g2, out, g2.shape[0], g2.shape[1], g2.shape[1]):
+        return
     check(lib.mbv_colsum_accum(_ptr(g2), _dt_flag(g2.dtype), g2.shape[0], g2.shape[1], _ptr(out),
                                _stream()), 'mbv_colsum_accum')
 
 
-# Small-token weight gradients are nobody's input.  During a backward pass they are collected and issued as ONE grouped
-# launch (mbv_wgrad_small_f32_group) from an autograd-engine callback at the end of that pass — 63 launches of ≈ 10 us
-# with the chip mostly idle become one that fills it.  `MBV_WGRAD_GROUP=0` keeps the per-layer launches (A/B).
+# Parameter gradients are nobody's input.  During a backward pass the small ones — exact-f32 weight gradients of the
+# decoder's few-row Linears, bias gradients (column sums), the per-block partial rows of K12's LayerNorm-parameter
+# gradients — are collected and issued as a few grouped launches (mbv_wgrad_small_f32_group, mbv_colsum_accum_group)
+# from an autograd-engine callback at the end of that pass: ≈ 140 launches of 5-12 us with the chip mostly idle become
+# four that fill it.  Only accumulations into ARENA gradients are deferred (nothing reads those before the pass ends).
+# `MBV_WGRAD_GROUP=0` keeps the per-layer launches (A/B).
 _PENDING_WGRADS: list = []
+_PENDING_COLSUMS: list = []
+
+
+def _defer_ok() -> bool:
+    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
+        return False
+    if not _PENDING_WGRADS and not _PENDING_COLSUMS:
+        try:        # only inside a running backward pass; the callback runs when that pass has executed every node
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_grads)
+        except RuntimeError:
+            return False
+    return True
 
 
 def _defer_small_wgrad(g2, x2, acc, bias_acc) -> bool:
-    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
+    if not _defer_ok():
         return False
-    if not _PENDING_WGRADS:
-        try:        # only inside a running backward pass; the callback runs when that pass has executed every node
-            torch.autograd.Variable._execution_engine.queue_callback(flush_small_wgrads)
-        except RuntimeError:
-            return False
     _PENDING_WGRADS.append((g2, x2, acc, bias_acc, torch.cuda.current_stream()))
     return True
 
 
-def flush_small_wgrads() -> None:
-    """Issue the collected small-token weight gradients (also callable directly; a no-op when nothing is pending)."""
-    if not _PENDING_WGRADS:
+def _defer_colsum(g2: torch.Tensor, out: torch.Tensor, rows: int, n: int, ld: int, offset: int = 0) -> bool:
+    """out (n,) f32 += column sums of the (rows, n) block of ``g2`` that starts ``offset`` elements in, row stride ld."""
+    if not g2.is_cuda or g2.dtype not in _ACT_DTYPES or out.dtype != torch.float32 or not out.is_contiguous():
+        return False
+    if not _defer_ok():
+        return False
+    _PENDING_COLSUMS.append((g2, out, int(rows), int(n), int(ld), int(offset), torch.cuda.current_stream()))
+    return True
+
+
+def flush_deferred_grads() -> None:
+    """Issue the collected parameter-gradient work (also callable directly; a no-op when nothing is pending)."""
+    if not _PENDING_WGRADS and not _PENDING_COLSUMS:
         return
-    items = list(_PENDING_WGRADS)
+    wg, cs = list(_PENDING_WGRADS), list(_PENDING_COLSUMS)
     _PENDING_WGRADS.clear()
+    _PENDING_COLSUMS.clear()
     lib = _lib.load()
     cur = torch.cuda.current_stream()
-    for s in {it[4] for it in items}:
-        if s != cur:
-            cur.wait_stream(s)
-    n = len(items)
-    PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
-    g = PA(*[it[0].data_ptr() for it in items])
-    x = PA(*[it[1].data_ptr() for it in items])
-    acc = PA(*[it[2].data_ptr() for it in items])
-    bias = PA(*[(it[3].data_ptr() if it[3] is not None else 0) for it in items])
-    t = IA(*[it[0].shape[0] for it in items])
-    o = IA(*[it[0].shape[1] for it in items])
-    i = IA(*[it[1].shape[1] for it in items])
-    check(lib.mbv_wgrad_small_f32_group(g, x, acc, bias, t, o, i, n, _stream()), 'mbv_wgrad_small_f32_group')
-    for it in items:                 # the producers' memory may be reused by later work on other streams
-        for tns in it[:2]:
-            if it[4] != cur:
-                tns.record_stream(cur)
+    for st in {it[-1] for it in wg + cs}:
+        if st != cur:
+            cur.wait_stream(st)
+    if wg:
+        n = len(wg)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+        check(lib.mbv_wgrad_small_f32_group(
+            PA(*[it[0].data_ptr() for it in wg]), PA(*[it[1].data_ptr() for it in wg]),
+            PA(*[it[2].data_ptr() for it in wg]), PA(*[(it[3].data_ptr() if it[3] is not None else 0) for it in wg]),
+            IA(*[it[0].shape[0] for it in wg]), IA(*[it[0].shape[1] for it in wg]), IA(*[it[1].shape[1] for it in wg]),
+            n, _stream()), 'mbv_wgrad_small_f32_group')
+    if cs:
+        n = len(cs)
+        PA, IA, LA = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
+        check(lib.mbv_colsum_accum_group(
+            PA(*[it[0].data_ptr() + it[5] * it[0].element_size() for it in cs]), IA(*[_dt_flag(it[0].dtype) for it in cs]),
+            LA(*[it[2] for it in cs]), IA(*[it[3] for it in cs]), LA(*[it[4] for it in cs]),
+            PA(*[it[1].data_ptr() for it in cs]), n, _stream()), 'mbv_colsum_accum_group')
+    for it in wg:                     # the producers' memory may be reused by later work on their own streams
+        if it[-1] != cur:
+            it[0].record_stream(cur)
+            it[1].record_stream(cur)
+    for it in cs:
+        if it[-1] != cur:
+            it[0].record_stream(cur)
+
+
+flush_small_wgrads = flush_deferred_grads
 
 
 def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc: Optional[torch.Tensor] = None,
@@ -1115,7 +1150,7 @@ class _Linear(torch.autograd.Function):
                 gw[rows[0]:rows[1]] = _wgrad(g2, x2)
         if bias is not None and ctx.needs_input_grad[2] and not bias_done:
             if bias_direct:
-                colsum_accum(g2, bias.grad if rows is None else bias.grad[rows[0]:rows[1]])
+                colsum_accum(g2, bias.grad if rows is None else bias.grad[rows[0]:rows[1]], persistent=True)
                 _fire_grad_hooks(bias)
             elif rows is None:
                 gb = g2.sum(0, dtype=torch.float32).to(bias.dtype)
@@ -1817,12 +1852,22 @@ class _AddLayerNorm(torch.autograd.Function):
         nblk = lib.mbv_add_layernorm_bwd_blocks(rows, c)
         bb = ctx.branch_bias             # arena gradient of the Linear bias that produced b: += colsum(dx)
         ws = torch.empty(max(1, nblk * 3 * c), dtype=torch.float32, device=s.device)
+        # arena gradients: the per-block partial rows of the large LayerNorms join the grouped column-sum launch at the
+        # end of the backward pass instead of one reduction launch per layer
+        np_ = 3 if bb is not None else 2
+        defer = bool(direct and not lib.mbv_add_layernorm_bwd_direct(rows, c) and _defer_ok())
         check(lib.mbv_add_layernorm_bwd(_ptr(gy), _dt_flag(gy.dtype), _ptr(gs),
                                         (_dt_flag(gs.dtype) if gs is not None else 0), _ptr(s), _ptr(mean),
                                         _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo),
                                         _dt_flag(lo) if lo is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                        1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws), _stream()),
+                                        1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws),
+                                        1 if defer else 0, _stream()),
               'mbv_add_layernorm_bwd')
+        if defer:
+            for j, dst in enumerate((dgamma, dbeta, None if bb is None else bb.grad)[:np_]):
+                ok = _defer_colsum(ws, dst, nblk, c, np_ * c, offset=j * c)
+                assert ok, 'deferred LayerNorm parameter reduction could not be queued'
+
         # (the branch Linear's own backward, which runs after this one, announces its bias gradient to the hooks)
         if direct:
             _fire_grad_hooks(weight)
