@@ -237,8 +237,9 @@ int mbv_msda_prepare_bwd_ld(const float* grad_loc, const float* grad_attn, const
  * 16, 32 or 64 and ws <= 11.
  * Backward zero-fills grad_table ((2ws-1)^2, heads) and grad_qkv_bias (3C: gradient reaching the bias
  * through padded tokens; with full_bias_grad != 0 also the column sums of grad_qkv over the real tokens, i.e.
- * the whole bias gradient of the qkv Linear, which then skips its own pass over grad_qkv) itself, then accumulates them with f32 atomics; grad_qkv (B, H, W, 3C) is
- * written in full.
+ * the whole bias gradient of the qkv Linear, which then skips its own pass over grad_qkv) itself, then accumulates them
+ * with f32 atomics — unless accumulate != 0: then they are gradients to be added INTO (parameter-arena views), no fill.
+ * grad_qkv (B, H, W, 3C) is written in full.
  */
 int64_t mbv_window_attn_lse_elems(int32_t batch, int32_t H, int32_t W, int32_t heads, int32_t ws);
 
@@ -250,7 +251,7 @@ int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bia
                         const void* grad_out, const float* lse, int32_t is_bf16,
                         int32_t batch, int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
                         void* grad_qkv, float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad,
-                        void* stream);
+                        int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8 — indexed bilinear point sampling of mask maps (loss and Hungarian targets).

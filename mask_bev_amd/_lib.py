@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 
 class MaskBevHipError(RuntimeError):
@@ -53,7 +53,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                               _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),
     'mbv_window_attn_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     'mbv_point_sample_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'mbv_point_sample_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P]),
     'mbv_hungarian': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),

@@ -664,7 +664,7 @@ MBV_F16_TWIN int mbv_window_attn_fwd_f16(const void*, const float*, const float*
                                          int32_t, int32_t, int32_t, void*, float*, void*);
 MBV_F16_TWIN int mbv_window_attn_bwd_f16(const void*, const float*, const float*, const void*, const void*, const float*,
                                          int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*,
-                                         float*, float*, int32_t, void*);
+                                         float*, float*, int32_t, int32_t, void*);
 #endif
 
 MBV_ENTRY int MBV_SYM(mbv_window_attn_fwd)(const void* qkv, const float* qkv_bias, const float* bias_table, int32_t is_bf16,
@@ -687,11 +687,12 @@ MBV_ENTRY int MBV_SYM(mbv_window_attn_fwd)(const void* qkv, const float* qkv_bia
 MBV_ENTRY int MBV_SYM(mbv_window_attn_bwd)(const void* qkv, const float* qkv_bias, const float* bias_table, const void* out,
                                    const void* grad_out, const float* lse, int32_t is_bf16, int32_t batch, int32_t H,
                                    int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, void* grad_qkv,
-                                   float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad, void* stream_) {
+                                   float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad,
+                                   int32_t accumulate, void* stream_) {
 #ifndef MBV_H16
   if (is_bf16 == MBV_DT_F16)
     return mbv_window_attn_bwd_f16(qkv, qkv_bias, bias_table, out, grad_out, lse, 1, batch, H, W, C, heads, ws, shift,
-                                   grad_qkv, grad_table, grad_qkv_bias, full_bias_grad, stream_);
+                                   grad_qkv, grad_table, grad_qkv_bias, full_bias_grad, accumulate, stream_);
 #endif
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WinGeom g;
@@ -701,7 +702,9 @@ MBV_ENTRY int MBV_SYM(mbv_window_attn_bwd)(const void* qkv, const float* qkv_bia
     return MBV_ERR_BAD_ARG;
   const int D = C / heads;
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
-  if (grad_qkv_bias == grad_table + (size_t)tsz * heads) {      // one allocation (ops.py): one fill launch
+  if (accumulate) {
+    // grad_table / grad_qkv_bias are (arena) gradients the kernel's atomics add into: no fill, no add afterwards
+  } else if (grad_qkv_bias == grad_table + (size_t)tsz * heads) {      // one allocation (ops.py): one fill launch
     MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * ((size_t)tsz * heads + 3 * (size_t)C), stream));
   } else {
     MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));

@@ -462,6 +462,7 @@ class _WindowAttention(torch.autograd.Function):
         check(rc, 'mbv_window_attn_fwd')
         ctx.save_for_backward(qkv, bias32, table32, out, lse)
         ctx.cfg = (num_heads, ws, shift, qkv_bias.dtype, bias_table.dtype)
+        ctx.params = (qkv_bias, bias_table)
         return out
 
     @staticmethod
@@ -473,15 +474,24 @@ class _WindowAttention(torch.autograd.Function):
         c = c3 // 3
         grad_out = grad_out.to(qkv.dtype).contiguous()
         g_qkv = torch.empty_like(qkv)
-        # the two small f32 gradients share one allocation: the library clears them with one fill launch
-        small = torch.empty(table32.numel() + bias32.numel(), dtype=torch.float32, device=qkv.device)
-        g_table = small[:table32.numel()].view(table32.shape)
-        g_bias = small[table32.numel():]
         is_bf16 = _dt_flag(qkv.dtype)
+        pb, pt = ctx.params
+        direct = all(getattr(p, '_mbv_arena', False) and p.grad is not None and p.grad.dtype == torch.float32
+                     and p.grad.is_contiguous() for p in (pb, pt))
+        if direct:          # the kernel's atomics add straight into the arena gradients: no fill, no add_ afterwards
+            g_table, g_bias = pt.grad, pb.grad
+        else:               # the two small f32 gradients share one allocation: the library clears them with one fill
+            small = torch.empty(table32.numel() + bias32.numel(), dtype=torch.float32, device=qkv.device)
+            g_table = small[:table32.numel()].view(table32.shape)
+            g_bias = small[table32.numel():]
         rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
                                      is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
-                                     _ptr(g_bias), 1 if ctx.full_bias_grad else 0, _stream())
+                                     _ptr(g_bias), 1 if ctx.full_bias_grad else 0, 1 if direct else 0, _stream())
         check(rc, 'mbv_window_attn_bwd')
+        if direct:
+            _fire_grad_hooks(pb)
+            _fire_grad_hooks(pt)
+            return g_qkv, None, None, None, None, None, None
         return g_qkv, g_bias.to(bias_dtype), g_table.to(table_dtype), None, None, None, None
 
 

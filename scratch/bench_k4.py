@@ -32,7 +32,7 @@ for (hw, c, heads, nblocks) in [(128, 192, 3, 2), (64, 384, 6, 2), (32, 768, 12,
 
         def bwd():
             assert lib.mbv_window_attn_bwd(P(qkv), P(bias), P(table), P(out), P(go), P(lse), flag, B, hw, hw, c, heads, ws,
-                                           shift, P(g_qkv), P(g_table), P(g_bias), 1, st) == 0
+                                           shift, P(g_qkv), P(g_table), P(g_bias), 1, 0, st) == 0
         with torch.cuda.stream(s):
             fwd(); bwd()
             torch.cuda.synchronize()
