@@ -96,6 +96,13 @@ def _wgrad_group(a) -> Work:
     return ('k_wgrad_small_group', 'mfma_f32', by, fl)
 
 
+def _colsum_group(a) -> Work:
+    n = _i(a[6])
+    dt, rows, cols = a[1], a[2], a[3]
+    by = sum(rows[j] * cols[j] * (4.0 if dt[j] == 0 else 2.0) + cols[j] * 8.0 for j in range(n))
+    return ('k_colsum_group', 'hbm', by, 0.0)
+
+
 MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_window_attn_fwd': lambda a: _window_attn(a, False),
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
@@ -131,6 +138,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                       (_i(a[2]) * (_i(a[3]) + _i(a[4])) + 2 * _i(a[3]) * _i(a[4])) * 4.0,
                                       2.0 * _i(a[2]) * _i(a[3]) * _i(a[4])),
     'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
+    'mbv_colsum_accum_group': lambda a: _colsum_group(a),
     'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
 }

@@ -24,7 +24,9 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_add_ln_fwd', r'k_add_ln_fwd', []),
     ('k_attn_bwd', r'k_attn_bwd', []),
     ('k_attn_fwd_split', r'k_attn_fwd_split', [r'k_attn_fwd_combine', r'k_attn_combine']),
-    ('k_wgrad_small', r'k_wgrad_small', []),
+    ('k_wgrad_small', r'k_wgrad_small\(', []),
+    ('k_wgrad_small_group', r'k_wgrad_small_group', []),
+    ('k_colsum_group', r'k_colsum_group', []),
     ('k_hungarian', r'k_hungarian', []),
     ('k_mask_logits', r'k_mask_logits', []),
     ('k_point_sample_fwd_lds', r'k_point_sample_fwd', []),
@@ -34,7 +36,7 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_mask_loss_rows_bwd', r'k_mask_loss_rows_bwd', []),
     ('k_match_cost_terms', r'k_match_cost_terms', []),
     ('k_act_bwd_colsum', r'k_act_bwd_colsum', []),
-    ('k_colsum', r'k_colsum', []),
+    ('k_colsum', r'k_colsum<', []),
     ('k_ln_apply', r'k_ln_apply', []),
     ('k_ln_bwd_dense', r'k_ln_bwd_dense', []),
 ]
