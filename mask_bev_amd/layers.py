@@ -238,13 +238,16 @@ class MultiheadAttention(nn.Module):
         ``ops.shared_kv_project`` together with the other layers of the same memory (key / value are ignored)."""
         e, h = self.embed_dims, self.num_heads
         w, bias = self.attn.in_proj_weight, self.attn.in_proj_bias
-        q = query + query_pos if query_pos is not None else query
-        q = ops.linear(q, w, bias, rows=(0, e))
+        q_in = query + query_pos if query_pos is not None else query
+        q = ops.linear(q_in, w, bias, rows=(0, e))
         if shared_kv is not None:
             holder, token, slot = shared_kv
             o = ops.attention_shared_kv(q, token, blocked, h, holder, slot)
         else:
-            k = key + key_pos if key_pos is not None else key
+            if key is query and key_pos is query_pos:        # self-attention: the positioned input is shared by q and k
+                k = q_in
+            else:
+                k = key + key_pos if key_pos is not None else key
             k = ops.linear(k, w, bias, rows=(e, 2 * e))
             v = ops.linear(value, w, bias, rows=(2 * e, 3 * e))
             o = ops.attention(q, k, v, blocked, h)                 # K6: heads split by addressing, mask per query

@@ -243,3 +243,50 @@ def test_bias_act_backward(device, kind, dt):
     want = b0.double() + zr.grad.sum(0)
     assert torch.allclose(bias.grad.double(), want, rtol=1e-4 if dt == torch.float32 else 5e-3,
                           atol=2e-3 if dt == torch.float32 else 0.3)
+
+
+def test_grouped_parameter_gradient_entry_points(device):
+    """mbv_wgrad_small_f32_group / mbv_colsum_accum_group through the C ABI: several products / column sums of different
+    shapes, dtypes and row strides in one call each, against f64 torch expressions; accumulation into non-zero
+    destinations; a bias entry that is NULL."""
+    import ctypes
+    from mask_bev_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shapes = [(400, 256, 256), (400, 2048, 256), (37, 48, 40), (400, 256, 2048), (2, 32, 32)]
+    gs = [torch.randn(t, o, generator=g).to(device) for t, o, i in shapes]
+    xs = [torch.randn(t, i, generator=g).to(device) for t, o, i in shapes]
+    accs = [torch.randn(o, i, generator=g).to(device) for t, o, i in shapes]
+    bias = [torch.randn(o, generator=g).to(device) if j != 2 else None for j, (t, o, i) in enumerate(shapes)]
+    want_w = [a.double() + gg.double().t() @ xx.double() for a, gg, xx in zip(accs, gs, xs)]
+    want_b = [None if b is None else b.double() + gg.double().sum(0) for b, gg in zip(bias, gs)]
+    n = len(shapes)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+    rc = lib.mbv_wgrad_small_f32_group(PA(*[t.data_ptr() for t in gs]), PA(*[t.data_ptr() for t in xs]),
+                                       PA(*[t.data_ptr() for t in accs]),
+                                       PA(*[(b.data_ptr() if b is not None else 0) for b in bias]),
+                                       IA(*[s[0] for s in shapes]), IA(*[s[1] for s in shapes]),
+                                       IA(*[s[2] for s in shapes]), n, st)
+    assert rc == 0
+    for a, w in zip(accs, want_w):
+        assert torch.allclose(a.double(), w, rtol=1e-5, atol=2e-5 * 400 ** 0.5)
+    for b, w in zip(bias, want_b):
+        if b is not None:
+            assert torch.allclose(b.double(), w, rtol=1e-5, atol=2e-5 * 400 ** 0.5)
+    # column sums: f32 / bf16 / fp16 blocks, one of them a strided window of a wider matrix (LayerNorm partial rows)
+    mats = [torch.randn(3000, 96, generator=g).to(device), torch.randn(65536, 384, generator=g).to(device).bfloat16(),
+            torch.randn(777, 132, generator=g).to(device).half(), torch.randn(500, 3 * 192, generator=g).to(device)]
+    views = [(mats[0], 0, 96, 96), (mats[1], 0, 384, 384), (mats[2], 0, 132, 132), (mats[3], 192, 192, 3 * 192)]
+    outs = [torch.randn(v[2], generator=g).to(device) for v in views]
+    want = [o.double() + m.double()[:, off:off + nn].sum(0) for o, (m, off, nn, ld) in zip(outs, views)]
+    n = len(views)
+    PA, IA, LA = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
+    flag = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+    rc = lib.mbv_colsum_accum_group(PA(*[m.data_ptr() + off * m.element_size() for m, off, nn, ld in views]),
+                                    IA(*[flag[m.dtype] for m, *_ in views]), LA(*[m.shape[0] for m, *_ in views]),
+                                    IA(*[nn for _, _, nn, _ in views]), LA(*[ld for *_, ld in views]),
+                                    PA(*[o.data_ptr() for o in outs]), n, st)
+    assert rc == 0
+    for o, w, (m, *_rest) in zip(outs, want, views):
+        assert torch.allclose(o.double(), w, rtol=1e-5, atol=1e-3 * (m.shape[0] ** 0.5) * 1e-2 + 1e-4)
