@@ -426,7 +426,6 @@ __global__ void __launch_bounds__(512, 2) k_attn_bwd(const TIn* __restrict__ q, 
   }
   if (part == 1 && wave < nkb) {   // ---- part 2: wave = key block → dK, dV of this split's keys
     const int kb = wave;
-    const int kl = 32 * kb + r;
     f32x16 dk[NCB], dv[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
