@@ -469,6 +469,17 @@ int mbv_matched_mask_iou(const float* logits, const int32_t* pred_row, const uin
  */
 int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
                   int32_t* row_to_col, void* stream);
+
+/* The same for matrices (rows = predictions) x (cols = ground-truth slots, rows <= cols <= 128) whose trailing columns
+ * are identical padding — the dataset pads the instance list to num_queries with all-zero masks of label 0
+ * (semantic_kitti_transforms.py:66-81), so for a given prediction those columns hold one and the same cost.
+ * real_cols (batch) i32 ON THE DEVICE: the number of leading real columns of each problem.  Solves the equivalent
+ * rectangular problem of the real columns (the padded columns' cost enters as the start value of the predictions'
+ * duals) — the same optimum, the same real pairs whenever it is unique, at about (real / rows)^2 of the search steps;
+ * the predictions left over take the padded columns in ascending order.  Problems without padding (real_cols ==
+ * cols) and non-square problems (a real column may then stay unmatched) are solved like mbv_hungarian. */
+int mbv_hungarian_padded(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols, const int32_t* real_cols,
+                         int32_t* row_to_col, void* stream);
 int mbv_hungarian_wide_t(const float* cost_t, int32_t batch, int32_t num_rows, int32_t num_cols,
                          int32_t* row_to_col, void* stream);
 

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 
 class MaskBevHipError(RuntimeError):
@@ -57,6 +57,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_point_sample_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'mbv_point_sample_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P]),
     'mbv_hungarian': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
+    'mbv_hungarian_padded': (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P]),
     'mbv_hungarian_wide_t': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
     'mbv_select_uncertain_points': (ctypes.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P, _P, _P]),

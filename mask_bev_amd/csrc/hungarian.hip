@@ -58,19 +58,56 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane) {
 // greedy matching on their zero reduced costs — a feasible dual with complementary slackness, so the
 // shortest-augmenting-path search only has to run for the rows the greedy pass left unmatched and still ends in
 // an optimal assignment (the same one as scipy's when the optimum is unique).
+//
+// Padded mode (`real_cols` != NULL, one entry per problem): the caller's matrix is SQUARE, (rows = predictions) x (cols
+// = ground-truth slots), and its columns real_cols[p] .. cols - 1 are IDENTICAL (the dataset pads the instance list
+// with all-zero masks of label 0, so those columns hold the same cost for a given prediction).  Assigning prediction i
+// to any of them costs d_i = a[i][cols - 1], so the square problem equals  sum_i d_i + min over injections of the K =
+// real_cols[p] real columns into the predictions of  sum_j (a[s(j)][j] - d_s(j)):  a RECTANGULAR problem with K rows
+// (the real instances) and `rows` columns (the predictions) — K augmenting paths instead of `rows`, each at most K
+// long.  It is solved on the original f32 costs in f64: the opt-out cost d enters as the START VALUE of the
+// predictions' duals (v_q = d_q instead of 0: every reduced cost a - u - v is then the reduced cost of the transformed
+// matrix), which is what a free column's dual has to be at the optimum.  The predictions left over take the padded
+// columns in ascending order (identical targets: any order gives the same loss).  Same optimum as the square solve —
+// the same real pairs whenever that optimum is unique — at ≈ (K / rows)^2 of its search steps.
 __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost_all, int rows, int cols,
-                                                  int transposed, int32_t* __restrict__ out_all, int out_len) {
+                                                  int transposed, int32_t* __restrict__ out_all, int out_len,
+                                                  const int32_t* __restrict__ real_cols) {
   __shared__ double u_row[kMaxDim];
+  __shared__ double d_col[kMaxDim];
   __shared__ int row_matched[kMaxDim];
   __shared__ float a_lds[kMaxDim * (kMaxDim + 1)];   // the whole cost matrix: every search step reads one row
   const int lane = threadIdx.x;
   const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
   int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
   constexpr int LD = kMaxDim + 1;
-  for (int e = lane; e < rows * cols; e += 64) {
-    int i, j;
-    if (transposed) { j = e / rows; i = e - j * rows; } else { i = e / cols; j = e - i * cols; }
-    a_lds[i * LD + j] = cost[e];
+  const int n_pred = rows, n_gt = cols;          // the caller's shape (padded mode)
+  bool padded = false;
+  if (real_cols) {
+    int k = real_cols[blockIdx.x];
+    k = k < 0 ? 0 : (k > n_gt ? n_gt : k);
+    // square problems only: every column — hence every REAL column — is matched there, which is what the rectangular
+    // form assumes (with more slots than predictions a real column may stay unmatched: solved in the plain form)
+    if (k < n_gt && n_gt == n_pred) {
+      padded = true;
+      // internal rows = real instances, internal columns = predictions: a_lds[g][q] = a[q][g]
+      for (int e = lane; e < n_pred * k; e += 64) {
+        const int q = e / k, gidx = e - q * k;
+        a_lds[gidx * LD + q] = cost[q * n_gt + gidx];
+      }
+      for (int q = lane; q < n_pred; q += 64) d_col[q] = (double)cost[q * n_gt + n_gt - 1];
+      rows = k;
+      cols = n_pred;
+      transposed = 1;
+    }
+  }
+  if (!padded) {
+    for (int e = lane; e < rows * cols; e += 64) {
+      int i, j;
+      if (transposed) { j = e / rows; i = e - j * rows; } else { i = e / cols; j = e - i * cols; }
+      a_lds[i * LD + j] = cost[e];
+    }
+    for (int q = lane; q < kMaxDim; q += 64) d_col[q] = 0.0;
   }
   __syncthreads();
   const int jA = lane + 1, jB = lane + 65;
@@ -78,16 +115,17 @@ __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost
   const double INF = 1e300;
   // -- row reduction: lane r owns rows r and r + 64 (row stride LD = 129 words: conflict-free)
   for (int r = lane; r < rows; r += 64) {
-    float m = a_lds[r * LD];
-    for (int j = 1; j < cols; ++j) m = fminf(m, a_lds[r * LD + j]);
-    u_row[r] = (double)m;
+    double m = (double)a_lds[r * LD] - d_col[0];
+    for (int j = 1; j < cols; ++j) m = fmin(m, (double)a_lds[r * LD + j] - d_col[j]);
+    u_row[r] = m;
     row_matched[r] = 0;
   }
   __syncthreads();
   // -- column reduction.  Only for square problems: with rows < cols a column may stay unmatched, and the dual of
-  // an unmatched column has to be 0 at the optimum (v = 0 is the start the search itself keeps for free columns).
-  double vA = 0.0, vB = 0.0;
-  if (rows == cols) {
+  // an unmatched column has to be 0 at the optimum (v = 0 is the start the search itself keeps for free columns;
+  // d in padded mode).
+  double vA = hasA ? d_col[jA - 1] : 0.0, vB = hasB ? d_col[jB - 1] : 0.0;
+  if (rows == cols && !padded) {
     vA = vB = INF;
     for (int i = 0; i < rows; ++i) {
       const double ui = u_row[i];
@@ -193,7 +231,14 @@ __global__ void __launch_bounds__(64) k_hungarian(const float* __restrict__ cost
     }
   }
   // outputs
-  if (!transposed) {
+  if (padded) {
+    // out[prediction] = its real instance, or — for the predictions left over — the padded columns in ascending order
+    const bool freeA = hasA && pA == 0, freeB = hasB && pB == 0;
+    const unsigned long long mA = __ballot(freeA), mB = __ballot(freeB);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (hasA) out[jA - 1] = pA > 0 ? pA - 1 : rows + __popcll(mA & below);
+    if (hasB) out[jB - 1] = pB > 0 ? pB - 1 : rows + __popcll(mA) + __popcll(mB & below);
+  } else if (!transposed) {
     if (hasA && pA > 0) out[pA - 1] = jA - 1;       // out[row] = col
     if (hasB && pB > 0) out[pB - 1] = jB - 1;
   } else {
@@ -373,11 +418,11 @@ extern "C" int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows,
   if (num_rows <= kMaxDim && num_cols <= kMaxDim) {
     if (num_rows <= num_cols) {
       hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
-                         num_rows);
+                         num_rows, (const int32_t*)nullptr);
     } else {
       // more rows than columns: solve the transposed problem; unmatched rows get -1
       hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_cols, num_rows, 1, row_to_col,
-                         num_rows);
+                         num_rows, (const int32_t*)nullptr);
     }
   } else {
     // wide problems read the matrix from global memory and need it in (rows <= cols) orientation:
@@ -386,6 +431,21 @@ extern "C" int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows,
     hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
                        num_rows);
   }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// Square-or-wider problems whose trailing columns are identical padding (see k_hungarian): real_cols (batch) i32 on the
+// device = number of leading real columns of each problem.  num_rows <= num_cols <= 128.
+extern "C" int mbv_hungarian_padded(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
+                                    const int32_t* real_cols, int32_t* row_to_col, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch < 0 || num_rows <= 0 || num_cols <= 0 || num_rows > num_cols) return MBV_ERR_BAD_ARG;
+  if (num_cols > kMaxDim) return MBV_ERR_UNSUPPORTED;
+  if (batch == 0) return MBV_OK;
+  if (!cost || !row_to_col || !real_cols) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col, num_rows,
+                     real_cols);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -562,6 +562,16 @@ class Mask2FormerHead(nn.Module):
         pts = PointSource(dev, self.point_seed)
         match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
         cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)
+        # The dataset pads the instance list to num_queries with all-zero masks of label 0: those cost columns are
+        # identical, and K9 solves the equivalent rectangular problem of the real columns (ops.hungarian).  A column
+        # counts as padding only if it has label 0 AND an empty mask AND every later column is padding too.
+        def real_cols():             # evaluated on the matcher's stream: nothing else needs it
+            if not (nq == ng <= 128 and isinstance(gt_flat, ops.PackedMasks)
+                    and os.environ.get('MBV_K9_PADDED', '1') != '0'):
+                return None
+            real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                  # (B, G)
+            last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)            # (B,) = K
+            return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()
         # K9 is latency-bound (one wavefront per problem).  When every query gets matched (G >= Q, the dataset's
         # padding convention) nothing of the importance sampling below depends on the assignment, so K9 runs on
         # a side stream underneath it.
@@ -577,10 +587,10 @@ class Mask2FormerHead(nn.Module):
             assigned = torch.empty((d * b, nq), dtype=torch.int32, device=dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.hungarian(cost, out=assigned)
+                ops.hungarian(cost, out=assigned, real_cols=real_cols())
             assigned = assigned.view(d, b, nq)
         else:
-            assigned = ops.hungarian(cost).view(d, b, nq)                                        # (D, B, Q) i32
+            assigned = ops.hungarian(cost, real_cols=real_cols()).view(d, b, nq)                   # (D, B, Q) i32
             matched = assigned >= 0
             safe = assigned.clamp(min=0).long()
 

@@ -1655,15 +1655,25 @@ def point_sample_packed(pm: PackedMasks, src_index: torch.Tensor, coords: torch.
 # K9 batched Hungarian assignment
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
-def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None,
+              real_cols: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cost (N, R, C) f32 on the device → (N, R) int32: column assigned to each row (min total cost), -1 for
-    rows left out when R > C.  No host synchronisation (K9, include/maskbev_hip.h)."""
+    rows left out when R > C.  No host synchronisation (K9, include/maskbev_hip.h).
+    ``real_cols`` (N,) int32 on the device: columns ``real_cols[n]`` … C-1 of problem n are identical padding (the
+    dataset's zero-padded instance list) — the equivalent rectangular problem of the real columns is solved instead
+    (R <= C <= 128; same optimum, same real pairs when it is unique)."""
     lib = _lib.load()
     _need_gpu(cost)
     cost = cost.to(torch.float32).contiguous()
     n, r, c = cost.shape
     if out is None:
         out = torch.empty((n, r), dtype=torch.int32, device=cost.device)
+    if real_cols is not None and r <= c <= 128:
+        real_cols = real_cols.to(torch.int32).contiguous()
+        if real_cols.numel() != n or not real_cols.is_cuda:
+            raise MaskBevHipError('hungarian: real_cols must be a device tensor with one entry per problem')
+        check(lib.mbv_hungarian_padded(_ptr(cost), n, r, c, _ptr(real_cols), _ptr(out), _stream()), 'mbv_hungarian_padded')
+        return out
     out.fill_(-1)
     if max(r, c) > 128 and r > c:         # wide problems are solved from global memory in (rows <= cols) orientation
         cost_t = cost.transpose(1, 2).contiguous()

@@ -38,3 +38,36 @@ def test_hungarian_tied_columns_same_cost(device):
         real_ours = {int(q): int(cc) for q, cc in enumerate(got[i]) if cc in range(1, 12)}
         real_ref = {int(q): int(cc) for q, cc in zip(rows, cols) if cc in range(1, 12)}
         assert real_ours == real_ref
+
+
+@pytest.mark.parametrize('q,g_slots', [(100, 100), (100, 128), (40, 40), (7, 9)])
+def test_hungarian_padded_columns_equal_the_square_solve(device, q, g_slots):
+    """ops.hungarian(real_cols=K): the dataset's zero-padded instance list makes columns K .. G-1 identical, and K9
+    solves the rectangular problem of the K real columns instead of the square one (mbv_hungarian_padded).  Against
+    scipy on the full matrix: a permutation into G slots, the same optimal cost (f64 sums, rel 1e-9), and — generic
+    real costs, unique optimum — exactly scipy's pairs on the real columns; predictions left over take the padded
+    columns in ascending order.  Problems with K = 0, K = G (no padding: the plain solve) and K of every size between."""
+    from mask_bev_amd import ops
+    gen = torch.Generator().manual_seed(q * 7 + g_slots)
+    ks = [0, 1, min(q, g_slots) // 3, min(q, g_slots) - 1, min(q, g_slots), 5, 17 % (min(q, g_slots) + 1)]
+    if g_slots == q:
+        ks.append(g_slots)                       # no padded column at all
+    n = len(ks)
+    cost = torch.empty(n, q, g_slots)
+    for i, k in enumerate(ks):
+        real = torch.randn(q, k, generator=gen) * 3 + torch.rand(q, k, generator=gen)
+        pad = (torch.randn(q, 1, generator=gen) * 2 + 1).expand(q, g_slots - k)        # one opt-out cost per prediction
+        cost[i] = torch.cat([real, pad], 1)
+    got = ops.hungarian(cost.to(device), real_cols=torch.tensor(ks, dtype=torch.int32, device=device)).cpu().numpy()
+    for i, k in enumerate(ks):
+        c = cost[i].double().numpy()
+        rows, cols = linear_sum_assignment(c)
+        assert len(set(got[i].tolist())) == q and got[i].min() >= 0 and got[i].max() < g_slots
+        ours = float(c[np.arange(q), got[i]].sum())
+        assert ours == pytest.approx(float(c[rows, cols].sum()), rel=1e-9, abs=1e-9)
+        real_ours = {int(p): int(cc) for p, cc in enumerate(got[i]) if cc < k}
+        real_ref = {int(p): int(cc) for p, cc in zip(rows, cols) if cc < k}
+        assert real_ours == real_ref
+        rest = [int(cc) for cc in got[i] if cc >= k]
+        if k < g_slots and q == g_slots:          # (non-square problems take the plain solve: any padded slots)
+            assert rest == list(range(k, k + len(rest)))                              # ascending padded slots
