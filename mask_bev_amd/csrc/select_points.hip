@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   // batches of BATCH points: their coordinate loads are issued together (one HBM round trip per batch, not per
   // point); a scheduling barrier after every batch keeps the compiler from hoisting later batches' loads over the
   // 40 live key registers (it spilled 197 VGPRs without it)
-  constexpr int BATCH = 8;
+  constexpr int BATCH = RNG ? 2 : 8;
 #pragma unroll
   for (int jb = 0; jb < kKeysPerThread; jb += BATCH) {
     float2 xy[BATCH];
@@ -195,11 +195,11 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     for (int u = 0; u < BATCH; ++u) {
       const int p = (jb + u) * kFusedThreads + tid;
       Bil b;
-      bil_setup(xy[u].x, xy[u].y, H, W, b);
+      bil_setup_clamped(xy[u].x, xy[u].y, H, W, b);
+      // same association as K8's gather loop ((((0 + t0) + t1) + t2) + t3): the fused form stays bit-identical to it
       float v = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (b.o[c] >= 0) v += b.w[c] * tile[b.o[c]];
+      for (int c = 0; c < 4; ++c) v += b.w[c] * tile[b.o[c]];
       keys[jb + u] = p < n ? abs_key(v) : 0xffffffffu;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -215,8 +215,9 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
-      const bool valid = j * kFusedThreads + tid < n;
-      if (valid && (keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
+      // slots beyond n hold the largest key (0xffffffff): counted in the top bin, they never reach the k-th smallest
+      // (k <= n), so no validity test — and no 40 live lane masks — is needed from here on
+      if ((keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
     }
     __syncthreads();
     // cumulative search: thread t owns bins 4t … 4t + 3; wave totals through LDS (cnt_lt doubles as scratch)
@@ -259,8 +260,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) {
-    const bool valid = j * kFusedThreads + tid < n;
-    const unsigned long long m_lt = __ballot(valid && keys[j] < T), m_eq = __ballot(valid && keys[j] == T);
+    const unsigned long long m_lt = __ballot(keys[j] < T), m_eq = __ballot(keys[j] == T && T != 0xffffffffu);
     if (lane == 0) {
       cnt_lt[j * kFusedWaves + wave] = __popcll(m_lt);
       cnt_eq[j * kFusedWaves + wave] = __popcll(m_eq);
@@ -310,8 +310,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     for (int u = 0; u < BATCH; ++u) {
       const int j = jb + u;
       const int p = j * kFusedThreads + tid;
-      const bool valid = p < n;
-      const bool is_lt = valid && keys[j] < T, is_eq = valid && keys[j] == T;
+      const bool is_lt = keys[j] < T, is_eq = keys[j] == T && T != 0xffffffffu;
       const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
       const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
       const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
