@@ -140,7 +140,8 @@ template <bool BF16, int D, typename TIn>
 __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ q, const TIn* __restrict__ k,
                                                         const TIn* __restrict__ v, const uint8_t* __restrict__ mask,
                                                         AttnGeom g, float scale, float* __restrict__ ws_m,
-                                                        float* __restrict__ ws_l, float* __restrict__ ws_o) {
+                                                        float* __restrict__ ws_l, float* __restrict__ ws_o,
+                                                        TIn* __restrict__ out, float* __restrict__ lse) {
   using L = Lay<BF16, D>;
   using T = typename L::T;
   constexpr int IMG = BF16 ? Swz<D>::IMG : L::ROW_IMG;      // 16-bit: swizzled, unpadded (mfma_tiles.hpp); f32: padded rows
@@ -224,9 +225,20 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
     }
   sum += __shfl_xor(sum, 32, 64);
   const int64_t wrow = (int64_t)blk.ws_row * NPAD;
+  const bool single = g.nsplit == 1;          // all keys in this block (the 100 x 100 self-attention): no combine pass
   if (h == 0) {
-    ws_m[wrow + ql] = m;
-    ws_l[wrow + ql] = sum;
+    if (!single) {
+      ws_m[wrow + ql] = m;
+      ws_l[wrow + ql] = sum;
+    } else if (ql < blk.nq) {
+      lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + ql] = (m + __log2f(sum)) * kLn2;
+    }
+  }
+  // 1 / sum of each accumulator row's query, for the direct store (rows of O are queries, lanes are d)
+  __shared__ float inv_s[NPAD];
+  if (single) {
+    if (h == 0) inv_s[ql] = 1.f / sum;
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave reads back only what it wrote
   }
   constexpr int NCB = (D + 31) / 32;
 #pragma unroll
@@ -241,7 +253,12 @@ __global__ void __launch_bounds__(256) k_attn_fwd_split(const TIn* __restrict__ 
     const int dcol = r + 32 * cb;
     if (dcol < D) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ws_o[(wrow + 32 * wave + acc_row(i, h)) * D + dcol] = o[i];
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (!single) ws_o[(wrow + qq) * D + dcol] = o[i];
+        else if (qq < blk.nq)
+          out[((int64_t)blk.b * g.Q + blk.q0 + qq) * g.E + blk.head * D + dcol] = (TIn)(o[i] * inv_s[qq]);
+      }
     }
   }
 }
@@ -511,12 +528,13 @@ int attn_fwd_launch(const AttnGeom& g, int D, const void* q, const void* k, cons
   const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(256);
   const TIn *qq = (const TIn*)q, *kk = (const TIn*)k, *vv = (const TIn*)v;
   switch (D) {
-    case 16: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 16, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
-    case 32: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 32, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
-    case 64: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 64, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o); break;
+    case 16: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 16, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o, (TIn*)out, lse); break;
+    case 32: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 32, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o, (TIn*)out, lse); break;
+    case 64: hipLaunchKernelGGL((k_attn_fwd_split<BF16, 64, TIn>), grid, block, 0, stream, qq, kk, vv, mask, g, scale, ws_m, ws_l, ws_o, (TIn*)out, lse); break;
     default: return MBV_ERR_UNSUPPORTED;
   }
   MBV_CHECK_LAUNCH();
+  if (g.nsplit == 1) return MBV_OK;            // the split kernel normalised and stored the output itself
   const int64_t total = (int64_t)g.B * g.heads * g.Q * D;
   hipLaunchKernelGGL((k_attn_combine<TIn>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws_m, ws_l,
                      ws_o, g, D, (TIn*)out, lse);
