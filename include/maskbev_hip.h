@@ -590,6 +590,21 @@ int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, 
                   int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* The weight gradients of `count` Linears in one GEMM launch (+ one parts-add launch) per 48 of them:
+ *   dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])          for i < count.
+ * Replaces the per-layer weight-gradient GEMMs of autograd's Linear backward (the same layers as above): a weight
+ * gradient is nobody's input, so the caller collects the (g, x, dw) triples of a backward pass and issues them together
+ * at its end — a 192 x 192 ... 2304 x 768 output alone cannot fill 256 CUs without cutting the token sum into slivers,
+ * the tiles of all layers together do.  Every array argument is a HOST array of length count; g / x are 16-bit
+ * (`dtype`), ld* in elements (multiples of 8), pointers 16-byte aligned, m[i] == 0 entries are skipped.  Token sums
+ * deeper than the work-item depth are cut into parts stored in `workspace` (mbv_gemm16_tn_group_workspace_bytes) and
+ * added to dw by their owner thread: no atomics, bit-reproducible. */
+size_t mbv_gemm16_tn_group_workspace_bytes(const int64_t* m, const int64_t* n, const int64_t* k, int32_t count);
+
+int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const* dw, const int64_t* m, const int64_t* n,
+                        const int64_t* k, const int64_t* ldg, const int64_t* ldx, int32_t count, int32_t dtype,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

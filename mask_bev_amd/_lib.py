@@ -102,6 +102,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gemm16_tn': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _I, _L, _L, _L, _P, c_size_t,
                                      _P]),
     'mbv_attn_bwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'mbv_gemm16_tn_group_workspace_bytes': (c_size_t, [_P, _P, _P, _I]),
+    'mbv_gemm16_tn_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, c_size_t, _P]),
 }
 
 _lib = None

@@ -77,6 +77,7 @@ struct GemmArgs {
   unsigned a_bytes, b_bytes;   // extent of one batch item of A / B for the buffer descriptors
   int ntm, ntn, splits, ksteps;  // tiles, split-K parts, K-steps of KB per part
   int out_f32;
+  int acc_out;          // STORE, f32 output, splits == 1: the product is ADDED to c (read-modify-write, no atomics)
 };
 
 template <typename T>
@@ -238,23 +239,23 @@ __device__ __forceinline__ void round8(float (&v)[8]) {
 }
 
 // OUT: 0 = STORE (C^T accumulators, row-major store through LDS with the epilogue), 1 = ATOMIC (f32 adds)
+// XCD-aware block order (blocks b and b + 8 share an XCD): every XCD walks a contiguous range of the work index
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, s = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+// One workgroup's share of a product: work item `bid` of the (batch, split, tile_m, tile_n) index, tile_n fastest, so
+// that the items that share an A panel are neighbours (and, after xcd_contiguous, share an L2).
 template <int KB, int NS, int WM, int TM, int TN, bool A_KS, bool B_KS, int OUT, int EPI, typename T>
-__global__ void __launch_bounds__(64 * 2 * WM, (Geo<KB, NS, WM, TM, TN>::WPS)) k_gemm16(const GemmArgs p) {
+__device__ __forceinline__ void gemm16_body(const GemmArgs& p, const int bid, char* smem) {
   using G = Geo<KB, NS, WM, TM, TN>;
   static_assert(OUT == 1 || TN == 2, "the STORE epilogue turns 64-column wave tiles");
   constexpr int BM = G::BM, BN = G::BN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware block order (blocks b and b + 8 share an XCD): every XCD walks a contiguous range of the
-  // (batch, split, tile_m, tile_n) index, tile_n fastest, so the blocks that share an A panel share an L2.
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, s = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
-  }
   const int tiles = p.ntm * p.ntn;
   const int z = bid / tiles, t = bid - z * tiles;
   const int tile_m = t / p.ntn, tile_n = t - tile_m * p.ntn;
@@ -450,6 +451,12 @@ __global__ void __launch_bounds__(64 * 2 * WM, (Geo<KB, NS, WM, TM, TN>::WPS)) k
           }
         }
       }
+      if (p.acc_out) {                                    // f32 destination owned by this workgroup: out += product
+        const float* d = reinterpret_cast<const float*>(p.c) + o;
+        const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
+        v[0] += d0.x; v[1] += d0.y; v[2] += d0.z; v[3] += d0.w;
+        v[4] += d1.x; v[5] += d1.y; v[6] += d1.z; v[7] += d1.w;
+      }
       store8<T>(p.c, o, v, p.out_f32);
       if (p.colsum_rows) {
         if (!p.out_f32) round8<T>(v);                     // sum what was stored
@@ -473,6 +480,84 @@ __global__ void __launch_bounds__(64 * 2 * WM, (Geo<KB, NS, WM, TM, TN>::WPS)) k
       *reinterpret_cast<float4*>(d + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
     }
   }
+}
+
+template <int KB, int NS, int WM, int TM, int TN, bool A_KS, bool B_KS, int OUT, int EPI, typename T>
+__global__ void __launch_bounds__(64 * 2 * WM, (Geo<KB, NS, WM, TM, TN>::WPS)) k_gemm16(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm16_body<KB, NS, WM, TM, TN, A_KS, B_KS, OUT, EPI, T>(p, xcd_contiguous(blockIdx.x, gridDim.x), smem);
+}
+
+// ---- grouped weight gradients ------------------------------------------------------------------------------------
+// Up to kTnGroup products dw_i (n_i, k_i) f32 += g_i (m_i, n_i)^T x_i (m_i, k_i) in ONE launch.  A weight gradient is
+// nobody's input, so the Linears of a backward pass hand theirs over and the pass issues them together at its end: a
+// 192 x 192 ... 2304 x 768 output is 2 ... 108 tiles of 128 x 128 — alone it fills the chip only by cutting the token
+// sum into slivers (and pays a pipeline fill per sliver and a round trip of partial tiles per split), together the
+// tiles of ~40 layers do.  Work item = (entry, split, tile_m, tile_n); every entry is cut into token ranges of about
+// the same depth, so the items are about equally long.  splits == 1: the owner adds its tile to dw in place;
+// splits > 1: partial tiles go to the workspace and k_add_parts_group folds them into dw (no atomics either way).
+constexpr int kTnGroup = 48;
+struct TnEntry {
+  const void* g; const void* x; float* out;     // out: dw (splits == 1) or this entry's parts in the workspace
+  int m, n, k, ldg, ldx, ldo;
+  int ntn, splits, ksteps, item_begin;
+};
+struct TnGroupArgs {
+  TnEntry e[kTnGroup];
+  int n, total_items;
+};
+
+template <int KB, int NS, typename T>
+__global__ void __launch_bounds__(256, (Geo<KB, NS, 2, 2, 2>::WPS)) k_gemm16_tn_group(const TnGroupArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+  int i = 0;
+  while (i + 1 < a.n && item >= a.e[i + 1].item_begin) ++i;     // block-uniform: a scalar loop over <= 48 entries
+  const TnEntry& e = a.e[i];
+  GemmArgs p;
+  p.a = e.g; p.b = e.x; p.c = e.out; p.c2 = nullptr; p.aux = nullptr; p.bias = nullptr; p.colsum_rows = nullptr;
+  p.gm = e.n; p.gn = e.k; p.gk = e.m;
+  p.lda = e.ldg; p.ldb = e.ldx; p.ldc = e.ldo; p.ldx = 0;
+  p.sa = 0; p.sb = 0; p.sc = 0;
+  p.ssplit = (long long)e.n * e.k;
+  p.a_bytes = (unsigned)(((long long)(e.m - 1) * e.ldg + e.n) * 2);
+  p.b_bytes = (unsigned)(((long long)(e.m - 1) * e.ldx + e.k) * 2);
+  p.ntm = (e.n + 127) / 128; p.ntn = e.ntn; p.splits = e.splits; p.ksteps = e.ksteps;
+  p.out_f32 = 1;
+  p.acc_out = e.splits == 1;
+  gemm16_body<KB, NS, 2, 2, 2, true, true, 0, EPI_NONE, T>(p, item - e.item_begin, smem);
+}
+
+constexpr int kPartsGroup = 96;
+struct PartsEntry {
+  const float* part; float* out;
+  long long n;                 // elements of out (a multiple of 4)
+  int parts, block_begin;
+};
+struct PartsGroupArgs {
+  PartsEntry e[kPartsGroup];
+  int n;
+};
+
+// out_i (n_i) += sum of its parts (parts_i, n_i), for up to kPartsGroup outputs; a thread owns 4 consecutive elements
+__global__ void __launch_bounds__(256) k_add_parts_group(const PartsGroupArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.e[i + 1].block_begin) ++i;
+  const PartsEntry& e = a.e[i];
+  const long long j = ((long long)(blockIdx.x - e.block_begin) * 256 + threadIdx.x) * 4;
+  if (j >= e.n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < e.parts; p += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = p + u < e.parts ? *reinterpret_cast<const float4*>(e.part + (long long)(p + u) * e.n + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  float4 o = *reinterpret_cast<const float4*>(e.out + j);
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *reinterpret_cast<float4*>(e.out + j) = o;
 }
 
 // out (n) += sum over rows of part (rows, n)
@@ -791,4 +876,98 @@ extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, 
     return MBV_OK;
   }
   return gemm16_launch(shape, 2, accumulate ? 1 : 0, EPI_NONE, dtype, a, batch, (hipStream_t)stream);
+}
+
+// ---- grouped weight gradients (see k_gemm16_tn_group) -------------------------------------------------------------
+// Token depth of one work item: MBV_GEMM_GROUP_DEPTH (A/B runs), default 4096.
+static int tn_group_depth() {
+  static const int d = [] { const char* e = getenv("MBV_GEMM_GROUP_DEPTH"); return e && atoi(e) >= 256 ? atoi(e) : 4096; }();
+  return d;
+}
+
+static void tn_group_split(int64_t m, int& splits, int& ksteps) {
+  const int total_steps = (int)((m + KB - 1) / KB);
+  int s = (int)((m + tn_group_depth() - 1) / tn_group_depth());
+  if (s < 1) s = 1;
+  ksteps = (total_steps + s - 1) / s;
+  splits = (total_steps + ksteps - 1) / ksteps;
+}
+
+static bool tn_group_entry_ok(const void* g, const void* x, const float* dw, int64_t m, int64_t n, int64_t k,
+                              int64_t ldg, int64_t ldx) {
+  if (m <= 0 || n <= 0 || k <= 0 || !g || !x || !dw) return false;
+  if ((n & 7) || (k & 7) || (ldg & 7) || (ldx & 7) || ldg < n || ldx < k) return false;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dw)) & 15) return false;
+  return fits_2g(m, ldg) && fits_2g(m, ldx) && n * k < 0x7fffffffLL;
+}
+
+extern "C" size_t mbv_gemm16_tn_group_workspace_bytes(const int64_t* m, const int64_t* n, const int64_t* k,
+                                                      int32_t count) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (m[i] <= 0 || n[i] <= 0 || k[i] <= 0) continue;
+    int splits, ksteps;
+    tn_group_split(m[i], splits, ksteps);
+    if (splits > 1) total += (size_t)splits * (size_t)n[i] * (size_t)k[i] * 4;
+  }
+  return total;
+}
+
+// dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])   for i < count, in one GEMM launch
+// (+ one parts-add launch) per 48 products.  Every array argument is a HOST array of length count.
+extern "C" int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const* dw, const int64_t* m,
+                                   const int64_t* n, const int64_t* k, const int64_t* ldg, const int64_t* ldx,
+                                   int32_t count, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (count < 0 || dtype < 0 || dtype > 1) return MBV_ERR_BAD_ARG;
+  if (count > 0 && (!g || !x || !dw || !m || !n || !k || !ldg || !ldx)) return MBV_ERR_BAD_ARG;
+  for (int i = 0; i < count; ++i) {
+    if (m[i] < 0) return MBV_ERR_BAD_ARG;
+    if (m[i] > 0 && !tn_group_entry_ok(g[i], x[i], dw[i], m[i], n[i], k[i], ldg[i], ldx[i])) return MBV_ERR_UNSUPPORTED;
+  }
+  if (mbv_gemm16_tn_group_workspace_bytes(m, n, k, count) > workspace_bytes) return MBV_ERR_WORKSPACE;
+  if (workspace_bytes && (!workspace || (reinterpret_cast<size_t>(workspace) & 15))) return MBV_ERR_WORKSPACE;
+  using G = Geo<KB, NS, 2, 2, 2>;
+  float* ws = reinterpret_cast<float*>(workspace);
+  for (int base = 0; base < count; base += kTnGroup) {
+    const int cnt = count - base < kTnGroup ? count - base : kTnGroup;
+    TnGroupArgs a;
+    PartsGroupArgs pa;
+    a.n = 0; pa.n = 0;
+    long long items = 0, pblocks = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      if (m[i] == 0) continue;
+      TnEntry& e = a.e[a.n++];
+      e.g = g[i]; e.x = x[i];
+      e.m = (int)m[i]; e.n = (int)n[i]; e.k = (int)k[i]; e.ldg = (int)ldg[i]; e.ldx = (int)ldx[i]; e.ldo = (int)k[i];
+      e.ntn = (int)((k[i] + 127) / 128);
+      tn_group_split(m[i], e.splits, e.ksteps);
+      e.item_begin = (int)items;
+      items += (long long)((n[i] + 127) / 128) * e.ntn * e.splits;
+      if (e.splits == 1) {
+        e.out = dw[i];
+      } else {
+        e.out = ws;
+        PartsEntry& q = pa.e[pa.n++];
+        q.part = ws; q.out = dw[i]; q.n = n[i] * k[i]; q.parts = e.splits; q.block_begin = (int)pblocks;
+        pblocks += (q.n / 4 + 255) / 256;
+        ws += (size_t)e.splits * (size_t)q.n;
+      }
+    }
+    if (a.n == 0) continue;
+    if (items > 0x7fffffffLL || pblocks > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+    a.total_items = (int)items;
+    if (dtype == 0)
+      hipLaunchKernelGGL((k_gemm16_tn_group<KB, NS, __bf16>), dim3((unsigned)items), dim3(256), G::LDS,
+                         (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((k_gemm16_tn_group<KB, NS, _Float16>), dim3((unsigned)items), dim3(256), G::LDS,
+                         (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+    if (pa.n) {
+      hipLaunchKernelGGL(k_add_parts_group, dim3((unsigned)pblocks), dim3(256), 0, (hipStream_t)stream, pa);
+      MBV_CHECK_LAUNCH();
+    }
+  }
+  return MBV_OK;
 }

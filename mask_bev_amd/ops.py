@@ -973,50 +973,117 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor, persistent: bool = False):
 # from an autograd-engine callback at the end of that pass: ≈ 140 launches of 5-12 us with the chip mostly idle become
 # four that fill it.  Only accumulations into ARENA gradients are deferred (nothing reads those before the pass ends).
 # `MBV_WGRAD_GROUP=0` keeps the per-layer launches (A/B).
-_PENDING_WGRADS: list = []
-_PENDING_COLSUMS: list = []
+_PENDING: dict = {}          # autograd graph-task id -> ([small weight gradients], [column sums]) of that backward pass
+
+
+def _pending_lists():
+    """The pending lists of the running backward pass (creating them and arming the end-of-pass callback on first use),
+    or None outside a pass / with the switch off.  Keyed by the engine's graph-task id: a re-entrant pass (the deferred
+    heads re-evaluate a sub-graph inside the outer backward) flushes its own work, and what a pass that raised left
+    behind is never mistaken for the next pass's work."""
+    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
+        return None
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        return None
+    lists = _PENDING.get(tid)
+    if lists is None:
+        try:        # the callback runs when this pass has executed every node
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred_grads(tid))
+        except RuntimeError:
+            return None
+        for old in [t for t in _PENDING if t < tid - 16]:       # leftovers of passes that never completed
+            del _PENDING[old]
+        lists = _PENDING[tid] = ([], [], [])
+    return lists
 
 
 def _defer_ok() -> bool:
-    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
-        return False
-    if not _PENDING_WGRADS and not _PENDING_COLSUMS:
-        try:        # only inside a running backward pass; the callback runs when that pass has executed every node
-            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_grads)
-        except RuntimeError:
-            return False
-    return True
+    return _pending_lists() is not None
 
 
 def _defer_small_wgrad(g2, x2, acc, bias_acc) -> bool:
-    if not _defer_ok():
+    lists = _pending_lists()
+    if lists is None:
         return False
-    _PENDING_WGRADS.append((g2, x2, acc, bias_acc, torch.cuda.current_stream()))
+    lists[0].append((g2, x2, acc, bias_acc, torch.cuda.current_stream()))
     return True
+
+
+def _tn_group_mode() -> str:
+    """MBV_TN_GROUP: ``1`` (default) — the K17 weight gradients of a backward pass are collected and issued as grouped
+    launches at its end (mbv_gemm16_tn_group); ``all`` — every 16-bit arena weight gradient with at least 512 tokens joins
+    the group, also those the per-layer policy leaves to the library (few tokens, wide inputs); ``0`` — per-layer launches."""
+    return os.environ.get('MBV_TN_GROUP', '1')
+
+
+def _defer_tn_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor) -> bool:
+    if _tn_group_mode() == '0' or not acc.is_contiguous():
+        return False
+    lists = _pending_lists()
+    if lists is None:
+        return False
+    lists[2].append((g2, x2, acc, torch.cuda.current_stream()))
+    return True
+
+
+def gemm16_tn_group(items) -> None:
+    """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` for every ``(g, x, acc)`` of ``items`` in one K17 launch per 48 (all of
+    one 16-bit dtype, contiguous ``acc``)."""
+    if not items:
+        return
+    lib = _lib.load()
+    n = len(items)
+    dt = items[0][0].dtype
+    for g, x, acc in items:
+        if (g.dtype != dt or not _gemm16_ok(g, x) or g.shape[0] != x.shape[0] or acc.dtype != torch.float32
+                or not acc.is_contiguous() or tuple(acc.shape) != (g.shape[1], x.shape[1]) or acc.data_ptr() % 16):
+            raise MaskBevHipError('gemm16_tn_group: unsupported operands')
+    PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    m, nn, k = LA(*[g.shape[0] for g, _, _ in items]), LA(*[g.shape[1] for g, _, _ in items]), \
+        LA(*[x.shape[1] for _, x, _ in items])
+    nbytes = lib.mbv_gemm16_tn_group_workspace_bytes(m, nn, k, n)
+    ws = _workspace(nbytes, items[0][0].device) if nbytes else None
+    check(lib.mbv_gemm16_tn_group(PA(*[g.data_ptr() for g, _, _ in items]), PA(*[x.data_ptr() for _, x, _ in items]),
+                                  PA(*[a.data_ptr() for _, _, a in items]), m, nn, k,
+                                  LA(*[g.stride(0) for g, _, _ in items]), LA(*[x.stride(0) for _, x, _ in items]),
+                                  n, _GEMM16_DT[dt], _ptr(ws), int(nbytes), _stream()), 'mbv_gemm16_tn_group')
 
 
 def _defer_colsum(g2: torch.Tensor, out: torch.Tensor, rows: int, n: int, ld: int, offset: int = 0) -> bool:
     """out (n,) f32 += column sums of the (rows, n) block of ``g2`` that starts ``offset`` elements in, row stride ld."""
     if not g2.is_cuda or g2.dtype not in _ACT_DTYPES or out.dtype != torch.float32 or not out.is_contiguous():
         return False
-    if not _defer_ok():
+    lists = _pending_lists()
+    if lists is None:
         return False
-    _PENDING_COLSUMS.append((g2, out, int(rows), int(n), int(ld), int(offset), torch.cuda.current_stream()))
+    lists[1].append((g2, out, int(rows), int(n), int(ld), int(offset), torch.cuda.current_stream()))
     return True
 
 
-def flush_deferred_grads() -> None:
-    """Issue the collected parameter-gradient work (also callable directly; a no-op when nothing is pending)."""
-    if not _PENDING_WGRADS and not _PENDING_COLSUMS:
+def flush_deferred_grads(task_id: Optional[int] = None) -> None:
+    """Issue the parameter-gradient work collected by backward pass ``task_id`` (default: by every pass that has some
+    pending — callable directly; a no-op when nothing is pending)."""
+    tids = [task_id] if task_id is not None else list(_PENDING)
+    wg, cs, tn = [], [], []
+    for t in tids:
+        lists = _PENDING.pop(t, None)
+        if lists is not None:
+            wg += lists[0]
+            cs += lists[1]
+            tn += lists[2]
+    if not wg and not cs and not tn:
         return
-    wg, cs = list(_PENDING_WGRADS), list(_PENDING_COLSUMS)
-    _PENDING_WGRADS.clear()
-    _PENDING_COLSUMS.clear()
     lib = _lib.load()
     cur = torch.cuda.current_stream()
-    for st in {it[-1] for it in wg + cs}:
+    for st in {it[-1] for it in wg + cs + tn}:
         if st != cur:
             cur.wait_stream(st)
+    if tn:
+        # deepest token sums first: their work items are the longest of a launch; one launch per dtype
+        tn.sort(key=lambda it: -it[0].shape[0])
+        for dt in {it[0].dtype for it in tn}:
+            gemm16_tn_group([it[:3] for it in tn if it[0].dtype == dt])
     if wg:
         n = len(wg)
         PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
@@ -1032,7 +1099,7 @@ def flush_deferred_grads() -> None:
             PA(*[it[0].data_ptr() + it[5] * it[0].element_size() for it in cs]), IA(*[_dt_flag(it[0].dtype) for it in cs]),
             LA(*[it[2] for it in cs]), IA(*[it[3] for it in cs]), LA(*[it[4] for it in cs]),
             PA(*[it[1].data_ptr() for it in cs]), n, _stream()), 'mbv_colsum_accum_group')
-    for it in wg:                     # the producers' memory may be reused by later work on their own streams
+    for it in wg + tn:                # the producers' memory may be reused by later work on their own streams
         if it[-1] != cur:
             it[0].record_stream(cur)
             it[1].record_stream(cur)
@@ -1051,11 +1118,14 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     ``persistent``: ``acc`` / ``bias_acc`` are arena gradients nobody reads before the backward pass ends — the
     small-token form may then be deferred to the grouped launch at the end of the pass."""
     t = g2.shape[0]
-    if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and _k17_wants('wgrad', t) and acc.stride(-1) == 1
-            and _gemm16_ok(g2, x2) and acc.data_ptr() % 16 == 0
-            and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')):     # 2048-wide patch rows: the library wins (77 vs 95 us)
-        gemm16_tn_acc(acc, g2, x2)               # K17: split over the tokens, f32 atomic adds into the arena
-        return False
+    if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
+            and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):
+        per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
+        if (persistent and (per_layer or (_tn_group_mode() == 'all' and t >= 512)) and _defer_tn_wgrad(g2, x2, acc)):
+            return False                         # K17, grouped with the pass's other weight gradients at its end
+        if per_layer:
+            gemm16_tn_acc(acc, g2, x2)           # K17: split over the tokens, parts added into the arena
+            return False
     if (g2.dtype == torch.float32 and x2.dtype == torch.float32 and t <= _SMALL_F32_ROWS and g2.is_cuda
             and acc.is_contiguous()):
         lib = _lib.load()

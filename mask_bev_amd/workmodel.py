@@ -96,6 +96,14 @@ def _wgrad_group(a) -> Work:
     return ('k_wgrad_small_group', 'mfma_f32', by, fl)
 
 
+def _tn_group(a) -> Work:
+    n = _i(a[8])
+    m, o, k = a[3], a[4], a[5]
+    by = sum(m[j] * (o[j] + k[j]) * 2.0 + 2 * o[j] * k[j] * 4.0 for j in range(n))
+    fl = sum(2.0 * m[j] * o[j] * k[j] for j in range(n))
+    return ('k_gemm16_tn_group', 'mfma', by, fl)        # bench.py prices the family against the roofline that bounds it
+
+
 def _colsum_group(a) -> Work:
     n = _i(a[6])
     dt, rows, cols = a[1], a[2], a[3]
@@ -139,6 +147,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                       2.0 * _i(a[2]) * _i(a[3]) * _i(a[4])),
     'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
     'mbv_colsum_accum_group': lambda a: _colsum_group(a),
+    'mbv_gemm16_tn_group': lambda a: _tn_group(a),
     'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
 }

@@ -290,3 +290,53 @@ def test_grouped_parameter_gradient_entry_points(device):
     assert rc == 0
     for o, w, (m, *_rest) in zip(outs, want, views):
         assert torch.allclose(o.double(), w, rtol=1e-5, atol=1e-3 * (m.shape[0] ** 0.5) * 1e-2 + 1e-4)
+
+
+def test_grouped_gradient_work_equals_per_layer_launches(device, monkeypatch):
+    """The end-of-backward grouping of the small parameter-gradient work (ops.flush_deferred_grads) is a reordering of
+    launches only: a flattened module gives the same arena gradient with MBV_WGRAD_GROUP=0 (per-layer launches) and with
+    the grouping on — same kernels' arithmetic, f32 atomics in another order.  fp32 compute, tolerance 5e-3 of the
+    largest entry per parameter: what two runs of ONE mode differ by (the backward's f32 atomics are unordered;
+    test_arena_gradients_equal_plain_autograd uses the same bound).  A backward pass that raises half-way must not leak
+    its pending work into the next pass."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    kw = dict(tiny_kwargs(nx=96, ny=96, q=8), compute_dtype='fp32')
+    scans = [x.to(device) for x in random_scans(kw, [3000, 2500], seed=0)]
+    labels, gt = random_gt(kw, 2, 3, seed=10)
+    batch = (scans, (labels.to(device), gt.to(device)))
+    grads = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('MBV_WGRAD_GROUP', mode)
+        monkeypatch.setenv('MBV_TN_GROUP', mode)
+        torch.manual_seed(0)
+        m = MaskBevModule(**kw).to(device).train()
+        m.log_scalars = False
+        h = m._panoptic_head._panoptic_head
+        h.num_points, h.point_seed = 600, 5
+        arena = m.flatten_parameters()
+        if mode == '1':
+            # a pass that dies after some work was queued: nothing of it may reach the arena later
+            class Boom(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, x):
+                    return x.clone()
+
+                @staticmethod
+                def backward(ctx, g):
+                    raise RuntimeError('boom')
+            lin = m._panoptic_head._panoptic_head.cls_embed
+            x = torch.randn(16, lin.in_features, device=device, requires_grad=True)
+            with pytest.raises(RuntimeError, match='boom'):
+                lin(Boom.apply(x)).sum().backward()
+            torch.cuda.synchronize()
+            arena.zero_grad()
+        m.training_step(batch, 0).backward()
+        torch.cuda.synchronize()
+        assert not ops._PENDING or all(not any(lists) for lists in ops._PENDING.values()) or mode == '1'
+        grads[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    ops._PENDING.clear()
+    for n, g0 in grads['0'].items():
+        g1 = grads['1'][n]
+        scale = float(g0.abs().max()) + 1e-12
+        assert float((g0 - g1).abs().max()) <= 5e-3 * scale + 1e-9, n

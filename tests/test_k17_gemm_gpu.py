@@ -122,6 +122,34 @@ def test_tn_weight_gradient_accumulates(dt, m, n, k, splits):
 
 
 @gpu
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_tn_group_equals_per_layer_products(dt):
+    """mbv_gemm16_tn_group: many weight gradients in one launch per 48 — single-part entries (owner adds in place),
+    multi-part entries (stored parts + k_add_parts_group), ragged token counts and edges, strided operands, a skipped
+    empty entry, more entries than one launch holds.  Against f64 on the same rounded inputs, and bit-reproducible."""
+    from mask_bev_amd import ops
+    shapes = [(256, 128, 128), (1000, 576, 192), (4099, 200, 72), (16384, 384, 1536), (70, 768, 192), (65536, 192, 192),
+              (5000, 96, 256), (21504, 544, 256), (4096, 2304, 768), (1024, 1536, 1536), (8200, 8, 8)]
+    shapes = shapes + [(300 + 17 * i, 64 + 8 * (i % 5), 40 + 8 * (i % 3)) for i in range(45)]     # 56 entries: two launches
+    items, refs = [], []
+    for i, (m, n, k) in enumerate(shapes):
+        g, x = _rand((m, n + 8), dt, 100 + i)[:, :n], _rand((m, k), dt, 200 + i)        # g with a row stride
+        acc0 = _rand((n, k), torch.float32, 300 + i)
+        items.append((g, x, acc0.clone()))
+        refs.append((acc0.double() + g.double().t() @ x.double(), m))
+    ops.gemm16_tn_group(items)
+    for (g, x, acc), (ref, m) in zip(items, refs):
+        err = (acc.double() - ref).abs().max().item()
+        assert err < 3e-5 * math.sqrt(m) * 4, (tuple(g.shape), tuple(x.shape), err)
+    again = [(g, x, _rand(tuple(a.shape), torch.float32, 300 + i)) for i, (g, x, a) in enumerate(items)]
+    ops.gemm16_tn_group(again)
+    for (_, _, a), (_, _, b) in zip(items, again):
+        assert torch.equal(a, b)
+    with pytest.raises(ops.MaskBevHipError):
+        ops.gemm16_tn_group([(items[0][0], items[0][1], items[0][2].t())])
+
+
+@gpu
 def test_tn_store_batched():
     from mask_bev_amd import ops
     dt = torch.bfloat16
