@@ -778,8 +778,10 @@ def gemm16_policy() -> str:
 
 
 # below these token counts the 128 x 128 tiles under-fill the chip and the library's split / stream-K kernels win
-# (scratch/bench_gemm.py on the bench shapes, profiles/r02/c_gemm_shapes.txt)
-_K17_MIN_TOKENS = {'fused': 8192, 'wgrad': 4096}
+# (scratch/bench_gemm.py on the bench shapes, profiles/r02/c_gemm_shapes.txt).  The fused FFN forms pay down to 4096
+# tokens (Swin stage 3): the K17 GEMM alone is slower there than the library's, but it replaces GEMM + GELU forward and
+# GEMM + activation-backward/column-sum pass backward — step A/B 8192 / 4096 / 1024: 29.19 / 28.92 / 30.51 ms
+_K17_MIN_TOKENS = {'fused': int(os.environ.get('MBV_K17_FUSED_MIN', '4096')), 'wgrad': 4096}
 
 
 def _k17_wants(kind: str, tokens: int) -> bool:
@@ -1692,18 +1694,25 @@ class PackedMasks:
 
 
 @torch.no_grad()
-def pack_binary_masks(masks: torch.Tensor) -> PackedMasks:
-    """masks (N, H, W) with values in {0, 1} → bit-packed form for :func:`point_sample_packed`."""
+def pack_binary_masks(masks: torch.Tensor, out: Optional[PackedMasks] = None) -> PackedMasks:
+    """masks (N, H, W) with values in {0, 1} → bit-packed form for :func:`point_sample_packed` (into ``out``'s words
+    when given: the HIP-graph step packs each batch's dense targets straight into its static buffer)."""
     lib = _lib.load()
     _need_gpu(masks)
     masks = masks.float().contiguous()
     n, h, w = masks.shape
-    words = torch.empty((n, lib.mbv_packed_mask_words(h, w)), dtype=torch.int32, device=masks.device)
+    if out is not None:
+        words = out.words
+        if (out.h, out.w) != (h, w) or tuple(words.shape) != (n, lib.mbv_packed_mask_words(h, w)) \
+                or words.dtype != torch.int32 or not words.is_contiguous() or words.device != masks.device:
+            raise MaskBevHipError('pack_binary_masks: `out` does not fit these masks')
+    else:
+        words = torch.empty((n, lib.mbv_packed_mask_words(h, w)), dtype=torch.int32, device=masks.device)
     for i in range(0, n, 65535):
         rc = lib.mbv_pack_binary_masks(_ptr(masks[i:i + 65535]), min(65535, n - i), h, w, _ptr(words[i:i + 65535]),
                                        _stream())
         check(rc, 'mbv_pack_binary_masks')
-    return PackedMasks(words, h, w)
+    return out if out is not None else PackedMasks(words, h, w)
 
 
 @torch.no_grad()
