@@ -426,6 +426,23 @@ int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32
  * the partials' column sums itself, typically for many layers at once with mbv_colsum_accum_group. */
 int mbv_add_layernorm_bwd_direct(int64_t rows, int32_t C);
 
+/* Patch merging without the unfolded copy: y (batch, h/2, w/2, 4c) = LayerNorm_{4c}(unfold_{2x2, stride 2}(x)) for a
+ * channels-last f32 token map x (batch, h, w, c), h and w even, channel order c*4 + kh*2 + kw — the nn.Unfold order of
+ * mmdet's PatchMerging as built at mask_bev/models/networks/swin/swin.py:611-616 (its `sampler` + `norm`; the `reduction`
+ * Linear follows as a GEMM on y).  Element 4v + k of row (b, oh, ow) is channel v of pixel (2oh + k/2, 2ow + k%2): K12's
+ * kernels gather / scatter with that addressing, so the (batch, h/2, w/2, 4c) copy, whose elements land 4 bytes at a
+ * time, is never written and the backward's dx arrives in x's layout (every pixel belongs to exactly one row).
+ * y: MBV_DT_F32 / BF16 / F16 (y_dtype); mean / rstd (batch*h/2*w/2) f32 are saved for the backward; dgamma / dbeta (4c),
+ * accumulate, partial_ws (mbv_add_layernorm_bwd_blocks(rows, 4c) * 2 * 4c floats) and defer_reduce as in
+ * mbv_add_layernorm_bwd. */
+int mbv_merge_layernorm_supported(int32_t h, int32_t w, int32_t c);
+int mbv_merge_layernorm_fwd(const float* x, int64_t batch, int32_t h, int32_t w, int32_t c, const float* gamma,
+                            const float* beta, float eps, void* y, int32_t y_dtype, float* mean, float* rstd,
+                            void* stream);
+int mbv_merge_layernorm_bwd(const void* dy, int32_t dy_dtype, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, int64_t batch, int32_t h, int32_t w, int32_t c, float* dx, float* dgamma,
+                            float* dbeta, int32_t accumulate, float* partial_ws, int32_t defer_reduce, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K14 — batch producer: instance-id map → instance ids → per-instance binary masks.
  * Replaces: FilterSmallMasks + MaskToLabelInstanceMasks of the reference's data pipeline

@@ -78,6 +78,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_add_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P, _P,
                                              _I, _P]),
     'mbv_add_layernorm_bwd_direct': (ctypes.c_int, [_L, _I]),
+    'mbv_merge_layernorm_supported': (ctypes.c_int, [_I, _I, _I]),
+    'mbv_merge_layernorm_fwd': (ctypes.c_int, [_P, _L, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
+    'mbv_merge_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     'mbv_colsum_accum_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_instance_ids': (ctypes.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_expand_instance_masks': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

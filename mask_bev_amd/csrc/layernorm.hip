@@ -44,6 +44,29 @@ __device__ __forceinline__ void store4(void* base, int kind, long elem, float4 v
   *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = u;
 }
 
+// Patch-merging rows (mmdet PatchMerging, mask_bev/models/networks/swin/swin.py:611-616: nn.Unfold(2, stride 2) of a
+// (B, H, W, C) token map, channel order c * 4 + kh * 2 + kw): row (b, oh, ow) of 4 C elements is gathered from the
+// four pixels (2 oh + kh, 2 ow + kw) of the f32 map — element 4 v + k of the row is channel v of pixel k — so the
+// unfolded copy (and its scattered 4-byte writes) never exists; the backward scatters dx the same way.
+struct MergeGeom {
+  int on;                            // 0: plain rows
+  int C, W, OW, OHW;                 // input channels, input width, output width, output pixels per sample
+  long sample;                       // H * W * C
+};
+__device__ __forceinline__ long merge_base(const MergeGeom& m, long row, int v) {
+  const long b = row / m.OHW;
+  const int r = (int)(row - b * m.OHW), oh = r / m.OW, ow = r - oh * m.OW;
+  return b * m.sample + ((long)(2 * oh) * m.W + 2 * ow) * m.C + v;
+}
+__device__ __forceinline__ float4 merge_load(const float* x, const MergeGeom& m, long row, int v) {
+  const float* p = x + merge_base(m, row, v);
+  return make_float4(p[0], p[m.C], p[(long)m.W * m.C], p[(long)m.W * m.C + m.C]);
+}
+__device__ __forceinline__ void merge_store(float* x, const MergeGeom& m, long row, int v, float4 d) {
+  float* p = x + merge_base(m, row, v);
+  p[0] = d.x; p[m.C] = d.y; p[(long)m.W * m.C] = d.z; p[(long)m.W * m.C + m.C] = d.w;
+}
+
 struct LnIo {
   const void* a; const void* b;      // inputs (b nullable)
   int a_bf16, b_bf16;
@@ -51,6 +74,7 @@ struct LnIo {
   float* s;                          // the sum, f32 (saved for the backward; nullable only when b == nullptr && !a_bf16)
   void* y; int y_bf16;
   float* mean; float* rstd;
+  MergeGeom mg;                      // mg.on: a is the f32 (B, H, W, C) map the rows are gathered from (b, s null)
 };
 
 // ITERS float4 per lane: C <= 256 * ITERS, C % 4 == 0
@@ -68,7 +92,8 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(LnIo io, long rows, int C, f
     const int v = lane + 64 * i;
     x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v < nvec) {
-      x[i] = load4(io.a, io.a_bf16, base + 4 * v);
+      x[i] = io.mg.on ? merge_load(reinterpret_cast<const float*>(io.a), io.mg, row, v)
+                      : load4(io.a, io.a_bf16, base + 4 * v);
       if (io.b) {
         const float4 t = load4(io.b, io.b_bf16, base + 4 * v);
         x[i].x += t.x; x[i].y += t.y; x[i].z += t.z; x[i].w += t.w;
@@ -119,6 +144,7 @@ struct LnBwdIo {
   float* dgamma; float* dbeta; float* dbranch;
   int np;                            // 2, or 3 when the column sums of dx are wanted too (the bias gradient of
                                      // the Linear that produced the residual branch: d(branch) = dx)
+  MergeGeom mg;                      // mg.on: s is the f32 (B, H, W, C) map of the forward, dx has its layout
 };
 
 template <int ITERS>
@@ -149,7 +175,7 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
       g[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v < nvec) {
         const float4 dy = load4(io.dy, io.dy_bf16, base + 4 * v);
-        const float4 sv = *reinterpret_cast<const float4*>(io.s + base + 4 * v);
+        const float4 sv = io.mg.on ? merge_load(io.s, io.mg, row, v) : *reinterpret_cast<const float4*>(io.s + base + 4 * v);
         xh[i].x = (sv.x - mean) * rstd; xh[i].y = (sv.y - mean) * rstd;
         xh[i].z = (sv.z - mean) * rstd; xh[i].w = (sv.w - mean) * rstd;
         dg[i].x += dy.x * xh[i].x; dg[i].y += dy.y * xh[i].y; dg[i].z += dy.z * xh[i].z; dg[i].w += dy.w * xh[i].w;
@@ -173,7 +199,8 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
           const float4 t = load4(io.ds, io.ds_bf16, base + 4 * v);
           d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
         }
-        *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
+        if (io.mg.on) merge_store(io.dx, io.mg, row, v, d);
+        else *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
         if (io.dx_lo) store4(io.dx_lo, io.dx_lo_kind, base + 4 * v, d);
         dxs[i].x += d.x; dxs[i].y += d.y; dxs[i].z += d.z; dxs[i].w += d.w;
       }
@@ -262,6 +289,18 @@ extern "C" int mbv_add_layernorm_bwd_direct(int64_t rows, int32_t C) {
   return mbv_add_layernorm_bwd_blocks(rows, C) <= 64 ? 1 : 0;
 }
 
+static int add_ln_fwd_launch(const LnIo& io, int it, int64_t rows, int32_t C, float eps, hipStream_t st) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  switch (it) {
+    case 1: hipLaunchKernelGGL(k_add_ln_fwd<1>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    case 2: hipLaunchKernelGGL(k_add_ln_fwd<2>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    case 4: hipLaunchKernelGGL(k_add_ln_fwd<4>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    default: hipLaunchKernelGGL(k_add_ln_fwd<8>, grid, block, 0, st, io, (long)rows, C, eps); break;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
 extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
                                      int32_t y_bf16, float* mean, float* rstd, void* stream) {
@@ -271,15 +310,41 @@ extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* 
   if (rows == 0) return MBV_OK;
   if (!a || !gamma || !beta || !y || !mean || !rstd) return MBV_ERR_BAD_ARG;
   if (!sum_out && (b || a_bf16)) return MBV_ERR_BAD_ARG;       // the backward needs the f32 LN input
-  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd};
-  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  switch (it) {
-    case 1: hipLaunchKernelGGL(k_add_ln_fwd<1>, grid, block, 0, st, io, (long)rows, C, eps); break;
-    case 2: hipLaunchKernelGGL(k_add_ln_fwd<2>, grid, block, 0, st, io, (long)rows, C, eps); break;
-    case 4: hipLaunchKernelGGL(k_add_ln_fwd<4>, grid, block, 0, st, io, (long)rows, C, eps); break;
-    default: hipLaunchKernelGGL(k_add_ln_fwd<8>, grid, block, 0, st, io, (long)rows, C, eps); break;
+  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd, MergeGeom{}};
+  return add_ln_fwd_launch(io, it, rows, C, eps, (hipStream_t)stream);
+}
+
+// The backward of `rows` rows of C elements: one kernel, then (many rows) the reduction of the per-block partial rows of
+// the parameter gradients unless the caller defers it.
+static int add_ln_bwd_launch(LnBwdIo io, int it, int64_t rows, int32_t C, int32_t accumulate, float* partial_ws,
+                             int32_t defer_reduce, hipStream_t st) {
+  const int np = io.np;
+  const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
+  const bool direct = nblk <= 64;          // few rows (the decoder's B*Q tokens): ≤ 64 adds per address, one launch
+  io.partial = direct ? nullptr : partial_ws;
+  if (direct && !accumulate) {
+    MBV_CHECK_HIP(mbv_fill_async(io.dgamma, 0, (size_t)C * 4, st));
+    MBV_CHECK_HIP(mbv_fill_async(io.dbeta, 0, (size_t)C * 4, st));
   }
+  const dim3 grid(nblk), block(512);
+  const size_t lds = (size_t)np * C * sizeof(double);
+  switch (it) {
+    case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
+    case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;
+    case 4: hipLaunchKernelGGL(k_add_ln_bwd<4>, grid, block, lds, st, io, (long)rows, C); break;
+    default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
+  }
+  MBV_CHECK_LAUNCH();
+  if (direct) return MBV_OK;
+  // defer_reduce (accumulating callers only): the (nblk, np, C) partial rows stay in partial_ws and the caller adds
+  // their column sums later — mbv_colsum_accum_group with rows = nblk, ld = np * C, one entry per parameter
+  if (defer_reduce && accumulate) return MBV_OK;
+  if (!accumulate) {
+    MBV_CHECK_HIP(mbv_fill_async(io.dgamma, 0, (size_t)C * 4, st));
+    MBV_CHECK_HIP(mbv_fill_async(io.dbeta, 0, (size_t)C * 4, st));
+  }
+  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((np * C + 63) / 64), (unsigned)((nblk + 63) / 64)), dim3(256), 0,
+                     st, partial_ws, nblk, C, np, io.dgamma, io.dbeta, io.dbranch);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -303,34 +368,54 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
   }
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
   if (dx_lo && dx_lo_dtype != MBV_DT_BF16 && dx_lo_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
-  const int np = dbranch_bias ? 3 : 2;
-  const int nblk = (int)mbv_add_layernorm_bwd_blocks(rows, C);
-  const bool direct = nblk <= 64;          // few rows (the decoder's B*Q tokens): ≤ 64 adds per address, one launch
-  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, direct ? nullptr : partial_ws,
-             dgamma, dbeta, dbranch_bias, np};
-  if (direct && !accumulate) {
-    MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
-    MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
-  }
-  const dim3 grid(nblk), block(512);
-  const size_t lds = (size_t)np * C * sizeof(double);
-  switch (it) {
-    case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
-    case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;
-    case 4: hipLaunchKernelGGL(k_add_ln_bwd<4>, grid, block, lds, st, io, (long)rows, C); break;
-    default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
-  }
-  MBV_CHECK_LAUNCH();
-  if (direct) return MBV_OK;
-  // defer_reduce (accumulating callers only): the (nblk, np, C) partial rows stay in partial_ws and the caller adds
-  // their column sums later — mbv_colsum_accum_group with rows = nblk, ld = np * C, one entry per parameter
-  if (defer_reduce && accumulate) return MBV_OK;
-  if (!accumulate) {
-    MBV_CHECK_HIP(mbv_fill_async(dgamma, 0, (size_t)C * 4, st));
-    MBV_CHECK_HIP(mbv_fill_async(dbeta, 0, (size_t)C * 4, st));
-  }
-  hipLaunchKernelGGL(k_ln_param_reduce, dim3((unsigned)((np * C + 63) / 64), (unsigned)((nblk + 63) / 64)), dim3(256), 0,
-                     st, partial_ws, nblk, C, np, dgamma, dbeta, dbranch_bias);
-  MBV_CHECK_LAUNCH();
-  return MBV_OK;
+  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, nullptr,
+             dgamma, dbeta, dbranch_bias, dbranch_bias ? 3 : 2, MergeGeom{}};
+  return add_ln_bwd_launch(io, it, rows, C, accumulate, partial_ws, defer_reduce, st);
+}
+
+// ---- patch merging: unfold(2 x 2, stride 2) + LayerNorm(4 C) without the unfolded copy (see MergeGeom) --------------
+static bool merge_geom(int64_t batch, int32_t h, int32_t w, int32_t c, MergeGeom& m, int64_t& rows) {
+  if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (h & 1) || (w & 1)) return false;
+  m.on = 1; m.C = c; m.W = w; m.OW = w / 2; m.OHW = (h / 2) * (w / 2);
+  m.sample = (long)h * w * c;
+  rows = batch * m.OHW;
+  return true;
+}
+
+extern "C" int mbv_merge_layernorm_supported(int32_t h, int32_t w, int32_t c) {
+  return (h > 0 && w > 0 && !(h & 1) && !(w & 1) && c > 0 && iters_for(4 * c)) ? 1 : 0;
+}
+
+// y (batch, h/2, w/2, 4 c) = LayerNorm_{4c}(unfold_{2x2}(x (batch, h, w, c) f32)); y 16-bit or f32 (y_dtype);
+// mean / rstd (batch * h/2 * w/2) saved for the backward
+extern "C" int mbv_merge_layernorm_fwd(const float* x, int64_t batch, int32_t h, int32_t w, int32_t c, const float* gamma,
+                                       const float* beta, float eps, void* y, int32_t y_dtype, float* mean, float* rstd,
+                                       void* stream) {
+  if (batch == 0) return MBV_OK;
+  MergeGeom m{};
+  int64_t rows = 0;
+  if (!merge_geom(batch, h, w, c, m, rows)) return MBV_ERR_UNSUPPORTED;
+  const int it = iters_for(4 * c);
+  if (!it) return MBV_ERR_UNSUPPORTED;
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return MBV_ERR_BAD_ARG;
+  LnIo io{x, nullptr, MBV_DT_F32, 0, gamma, beta, nullptr, y, y_dtype, mean, rstd, m};
+  return add_ln_fwd_launch(io, it, rows, 4 * c, eps, (hipStream_t)stream);
+}
+
+// dx (batch, h, w, c) f32 = the input gradient (every pixel belongs to exactly one row: dx is fully written);
+// dgamma / dbeta (4 c) as in mbv_add_layernorm_bwd (accumulate, partial_ws of mbv_add_layernorm_bwd_blocks(rows, 4 c)
+// * 2 * 4 c floats, defer_reduce)
+extern "C" int mbv_merge_layernorm_bwd(const void* dy, int32_t dy_dtype, const float* x, const float* mean,
+                                       const float* rstd, const float* gamma, int64_t batch, int32_t h, int32_t w,
+                                       int32_t c, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+                                       float* partial_ws, int32_t defer_reduce, void* stream) {
+  if (batch == 0) return MBV_OK;
+  MergeGeom m{};
+  int64_t rows = 0;
+  if (!merge_geom(batch, h, w, c, m, rows)) return MBV_ERR_UNSUPPORTED;
+  const int it = iters_for(4 * c);
+  if (!it) return MBV_ERR_UNSUPPORTED;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return MBV_ERR_BAD_ARG;
+  LnBwdIo io{dy, dy_dtype, nullptr, 0, x, mean, rstd, gamma, dx, nullptr, 0, nullptr, dgamma, dbeta, nullptr, 2, m};
+  return add_ln_bwd_launch(io, it, rows, 4 * c, accumulate, partial_ws, defer_reduce, (hipStream_t)stream);
 }

@@ -144,6 +144,13 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, pw, 0, ph))
             h, w = h + ph, w + pw
         oh, ow = (h - 2) // s + 1, (w - 2) // s + 1
+        n = self.norm
+        if (s == 2 and not (ph or pw) and ops.merge_layernorm_supported(x) and n.weight is not None
+                and n.bias is not None):
+            # unfold + LayerNorm as one gather pass (K12): no (B, H/2, W/2, 4C) copy with 4-byte scattered elements
+            lo = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES
+            y = ops.merge_layernorm(x, n.weight, n.bias, n.eps, torch.get_autocast_dtype('cuda') if lo else torch.float32)
+            return self.reduction(y)
         if s == 2:
             x = x[:, :oh * 2, :ow * 2].reshape(b, oh, 2, ow, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(b, oh, ow, 4 * c)
         else:

@@ -2063,6 +2063,82 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
     return (y, a if s is None else s) if return_sum else y
 
 
+class _MergeLayerNorm(torch.autograd.Function):
+    """LayerNorm_{4C}(unfold_{2x2, stride 2}(x)) for a channels-last f32 (B, H, W, C) map, gathered / scattered by K12's
+    addressing (mbv_merge_layernorm_*): the unfolded copy never exists, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        lib = _lib.load()
+        _need_gpu(x, weight, bias)
+        b, h, w, c = x.shape
+        if x.dtype != torch.float32 or weight.dtype != torch.float32 or bias.dtype != torch.float32 \
+                or out_dtype not in _ACT_DTYPES or not lib.mbv_merge_layernorm_supported(h, w, c):
+            raise MaskBevHipError('merge_layernorm: f32 (B, H, W, C) map with even H, W and 4C <= 2048, f32 parameters')
+        x2 = x.contiguous()
+        rows = b * (h // 2) * (w // 2)
+        y = torch.empty((b, h // 2, w // 2, 4 * c), dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        wc, bc = weight.contiguous(), bias.contiguous()
+        check(lib.mbv_merge_layernorm_fwd(_ptr(x2), b, h, w, c, _ptr(wc), _ptr(bc), float(eps), _ptr(y),
+                                          _dt_flag(out_dtype), _ptr(mean), _ptr(rstd), _stream()),
+              'mbv_merge_layernorm_fwd')
+        ctx.save_for_backward(x2, mean, rstd, wc)
+        ctx.weight, ctx.bias = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, mean, rstd, w = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        b, h, wd, c = x.shape
+        c4 = 4 * c
+        rows = mean.numel()
+        gy = gy.contiguous()
+        if gy.dtype not in _ACT_DTYPES:
+            gy = gy.float()
+        dx = torch.empty_like(x)
+        direct = (getattr(weight, '_mbv_arena', False) and getattr(bias, '_mbv_arena', False)
+                  and weight.grad is not None and bias.grad is not None
+                  and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32)
+        if direct:
+            dgamma, dbeta = weight.grad, bias.grad
+        else:
+            dgamma = torch.empty(c4, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c4, dtype=torch.float32, device=x.device)
+        nblk = lib.mbv_add_layernorm_bwd_blocks(rows, c4)
+        ws = torch.empty(max(1, nblk * 2 * c4), dtype=torch.float32, device=x.device)
+        defer = bool(direct and not lib.mbv_add_layernorm_bwd_direct(rows, c4) and _defer_ok())
+        check(lib.mbv_merge_layernorm_bwd(_ptr(gy), _dt_flag(gy.dtype), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), b, h,
+                                          wd, c, _ptr(dx), _ptr(dgamma), _ptr(dbeta), 1 if direct else 0, _ptr(ws),
+                                          1 if defer else 0, _stream()), 'mbv_merge_layernorm_bwd')
+        if defer:
+            for j, dst in enumerate((dgamma, dbeta)):
+                ok = _defer_colsum(ws, dst, nblk, c4, 2 * c4, offset=j * c4)
+                assert ok, 'deferred LayerNorm parameter reduction could not be queued'
+        if direct:
+            _fire_grad_hooks(weight)
+            _fire_grad_hooks(bias)
+            dgamma = dbeta = None
+        else:
+            dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
+        return dx, dgamma, dbeta, None, None
+
+
+def merge_layernorm_supported(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+            and add_layernorm_supported(4 * x.shape[3]) and os.environ.get('MBV_MERGE_LN', '1') != '0')
+
+
+def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+                    out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """(B, H, W, C) f32 → (B, H/2, W/2, 4C): the 2 x 2 neighbourhood concat of patch merging (channel order
+    ``c*4 + kh*2 + kw``) and its LayerNorm in one pass (K12 with gather addressing)."""
+    return _MergeLayerNorm.apply(x, weight, bias, eps, out_dtype or torch.float32)
+
+
 @torch.no_grad()
 def match_cost_terms(logits: torch.Tensor):
     """logits (G, Q, P) f32 sampled mask logits → (terms (G, 3Q, P) f32 = [softplus(-x); softplus(x); sigmoid(x)]

@@ -85,3 +85,67 @@ def test_layernorm_module_accumulates_into_arena(device):
     assert mine.weight.grad.data_ptr() == arena.grad.data_ptr() + 4 * arena.layout[0][1]
     assert torch.allclose(mine.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(mine.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-6)
+
+
+def _unfold_ref(x):
+    """nn.Unfold(2, stride 2) of a channels-last map: (B, H, W, C) → (B, H/2, W/2, 4C), channel order c*4 + kh*2 + kw
+    (mmdet PatchMerging's sampler, swin.py:611-616)."""
+    b, h, w, c = x.shape
+    u = F.unfold(x.permute(0, 3, 1, 2), kernel_size=2, stride=2)                  # (B, C*4, H/2 * W/2)
+    return u.transpose(1, 2).reshape(b, h // 2, w // 2, 4 * c)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 48), (4, 32, 32, 192), (1, 10, 6, 384), (3, 4, 4, 512), (2, 64, 64, 192)])
+@pytest.mark.parametrize('out_dt', [torch.float32, torch.bfloat16, torch.float16])
+def test_merge_layernorm(device, shape, out_dt):
+    """K12 with patch-merging addressing against nn.Unfold + F.layer_norm in f64: forward, dx (scattered back into the
+    map's layout), dgamma, dbeta.  Tolerances as test_add_layernorm."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    b, h, w, c = shape
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(device).requires_grad_()
+    wt = (torch.rand(4 * c, generator=g) + 0.5).to(device).requires_grad_()
+    bias = torch.randn(4 * c, generator=g).to(device).requires_grad_()
+    xr, wr, br = (t.detach().double().requires_grad_() for t in (x, wt, bias))
+    yr = F.layer_norm(_unfold_ref(xr), (4 * c,), wr, br, 1e-5)
+    y = ops.merge_layernorm(x, wt, bias, 1e-5, out_dt)
+    assert y.dtype == out_dt and tuple(y.shape) == (b, h // 2, w // 2, 4 * c)
+    LO = {torch.bfloat16: 1.6e-2, torch.float16: 2e-3}
+    tol = LO.get(out_dt, 2e-5)
+    assert torch.allclose(y.double(), yr, rtol=tol, atol=tol)
+    gy = torch.randn(y.shape, generator=g).to(device)
+    (y.double() * gy.double()).sum().backward()
+    (yr * gy.double()).sum().backward()
+
+    def close(got, want, t):
+        return float((got.double() - want).abs().max()) <= t * (float(want.abs().max()) + 1e-12)
+
+    lowp = out_dt in LO
+    assert close(x.grad, xr.grad, LO[out_dt] if lowp else 3e-5)
+    assert close(wt.grad, wr.grad, (1e-2 if out_dt == torch.bfloat16 else 2e-3) if lowp else 1e-4)
+    assert close(bias.grad, br.grad, (1e-2 if out_dt == torch.bfloat16 else 2e-3) if lowp else 1e-4)
+
+
+def test_patch_merging_module_equals_unfused_path(device, monkeypatch):
+    """layers.PatchMerging through the gather kernel and through the copy + K12 path: same output and gradients (f32
+    compute; the two differ only in the order of the f32 partial sums of dgamma / dbeta); odd maps take the padded path."""
+    from mask_bev_amd.layers import PatchMerging
+    torch.manual_seed(1)
+    m = PatchMerging(96, 192).to(device)
+    with torch.no_grad():
+        m.norm.weight.uniform_(0.5, 1.5)
+        m.norm.bias.normal_()
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('MBV_MERGE_LN', mode)
+        x = torch.randn(2, 16, 20, 96, device=device, generator=torch.Generator(device=device).manual_seed(3)).requires_grad_()
+        for p in m.parameters():
+            p.grad = None
+        y = m(x)
+        y.square().sum().backward()
+        res[mode] = (y.detach(), x.grad, m.norm.weight.grad.clone(), m.norm.bias.grad.clone(), m.reduction.weight.grad.clone())
+    for a, b in zip(res['1'], res['0']):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    monkeypatch.setenv('MBV_MERGE_LN', '1')
+    y = m(torch.randn(1, 7, 9, 96, device=device))
+    assert tuple(y.shape) == (1, 4, 5, 192)
