@@ -607,6 +607,26 @@ int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, 
                   int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* K18 — GroupNorm of NCHW maps fused with its surroundings in mmcv's ConvModule (conv -> GroupNorm(32) [-> ReLU]) as
+ * the pixel decoder builds it (mask_bev/models/head/mask_bev_panoptic_head.py:119-123 -> mmdet MSDeformAttnPixelDecoder
+ * input_convs / lateral_convs / output_convs) and the FPN step  lateral + F.interpolate(previous, bilinear,
+ * align_corners=False)  between them.  x (batch, channels, h, w) in x_dtype (MBV_DT_*), h*w % 4 == 0, 16-byte aligned;
+ *   y = GroupNorm(x; groups, gamma, beta, eps)  [+ up-sampled `add` (batch, channels, add_h, add_w), w % 4 == 0]  [ReLU]
+ * stored in y_dtype; mean / rstd (batch * groups) f32 are saved for the backward; statistics in f64 (biased variance).
+ * Backward: dx in dx_dtype, dgamma / dbeta (channels) stored or (accumulate != 0) added to; the ReLU gate is recomputed
+ * from x with the forward's arithmetic; the gradient of `add` is the up-sampling's backward of dy (left to the caller).
+ * plane_sums: batch * channels * 2 floats of scratch. */
+int mbv_groupnorm_supported(int32_t channels, int32_t groups, int32_t h, int32_t w);
+size_t mbv_groupnorm_workspace_bytes(int64_t batch, int32_t channels, int32_t groups, int32_t h, int32_t w);
+int mbv_groupnorm_fwd(const void* x, int32_t x_dtype, int64_t batch, int32_t channels, int32_t h, int32_t w,
+                      int32_t groups, const float* gamma, const float* beta, float eps, const void* add,
+                      int32_t add_dtype, int32_t add_h, int32_t add_w, int32_t relu, void* y, int32_t y_dtype, float* mean,
+                      float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+int mbv_groupnorm_bwd(const void* dy, int32_t dy_dtype, const void* x, int32_t x_dtype, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int64_t batch, int32_t channels, int32_t h,
+                      int32_t w, int32_t groups, int32_t relu, void* dx, int32_t dx_dtype, float* dgamma, float* dbeta,
+                      int32_t accumulate, float* plane_sums, void* stream);
+
 /* The weight gradients of `count` Linears in one GEMM launch (+ one parts-add launch) per 48 of them:
  *   dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])          for i < count.
  * Replaces the per-layer weight-gradient GEMMs of autograd's Linear backward (the same layers as above): a weight

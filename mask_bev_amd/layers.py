@@ -184,9 +184,21 @@ class ConvGN(nn.Module):
         self.gn = nn.GroupNorm(groups, cout)
         self.relu = relu
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.gn(conv1x1(self.conv, x) if self.conv.kernel_size == (1, 1) and x.is_cuda else self.conv(x))
-        return F.relu(x) if self.relu else x
+    def forward(self, x: torch.Tensor, add_upsampled: Optional[torch.Tensor] = None, conv_input: bool = False) -> torch.Tensor:
+        """``add_upsampled``: a coarser (B, C, h, w) map whose bilinear up-sampling is added to the normalised result
+        (the FPN step of the pixel decoder: ``lateral + F.interpolate(previous)``); ``conv_input``: the result only
+        feeds convolutions, so under autocast it is stored in the autocast dtype (what they would cast it to)."""
+        y = conv1x1(self.conv, x) if self.conv.kernel_size == (1, 1) and x.is_cuda else self.conv(x)
+        if ops.group_norm_supported(y, self.gn.num_groups) and self.gn.weight is not None and \
+                (add_upsampled is None or (y.shape[-1] % 4 == 0 and add_upsampled.dtype in ops._ACT_DTYPES)):
+            lo = (conv_input and torch.is_autocast_enabled('cuda')
+                  and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES)
+            return ops.group_norm(y, self.gn.weight, self.gn.bias, self.gn.num_groups, self.gn.eps, self.relu,
+                                  add_upsampled, torch.get_autocast_dtype('cuda') if lo else torch.float32)
+        y = self.gn(y)
+        if add_upsampled is not None:
+            y = y + F.interpolate(add_upsampled, size=y.shape[-2:], mode='bilinear', align_corners=False)
+        return F.relu(y) if self.relu else y
 
 
 _SINE_CACHE: Dict[Tuple, torch.Tensor] = {}

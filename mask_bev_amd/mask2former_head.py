@@ -138,9 +138,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with ctx:
             tail = list(outs)
             for j, i in enumerate(range(n - nl - 1, -1, -1)):
-                cur = self.lateral_convs[j](feats[i])
-                y = cur + F.interpolate(tail[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
-                tail.append(self.output_convs[j](y))
+                # K18: GroupNorm + up-sampled add of the coarser level in one pass, stored for the 3 x 3 convolution
+                y = self.lateral_convs[j](feats[i], add_upsampled=tail[-1], conv_input=True)
+                # outputs beyond num_outs only feed the next FPN step / the mask-feature projection (convolutions)
+                tail.append(self.output_convs[j](y, conv_input=len(tail) >= self.num_outs))
             mask_feature = (conv1x1(self.mask_feature, tail[-1]) if tail[-1].is_cuda
                             else self.mask_feature(tail[-1]))
         if side is not None:

@@ -2063,6 +2063,90 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
     return (y, a if s is None else s) if return_sum else y
 
 
+class _GroupNorm(torch.autograd.Function):
+    """K18: ``y = GroupNorm(x) [+ bilinear-upsampled add] [ReLU]`` on an NCHW map, stored in ``out_dtype``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu, add, out_dtype):
+        lib = _lib.load()
+        _need_gpu(x, weight, bias)
+        b, c, h, w = x.shape
+        if (x.dtype not in _ACT_DTYPES or out_dtype not in _ACT_DTYPES or weight.dtype != torch.float32
+                or bias.dtype != torch.float32 or not lib.mbv_groupnorm_supported(c, groups, h, w)):
+            raise MaskBevHipError('group_norm: (B, C, H, W) f32 / bf16 / fp16 map with H*W % 4 == 0, f32 parameters')
+        x2 = x.contiguous()
+        add2 = None
+        if add is not None:
+            if add.dim() != 4 or add.shape[:2] != x.shape[:2] or add.dtype not in _ACT_DTYPES or w % 4:
+                raise MaskBevHipError('group_norm: the added map must be (B, C, h, w) and W % 4 == 0')
+            add2 = add.contiguous()
+        y = torch.empty((b, c, h, w), dtype=out_dtype, device=x.device)
+        mean = torch.empty(b * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(b * groups, dtype=torch.float32, device=x.device)
+        wc, bc = weight.contiguous(), bias.contiguous()
+        nbytes = lib.mbv_groupnorm_workspace_bytes(b, c, groups, h, w)
+        ws = _workspace(nbytes, x.device)
+        check(lib.mbv_groupnorm_fwd(_ptr(x2), _dt_flag(x2.dtype), b, c, h, w, groups, _ptr(wc), _ptr(bc), float(eps),
+                                    _ptr(add2), _dt_flag(add2.dtype) if add2 is not None else 0,
+                                    add2.shape[2] if add2 is not None else 0, add2.shape[3] if add2 is not None else 0,
+                                    1 if relu else 0, _ptr(y), _dt_flag(out_dtype), _ptr(mean), _ptr(rstd), _ptr(ws),
+                                    int(nbytes), _stream()), 'mbv_groupnorm_fwd')
+        ctx.save_for_backward(x2, mean, rstd, wc, bc)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.meta = (groups, bool(relu), None if add is None else (tuple(add.shape), add.dtype), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, mean, rstd, w, bvec = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        groups, relu, add_meta, x_dtype = ctx.meta
+        b, c, h, wd = x.shape
+        gy = gy.contiguous()
+        if gy.dtype not in _ACT_DTYPES:
+            gy = gy.float()
+        dx = torch.empty_like(x)
+        direct = (getattr(weight, '_mbv_arena', False) and getattr(bias, '_mbv_arena', False)
+                  and weight.grad is not None and bias.grad is not None
+                  and weight.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32)
+        if direct:
+            dgamma, dbeta = weight.grad, bias.grad
+        else:
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        sums = torch.empty(b * c * 2, dtype=torch.float32, device=x.device)
+        check(lib.mbv_groupnorm_bwd(_ptr(gy), _dt_flag(gy.dtype), _ptr(x), _dt_flag(x.dtype), _ptr(mean), _ptr(rstd),
+                                    _ptr(w), _ptr(bvec), b, c, h, wd, groups, 1 if relu else 0, _ptr(dx),
+                                    _dt_flag(dx.dtype), _ptr(dgamma), _ptr(dbeta), 1 if direct else 0, _ptr(sums),
+                                    _stream()), 'mbv_groupnorm_bwd')
+        if direct:
+            _fire_grad_hooks(weight)
+            _fire_grad_hooks(bias)
+            dgamma = dbeta = None
+        else:
+            dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
+        gadd = None
+        if add_meta is not None and ctx.needs_input_grad[6]:
+            shape, adt = add_meta                 # the added map entered through F.interpolate(bilinear, align_corners=False)
+            gadd = torch.ops.aten.upsample_bilinear2d_backward(gy, [h, wd], list(shape), False, None, None).to(adt)
+        return dx, dgamma, dbeta, None, None, None, gadd, None
+
+
+def group_norm_supported(x: torch.Tensor, groups: int) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _ACT_DTYPES and x.shape[1] % groups == 0
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and os.environ.get('MBV_GROUPNORM', '1') != '0')
+
+
+def group_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float = 1e-5,
+               relu: bool = False, add_upsampled: Optional[torch.Tensor] = None,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``relu?(GroupNorm(x) + interpolate(add_upsampled, size=x.shape[-2:], mode='bilinear', align_corners=False))`` for
+    an NCHW map in two passes over ``x`` (K18); ``out_dtype`` (default f32) is the storage type of the result."""
+    return _GroupNorm.apply(x, weight, bias, int(groups), float(eps), bool(relu), add_upsampled,
+                            out_dtype or torch.float32)
+
+
 class _MergeLayerNorm(torch.autograd.Function):
     """LayerNorm_{4C}(unfold_{2x2, stride 2}(x)) for a channels-last f32 (B, H, W, C) map, gathered / scattered by K12's
     addressing (mbv_merge_layernorm_*): the unfolded copy never exists, forward or backward."""

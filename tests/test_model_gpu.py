@@ -142,9 +142,12 @@ def test_loss_on_given_logits_any_gt_count(device, n_gt):
 BF16_TOL = dict(mask_logits_final=6e-2, logits_any_layer=3e-1, loss=2e-2, grad=3e-1, grad_l2=2e-1)
 # fp16 (BASELINE.json configs[4]'s dtype): the same operand positions hold IEEE half — 11 significand bits instead of
 # 8, so rounding is 8x finer, but the discontinuities above remain; gradients are taken through the device-side loss
-# scaler (arena.LossScaler) and compared after dividing by the scale.  Measured: final mask logits 1.7e-3, worst layer
-# 6.5e-3 (mask) / 6.7e-3 (class), loss 2.6e-4, gradients 8e-4 .. 5.4e-2 (max) and 8e-4 .. 3e-2 (L2).  Declared:
-FP16_TOL = dict(mask_logits_final=8e-3, logits_any_layer=3e-2, loss=5e-3, grad=1.5e-1, grad_l2=1e-1)
+# scaler (arena.LossScaler) and compared after dividing by the scale.  Measured: final mask logits 1.7e-3 .. 3.2e-3,
+# loss 1.3e-4 .. 5.5e-4, gradients 5e-4 .. 7.3e-2 (max) and 6e-4 .. 5.3e-2 (L2); worst intermediate layer 4e-3 (mask) /
+# 4e-3 (class) when no attention-mask bit flips and 5.5e-2 / 9.3e-2 when ONE does — which of the two a build shows is
+# decided by last-bit differences (K18 on / off changes the pixel decoder's outputs by one half-precision ulp, 2-6e-4,
+# and the second decoder output by 5e-2: scratch/gn_ab_check.py), so the intermediate-layer bound allows a flip.
+FP16_TOL = dict(mask_logits_final=8e-3, logits_any_layer=1.5e-1, loss=5e-3, grad=1.5e-1, grad_l2=1e-1)
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
