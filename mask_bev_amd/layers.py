@@ -165,6 +165,13 @@ def conv1x1(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     fp16 (MIOpen's fp16 solver for the mask-feature projection was measured to change its result from call to call,
     which made every decoder layer after it — and the gradients — irreproducible)."""
     b, c, h, w = x.shape
+    if (not x.is_contiguous() and x.is_cuda and x.permute(0, 2, 3, 1).is_contiguous()
+            and os.environ.get('MBV_CONV1X1_TOKENS', '1') != '0'):
+        # a channels-last map (the backbone's stage outputs are (B, H, W, C) tokens seen through a permute): the GEMM
+        # reads the token matrix as its transposed operand and writes NCHW; its backward returns token-major gradients
+        y = ops.conv1x1_tokens(x.permute(0, 2, 3, 1).reshape(b, h * w, c), conv.weight.view(conv.weight.shape[0], c),
+                               conv.bias)
+        return y.view(b, -1, h, w)
     w2 = conv.weight.view(conv.weight.shape[0], c).unsqueeze(0).expand(b, -1, -1)
     x2 = x.flatten(2)
     if conv.bias is None:

@@ -2063,6 +2063,52 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
     return (y, a if s is None else s) if return_sum else y
 
 
+class _Conv1x1Tokens(torch.autograd.Function):
+    """A 1 x 1 convolution of a CHANNELS-LAST map handed over as tokens: ``y (B, Cout, HW) = W (Cout, Cin) · x[b]^T + bias``
+    for ``x (B, HW, Cin)`` — the backbone's stage outputs are token-major and the pixel decoder's ConvModules want NCHW,
+    and the GEMM does that turn for free (the token matrix is the transposed operand), forward and backward:
+    ``dx (B, HW, Cin) = dy[b]^T · W`` arrives token-major again.  No (B, C, H, W) copy of the stage outputs either way
+    (four permute copies forward, four backward: 0.28 ms of a 29 ms step).  Library GEMMs (torch.bmm); the operands are
+    cast to the autocast dtype, the gradient of x returns in x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+        with torch.autocast('cuda', enabled=False):
+            xc = x.to(dt)
+            wc = _compute_copy(weight, dt)
+            b = x.shape[0]
+            w3 = wc.unsqueeze(0).expand(b, -1, -1)
+            if bias is None:
+                y = torch.bmm(w3, xc.transpose(1, 2))
+            else:
+                y = torch.baddbmm(_compute_copy(bias, dt).view(1, -1, 1), w3, xc.transpose(1, 2))
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc = ctx.saved_tensors
+        x_dtype, w_dtype, b_dtype = ctx.meta
+        gy = gy.to(xc.dtype).contiguous()
+        b = xc.shape[0]
+        od = {} if xc.dtype == torch.float32 else dict(out_dtype=torch.float32)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.bmm(gy.transpose(1, 2), wc.unsqueeze(0).expand(b, -1, -1), **od).to(x_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy, xc, **od).sum(0).to(w_dtype)
+        if b_dtype is not None and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2), dtype=torch.float32).to(b_dtype)
+        return gx, gw, gb
+
+
+def conv1x1_tokens(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x (B, HW, Cin) tokens, weight (Cout, Cin) → (B, Cout, HW)."""
+    return _Conv1x1Tokens.apply(x, weight, bias)
+
+
 class _GroupNorm(torch.autograd.Function):
     """K18: ``y = GroupNorm(x) [+ bilinear-upsampled add] [ReLU]`` on an NCHW map, stored in ``out_dtype``."""
 

@@ -8,6 +8,7 @@ addressing instead of materialising five layout copies per block.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -180,5 +181,8 @@ class CustomSwinTransformer(nn.Module):
                 x = cut['x_leaf'] = x.detach().requires_grad_()
             x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None)
             if i in self.out_indices:
-                outs.append(out.permute(0, 3, 1, 2).contiguous())
+                # (B, C, H, W) as the reference returns it, but as a VIEW of the channels-last map: the head's 1 x 1
+                # convolutions read it as tokens (layers.conv1x1), so no NCHW copy is made — forward or backward
+                outs.append(out.permute(0, 3, 1, 2) if out.is_cuda and os.environ.get('MBV_CONV1X1_TOKENS', '1') != '0'
+                            else out.permute(0, 3, 1, 2).contiguous())
         return outs

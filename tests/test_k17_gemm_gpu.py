@@ -253,3 +253,32 @@ def test_conv1x1_as_batched_gemm_equals_conv2d(bias):
     got = [y.detach(), x.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
     for a, b in zip(got, want):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
+
+
+@gpu
+@pytest.mark.parametrize('bias', [True, False])
+@pytest.mark.parametrize('autocast', [None, torch.bfloat16])
+def test_conv1x1_of_a_channels_last_view(bias, autocast):
+    """The backbone hands its stage outputs over as (B, C, H, W) VIEWS of channels-last token maps; layers.conv1x1 reads
+    them as the transposed GEMM operand (ops.conv1x1_tokens) and its backward returns a token-major gradient — against
+    nn.Conv2d on a contiguous copy: output, input gradient (and that it is channels-last, i.e. no copy is needed to hand
+    it back to the backbone), weight and bias gradients.  fp32 exact to 2e-4; under bf16 autocast to one bf16 rounding."""
+    from mask_bev_amd.layers import conv1x1
+    device = _dev()
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(96, 64, 1, bias=bias).to(device)
+    tokens = torch.randn(3, 20, 28, 96, device=device, requires_grad=True)          # (B, H, W, C)
+    go = torch.randn(3, 64, 20, 28, device=device)
+    xr = tokens.detach().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    y_ref = conv(xr)
+    y_ref.backward(go)
+    want = [y_ref.detach(), xr.grad.permute(0, 2, 3, 1), conv.weight.grad.clone()] + ([conv.bias.grad.clone()] if bias else [])
+    conv.zero_grad()
+    with torch.autocast('cuda', dtype=autocast or torch.bfloat16, enabled=autocast is not None):
+        y = conv1x1(conv, tokens.permute(0, 3, 1, 2))
+    y.backward(go.to(y.dtype))
+    assert tokens.grad.is_contiguous()
+    got = [y.detach().float(), tokens.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
+    tol = 2e-4 if autocast is None else 2e-2
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + tol * 1e-2
