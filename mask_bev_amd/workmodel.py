@@ -104,6 +104,27 @@ def _tn_group(a) -> Work:
     return ('k_gemm16_tn_group', 'mfma', by, fl)        # bench.py prices the family against the roofline that bounds it
 
 
+def _sz(flag) -> float:
+    return 4.0 if _i(flag) == 0 else 2.0
+
+
+def _groupnorm(a, bwd: bool) -> Work:
+    if bwd:                                     # dy + x read, dx written (the per-plane sums pass re-reads dy and x)
+        n = _i(a[8]) * _i(a[9]) * _i(a[10]) * _i(a[11])
+        return ('k_gn_bwd', 'hbm', n * (_sz(a[1]) + _sz(a[3]) + _sz(a[15])), 0.0)
+    n = _i(a[2]) * _i(a[3]) * _i(a[4]) * _i(a[5])
+    add = _i(a[2]) * _i(a[3]) * _i(a[12]) * _i(a[13]) * _sz(a[11]) if _i(a[10]) else 0.0
+    return ('k_gn_fwd', 'hbm', n * (_sz(a[1]) + _sz(a[16])) + add, 0.0)
+
+
+def _merge_ln(a, bwd: bool) -> Work:
+    if bwd:
+        n = _i(a[6]) * _i(a[7]) * _i(a[8]) * _i(a[9])
+        return ('k_add_ln_bwd', 'hbm', n * (_sz(a[1]) + 4.0 + 4.0), 0.0)
+    n = _i(a[1]) * _i(a[2]) * _i(a[3]) * _i(a[4])
+    return ('k_add_ln_fwd', 'hbm', n * (4.0 + _sz(a[9])), 0.0)
+
+
 def _colsum_group(a) -> Work:
     n = _i(a[6])
     dt, rows, cols = a[1], a[2], a[3]
@@ -148,6 +169,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
     'mbv_colsum_accum_group': lambda a: _colsum_group(a),
     'mbv_gemm16_tn_group': lambda a: _tn_group(a),
+    'mbv_groupnorm_fwd': lambda a: _groupnorm(a, False),
+    'mbv_groupnorm_bwd': lambda a: _groupnorm(a, True),
+    'mbv_merge_layernorm_fwd': lambda a: _merge_ln(a, False),
+    'mbv_merge_layernorm_bwd': lambda a: _merge_ln(a, True),
     'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
 }

@@ -12,6 +12,9 @@ import sys
 
 FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged to the same call)
     ('k_gemm16<TN>', r'k_gemm16I.*Lb1ELb1ELi0E', [r'k_add_parts']),
+    ('k_gemm16_tn_group', r'k_gemm16_tn_group', [r'k_add_parts_group']),
+    ('k_gn_fwd', r'k_gn_apply', [r'k_gn_stats']),
+    ('k_gn_bwd', r'k_gn_bwd_dx', [r'k_gn_bwd_sums']),
     ('k_gemm16<NN>', r'k_gemm16I.*Lb0ELb1ELi0E', [r'k_sum_rows']),
     ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0E', []),
     ('k_adamw', r'k_adamw', []),
