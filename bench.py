@@ -354,7 +354,11 @@ def main():
         if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
                 and args.distribution == 'lidar' and os.path.exists(os.path.join(ROOT, traffic_file))):
             with open(os.path.join(ROOT, traffic_file)) as fh:
-                traffic = {k: v for k, v in json.load(fh).items() if not k.startswith('_')}
+                raw = json.load(fh)
+            traffic = {k: v for k, v in raw.items() if not k.startswith('_')}
+            for k in raw.get('_per_step', []):      # group launches at the end of a backward: recorded per step
+                if k in traffic and k in profile and profile[k]['launches_per_step'] > 0:
+                    traffic[k] = traffic[k] / profile[k]['launches_per_step']
         roof = {}
         for name, ms in times.items():          # in-library / in-stream events recorded inside the timed region
             if not ms or name not in algo:

@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
                                                         const float* __restrict__ loc, const float* __restrict__ attn,
                                                         int level, int levels, int h, int w, int lstart, int num_value,
                                                         int num_query, int heads, int points_rt,
-                                                        float* __restrict__ grad_value) {
+                                                        float* __restrict__ grad_value, int ablate) {
   constexpr int dim = 32, CG = 4;
   const int points = P > 0 ? P : points_rt;
   extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
@@ -588,6 +588,7 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
           const int off = c.off[j];
           if (off < 0) continue;
           const float wj = c.wgt[j] * aw[u];
+          if (ablate & 2) continue;
           atomicAdd(&map[off], (double)(wj * go.x));
           atomicAdd(&map[npix + off], (double)(wj * go.y));
           atomicAdd(&map[2 * npix + off], (double)(wj * go.z));
@@ -597,6 +598,7 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
     }
   }
   __syncthreads();
+  if (ablate & 1) return;
   float* gv = grad_value + ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + split * CG;
   for (int i = threadIdx.x; i < npix; i += 1024)
     *reinterpret_cast<float4*>(gv + (int64_t)i * stride_pix) =
@@ -753,17 +755,18 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
         attr_done = true;
       }
       const int which = part;
+      const int ablate = getenv("MBV_MSDA_ABLATE") ? atoi(getenv("MBV_MSDA_ABLATE")) : 0;     // timing experiments only
       for (int l = num_levels - 1; l >= 0 && (which & 1); --l) {      // finest (longest) level first
         const dim3 grid((unsigned)(batch * num_heads * 8)), block(1024);
         const size_t lds = (size_t)lv.h[l] * lv.w[l] * 4 * sizeof(double);
         if (num_points == 4)
           hipLaunchKernelGGL(k_msda_bwd_value<4>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
                              num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
-                             grad_value);
+                             grad_value, ablate);
         else
           hipLaunchKernelGGL(k_msda_bwd_value<0>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
                              num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
-                             grad_value);
+                             grad_value, ablate);
         MBV_CHECK_LAUNCH();
       }
       if (which & 2) {

@@ -36,6 +36,33 @@ __global__ void __launch_bounds__(256) k_point_sample_fwd(const float* __restric
   out[(int64_t)g * P + p] = v;
 }
 
+// A map of hw floats → LDS.  Eight 16-byte loads per thread are issued before the first LDS store: written as a plain
+// load / store loop the compiler waits for every load in turn (the trip count is a run-time value), i.e. eight
+// dependent memory round trips per 64 KB map instead of one.
+__device__ __forceinline__ void stage_map(float* tile, const float* __restrict__ s, int hw) {
+  const int nt = blockDim.x;
+  if ((hw & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    const int n4 = hw >> 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * nt) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nt;
+        v[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * nt;
+        if (i < n4) t4[i] = v[u];
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += nt) tile[i] = s[i];
+  }
+}
+
 // forward, one workgroup per row: the whole (H, W) map is staged in LDS with coalesced loads, then sampled from
 // LDS — instead of 4 random 4-byte HBM/L2 gathers per point
 __global__ void __launch_bounds__(512) k_point_sample_fwd_lds(const float* __restrict__ src,
@@ -47,24 +74,31 @@ __global__ void __launch_bounds__(512) k_point_sample_fwd_lds(const float* __res
   const int g = blockIdx.x;
   const int hw = H * W;
   const float* s = src + (int64_t)src_index[g] * hw;
-  if ((hw & 3) == 0) {
-    for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
-      *reinterpret_cast<float4*>(&tile[i]) = *reinterpret_cast<const float4*>(s + i);
-  } else {
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = s[i];
-  }
+  stage_map(tile, s, hw);
   __syncthreads();
-  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  const float2* c = reinterpret_cast<const float2*>(coords + (int64_t)coord_index[g] * P * 2);
   float* o = out + (int64_t)g * P;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    const float2 xy = *reinterpret_cast<const float2*>(c + p * 2);
-    Bil b;
-    bil_setup(xy.x, xy.y, H, W, b);
-    float v = 0.f;
+  // batches of 4 points per thread: their coordinate loads are in flight together (one memory round trip per batch)
+  for (int p0 = threadIdx.x; p0 < P; p0 += 4 * (int)blockDim.x) {
+    float2 xy[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (b.o[j] >= 0) v += b.w[j] * tile[b.o[j]];
-    o[p] = v;
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      xy[u] = p < P ? c[p] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      if (p < P) {
+        Bil b;
+        bil_setup(xy[u].x, xy[u].y, H, W, b);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (b.o[j] >= 0) v += b.w[j] * tile[b.o[j]];
+        o[p] = v;
+      }
+    }
   }
 }
 
@@ -123,17 +157,28 @@ __global__ void __launch_bounds__(512) k_point_sample_packed(const uint32_t* __r
   const uint32_t* s = packed + (int64_t)src_index[g] * words_per_map;
   for (int i = threadIdx.x; i < (int)words_per_map; i += blockDim.x) bits[i] = s[i];
   __syncthreads();
-  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  const float2* c = reinterpret_cast<const float2*>(coords + (int64_t)coord_index[g] * P * 2);
   float* o = out + (int64_t)g * P;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    const float2 xy = *reinterpret_cast<const float2*>(c + p * 2);
-    Bil b;
-    bil_setup(xy.x, xy.y, H, W, b);
-    float v = 0.f;
+  for (int p0 = threadIdx.x; p0 < P; p0 += 4 * (int)blockDim.x) {       // 4 coordinate loads in flight per thread
+    float2 xy[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (b.o[j] >= 0 && ((bits[b.o[j] >> 5] >> (b.o[j] & 31)) & 1u)) v += b.w[j];
-    o[p] = v;
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      xy[u] = p < P ? c[p] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      if (p < P) {
+        Bil b;
+        bil_setup(xy[u].x, xy[u].y, H, W, b);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (b.o[j] >= 0 && ((bits[b.o[j] >> 5] >> (b.o[j] & 31)) & 1u)) v += b.w[j];
+        o[p] = v;
+      }
+    }
   }
 }
 
@@ -150,19 +195,36 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
   const int hw = H * W;
   for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = 0.0;
   __syncthreads();
-  const float* c = coords + (int64_t)coord_index[g] * P * 2;
+  const float2* c = reinterpret_cast<const float2*>(coords + (int64_t)coord_index[g] * P * 2);
   const float* go = grad_out + (int64_t)g * P;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    Bil b;
-    bil_setup(c[p * 2], c[p * 2 + 1], H, W, b);
-    const float gv = go[p];
+  for (int p0 = threadIdx.x; p0 < P; p0 += 4 * (int)blockDim.x) {       // 4 + 4 loads in flight per thread
+    float2 xy[4];
+    float gv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], (double)(b.w[j] * gv));
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      xy[u] = p < P ? c[p] : make_float2(0.f, 0.f);
+      gv[u] = p < P ? go[p] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p0 + u * (int)blockDim.x < P) {
+        Bil b;
+        bil_setup(xy[u].x, xy[u].y, H, W, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], (double)(b.w[j] * gv[u]));
+      }
+    }
   }
   __syncthreads();
   float* dst = grad_src + (int64_t)src_index[g] * hw;
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (float)tile[i];
+  if ((hw & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(dst + i) = make_float4((float)tile[i], (float)tile[i + 1], (float)tile[i + 2], (float)tile[i + 3]);
+  } else {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (float)tile[i];
+  }
 }
 
 __global__ void __launch_bounds__(256) k_point_sample_bwd_atomic(const float* __restrict__ grad_out,

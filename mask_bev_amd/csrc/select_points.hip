@@ -169,8 +169,21 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   const int hw = H * W;
   const float* s = src + (int64_t)src_index[row] * hw;
   if ((hw & 3) == 0) {
-    for (int i = tid * 4; i < hw; i += kFusedThreads * 4)
-      *reinterpret_cast<float4*>(&tile[i]) = *reinterpret_cast<const float4*>(s + i);
+    // every 16-byte load of the map is issued before the first LDS store (one memory round trip, not four)
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    const int n4 = hw >> 2;
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * kFusedThreads;
+      v[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * kFusedThreads;
+      if (i < n4) t4[i] = v[u];
+    }
   } else {
     for (int i = tid; i < hw; i += kFusedThreads) tile[i] = s[i];
   }

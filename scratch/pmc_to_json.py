@@ -45,6 +45,12 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
 ]
 
 
+# End-of-backward group launches: the graph step flushes them once per captured graph (two calls per step), the eager
+# step bench.py instruments once per step — their traffic is recorded PER STEP (listed under "_per_step") and bench.py
+# divides by the calls per step it measured.
+PER_STEP = ['k_gemm16_tn_group', 'k_wgrad_small_group', 'k_colsum_group']
+
+
 def load(path, counter):
     acc = collections.defaultdict(list)
     with open(path) as fh:
@@ -63,10 +69,14 @@ def main():
         calls = sum(len(v) for k, v in fetch.items() if re.search(primary, k))
         if not calls:
             continue
+        if name in PER_STEP:
+            # = backward passes of the run (one importance-sampling launch each, graph warm-up iterations included)
+            calls = sum(len(v) for k, v in fetch.items() if re.search(r'k_sample_select', k)) or calls
         f = 2.0 * total(fetch, [primary] + extra) * 1024 / calls
         w = total(write, [primary] + extra) * 1024 / calls
         out[name] = f + w
         rows.append((name, calls, f / 1e6, w / 1e6, (f + w) / 1e6))
+    out['_per_step'] = [n for n in PER_STEP if n in out]
     out['_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py '
                       'semantic_kitti_512 B=4 bf16; FETCH_SIZE doubled (gfx950 128-byte requests counted at 64); '
                       'bytes per C-ABI call, averaged over the calls of the run')
