@@ -1123,7 +1123,11 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
             and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):
         per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
-        if (persistent and (per_layer or (_tn_group_mode() == 'all' and t >= 512)) and _defer_tn_wgrad(g2, x2, acc)):
+        # few-token 16-bit products (the decoder's 400-row output projections: a 256 x 256 result over 400 rows) are a
+        # handful of work items of the grouped launch; alone, the library ran them as ONE 256 x 256 tile — 30 us each
+        few = t <= _SMALL_F32_ROWS and gemm16_policy() == 'auto'
+        if (persistent and (per_layer or few or (_tn_group_mode() == 'all' and t >= 512))
+                and _defer_tn_wgrad(g2, x2, acc)):
             return False                         # K17, grouped with the pass's other weight gradients at its end
         if per_layer:
             gemm16_tn_acc(acc, g2, x2)           # K17: split over the tokens, parts added into the arena
