@@ -1125,7 +1125,7 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
         per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
         # few-token 16-bit products (the decoder's 400-row output projections: a 256 x 256 result over 400 rows) are a
         # handful of work items of the grouped launch; alone, the library ran them as ONE 256 x 256 tile — 30 us each
-        few = t <= _SMALL_F32_ROWS and gemm16_policy() == 'auto'
+        few = t <= 512 and gemm16_policy() == 'auto'       # (Swin stage 4's 1024-token layers stay with the library: measured)
         if (persistent and (per_layer or few or (_tn_group_mode() == 'all' and t >= 512))
                 and _defer_tn_wgrad(g2, x2, acc)):
             return False                         # K17, grouped with the pass's other weight gradients at its end
