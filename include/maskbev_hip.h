@@ -210,6 +210,13 @@ int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int6
  * Supported: L <= 8, L*P <= 16 (mbv_msda_prepare_supported); the caller composes torch ops otherwise. */
 int mbv_msda_prepare_supported(int32_t num_levels, int32_t num_points);
 
+/* The 16-bit GEMM inputs of the query side in one pass: x_lo = lo(x) (value projection input) and q_lo = lo(x + pos)
+ * (offset / attention-weight projection input) for x (rows, C) f32 and pos (pos_rows, C) f32 repeating every pos_rows
+ * rows — `query = query + query_pos` of mmcv MultiScaleDeformableAttention.forward under autocast (same call site).
+ * dtype: MBV_DT_BF16 / MBV_DT_F16; C % 4 == 0. */
+int mbv_msda_query_inputs(const float* x, const float* pos, int64_t rows, int64_t pos_rows, int32_t C, int32_t dtype,
+                          void* x_lo, void* q_lo, void* stream);
+
 int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int32_t is_bf16, const float* ref_points,
                          const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
                          int32_t num_levels, int32_t num_points, float* loc, float* attn, void* stream);

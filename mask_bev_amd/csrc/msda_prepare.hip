@@ -243,6 +243,33 @@ bool fill_norm(const int64_t* shapes_host, int levels, Norm& n) {
   return true;
 }
 
+// The two 16-bit GEMM inputs of the query side in one pass over the f32 token map: x_lo = lo(x) (value projection) and
+// q_lo = lo(x + pos) (offset / weight projections), pos (pos_rows, C) broadcast over the batch.  torch ran a cast and
+// a type-converting add (a non-vectorised kernel: 18 us for 22 MB).  A thread owns 4 consecutive channels.
+__global__ void __launch_bounds__(256) k_msda_query_inputs(const float* __restrict__ x, const float* __restrict__ pos,
+                                                           long n4, long pos_n4, int f16, unsigned short* __restrict__ x_lo,
+                                                           unsigned short* __restrict__ q_lo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[i];
+  const float4 p = reinterpret_cast<const float4*>(pos)[i % pos_n4];
+  const float q[4] = {a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
+  const float v[4] = {a.x, a.y, a.z, a.w};
+  unsigned short xo[4], qo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (f16) {
+      xo[e] = __builtin_bit_cast(unsigned short, (_Float16)v[e]);
+      qo[e] = __builtin_bit_cast(unsigned short, (_Float16)q[e]);
+    } else {
+      xo[e] = f32_to_bf16_rne(v[e]);
+      qo[e] = f32_to_bf16_rne(q[e]);
+    }
+  }
+  reinterpret_cast<uint2*>(x_lo)[i] = make_uint2(xo[0] | ((unsigned)xo[1] << 16), xo[2] | ((unsigned)xo[3] << 16));
+  reinterpret_cast<uint2*>(q_lo)[i] = make_uint2(qo[0] | ((unsigned)qo[1] << 16), qo[2] | ((unsigned)qo[3] << 16));
+}
+
 }  // namespace
 
 extern "C" int mbv_msda_prepare_supported(int32_t num_levels, int32_t num_points) {
@@ -315,4 +342,24 @@ extern "C" int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_att
   return mbv_msda_prepare_bwd_ld(grad_loc, grad_attn, attn, spatial_shapes_host, batch, num_query, num_heads,
                                  num_levels, num_points, out_bf16, grad_offsets, num_heads * lp * 2, grad_logits,
                                  num_heads * lp, stream);
+}
+
+// x (rows, C) f32, pos (pos_rows, C) f32 with rows % pos_rows == 0 (pos repeats every pos_rows rows: the batch
+// broadcast of the pixel decoder's positional encoding, mask_bev_panoptic_head.py:127-136 → mmcv
+// MultiScaleDeformableAttention.forward `query = query + query_pos`); x_lo = lo(x), q_lo = lo(x + pos) in `dtype`
+// (MBV_DT_BF16 / MBV_DT_F16).  C % 4 == 0, 16-byte aligned pointers.
+extern "C" int mbv_msda_query_inputs(const float* x, const float* pos, int64_t rows, int64_t pos_rows, int32_t C,
+                                     int32_t dtype, void* x_lo, void* q_lo, void* stream) {
+  if (rows < 0 || pos_rows <= 0 || C <= 0 || (C & 3)) return MBV_ERR_BAD_ARG;
+  if (dtype != MBV_DT_BF16 && dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
+  if (rows == 0) return MBV_OK;
+  if (!x || !pos || !x_lo || !q_lo || rows % pos_rows) return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(pos)) & 15) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(x_lo) | reinterpret_cast<size_t>(q_lo)) & 7) return MBV_ERR_UNSUPPORTED;
+  const long n4 = rows * (C / 4), pn4 = pos_rows * (C / 4);
+  hipLaunchKernelGGL(k_msda_query_inputs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, pos,
+                     n4, pn4, dtype == MBV_DT_F16 ? 1 : 0, reinterpret_cast<unsigned short*>(x_lo),
+                     reinterpret_cast<unsigned short*>(q_lo));
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
 }

@@ -654,11 +654,20 @@ class _MSDAQuerySide(torch.autograd.Function):
         if dt not in _ACT_DTYPES:
             raise MaskBevHipError('msda_query_side supports f32, bf16 and fp16 compute')
         with torch.autocast('cuda', enabled=False):
-            xb = x.to(dt)
             qb = torch.empty(x.shape, dtype=dt, device=x.device)
-            torch.add(x, pos, out=qb)                     # the sum, stored in the compute dtype by the same launch
             wvc, woc, wac = _compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)
-            value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
+            pos_rows = pos.numel() // e
+            if (dt in _LO_DTYPES and x.dtype == torch.float32 and pos.dtype == torch.float32 and x.is_contiguous()
+                    and pos.is_contiguous() and e % 4 == 0 and (b * n) % pos_rows == 0):
+                xb = torch.empty(x.shape, dtype=dt, device=x.device)      # both 16-bit GEMM inputs in one pass over x
+                check(lib.mbv_msda_query_inputs(_ptr(x), _ptr(pos), b * n, pos_rows, e, _dt_flag(dt), _ptr(xb), _ptr(qb),
+                                                _stream()), 'mbv_msda_query_inputs')
+                # the value map is consumed in f32 (K5): accumulate and store it in f32, no 16-bit round trip + cast
+                value = torch.addmm(bv.float(), xb.view(b * n, e), wvc.t(), out_dtype=torch.float32).view(b, n, e)
+            else:
+                xb = x.to(dt)
+                torch.add(x, pos, out=qb)                 # the sum, stored in the compute dtype by the same launch
+                value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
             off = torch.nn.functional.linear(qb, woc, _compute_copy(bo, dt)).contiguous()
             logit = torch.nn.functional.linear(qb, wac, _compute_copy(ba, dt)).contiguous()
         host = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
