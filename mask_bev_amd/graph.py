@@ -32,6 +32,7 @@ the capture (PyTorch emits its "AccumulateGrad node's stream does not match" war
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -101,9 +102,20 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss_static = self._forward_backward_head()
+        # A/B switch MBV_TN_OVERLAP=1 (one GPU only): the grouped weight-gradient launch of the early stages (≈ 0.65 ms,
+        # nobody's input inside the graph) is taken out of the capture and issued after the replay on a side stream,
+        # beside the eager encoder backward; the captured operands stay alive in the graph's pool (held here), so their
+        # addresses are the replay's.  MEASURED SLOWER — 28.3 vs 27.7 ms: the MFMA / L2-heavy launch slows the
+        # latency-bound per-pillar walks it runs beside by more than it hides (as the optimizer pass did).
+        self._late_tn = [] if (reducer is None and os.environ.get('MBV_TN_OVERLAP', '0') == '1') else None
+        self._tn_stream = torch.cuda.Stream(device=dev) if self._late_tn is not None else None
         self.graph_late = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_late, pool=self.graph.pool()):
-            self._backward_early_stages()
+        ops.set_tn_sink(self._late_tn)
+        try:
+            with torch.cuda.graph(self.graph_late, pool=self.graph.pool()):
+                self._backward_early_stages()
+        finally:
+            ops.set_tn_sink(None)
         torch.cuda.synchronize()
         self._ranges_head, self._ranges_late = self._arena_ranges()
 
@@ -193,7 +205,14 @@ class GraphedTrainStep:
             handles += early + self.reducer.start_ranges(self.arena, [r for r in rest if r[1] > r[0]])
             self.reducer.finish_arena(self.arena, handles, self.opt)
         else:
+            if self._late_tn:                              # the early stages' weight gradients, beside the encoder backward
+                main = torch.cuda.current_stream()
+                self._tn_stream.wait_stream(main)
+                with torch.cuda.stream(self._tn_stream):
+                    ops.launch_tn_group(self._late_tn)
             x.backward(self.x_static.grad)                 # eager: backward of K3 / K2
+            if self._late_tn:
+                torch.cuda.current_stream().wait_stream(self._tn_stream)
             if self.reducer is not None:
                 self.reducer.reduce_all()
         self.opt.step()

@@ -1038,6 +1038,24 @@ def _defer_tn_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor) -> bo
     return True
 
 
+_TN_SINK: Optional[list] = None
+
+
+def set_tn_sink(sink: Optional[list]) -> None:
+    """While a list is installed, the end-of-pass flush appends the pass's ``(g, x, acc)`` weight-gradient products to it
+    instead of launching them (``None`` restores the launch)."""
+    global _TN_SINK
+    _TN_SINK = sink
+
+
+def launch_tn_group(items) -> None:
+    """The grouped launch(es) for a pass's products: deepest token sums first (their work items are the longest of a
+    launch), one call per 16-bit dtype."""
+    items = sorted(items, key=lambda it: -it[0].shape[0])
+    for dt in {it[0].dtype for it in items}:
+        gemm16_tn_group([it for it in items if it[0].dtype == dt])
+
+
 def gemm16_tn_group(items) -> None:
     """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` for every ``(g, x, acc)`` of ``items`` in one K17 launch per 48 (all of
     one 16-bit dtype, contiguous ``acc``)."""
@@ -1090,11 +1108,13 @@ def flush_deferred_grads(task_id: Optional[int] = None) -> None:
     for st in {it[-1] for it in wg + cs + tn}:
         if st != cur:
             cur.wait_stream(st)
+    if tn and _TN_SINK is not None:
+        # the caller (graph.py, while it captures a backward pass) takes the pass's weight-gradient products over and
+        # issues them itself — after the replay, on a side stream, underneath the eager encoder backward
+        _TN_SINK.extend(it[:3] for it in tn)
+        tn = []
     if tn:
-        # deepest token sums first: their work items are the longest of a launch; one launch per dtype
-        tn.sort(key=lambda it: -it[0].shape[0])
-        for dt in {it[0].dtype for it in tn}:
-            gemm16_tn_group([it[:3] for it in tn if it[0].dtype == dt])
+        launch_tn_group([it[:3] for it in tn])
     if wg:
         n = len(wg)
         PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
