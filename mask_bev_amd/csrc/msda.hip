@@ -605,6 +605,91 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
         make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
 }
 
+// The same kernel with NEIGHBOUR MERGING (P = 4): lanes are consecutive queries, i.e. neighbouring pixels of a map
+// row, and deformable offsets vary smoothly over the map (at initialisation they are identical for all queries): the
+// right-hand corners of lane i's sample are then the left-hand corners of lane i + 1's.  Before the adds, every lane
+// looks at its left neighbour's right-corner offset (one DPP wave shift); where it equals its own left-corner offset
+// it adds the neighbour's contribution to its own and the neighbour skips that corner — up to 8 of the 16 f64 LDS adds
+// per sample go away (the kernel is bound by exactly those adds).  Lanes that do not match (row ends,
+// rough offsets) add as before; the sums are the same addends in another order (f64).  Pure VALU exchanges: DPP
+// wave_shr / wave_shl, no LDS traffic.
+__device__ __forceinline__ int dpp_from_left_i(int v, int fill) {      // lane i receives lane i-1's v; lane 0: fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float dpp_from_left_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int dpp_from_right_i(int v, int fill) {     // lane i receives lane i+1's v; lane 63: fill
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ void __launch_bounds__(1024) k_msda_bwd_value_merge(const float* __restrict__ grad_out,
+                                                              const float* __restrict__ loc,
+                                                              const float* __restrict__ attn, int level, int levels,
+                                                              int h, int w, int lstart, int num_value, int num_query,
+                                                              int heads, float* __restrict__ grad_value) {
+  constexpr int dim = 32, CG = 4, P = 4;
+  extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
+  const int nbh = gridDim.x >> 3;
+  const int split = blockIdx.x / nbh, bhid = blockIdx.x - split * nbh;
+  const int hd = bhid % heads, b = bhid / heads;
+  const int npix = h * w, stride_pix = heads * dim;
+  for (int i = threadIdx.x; i < CG * npix; i += 1024) map[i] = 0.0;
+  __syncthreads();
+  for (int q0 = 0; q0 < num_query; q0 += 1024) {            // wave-uniform trip count: the DPP exchanges need it
+    const int q = q0 + (int)threadIdx.x;
+    const bool live = q < num_query;
+    const int64_t qh = ((int64_t)b * num_query + (live ? q : 0)) * heads + hd;
+    float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + split * CG);
+    if (!live) go = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t kb = (qh * levels + level) * P;
+    const float4 l01 = *reinterpret_cast<const float4*>(loc + kb * 2);
+    const float4 l23 = *reinterpret_cast<const float4*>(loc + kb * 2 + 4);
+    const float4 a4 = *reinterpret_cast<const float4*>(attn + kb);
+    const float lx[4] = {l01.x, l01.z, l23.x, l23.z}, ly[4] = {l01.y, l01.w, l23.y, l23.w};
+    const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+    // the left neighbour's gradient row (constant over the samples of this query)
+    const float gpx = dpp_from_left_f(go.x), gpy = dpp_from_left_f(go.y), gpz = dpp_from_left_f(go.z),
+                gpw = dpp_from_left_f(go.w);
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      Corner c;
+      const bool ok = live && bilinear_setup(lx[u], ly[u], h, w, 1, c);          // offsets in pixels
+      if (!ok) { c.off[0] = c.off[1] = c.off[2] = c.off[3] = -1; c.wgt[0] = c.wgt[1] = c.wgt[2] = c.wgt[3] = 0.f; }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {                          // the two map rows of the sample: corners (2r, 2r + 1)
+        const int offL = c.off[2 * r], offR = c.off[2 * r + 1];
+        const float wL = c.wgt[2 * r] * aw[u], wR = c.wgt[2 * r + 1] * aw[u];
+        const int offRp = dpp_from_left_i(offR, -2);
+        const float wRp = dpp_from_left_f(wR);
+        const int take = (offL >= 0 && offRp == offL) ? 1 : 0;      // this lane adds its left neighbour's right corner
+        const int given = dpp_from_right_i(take, 0);                // the right neighbour adds this lane's right corner
+        if (offL >= 0) {
+          double v0 = (double)(wL * go.x), v1 = (double)(wL * go.y), v2 = (double)(wL * go.z), v3 = (double)(wL * go.w);
+          if (take) {
+            v0 += (double)(wRp * gpx); v1 += (double)(wRp * gpy); v2 += (double)(wRp * gpz); v3 += (double)(wRp * gpw);
+          }
+          atomicAdd(&map[offL], v0);
+          atomicAdd(&map[npix + offL], v1);
+          atomicAdd(&map[2 * npix + offL], v2);
+          atomicAdd(&map[3 * npix + offL], v3);
+        }
+        if (offR >= 0 && !given) {
+          atomicAdd(&map[offR], (double)(wR * go.x));
+          atomicAdd(&map[npix + offR], (double)(wR * go.y));
+          atomicAdd(&map[2 * npix + offR], (double)(wR * go.z));
+          atomicAdd(&map[3 * npix + offR], (double)(wR * go.w));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* gv = grad_value + ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + split * CG;
+  for (int i = threadIdx.x; i < npix; i += 1024)
+    *reinterpret_cast<float4*>(gv + (int64_t)i * stride_pix) =
+        make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
+}
+
 // d(location), d(weight): 8 lanes per (query, head), 4 channels per lane
 __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restrict__ grad_out,
                                                           const float* __restrict__ value,
@@ -752,14 +837,24 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value_merge),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_done = true;
       }
       const int which = part;
       const int ablate = getenv("MBV_MSDA_ABLATE") ? atoi(getenv("MBV_MSDA_ABLATE")) : 0;     // timing experiments only
+      // A/B switch, default OFF: measured 166 -> 156 us with identical offsets for all queries, 218 -> 225 us with random
+      // ones — an f64 LDS atomic costs ~13 cycles per WAVE instruction whatever its active lanes, so emptying most lanes
+      // of half the instructions buys little
+      const char* me = getenv("MBV_MSDA_MERGE");
+      const bool merge = me && me[0] == '1' && !ablate;
       for (int l = num_levels - 1; l >= 0 && (which & 1); --l) {      // finest (longest) level first
         const dim3 grid((unsigned)(batch * num_heads * 8)), block(1024);
         const size_t lds = (size_t)lv.h[l] * lv.w[l] * 4 * sizeof(double);
-        if (num_points == 4)
+        if (num_points == 4 && merge)
+          hipLaunchKernelGGL(k_msda_bwd_value_merge, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
+                             num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, grad_value);
+        else if (num_points == 4)
           hipLaunchKernelGGL(k_msda_bwd_value<4>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
                              num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
                              grad_value, ablate);
