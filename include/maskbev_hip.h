@@ -182,7 +182,8 @@ int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch
  * caller enqueue the two independent parts on two streams.  (b) host shapes given and num_query == num_value
  * (self-attention over the multi-scale map): bands of every level's map in LDS (f64), flushed bands and out-of-band
  * corners as global f32 atomics.  (c) otherwise: global f32 atomics.  (b) and (c) zero-fill grad_value themselves and
- * take only part == 3.
+ * take only part == 3.  In form (a) with part == 1, bits 2.. of `part` may carry a mask of the levels whose d(value) this
+ * call produces (0 = all): the per-level launches are independent (A/B experiments put them on different streams).
  */
 int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
                            const float* sampling_loc, const float* attn_weight,

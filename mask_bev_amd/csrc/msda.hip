@@ -557,17 +557,45 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
   const int npix = h * w, stride_pix = heads * dim;
   for (int i = threadIdx.x; i < CG * npix; i += 1024) map[i] = 0.0;
   __syncthreads();
+  // P == 4: the loads of the thread's NEXT query (gradient row, 4 locations, 4 weights: 64 B) are issued before the
+  // current query's 64 LDS adds, so that their round trip runs underneath them — the 16 waves of the workgroup share one
+  // LDS-atomic pipe and otherwise fall into lockstep: everybody waits for memory, then everybody queues adds
+  float4 n_go = make_float4(0.f, 0.f, 0.f, 0.f), n_l01 = n_go, n_l23 = n_go, n_a4 = n_go;
+  if constexpr (P == 4) {
+    if ((int)threadIdx.x < num_query) {
+      const int64_t qh0 = ((int64_t)b * num_query + threadIdx.x) * heads + hd;
+      const int64_t kb0 = (qh0 * levels + level) * 4;
+      n_go = *reinterpret_cast<const float4*>(grad_out + qh0 * dim + split * CG);
+      n_l01 = *reinterpret_cast<const float4*>(loc + kb0 * 2);
+      n_l23 = *reinterpret_cast<const float4*>(loc + kb0 * 2 + 4);
+      n_a4 = *reinterpret_cast<const float4*>(attn + kb0);
+    }
+  }
   for (int q = threadIdx.x; q < num_query; q += 1024) {
     const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + split * CG);
+    float4 go;
+    float4 c_l01, c_l23, c_a4;
+    if constexpr (P == 4) {
+      go = n_go; c_l01 = n_l01; c_l23 = n_l23; c_a4 = n_a4;
+      if (q + 1024 < num_query) {
+        const int64_t qh1 = ((int64_t)b * num_query + q + 1024) * heads + hd;
+        const int64_t kb1 = (qh1 * levels + level) * 4;
+        n_go = *reinterpret_cast<const float4*>(grad_out + qh1 * dim + split * CG);
+        n_l01 = *reinterpret_cast<const float4*>(loc + kb1 * 2);
+        n_l23 = *reinterpret_cast<const float4*>(loc + kb1 * 2 + 4);
+        n_a4 = *reinterpret_cast<const float4*>(attn + kb1);
+      }
+    } else {
+      go = *reinterpret_cast<const float4*>(grad_out + qh * dim + split * CG);
+    }
     const int64_t kb = (qh * levels + level) * points;
     constexpr int U = P > 0 ? P : 1;
     for (int p0 = 0; p0 < points; p0 += U) {
       float lx[U], ly[U], aw[U];
       if constexpr (P == 4) {
-        const float4 l01 = *reinterpret_cast<const float4*>(loc + kb * 2);
-        const float4 l23 = *reinterpret_cast<const float4*>(loc + kb * 2 + 4);
-        const float4 a4 = *reinterpret_cast<const float4*>(attn + kb);
+        const float4 l01 = c_l01;
+        const float4 l23 = c_l23;
+        const float4 a4 = c_a4;
         lx[0] = l01.x; ly[0] = l01.y; lx[1] = l01.z; ly[1] = l01.w;
         lx[2] = l23.x; ly[2] = l23.y; lx[3] = l23.z; ly[3] = l23.w;
         aw[0] = a4.x; aw[1] = a4.y; aw[2] = a4.z; aw[3] = a4.w;
@@ -589,6 +617,12 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
           if (off < 0) continue;
           const float wj = c.wgt[j] * aw[u];
           if (ablate & 2) continue;
+          if (ablate & 4) {                     // timing experiment: one f32 -> f64 conversion instead of four
+            const double d = (double)(wj * go.x);
+            atomicAdd(&map[off], d); atomicAdd(&map[npix + off], d); atomicAdd(&map[2 * npix + off], d);
+            atomicAdd(&map[3 * npix + off], d);
+            continue;
+          }
           atomicAdd(&map[off], (double)(wj * go.x));
           atomicAdd(&map[npix + off], (double)(wj * go.y));
           atomicAdd(&map[2 * npix + off], (double)(wj * go.z));
@@ -813,7 +847,11 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_value ||
       !grad_loc || !grad_attn)
     return MBV_ERR_BAD_ARG;
-  if (part < 1 || part > 3) return MBV_ERR_BAD_ARG;
+  // part: bit 0 = d(value), bit 1 = d(location, weight); bits 2.. = optional mask of the levels whose d(value) this
+  // call produces (0 = all) — a caller may put the levels' launches on different streams
+  const int level_mask = part >> 2;
+  part &= 3;
+  if (part < 1 || level_mask < 0 || level_mask > 255 || (level_mask && part != 1)) return MBV_ERR_BAD_ARG;
   {
     // no global atomics (see k_msda_bwd_value); MBV_MSDA_BWD_BANDED=1 keeps the banded form (A/B switch)
     bool fits = mbv_ms_deform_attn_bwd_split(head_dim, num_levels, spatial_shapes_host) != 0 &&
@@ -849,6 +887,7 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
       const char* me = getenv("MBV_MSDA_MERGE");
       const bool merge = me && me[0] == '1' && !ablate;
       for (int l = num_levels - 1; l >= 0 && (which & 1); --l) {      // finest (longest) level first
+        if (level_mask && !((level_mask >> l) & 1)) continue;
         const dim3 grid((unsigned)(batch * num_heads * 8)), block(1024);
         const size_t lds = (size_t)lv.h[l] * lv.w[l] * 4 * sizeof(double);
         if (num_points == 4 && merge)
