@@ -1310,6 +1310,7 @@ class _FFN(torch.autograd.Function):
         ctx.save_for_backward(x2, a if h is None else h, a, w1c, w2c)
         ctx.params = (w1, b1, w2, b2)
         ctx.kind, ctx.defer_out_bias, ctx.xshape = kind, defer_out_bias, x.shape
+        ctx.x_f32 = x.dtype == torch.float32
         return out.view(x.shape[:-1] + (w2.shape[0],))
 
     @staticmethod
@@ -1333,7 +1334,13 @@ class _FFN(torch.autograd.Function):
         _fire_grad_hooks(w1)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (gemm16_nn(dh, w1c) if gemm16_policy() == 'all' else dh.mm(w1c)).view(ctx.xshape)
+            if gemm16_policy() == 'all':
+                gx = gemm16_nn(dh, w1c)
+            elif ctx.x_f32:        # an f32 input (post-LN residual stream) takes its gradient in f32: no 16-bit round trip + cast
+                gx = torch.mm(dh, w1c, out_dtype=torch.float32)
+            else:
+                gx = dh.mm(w1c)
+            gx = gx.view(ctx.xshape)
         return gx, None, None, None, None, None, None
 
 
