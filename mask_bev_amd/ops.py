@@ -790,6 +790,7 @@ def gemm16_policy() -> str:
 # (scratch/bench_gemm.py on the bench shapes, profiles/r02/c_gemm_shapes.txt).  The fused FFN forms pay down to 4096
 # tokens (Swin stage 3): the K17 GEMM alone is slower there than the library's, but it replaces GEMM + GELU forward and
 # GEMM + activation-backward/column-sum pass backward — step A/B 8192 / 4096 / 1024: 29.19 / 28.92 / 30.51 ms
+_TN_MAX_IN = int(os.environ.get('MBV_TN_MAX_IN', '1536'))      # widest input of a Linear whose weight gradient K17 takes
 _K17_MIN_TOKENS = {'fused': int(os.environ.get('MBV_K17_FUSED_MIN', '4096')), 'wgrad': 4096}
 
 
@@ -1151,7 +1152,7 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     t = g2.shape[0]
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
             and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):
-        per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= 1536 or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
+        per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= _TN_MAX_IN or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
         # few-token 16-bit products (the decoder's 400-row output projections: a 256 x 256 result over 400 rows) are a
         # handful of work items of the grouped launch; alone, the library ran them as ONE 256 x 256 tile — 30 us each
         few = t <= 512 and gemm16_policy() == 'auto'       # (Swin stage 4's 1024-token layers stay with the library: measured)
