@@ -147,8 +147,13 @@ struct LnBwdIo {
   MergeGeom mg;                      // mg.on: s is the f32 (B, H, W, C) map of the forward, dx has its layout
 };
 
+// Wide rows (ITERS >= 4, C > 512) add their column sums to the block's LDS accumulators ROW BY ROW instead of keeping
+// three register accumulators per channel across the rows of a wave: few rows reach such a wave (4 096 x 768 at Swin
+// stage 3: one or two), the 36-72 f64 LDS adds per row cost ~0.2 us of a shared pipe, and the 48-96 VGPRs they free
+// let two workgroups share a CU (ITERS = 4: 164 -> <= 128 VGPRs) — the kernel is latency-bound at these sizes.
 template <int ITERS>
-__global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C) {
+__global__ void __launch_bounds__(512, (ITERS == 4 ? 4 : 1)) k_add_ln_bwd(LnBwdIo io, long rows, int C) {
+  constexpr bool ROW_LDS = ITERS >= 4;
   extern __shared__ double red[];    // [np][C]; f64: LDS ds_add_f32 is ≈ 20x slower than ds_add_f64 on gfx950
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
@@ -178,8 +183,15 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
         const float4 sv = io.mg.on ? merge_load(io.s, io.mg, row, v) : *reinterpret_cast<const float4*>(io.s + base + 4 * v);
         xh[i].x = (sv.x - mean) * rstd; xh[i].y = (sv.y - mean) * rstd;
         xh[i].z = (sv.z - mean) * rstd; xh[i].w = (sv.w - mean) * rstd;
-        dg[i].x += dy.x * xh[i].x; dg[i].y += dy.y * xh[i].y; dg[i].z += dy.z * xh[i].z; dg[i].w += dy.w * xh[i].w;
-        db[i].x += dy.x; db[i].y += dy.y; db[i].z += dy.z; db[i].w += dy.w;
+        if (ROW_LDS) {
+          atomicAdd(&red[4 * v + 0], (double)(dy.x * xh[i].x)); atomicAdd(&red[4 * v + 1], (double)(dy.y * xh[i].y));
+          atomicAdd(&red[4 * v + 2], (double)(dy.z * xh[i].z)); atomicAdd(&red[4 * v + 3], (double)(dy.w * xh[i].w));
+          atomicAdd(&red[C + 4 * v + 0], (double)dy.x); atomicAdd(&red[C + 4 * v + 1], (double)dy.y);
+          atomicAdd(&red[C + 4 * v + 2], (double)dy.z); atomicAdd(&red[C + 4 * v + 3], (double)dy.w);
+        } else {
+          dg[i].x += dy.x * xh[i].x; dg[i].y += dy.y * xh[i].y; dg[i].z += dy.z * xh[i].z; dg[i].w += dy.w * xh[i].w;
+          db[i].x += dy.x; db[i].y += dy.y; db[i].z += dy.z; db[i].w += dy.w;
+        }
         g[i].x = dy.x * gam[i].x; g[i].y = dy.y * gam[i].y; g[i].z = dy.z * gam[i].z; g[i].w = dy.w * gam[i].w;
         s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
         s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
@@ -202,7 +214,14 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
         if (io.mg.on) merge_store(io.dx, io.mg, row, v, d);
         else *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
         if (io.dx_lo) store4(io.dx_lo, io.dx_lo_kind, base + 4 * v, d);
-        dxs[i].x += d.x; dxs[i].y += d.y; dxs[i].z += d.z; dxs[i].w += d.w;
+        if (ROW_LDS) {
+          if (np == 3) {
+            atomicAdd(&red[2 * C + 4 * v + 0], (double)d.x); atomicAdd(&red[2 * C + 4 * v + 1], (double)d.y);
+            atomicAdd(&red[2 * C + 4 * v + 2], (double)d.z); atomicAdd(&red[2 * C + 4 * v + 3], (double)d.w);
+          }
+        } else {
+          dxs[i].x += d.x; dxs[i].y += d.y; dxs[i].z += d.z; dxs[i].w += d.w;
+        }
       }
     }
   }
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(512) k_add_ln_bwd(LnBwdIo io, long rows, int C
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const int v = lane + 64 * i;
-    if (v < nvec) {
+    if (!ROW_LDS && v < nvec) {
       atomicAdd(&red[4 * v + 0], (double)dg[i].x); atomicAdd(&red[4 * v + 1], (double)dg[i].y);
       atomicAdd(&red[4 * v + 2], (double)dg[i].z); atomicAdd(&red[4 * v + 3], (double)dg[i].w);
       atomicAdd(&red[C + 4 * v + 0], (double)db[i].x); atomicAdd(&red[C + 4 * v + 1], (double)db[i].y);
@@ -277,9 +296,10 @@ int iters_for(int C) {
 
 extern "C" int mbv_add_layernorm_supported(int32_t C) { return iters_for(C) ? 1 : 0; }
 
-// one 512-thread block per CU for wide rows (≤ 256 VGPRs), up to four for narrow ones
+// one 512-thread block per CU for the widest rows, two for C <= 1024 (per-row LDS accumulation), up to four for narrow ones
 extern "C" int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C) {
-  const int64_t cap = iters_for(C) <= 2 ? 1024 : 256;
+  const int it = iters_for(C);
+  const int64_t cap = it <= 2 ? 1024 : (it == 4 ? 512 : 256);
   int64_t b = (rows + 7) / 8;
   return b < 1 ? 1 : (b > cap ? cap : b);
 }
