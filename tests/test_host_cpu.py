@@ -272,3 +272,36 @@ def test_mask_map_matches_coco_protocol_oracle():
     assert torch.allclose(torch.diag(m.images[0]['ious'])[:2], torch.ones(2, dtype=torch.float64))
     out = m.compute()
     assert out['map_50'] == pytest.approx(0.5)                 # class 1: AP 1; class 0: the zero-area padding is never matched
+
+
+def test_workmodel_prices_every_instrumented_entry_point():
+    """bench.py prices each C-ABI call from its argument list (mask_bev_amd/workmodel.py: positions follow
+    include/maskbev_hip.h).  Every modelled entry point must exist in the binding table, and the models of the entry
+    points added in round 2 must return the byte counts of their shapes (known-answer checks)."""
+    import ctypes
+    from mask_bev_amd import _lib, workmodel as W
+    for name in W.MODELS:
+        assert name in _lib.SIGNATURES, name
+    n = 4 * 256 * 128 * 128
+    # GroupNorm forward: bf16 in, bf16 out, f32 (4, 256, 64, 64) map added after up-sampling
+    args = (ctypes.c_void_p(1), 1, 4, 256, 128, 128, 32, None, None, 1e-5, ctypes.c_void_p(2), 0, 64, 64, 0,
+            ctypes.c_void_p(3), 1)
+    k, bound, by, fl = W.MODELS['mbv_groupnorm_fwd'](args)
+    assert (k, bound, fl) == ('k_gn_fwd', 'hbm', 0.0) and by == n * 4 + 4 * 256 * 64 * 64 * 4
+    # ... without the added map
+    args = args[:10] + (ctypes.c_void_p(None),) + args[11:]
+    assert W.MODELS['mbv_groupnorm_fwd'](args)[2] == n * 4
+    # GroupNorm backward: bf16 dy, bf16 x, bf16 dx
+    bwd = (None, 1, None, 1, None, None, None, None, 4, 256, 128, 128, 32, 0, None, 1)
+    assert W.MODELS['mbv_groupnorm_bwd'](bwd)[2] == n * 6
+    # patch merging: f32 map in, bf16 rows out / bf16 dy, f32 x, f32 dx
+    m = 4 * 128 * 128 * 192
+    assert W.MODELS['mbv_merge_layernorm_fwd']((None, 4, 128, 128, 192, None, None, 1e-5, None, 1))[2] == m * 6
+    assert W.MODELS['mbv_merge_layernorm_bwd']((None, 1, None, None, None, None, 4, 128, 128, 192))[2] == m * 10
+    # grouped weight gradients: two products
+    L = ctypes.c_int64 * 2
+    grp = (None, None, None, L(4096, 400), L(768, 256), L(768, 256), None, None, 2)
+    k, bound, by, fl = W.MODELS['mbv_gemm16_tn_group'](grp)
+    assert k == 'k_gemm16_tn_group'
+    assert fl == 2.0 * (4096 * 768 * 768 + 400 * 256 * 256)
+    assert by == (4096 * (768 + 768) + 400 * (256 + 256)) * 2.0 + 2 * (768 * 768 + 256 * 256) * 4.0
