@@ -428,6 +428,14 @@ int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
                           void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
                           float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream);
+/* mbv_add_layernorm_bwd with a second gradient of y (dy2, nullable, dy2_dtype = MBV_DT_*) that is added to dy on load:
+ * the output of a post-LN layer feeds both the next residual add and the next branch (mask_bev_panoptic_head.py:119-176),
+ * and its two gradients arrive separately instead of through an element-wise add launch. */
+int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
+                           int32_t ds_bf16, const float* s, const float* mean, const float* rstd, const float* gamma,
+                           int64_t rows, int32_t C, float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma,
+                           float* dbeta, int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce,
+                           void* stream);
 /* 1 = the backward of (rows, C) adds the parameter gradients from inside its one kernel; 0 = it writes per-block
  * partial rows (nblk = mbv_add_layernorm_bwd_blocks, layout [nblk][np][C], np = 3 with dbranch_bias else 2) and reduces
  * them with a second launch — unless defer_reduce != 0 (accumulating callers only), in which case the caller adds

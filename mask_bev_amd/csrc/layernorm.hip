@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(LnIo io, long rows, int C, f
 
 struct LnBwdIo {
   const void* dy; int dy_bf16;
+  const void* dy2; int dy2_kind;     // optional second gradient of y (y fanned out to two consumers): dy + dy2 on load
   const void* ds; int ds_bf16;       // gradient arriving at the sum from the residual path (nullable)
   const float* s; const float* mean; const float* rstd; const float* gamma;
   float* dx;                         // f32 gradient of the sum (= of a and of b)
@@ -179,7 +180,11 @@ __global__ void __launch_bounds__(512, (ITERS == 4 ? 4 : 1)) k_add_ln_bwd(LnBwdI
       const int v = lane + 64 * i;
       g[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v < nvec) {
-        const float4 dy = load4(io.dy, io.dy_bf16, base + 4 * v);
+        float4 dy = load4(io.dy, io.dy_bf16, base + 4 * v);
+        if (io.dy2) {
+          const float4 t = load4(io.dy2, io.dy2_kind, base + 4 * v);
+          dy.x += t.x; dy.y += t.y; dy.z += t.z; dy.w += t.w;
+        }
         const float4 sv = io.mg.on ? merge_load(io.s, io.mg, row, v) : *reinterpret_cast<const float4*>(io.s + base + 4 * v);
         xh[i].x = (sv.x - mean) * rstd; xh[i].y = (sv.y - mean) * rstd;
         xh[i].z = (sv.z - mean) * rstd; xh[i].w = (sv.w - mean) * rstd;
@@ -369,11 +374,13 @@ static int add_ln_bwd_launch(LnBwdIo io, int it, int64_t rows, int32_t C, int32_
   return MBV_OK;
 }
 
-extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
-                                     const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
-                                     float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta,
-                                     int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce,
-                                     void* stream) {
+// dy2 (nullable, dy2_dtype): a second gradient of y, added to dy on load — a post-LN output that feeds both the next
+// residual add and the next branch hands its two gradients over separately instead of through an autograd add launch
+extern "C" int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
+                                      int32_t ds_bf16, const float* s, const float* mean, const float* rstd,
+                                      const float* gamma, int64_t rows, int32_t C, float* dx, void* dx_lo,
+                                      int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
+                                      float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream) {
   const int it = iters_for(C);
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
@@ -388,9 +395,18 @@ extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void
   }
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
   if (dx_lo && dx_lo_dtype != MBV_DT_BF16 && dx_lo_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
-  LnBwdIo io{dy, dy_bf16, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, nullptr,
+  LnBwdIo io{dy, dy_bf16, dy2, dy2_dtype, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, nullptr,
              dgamma, dbeta, dbranch_bias, dbranch_bias ? 3 : 2, MergeGeom{}};
   return add_ln_bwd_launch(io, it, rows, C, accumulate, partial_ws, defer_reduce, st);
+}
+
+extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
+                                     const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C,
+                                     float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta,
+                                     int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce,
+                                     void* stream) {
+  return mbv_add_layernorm_bwd2(dy, dy_bf16, nullptr, 0, ds, ds_bf16, s, mean, rstd, gamma, rows, C, dx, dx_lo,
+                                dx_lo_dtype, dgamma, dbeta, accumulate, dbranch_bias, partial_ws, defer_reduce, stream);
 }
 
 // ---- patch merging: unfold(2 x 2, stride 2) + LayerNorm(4 C) without the unfolded copy (see MergeGeom) --------------
@@ -436,6 +452,6 @@ extern "C" int mbv_merge_layernorm_bwd(const void* dy, int32_t dy_dtype, const f
   const int it = iters_for(4 * c);
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return MBV_ERR_BAD_ARG;
-  LnBwdIo io{dy, dy_dtype, nullptr, 0, x, mean, rstd, gamma, dx, nullptr, 0, nullptr, dgamma, dbeta, nullptr, 2, m};
+  LnBwdIo io{dy, dy_dtype, nullptr, 0, nullptr, 0, x, mean, rstd, gamma, dx, nullptr, 0, nullptr, dgamma, dbeta, nullptr, 2, m};
   return add_ln_bwd_launch(io, it, rows, 4 * c, accumulate, partial_ws, defer_reduce, (hipStream_t)stream);
 }

@@ -36,10 +36,11 @@ class LayerNorm(nn.LayerNorm):
 
     ``forward(x, residual=None, gemm_input=False, return_sum=False)``:
     ``y = LN(x + residual)``; ``gemm_input=True`` says y only feeds GEMM layers, so under autocast it is stored in
-    the autocast dtype (what the GEMM would cast it to anyway); ``return_sum`` also returns the f32 sum."""
+    the autocast dtype (what the GEMM would cast it to anyway); ``return_sum`` also returns the f32 sum; ``fanout``
+    returns ``(y, y')``, the same values for two consumers (post-LN: the next residual add and the next branch)."""
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, gemm_input: bool = False,
-                return_sum: bool = False, residual_bias: Optional[torch.Tensor] = None):
+                return_sum: bool = False, residual_bias: Optional[torch.Tensor] = None, fanout: bool = False):
         """``residual_bias``: the bias Parameter of the Linear that produced ``residual`` when that layer was run with
         ``skip_bias_grad=True`` — its gradient (the column sums of d(residual)) is accumulated by this op."""
         c = x.shape[-1]
@@ -50,12 +51,17 @@ class LayerNorm(nn.LayerNorm):
             if (gemm_input and torch.is_autocast_enabled('cuda')
                     and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES):
                 out_dtype = torch.get_autocast_dtype('cuda')
+            if fanout and os.environ.get('MBV_LN_FANOUT', '1') == '0':
+                y = ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, branch_bias=residual_bias)
+                return y, y
             return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum,
-                                     branch_bias=residual_bias)
+                                     branch_bias=residual_bias, fanout=fanout)
         if residual_bias is not None:
             residual = ops.accumulate_bias_grad(residual, residual_bias)      # the deferred gradient must not be lost
         s = x if residual is None else x + residual
         y = super().forward(s.float() if s.dtype != torch.float32 and not torch.is_autocast_enabled('cuda') else s)
+        if fanout:
+            return y, y
         return (y, s) if return_sum else y
 
 

@@ -30,14 +30,19 @@ class _DeformEncoderLayer(nn.Module):
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
         self.norms = nn.ModuleList([LayerNorm(embed_dims), LayerNorm(embed_dims)])
 
-    def forward(self, q, pos, ref, shapes, shapes_t, level_start):
-        # post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12)
+    def forward(self, q, pos, ref, shapes, shapes_t, level_start, q_branch=None, fanout=False):
+        """post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12).  A LayerNorm output has two
+        consumers — the next residual add and the next branch: it is handed on as a PAIR of tensors over one buffer
+        (``q`` for the residual, ``q_branch`` for the branch) so that K12's backward receives the two gradients
+        separately and adds them on load.  ``fanout``: return such a pair (every layer but the last)."""
         c = q.shape[-1]
         ob, fb = self.self_attn.output_proj.bias, self.ffn.layers[1].bias
         d1, d2 = ops.bias_grad_deferrable(ob, c), ops.bias_grad_deferrable(fb, c)
-        q = self.norms[0](q, self.self_attn(q, pos, ref, shapes, shapes_t, level_start, add_identity=False,
-                                            defer_out_bias=d1), residual_bias=ob if d1 else None)
-        return self.norms[1](q, self.ffn(q, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None)
+        q_branch = q if q_branch is None else q_branch
+        q, qb = self.norms[0](q, self.self_attn(q_branch, pos, ref, shapes, shapes_t, level_start, add_identity=False,
+                                                defer_out_bias=d1), residual_bias=ob if d1 else None, fanout=True)
+        return self.norms[1](q, self.ffn(qb, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None,
+                             fanout=fanout)
 
 
 class _DeformEncoder(nn.Module):
@@ -120,8 +125,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
             lvl_pos.append(pos[i] + self.level_encoding.weight[i].view(1, 1, -1))
         q = torch.cat(tokens, 1)
         qpos = torch.cat(lvl_pos, 1)
-        for layer in self.encoder.layers:
-            q = layer(q, qpos, ref, shapes, shapes_t, level_start)
+        q_branch = None
+        nlay = len(self.encoder.layers)
+        for li, layer in enumerate(self.encoder.layers):
+            if li + 1 < nlay:
+                q, q_branch = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch, fanout=True)
+            else:
+                q = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch)
         outs = [t.transpose(1, 2).reshape(bs, -1, h, w) for t, (h, w) in
                 zip(torch.split(q, [h * w for h, w in shapes], dim=1), shapes)]
         # The FPN tail (lateral / output convolutions, mask-feature projection) runs on a second stream and is joined
@@ -170,18 +180,24 @@ class _DecoderLayer(nn.Module):
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
         self.norms = nn.ModuleList([LayerNorm(embed_dims) for _ in range(3)])
 
-    def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None, shared_kv=None):
+    def forward(self, query, memory, query_pos, memory_pos, blocked, memory_key=None, shared_kv=None,
+                query_branch=None, fanout=False):
         """``memory_key`` = memory + memory_pos when the caller has it (it is the same for every layer that reads
-        this level); ``shared_kv``: this layer's slot of the level's batched key / value projection."""
+        this level); ``shared_kv``: this layer's slot of the level's batched key / value projection.
+        ``query_branch``: the previous layer's output as handed to this layer's branch (``query`` then only feeds the
+        residual add); ``fanout``: return the output as such a pair ``(residual copy, branch copy)``."""
+        qb0 = query if query_branch is None else query_branch
         if shared_kv is not None:
-            r = self.cross_attn(query, None, None, query_pos, None, blocked, add_identity=False, shared_kv=shared_kv)
+            r = self.cross_attn(qb0, None, None, query_pos, None, blocked, add_identity=False, shared_kv=shared_kv)
         elif memory_key is None:
-            r = self.cross_attn(query, memory, memory, query_pos, memory_pos, blocked, add_identity=False)
+            r = self.cross_attn(qb0, memory, memory, query_pos, memory_pos, blocked, add_identity=False)
         else:
-            r = self.cross_attn(query, memory_key, memory, query_pos, None, blocked, add_identity=False)
-        q = self.norms[0](query, r)                      # post-LN, residual add inside the LayerNorm kernel (K12)
-        q = self.norms[1](q, self.self_attn(q, q, q, query_pos, query_pos, None, add_identity=False))
-        return self.norms[2](q, self.ffn(q, add_identity=False))
+            r = self.cross_attn(qb0, memory_key, memory, query_pos, None, blocked, add_identity=False)
+        # post-LN, residual add inside the LayerNorm kernel (K12); each output leaves as a pair (residual / branch
+        # consumer) whose gradients K12's backward adds on load
+        q, qb = self.norms[0](query, r, fanout=True)
+        q, qb = self.norms[1](q, self.self_attn(qb, qb, qb, query_pos, query_pos, None, add_identity=False), fanout=True)
+        return self.norms[2](q, self.ffn(qb, add_identity=False), fanout=fanout)
 
 
 class Mask2FormerTransformerDecoder(nn.Module):
@@ -426,11 +442,19 @@ class Mask2FormerHead(nn.Module):
                     [(layers[i].cross_attn.attn.in_proj_weight, layers[i].cross_attn.attn.in_proj_bias) for i in idx])
                 for slot, i in enumerate(idx):
                     shared[i] = (holder, token, slot)
+        query_branch = None
         for i, layer in enumerate(layers):
             lvl = i % nl
-            query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl], shared[i])
-            feats_q.append(query_feat)
-            cls_pred, mask_pred, blocked = heads(query_feat, memories[(i + 1) % nl].shape[-2:],
+            if i + 1 < len(layers):       # the output feeds the next residual add (query_feat) and, as its twin over the
+                #                           same buffer, the next branch and the prediction head (K12's fan-out)
+                query_feat, query_branch = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked,
+                                                 dec_key[lvl], shared[i], query_branch=query_branch, fanout=True)
+            else:
+                query_feat = layer(query_feat, dec_in[lvl], query_embed, dec_pos[lvl], blocked, dec_key[lvl], shared[i],
+                                   query_branch=query_branch)
+                query_branch = query_feat
+            feats_q.append(query_branch)
+            cls_pred, mask_pred, blocked = heads(query_branch, memories[(i + 1) % nl].shape[-2:],
                                                  None if stack is None else stack[i + 1])
             cls_list.append(cls_pred)
             mask_list.append(mask_pred)

@@ -1923,7 +1923,7 @@ def add_layernorm_supported(channels: int) -> bool:
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, weight, bias, eps, out_dtype, branch_bias=None):
+    def forward(ctx, a, b, weight, bias, eps, out_dtype, branch_bias=None, fanout=False):
         lib = _lib.load()
         _need_gpu(a, b, weight, bias)
         ctx.branch_bias = branch_bias
@@ -1952,14 +1952,18 @@ class _AddLayerNorm(torch.autograd.Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.dtypes = (a.dtype, None if b is None else b.dtype)
         ctx.set_materialize_grads(False)
-        return y, s                                       # s is None for a lone f32 input (it IS the input)
+        # fanout: y leaves as two tensors over one buffer — one per consumer (the next residual add, the next branch) — so
+        # that their gradients come back separately and K12's backward adds them on load (no autograd add launch)
+        return y, s, (y.view_as(y) if fanout else None)   # s is None for a lone f32 input (it IS the input)
 
     @staticmethod
-    def backward(ctx, gy, gs):
+    def backward(ctx, gy, gs, gy2=None):
         lib = _lib.load()
         s, mean, rstd, w = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
         da, db = ctx.dtypes
+        if gy is None and gy2 is not None:
+            gy, gy2 = gy2, None
         if gy is None:                                    # only the residual path carries gradient
             bb = ctx.branch_bias
             if gs is not None and bb is not None:         # the deferred bias gradient of the branch Linear: colsum(gs)
@@ -1968,12 +1972,16 @@ class _AddLayerNorm(torch.autograd.Function):
                 _fire_grad_hooks(bb)
             ga = None if gs is None else gs.to(da)
             gb = None if (gs is None or db is None) else gs.to(db)
-            return ga, gb, None, None, None, None, None
+            return ga, gb, None, None, None, None, None, None
         c = s.shape[-1]
         rows = s.numel() // c
         gy = gy.contiguous()
         if gy.dtype not in _ACT_DTYPES:
             gy = gy.float()
+        if gy2 is not None:
+            gy2 = gy2.contiguous()
+            if gy2.dtype not in _ACT_DTYPES:
+                gy2 = gy2.float()
         if gs is not None:
             gs = gs.contiguous()
             if gs.dtype not in _ACT_DTYPES:
@@ -1996,13 +2004,14 @@ class _AddLayerNorm(torch.autograd.Function):
         # end of the backward pass instead of one reduction launch per layer
         np_ = 3 if bb is not None else 2
         defer = bool(direct and not lib.mbv_add_layernorm_bwd_direct(rows, c) and _defer_ok())
-        check(lib.mbv_add_layernorm_bwd(_ptr(gy), _dt_flag(gy.dtype), _ptr(gs),
-                                        (_dt_flag(gs.dtype) if gs is not None else 0), _ptr(s), _ptr(mean),
-                                        _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo),
-                                        _dt_flag(lo) if lo is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                        1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws),
-                                        1 if defer else 0, _stream()),
-              'mbv_add_layernorm_bwd')
+        check(lib.mbv_add_layernorm_bwd2(_ptr(gy), _dt_flag(gy.dtype), _ptr(gy2),
+                                         (_dt_flag(gy2.dtype) if gy2 is not None else 0), _ptr(gs),
+                                         (_dt_flag(gs.dtype) if gs is not None else 0), _ptr(s), _ptr(mean),
+                                         _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo),
+                                         _dt_flag(lo) if lo is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                         1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws),
+                                         1 if defer else 0, _stream()),
+              'mbv_add_layernorm_bwd2')
         if defer:
             for j, dst in enumerate((dgamma, dbeta, None if bb is None else bb.grad)[:np_]):
                 ok = _defer_colsum(ws, dst, nblk, c, np_ * c, offset=j * c)
@@ -2017,7 +2026,7 @@ class _AddLayerNorm(torch.autograd.Function):
             dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
         ga = dx_lo if da in _LO_DTYPES else dx
         gb = None if db is None else (dx_lo if db in _LO_DTYPES else dx)
-        return ga, gb, dgamma, dbeta, None, None, None
+        return ga, gb, dgamma, dbeta, None, None, None, None
 
 
 class _BiasAct(torch.autograd.Function):
@@ -2093,14 +2102,18 @@ def bias_grad_deferrable(bias: Optional[torch.Tensor], channels: int) -> bool:
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
                   eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, return_sum: bool = False,
-                  branch_bias: Optional[torch.Tensor] = None):
+                  branch_bias: Optional[torch.Tensor] = None, fanout: bool = False):
     """``y = LayerNorm_C(a + b)`` over the last axis in one pass (K12); ``b=None`` is a plain LayerNorm.
     ``out_dtype`` (default: the autocast dtype when autocast is on and the consumer is a GEMM — pass it explicitly —
     else f32) is the storage type of y; statistics and the sum are f32.  With ``return_sum`` the f32 sum ``a + b``
-    (the new residual stream of a pre-LN block) is returned as well: ``(y, s)``."""
+    (the new residual stream of a pre-LN block) is returned as well: ``(y, s)``.  ``fanout`` (post-LN layers, instead
+    of ``return_sum``): returns ``(y, y')`` — the same values as two tensors, one for each of y's two consumers, whose
+    gradients the backward kernel then adds on load instead of autograd adding them with a launch of its own."""
     if out_dtype is None:
         out_dtype = torch.float32
-    y, s = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias)
+    y, s, y2 = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias, fanout)
+    if fanout:
+        return y, y2
     return (y, a if s is None else s) if return_sum else y
 
 

@@ -149,3 +149,39 @@ def test_patch_merging_module_equals_unfused_path(device, monkeypatch):
     monkeypatch.setenv('MBV_MERGE_LN', '1')
     y = m(torch.randn(1, 7, 9, 96, device=device))
     assert tuple(y.shape) == (1, 4, 5, 192)
+
+
+@pytest.mark.parametrize('shape,dt2', [((4, 100, 256), torch.float32), ((3000, 192), torch.bfloat16), ((37, 768), torch.float32)])
+def test_add_layernorm_fanout_adds_the_two_gradients_on_load(device, shape, dt2):
+    """``fanout``: y leaves as two tensors over one buffer; the backward kernel adds their gradients on load
+    (mbv_add_layernorm_bwd2) — against F.layer_norm in f64 with dy = g1 + g2; one of the two gradients missing works too."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[-1]
+    a = (torch.randn(shape, generator=g) * 2 + 0.5).to(device).requires_grad_()
+    b = torch.randn(shape, generator=g).to(device).requires_grad_()
+    w = (torch.rand(c, generator=g) + 0.5).to(device).requires_grad_()
+    bias = torch.randn(c, generator=g).to(device).requires_grad_()
+    g1 = torch.randn(shape, generator=g).to(device)
+    g2 = torch.randn(shape, generator=g).to(device).to(dt2)
+    ar, br, wr, biasr = (t.detach().double().requires_grad_() for t in (a, b, w, bias))
+    yr = F.layer_norm(ar + br, (c,), wr, biasr, 1e-5)
+    (yr * (g1.double() + g2.double())).sum().backward()
+    y, y2 = ops.add_layernorm(a, b, w, bias, 1e-5, torch.float32, fanout=True)
+    assert y.data_ptr() == y2.data_ptr() and torch.equal(y, y2)
+    assert torch.allclose(y.double(), yr, rtol=2e-5, atol=2e-5)
+    torch.autograd.backward([y, y2], [g1, g2.to(y2.dtype) if dt2 == torch.float32 else g2.float()])
+
+    def close(got, want, t):
+        return float((got.double() - want).abs().max()) <= t * (float(want.abs().max()) + 1e-12)
+
+    for got, want in ((a.grad, ar.grad), (b.grad, br.grad)):
+        assert close(got, want, 3e-5)
+    assert close(w.grad, wr.grad, 1e-4) and close(bias.grad, biasr.grad, 1e-4)
+    # only the second consumer sends a gradient
+    a2 = a.detach().clone().requires_grad_()
+    y, y2 = ops.add_layernorm(a2, b.detach(), w.detach(), bias.detach(), 1e-5, torch.float32, fanout=True)
+    (y2 * g1).sum().backward()
+    ar2 = a.detach().double().requires_grad_()
+    (F.layer_norm(ar2 + b.detach().double(), (c,), w.detach().double(), bias.detach().double(), 1e-5) * g1.double()).sum().backward()
+    assert close(a2.grad, ar2.grad, 3e-5)
