@@ -1202,8 +1202,10 @@ class _Linear(torch.autograd.Function):
                 x.dtype == torch.float32 and weight.dtype == torch.float32
                 and x.numel() <= _SMALL_F32_ROWS * x.shape[-1] and x.numel() * weight.shape[0] <= _SMALL_F32_MACS):
             dt = torch.get_autocast_dtype('cuda')
+            ctx.gx_f32 = x.dtype == torch.float32 and dt in _LO_DTYPES and x.is_cuda    # the caller's tensor is f32
             x, w, b = x.to(dt), _compute_copy(weight, dt), _compute_copy(bias, dt)
         else:
+            ctx.gx_f32 = False
             w, b = weight, bias
         if rows is not None:
             w = w[rows[0]:rows[1]]
@@ -1242,6 +1244,8 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if gemm16_policy() == 'all' and g2.is_cuda and _gemm16_ok(g2, w):
                 gx = gemm16_nn(g2, w).view_as(x)
+            elif ctx.gx_f32:         # an f32 input was cast for the GEMM: its gradient leaves the GEMM as f32 (no cast pass)
+                gx = torch.mm(g2, w, out_dtype=torch.float32).view_as(x)
             else:
                 gx = g2.mm(w).view_as(x)
         bias_direct = (bias is not None and ctx.needs_input_grad[2] and getattr(bias, '_mbv_arena', False)
