@@ -716,7 +716,8 @@ class _MSDAQuerySide(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g, wcat, **od).view(b, n, e).to(x_dtype)
         if ctx.needs_input_grad[1]:                                       # pos is broadcast over the batch
-            gq_sum = g.view(b, n, width)[:, :, e:].sum(0, dtype=torch.float32).to(dt)
+            # (a 16-bit sum accumulates in f32 and rounds once on the way out: the same value as an f32 sum + cast, one launch)
+            gq_sum = g.view(b, n, width)[:, :, e:].sum(0) if dt in _LO_DTYPES else g.view(b, n, width)[:, :, e:].sum(0, dtype=torch.float32)
             gpos = torch.mm(gq_sum, wcat[e:], **od).view(1, n, e)
             if tuple(pos_shape) != (1, n, e):
                 gpos = gpos.sum_to_size(pos_shape) if len(pos_shape) == 3 else gpos.reshape(pos_shape)
