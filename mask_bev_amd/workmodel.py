@@ -88,6 +88,14 @@ def _add_ln(a, bwd: bool) -> Work:
     return ('k_add_ln_fwd', 'hbm', by, 0.0)
 
 
+def _add_ln_bwd2(a) -> Work:
+    """mbv_add_layernorm_bwd2: dy (+ dy2) (+ ds) and the f32 sum read, dx (+ its 16-bit copy) written."""
+    rows, c = _i(a[10]), _i(a[11])
+    by = rows * c * ((2 if _i(a[1]) else 4) + (0 if not _i(a[2]) else (2 if _i(a[3]) else 4))
+                     + (0 if not _i(a[4]) else (2 if _i(a[5]) else 4)) + 4 + 4 + (2 if _i(a[13]) else 0))
+    return ('k_add_ln_bwd', 'hbm', by, 0.0)
+
+
 def _wgrad_group(a) -> Work:
     n = _i(a[7])
     t, o, i = a[4], a[5], a[6]
@@ -146,6 +154,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
     'mbv_add_layernorm_bwd': lambda a: _add_ln(a, True),
+    'mbv_add_layernorm_bwd2': lambda a: _add_ln_bwd2(a),
     # importance sampling: every row's (H, W) f32 map is read once; the 3x over-sampled candidates never touch HBM
     'mbv_sample_select_uncertain': lambda a: ('k_sample_select', 'hbm',
                                               _i(a[4]) * (_i(a[7]) * _i(a[8]) * 4.0 + _i(a[6]) * 8.0), 0.0),

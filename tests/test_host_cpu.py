@@ -305,3 +305,14 @@ def test_workmodel_prices_every_instrumented_entry_point():
     assert k == 'k_gemm16_tn_group'
     assert fl == 2.0 * (4096 * 768 * 768 + 400 * 256 * 256)
     assert by == (4096 * (768 + 768) + 400 * (256 + 256)) * 2.0 + 2 * (768 * 768 + 256 * 256) * 4.0
+
+
+def test_workmodel_add_layernorm_bwd2_known_answer():
+    """K12's backward with two gradients of y: bf16 dy2 beside an f32 dy, no residual-path gradient, 16-bit dx copy."""
+    import ctypes
+    from mask_bev_amd import workmodel as W
+    P = ctypes.c_void_p
+    args = (P(1), 0, P(2), 1, P(None), 0, P(3), P(4), P(5), P(6), 21504, 256, P(7), P(8), 1)
+    k, bound, by, fl = W.MODELS['mbv_add_layernorm_bwd2'](args)
+    assert (k, bound, fl) == ('k_add_ln_bwd', 'hbm', 0.0)
+    assert by == 21504 * 256 * (4 + 2 + 0 + 4 + 4 + 2)
