@@ -269,7 +269,7 @@ int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bia
  * out[g][p] = bilinear(src[src_index[g]] (H, W), coords[coord_index[g]][p] (x, y in [0, 1])).
  * src (num_src_maps, H, W) f32; src_index, coord_index (num_rows) i32; coords (*, num_points, 2) f32;
  * out / grad_out (num_rows, num_points) f32.
- * Backward zero-fills grad_src (num_src_maps, H, W) itself.  For H*W <= 16384 each row's gradient tile is
+ * Backward zero-fills grad_src (num_src_maps, H, W) itself (skipped when every map is sampled: num_rows == num_src_maps).  For H*W <= 16384 each row's gradient tile is
  * accumulated in LDS and stored once, which requires src_index to hold no duplicates; larger maps use
  * global f32 atomics.
  */
