@@ -725,8 +725,18 @@ class _MSDAQuerySide(torch.autograd.Function):
         x2, q2 = xb.view(t, e), qb.view(t, e)
         cols = ((0, e, x2), (e, e + lo, q2), (e + lo, width, q2))
         grads = [None] * 6
+        # bias gradients = column sums of the three blocks of G.  Arena biases take theirs through the end-of-pass grouped
+        # column-sum launch (one entry per block, row stride `width`): no zero fill, no column-sum launch of its own, no
+        # accumulate launch — 25 us per layer
         bias_tmp = None
-        if any(ctx.needs_input_grad[4 + 2 * j] for j in range(3)):
+        arena_bias = [bool(ctx.needs_input_grad[4 + 2 * j] and getattr(bia, '_mbv_arena', False) and bia.grad is not None
+                           and bia.grad.dtype == torch.float32 and bia.grad.is_contiguous())
+                      for j, bia in enumerate((bv, bo, ba))]
+        deferred = [False, False, False]
+        for j, (c0, c1) in enumerate(((0, e), (e, e + lo), (e + lo, width))):
+            if arena_bias[j]:
+                deferred[j] = _defer_colsum(g, (bv, bo, ba)[j].grad, t, c1 - c0, width, offset=c0)
+        if any(ctx.needs_input_grad[4 + 2 * j] and not deferred[j] for j in range(3)):
             bias_tmp = torch.zeros(width, dtype=torch.float32, device=dev)
             colsum_accum(g, bias_tmp)
         dst, src = [], []
@@ -741,15 +751,18 @@ class _MSDAQuerySide(torch.autograd.Function):
                     _wgrad_into(acc, gj, inp)
                     grads[2 * j] = acc.to(w.dtype)
             if ctx.needs_input_grad[4 + 2 * j]:
-                if getattr(bia, '_mbv_arena', False) and bia.grad is not None and bia.grad.dtype == torch.float32:
+                if deferred[j]:
+                    _fire_grad_hooks(bia)
+                elif getattr(bia, '_mbv_arena', False) and bia.grad is not None and bia.grad.dtype == torch.float32:
                     dst.append(bia.grad)
                     src.append(bias_tmp[c0:c1])
                 else:
                     grads[2 * j + 1] = bias_tmp[c0:c1].to(bia.dtype)
         if dst:
             torch._foreach_add_(dst, src)
-            for bia in (bv, bo, ba):
-                _fire_grad_hooks(bia)
+            for j, bia in enumerate((bv, bo, ba)):
+                if not deferred[j]:
+                    _fire_grad_hooks(bia)
         return (gx, gpos, None) + tuple(grads) + (None,) * 6
 
 
