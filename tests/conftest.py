@@ -1,3 +1,16 @@
+"""Test-session plumbing.
+
+The GPU suite must never die anonymously (round-2 driver run: SIGABRT, no test named, the terminal tail
+eaten by faulthandler's all-thread dump).  Hence:
+
+* faulthandler writes to ``gpurun_out/fault.log`` (current thread only), so the terminal keeps the runtime's
+  own last words ("Memory access fault by GPU node…", "terminate called…");
+* every test's node id goes to the real stderr and — flushed and fsync'ed — to ``gpurun_out/last_test.txt``
+  *before* it runs, with a running ``passed=N`` every 25 tests;
+* per-kernel parity tests are collected before whole-model, graph, launcher and multi-process tests, so a
+  fault in the latter cannot hide the former's results.
+"""
+import faulthandler
 import os
 import sys
 
@@ -7,9 +20,100 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_STATE = {'passed': 0, 'failed': 0, 'skipped': 0, 'started': 0, 'fault_file': None, 'last_path': None}
 
+
+def _scratch_dir():
+    for d in (os.path.join(ROOT, 'gpurun_out'), os.environ.get('TMPDIR') or '/tmp'):
+        try:
+            os.makedirs(d, exist_ok=True)
+            probe = os.path.join(d, f'.probe_{os.getpid()}')
+            with open(probe, 'w'):
+                pass
+            os.remove(probe)
+            return d
+        except OSError:
+            continue
+    return None
+
+
+@pytest.hookimpl(trylast=True)
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    d = _scratch_dir()
+    if d is None:
+        return
+    try:
+        f = open(os.path.join(d, 'fault.log'), 'w')
+    except OSError:
+        return
+    _STATE['fault_file'] = f
+    _STATE['last_path'] = os.path.join(d, 'last_test.txt')
+    # after pytest's own faulthandler plugin (trylast): the dump goes to the file, one thread only
+    faulthandler.enable(file=f, all_threads=False)
+
+
+def pytest_unconfigure(config):
+    f = _STATE.get('fault_file')
+    if f is not None:
+        try:
+            faulthandler.disable()
+            f.close()
+        except Exception:
+            pass
+        _STATE['fault_file'] = None
+
+
+def _announce(text):
+    try:
+        sys.__stderr__.write(text + '\n')
+        sys.__stderr__.flush()
+    except Exception:
+        pass
+
+
+def pytest_runtest_logstart(nodeid, location):
+    _STATE['started'] += 1
+    _announce(f'[mbv-test {_STATE["started"]}] {nodeid}')
+    path = _STATE.get('last_path')
+    if path:
+        try:
+            with open(path, 'w') as fh:
+                fh.write(f'{nodeid}\npassed_before={_STATE["passed"]} failed_before={_STATE["failed"]}\n')
+                fh.flush()
+                os.fsync(fh.fileno())
+        except OSError:
+            pass
+
+
+def pytest_runtest_logreport(report):
+    if report.when == 'call':
+        if report.passed:
+            _STATE['passed'] += 1
+            if _STATE['passed'] % 25 == 0:
+                _announce(f'[mbv-test] passed={_STATE["passed"]} failed={_STATE["failed"]}')
+        elif report.failed:
+            _STATE['failed'] += 1
+            _announce(f'[mbv-test] FAILED {report.nodeid}')
+    elif report.when == 'setup' and report.skipped:
+        _STATE['skipped'] += 1
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _announce(f'[mbv-test] session end: passed={_STATE["passed"]} failed={_STATE["failed"]} '
+              f'skipped={_STATE["skipped"]} exit={exitstatus}')
+
+
+# per-kernel parity first, whole-model next, then captured-graph / launcher / multi-process tests
+_LATE = {'test_model_gpu.py': 1, 'test_fp16_gpu.py': 2, 'test_graph_gpu.py': 3, 'test_launcher_gpu.py': 4,
+         'test_ddp_graph_gpu.py': 5}
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.basename(str(item.fspath))
+        return _LATE.get(name, 0)
+    items.sort(key=key)          # stable: the order inside a class of files is the alphabetical one
 
 
 @pytest.fixture(scope='session')
