@@ -1068,7 +1068,28 @@ def launch_tn_group(items) -> None:
     launch), one call per 16-bit dtype."""
     items = sorted(items, key=lambda it: -it[0].shape[0])
     for dt in {it[0].dtype for it in items}:
-        gemm16_tn_group([it for it in items if it[0].dtype == dt])
+        for wave in _distinct_destination_waves([it for it in items if it[0].dtype == dt]):
+            gemm16_tn_group(wave)
+
+
+def _distinct_destination_waves(items):
+    """Split ``(g, x, acc)`` products into successive launches whose ``acc`` ranges are pairwise disjoint.  Inside one
+    grouped launch a destination is read-modified-written without atomics (single-range entries add their tile in
+    place, multi-range entries are folded in by ``k_add_parts_group``), so a weight used twice in one backward pass —
+    tied weights, one Linear applied twice — must not meet itself in a launch: its second product goes to the next
+    one, which the stream orders behind the first."""
+    waves = []                       # [(items, [(lo, hi) byte ranges])]
+    for it in items:
+        lo = it[2].data_ptr()
+        hi = lo + it[2].numel() * it[2].element_size()
+        for w_items, w_ranges in waves:
+            if all(hi <= a or lo >= b for a, b in w_ranges):
+                w_items.append(it)
+                w_ranges.append((lo, hi))
+                break
+        else:
+            waves.append(([it], [(lo, hi)]))
+    return [w for w, _ in waves]
 
 
 def gemm16_tn_group(items) -> None:
@@ -1103,6 +1124,23 @@ def _defer_colsum(g2: torch.Tensor, out: torch.Tensor, rows: int, n: int, ld: in
         return False
     lists[1].append((g2, out, int(rows), int(n), int(ld), int(offset), torch.cuda.current_stream()))
     return True
+
+
+def _colsum_now(g2: torch.Tensor, out: torch.Tensor, rows: int, n: int, ld: int, offset: int = 0) -> None:
+    """The immediate form of :func:`_defer_colsum` (the kernel that produced ``g2`` was told its reduction comes later,
+    so when the queue refuses it the reduction has to happen here — dropping it would lose the gradient silently)."""
+    if g2.dtype not in _ACT_DTYPES or out.dtype != torch.float32:
+        raise MaskBevHipError('column-sum accumulate: g2 must be f32, bf16 or fp16 and out f32')
+    if not out.is_contiguous():
+        tmp = torch.zeros(n, dtype=torch.float32, device=out.device)
+        _colsum_now(g2, tmp, rows, n, ld, offset)
+        out.add_(tmp)
+        return
+    lib = _lib.load()
+    PA, IA, LA = ctypes.c_void_p * 1, ctypes.c_int32 * 1, ctypes.c_int64 * 1
+    check(lib.mbv_colsum_accum_group(PA(g2.data_ptr() + offset * g2.element_size()), IA(_dt_flag(g2.dtype)),
+                                     LA(int(rows)), IA(int(n)), LA(int(ld)), PA(out.data_ptr()), 1, _stream()),
+          'mbv_colsum_accum_group')
 
 
 def flush_deferred_grads(task_id: Optional[int] = None) -> None:
@@ -2032,8 +2070,8 @@ class _AddLayerNorm(torch.autograd.Function):
               'mbv_add_layernorm_bwd2')
         if defer:
             for j, dst in enumerate((dgamma, dbeta, None if bb is None else bb.grad)[:np_]):
-                ok = _defer_colsum(ws, dst, nblk, c, np_ * c, offset=j * c)
-                assert ok, 'deferred LayerNorm parameter reduction could not be queued'
+                if not _defer_colsum(ws, dst, nblk, c, np_ * c, offset=j * c):
+                    _colsum_now(ws, dst, nblk, c, np_ * c, offset=j * c)
 
         # (the branch Linear's own backward, which runs after this one, announces its bias gradient to the hooks)
         if direct:
@@ -2318,8 +2356,8 @@ class _MergeLayerNorm(torch.autograd.Function):
                                           1 if defer else 0, _stream()), 'mbv_merge_layernorm_bwd')
         if defer:
             for j, dst in enumerate((dgamma, dbeta)):
-                ok = _defer_colsum(ws, dst, nblk, c4, 2 * c4, offset=j * c4)
-                assert ok, 'deferred LayerNorm parameter reduction could not be queued'
+                if not _defer_colsum(ws, dst, nblk, c4, 2 * c4, offset=j * c4):
+                    _colsum_now(ws, dst, nblk, c4, 2 * c4, offset=j * c4)
         if direct:
             _fire_grad_hooks(weight)
             _fire_grad_hooks(bias)

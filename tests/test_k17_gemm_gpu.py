@@ -150,6 +150,56 @@ def test_tn_group_equals_per_layer_products(dt):
 
 
 @gpu
+def test_tn_group_with_a_repeated_destination():
+    """A weight used twice in one backward pass (tied weights, one Linear applied twice) queues two products on the
+    SAME dW.  Inside one grouped launch a destination is updated without atomics, so the launcher must separate them
+    (ops.launch_tn_group -> successive launches): both contributions arrive, single-part and multi-part entries alike."""
+    from mask_bev_amd import ops
+    dt = torch.bfloat16
+    items, acc0, refs = [], {}, {}
+    for name, (n, k) in {'small': (128, 128), 'deep': (192, 192)}.items():
+        acc0[name] = _rand((n, k), torch.float32, 7)
+        refs[name] = acc0[name].double().clone()
+    accs = {name: a.clone() for name, a in acc0.items()}
+    for i, (name, m) in enumerate([('small', 400), ('deep', 20000), ('small', 700), ('deep', 9000), ('small', 400)]):
+        n, k = accs[name].shape
+        g, x = _rand((m, n), dt, 10 + i), _rand((m, k), dt, 20 + i)
+        items.append((g, x, accs[name]))
+        refs[name] += g.double().t() @ x.double()
+    waves = ops._distinct_destination_waves(items)
+    assert [len(w) for w in waves] == [2, 2, 1]
+    ops.launch_tn_group(items)
+    for name in accs:
+        err = (accs[name].double() - refs[name]).abs().max().item()
+        assert err < 3e-5 * math.sqrt(30000) * 4, (name, err)
+
+
+@gpu
+def test_linear_applied_twice_in_one_backward_pass():
+    """The same through autograd: one arena Linear applied twice to 16-bit inputs; its weight gradient (two deferred
+    K17 products on one dW) against the f32 expression on the same rounded operands."""
+    from mask_bev_amd import arena as A, layers, ops
+    torch.manual_seed(0)
+    lin = layers.Linear(192, 192).to(_dev())
+    A.ParameterArena([('m', lin)], torch.bfloat16)
+    assert getattr(lin.weight, '_mbv_arena', False)
+    x1 = _rand((8192, 192), torch.bfloat16, 1).requires_grad_()
+    x2 = _rand((8192, 192), torch.bfloat16, 2).requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = lin(x1).float().square().sum() * 1e-3 + lin(x2).float().sum()
+    y.backward()
+    ops.flush_deferred_grads()
+    w = lin.weight.detach().to(torch.bfloat16).double()
+    b = lin.bias.detach().double()
+    y1 = x1.detach().double() @ w.t() + b
+    g1 = (2e-3 * y1).to(torch.bfloat16).double()            # the gradient the 16-bit layer sees
+    g2 = torch.ones_like(y1)
+    ref = g1.t() @ x1.detach().double() + g2.t() @ x2.detach().double()
+    got = lin.weight.grad.double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
+@gpu
 def test_tn_store_batched():
     from mask_bev_amd import ops
     dt = torch.bfloat16

@@ -14,15 +14,17 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
 
 
+@pytest.mark.parametrize('pc_dim', [4, 3])
 @pytest.mark.parametrize('chans,P,sizes,training', [([32, 32, 32], 8, [3000, 2000], True),
                                                     ([128, 128, 128], 32, [6000], True),
                                                     ([64, 128], 4, [1500, 10, 900], True),
                                                     ([32, 32, 32], 8, [2500], False)])
-def test_pfn_matches_dense_oracle(device, chans, P, sizes, training):
+def test_pfn_matches_dense_oracle(device, chans, P, sizes, training, pc_dim):
     from mask_bev_amd import ops
     from mask_bev_amd.encoders import PillarFeatureNet
     kw = dict(x_range=(-10, 10), y_range=(-10, 10), z_range=(-3, 1), voxel_size=0.25, num_queries=4, max_num_points=P,
-              encoder_feat_channels=chans, backbone_embed_dim=48, head_feat_channels=128, head_out_channels=128)
+              encoder_feat_channels=chans, backbone_embed_dim=48, head_feat_channels=128, head_out_channels=128,
+              pc_point_dim=pc_dim)      # 3 = xyz only (Waymo, mask_bev_module.py:74): a 10-channel decoration
     cfg = O.make_cfg(**kw)
     sd = {k: v for k, v in O.make_state_dict(cfg, 3).items() if k.startswith(O.ENC + '_voxel_encoder')}
     for k in list(sd):
@@ -40,7 +42,7 @@ def test_pfn_matches_dense_oracle(device, chans, P, sizes, training):
     go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
     ref.backward(go)
     # product
-    net = PillarFeatureNet(in_channels=4, feat_channels=chans, with_distance=True, voxel_size=cfg.voxel_size3,
+    net = PillarFeatureNet(in_channels=pc_dim, feat_channels=chans, with_distance=True, voxel_size=cfg.voxel_size3,
                            point_cloud_range=cfg.pc_range)
     net.load_state_dict({k[len(O.ENC + '_voxel_encoder.'):]: v for k, v in sd.items()})
     net = net.to(device).train(training)

@@ -206,16 +206,23 @@ def main(argv=None):
                 tot += float(model.validation_step(val.batch(epoch, i), i))
                 n += 1
         model.train()
-        return tot / max(1, n)
+        v = tot / max(1, n)
+        if world > 1:                  # every rank validates its own shard: the monitored value is the mean over ranks
+            from mask_bev_amd.ddp import reduce_scalars
+            v = reduce_scalars({'val_loss': torch.tensor(v, device=device)})['val_loss']
+        return float(v)
 
     if is_training:
         model.train()
         if rank == 0:
             checkpoint_folder_path.mkdir(parents=True, exist_ok=True)
         graphed, step_count, best = None, 0, float('inf')
+        # EarlyStopping(check_metric, patience=30) of the reference's Trainer (train_mask_bev.py:100): stop after 30
+        # epochs without an improvement of the monitored metric (Lightning's default min_delta = 0, mode = 'min')
+        es_best, es_wait, es_patience = float('inf'), 0, 30
         for epoch in range(args.max_epochs):
             model.current_epoch = epoch
-            t0, losses = time.perf_counter(), []
+            t0, loss_sum, n_steps = time.perf_counter(), None, 0
             n_batches = int(len(data) * float(config.get('limit_train_batches', 1.0))) if isinstance(
                 config.get('limit_train_batches', 1.0), float) else int(config.get('limit_train_batches'))
             for i in range(max(1, n_batches)):
@@ -236,11 +243,15 @@ def main(argv=None):
                         reducer.finish(optimizer)
                     optimizer.step()
                     optimizer.zero_grad(set_to_none=False)
-                losses.append(loss.detach())
+                # accumulate on the device: the graphed step returns ONE static tensor that every replay overwrites,
+                # so keeping references would average N aliases of the last batch's loss (the reference monitors the
+                # epoch mean of train_loss, mask_bev_module.py:296 `self.log('train_loss', ..., on_epoch=True)`)
+                loss_sum = loss.detach().clone() if loss_sum is None else loss_sum + loss.detach()
+                n_steps += 1
                 step_count += 1
                 if 0 < args.max_steps <= step_count:
                     break
-            train_loss = float(torch.stack(losses).mean())
+            train_loss = float(loss_sum) / max(1, n_steps)
             if world > 1:
                 from mask_bev_amd.ddp import reduce_scalars
                 train_loss = reduce_scalars({'train_loss': torch.tensor(train_loss, device=device)})['train_loss']
@@ -254,7 +265,7 @@ def main(argv=None):
                 dt = time.perf_counter() - t0
                 print(f'epoch {epoch}: train_loss {train_loss:.6f}'
                       + (f' val_loss {val_loss:.6f}' if val_loss is not None else '')
-                      + f'  {len(losses) * int(config.get("batch_size", 1)) * world / dt:.1f} scans/s', flush=True)
+                      + f'  {n_steps * int(config.get("batch_size", 1)) * world / dt:.1f} scans/s', flush=True)
                 save_checkpoint(model, optimizer, checkpoint_folder_path / 'last.ckpt', epoch, check_metric, monitored)
                 if monitored < best:
                     best = monitored
@@ -263,12 +274,23 @@ def main(argv=None):
                     save_checkpoint(model, optimizer, checkpoint_folder_path /
                                     f'{exp_name}-epoch={epoch:02d}-{check_metric}={monitored:.6f}.ckpt', epoch,
                                     check_metric, monitored)
+            if monitored < es_best:
+                es_best, es_wait = monitored, 0
+            else:
+                es_wait += 1
+            if es_wait >= es_patience:         # `monitored` is rank-reduced, so every rank stops at the same epoch
+                if rank == 0:
+                    print(f'early stopping: {check_metric} did not improve in {es_patience} epochs '
+                          f'(best {es_best:.6f})', flush=True)
+                break
             if 0 < args.max_steps <= step_count:
                 break
         if graphed is not None:
             graphed.close()
 
     if is_testing:
+        # the reference runs trainer.validate then trainer.test (train_mask_bev.py:118-119); MaskBevModule defines no
+        # test_step, so the test pass has nothing of its own to run: validation is the whole of it
         v = validate(0)
         if rank == 0:
             print(f'val_loss {v}' if v is not None else 'no validation data configured')
