@@ -193,6 +193,25 @@ int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, co
 
 int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int64_t* spatial_shapes_host);
 
+/* d(value) of form (a) with packed fixed-point LDS accumulators (16-bit compute modes): two adjacent channels of a
+ * contribution are rounded to signed 32-bit fixed point and added as ONE `ds_add_u64` — half the LDS-atomic instructions
+ * of the f64 form, all levels in one launch, order-independent (integer) sums.  The scale is taken per block from
+ * L1 = sum over queries of (|attention weights| of the level) x (largest |grad_out| of the block's channels), an upper
+ * bound of every pixel's sum for any sampling pattern, so the 32-bit halves cannot wrap; addends are rounded to
+ * 2^-30 of that bound's power of two.  head_dim == 32, num_points == 4, every level map <= 8192 pixels,
+ * host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
+ * consecutive (batch, value) rows — e.g. straight into the first H*D columns of the 16-bit matrix
+ * [d value | d offsets | d logits] whose product with [Wv; Wo; Wa] is d(x).  Every element of that block is written
+ * (no zero fill needed).  `_supported` returns 1 when the shape qualifies (and MBV_MSDA_PACKED != 0).
+ * Replaces the same mmcv backward as mbv_ms_deform_attn_bwd (value part). */
+int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, int32_t num_levels, int32_t num_points,
+                                                  int32_t num_query, const int64_t* spatial_shapes_host);
+int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const float* sampling_loc, const float* attn_weight,
+                                        int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
+                                        int32_t num_levels, int32_t num_query, int32_t num_points,
+                                        const int64_t* spatial_shapes_host, void* grad_value, int32_t out_dtype,
+                                        int64_t out_ld, void* stream);
+
 int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
                            int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
@@ -657,6 +676,55 @@ size_t mbv_gemm16_tn_group_workspace_bytes(const int64_t* m, const int64_t* n, c
 int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const* dw, const int64_t* m, const int64_t* n,
                         const int64_t* k, const int64_t* ldg, const int64_t* ldx, int32_t count, int32_t dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K19 — row-local stage chains of the transformer decoder's query side (csrc/rowchain.hip).
+ * Replaces, per decoder layer, the few-row Linear / LayerNorm / ReLU / add launches between two attention calls of
+ * mask_bev/models/networks/mask2former_head/mask2former_head.py:535-560 (mmdet Mask2FormerTransformerDecoderLayer:
+ * cross-attn out-proj + LN, self-attn projections, out-proj + LN, FFN + LN) and the prediction-head MLPs of :428-472.
+ * A workgroup owns 16 token rows and runs `num_stages` stages over them; activations stay in LDS slots
+ * (mbv_rowchain_slots() slots of 16 x 256 f32) between stages.  Stage operations:
+ *   MBV_RC_LOAD    dst <- rows of p0 (dtype = flags & 3, row stride ld) [+ f32 p1 at row (r % q_mod), stride ld2];
+ *                  p0 == NULL: the base operand is slot `src` (then p1 is required).  Rows >= `rows` load as zeros.
+ *   MBV_RC_STORE   rows of p0 <- src (dtype = flags & 3, stride ld); MBV_RC_ACCUM: p0 += src (f32).
+ *   MBV_RC_GEMM    dst = act((ACCUM ? dst : 0) + src (16 x k) . W^T + bias), W = p0 (n, k) row-major with row stride ld in
+ *                  the program's weight dtype, bias = p1 f32 or NULL; MBV_RC_RELU; MBV_RC_MASK: result zeroed where
+ *                  slot src2 <= 0 (ReLU backward).  f32 weights: exact f32 MFMA; 16-bit weights: activations rounded to
+ *                  that type, f32 accumulation.  n <= 256, k <= 256, k % 16 (f32) / 32 (16-bit) == 0, dst != src.
+ *   MBV_RC_LN      dst = LayerNorm(src [+ src2]) * p0 + p1 (src2 = -1: none); MBV_RC_SAVE_SUM: src <- the sum;
+ *                  p2 (nullable): (rows, 2) f32 <- (mean, rstd).
+ *   MBV_RC_LN_BWD  dst = d(sum) given src = d(output), src2 = the sum, p0 = gamma, p2 = stats; p1 (nullable):
+ *                  (blocks, 2 n) f32 <- this block's partial d(gamma) | d(beta).
+ *   MBV_RC_ADD     dst = src + src2.      MBV_RC_COLSUM  p0[block * ld + c] = sum over the block's rows of src.
+ * Data gradients dX = dY . W are MBV_RC_GEMM stages against transposed weight copies (mbv_transpose_group).
+ * The program is copied into the kernel arguments (<= mbv_rowchain_max_stages() stages): nothing is retained. */
+#define MBV_RC_LOAD 0
+#define MBV_RC_STORE 1
+#define MBV_RC_GEMM 2
+#define MBV_RC_LN 3
+#define MBV_RC_LN_BWD 4
+#define MBV_RC_ADD 5
+#define MBV_RC_COLSUM 6
+#define MBV_RC_ACCUM 4
+#define MBV_RC_RELU 8
+#define MBV_RC_MASK 16
+#define MBV_RC_SAVE_SUM 32
+#define MBV_TR_MAX 96
+typedef struct MbvRowStage {
+  int32_t op;
+  int16_t dst, src, src2, reserved;
+  int32_t n, k, flags, ld, ld2;
+  const void* p0;
+  const void* p1;
+  const void* p2;
+} MbvRowStage;
+int mbv_rowchain_max_stages(void);
+int mbv_rowchain_slots(void);
+int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
+                     int32_t wdtype, void* stream);
+/* dst[i] (cols, rows) = transpose of src[i] (rows, cols), n matrices of elem_size 2 or 4 bytes, <= MBV_TR_MAX per launch. */
+int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols, int32_t n,
+                        int32_t elem_size, void* stream);
 
 #ifdef __cplusplus
 }

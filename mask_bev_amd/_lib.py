@@ -49,8 +49,14 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_msda_prepare_bwd_ld': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_ms_deform_attn_bwd_split': (ctypes.c_int, [_I, _I, _P]),
+    'mbv_ms_deform_attn_bwd_value_packed_supported': (ctypes.c_int, [_I, _I, _I, _I, _P]),
+    'mbv_ms_deform_attn_bwd_value_packed': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _L, _P]),
     'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I,
                                               _P]),
+    'mbv_rowchain_max_stages': (ctypes.c_int, []),
+    'mbv_rowchain_slots': (ctypes.c_int, []),
+    'mbv_rowchain_run': (ctypes.c_int, [_P, _I, _I, _I, _F, _I, _P]),
+    'mbv_transpose_group': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),
     'mbv_window_attn_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),

@@ -724,6 +724,182 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value_merge(const float* __re
         make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// d(value) with PACKED FIXED-POINT LDS accumulators (round 3; 16-bit compute modes).
+//
+// The f64 form above is bound by the LDS atomic pipe: one `ds_add_f64` wave instruction costs 9-16 clocks whatever
+// its active lanes and carries ONE f32 addend per lane — 16 instructions per sample for a 4-channel group.  Integer
+// LDS atomics cost the same per instruction (`ds_add_u64` ≈ 9 clocks, scratch/ubench/lds_atomic.hip), and an integer
+// sum can carry TWO addends: a contribution w·g of two adjacent channels is rounded to two signed 32-bit fixed-point
+// numbers and added as one 64-bit word `(hi << 32) + lo` (two's complement: a negative `lo` borrows from `hi`, and the
+// borrow is undone exactly when the word is split again, as long as both sums stay inside 32 bits).  Half the atomic
+// instructions, the cheaper instruction, half the LDS per channel — so one launch holds all three levels (the
+// finest level's blocks take 2 channels = one 32 KB plane, the coarser levels' 4 channels = two planes) with every
+// block resident at once — and integer addition is associative: the result does not depend on the order in which the
+// waves arrive (bit-reproducible, like the f64 form).
+//
+// Range / precision: a block first takes L1 = sum over its queries of (attention mass of the (query, head) on this
+// level) x (largest |grad_out| among the block's channels) from the rows it is going to read anyway.  The bilinear
+// weight of a corner is in [0, 1] and a sample puts at most one corner on a pixel, so |sum at a pixel| <= L1 for ANY
+// sampling pattern and any weights; with the scale 2^(29 - e), L1 < 2^e, the 32-bit halves cannot wrap (one bit of
+// margin for the roundings).  Every addend is rounded to 2^(e - 30): with 5 376 queries and unit-variance gradients
+// about 4e-6 — three decimal digits finer than the bf16 / fp16 GEMM operands on either side of this kernel.  The f32
+// compute mode keeps the f64 accumulators.
+//
+// Output: written straight in the caller's dtype (f32, or the 16-bit type of the matrix whose first columns are
+// d(value) — ops._MSDAQuerySide's [d value | d offsets | d logits]) with the caller's row stride.
+struct MsdaFxArgs {
+  const float* grad_out;
+  const float* loc;
+  const float* attn;
+  void* out;
+  int64_t out_ld;        // elements between consecutive (b, n) rows of `out`
+  int out_dt;            // MBV_DT_F32 / BF16 / F16
+  int levels, num_value, num_query, heads, frac_bits, batch;
+  int h[8], w[8], lstart[8];
+  int planes[8];         // u64 planes per block of that level: 1 (2 channels) or 2 (4 channels)
+  int block_begin[9];    // first block of each level's range
+};
+
+__device__ __forceinline__ unsigned long long fx_pack(float a, float b) {      // a -> low half, b -> high half
+  const int lo = __float2int_rn(a), hi = __float2int_rn(b);
+  return ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32) | (unsigned)lo;
+}
+
+// two adjacent channels in the output's dtype (DT = MBV_DT_F32 / BF16 / F16), one 8- or 4-byte store
+template <int DT>
+__device__ __forceinline__ void fx_store2(void* base, int64_t elem, float a, float b) {
+  if constexpr (DT == MBV_DT_F32) {
+    *reinterpret_cast<float2*>(reinterpret_cast<float*>(base) + elem) = make_float2(a, b);
+  } else {
+    unsigned ua, ub;
+    if constexpr (DT == MBV_DT_BF16) {
+      ua = f32_to_bf16_rne(a); ub = f32_to_bf16_rne(b);
+    } else {
+      ua = __builtin_bit_cast(unsigned short, (_Float16)a); ub = __builtin_bit_cast(unsigned short, (_Float16)b);
+    }
+    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(base) + elem) = ua | (ub << 16);
+  }
+}
+
+template <int PLANES, int DT>
+__device__ __forceinline__ void msda_value_fx_block(const MsdaFxArgs& A, int level, int local, unsigned long long* map) {
+  constexpr int dim = 32, CH = 2 * PLANES, NT = 512;
+  const int nbh = A.batch * A.heads;
+  // block -> (group, batch*head): the groups of one (batch, head) sit at ids equal modulo 8, i.e. on one XCD / L2
+  const int split = local / nbh, bhid = local - split * nbh;
+  const int hd = bhid % A.heads, b = bhid / A.heads;
+  const int h = A.h[level], w = A.w[level], npix = h * w;
+  const int num_query = A.num_query, heads = A.heads, levels = A.levels;
+  for (int i = threadIdx.x; i < PLANES * npix; i += NT) map[i] = 0ull;
+  // Range: |sum at a pixel| <= L1 := sum over queries of (this level's attention mass of the (query, head)) x (largest
+  // |grad_out| among this block's channels) — every addend is (bilinear weight <= 1) x (attention weight) x g, and a
+  // sample puts at most one corner on a pixel.  The block computes L1 from the rows it is going to read anyway and
+  // scales by 2^(29 - e), L1 < 2^e: the 32-bit halves cannot wrap (one bit of margin for the roundings), whatever the
+  // sampling pattern, and typical inputs get 4-5 bits more than the a-priori bound num_query * max|g| would leave.
+  __shared__ float red[NT / 64];
+  const int QS = (num_query + 63) >> 6;                // lane l of every wave owns queries l * QS .. l * QS + QS - 1
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float l1 = 0.f;
+  for (int it = wave; it < QS; it += NT / 64) {
+    const int q = lane * QS + it;
+    if (q >= num_query) continue;
+    const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
+    const float* gp = A.grad_out + qh * dim + split * CH;
+    float m;
+    if constexpr (PLANES == 2) {
+      const float4 g = *reinterpret_cast<const float4*>(gp);
+      m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+    } else {
+      const float2 g = *reinterpret_cast<const float2*>(gp);
+      m = fmaxf(fabsf(g.x), fabsf(g.y));
+    }
+    const float4 a4 = *reinterpret_cast<const float4*>(A.attn + (qh * levels + level) * 4);
+    l1 += m * (fabsf(a4.x) + fabsf(a4.y) + fabsf(a4.z) + fabsf(a4.w));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o);
+  if (lane == 0) red[wave] = l1;
+  __syncthreads();
+  l1 = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) l1 += red[i];
+  l1 *= 1.0001f;                                       // the f32 sum itself is rounded
+  if (!(l1 == l1) || l1 > 3.0e38f) l1 = 3.0e38f;      // NaN / inf gradients: no meaningful scale, keep the kernel defined
+  int e = 0;
+  if (l1 > 0.f) (void)frexpf(l1, &e);                 // l1 = f * 2^e, f in [0.5, 1): l1 < 2^e
+  const float scale = ldexpf(1.f, 29 - e), inv_scale = ldexpf(1.f, e - 29);
+  // lane -> query map with stride QS: the 64 lanes of an atomic instruction are QS queries apart (more than a map row),
+  // so they rarely meet on a pixel — consecutive queries are neighbouring pixels whose samples share corners at every
+  // level, and an LDS atomic serialises lanes that hit the same address.  (The loads lose nothing: a query's rows are
+  // 768 B / 1 KB apart either way.)  The next query's 64 bytes are requested before the current query's adds.
+  float4 n_go = make_float4(0.f, 0.f, 0.f, 0.f), n_l01 = n_go, n_l23 = n_go, n_a4 = n_go;
+  auto load_q = [&](int q, float4& go, float4& l01, float4& l23, float4& a4) {
+    const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
+    const int64_t kb = (qh * levels + level) * 4;
+    const float* gp = A.grad_out + qh * dim + split * CH;
+    if constexpr (PLANES == 2) {
+      go = *reinterpret_cast<const float4*>(gp);
+    } else {
+      const float2 g = *reinterpret_cast<const float2*>(gp);
+      go = make_float4(g.x, g.y, 0.f, 0.f);
+    }
+    l01 = *reinterpret_cast<const float4*>(A.loc + kb * 2);
+    l23 = *reinterpret_cast<const float4*>(A.loc + kb * 2 + 4);
+    a4 = *reinterpret_cast<const float4*>(A.attn + kb);
+  };
+  if (wave < QS && lane * QS + wave < num_query) load_q(lane * QS + wave, n_go, n_l01, n_l23, n_a4);
+  for (int it = wave; it < QS; it += NT / 64) {
+    const int q = lane * QS + it;
+    const bool live = q < num_query;
+    float4 go = n_go;
+    const float4 l01 = n_l01, l23 = n_l23, a4 = n_a4;
+    const int itn = it + NT / 64;
+    if (itn < QS && lane * QS + itn < num_query) load_q(lane * QS + itn, n_go, n_l01, n_l23, n_a4);
+    if (!live) continue;
+    go.x *= scale; go.y *= scale; go.z *= scale; go.w *= scale;
+    const float lx[4] = {l01.x, l01.z, l23.x, l23.z}, ly[4] = {l01.y, l01.w, l23.y, l23.w};
+    const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      Corner c;
+      if (!bilinear_setup(lx[u], ly[u], h, w, 1, c)) continue;          // offsets in pixels
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = c.off[j];
+        if (off < 0) continue;
+        const float wj = c.wgt[j] * aw[u];
+        atomicAdd(&map[off], fx_pack(wj * go.x, wj * go.y));
+        if constexpr (PLANES == 2) atomicAdd(&map[npix + off], fx_pack(wj * go.z, wj * go.w));
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t gv = ((int64_t)b * A.num_value + A.lstart[level]) * A.out_ld + hd * dim + split * CH;
+  for (int i = threadIdx.x; i < npix; i += NT) {
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl) {
+      const long long v = (long long)map[pl * npix + i];
+      const int lo = (int)(unsigned)(v & 0xffffffffll);
+      const int hi = (int)((v - (long long)lo) >> 32);
+      fx_store2<DT>(A.out, gv + (int64_t)i * A.out_ld + 2 * pl, (float)lo * inv_scale, (float)hi * inv_scale);
+    }
+  }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(512) k_msda_bwd_value_fx(const MsdaFxArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long fxmap[];
+  int level = 0;                                     // block ranges: block_begin[l] .. block_begin[l + 1]
+  for (int l = 1; l < A.levels; ++l)
+    if ((int)blockIdx.x >= A.block_begin[l]) level = l;
+  const int local = (int)blockIdx.x - A.block_begin[level];
+  if (A.planes[level] == 2)
+    msda_value_fx_block<2, DT>(A, level, local, fxmap);
+  else
+    msda_value_fx_block<1, DT>(A, level, local, fxmap);
+}
+
 // d(location), d(weight): 8 lanes per (query, head), 4 channels per lane
 __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restrict__ grad_out,
                                                           const float* __restrict__ value,
@@ -844,9 +1020,9 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0 || num_points <= 0)
     return MBV_ERR_BAD_ARG;
   if (!pow2_le64(head_dim)) return MBV_ERR_UNSUPPORTED;
-  if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_value ||
-      !grad_loc || !grad_attn)
-    return MBV_ERR_BAD_ARG;
+  if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight) return MBV_ERR_BAD_ARG;
+  // an output may be null when `part` leaves it out (1 = value only, 2 = location / weight only)
+  if ((!grad_value && ((part & 3) != 2)) || ((!grad_loc || !grad_attn) && ((part & 3) != 1))) return MBV_ERR_BAD_ARG;
   // part: bit 0 = d(value), bit 1 = d(location, weight); bits 2.. = optional mask of the levels whose d(value) this
   // call produces (0 = all) — a caller may put the levels' launches on different streams
   const int level_mask = part >> 2;
@@ -958,6 +1134,74 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   hipLaunchKernelGGL(k_msda_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, grad_out, value,
                      spatial_shapes, level_start, sampling_loc, attn_weight, total, num_value, num_heads, head_dim,
                      num_levels, num_query, num_points, grad_value, grad_loc, grad_attn);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, int32_t num_levels, int32_t num_points,
+                                                             int32_t num_query, const int64_t* spatial_shapes_host) {
+  if (!spatial_shapes_host || head_dim != 32 || num_points != 4 || num_levels <= 0 || num_levels > 8) return 0;
+  if (num_query <= 0 || num_query > (1 << 18)) return 0;            // >= 12 fractional bits
+  const char* off = getenv("MBV_MSDA_PACKED");
+  if (off && off[0] == '0') return 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const int64_t h = spatial_shapes_host[2 * l], w = spatial_shapes_host[2 * l + 1];
+    if (h <= 0 || w <= 0 || h * w > 8192) return 0;                 // one 64 KB plane at most
+  }
+  return 1;
+}
+
+extern "C" int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const float* sampling_loc,
+                                                   const float* attn_weight, int32_t batch, int32_t num_value,
+                                                   int32_t num_heads, int32_t head_dim, int32_t num_levels,
+                                                   int32_t num_query, int32_t num_points,
+                                                   const int64_t* spatial_shapes_host, void* grad_value,
+                                                   int32_t out_dtype, int64_t out_ld, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0) return MBV_ERR_BAD_ARG;
+  if (!grad_out || !sampling_loc || !attn_weight || !grad_value || !spatial_shapes_host) return MBV_ERR_BAD_ARG;
+  if (!mbv_ms_deform_attn_bwd_value_packed_supported(head_dim, num_levels, num_points, num_query, spatial_shapes_host))
+    return MBV_ERR_UNSUPPORTED;
+  if (out_dtype != MBV_DT_F32 && out_dtype != MBV_DT_BF16 && out_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
+  const int esz = out_dtype == MBV_DT_F32 ? 4 : 2;
+  if (out_ld < (int64_t)num_heads * head_dim || (out_ld * esz) % 4 != 0 || (reinterpret_cast<size_t>(grad_value) & 7) != 0 ||
+      ((reinterpret_cast<size_t>(grad_out) | reinterpret_cast<size_t>(sampling_loc) |
+        reinterpret_cast<size_t>(attn_weight)) & 15) != 0)
+    return MBV_ERR_BAD_ARG;
+  if (out_dtype == MBV_DT_F32 && (out_ld % 2) != 0) return MBV_ERR_BAD_ARG;
+  MsdaFxArgs A;
+  A.grad_out = grad_out; A.loc = sampling_loc; A.attn = attn_weight; A.out = grad_value; A.out_ld = out_ld;
+  A.out_dt = out_dtype; A.levels = num_levels; A.num_value = num_value; A.num_query = num_query; A.heads = num_heads;
+  A.batch = batch;
+  int bits = 0;
+  while ((1 << bits) < num_query) ++bits;
+  A.frac_bits = 30 - bits;
+  int lstart = 0, max_pix_bytes = 0;
+  const int nbh = batch * num_heads;
+  for (int l = 0; l < num_levels; ++l) {
+    A.h[l] = (int)spatial_shapes_host[2 * l]; A.w[l] = (int)spatial_shapes_host[2 * l + 1]; A.lstart[l] = lstart;
+    lstart += A.h[l] * A.w[l];
+  }
+  if (lstart != num_value) return MBV_ERR_BAD_ARG;
+  // a level with a large map gets one plane (2 channels) per block, so that every block fits 32 KB of LDS and all
+  // blocks of the launch (4 per CU) are resident at once
+  int blocks = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const int npix = A.h[l] * A.w[l];
+    A.planes[l] = npix * 16 <= 32768 ? 2 : 1;
+    const int bytes = A.planes[l] * npix * 8;
+    if (bytes > max_pix_bytes) max_pix_bytes = bytes;
+    A.block_begin[l] = blocks;
+    blocks += nbh * (32 / (2 * A.planes[l]));
+  }
+  A.block_begin[num_levels] = blocks;
+  const dim3 grid((unsigned)blocks), block(512);
+  if (out_dtype == MBV_DT_F32)
+    hipLaunchKernelGGL(k_msda_bwd_value_fx<MBV_DT_F32>, grid, block, (size_t)max_pix_bytes, stream, A);
+  else if (out_dtype == MBV_DT_BF16)
+    hipLaunchKernelGGL(k_msda_bwd_value_fx<MBV_DT_BF16>, grid, block, (size_t)max_pix_bytes, stream, A);
+  else
+    hipLaunchKernelGGL(k_msda_bwd_value_fx<MBV_DT_F16>, grid, block, (size_t)max_pix_bytes, stream, A);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

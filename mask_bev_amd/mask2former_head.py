@@ -442,6 +442,9 @@ class Mask2FormerHead(nn.Module):
                     [(layers[i].cross_attn.attn.in_proj_weight, layers[i].cross_attn.attn.in_proj_bias) for i in idx])
                 for slot, i in enumerate(idx):
                     shared[i] = (holder, token, slot)
+        if self._fused_decoder_ok(mask_features, shared, deferred):
+            return self._forward_decoder_fused(query_feat, query_embed, mask_features, memories, shared, stack, deferred,
+                                               cls_list, mask_list, blocked, feats_q)
         query_branch = None
         for i, layer in enumerate(layers):
             lvl = i % nl
@@ -458,6 +461,90 @@ class Mask2FormerHead(nn.Module):
                                                  None if stack is None else stack[i + 1])
             cls_list.append(cls_pred)
             mask_list.append(mask_pred)
+        if deferred:
+            self._deferred_autocast = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None
+            outs = _DeferredHeads.apply(self, torch.stack(cls_list, 0), mask_features, *feats_q)
+            cls_list, mask_list = list(outs[0].unbind(0)), list(outs[1:])
+        return cls_list, mask_list, [None for _ in cls_list]
+
+    # ------------------------------------------------------------------ fused query side (K19)
+    def _fused_decoder_ok(self, mask_features, shared, deferred) -> bool:
+        """The row-chain form of the decoder layers (decoder_fused.py): GPU, shared key / value projections for every
+        layer (<= 128 queries), embed / head widths the 256-column LDS slots hold, and either no autograd graph or the
+        deferred (batched-backward) prediction heads — the chain's own heads carry no gradient."""
+        from . import decoder_fused as DF
+        e = self.decoder_embed_dims
+        layers = self.transformer_decoder.layers
+        f = layers[0].ffn.layers[0][0].out_features
+        oc = self.mask_embed[4].out_features
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
+        return (DF.enabled() and mask_features.is_cuda and all(s is not None for s in shared)
+                and (deferred or not torch.is_grad_enabled())
+                and e % 32 == 0 and e <= 256 and f % 32 == 0 and oc % 4 == 0 and oc <= 256
+                and self.mask_embed[0].out_features <= 256 and self.mask_embed[2].out_features <= 256
+                and self.mask_embed[0].out_features % 32 == 0 and self.mask_embed[2].out_features % 32 == 0
+                and dt in ops._ACT_DTYPES and mask_features.dtype in ops._ACT_DTYPES)
+
+    def _forward_decoder_fused(self, query_feat, query_embed, mask_features, memories, shared, stack, deferred,
+                               cls_list, mask_list, blocked, feats_q):
+        """The decoder loop of mask2former_head.py:535-560 with the query side of every layer as two row-chain launches
+        (+ the attention kernels): decoder_fused._DecA / _DecB."""
+        from . import decoder_fused as DF
+        layers = self.transformer_decoder.layers
+        nl = self.num_transformer_feat_level
+        bs, q, e = query_feat.shape
+        dev = mask_features.device
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
+        need_grad = torch.is_grad_enabled()
+        tw = getattr(self, '_dec_transposed', None)
+        if tw is None:
+            tw = self._dec_transposed = DF.TransposedWeights()
+        if need_grad:        # transposed copies for the data gradients: one grouped launch per step
+            ents = []
+            for i, layer in enumerate(layers):
+                ca, sa = layer.cross_attn.attn, layer.self_attn.attn
+                ents += [(ca.out_proj.weight, None), (sa.in_proj_weight, (0, e)), (sa.in_proj_weight, (e, 2 * e)),
+                         (sa.in_proj_weight, (2 * e, 3 * e)), (sa.out_proj.weight, None),
+                         (layer.ffn.layers[0][0].weight, None), (layer.ffn.layers[1].weight, None)]
+                if i > 0:
+                    ents.append((ca.in_proj_weight, (0, e)))
+            tw.refresh(ents, dt)
+        holder = {}
+        qpos = DF.QueryPositions.apply(self.query_embed.weight, holder)
+        f = layers[0].ffn.layers[0][0].out_features
+        lc = DF.LayerCtx(bs, q, e, self.num_heads, f, layers[0].norms[0].eps, dt, tw, holder, qpos)
+        post = self.transformer_decoder.post_norm
+        mlp = [(self.mask_embed[j].weight, self.mask_embed[j].bias) for j in (0, 2, 4)]
+        with torch.autocast('cuda', enabled=False):
+            # layer 0's masked cross-attention (its query projection has no producer chain)
+            l0 = layers[0].cross_attn.attn
+            q_in = query_feat + qpos.unsqueeze(0)
+            qc = ops.linear(q_in, l0.in_proj_weight, l0.in_proj_bias, rows=(0, e))
+            h0, tok0, slot0 = shared[0]
+            o1 = ops.attention_shared_kv(qc, tok0, blocked, self.num_heads, h0, slot0)
+            x = query_feat
+            for i, layer in enumerate(layers):
+                ca, sa = layer.cross_attn.attn, layer.self_attn.attn
+                x1, o2 = DF._DecA.apply(lc, x, o1, ca.out_proj.weight, ca.out_proj.bias, layer.norms[0].weight,
+                                        layer.norms[0].bias, sa.in_proj_weight, sa.in_proj_bias)
+                head = DF.HeadSpec(post.weight, post.bias, self.cls_embed.weight, self.cls_embed.bias, mlp, mask_features,
+                                   None if stack is None else stack[i + 1])
+                nxt, token, nw, nb = None, None, None, None
+                if i + 1 < len(layers):
+                    hn, token, slotn = shared[i + 1]
+                    nca = layers[i + 1].cross_attn.attn
+                    nw, nb = nca.in_proj_weight, nca.in_proj_bias
+                    nxt = DF.NextCross(nw, nb, hn, slotn, memories[(i + 1) % nl].shape[-2:])
+                fc1, fc2 = layer.ffn.layers[0][0], layer.ffn.layers[1]
+                outs = DF._DecB.apply(lc, head, nxt, x1, o2, token, sa.out_proj.weight, sa.out_proj.bias,
+                                      layer.norms[1].weight, layer.norms[1].bias, fc1.weight, fc1.bias, fc2.weight,
+                                      fc2.bias, layer.norms[2].weight, layer.norms[2].bias, nw, nb)
+                x, cls_pred, mask_pred = outs[0], outs[1], outs[2]
+                if nxt is not None:
+                    o1 = outs[3]
+                feats_q.append(x)
+                cls_list.append(cls_pred)
+                mask_list.append(mask_pred)
         if deferred:
             self._deferred_autocast = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None
             outs = _DeferredHeads.apply(self, torch.stack(cls_list, 0), mask_features, *feats_q)

@@ -549,7 +549,30 @@ class _MSDeformAttn(torch.autograd.Function):
 _MSDA_SIDE = {}
 
 
-def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn):
+def msda_value_packed_ok(dims, host) -> bool:
+    """Whether d(value) of this shape can take the packed fixed-point form (mbv_ms_deform_attn_bwd_value_packed)."""
+    b, nv, nh, d, nl, nq, npnt = dims
+    return bool(host is not None and _lib.load().mbv_ms_deform_attn_bwd_value_packed_supported(d, nl, npnt, nq, host))
+
+
+def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn,
+                   packed_out=None):
+    """``packed_out = (tensor, row stride in elements)``: d(value) goes there in the tensor's dtype through the packed
+    fixed-point kernel (16-bit compute modes; the caller guarantees softmaxed weights) and ``g_value`` is not written."""
+    if packed_out is not None:
+        b, nv, nh, d, nl, nq, npnt = dims
+        dst, ld = packed_out
+        check(lib.mbv_ms_deform_attn_bwd_value_packed(_ptr(g_out), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt, host,
+                                                      _ptr(dst), _dt_flag(dst.dtype), int(ld), _stream()),
+              'mbv_ms_deform_attn_bwd_value_packed')
+        check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
+                                         _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(None), _ptr(g_loc),
+                                         _ptr(g_attn), 2, _stream()), 'mbv_ms_deform_attn_bwd')
+        return
+    _msda_backward_f64(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn)
+
+
+def _msda_backward_f64(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn):
     """K5 backward.  The no-atomics form has two independent parts — d(value), bound by the LDS f64-atomic rate, and
     d(location) / d(weight), bound by L2 gathers.  MBV_MSDA_BWD_OVERLAP=1 puts them on two streams; measured inside the
     HIP-graph step the fork / join edges cost more than the overlap returns (34.17 vs 33.88 ms per step), so the
@@ -697,14 +720,21 @@ class _MSDAQuerySide(torch.autograd.Function):
         t = b * n
         dev = xb.device
         g_out = g_out.to(torch.float32).contiguous()
-        g_value = torch.empty_like(value)
         g_loc = torch.empty_like(loc)
         g_attn = torch.empty_like(attn)
         host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
-        _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, (b, n, heads, d, levels, n, points), host_b,
-                       g_value, g_loc, g_attn)
         g = torch.empty((t, width), dtype=dt, device=dev)                 # [d value | d offsets | d logits]
-        g[:, :e].copy_(g_value.view(t, e))
+        dims = (b, n, heads, d, levels, n, points)
+        if dt in _LO_DTYPES and width % 2 == 0 and msda_value_packed_ok(dims, host_b):
+            # 16-bit compute: K5's value gradient is accumulated in packed fixed point (the attention weights are
+            # K16's softmax outputs) and stored straight into the first E columns of G in its dtype — no f32
+            # d(value) tensor, no cast pass
+            _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host_b, None, g_loc, g_attn,
+                           packed_out=(g, width))
+        else:
+            g_value = torch.empty_like(value)
+            _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host_b, g_value, g_loc, g_attn)
+            g[:, :e].copy_(g_value.view(t, e))
         esz = g.element_size()
         check(lib.mbv_msda_prepare_bwd_ld(_ptr(g_loc), _ptr(g_attn), _ptr(attn), host, b, n, heads, levels, points,
                                           _dt_flag(dt), ctypes.c_void_p(g.data_ptr() + e * esz), width,

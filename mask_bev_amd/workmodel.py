@@ -49,6 +49,14 @@ def _msda(a, bwd: bool) -> Work:
     return ('k_msda_fwd_v4', 'hbm', vmap + qmap + samples * 12.0, 0.0)
 
 
+def _msda_value_packed(a) -> Work:
+    # grad_out, loc, attn in; grad_value out in its own dtype
+    b, nv, heads, d, levels, nq, pts = (_i(a[i]) for i in (3, 4, 5, 6, 7, 8, 9))
+    samples = b * nq * heads * levels * pts
+    out_es = 4.0 if _i(a[12]) == 0 else 2.0
+    return ('k_msda_bwd_value_fx', 'hbm', b * nv * heads * d * out_es + b * nq * heads * d * 4.0 + samples * 12.0, 0.0)
+
+
 def _attn(a, bwd: bool, ld: bool) -> Work:
     if bwd:
         i0 = 8 if ld else 7
@@ -145,6 +153,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
     'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
     'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
+    'mbv_ms_deform_attn_bwd_value_packed': _msda_value_packed,
     'mbv_attn_fwd': lambda a: _attn(a, False, False),
     'mbv_attn_fwd_ld': lambda a: _attn(a, False, True),
     'mbv_attn_bwd': lambda a: _attn(a, True, False),

