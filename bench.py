@@ -54,6 +54,10 @@ def parse():
     ap.add_argument('--pool', type=int, default=2, help='distinct synthetic batches kept resident in HBM')
     ap.add_argument('--no-arena', action='store_true', help='per-tensor parameters and torch.optim.AdamW')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the HIP graph')
+    ap.add_argument('--dry-run-collectives', action='store_true',
+                    help='N > 1: log, per step, the bytes and host launch time of every gradient all-reduce piece relative '
+                         'to the graph replays / the encoder backward it is meant to hide under (any backend; with '
+                         'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
     return ap.parse_args()
 
 
@@ -343,6 +347,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if args.dry_run_collectives and graphed is not None:
+        graphed.trace = []
     ops.TIMER.reset()
     ops.TIMER.enabled = True
     if world > 1:
@@ -448,6 +454,17 @@ def main():
             step_roofline=step_roof)
         if fp32_line is not None:
             line['fp32'] = fp32_line
+        if args.dry_run_collectives and graphed is not None and graphed.trace:
+            # host-side launch schedule of the last step: (mark, ms after the first graph replay was issued, MB reduced)
+            last = graphed.trace[-1]
+            t0m = last[0][1]
+            total = sum(nb for _, _, nb in last)
+            line['collectives'] = dict(
+                backend=os.environ.get('MBV_DIST_BACKEND', 'nccl'), bytes_per_step=total,
+                schedule=[dict(mark=name, ms=round((t - t0m) * 1e3, 3), mb=round(nb / 1e6, 2)) for name, t, nb in last],
+                note='host launch times: a piece is launched as soon as the host has issued the work that completes its '
+                     'gradients; on the device it waits for that work through stream order (the comm stream waits for '
+                     'the compute stream at launch)')
         if not args.no_cpu_baseline and world == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.workload, model, args.cpu_baseline_budget_s)

@@ -143,6 +143,11 @@ class _LibProxy:
         return lambda *args: hook(name, fn, args)
 
 
+# What a call's argument list does not say about its algorithmic work (read by workmodel.py under bench.py's hook only):
+# e.g. how many DISTINCT source maps / coordinate sets the rows of a point-sampling call share.
+WORK_HINT: dict = {}
+
+
 def load() -> '_LibProxy':
     """Load the shared library, binding every declared symbol; raises if anything is missing."""
     global _lib

@@ -277,9 +277,9 @@ class _DecA(torch.autograd.Function):
         m, e = lc.m, lc.e
         dev = x0.device
         f32 = dict(dtype=torch.float32, device=dev)
+        ctx.in_shapes = (x0.shape, o1.shape)
         x0 = x0.reshape(m, e).contiguous()
         o1 = o1.reshape(m, e).contiguous()
-        need = torch.is_grad_enabled()
         sum1 = torch.empty((m, e), **f32)
         stats1 = torch.empty((m, 2), **f32)
         x1 = torch.empty((m, e), **f32)
@@ -361,7 +361,7 @@ class _DecA(torch.autograd.Function):
         gbo = _partial_grad(bo, None, part_b, 3 * e, e, ni[4])
         gg1 = _partial_grad(g1, None, part_ln, 0, e, ni[5])
         gb1 = _partial_grad(b1, None, part_ln, e, e, ni[6])
-        return None, ds1.view(lc.b, lc.q, e), g_o1.view(lc.b, lc.q, e), gwo, gbo, gg1, gb1, gw_in, gb_in
+        return None, ds1.view(ctx.in_shapes[0]), g_o1.view(ctx.in_shapes[1]), gwo, gbo, gg1, gb1, gw_in, gb_in
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -389,6 +389,7 @@ class _DecB(torch.autograd.Function):
         m, e, f = lc.m, lc.e, lc.f
         dev = x1.device
         f32 = dict(dtype=torch.float32, device=dev)
+        ctx.in_shapes = (x1.shape, o2.shape)
         x1 = x1.reshape(m, e).contiguous()
         o2 = o2.reshape(m, e).contiguous()
         sum2, sum3 = torch.empty((m, e), **f32), torch.empty((m, e), **f32)
@@ -548,7 +549,7 @@ class _DecB(torch.autograd.Function):
         if g_qc is not None:
             gnw = _weight_grad(nw_in, (0, e), g_qc, t3, ni[16])
             gnb = _partial_grad(nb_in, (0, e), part_b, 0, e, ni[17])
-        return (None, None, None, ds2.view(b, q, e), g_o2.view(b, q, e), None, gwo, gbo, gg2, gb2, gw1, gbb1, gw2, gbb2, gg3,
+        return (None, None, None, ds2.view(ctx.in_shapes[0]), g_o2.view(ctx.in_shapes[1]), None, gwo, gbo, gg2, gb2, gw1, gbb1, gw2, gbb2, gg3,
                 gb3, gnw, gnb)
 
 

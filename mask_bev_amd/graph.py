@@ -33,12 +33,33 @@ the capture (PyTorch emits its "AccumulateGrad node's stream does not match" war
 from __future__ import annotations
 
 import os
+import time
 from typing import Dict, Optional
 
 import torch
 
 from . import ops
 from .mask_bev_module import MaskBevModule
+
+
+def arena_reduce_plan(module: MaskBevModule, arena):
+    """The four pieces of the data-parallel gradient all-reduce of a graph step, in launch order, as element ranges of
+    the arena gradient: [(name, [(lo, hi), ...]), ...].  Each piece is launched as soon as its gradients are complete
+    (``GraphedTrainStep.step``): (1) after graph 1, underneath graph 2; (2) after graph 2 and (3) from the gradient
+    hook of K3's backward, both underneath the eager encoder backward; (4) after it — the only exposed part.
+    Together they cover the arena exactly once (tests/test_ddp_gloo.py).  Replaces Lightning's DDP bucket order
+    (/root/reference: train_mask_bev.py:92-96, ``strategy='ddp'``)."""
+    swin = module._backbone._backbone
+    last = len(swin.stages) - 1
+    a, b = arena.segments['backbone']
+    lo, hi = arena.range_of(swin.stages[last])
+    ln = arena.range_of(module._encoder._layer_norm)
+    ea, eb = arena.segments['encoder']
+    nonempty = lambda rs: [r for r in rs if r[1] > r[0]]
+    return [('head + last backbone stage', nonempty([arena.segments['head'], (lo, hi)])),
+            ('earlier backbone stages + patch projection', nonempty([(a, lo), (hi, b)])),
+            ('encoder LayerNorm affine', [ln]),
+            ('pillar feature net', nonempty([(ea, ln[0]), (ln[1], eb)]))]
 
 
 class GraphedTrainStep:
@@ -49,6 +70,7 @@ class GraphedTrainStep:
         self.m = module
         self.opt = optimizer
         self.reducer = reducer
+        self.trace = None       # a list -> every step appends [(mark, host time, bytes), ...] (bench.py --dry-run-collectives)
         scans, labels, masks, _ = module._unpack(example_batch)
         dev = labels.device
         head = module._panoptic_head._panoptic_head
@@ -154,11 +176,8 @@ class GraphedTrainStep:
         """Arena ranges whose gradients are complete after graph 1 / only after graph 2."""
         if self.arena is None:
             return None, None
-        swin = self.m._backbone._backbone
-        last = len(swin.stages) - 1
-        a, b = self.arena.segments['backbone']
-        lo, hi = self.arena.range_of(swin.stages[last])
-        return [self.arena.segments['head'], (lo, hi)], [(a, lo), (hi, b)]
+        plan = dict(arena_reduce_plan(self.m, self.arena))
+        return plan['head + last backbone stage'], plan['earlier backbone stages + patch projection']
 
     def step(self, batch) -> torch.Tensor:
         m = self.m
@@ -177,12 +196,22 @@ class GraphedTrainStep:
         elif masks.data_ptr() != self.masks.data_ptr():
             self.masks.copy_(masks)
         overlap = self.reducer is not None and self.arena is not None
+        tr = self.trace
+        if tr is not None:
+            tr.append([])
+        mark = (lambda name, nbytes=0: tr[-1].append((name, time.perf_counter(), int(nbytes)))) if tr is not None \
+            else (lambda *a: None)
+        nb = lambda ranges: 4 * sum(b - a for a, b in ranges)
+        mark('graph 1 replay')
         self.graph.replay()                                # backbone, head, loss; backward of head + last stage
         handles = None
         if overlap:                                        # their all-reduce runs underneath the second graph
+            mark('all-reduce: head + last backbone stage', nb(self._ranges_head))
             handles = self.reducer.start_ranges(self.arena, self._ranges_head)
+        mark('graph 2 replay')
         self.graph_late.replay()                           # backward of the earlier backbone stages
         if overlap:
+            mark('all-reduce: earlier backbone stages + patch projection', nb(self._ranges_late))
             handles += self.reducer.start_ranges(self.arena, self._ranges_late)
             # K3's backward is the FIRST kernel of the encoder backward and produces the two largest gradients of
             # the model (the (C, ny, nx) LayerNorm affine, 268 MB): their all-reduce starts from the gradient hook,
@@ -193,17 +222,23 @@ class GraphedTrainStep:
 
             def launch_ln(_p):          # the hook may be announced more than once per backward: launch once
                 if not early:
+                    mark('all-reduce: encoder LayerNorm affine (from its gradient hook)', nb([ln_range]))
                     early.extend(self.reducer.start_ranges(self.arena, [ln_range]))
 
             hook = ln.bias.register_post_accumulate_grad_hook(launch_ln)
             try:
+                mark('encoder backward (eager)')
                 x.backward(self.x_static.grad)             # eager: backward of K3 / K2
             finally:
                 hook.remove()
             a, b = self.arena.segments['encoder']
             rest = [(a, b)] if not early else [(a, ln_range[0]), (ln_range[1], b)]
-            handles += early + self.reducer.start_ranges(self.arena, [r for r in rest if r[1] > r[0]])
+            rest = [r for r in rest if r[1] > r[0]]
+            mark('all-reduce: pillar feature net' + ('' if early else ' + LayerNorm affine'), nb(rest))
+            handles += early + self.reducer.start_ranges(self.arena, rest)
+            mark('wait for the collectives')
             self.reducer.finish_arena(self.arena, handles, self.opt)
+            mark('optimizer')
         else:
             if self._late_tn:                              # the early stages' weight gradients, beside the encoder backward
                 main = torch.cuda.current_stream()

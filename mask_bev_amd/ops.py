@@ -1778,6 +1778,7 @@ class _PointSample(torch.autograd.Function):
         g = int(src_index.shape[0])
         p = int(coords.shape[1])
         out = torch.empty((g, p), dtype=torch.float32, device=src.device)
+        _lib.WORK_HINT['point_sample'] = (int(n_src), int(coords.shape[0]))
         rc = lib.mbv_point_sample_fwd(_ptr(src), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, h, w, _ptr(out),
                                       _stream())
         check(rc, 'mbv_point_sample_fwd')
@@ -1794,6 +1795,7 @@ class _PointSample(torch.autograd.Function):
         grad_out = grad_out.to(torch.float32).contiguous()
         g, p = grad_out.shape
         g_src = torch.empty((n_src, h, w), dtype=torch.float32, device=grad_out.device)
+        _lib.WORK_HINT['point_sample'] = (int(n_src), int(coords.shape[0]))
         rc = lib.mbv_point_sample_bwd(_ptr(grad_out), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, h, w, n_src,
                                       _ptr(g_src), _stream())
         check(rc, 'mbv_point_sample_bwd')
@@ -1851,6 +1853,7 @@ def point_sample_packed(pm: PackedMasks, src_index: torch.Tensor, coords: torch.
     coords = coords.float().contiguous()
     g, p = int(src_index.shape[0]), int(coords.shape[1])
     out = torch.empty((g, p), dtype=torch.float32, device=coords.device)
+    _lib.WORK_HINT['point_sample'] = (int(pm.words.shape[0]), int(coords.shape[0]))
     rc = lib.mbv_point_sample_packed_fwd(_ptr(pm.words), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, pm.h,
                                          pm.w, _ptr(out), _stream())
     check(rc, 'mbv_point_sample_packed_fwd')

@@ -57,6 +57,23 @@ def _msda_value_packed(a) -> Work:
     return ('k_msda_bwd_value_fx', 'hbm', b * nv * heads * d * out_es + b * nq * heads * d * 4.0 + samples * 12.0, 0.0)
 
 
+def _point_rows(rows: int, pts: int) -> float:
+    """Coordinate reads + sample writes of a point-sampling call: the coordinate sets are shared by the rows that name
+    them (one set per (decoder output, scan) for 100 queries), 8 B per point of a distinct set + 4 B per sample."""
+    from . import _lib
+    _, n_sets = _lib.WORK_HINT.get('point_sample', (rows, rows))
+    return min(rows, n_sets) * pts * 8.0 + rows * pts * 4.0
+
+
+def _point_sample(a, kernel: str, bytes_per_pixel: float) -> Work:
+    """Every DISTINCT source map is read once (the ten decoder outputs' rows of a ground-truth mask share it: round 2
+    charged one map per row and the model exceeded the measured traffic), plus the coordinate / sample traffic."""
+    from . import _lib
+    rows, pts, h, w = _i(a[4]), _i(a[5]), _i(a[6]), _i(a[7])
+    n_src, _ = _lib.WORK_HINT.get('point_sample', (rows, rows))
+    return (kernel, 'hbm', min(rows, n_src) * h * w * bytes_per_pixel + _point_rows(rows, pts), 0.0)
+
+
 def _attn(a, bwd: bool, ld: bool) -> Work:
     if bwd:
         i0 = 8 if ld else 7
@@ -172,12 +189,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                       _i(a[3]) * (_i(a[4]) * _i(a[5]) + _i(a[5]) * _i(a[6])) * (2 if _i(a[2]) else 4)
                                       + _i(a[3]) * _i(a[4]) * _i(a[6]) * (4 if (_i(a[8]) or not _i(a[2])) else 2),
                                       2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6])),
-    'mbv_point_sample_fwd': lambda a: ('k_point_sample_fwd_lds', 'hbm',
-                                       _i(a[4]) * (_i(a[6]) * _i(a[7]) * 4.0 + _i(a[5]) * 12.0), 0.0),
+    'mbv_point_sample_fwd': lambda a: _point_sample(a, 'k_point_sample_fwd_lds', 4.0),
     'mbv_point_sample_bwd': lambda a: ('k_point_sample_bwd_lds', 'hbm',
-                                       _i(a[8]) * _i(a[6]) * _i(a[7]) * 4.0 + _i(a[4]) * _i(a[5]) * 12.0, 0.0),
-    'mbv_point_sample_packed_fwd': lambda a: ('k_point_sample_packed', 'hbm',
-                                              _i(a[4]) * (_i(a[6]) * _i(a[7]) / 8.0 + _i(a[5]) * 12.0), 0.0),
+                                       _i(a[8]) * _i(a[6]) * _i(a[7]) * 4.0 + _point_rows(_i(a[4]), _i(a[5])), 0.0),
+    'mbv_point_sample_packed_fwd': lambda a: _point_sample(a, 'k_point_sample_packed', 1.0 / 8.0),
     'mbv_mask_loss_rows_fwd': lambda a: ('k_mask_loss_rows_fwd', 'hbm', _i(a[2]) * _i(a[3]) * 8.0, 0.0),
     'mbv_mask_loss_rows_bwd': lambda a: ('k_mask_loss_rows_bwd', 'hbm', _i(a[3]) * _i(a[4]) * 12.0, 0.0),
     'mbv_act_bwd_colsum': lambda a: ('k_act_bwd_colsum', 'hbm', _i(a[4]) * _i(a[5]) * 3.0 * (2 if _i(a[2]) else 4), 0.0),

@@ -255,3 +255,41 @@ def test_ranks_with_different_unused_parameters_stay_in_step():
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
     assert out[0][2].abs().sum() > 0                       # the `extra` weight exists and moved (rank 0's half gradient)
+
+
+def test_graph_step_reduce_plan_covers_the_arena_exactly_once():
+    """The four pieces GraphedTrainStep launches (head + last stage, earlier stages + patch projection, the encoder's
+    LayerNorm affine, the pillar feature net — graph.arena_reduce_plan) are disjoint, in that order, and cover every
+    element of the arena gradient exactly once; each parameter lies wholly inside one piece.  CPU: the plan is pure
+    arithmetic on the arena layout (the RCCL launches themselves: tests/test_ddp_graph_gpu.py, gloo on a GPU)."""
+    from mask_bev_amd.graph import arena_reduce_plan
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    from tests.util_cfg import tiny_kwargs
+    m = MaskBevModule(**tiny_kwargs(nx=40, ny=40, q=4))
+    from mask_bev_amd.arena import ParameterArena
+    arena = ParameterArena([('encoder', m._encoder), ('backbone', m._backbone), ('head', m._panoptic_head)],
+                           shadow_dtype=None)
+    plan = arena_reduce_plan(m, arena)
+    assert [name for name, _ in plan] == ['head + last backbone stage', 'earlier backbone stages + patch projection',
+                                          'encoder LayerNorm affine', 'pillar feature net']
+    cover = torch.zeros(arena.numel, dtype=torch.int32)
+    for _, ranges in plan:
+        for a, b in ranges:
+            assert 0 <= a < b <= arena.numel
+            cover[a:b] += 1
+    assert bool((cover == 1).all())
+    piece_of = {}
+    for i, (_, ranges) in enumerate(plan):
+        for a, b in ranges:
+            for p, off in arena.layout:
+                if a <= off and off + p.numel() <= b:
+                    assert id(p) not in piece_of
+                    piece_of[id(p)] = i
+    assert len(piece_of) == len(arena.layout)                      # no parameter straddles two pieces
+    names = {id(p): n for n, p in m.named_parameters()}
+    by_piece = {i: {names[k] for k, v in piece_of.items() if v == i} for i in range(4)}
+    assert all(n.startswith('_panoptic_head.') or '.stages.3.' in n or n.startswith('_backbone._backbone.norm3')
+               for n in by_piece[0]), sorted(by_piece[0])[:5]
+    assert by_piece[2] == {'_encoder._layer_norm.weight', '_encoder._layer_norm.bias'}
+    assert all(n.startswith('_encoder._voxel_encoder.') or n.startswith('_encoder._pos_encoder.') for n in by_piece[3])
+    assert all(n.startswith('_backbone.') for n in by_piece[1])
