@@ -691,11 +691,21 @@ int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const
  *                  the program's weight dtype, bias = p1 f32 or NULL; MBV_RC_RELU; MBV_RC_MASK: result zeroed where
  *                  slot src2 <= 0 (ReLU backward).  f32 weights: exact f32 MFMA; 16-bit weights: activations rounded to
  *                  that type, f32 accumulation.  n <= 256, k <= 256, k % 16 (f32) / 32 (16-bit) == 0, dst != src.
+ *                  MBV_RC_FRAG (16-bit): p0 is a fragment-major copy (mbv_fragment_group) positioned at the stage's first
+ *                  (tile, block) and ld = its 32-column blocks per tile row (one load instruction = 8 full cache lines
+ *                  instead of 16 half lines).  The FFN stage's weights are always fragment-major (ld / ld2 likewise).
  *   MBV_RC_LN      dst = LayerNorm(src [+ src2]) * p0 + p1 (src2 = -1: none); MBV_RC_SAVE_SUM: src <- the sum;
  *                  p2 (nullable): (rows, 2) f32 <- (mean, rstd).
  *   MBV_RC_LN_BWD  dst = d(sum) given src = d(output), src2 = the sum, p0 = gamma, p2 = stats; p1 (nullable):
  *                  (blocks, 2 n) f32 <- this block's partial d(gamma) | d(beta).
  *   MBV_RC_ADD     dst = src + src2.      MBV_RC_COLSUM  p0[block * ld + c] = sum over the block's rows of src.
+ *   MBV_RC_FFN     (16-bit weights) the MLP pair with the hidden dimension cut into 256-wide chunks owned by the waves in
+ *                  parallel: forward dst = relu(src . W1^T + b1) . W2^T with W1 = p0 (k x n, stride ld), b1 = p1, W2 = p2
+ *                  (n x k, stride ld2); MBV_RC_MASK = backward: dst = ((src . p0^T) * (act > 0)) . p2^T with p0 = W2^T,
+ *                  p2 = W1^T.  n = embed width (<= 256, % 32), k = hidden width (% 256); src2 = first of 5 scratch slots.
+ *                  Directly followed by an MBV_RC_FFN_IO descriptor: p0 = hidden activations (rows x k f32, stride ld;
+ *                  written forward, read backward), p1 = d(hidden) out (backward), p2 = (blocks, ld2) column partials of
+ *                  d(hidden) (backward, nullable).  The output bias is left to the caller (e.g. a following LN's operand).
  * Data gradients dX = dY . W are MBV_RC_GEMM stages against transposed weight copies (mbv_transpose_group).
  * The program is copied into the kernel arguments (<= mbv_rowchain_max_stages() stages): nothing is retained. */
 #define MBV_RC_LOAD 0
@@ -705,10 +715,13 @@ int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const
 #define MBV_RC_LN_BWD 4
 #define MBV_RC_ADD 5
 #define MBV_RC_COLSUM 6
+#define MBV_RC_FFN 7
+#define MBV_RC_FFN_IO 8
 #define MBV_RC_ACCUM 4
 #define MBV_RC_RELU 8
 #define MBV_RC_MASK 16
 #define MBV_RC_SAVE_SUM 32
+#define MBV_RC_FRAG 128
 #define MBV_TR_MAX 96
 typedef struct MbvRowStage {
   int32_t op;
@@ -722,6 +735,12 @@ int mbv_rowchain_max_stages(void);
 int mbv_rowchain_slots(void);
 int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
                      int32_t wdtype, void* stream);
+/* Fragment-major copies of 16-bit weight matrices for the 16 x 16 x 32 MFMA B operand: for the logical (rows, cols) matrix
+ * W, dst[((t * (cols / 32) + kb) * 64 + lane) * 8 + j] = W[t * 16 + lane % 16][kb * 32 + 8 * (lane / 16) + j], rows padded
+ * with zeros to a multiple of 16; transposed[i] != 0: W[r][c] = src[c * ld + r] (the data-gradient operand), else
+ * src[r * ld + c].  cols % 32 == 0.  dst holds ceil(rows / 16) * 16 * cols elements. */
+int mbv_fragment_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols,
+                       const int32_t* ld, const int32_t* transposed, int32_t n, void* stream);
 /* dst[i] (cols, rows) = transpose of src[i] (rows, cols), n matrices of elem_size 2 or 4 bytes, <= MBV_TR_MAX per launch. */
 int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols, int32_t n,
                         int32_t elem_size, void* stream);

@@ -19,6 +19,8 @@
 // activations are rounded to that type as MFMA A fragments, f32 accumulation (v_mfma_f32_16x16x32_{bf16,f16}).
 // Backward data gradients dX = dY W are NT products against TRANSPOSED weight copies (mbv_transpose_group, one launch
 // per step for the whole decoder), so that the reduction index is the contiguous one in every stream.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -32,6 +34,28 @@ struct RowProgram {
   int pad[3];
   MbvRowStage st[RC_MAX_STAGES];
 };
+
+// Pointers that arrive inside the program are GLOBAL memory.  Left generic, every access compiled to a FLAT instruction,
+// which counts in lgkmcnt as well as vmcnt: each LDS wait (and the stage barrier's) then also drained the prefetched
+// loads.  Everything below goes through address-space-1 pointers (global_load / global_store: vmcnt only).
+#define G1 __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const G1 T* gp(const void* p) { return (const G1 T*)p; }
+template <typename T>
+__device__ __forceinline__ G1 T* gpw(const void* p) { return (G1 T*)const_cast<void*>(p); }
+// 16- / 8-byte global accesses through native vector types (HIP's uint4 / float4 classes cannot bind to address space 1)
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
+__device__ __forceinline__ uint4 gld16(const G1 void* p) {
+  const u32x4_t v = *reinterpret_cast<const G1 u32x4_t*>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gld8(const G1 void* p) {
+  const u32x2_t v = *reinterpret_cast<const G1 u32x2_t*>(p);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void gst16(G1 void* p, uint4 v) { *reinterpret_cast<G1 u32x4_t*>(p) = u32x4_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gst8(G1 void* p, uint2 v) { *reinterpret_cast<G1 u32x2_t*>(p) = u32x2_t{v.x, v.y}; }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -51,39 +75,74 @@ __device__ __forceinline__ unsigned short f32_to_16(float f, int dt) {
 }
 
 // ---- stages ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void st_load(const MbvRowStage& s, float* slots, int row0, int rows, int q_mod) {
-  float* dst = slots + s.dst * (RC_ROWS * RC_LD);
-  const int dt = s.flags & 3, n = s.n;
-  const int n4 = n >> 2;                                   // n % 4 == 0 (host-checked)
-  for (int i = threadIdx.x; i < RC_ROWS * n4; i += RC_NT) {
+// A workgroup's chain is a sequence of short dependent stages; left alone, every LOAD and every GEMM would expose one
+// full global-memory round trip (1-2 us against 0.1-0.3 us of work).  All global READS of a program are of data no
+// stage of the same program writes (weights, and activations earlier kernels produced — the host side keeps to that),
+// so they can be requested early: the NEXT load / GEMM stage's operands are fetched into registers while the current
+// stages run, and the stage barriers wait for LDS traffic only (a plain __syncthreads() would drain vmcnt, i.e. wait
+// for the prefetches).
+struct LoadPre {
+  uint4 v[2];             // raw bytes of up to two pieces per thread of the 16 x 256 block (16 B f32 / 8 B 16-bit)
+  float4 a[2];            // the same pieces of the added f32 operand
+};
+
+// Every load below is UNCONDITIONAL (addresses are clamped into the tensor, validity is applied when the registers are
+// consumed): a predicated load compiles to a branch with `s_waitcnt vmcnt(0)` behind it, which serialises the prefetch.
+__device__ __forceinline__ void load_prefetch(const MbvRowStage& s, LoadPre& pre, int row0, int rows, int q_mod) {
+  const int dt = s.flags & 3, n4 = s.n >> 2;
+  const bool has0 = s.p0 != nullptr, has1 = s.p1 != nullptr;
+  const G1 char* base0 = gp<char>(has0 ? s.p0 : s.p1);      // some readable address either way
+  const G1 float* base1 = gp<float>(has1 ? s.p1 : s.p0);
+  const int ld0 = has0 ? s.ld : 0, ld1 = has1 ? s.ld2 : 0;
+  const int es = dt == MBV_DT_F32 ? 4 : 2;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int i = threadIdx.x + u * RC_NT;
+    i = i < RC_ROWS * n4 ? i : RC_ROWS * n4 - 1;
     const int r = i / n4, c = (i - r * n4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int row = row0 + r;
-    if (row < rows) {
-      const int64_t o = (int64_t)row * s.ld + c;
-      if (!s.p0) {                                         // base operand from a slot (e.g. x + positions)
-        v = *reinterpret_cast<const float4*>(slots + s.src * (RC_ROWS * RC_LD) + r * RC_LD + c);
-      } else if (dt == MBV_DT_F32) {
-        v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.p0) + o);
-      } else {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(s.p0) + o);
-        if (dt == MBV_DT_BF16) {
-          v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                          __uint_as_float(u.y & 0xffff0000u));
-        } else {
-          v = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(u.x & 0xffff)),
-                          (float)__builtin_bit_cast(_Float16, (unsigned short)(u.x >> 16)),
-                          (float)__builtin_bit_cast(_Float16, (unsigned short)(u.y & 0xffff)),
-                          (float)__builtin_bit_cast(_Float16, (unsigned short)(u.y >> 16)));
-        }
-      }
-      if (s.p1) {                                          // + a second f32 operand, row index modulo q_mod (positions)
-        const int prow = q_mod > 0 ? row % q_mod : row;
-        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s.p1) + (int64_t)prow * s.ld2 + c);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
+    int row = row0 + r;
+    row = row < rows ? row : rows - 1;
+    const G1 char* p = base0 + ((int64_t)row * ld0 + (has0 ? c : 0)) * (has0 ? es : 4);
+    if (dt == MBV_DT_F32 || !has0) {
+      pre.v[u] = gld16(p);
+    } else {
+      const uint2 t = gld8(p);
+      pre.v[u].x = t.x; pre.v[u].y = t.y; pre.v[u].z = 0u; pre.v[u].w = 0u;
     }
-    *reinterpret_cast<float4*>(dst + r * RC_LD + c) = v;
+    const int prow = q_mod > 0 ? row % q_mod : row;
+    pre.a[u] = __builtin_bit_cast(float4, gld16(base1 + (int64_t)prow * ld1 + (has1 ? c : 0)));
+  }
+}
+
+__device__ __forceinline__ void st_load(const MbvRowStage& s, float* slots, const LoadPre& pre, int row0, int rows) {
+  float* dst = slots + s.dst * (RC_ROWS * RC_LD);
+  const int dt = s.flags & 3, n4 = s.n >> 2;                // n % 4 == 0 (host-checked)
+  const bool has0 = s.p0 != nullptr, has1 = s.p1 != nullptr;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * RC_NT;
+    if (i < RC_ROWS * n4) {
+      const int r = i / n4, c = (i - r * n4) * 4;
+      const bool live = row0 + r < rows;
+      float4 v;
+      const uint4 raw = pre.v[u];
+      if (!has0) {                                           // base operand from a slot (e.g. x + positions)
+        v = *reinterpret_cast<const float4*>(__builtin_assume_aligned(slots + s.src * (RC_ROWS * RC_LD) + r * RC_LD + c, 16));
+      } else if (dt == MBV_DT_F32) {
+        v = __builtin_bit_cast(float4, raw);
+      } else if (dt == MBV_DT_BF16) {
+        v = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                        __uint_as_float(raw.y & 0xffff0000u));
+      } else {
+        v = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(raw.x & 0xffff)),
+                        (float)__builtin_bit_cast(_Float16, (unsigned short)(raw.x >> 16)),
+                        (float)__builtin_bit_cast(_Float16, (unsigned short)(raw.y & 0xffff)),
+                        (float)__builtin_bit_cast(_Float16, (unsigned short)(raw.y >> 16)));
+      }
+      if (has1) { v.x += pre.a[u].x; v.y += pre.a[u].y; v.z += pre.a[u].z; v.w += pre.a[u].w; }
+      if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(__builtin_assume_aligned(dst + r * RC_LD + c, 16)) = v;
+    }
   }
 }
 
@@ -93,25 +152,28 @@ __device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slot
   const bool accum = (s.flags & MBV_RC_ACCUM) != 0;
   if ((n & 3) == 0) {
     const int n4 = n >> 2;
-    for (int i = threadIdx.x; i < RC_ROWS * n4; i += RC_NT) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                            // 16 x 256 / 4 = 1024 pieces over 512 threads: no loop
+      const int i = threadIdx.x + u * RC_NT;
+      if (i >= RC_ROWS * n4) continue;
       const int r = i / n4, c = (i - r * n4) * 4;
       const int row = row0 + r;
       if (row >= rows) continue;
-      const float4 v = *reinterpret_cast<const float4*>(src + r * RC_LD + c);
+      const float4 v = *reinterpret_cast<const float4*>(__builtin_assume_aligned(src + r * RC_LD + c, 16));
       const int64_t o = (int64_t)row * s.ld + c;
       if (dt == MBV_DT_F32) {
-        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(const_cast<void*>(s.p0)) + o);
+        G1 float* p = gpw<float>(s.p0) + o;
         if (accum) {
-          const float4 old = *p;
-          *p = make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w);
+          const float4 old = __builtin_bit_cast(float4, gld16(p));
+          gst16(p, __builtin_bit_cast(uint4, make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w)));
         } else {
-          *p = v;
+          gst16(p, __builtin_bit_cast(uint4, v));
         }
       } else {
-        uint2 u;
-        u.x = (unsigned)f32_to_16(v.x, dt) | ((unsigned)f32_to_16(v.y, dt) << 16);
-        u.y = (unsigned)f32_to_16(v.z, dt) | ((unsigned)f32_to_16(v.w, dt) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(const_cast<void*>(s.p0)) + o) = u;
+        uint2 u2;
+        u2.x = (unsigned)f32_to_16(v.x, dt) | ((unsigned)f32_to_16(v.y, dt) << 16);
+        u2.y = (unsigned)f32_to_16(v.z, dt) | ((unsigned)f32_to_16(v.w, dt) << 16);
+        gst8(gpw<unsigned short>(s.p0) + o, u2);
       }
     }
   } else {                                                 // narrow outputs (the class head: n = classes + 1)
@@ -122,20 +184,166 @@ __device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slot
       const float v = src[r * RC_LD + c];
       const int64_t o = (int64_t)row * s.ld + c;
       if (dt == MBV_DT_F32) {
-        float* p = reinterpret_cast<float*>(const_cast<void*>(s.p0)) + o;
+        G1 float* p = gpw<float>(s.p0) + o;
         *p = accum ? *p + v : v;
       } else {
-        reinterpret_cast<unsigned short*>(const_cast<void*>(s.p0))[o] = f32_to_16(v, dt);
+        gpw<unsigned short>(s.p0)[o] = f32_to_16(v, dt);
+      }
+    }
+  }
+}
+
+template <int WDT>
+struct GemmPre {
+  static constexpr int KB = WDT == MBV_DT_F32 ? RC_MAXC / 16 : RC_MAXC / 32;
+  uint4 b[WDT == MBV_DT_F32 ? 1 : KB];            // the B fragments of the wave's FIRST tile of a GEMM stage (16-bit weights)
+};
+
+// Weight operands of the 16-bit programs come in FRAGMENT-MAJOR copies (mbv_fragment_group): the 64 lanes' 16-byte
+// B fragments of (16-row tile t, 32-column block kb) are 1 KB of consecutive memory at ((t * KBN + kb) * 64 + lane) * 16.
+// Read from the row-major matrix the same fragments are 16 rows x 64 bytes — 16 cache lines per load instruction, and
+// the texture-address unit works per line: 1.8 us per tile with all eight waves loading (measured; unchanged with the
+// weights resident in L1).  One instruction now covers 8 full lines.
+template <int WDT>
+__device__ __forceinline__ void gemm_load_tile(const MbvRowStage& s, int t, uint4* b) {
+  constexpr int KB = GemmPre<WDT>::KB;
+  constexpr int KSTEP = WDT == MBV_DT_F32 ? 16 : 32, ES = WDT == MBV_DT_F32 ? 4 : 2;
+  const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+  const int tiles = (s.n + 15) >> 4;
+  t = t < tiles ? t : tiles - 1;                       // a wave without this tile re-reads the last one (unused)
+  if (s.flags & MBV_RC_FRAG) {
+    const G1 char* base = gp<char>(s.p0) + ((int64_t)t * s.ld * 64 + lane) * 16;       // ld = k blocks per fragment row
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int ko = kb * KSTEP < s.k ? kb : 0;        // k blocks beyond k re-read block 0 and are never multiplied
+      b[kb] = gld16(base + ko * 1024);
+    }
+    return;
+  }
+  int col = t * 16 + m;
+  col = col < s.n ? col : s.n - 1;                     // clamped, not predicated: columns >= n are never stored
+  const G1 char* wrow = gp<char>(s.p0) + ((int64_t)col * s.ld + (KSTEP / 4) * g) * ES;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int ko = kb * KSTEP < s.k ? kb * KSTEP : 0;  // k blocks beyond k re-read block 0 and are never multiplied
+    b[kb] = gld16(wrow + ko * ES);
+  }
+}
+
+// (f32 weights: 16 float4 fragments per tile — three live sets would spill; the f32 program, which is not the
+// throughput path, loads each tile at its stage instead)
+template <int WDT>
+__device__ __forceinline__ void gemm_prefetch(const MbvRowStage& s, GemmPre<WDT>& pre) {
+  if constexpr (WDT != MBV_DT_F32) gemm_load_tile<WDT>(s, threadIdx.x >> 6, pre.b);
+}
+
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+// The A fragments of a stage: the SAME for every output tile, so each wave reads and converts them ONCE per stage —
+// all LDS reads issued back to back as 16-byte accesses (the slot rows are 16-byte aligned; without the alignment
+// promise the compiler split them into b96 + b32 pieces with a wait behind each: 1.1 us per tile), then the products
+// of both tiles.  NKB k-blocks, compile-time: a run-time bound put every block in its own basic block.
+template <int WDT, int NKB>
+__device__ __forceinline__ void gemm_tiles(const float* X, const uint4* b0, const uint4* b1, bool two, f32x4* acc) {
+  const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+  if constexpr (WDT == MBV_DT_F32) {
+    // k permuted consistently in A and B: MFMA j of a 16-wide k block sums k = kb + 4 g' + j, g' = 0..3
+    const float4* xr = reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + 4 * g, 16));
+    float4 a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) a[kb] = xr[kb * 4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      if (tt == 1 && !two) break;
+      const uint4* b = tt == 0 ? b0 : b1;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float4 bb = __builtin_bit_cast(float4, b[kb]);
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].x, bb.x, acc[tt], 0, 0, 0);
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].y, bb.y, acc[tt], 0, 0, 0);
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].z, bb.z, acc[tt], 0, 0, 0);
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].w, bb.w, acc[tt], 0, 0, 0);
+      }
+    }
+  } else {
+    const float4* xr = reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + 8 * g, 16));
+    float4 r0[NKB], r1[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      r0[kb] = xr[kb * 8];
+      r1[kb] = xr[kb * 8 + 1];
+    }
+    uint4 a[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const f32x8 v = {r0[kb].x, r0[kb].y, r0[kb].z, r0[kb].w, r1[kb].x, r1[kb].y, r1[kb].z, r1[kb].w};
+      if constexpr (WDT == MBV_DT_BF16) a[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, bf16x8));
+      else a[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, f16x8));
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      if (tt == 1 && !two) break;
+      const uint4* b = tt == 0 ? b0 : b1;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if constexpr (WDT == MBV_DT_BF16)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kb]), __builtin_bit_cast(bf16x8, b[kb]),
+                                                            acc[tt], 0, 0, 0);
+        else
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[kb]), __builtin_bit_cast(f16x8, b[kb]),
+                                                           acc[tt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// any k (a multiple of the block width): k-blocks tested one by one — the slow form, used by odd test widths only
+template <int WDT>
+__device__ __forceinline__ void gemm_tiles_any(const float* X, const uint4* b0, const uint4* b1, bool two, int k, f32x4* acc) {
+  constexpr int KB = GemmPre<WDT>::KB, KSTEP = WDT == MBV_DT_F32 ? 16 : 32;
+  const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    if (tt == 1 && !two) break;
+    const uint4* b = tt == 0 ? b0 : b1;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb * KSTEP < k) {
+        if constexpr (WDT == MBV_DT_F32) {
+          const float4 a = *reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + kb * 16 + 4 * g, 16));
+          const float4 bb = __builtin_bit_cast(float4, b[kb]);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc[tt], 0, 0, 0);
+        } else {
+          const float4* xr = reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + kb * 32 + 8 * g, 16));
+          const float4 r0 = xr[0], r1 = xr[1];
+          const f32x8 v = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          if constexpr (WDT == MBV_DT_BF16)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_convertvector(v, bf16x8),
+                                                              __builtin_bit_cast(bf16x8, b[kb]), acc[tt], 0, 0, 0);
+          else
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_convertvector(v, f16x8),
+                                                             __builtin_bit_cast(f16x8, b[kb]), acc[tt], 0, 0, 0);
+        }
       }
     }
   }
 }
 
 // dst[r][j] = act((ACCUM ? dst[r][j] : 0) + sum_k src[r][k] W[j][k] + bias[j]) [* (src2[r][j] > 0)], j < n.
-// One wave owns 16-column output tiles t = wave, wave + 8, ...; its B fragments come straight from global memory
-// (16 rows of W x 64 contiguous bytes per load instruction), all of a tile's loads issued before its first MFMA.
+// One wave owns the 16-column output tiles t = wave and wave + 8 (n <= 256); its B fragments come straight from global
+// memory (16 rows of W x 64 contiguous bytes per load instruction).  `pre` holds the first tile's fragments, requested
+// while the previous stages ran.  The stage requests its second tile's fragments first, multiplies the first tile
+// (already here), then the second, and only then — `pre` is dead — requests the NEXT GEMM stage's first tile into the
+// same registers, so that its round trip runs underneath the epilogue, the barrier and whatever stages follow.
+// (Two alternating register sets would hide more, but across this kernel's stage switch the register allocator splits
+// their live ranges and copies them — behind an `s_waitcnt vmcnt(0)`.)
 template <int WDT>
-__device__ __forceinline__ void st_gemm(const MbvRowStage& s, float* slots) {
+__device__ __forceinline__ void st_gemm(const MbvRowStage& s, bool has_next, const MbvRowStage& next, float* slots,
+                                        GemmPre<WDT>& pre) {
+  constexpr int KB = GemmPre<WDT>::KB;
   const float* X = slots + s.src * (RC_ROWS * RC_LD);
   float* Y = slots + s.dst * (RC_ROWS * RC_LD);
   const float* Mk = (s.flags & MBV_RC_MASK) ? slots + s.src2 * (RC_ROWS * RC_LD) : nullptr;
@@ -144,64 +352,55 @@ __device__ __forceinline__ void st_gemm(const MbvRowStage& s, float* slots) {
   const int n = s.n, k = s.k;
   const int tiles = (n + 15) >> 4;
   const bool accum = (s.flags & MBV_RC_ACCUM) != 0, relu = (s.flags & MBV_RC_RELU) != 0;
-  const float* bias = reinterpret_cast<const float*>(s.p1);
-  for (int t = wave; t < tiles; t += RC_NW) {
-    const int col = t * 16 + m;
-    const bool valid = col < n;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const G1 float* bias = gp<float>(s.p1);
+  const G1 float* bp = bias ? bias : gp<float>(s.p0);     // unconditional loads, selected below
+  uint4 b2[KB];
+  if constexpr (WDT != MBV_DT_F32) gemm_load_tile<WDT>(s, wave + RC_NW, b2);
+  float bvs[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int c = (wave + tt * RC_NW) * 16 + m;
+    bvs[tt] = bp[c < n ? c : n - 1];
+  }
+  f32x4 acc[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int col = (wave + tt * RC_NW) * 16 + m;
+    acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (accum) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = Y[(4 * g + i) * RC_LD + col];
+      for (int i = 0; i < 4; ++i) acc[tt][i] = Y[(4 * g + i) * RC_LD + (col < n ? col : 0)];
     }
-    if constexpr (WDT == MBV_DT_F32) {
-      // k permuted consistently in A and B: MFMA j of a 16-wide k block sums k = kb + 4 g' + j, g' = 0..3
-      const float* wrow = reinterpret_cast<const float*>(s.p0) + (int64_t)(valid ? col : 0) * s.ld + 4 * g;
-      constexpr int KB = RC_MAXC / 16;
-      float4 b[KB];
+  }
+  const bool two = wave + RC_NW < tiles;               // wave-uniform
+  if (wave < tiles) {
+    constexpr int KSTEP = WDT == MBV_DT_F32 ? 16 : 32;
+    if constexpr (WDT == MBV_DT_F32) {                 // (f32: the tiles' fragments are loaded here, one at a time)
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        b[kb] = (valid && kb * 16 < k) ? *reinterpret_cast<const float4*>(wrow + kb * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        if (kb * 16 < k) {
-          const float4 a = *reinterpret_cast<const float4*>(X + m * RC_LD + kb * 16 + 4 * g);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[kb].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[kb].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[kb].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[kb].w, acc, 0, 0, 0);
-        }
+      for (int tt = 0; tt < 2; ++tt) {
+        if (tt == 1 && !two) break;
+        gemm_load_tile<WDT>(s, wave + tt * RC_NW, b2);
+        if (k == KB * KSTEP) gemm_tiles<WDT, KB>(X, b2, b2, false, acc + tt);
+        else if (k * 2 == KB * KSTEP) gemm_tiles<WDT, KB / 2>(X, b2, b2, false, acc + tt);
+        else gemm_tiles_any<WDT>(X, b2, b2, false, k, acc + tt);
       }
     } else {
-      const unsigned short* wrow = reinterpret_cast<const unsigned short*>(s.p0) + (int64_t)(valid ? col : 0) * s.ld + 8 * g;
-      constexpr int KB = RC_MAXC / 32;
-      uint4 b[KB];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        b[kb] = (valid && kb * 32 < k) ? *reinterpret_cast<const uint4*>(wrow + kb * 32) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        if (kb * 32 < k) {
-          const float4 a0 = *reinterpret_cast<const float4*>(X + m * RC_LD + kb * 32 + 8 * g);
-          const float4 a1 = *reinterpret_cast<const float4*>(X + m * RC_LD + kb * 32 + 8 * g + 4);
-          if constexpr (WDT == MBV_DT_BF16) {
-            bf16x8 a;
-            a[0] = (__bf16)a0.x; a[1] = (__bf16)a0.y; a[2] = (__bf16)a0.z; a[3] = (__bf16)a0.w;
-            a[4] = (__bf16)a1.x; a[5] = (__bf16)a1.y; a[6] = (__bf16)a1.z; a[7] = (__bf16)a1.w;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b[kb]), acc, 0, 0, 0);
-          } else {
-            f16x8 a;
-            a[0] = (_Float16)a0.x; a[1] = (_Float16)a0.y; a[2] = (_Float16)a0.z; a[3] = (_Float16)a0.w;
-            a[4] = (_Float16)a1.x; a[5] = (_Float16)a1.y; a[6] = (_Float16)a1.z; a[7] = (_Float16)a1.w;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(f16x8, b[kb]), acc, 0, 0, 0);
-          }
-        }
-      }
+      if (k == KB * KSTEP) gemm_tiles<WDT, KB>(X, pre.b, b2, two, acc);
+      else if (k * 2 == KB * KSTEP) gemm_tiles<WDT, KB / 2>(X, pre.b, b2, two, acc);
+      else gemm_tiles_any<WDT>(X, pre.b, b2, two, k, acc);
     }
-    if (valid) {
-      const float bv = bias ? bias[col] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);                 // the refill of `pre` must not be hoisted above its last use
+  if (has_next) gemm_prefetch<WDT>(next, pre);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = wave + tt * RC_NW;
+    const int col = t * 16 + m;
+    if (t < tiles && col < n) {
+      const float bv = bias ? bvs[tt] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v = acc[i] + bv;
+        float v = acc[tt][i] + bv;
         if (relu) v = fmaxf(v, 0.f);
         if (Mk) v = Mk[(4 * g + i) * RC_LD + col] > 0.f ? v : 0.f;
         Y[(4 * g + i) * RC_LD + col] = v;
@@ -216,9 +415,15 @@ __device__ __forceinline__ void st_ln(const MbvRowStage& s, float* slots, int ro
   const float* B = s.src2 >= 0 ? slots + s.src2 * (RC_ROWS * RC_LD) : nullptr;
   float* Y = slots + s.dst * (RC_ROWS * RC_LD);
   const int r = threadIdx.x >> 5, l = threadIdx.x & 31, n = s.n;
-  const float* gamma = reinterpret_cast<const float*>(s.p0);
-  const float* beta = reinterpret_cast<const float*>(s.p1);
-  float v[RC_MAXC / 32];
+  const G1 float* gamma = gp<float>(s.p0);
+  const G1 float* beta = gp<float>(s.p1);
+  float v[RC_MAXC / 32], gm[RC_MAXC / 32], bt[RC_MAXC / 32];
+#pragma unroll
+  for (int j = 0; j < RC_MAXC / 32; ++j) {               // unconditional (clamped) loads, requested before the statistics
+    const int c = l + 32 * j, cc = c < n ? c : n - 1;
+    gm[j] = gamma[cc];
+    bt[j] = beta[cc];
+  }
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < RC_MAXC / 32; ++j) {
@@ -249,11 +454,11 @@ __device__ __forceinline__ void st_ln(const MbvRowStage& s, float* slots, int ro
     const int c = l + 32 * j;
     if (c < n) {
       if (save) A[r * RC_LD + c] = v[j];
-      Y[r * RC_LD + c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+      Y[r * RC_LD + c] = (v[j] - mean) * rstd * gm[j] + bt[j];
     }
   }
   if (s.p2 && l == 0 && row0 + r < rows) {
-    float* st = reinterpret_cast<float*>(const_cast<void*>(s.p2)) + (int64_t)(row0 + r) * 2;
+    G1 float* st = gpw<float>(s.p2) + (int64_t)(row0 + r) * 2;
     st[0] = mean;
     st[1] = rstd;
   }
@@ -266,15 +471,16 @@ __device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, fl
   const float* S = slots + s.src2 * (RC_ROWS * RC_LD);
   float* D = slots + s.dst * (RC_ROWS * RC_LD);
   const int r = threadIdx.x >> 5, l = threadIdx.x & 31, n = s.n;
-  const float* gamma = reinterpret_cast<const float*>(s.p0);
+  const G1 float* gamma = gp<float>(s.p0);
   const bool live = row0 + r < rows;
-  float mean = 0.f, rstd = 0.f;
-  if (live) {
-    const float* st = reinterpret_cast<const float*>(s.p2) + (int64_t)(row0 + r) * 2;
-    mean = st[0];
-    rstd = st[1];
+  const G1 float* st = gp<float>(s.p2) + (int64_t)(live ? row0 + r : rows - 1) * 2;
+  const float mean = st[0], rstd = st[1];
+  float gw[RC_MAXC / 32], xh[RC_MAXC / 32], gr[RC_MAXC / 32], gm[RC_MAXC / 32];
+#pragma unroll
+  for (int j = 0; j < RC_MAXC / 32; ++j) {
+    const int c = l + 32 * j;
+    gm[j] = gamma[c < n ? c : n - 1];
   }
-  float gw[RC_MAXC / 32], xh[RC_MAXC / 32], gr[RC_MAXC / 32];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int j = 0; j < RC_MAXC / 32; ++j) {
@@ -284,7 +490,7 @@ __device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, fl
       const float g = G[r * RC_LD + c];
       xh[j] = (S[r * RC_LD + c] - mean) * rstd;
       gr[j] = g;
-      gw[j] = g * gamma[c];
+      gw[j] = g * gm[j];
       s1 += gw[j];
       s2 += gw[j] * xh[j];
     }
@@ -309,8 +515,9 @@ __device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, fl
       }
     }
     __syncthreads();
-    float* out = reinterpret_cast<float*>(const_cast<void*>(s.p1)) + (int64_t)blockIdx.x * 2 * n;
-    for (int i = threadIdx.x; i < 2 * n; i += RC_NT) {
+    G1 float* out = gpw<float>(s.p1) + (int64_t)blockIdx.x * 2 * n;
+    const int i = threadIdx.x;                                // 2 n <= 512 threads
+    if (i < 2 * n) {
       const int which = i / n, c = i - which * n;
       float a = 0.f;
 #pragma unroll
@@ -325,19 +532,24 @@ __device__ __forceinline__ void st_add(const MbvRowStage& s, float* slots) {
   const float* B = slots + s.src2 * (RC_ROWS * RC_LD);
   float* Y = slots + s.dst * (RC_ROWS * RC_LD);
   const int n4 = s.n >> 2;
-  for (int i = threadIdx.x; i < RC_ROWS * n4; i += RC_NT) {
-    const int r = i / n4, c = (i - r * n4) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(A + r * RC_LD + c);
-    const float4 b = *reinterpret_cast<const float4*>(B + r * RC_LD + c);
-    *reinterpret_cast<float4*>(Y + r * RC_LD + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * RC_NT;
+    if (i < RC_ROWS * n4) {
+      const int r = i / n4, c = (i - r * n4) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(__builtin_assume_aligned(A + r * RC_LD + c, 16));
+      const float4 b = *reinterpret_cast<const float4*>(__builtin_assume_aligned(B + r * RC_LD + c, 16));
+      *reinterpret_cast<float4*>(__builtin_assume_aligned(Y + r * RC_LD + c, 16)) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
   }
 }
 
 // p0[block * ld + c] = sum over the block's rows of src[r][c]  (rows beyond `rows` are zero by construction)
 __device__ __forceinline__ void st_colsum(const MbvRowStage& s, const float* slots) {
   const float* A = slots + s.src * (RC_ROWS * RC_LD);
-  float* out = reinterpret_cast<float*>(const_cast<void*>(s.p0)) + (int64_t)blockIdx.x * s.ld;
-  for (int c = threadIdx.x; c < s.n; c += RC_NT) {
+  G1 float* out = gpw<float>(s.p0) + (int64_t)blockIdx.x * s.ld;
+  const int c = threadIdx.x;                                  // n <= 256 < 512 threads
+  if (c < s.n) {
     float a = 0.f;
 #pragma unroll
     for (int r = 0; r < RC_ROWS; ++r) a += A[r * RC_LD + c];
@@ -345,25 +557,271 @@ __device__ __forceinline__ void st_colsum(const MbvRowStage& s, const float* slo
   }
 }
 
+// ---- MBV_RC_FFN: the two GEMMs of an MLP (forward: h = relu(x W1^T + b1), y = h W2^T; backward: dh = (dy W2) * (h > 0),
+// dx = dh W1) with the hidden dimension cut into 256-wide chunks that the eight waves own IN PARALLEL.
+//
+// As a chain of stages the MLP is 16 dependent GEMM stages, each exposing a global-memory round trip in front of a
+// barrier (4 us per stage measured, 64 us for the pair — slower than two library GEMM launches).  Here a wave streams
+// its own 2 x 128 KB of weights through a private software pipeline — no barrier, no other wave's schedule to wait
+// for: phase 1 produces the chunk's 16 hidden tiles (epilogue in registers, the tile leaves for global memory and, in
+// the weight dtype, for the wave's private LDS image), phase 2 multiplies that image with the second weight and adds
+// its 16 x 256 partial result into a shared f64 image with LDS atomics (`ds_add_f64`, 9-16 clocks per wave instruction;
+// `ds_add_f32` serialises its lanes).  16-bit weights only (the f32 program keeps the staged form).
+//   p0 = first weight  (F rows x E: W1, or W2^T in backward), ld;  p1 = its bias (forward) or NULL
+//   p2 = second weight (E rows x F: W2, or W1^T in backward), ld2
+//   src = input slot (16 x E), dst = output slot (16 x E, f32, without the output bias), src2 = FIRST of the scratch
+//   slots (n_chunks_in_flight x 8.3 KB of wave-private bf16 images: 5 slots for eight waves)
+//   n = E (<= 256), k = F (multiple of 256);  flags: MBV_RC_MASK = backward (mask by the stored activations)
+// The hidden activations / their gradients go to / come from HID = header pointer q (forward: written; backward:
+// activations read from `hid_in`, gradients written to `hid_out`), passed through a second, LOAD-typed pseudo stage
+// that directly FOLLOWS the FFN stage: p0 = activations (M x F f32), p1 = gradient out (backward) or NULL, p2 = per-block
+// column partials of the gradient (backward, (blocks, ld2) f32 at column offset 0) or NULL, ld = F.
 template <int WDT>
-__global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P) {
+__device__ __forceinline__ f32x4 ffn_mma(const uint4* a, const uint4* b, f32x4 acc) {
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    if constexpr (WDT == MBV_DT_BF16)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kb]), __builtin_bit_cast(bf16x8, b[kb]), acc, 0, 0, 0);
+    else
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[kb]), __builtin_bit_cast(f16x8, b[kb]), acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int WDT>
+__device__ __forceinline__ void st_ffn(const MbvRowStage& s, const MbvRowStage& io, float* slots, float* red, int row0,
+                                       int rows) {
+  if constexpr (WDT == MBV_DT_F32) {
+    return;
+  } else {
+    constexpr int HB = 264;                            // row stride (16-bit elements) of a wave's hidden image: 528 B
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    const int E = s.n, F = s.k;
+    const bool bwd = (s.flags & MBV_RC_MASK) != 0;
+    const float* X = slots + s.src * (RC_ROWS * RC_LD);
+    unsigned short* himg = reinterpret_cast<unsigned short*>(slots + s.src2 * (RC_ROWS * RC_LD)) + wave * (RC_ROWS * HB);
+    double* acc64 = reinterpret_cast<double*>(red);    // [16][256] f64: 32 KB, the LayerNorm-backward scratch
+    for (int i = threadIdx.x; i < RC_ROWS * RC_MAXC; i += RC_NT) acc64[i] = 0.0;
+    __syncthreads();                                   // acc64 zeroed
+    const G1 char* w1 = gp<char>(s.p0);
+    const G1 char* w2 = gp<char>(s.p2);
+    const G1 float* bias1 = gp<float>(s.p1);
+    const G1 float* hid_in = gp<float>(io.p0);
+    G1 float* hid_out = gpw<float>(bwd ? io.p1 : io.p0);
+    G1 float* part = gpw<float>(io.p2);
+    const int e_tiles = (E + 15) >> 4;
+    for (int c = wave; c * 256 < F; c += RC_NW) {
+      // ---- phase 1: 16 hidden tiles of this chunk, fragments of tile t + 1 requested before tile t is multiplied
+      uint4 bA[8], bB[8];
+      const int hrow0 = c * 256;
+      // A fragments of the input (all E <= 256 columns; blocks beyond E are zero) — per chunk, so that they are dead
+      // in phase 2 (its own A fragments take the registers)
+      uint4 ax[8];
+      {
+        const float4* xr = reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + 8 * g, 16));
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (kb * 32 < E) {
+            const float4 r0 = xr[kb * 8], r1 = xr[kb * 8 + 1];
+            v = f32x8{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          }
+          if constexpr (WDT == MBV_DT_BF16) ax[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, bf16x8));
+          else ax[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, f16x8));
+        }
+      }
+      // (k blocks beyond E: the fragment rows are E*2 bytes long; clamp the offset, the A blocks there are zero)
+      // both weights in fragment-major layout (see gemm_load_tile): first weight F rows x E (ld = E / 32 blocks per row)
+      auto load1 = [&](int t, uint4* b) {
+        const G1 char* base = w1 + ((int64_t)(c * 16 + t) * s.ld * 64 + lane) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) b[kb] = gld16(base + (kb * 32 < E ? kb : 0) * 1024);
+      };
+      load1(0, bA);
+#pragma unroll 1
+      for (int t = 0; t < 16; t += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int tt = t + half;
+          uint4* cur = half == 0 ? bA : bB;
+          uint4* nxt = half == 0 ? bB : bA;
+          const int hcol = hrow0 + tt * 16 + m;                  // hidden unit of this lane's column
+          // the epilogue's own operands are requested BEFORE the next tile's fragments: loads return in order, so
+          // waiting for them must not mean waiting for the fragments issued behind them
+          float hv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bwd) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int row = row0 + 4 * g + i;
+              row = row < rows ? row : rows - 1;
+              hv[i] = hid_in[(int64_t)row * io.ld + hcol];
+            }
+          }
+          const G1 float* bp1 = bias1 ? bias1 : reinterpret_cast<const G1 float*>(w1);
+          float bv = bp1[hcol];
+          bv = (!bwd && bias1) ? bv : 0.f;
+          if (tt + 1 < 16) load1(tt + 1, nxt);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = ffn_mma<WDT>(ax, cur, acc);
+          float colsum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = acc[i] + bv;
+            if (bwd) v = hv[i] > 0.f ? v : 0.f;
+            else v = fmaxf(v, 0.f);
+            const int row = row0 + 4 * g + i;
+            if (row >= rows) v = 0.f;
+            colsum += v;
+            himg[(4 * g + i) * HB + tt * 16 + m] = f32_to_16(v, WDT);
+            if (row < rows) hid_out[(int64_t)row * io.ld + hcol] = v;
+          }
+          if (bwd && part) {                                     // column partial of d(hidden): sum over the 16 rows
+            colsum += __shfl_xor(colsum, 16, 64);
+            colsum += __shfl_xor(colsum, 32, 64);
+            if (g == 0) part[(int64_t)blockIdx.x * io.ld2 + hcol] = colsum;
+          }
+        }
+      }
+      // ---- phase 2: partial output = (16 x 256 chunk image) x second weight[:, chunk]
+      uint4 ah[8];
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb)                             // the wave's own writes: same-wave LDS ordering
+        ah[kb] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(himg + m * HB + kb * 32 + 8 * g, 16));
+      // second weight E rows x F (ld2 = F / 32 blocks per row): this chunk is blocks c * 8 .. c * 8 + 7
+      auto load2 = [&](int t, uint4* b) {
+        const G1 char* base = w2 + (((int64_t)t * s.ld2 + c * 8) * 64 + lane) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) b[kb] = gld16(base + kb * 1024);
+      };
+      load2(0, bA);
+#pragma unroll 1
+      for (int t = 0; t < e_tiles; t += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int tt = t + half;
+          if (tt >= e_tiles) break;
+          uint4* cur = half == 0 ? bA : bB;
+          uint4* nxt = half == 0 ? bB : bA;
+          if (tt + 1 < e_tiles) load2(tt + 1, nxt);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = ffn_mma<WDT>(ah, cur, acc);
+          const int col = tt * 16 + m;
+          if (col < E) {
+#pragma unroll
+            // columns rotated by 16 per row group: the four groups of a wave instruction fall on different banks
+            for (int i = 0; i < 4; ++i) atomicAdd(&acc64[(4 * g + i) * RC_MAXC + ((col + 16 * g) & (RC_MAXC - 1))], (double)acc[i]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* Y = slots + s.dst * (RC_ROWS * RC_LD);
+    const G1 float* bias_out = bwd ? nullptr : gp<float>(io.p1);
+    for (int i = threadIdx.x; i < RC_ROWS * RC_MAXC; i += RC_NT) {
+      const int r = i >> 8, cc = i & 255;
+      if (cc < E) Y[r * RC_LD + cc] = (float)acc64[r * RC_MAXC + ((cc + 16 * (r >> 2)) & (RC_MAXC - 1))] + (bias_out ? bias_out[cc] : 0.f);
+    }
+  }
+}
+
+// barrier between stages: LDS traffic only (the prefetched global loads stay in flight across it)
+__device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The program arrives in the kernel-argument segment, which lives in host-visible memory: read stage by stage with
+// scalar loads, EVERY stage paid a fresh miss of several microseconds (measured: 3.3 us per stage whatever its type,
+// 150 us for the 44-stage FFN chain).  The workgroup therefore copies the whole program into LDS with one round of
+// vector loads and decodes each stage from there (broadcast LDS reads + v_readfirstlane: the fields stay scalar).
+constexpr int RC_PROG_WORDS = (int)(sizeof(RowProgram) / 4);
+constexpr int RC_STAGE_WORDS = (int)(sizeof(MbvRowStage) / 4), RC_HEAD_WORDS = 8;
+static_assert(sizeof(MbvRowStage) == 56 && sizeof(RowProgram) == 32 + RC_MAX_STAGES * 56, "program layout");
+
+__device__ __forceinline__ MbvRowStage rc_stage(const uint32_t* sprog, int i) {
+  uint32_t w[RC_STAGE_WORDS];
+#pragma unroll
+  for (int j = 0; j < RC_STAGE_WORDS; ++j)
+    w[j] = __builtin_amdgcn_readfirstlane(sprog[RC_HEAD_WORDS + i * RC_STAGE_WORDS + j]);
+  MbvRowStage s;
+  __builtin_memcpy(&s, w, sizeof(s));
+  return s;
+}
+
+template <int WDT>
+__global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
   extern __shared__ __attribute__((aligned(16))) float rc_lds[];
+  __shared__ uint32_t sprog[RC_PROG_WORDS];
   float* slots = rc_lds;
   float* red = rc_lds + RC_SLOTS * RC_ROWS * RC_LD;       // [2][16][256] scratch of the LayerNorm backward
   const int row0 = blockIdx.x * RC_ROWS;
-  for (int i = 0; i < P.num_stages; ++i) {
-    const MbvRowStage& s = P.st[i];
+  {
+    const __attribute__((address_space(4))) uint32_t* kp =
+        (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int w = threadIdx.x; w < RC_PROG_WORDS; w += RC_NT) sprog[w] = kp[w];
+  }
+  __syncthreads();
+  const int num_stages = __builtin_amdgcn_readfirstlane(sprog[0]);
+  const int rows = __builtin_amdgcn_readfirstlane(sprog[1]);
+  const int q_mod = __builtin_amdgcn_readfirstlane(sprog[2]);
+  const float eps = __uint_as_float(__builtin_amdgcn_readfirstlane(sprog[4]));
+  int ng = (int)__builtin_amdgcn_readfirstlane(sprog[5]);        // first GEMM / first LOAD stage (host-computed, -1: none)
+  int nl = (int)__builtin_amdgcn_readfirstlane(sprog[6]);
+  GemmPre<WDT> gpre;
+  LoadPre lpre;
+  if (nl >= 0) {
+    const MbvRowStage nx = rc_stage(sprog, nl);
+    load_prefetch(nx, lpre, row0, rows, q_mod);
+  }
+  if (ng >= 0) {
+    const MbvRowStage nx = rc_stage(sprog, ng);
+    gemm_prefetch<WDT>(nx, gpre);
+  }
+  for (int i = 0; i < num_stages; ++i) {
+    const MbvRowStage s = rc_stage(sprog, i);
+    // `reserved`: the next GEMM stage (low byte) and the next LOAD stage (high byte) after this one, 0xff = none
+    const int nxt_g = s.reserved & 0xff, nxt_l = (s.reserved >> 8) & 0xff;
     switch (s.op) {
-      case MBV_RC_LOAD: st_load(s, slots, row0, P.rows, P.q_mod); break;
-      case MBV_RC_STORE: st_store(s, slots, row0, P.rows); break;
-      case MBV_RC_GEMM: st_gemm<WDT>(s, slots); break;
-      case MBV_RC_LN: st_ln(s, slots, row0, P.rows, P.eps); break;
-      case MBV_RC_LN_BWD: st_ln_bwd(s, slots, red, row0, P.rows); break;
+      case MBV_RC_LOAD:
+        st_load(s, slots, lpre, row0, rows);
+        __builtin_amdgcn_sched_barrier(0);                   // refill `lpre` only after its last use
+        if (nxt_l != 0xff) {
+          const MbvRowStage nx = rc_stage(sprog, nxt_l);
+          load_prefetch(nx, lpre, row0, rows, q_mod);
+        }
+        break;
+      case MBV_RC_STORE: st_store(s, slots, row0, rows); break;
+      case MBV_RC_GEMM: {
+        const MbvRowStage nx = rc_stage(sprog, nxt_g != 0xff ? nxt_g : i);
+        st_gemm<WDT>(s, nxt_g != 0xff, nx, slots, gpre);
+        break;
+      }
+      case MBV_RC_LN: st_ln(s, slots, row0, rows, eps); break;
+      case MBV_RC_LN_BWD: st_ln_bwd(s, slots, red, row0, rows); break;
       case MBV_RC_ADD: st_add(s, slots); break;
       case MBV_RC_COLSUM: st_colsum(s, slots); break;
+      case MBV_RC_FFN: {
+        // the prefetch registers are dead across this stage (the host routes the prefetches AROUND an FFN stage: the
+        // stage before it requests nothing, this stage requests the next GEMM / LOAD operands when it is done)
+        {
+          GemmPre<WDT> undef_g;
+          LoadPre undef_l;
+          gpre = undef_g;
+          lpre = undef_l;
+        }
+        const MbvRowStage io = rc_stage(sprog, i + 1);
+        st_ffn<WDT>(s, io, slots, red, row0, rows);
+        if (nxt_l != 0xff) {
+          const MbvRowStage nx = rc_stage(sprog, nxt_l);
+          load_prefetch(nx, lpre, row0, rows, q_mod);
+        }
+        if (nxt_g != 0xff) {
+          const MbvRowStage nx = rc_stage(sprog, nxt_g);
+          gemm_prefetch<WDT>(nx, gpre);
+        }
+        ++i;                                               // the descriptor stage that follows is consumed here
+        break;
+      }
       default: break;
     }
-    __syncthreads();
+    stage_barrier();
   }
 }
 
@@ -403,6 +861,44 @@ __global__ void __launch_bounds__(256) k_transpose_group(const TrArgs A) {
   }
 }
 
+// ---- fragment-major weight copies (16-bit): dst[((t * KBN + kb) * 64 + lane) * 8 + j] = W[t * 16 + lane % 16][kb * 32 +
+// 8 * (lane / 16) + j] for the logical (rows x cols) matrix W; `transposed`: W[r][c] is read from src[c * ld + r] (the
+// data-gradient operand W^T of a row-major src), else from src[r * ld + c].  Rows beyond `rows` are zero.
+struct FragEntry {
+  const void* src;
+  void* dst;
+  int rows, cols, ld, transposed, piece_begin;
+};
+struct FragArgs {
+  int n;
+  FragEntry e[MBV_TR_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_fragment_group(const FragArgs A, int total) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  int ei = 0;
+  for (int i = 1; i < A.n; ++i)
+    if (p >= A.e[i].piece_begin) ei = i;
+  const FragEntry& e = A.e[ei];
+  const int q = p - e.piece_begin;
+  const int lane = q & 63, blk = q >> 6;
+  const int kbn = e.cols >> 5;
+  const int t = blk / kbn, kb = blk - t * kbn;
+  const int r = t * 16 + (lane & 15), c0 = kb * 32 + 8 * (lane >> 4);
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(e.src);
+  unsigned short v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = 0;
+    if (r < e.rows) v[j] = e.transposed ? src[(int64_t)(c0 + j) * e.ld + r] : src[(int64_t)r * e.ld + c0 + j];
+  }
+  uint4 o;
+  o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+  o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+  reinterpret_cast<uint4*>(e.dst)[q] = o;
+}
+
 }  // namespace
 
 extern "C" int mbv_rowchain_max_stages(void) { return RC_MAX_STAGES; }
@@ -415,7 +911,8 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
   if (wdtype != MBV_DT_F32 && wdtype != MBV_DT_BF16 && wdtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   RowProgram P;
   P.num_stages = num_stages; P.rows = rows; P.q_mod = q_mod; P.wdtype = wdtype; P.eps = eps;
-  P.pad[0] = P.pad[1] = P.pad[2] = 0;
+  P.pad[0] = P.pad[1] = -1;                            // first GEMM / first LOAD stage, filled below
+  P.pad[2] = 0;
   const int kq = wdtype == MBV_DT_F32 ? 16 : 32;          // reduction granularity of the MFMA k blocks
   const int wes = wdtype == MBV_DT_F32 ? 4 : 2;
   for (int i = 0; i < num_stages; ++i) {
@@ -437,7 +934,8 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
         break;
       case MBV_RC_GEMM:
         if (!slot_ok(s.dst) || !slot_ok(s.src) || s.dst == s.src || !s.p0 || s.n <= 0 || s.n > RC_MAXC || s.k <= 0 ||
-            s.k > RC_MAXC || (s.k % kq) || ((int64_t)s.ld * wes) % 16 || (reinterpret_cast<size_t>(s.p0) & 15) ||
+            s.k > RC_MAXC || (s.k % kq) || (!(s.flags & MBV_RC_FRAG) && ((int64_t)s.ld * wes) % 16) ||
+            ((s.flags & MBV_RC_FRAG) && (wdtype == MBV_DT_F32 || s.ld * 32 < s.k)) || (reinterpret_cast<size_t>(s.p0) & 15) ||
             ((s.flags & MBV_RC_MASK) && (!slot_ok(s.src2) || s.src2 == s.dst)))
           return MBV_ERR_BAD_ARG;
         break;
@@ -457,11 +955,38 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
       case MBV_RC_COLSUM:
         if (!slot_ok(s.src) || !s.p0 || s.n <= 0 || s.n > RC_MAXC || s.ld < s.n) return MBV_ERR_BAD_ARG;
         break;
+      case MBV_RC_FFN: {
+        // [FFN stage][io descriptor]: 16-bit weights; scratch slots src2 .. src2 + 4 (8 wave images of 16 x 264 x 2 B)
+        if (wdtype == MBV_DT_F32 || i + 1 >= num_stages || stages[i + 1].op != MBV_RC_FFN_IO) return MBV_ERR_BAD_ARG;
+        const MbvRowStage& io = stages[i + 1];
+        const bool bwd = (s.flags & MBV_RC_MASK) != 0;
+        if (!slot_ok(s.dst) || !slot_ok(s.src) || !slot_ok(s.src2) || s.src2 + 5 > RC_SLOTS || s.dst == s.src ||
+            (s.src >= s.src2 && s.src < s.src2 + 5) || (s.dst >= s.src2 && s.dst < s.src2 + 5) || !s.p0 || !s.p2 ||
+            s.n <= 0 || s.n > RC_MAXC || (s.n % 32) || s.k <= 0 || (s.k % 256) || s.ld * 32 < s.n || s.ld2 * 32 < s.k || (reinterpret_cast<size_t>(s.p0) & 15) || (reinterpret_cast<size_t>(s.p2) & 15) || !io.p0 ||
+            io.ld < s.k || (bwd && !io.p1) || (io.p2 && io.ld2 < s.k))
+          return MBV_ERR_BAD_ARG;
+        P.st[i] = s;
+        ++i;
+        P.st[i] = stages[i];
+        continue;
+      }
+      case MBV_RC_FFN_IO:
+        return MBV_ERR_BAD_ARG;                            // only valid directly behind an FFN stage (consumed above)
       default:
         return MBV_ERR_BAD_ARG;
     }
     P.st[i] = s;
   }
+  // stage i's `reserved`: the next GEMM (low byte) / LOAD (high byte) stage after i, 0xff = none; header: the first ones
+  int next_g = 0xff, next_l = 0xff;
+  for (int i = num_stages - 1; i >= 0; --i) {
+    P.st[i].reserved = (int16_t)(next_g | (next_l << 8));
+    if (P.st[i].op == MBV_RC_GEMM) next_g = i;
+    if (P.st[i].op == MBV_RC_LOAD) next_l = i;
+    if (P.st[i].op == MBV_RC_FFN) next_g = next_l = 0xff;  // nothing is prefetched across an FFN stage (it re-arms both)
+  }
+  P.pad[0] = next_g == 0xff ? -1 : next_g;
+  P.pad[1] = next_l == 0xff ? -1 : next_l;
   const size_t lds = (size_t)(RC_SLOTS * RC_ROWS * RC_LD + 2 * RC_ROWS * RC_MAXC) * sizeof(float);
   static bool attr_done = false;       // idempotent attribute of the code objects, not library state
   if (!attr_done) {
@@ -481,6 +1006,30 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
   else
     hipLaunchKernelGGL(k_rowchain<MBV_DT_F16>, grid, block, lds, stream, P);
   MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_fragment_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols,
+                                  const int32_t* ld, const int32_t* transposed, int32_t n, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!src || !dst || !rows || !cols || !ld || !transposed || n < 0) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < n; base += MBV_TR_MAX) {
+    FragArgs A;
+    A.n = n - base < MBV_TR_MAX ? n - base : MBV_TR_MAX;
+    int pieces = 0;
+    for (int i = 0; i < A.n; ++i) {
+      const int j = base + i;
+      if (!src[j] || !dst[j] || rows[j] <= 0 || cols[j] <= 0 || (cols[j] % 32) || ld[j] <= 0 ||
+          (reinterpret_cast<size_t>(dst[j]) & 15) || (!transposed[j] && ((ld[j] % 8) || (reinterpret_cast<size_t>(src[j]) & 15))))
+        return MBV_ERR_BAD_ARG;
+      A.e[i].src = src[j]; A.e[i].dst = dst[j]; A.e[i].rows = rows[j]; A.e[i].cols = cols[j]; A.e[i].ld = ld[j];
+      A.e[i].transposed = transposed[j];
+      A.e[i].piece_begin = pieces;
+      pieces += ((rows[j] + 15) / 16) * (cols[j] / 32) * 64;
+    }
+    hipLaunchKernelGGL(k_fragment_group, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, A, pieces);
+    MBV_CHECK_LAUNCH();
+  }
   return MBV_OK;
 }
 

@@ -30,8 +30,8 @@ import torch
 from . import _lib, ops
 from ._lib import MaskBevHipError, check
 
-OP_LOAD, OP_STORE, OP_GEMM, OP_LN, OP_LN_BWD, OP_ADD, OP_COLSUM = range(7)
-F_ACCUM, F_RELU, F_MASK, F_SAVE_SUM = 4, 8, 16, 32
+OP_LOAD, OP_STORE, OP_GEMM, OP_LN, OP_LN_BWD, OP_ADD, OP_COLSUM, OP_FFN, OP_FFN_IO = range(9)
+F_ACCUM, F_RELU, F_MASK, F_SAVE_SUM, F_FRAG = 4, 8, 16, 32, 128
 ROWS = 16
 
 
@@ -53,13 +53,42 @@ def _addr(t: Optional[torch.Tensor], offset_elems: int = 0) -> Optional[int]:
     return t.data_ptr() + offset_elems * t.element_size()
 
 
+class WRef:
+    """A GEMM weight operand: a row-major matrix (f32 programs, tests) or a fragment-major 16-bit copy
+    (``mbv_fragment_group``) of a logical (rows, cols) matrix."""
+
+    def __init__(self, tensor: torch.Tensor, rows: int, cols: int, frag: bool):
+        self.t, self.rows, self.cols, self.frag = tensor, rows, cols, frag
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+
+def fragment_copy(w: torch.Tensor, transposed: bool = False) -> WRef:
+    """Fragment-major copy of the 16-bit matrix ``w`` (or of its transpose): one launch; for tests / one-off use —
+    the decoder refreshes all of its copies with one grouped launch per step (:class:`WeightCopies`)."""
+    lib = _lib.load()
+    if w.dtype not in (torch.bfloat16, torch.float16) or w.dim() != 2 or w.stride(1) != 1:
+        raise MaskBevHipError('fragment_copy: a 16-bit row-major matrix')
+    rows, cols = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    dst = torch.empty(((rows + 15) // 16 * 16) * cols, dtype=w.dtype, device=w.device)
+    P1, I1 = ctypes.c_void_p * 1, ctypes.c_int32 * 1
+    check(lib.mbv_fragment_group(P1(w.data_ptr()), P1(dst.data_ptr()), I1(rows), I1(cols), I1(w.stride(0)),
+                                 I1(1 if transposed else 0), 1, ops._stream()), 'mbv_fragment_group')
+    return WRef(dst, rows, cols, True)
+
+
 class Program:
     """A stage list for ``mbv_rowchain_run``.  Tensors named in stages are kept referenced until :meth:`run` returns
     (the launch is stream-ordered after that, like any other op on torch's current stream)."""
 
-    def __init__(self, rows: int, q_mod: int, eps: float, wdtype: torch.dtype):
+    TIMING = None       # a list -> run() brackets every launch with events and appends (label, start, end) (scratch/time_k19.py)
+
+    def __init__(self, rows: int, q_mod: int, eps: float, wdtype: torch.dtype, label: str = ''):
         self.rows, self.q_mod, self.eps = int(rows), int(q_mod), float(eps)
         self.wdtype = wdtype
+        self.label = label
         self.stages: List[RowStage] = []
         self.keep: list = []
 
@@ -85,14 +114,29 @@ class Program:
         self._add(OP_STORE, src=src, n=n, flags=_dt(t) | (F_ACCUM if accum else 0), ld=t.stride(0), p0=_addr(t, col0))
 
     def gemm(self, dst: int, src: int, w: torch.Tensor, n: int, k: int, bias: Optional[torch.Tensor] = None,
-             row0: int = 0, col0: int = 0, relu: bool = False, accum: bool = False, mask: int = -1, bias0: int = 0):
-        """slot dst = act([dst +] src (16, k) @ w[row0:row0 + n, col0:col0 + k]^T + bias[bias0:bias0 + n])."""
-        if w.dtype != self.wdtype or w.stride(1) != 1:
-            raise MaskBevHipError('rowchain: weight dtype / layout mismatch')
-        self.keep += [w, bias]
-        flags = (F_RELU if relu else 0) | (F_ACCUM if accum else 0) | (F_MASK if mask >= 0 else 0)
-        self._add(OP_GEMM, dst=dst, src=src, src2=mask, n=n, k=k, flags=flags, ld=w.stride(0),
-                  p0=_addr(w, row0 * w.stride(0) + col0), p1=_addr(bias, bias0))
+             row0: int = 0, col0: int = 0, relu: bool = False, accum: bool = False, mask: int = -1, bias0: int = 0,
+             out: Optional[torch.Tensor] = None, out_col0: int = 0):
+        """slot dst = act([dst +] src (16, k) @ w[row0:row0 + n, col0:col0 + k]^T + bias[bias0:bias0 + n]);
+        ``out``: the result rows also go to out[:, out_col0:out_col0 + n] (saves a STORE stage)."""
+        if isinstance(w, WRef) and w.frag:
+            if w.dtype != self.wdtype or row0 % 16 or col0 % 32:
+                raise MaskBevHipError('rowchain: fragment weight dtype / offsets')
+            kbn = w.cols // 32
+            self.keep += [w.t, bias]
+            flags = (F_RELU if relu else 0) | (F_ACCUM if accum else 0) | (F_MASK if mask >= 0 else 0) | F_FRAG
+            self._add(OP_GEMM, dst=dst, src=src, src2=mask, n=n, k=k, flags=flags, ld=kbn,
+                      p0=_addr(w.t, ((row0 // 16) * kbn + col0 // 32) * 512), p1=_addr(bias, bias0))
+        else:
+            if isinstance(w, WRef):
+                w = w.t
+            if w.dtype != self.wdtype or w.stride(1) != 1:
+                raise MaskBevHipError('rowchain: weight dtype / layout mismatch')
+            self.keep += [w, bias]
+            flags = (F_RELU if relu else 0) | (F_ACCUM if accum else 0) | (F_MASK if mask >= 0 else 0)
+            self._add(OP_GEMM, dst=dst, src=src, src2=mask, n=n, k=k, flags=flags, ld=w.stride(0),
+                      p0=_addr(w, row0 * w.stride(0) + col0), p1=_addr(bias, bias0))
+        if out is not None:          # (an epilogue store from the MFMA accumulators was measured slower than a STORE stage)
+            self.store(dst, out, n, col0=out_col0)
 
     def ln(self, dst: int, a: int, b: int, gamma: torch.Tensor, beta: torch.Tensor, n: int,
            stats: Optional[torch.Tensor] = None, save_sum: bool = False):
@@ -113,56 +157,110 @@ class Program:
         self.keep.append(partial)
         self._add(OP_COLSUM, src=src, n=n, ld=partial.stride(0), p0=_addr(partial, col0))
 
+    def ffn(self, dst: int, src: int, scratch: int, w_a: torch.Tensor, w_b: torch.Tensor, e: int, f: int,
+            hid: torch.Tensor, bias_a: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
+            backward: bool = False, d_hid: Optional[torch.Tensor] = None, partial: Optional[torch.Tensor] = None,
+            partial_col0: int = 0):
+        """The MLP pair as ONE stage with the hidden chunks spread over the waves (16-bit weights).
+        forward: slot dst = relu(src @ w_a^T + bias_a) @ w_b^T (+ bias_out), w_a = W1 (f, e), w_b = W2 (e, f); the hidden
+        activations go to ``hid`` (rows, f) f32.  backward: slot dst = ((src @ w_a^T) * (hid > 0)) @ w_b^T with
+        w_a = W2^T (f, e), w_b = W1^T (e, f); d(hidden) goes to ``d_hid``, its per-block column sums to
+        ``partial[:, partial_col0:partial_col0 + f]``.  ``scratch``: first of 5 free consecutive slots."""
+        if (not isinstance(w_a, WRef) or not isinstance(w_b, WRef) or not w_a.frag or not w_b.frag
+                or w_a.dtype != self.wdtype or w_b.dtype != self.wdtype or self.wdtype == torch.float32
+                or (w_a.rows, w_a.cols) != (f, e) or (w_b.rows, w_b.cols) != (e, f)):
+            raise MaskBevHipError('rowchain ffn: fragment-major 16-bit weights (f, e) and (e, f) in the program dtype')
+        self.keep += [w_a.t, w_b.t, hid, bias_a, bias_out, d_hid, partial]
+        dbg = 64 if os.environ.get('MBV_RC_FFN_DEBUG') == '1' else 0
+        self._add(OP_FFN, dst=dst, src=src, src2=scratch, n=e, k=f, flags=(F_MASK if backward else 0) | dbg, ld=e // 32,
+                  ld2=f // 32, p0=_addr(w_a.t), p1=_addr(bias_a), p2=_addr(w_b.t))
+        self._add(OP_FFN_IO, ld=hid.stride(0), ld2=0 if partial is None else partial.stride(0), p0=_addr(hid),
+                  p1=_addr(d_hid if backward else bias_out), p2=_addr(partial, partial_col0))
+
     def run(self):
         lib = _lib.load()
         n = len(self.stages)
         if n == 0:
             return
         arr = (RowStage * n)(*self.stages)
+        ev = None
+        if Program.TIMING is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         check(lib.mbv_rowchain_run(arr, n, self.rows, self.q_mod, self.eps, ops._dt_flag(self.wdtype), ops._stream()),
               'mbv_rowchain_run')
+        if ev is not None:
+            ev[1].record()
+            Program.TIMING.append((self.label, n, ev[0], ev[1]))
         self.keep = []
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # transposed weight copies (data gradients), refreshed once per step
 # ---------------------------------------------------------------------------------------------------------------------
-class TransposedWeights:
-    """``get(param, rows)`` -> the transpose of ``param[rows]`` in the compute dtype.  ``refresh(entries, dt)`` fills all
-    of them with one grouped launch (``mbv_transpose_group``); buffers are allocated once and reused."""
+class WeightCopies:
+    """The GEMM operands of the decoder's chains, refreshed once per step.
+
+    16-bit compute: every weight — as it is for the forward products, transposed for the data gradients ``dX = dY W`` —
+    as a fragment-major copy, all written by ONE grouped launch (``mbv_fragment_group``) from the 16-bit weight copies.
+    f32 compute: the forward operands are the master weights themselves (row-major); the transposes are f32 copies
+    (``mbv_transpose_group``).  ``get(param, rows, transposed)`` -> :class:`WRef`.  Buffers are allocated once."""
 
     def __init__(self):
         self.buf = {}
-        self.dt = None
+        self.ref = {}
 
     def refresh(self, entries, dt: torch.dtype):
         lib = _lib.load()
-        src_p, dst_p, rows_l, cols_l = [], [], [], []
+        self.ref = {}
         keep = []
-        for p, rows in entries:
-            w = p.detach() if dt == torch.float32 else ops._compute_copy(p, dt)
+        if dt == torch.float32:
+            src_p, dst_p, rows_l, cols_l = [], [], [], []
+            for p, rows, tr in entries:
+                w = p.detach()
+                if rows is not None:
+                    w = w[rows[0]:rows[1]]
+                key = (id(p), rows, tr)
+                if not tr:
+                    self.ref[key] = WRef(w, w.shape[0], w.shape[1], False)
+                    continue
+                t = self.buf.get(key)
+                if t is None or t.dtype != dt or t.shape != (w.shape[1], w.shape[0]) or t.device != w.device:
+                    t = self.buf[key] = torch.empty((w.shape[1], w.shape[0]), dtype=dt, device=w.device)
+                keep.append(w)
+                src_p.append(w.data_ptr()); dst_p.append(t.data_ptr()); rows_l.append(w.shape[0]); cols_l.append(w.shape[1])
+                self.ref[key] = WRef(t, w.shape[1], w.shape[0], False)
+            n = len(src_p)
+            if n:
+                PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+                check(lib.mbv_transpose_group(PA(*src_p), PA(*dst_p), IA(*rows_l), IA(*cols_l), n, 4, ops._stream()),
+                      'mbv_transpose_group')
+            return
+        src_p, dst_p, rows_l, cols_l, ld_l, tr_l = [], [], [], [], [], []
+        for p, rows, tr in entries:
+            w = ops._compute_copy(p, dt)
             if rows is not None:
                 w = w[rows[0]:rows[1]]
-            key = (id(p), rows)
-            t = self.buf.get(key)
-            if t is None or t.dtype != dt or t.shape != (w.shape[1], w.shape[0]) or t.device != w.device:
-                t = self.buf[key] = torch.empty((w.shape[1], w.shape[0]), dtype=dt, device=w.device)
-            if not w.is_contiguous():
+            if w.stride(1) != 1:
                 w = w.contiguous()
+            lr, lc = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
+            key = (id(p), rows, tr)
+            numel = ((lr + 15) // 16 * 16) * lc
+            t = self.buf.get(key)
+            if t is None or t.dtype != dt or t.numel() != numel or t.device != w.device:
+                t = self.buf[key] = torch.empty(numel, dtype=dt, device=w.device)
             keep.append(w)
-            src_p.append(w.data_ptr())
-            dst_p.append(t.data_ptr())
-            rows_l.append(w.shape[0])
-            cols_l.append(w.shape[1])
+            src_p.append(w.data_ptr()); dst_p.append(t.data_ptr()); rows_l.append(lr); cols_l.append(lc)
+            ld_l.append(w.stride(0)); tr_l.append(1 if tr else 0)
+            self.ref[key] = WRef(t, lr, lc, True)
         n = len(src_p)
         if n:
             PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
-            check(lib.mbv_transpose_group(PA(*src_p), PA(*dst_p), IA(*rows_l), IA(*cols_l), n,
-                                          4 if dt == torch.float32 else 2, ops._stream()), 'mbv_transpose_group')
-        self.dt = dt
+            check(lib.mbv_fragment_group(PA(*src_p), PA(*dst_p), IA(*rows_l), IA(*cols_l), IA(*ld_l), IA(*tr_l), n,
+                                         ops._stream()), 'mbv_fragment_group')
 
-    def get(self, p, rows=None) -> torch.Tensor:
-        return self.buf[(id(p), rows)]
+    def get(self, p, rows=None, transposed: bool = False) -> WRef:
+        return self.ref[(id(p), rows, transposed)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -243,15 +341,19 @@ class QueryPositions(torch.autograd.Function):
 class LayerCtx:
     """Per-call constants shared by the two Functions of a layer (plain Python object, not seen by autograd)."""
 
-    def __init__(self, batch, queries, embed, heads, ffn, eps, dt, tw: TransposedWeights, dpos_holder, qpos):
+    def __init__(self, batch, queries, embed, heads, ffn, eps, dt, tw: WeightCopies, dpos_holder, qpos):
         self.b, self.q, self.e, self.h, self.f, self.eps, self.dt = batch, queries, embed, heads, ffn, eps, dt
         self.m = batch * queries
         self.tw, self.dpos_holder, self.qpos = tw, dpos_holder, qpos
         self.wdt = torch.float32 if dt == torch.float32 else dt
 
-    def w(self, p):
-        """The GEMM operand copy of parameter p (f32 master or the 16-bit copy)."""
-        return p.detach() if self.wdt == torch.float32 else ops._compute_copy(p, self.wdt)
+    def w(self, p, rows=None):
+        """The forward GEMM operand of parameter p[rows]."""
+        return self.tw.get(p, rows, False)
+
+    def wt(self, p, rows=None):
+        """The data-gradient operand (p[rows] transposed)."""
+        return self.tw.get(p, rows, True)
 
     def dpos(self, like: torch.Tensor) -> torch.Tensor:
         acc = self.dpos_holder.get('acc')
@@ -286,7 +388,7 @@ class _DecA(torch.autograd.Function):
         t1 = torch.empty((m, e), **f32)
         qkv = torch.empty((3, m, e), **f32)
         w_o, w_i = lc.w(wo), lc.w(w_in)
-        P = Program(m, lc.q, lc.eps, lc.wdt)
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.fwd')
         P.load(0, o1, e)
         P.gemm(1, 0, w_o, e, e, bias=bo)
         P.load(2, x0, e)
@@ -295,12 +397,9 @@ class _DecA(torch.autograd.Function):
         P.store(3, x1, e)
         P.load_slot_plus(0, 3, lc.qpos, e)                      # x1 + positions: the q / k input
         P.store(0, t1, e)
-        P.gemm(1, 0, w_i, e, e, bias=b_in, row0=0, bias0=0)
-        P.store(1, qkv[0], e)
-        P.gemm(2, 0, w_i, e, e, bias=b_in, row0=e, bias0=e)
-        P.store(2, qkv[1], e)
-        P.gemm(4, 3, w_i, e, e, bias=b_in, row0=2 * e, bias0=2 * e)
-        P.store(4, qkv[2], e)
+        P.gemm(1, 0, w_i, e, e, bias=b_in, row0=0, bias0=0, out=qkv[0])
+        P.gemm(2, 0, w_i, e, e, bias=b_in, row0=e, bias0=e, out=qkv[1])
+        P.gemm(4, 3, w_i, e, e, bias=b_in, row0=2 * e, bias0=2 * e, out=qkv[2])      # (row offsets: multiples of 16)
         P.run()
         o2, lse = _self_attention_fwd(qkv[0], qkv[1], qkv[2], lc.b, lc.q, lc.h)
         ctx.lc = lc
@@ -330,25 +429,24 @@ class _DecA(torch.autograd.Function):
         ds1 = torch.empty((m, e), **f32)
         g_o1 = torch.empty((m, e), dtype=o1.dtype, device=dev)
         tw = lc.tw
-        P = Program(m, lc.q, lc.eps, lc.wdt)
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.bwd')
         P.load(0, g_qkv[0], e)
         P.colsum(0, part_b, e, 0)
-        P.gemm(1, 0, tw.get(w_in, (0, e)), e, e)
+        P.gemm(1, 0, lc.wt(w_in, (0, e)), e, e)
         P.load(2, g_qkv[1], e)
         P.colsum(2, part_b, e, e)
-        P.gemm(1, 2, tw.get(w_in, (e, 2 * e)), e, e, accum=True)
+        P.gemm(1, 2, lc.wt(w_in, (e, 2 * e)), e, e, accum=True)
         P.store(1, lc.dpos(g_x1), e, accum=True)                # d(positions) of this layer's self-attention
         P.load(3, g_qkv[2], e)
         P.colsum(3, part_b, e, 2 * e)
-        P.gemm(1, 3, tw.get(w_in, (2 * e, 3 * e)), e, e, accum=True)
+        P.gemm(1, 3, lc.wt(w_in, (2 * e, 3 * e)), e, e, accum=True)
         P.load(4, g_x1, e)
         P.add(1, 1, 4, e)
         P.load(5, sum1, e)
         P.ln_bwd(6, 1, 5, g1, stats1, e, partial=part_ln)
         P.store(6, ds1, e)
         P.colsum(6, part_b, e, 3 * e)
-        P.gemm(0, 6, tw.get(wo), e, e)
-        P.store(0, g_o1, e)
+        P.gemm(0, 6, lc.wt(wo), e, e, out=g_o1)
         P.run()
         ni = ctx.needs_input_grad
         gw_in = _sum_grads(_sum_grads(_weight_grad(w_in, (0, e), g_qkv[0], t1, ni[7]),
@@ -401,39 +499,39 @@ class _DecB(torch.autograd.Function):
         oc = head.mlp[2][0].shape[0]
         me = torch.empty((m, oc), dtype=head.mask_feature.dtype, device=dev)
         w_o, w_1, w_2 = lc.w(wo), lc.w(w1), lc.w(w2)
-        P = Program(m, lc.q, lc.eps, lc.wdt)
-        P.load(0, o2, e)
-        P.gemm(1, 0, w_o, e, e, bias=bo)
-        P.load(2, x1, e)
-        P.ln(3, 2, 1, g2, b2, e, stats=stats2, save_sum=True)
-        P.store(2, sum2, e)
-        P.store(3, x2, e)
-        ch = 256
-        for c in range(0, f, ch):
-            n = min(ch, f - c)
-            P.gemm(0, 3, w_1, n, e, bias=bb1, row0=c, bias0=c, relu=True)
-            P.store(0, hid, n, col0=c)
-            P.gemm(1, 0, w_2, e, n, bias=bb2 if c == 0 else None, col0=c, accum=c > 0)
-        P.ln(4, 3, 1, g3, b3, e, stats=stats3, save_sum=True)
-        P.store(3, sum3, e)
-        P.store(4, x3, e)
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'B.fwd')
+        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+        P.load(2, o2, e)
+        P.gemm(3, 2, w_o, e, e, bias=bo)
+        P.load(4, x1, e)
+        P.ln(0, 4, 3, g2, b2, e, stats=stats2, save_sum=True)          # x2 -> slot 0
+        P.store(4, sum2, e)
+        P.store(0, x2, e)
+        if fused_ffn:
+            P.ffn(1, 0, 2, w_1, w_2, e, f, hid, bias_a=bb1, bias_out=bb2)    # y -> slot 1; scratch slots 2..6
+        else:
+            ch = 256
+            for c in range(0, f, ch):
+                n = min(ch, f - c)
+                P.gemm(2, 0, w_1, n, e, bias=bb1, row0=c, bias0=c, relu=True, out=hid, out_col0=c)
+                P.gemm(1, 2, w_2, e, n, bias=bb2 if c == 0 else None, col0=c, accum=c > 0)
+        P.ln(2, 0, 1, g3, b3, e, stats=stats3, save_sum=True)          # x3 -> slot 2, the sum -> slot 0
+        P.store(0, sum3, e)
+        P.store(2, x3, e)
         # prediction heads (no gradient through here: ops._DeferredHeads re-evaluates them in one batched backward)
-        P.ln(0, 4, -1, head.post_g, head.post_b, e)
-        P.gemm(1, 0, lc.w(head.cls_w), ncls, e, bias=head.cls_b)
-        P.store(1, cls, ncls)
+        P.ln(3, 2, -1, head.post_g, head.post_b, e)
+        P.gemm(4, 3, lc.w(head.cls_w), ncls, e, bias=head.cls_b, out=cls)
         (m1w, m1b), (m2w, m2b), (m3w, m3b) = head.mlp
-        P.gemm(1, 0, lc.w(m1w), m1w.shape[0], e, bias=m1b, relu=True)
-        P.gemm(2, 1, lc.w(m2w), m2w.shape[0], m1w.shape[0], bias=m2b, relu=True)
-        P.gemm(1, 2, lc.w(m3w), oc, m2w.shape[0], bias=m3b)
-        P.store(1, me, oc)
+        P.gemm(4, 3, lc.w(m1w), m1w.shape[0], e, bias=m1b, relu=True)
+        P.gemm(5, 4, lc.w(m2w), m2w.shape[0], m1w.shape[0], bias=m2b, relu=True)
+        P.gemm(4, 5, lc.w(m3w), oc, m2w.shape[0], bias=m3b, out=me)
         qc = t3 = None
         if nxt is not None:
             t3 = torch.empty((m, e), **f32)
             qc = torch.empty((m, e), dtype=nxt.holder.k_cat.dtype, device=dev)
-            P.load_slot_plus(0, 4, lc.qpos, e)
-            P.store(0, t3, e)
-            P.gemm(1, 0, lc.w(nxt.w_in), e, e, bias=nxt.b_in, row0=0, bias0=0)
-            P.store(1, qc, e)
+            P.load_slot_plus(3, 2, lc.qpos, e)
+            P.store(3, t3, e)
+            P.gemm(4, 3, lc.w(nxt.w_in), e, e, bias=nxt.b_in, row0=0, bias0=0, out=qc)
         P.run()
         b, q = lc.b, lc.q
         with torch.no_grad():
@@ -503,36 +601,38 @@ class _DecB(torch.autograd.Function):
         ds3, ds2 = torch.empty((m, e), **f32), torch.empty((m, e), **f32)
         dh = torch.empty((m, f), **f32)
         g_o2 = torch.empty((m, e), **f32)
-        P = Program(m, lc.q, lc.eps, lc.wdt)
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'B.bwd')
+        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
         if g_qc is not None:
-            P.load(0, g_qc, e)
-            P.colsum(0, part_b, e, 0)
-            P.gemm(1, 0, tw.get(nxt.w_in, (0, e)), e, e)
-            P.store(1, lc.dpos(g_x3), e, accum=True)
-            P.load(2, g_x3, e)
-            P.add(1, 1, 2, e)
+            P.load(2, g_qc, e)
+            P.colsum(2, part_b, e, 0)
+            P.gemm(3, 2, lc.wt(nxt.w_in, (0, e)), e, e)
+            P.store(3, lc.dpos(g_x3), e, accum=True)
+            P.load(4, g_x3, e)
+            P.add(3, 3, 4, e)
         else:
-            P.load(1, g_x3, e)
-        P.load(2, sum3, e)
-        P.ln_bwd(3, 1, 2, g3, stats3, e, partial=part_ln3)
-        P.store(3, ds3, e)
-        P.colsum(3, part_b, e, e)
-        w2t, w1t = tw.get(w2), tw.get(w1)                       # (f, e) and (e, f)
-        ch = 256
-        for c in range(0, f, ch):
-            n = min(ch, f - c)
-            P.load(0, hid, n, col0=c)
-            P.gemm(1, 3, w2t, n, e, row0=c, mask=0)             # d hidden chunk = (ds3 W2[:, chunk]) * (h > 0)
-            P.store(1, dh, n, col0=c)
-            P.colsum(1, part_b, n, 3 * e + c)
-            P.gemm(4, 1, w1t, e, n, col0=c, accum=c > 0)        # d x2 += d hidden chunk . W1[chunk]
-        P.add(4, 4, 3, e)
+            P.load(3, g_x3, e)
+        P.load(4, sum3, e)
+        P.ln_bwd(0, 3, 4, g3, stats3, e, partial=part_ln3)              # ds3 -> slot 0
+        P.store(0, ds3, e)
+        P.colsum(0, part_b, e, e)
+        w2t, w1t = lc.wt(w2), lc.wt(w1)                         # (f, e) and (e, f)
+        if fused_ffn:
+            P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part_b, partial_col0=3 * e)
+        else:
+            ch = 256
+            for c in range(0, f, ch):
+                n = min(ch, f - c)
+                P.load(2, hid, n, col0=c)
+                P.gemm(3, 0, w2t, n, e, row0=c, mask=2, out=dh, out_col0=c)   # d hidden chunk = (ds3 W2[:, chunk]) * (h > 0)
+                P.colsum(3, part_b, n, 3 * e + c)
+                P.gemm(1, 3, w1t, e, n, col0=c, accum=c > 0)        # d x2 += d hidden chunk . W1[chunk]
+        P.add(1, 1, 0, e)
         P.load(2, sum2, e)
-        P.ln_bwd(5, 4, 2, g2, stats2, e, partial=part_ln2)
-        P.store(5, ds2, e)
-        P.colsum(5, part_b, e, 2 * e)
-        P.gemm(0, 5, tw.get(wo), e, e)
-        P.store(0, g_o2, e)
+        P.ln_bwd(3, 1, 2, g2, stats2, e, partial=part_ln2)
+        P.store(3, ds2, e)
+        P.colsum(3, part_b, e, 2 * e)
+        P.gemm(4, 3, lc.wt(wo), e, e, out=g_o2)
         P.run()
         ni = ctx.needs_input_grad         # lc, head, nxt, x1, o2, token, wo, bo, g2, b2, w1, bb1, w2, bb2, g3, b3, nw_in, nb_in
         gwo = _weight_grad(wo, None, ds2, o2, ni[6])

@@ -496,19 +496,26 @@ class Mask2FormerHead(nn.Module):
         dev = mask_features.device
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
         need_grad = torch.is_grad_enabled()
-        tw = getattr(self, '_dec_transposed', None)
+        tw = getattr(self, '_dec_weights', None)
         if tw is None:
-            tw = self._dec_transposed = DF.TransposedWeights()
-        if need_grad:        # transposed copies for the data gradients: one grouped launch per step
-            ents = []
-            for i, layer in enumerate(layers):
-                ca, sa = layer.cross_attn.attn, layer.self_attn.attn
-                ents += [(ca.out_proj.weight, None), (sa.in_proj_weight, (0, e)), (sa.in_proj_weight, (e, 2 * e)),
-                         (sa.in_proj_weight, (2 * e, 3 * e)), (sa.out_proj.weight, None),
-                         (layer.ffn.layers[0][0].weight, None), (layer.ffn.layers[1].weight, None)]
+            tw = self._dec_weights = DF.WeightCopies()
+        # the chains' GEMM operands (fragment-major 16-bit copies; with a graph also the transposed ones for the data
+        # gradients): one grouped launch per step
+        ents = [(self.cls_embed.weight, None, False)] + [(self.mask_embed[j].weight, None, False) for j in (0, 2, 4)]
+        for i, layer in enumerate(layers):
+            ca, sa = layer.cross_attn.attn, layer.self_attn.attn
+            fc1, fc2 = layer.ffn.layers[0][0], layer.ffn.layers[1]
+            ents += [(ca.out_proj.weight, None, False), (sa.in_proj_weight, None, False), (sa.out_proj.weight, None, False),
+                     (fc1.weight, None, False), (fc2.weight, None, False)]
+            if i > 0:
+                ents.append((ca.in_proj_weight, None, False))
+            if need_grad:
+                ents += [(ca.out_proj.weight, None, True), (sa.in_proj_weight, (0, e), True),
+                         (sa.in_proj_weight, (e, 2 * e), True), (sa.in_proj_weight, (2 * e, 3 * e), True),
+                         (sa.out_proj.weight, None, True), (fc1.weight, None, True), (fc2.weight, None, True)]
                 if i > 0:
-                    ents.append((ca.in_proj_weight, (0, e)))
-            tw.refresh(ents, dt)
+                    ents.append((ca.in_proj_weight, (0, e), True))
+        tw.refresh(ents, dt)
         holder = {}
         qpos = DF.QueryPositions.apply(self.query_embed.weight, holder)
         f = layers[0].ffn.layers[0][0].out_features

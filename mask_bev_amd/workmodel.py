@@ -57,6 +57,30 @@ def _msda_value_packed(a) -> Work:
     return ('k_msda_bwd_value_fx', 'hbm', b * nv * heads * d * out_es + b * nq * heads * d * 4.0 + samples * 12.0, 0.0)
 
 
+def _rowchain(a) -> Work:
+    """K19: a stage program over `rows` token rows.  Algorithmic bytes: every LOAD / STORE row once, every GEMM's weight
+    block once per launch (the 25 workgroups re-read it through L2), the LayerNorm statistics; flops: the GEMMs."""
+    stages, n, rows, wdt = a[0], _i(a[1]), _i(a[2]), _i(a[5])
+    wes = 4.0 if wdt == 0 else 2.0
+    by = fl = 0.0
+    for i in range(n):
+        st = stages[i]
+        es = 4.0 if (st.flags & 3) == 0 else 2.0
+        if st.op == 0:                      # LOAD
+            by += rows * st.n * (es if st.p0 else 0.0)
+        elif st.op == 1:                    # STORE (accumulate: read + write)
+            by += rows * st.n * es * (2.0 if st.flags & 4 else 1.0)
+        elif st.op == 2:                    # GEMM
+            by += st.n * st.k * wes
+            fl += 2.0 * rows * st.n * st.k
+        elif st.op in (3, 4):               # LayerNorm forward / backward: statistics, parameter partials
+            by += rows * 8.0
+        elif st.op == 7:                    # FFN pair: both weights once, the hidden activations (and their gradient)
+            by += 2.0 * st.n * st.k * wes + rows * st.k * 4.0 * (2.0 if st.flags & 16 else 1.0)
+            fl += 4.0 * rows * st.n * st.k
+    return ('k_rowchain', 'hbm', by, fl)
+
+
 def _point_rows(rows: int, pts: int) -> float:
     """Coordinate reads + sample writes of a point-sampling call: the coordinate sets are shared by the rows that name
     them (one set per (decoder output, scan) for 100 queries), 8 B per point of a distinct set + 4 B per sample."""
@@ -171,6 +195,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
     'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
     'mbv_ms_deform_attn_bwd_value_packed': _msda_value_packed,
+    'mbv_rowchain_run': _rowchain,
     'mbv_attn_fwd': lambda a: _attn(a, False, False),
     'mbv_attn_fwd_ld': lambda a: _attn(a, False, True),
     'mbv_attn_bwd': lambda a: _attn(a, True, False),

@@ -21,7 +21,9 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_sample_select', r'k_sample_select', []),
     ('k_window_attn_bwd', r'k_window_attn_bwd', []),
     ('k_window_attn_fwd', r'k_window_attn_fwd', []),
-    ('k_msda_bwd', r'k_msda_bwd_locattn', [r'k_msda_bwd_value']),
+    ('k_msda_bwd', r'k_msda_bwd_locattn', [r'k_msda_bwd_value<', r'k_msda_bwd_valueI']),
+    ('k_msda_bwd_value_fx', r'k_msda_bwd_value_fx', []),
+    ('k_rowchain', r'k_rowchain', []),
     ('k_msda_fwd_v4', r'k_msda_fwd', []),
     ('k_add_ln_bwd', r'k_add_ln_bwd', [r'k_ln_param_reduce']),
     ('k_add_ln_fwd', r'k_add_ln_fwd', []),

@@ -56,13 +56,14 @@ def test_rowchain_forward_stages(wdt, rows, e, q):
     P.store(2, s_sum, e)
     P.store(3, y, e)
     w1c, w2c = W(w1), W(w2)
+    if wdt != torch.float32 and e % 32 == 0:          # 16-bit programs: the fragment-major operand form (row / block offsets)
+        w1c, w2c = DF.fragment_copy(w1c), DF.fragment_copy(w2c)
     ch = e                                # two K chunks of the hidden layer
     for c in range(0, f, ch):
-        P.gemm(0, 3, w1c, ch, e, bias=b1, row0=c, bias0=c, relu=True)
-        P.store(0, hid, ch, col0=c)
-        P.gemm(1, 0, w2c, e, ch, bias=b2 if c == 0 else None, col0=c, accum=c > 0)
+        P.gemm(0, 3, w1c, ch, e, bias=b1, row0=c, bias0=c, relu=True, out=hid, out_col0=c)      # stored by the epilogue
+        last = c + ch >= f
+        P.gemm(1, 0, w2c, e, ch, bias=b2 if c == 0 else None, col0=c, accum=c > 0, out=out16 if last else None)
     P.store(1, out, e)
-    P.store(1, out16, e)
     P.gemm(4, 3, W(wc), 2, e, bias=bc)
     P.store(4, cls, 2)
     P.load_slot_plus(5, 3, pos, e)
@@ -153,6 +154,53 @@ def test_rowchain_backward_stages(wdt, rows, e):
     assert float((pb[:e] - ds.to(D).sum(0)).abs().max()) < 1e-4 * float(ds.abs().sum(0).max())
     assert float((pb[e:] - dh.to(D).sum(0)).abs().max()) < 1e-4 * float(dh.abs().sum(0).max())
     assert float((acc.to(D) - (acc0.to(D) + dh.to(D) + hmask.to(D))).abs().max()) < 1e-5 * 10
+
+
+@pytest.mark.parametrize('wdt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('rows,e,f', [(400, 256, 2048), (16, 128, 1024), (90, 256, 512), (37, 160, 2048)])
+def test_rowchain_ffn_stage(wdt, rows, e, f):
+    """MBV_RC_FFN forward and backward (hidden chunks spread over the waves, partial outputs summed in an f64 LDS image)
+    against f64 on the operands as the kernel rounds them: the input and the hidden image enter their GEMMs in the weight
+    dtype; the hidden activations / their gradient leave as f32."""
+    from mask_bev_amd import decoder_fused as DF
+    dev = torch.device('cuda', 0)
+    D = torch.float64
+    x = _r((rows, e), 31)
+    w1, b1 = _r((f, e), 32, 0.1), _r((f,), 33)
+    w2, b2 = _r((e, f), 34, 0.05), _r((e,), 35)
+    hid = torch.full((rows, f), -7.0, device=dev)
+    y = torch.empty((rows, e), device=dev)
+    P = DF.Program(rows, rows, 1e-5, wdt)
+    P.load(0, x, e)
+    P.ffn(1, 0, 2, DF.fragment_copy(w1.to(wdt)), DF.fragment_copy(w2.to(wdt)), e, f, hid, bias_a=b1, bias_out=b2)
+    P.store(1, y, e)
+    P.run()
+    torch.cuda.synchronize()
+    R = lambda t: _round(t, wdt).to(D)
+    h_ref = torch.relu(R(x) @ R(w1).t() + b1.to(D))
+    assert float((hid.to(D) - h_ref).abs().max()) < 1e-4 * float(h_ref.abs().max())
+    y_ref = R(hid) @ R(w2).t() + b2.to(D)
+    assert float((y.to(D) - y_ref).abs().max()) < 2e-4 * float(y_ref.abs().max())
+    # backward: dh = (g W2) * (hid > 0), dx = dh W1, column partials of dh
+    g = _r((rows, e), 36)
+    nblk = (rows + 15) // 16
+    dh = torch.full((rows, f), -7.0, device=dev)
+    part = torch.full((nblk, f + 8), 9.0, device=dev)
+    dx = torch.empty((rows, e), device=dev)
+    # the data-gradient operands: fragment-major copies of W2^T (f, e) and W1^T (e, f) made from the row-major weights
+    w2t, w1t = DF.fragment_copy(w2.to(wdt), transposed=True), DF.fragment_copy(w1.to(wdt), transposed=True)
+    P = DF.Program(rows, rows, 1e-5, wdt)
+    P.load(0, g, e)
+    P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part, partial_col0=8)
+    P.store(1, dx, e)
+    P.run()
+    torch.cuda.synchronize()
+    dh_ref = (R(g) @ R(w2)) * (hid.to(D) > 0)
+    assert float((dh.to(D) - dh_ref).abs().max()) < 1e-4 * float(dh_ref.abs().max())
+    dx_ref = R(dh) @ R(w1)
+    assert float((dx.to(D) - dx_ref).abs().max()) < 2e-4 * float(dx_ref.abs().max())
+    assert float((part[:, 8:].to(D).sum(0) - dh.to(D).sum(0)).abs().max()) < 1e-4 * float(dh.abs().sum(0).max())
+    assert bool((part[:, :8] == 9.0).all())
 
 
 def test_rowchain_rejects_bad_programs():
