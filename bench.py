@@ -18,7 +18,9 @@ Extra objects on the line:
                 `roofline_all` lists every instrumented kernel, ranked by time per step; `traffic` is the measured HBM
                 bytes per launch from the PMC passes kept in `roofline_traffic_source` (null when not measured).
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample:
-                1 warm-up + 3 iterations, forward and forward+backward, at os.cpu_count() and at 6 threads.
+                1 warm-up + 3 iterations, forward and forward+backward, at 6 threads (the reference's setting) and at
+                min(32, os.cpu_count()) threads.
+  fp32          the same step in fp32 — the precision the reference trains in — timed the same way (20 steps).
 """
 from __future__ import annotations
 
@@ -405,8 +407,8 @@ def main():
                 # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
                 'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
         # HBM bytes per launch measured with the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
-        # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload and build: profiles/r02/pmc_hbm_traffic.json
-        traffic, traffic_file = {}, os.path.join('profiles', 'r02', 'pmc_hbm_traffic.json')
+        # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload and build: profiles/r03/pmc_hbm_traffic.json
+        traffic, traffic_file = {}, os.path.join('profiles', 'r03', 'pmc_hbm_traffic.json')
         if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
                 and args.distribution == 'lidar' and os.path.exists(os.path.join(ROOT, traffic_file))):
             with open(os.path.join(ROOT, traffic_file)) as fh:

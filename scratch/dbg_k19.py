@@ -8,14 +8,20 @@ m = MaskBevModule(**synthetic.module_kwargs('semantic_kitti_512', 4, compute_dty
 m.log_scalars = False; m.flatten_parameters()
 batch = synthetic.make_batch('semantic_kitti_512', 4, 0, 0, dev)
 raw = ctypes.CDLL(os.path.join(os.path.dirname(_lib.__file__), 'libmaskbev_hip.so'))
+names = ['LOAD', 'STORE', 'GEMM', 'LN', 'LN_BWD', 'ADD', 'COLSUM', 'FFN', 'FFN_IO']
 orig = DF.Program.run
-seen = set()
+seen = {}
 def run(self):
     orig(self)
-    if self.label in ('B.fwd', 'B.bwd') and self.label not in seen:
-        seen.add(self.label)
+    seen[self.label] = seen.get(self.label, 0) + 1
+    if seen[self.label] == 3:
         torch.cuda.synchronize()
-        b = (ctypes.c_ulonglong * 16)(); raw.mbv_rowchain_debug3(b); u = list(b)
-        print(self.label, 'FFN op (wave 0): zero %.2f | phase 1 %.2f | phase 2 %.2f | wait others %.2f us' % tuple(x / 100.0 for x in (u[1]-u[0], u[2]-u[1], u[3]-u[2], u[4]-u[3])))
+        b = (ctypes.c_ulonglong * 160)(); raw.mbv_rowchain_debug(b); t = list(b)
+        n = len(self.stages)
+        out = []; prev = t[1]; i = 0
+        while i < n:
+            op = int(t[80 + i]); out.append('%s %.1f' % (names[op], (t[2 + i] - prev) / 100.0)); prev = t[2 + i]
+            i += 2 if op == 7 else 1
+        print(self.label, 'total %.1f us:' % ((prev - t[0]) / 100.0), ' | '.join(out))
 DF.Program.run = run
 loss = m.training_step(batch, 0); loss.backward(); torch.cuda.synchronize()
