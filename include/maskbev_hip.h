@@ -202,15 +202,19 @@ int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int
  * host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
  * consecutive (batch, value) rows — e.g. straight into the first H*D columns of the 16-bit matrix
  * [d value | d offsets | d logits] whose product with [Wv; Wo; Wa] is d(x).  Every element of that block is written
- * (no zero fill needed).  `_supported` returns 1 when the shape qualifies (and MBV_MSDA_PACKED != 0).
+ * (no zero fill needed).  `_supported` returns 1 when the shape qualifies (and MBV_MSDA_PACKED != 0).  A first launch
+ * re-lays grad_out (by 4-channel group), the locations and the weights (by level) into the caller's workspace
+ * (`_workspace_bytes`), so that every block of the accumulation kernel reads contiguous streams (full cache lines).
  * Replaces the same mmcv backward as mbv_ms_deform_attn_bwd (value part). */
 int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, int32_t num_levels, int32_t num_points,
                                                   int32_t num_query, const int64_t* spatial_shapes_host);
+size_t mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(int32_t batch, int32_t num_heads, int32_t num_levels,
+                                                           int32_t num_query);
 int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const float* sampling_loc, const float* attn_weight,
                                         int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
                                         int32_t num_levels, int32_t num_query, int32_t num_points,
                                         const int64_t* spatial_shapes_host, void* grad_value, int32_t out_dtype,
-                                        int64_t out_ld, void* stream);
+                                        int64_t out_ld, void* workspace, size_t workspace_bytes, void* stream);
 
 int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start, const float* sampling_loc, const float* attn_weight,

@@ -50,7 +50,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_ms_deform_attn_bwd_split': (ctypes.c_int, [_I, _I, _P]),
     'mbv_ms_deform_attn_bwd_value_packed_supported': (ctypes.c_int, [_I, _I, _I, _I, _P]),
-    'mbv_ms_deform_attn_bwd_value_packed': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _L, _P]),
+    'mbv_ms_deform_attn_bwd_value_packed_workspace_bytes': (c_size_t, [_I, _I, _I, _I]),
+    'mbv_ms_deform_attn_bwd_value_packed': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _L, _P, c_size_t, _P]),
     'mbv_ms_deform_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I,
                                               _P]),
     'mbv_rowchain_max_stages': (ctypes.c_int, []),

@@ -752,6 +752,12 @@ struct MsdaFxArgs {
   const float* grad_out;
   const float* loc;
   const float* attn;
+  // stream-ordered copies written by k_msda_bwd_relayout (see there): what a block reads is CONTIGUOUS in them
+  const float* go_t;     // [B][H][8][Nq][4]      grad_out by 4-channel group
+  const float* loc_t;    // [B][H][L][Nq][4][2]   sampling locations by level
+  const float* attn_t;   // [B][H][L][Nq][4]      attention weights by level
+  const float* l1_part;  // [B][H][tiles][L][8]   per 64-query tile: sum of (attention mass) x (max |g| of the group)
+  int q_tiles;
   void* out;
   int64_t out_ld;        // elements between consecutive (b, n) rows of `out`
   int out_dt;            // MBV_DT_F32 / BF16 / F16
@@ -799,21 +805,11 @@ __device__ __forceinline__ void msda_value_fx_block(const MsdaFxArgs& A, int lev
   // sampling pattern, and typical inputs get 4-5 bits more than the a-priori bound num_query * max|g| would leave.
   __shared__ float red[NT / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // L1 = the sum of the relayout pass's per-tile partial sums for this (batch, head, level, 4-channel group)
+  const int grp4 = PLANES == 2 ? split : split >> 1;       // a 2-channel block uses its 4-channel group's (larger) bound
   float l1 = 0.f;
-  for (int q = threadIdx.x; q < num_query; q += NT) {
-    const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
-    const float* gp = A.grad_out + qh * dim + split * CH;
-    float m;
-    if constexpr (PLANES == 2) {
-      const float4 g = *reinterpret_cast<const float4*>(gp);
-      m = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
-    } else {
-      const float2 g = *reinterpret_cast<const float2*>(gp);
-      m = fmaxf(fabsf(g.x), fabsf(g.y));
-    }
-    const float4 a4 = *reinterpret_cast<const float4*>(A.attn + (qh * levels + level) * 4);
-    l1 += m * (fabsf(a4.x) + fabsf(a4.y) + fabsf(a4.z) + fabsf(a4.w));
-  }
+  for (int t = threadIdx.x; t < A.q_tiles; t += NT)
+    l1 += A.l1_part[((((int64_t)b * heads + hd) * A.q_tiles + t) * levels + level) * 8 + grp4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o);
   if (lane == 0) red[wave] = l1;
@@ -831,19 +827,22 @@ __device__ __forceinline__ void msda_value_fx_block(const MsdaFxArgs& A, int lev
   // was measured: 131 -> 169 us, the scattered slots collide on banks far more often than neighbours meet on a pixel.)
   // The next query's 64 bytes are requested before the current query's adds.
   float4 n_go = make_float4(0.f, 0.f, 0.f, 0.f), n_l01 = n_go, n_l23 = n_go, n_a4 = n_go;
+  // consecutive lanes read consecutive 16 / 32 / 16-byte records: full cache lines (from the original tensors a lane's
+  // 16 bytes of grad_out sit 1 KB from its neighbour's, its locations 768 B: 64 lines per load instruction, and the
+  // texture-address unit works per line — the kernel was bound by that, not by the LDS atomics)
+  const float* go_b = A.go_t + ((((int64_t)b * heads + hd) * 8 + grp4) * num_query) * 4 + (PLANES == 2 ? 0 : (split & 1) * 2);
+  const float* loc_b = A.loc_t + ((((int64_t)b * heads + hd) * levels + level) * num_query) * 8;
+  const float* attn_b = A.attn_t + ((((int64_t)b * heads + hd) * levels + level) * num_query) * 4;
   auto load_q = [&](int q, float4& go, float4& l01, float4& l23, float4& a4) {
-    const int64_t qh = ((int64_t)b * num_query + q) * heads + hd;
-    const int64_t kb = (qh * levels + level) * 4;
-    const float* gp = A.grad_out + qh * dim + split * CH;
     if constexpr (PLANES == 2) {
-      go = *reinterpret_cast<const float4*>(gp);
+      go = *reinterpret_cast<const float4*>(go_b + (int64_t)q * 4);
     } else {
-      const float2 g = *reinterpret_cast<const float2*>(gp);
+      const float2 g = *reinterpret_cast<const float2*>(go_b + (int64_t)q * 4);
       go = make_float4(g.x, g.y, 0.f, 0.f);
     }
-    l01 = *reinterpret_cast<const float4*>(A.loc + kb * 2);
-    l23 = *reinterpret_cast<const float4*>(A.loc + kb * 2 + 4);
-    a4 = *reinterpret_cast<const float4*>(A.attn + kb);
+    l01 = *reinterpret_cast<const float4*>(loc_b + (int64_t)q * 8);
+    l23 = *reinterpret_cast<const float4*>(loc_b + (int64_t)q * 8 + 4);
+    a4 = *reinterpret_cast<const float4*>(attn_b + (int64_t)q * 4);
   };
   if ((int)threadIdx.x < num_query) load_q(threadIdx.x, n_go, n_l01, n_l23, n_a4);
   for (int q = threadIdx.x; q < num_query; q += NT) {
@@ -877,6 +876,88 @@ __device__ __forceinline__ void msda_value_fx_block(const MsdaFxArgs& A, int lev
       const int hi = (int)((v - (long long)lo) >> 32);
       fx_store2<DT>(A.out, gv + (int64_t)i * A.out_ld + 2 * pl, (float)lo * inv_scale, (float)hi * inv_scale);
     }
+  }
+}
+
+// Re-layout pass of the packed value-gradient kernel: one block = (batch, head, 64 consecutive queries).  Reads the
+// block's grad_out (64 x 128 B), locations (64 x L x 32 B) and weights (64 x L x 16 B) in full lines, turns them through
+// LDS and writes them where the value kernel's blocks read CONTIGUOUS streams: grad_out by 4-channel group, locations /
+// weights by level.  It also leaves, per (batch, head, tile, level, group), the tile's share of the range bound L1.
+// num_points == 4, head_dim == 32, levels <= 8.
+__global__ void __launch_bounds__(256) k_msda_bwd_relayout(const float* __restrict__ grad_out,
+                                                           const float* __restrict__ loc, const float* __restrict__ attn,
+                                                           int num_query, int heads, int levels, int q_tiles,
+                                                           float* __restrict__ go_t, float* __restrict__ loc_t,
+                                                           float* __restrict__ attn_t, float* __restrict__ l1_part) {
+  __shared__ __attribute__((aligned(16))) float s_go[64 * 32];          // [q][32 ch]
+  __shared__ __attribute__((aligned(16))) float s_loc[64 * 8 * 8];      // [q][l][8]   (levels <= 8)
+  __shared__ __attribute__((aligned(16))) float s_at[64 * 8 * 4];       // [q][l][4]
+  __shared__ float s_sum[8 * 8];                                         // [l][group]
+  const int tile = blockIdx.x % q_tiles;
+  const int bh = blockIdx.x / q_tiles;
+  const int hd = bh % heads, b = bh / heads;
+  const int q0 = tile * 64;
+  const int tid = threadIdx.x;
+  if (tid < 64) s_sum[tid] = 0.f;
+  // grad_out: 64 queries x 8 pieces of 16 B
+  for (int p = tid; p < 64 * 8; p += 256) {
+    const int q = p >> 3, c = p & 7;
+    const int qq = q0 + q < num_query ? q0 + q : num_query - 1;
+    *reinterpret_cast<float4*>(s_go + q * 32 + c * 4) =
+        *reinterpret_cast<const float4*>(grad_out + (((int64_t)b * num_query + qq) * heads + hd) * 32 + c * 4);
+  }
+  const int lp = levels * 2;                           // 16-byte pieces of locations per (query, head): L x 4 points x 2 / 4
+  for (int p = tid; p < 64 * lp; p += 256) {
+    const int q = p / lp, c = p - q * lp;
+    const int qq = q0 + q < num_query ? q0 + q : num_query - 1;
+    *reinterpret_cast<float4*>(s_loc + q * 64 + c * 4) =
+        *reinterpret_cast<const float4*>(loc + ((((int64_t)b * num_query + qq) * heads + hd) * levels) * 8 + c * 4);
+  }
+  for (int p = tid; p < 64 * levels; p += 256) {
+    const int q = p / levels, l = p - q * levels;
+    const int qq = q0 + q < num_query ? q0 + q : num_query - 1;
+    *reinterpret_cast<float4*>(s_at + q * 32 + l * 4) =
+        *reinterpret_cast<const float4*>(attn + ((((int64_t)b * num_query + qq) * heads + hd) * levels + l) * 4);
+  }
+  __syncthreads();
+  // grad_out by group: piece (g, q)
+  for (int p = tid; p < 8 * 64; p += 256) {
+    const int g = p >> 6, q = p & 63;
+    if (q0 + q < num_query)
+      *reinterpret_cast<float4*>(go_t + ((((int64_t)b * heads + hd) * 8 + g) * num_query + q0 + q) * 4) =
+          *reinterpret_cast<const float4*>(s_go + q * 32 + g * 4);
+  }
+  for (int p = tid; p < levels * 64 * 2; p += 256) {   // locations by level: piece (l, q, half)
+    const int l = p / 128, r = p - l * 128, q = r >> 1, hf = r & 1;
+    if (q0 + q < num_query)
+      *reinterpret_cast<float4*>(loc_t + ((((int64_t)b * heads + hd) * levels + l) * num_query + q0 + q) * 8 + hf * 4) =
+          *reinterpret_cast<const float4*>(s_loc + q * 64 + l * 8 + hf * 4);
+  }
+  for (int p = tid; p < levels * 64; p += 256) {       // weights by level: piece (l, q)
+    const int l = p >> 6, q = p & 63;
+    if (q0 + q < num_query)
+      *reinterpret_cast<float4*>(attn_t + ((((int64_t)b * heads + hd) * levels + l) * num_query + q0 + q) * 4) =
+          *reinterpret_cast<const float4*>(s_at + q * 32 + l * 4);
+  }
+  // range-bound partial sums: (query, group) pairs, 64 x 8 = 512 over 256 threads; LDS f32 sums of <= 64 addends
+  for (int p = tid; p < 64 * 8; p += 256) {
+    const int q = p & 63, g = p >> 6;
+    const bool live = q0 + q < num_query;              // (no early exit: the whole wave takes part in the shuffles)
+    const float4 gv = *reinterpret_cast<const float4*>(s_go + q * 32 + g * 4);
+    const float m = fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w)));
+    for (int l = 0; l < levels; ++l) {
+      const float4 a = *reinterpret_cast<const float4*>(s_at + q * 32 + l * 4);
+      float t = live ? m * (fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w)) : 0.f;
+      // the 64 queries of a group are the 64 lanes of one wave: reduce in the wave, one LDS add per (level, group)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if ((tid & 63) == 0) s_sum[l * 8 + g] = t;       // one wave per (g): no race (p = tid + 256 * it -> g = tid / 64 + 4 it)
+    }
+  }
+  __syncthreads();
+  if (tid < levels * 8) {
+    const int l = tid >> 3, g = tid & 7;
+    l1_part[((((int64_t)b * heads + hd) * q_tiles + tile) * levels + l) * 8 + g] = s_sum[l * 8 + g];
   }
 }
 
@@ -1144,12 +1225,21 @@ extern "C" int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, i
   return 1;
 }
 
+extern "C" size_t mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(int32_t batch, int32_t num_heads, int32_t num_levels,
+                                                                      int32_t num_query) {
+  if (batch <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0) return 0;
+  const size_t bhq = (size_t)batch * num_heads * num_query, q_tiles = ((size_t)num_query + 63) / 64;
+  return mbv_align_up(bhq * 32 * 4, 256) + mbv_align_up(bhq * num_levels * 8 * 4, 256) +
+         mbv_align_up(bhq * num_levels * 4 * 4, 256) + mbv_align_up((size_t)batch * num_heads * q_tiles * num_levels * 8 * 4, 256);
+}
+
 extern "C" int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const float* sampling_loc,
                                                    const float* attn_weight, int32_t batch, int32_t num_value,
                                                    int32_t num_heads, int32_t head_dim, int32_t num_levels,
                                                    int32_t num_query, int32_t num_points,
                                                    const int64_t* spatial_shapes_host, void* grad_value,
-                                                   int32_t out_dtype, int64_t out_ld, void* stream_) {
+                                                   int32_t out_dtype, int64_t out_ld, void* workspace,
+                                                   size_t workspace_bytes, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0) return MBV_ERR_BAD_ARG;
   if (!grad_out || !sampling_loc || !attn_weight || !grad_value || !spatial_shapes_host) return MBV_ERR_BAD_ARG;
@@ -1162,7 +1252,23 @@ extern "C" int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const 
         reinterpret_cast<size_t>(attn_weight)) & 15) != 0)
     return MBV_ERR_BAD_ARG;
   if (out_dtype == MBV_DT_F32 && (out_ld % 2) != 0) return MBV_ERR_BAD_ARG;
+  if (!workspace || (reinterpret_cast<size_t>(workspace) & 15) ||
+      workspace_bytes < mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(batch, num_heads, num_levels, num_query))
+    return MBV_ERR_BAD_ARG;
   MsdaFxArgs A;
+  const int q_tiles = (num_query + 63) / 64;
+  {
+    MbvCarver cw(workspace);
+    const size_t bhq = (size_t)batch * num_heads * num_query;
+    float* go_t = cw.take<float>(bhq * 32);
+    float* loc_t = cw.take<float>(bhq * num_levels * 8);
+    float* attn_t = cw.take<float>(bhq * num_levels * 4);
+    float* l1p = cw.take<float>((size_t)batch * num_heads * q_tiles * num_levels * 8);
+    A.go_t = go_t; A.loc_t = loc_t; A.attn_t = attn_t; A.l1_part = l1p; A.q_tiles = q_tiles;
+    hipLaunchKernelGGL(k_msda_bwd_relayout, dim3((unsigned)(batch * num_heads * q_tiles)), dim3(256), 0, stream, grad_out,
+                       sampling_loc, attn_weight, num_query, num_heads, num_levels, q_tiles, go_t, loc_t, attn_t, l1p);
+    MBV_CHECK_LAUNCH();
+  }
   A.grad_out = grad_out; A.loc = sampling_loc; A.attn = attn_weight; A.out = grad_value; A.out_ld = out_ld;
   A.out_dt = out_dtype; A.levels = num_levels; A.num_value = num_value; A.num_query = num_query; A.heads = num_heads;
   A.batch = batch;

@@ -562,8 +562,9 @@ def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, ho
     if packed_out is not None:
         b, nv, nh, d, nl, nq, npnt = dims
         dst, ld = packed_out
+        ws = _workspace(lib.mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(b, nh, nl, nq), g_out.device)
         check(lib.mbv_ms_deform_attn_bwd_value_packed(_ptr(g_out), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt, host,
-                                                      _ptr(dst), _dt_flag(dst.dtype), int(ld), _stream()),
+                                                      _ptr(dst), _dt_flag(dst.dtype), int(ld), _ptr(ws), ws.numel(), _stream()),
               'mbv_ms_deform_attn_bwd_value_packed')
         check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
                                          _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(None), _ptr(g_loc),

@@ -54,6 +54,7 @@ def _msda_value_packed(a) -> Work:
     b, nv, heads, d, levels, nq, pts = (_i(a[i]) for i in (3, 4, 5, 6, 7, 8, 9))
     samples = b * nq * heads * levels * pts
     out_es = 4.0 if _i(a[12]) == 0 else 2.0
+    # (the re-layout launch reads and writes grad_out / locations / weights once more: not algorithmic)
     return ('k_msda_bwd_value_fx', 'hbm', b * nv * heads * d * out_es + b * nq * heads * d * 4.0 + samples * 12.0, 0.0)
 
 

@@ -29,6 +29,7 @@ host = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in shapes for v in hw])
 gv = torch.empty_like(value); gl = torch.empty_like(loc); ga = torch.empty_like(attn)
 G = torch.empty(B * nv, 544, dtype=torch.bfloat16, device=dev)
 P_ = ops._ptr
+WS = torch.empty(lib.mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(B, H, L, nv), dtype=torch.uint8, device=dev)
 
 def f64_value():
     ops.check(lib.mbv_ms_deform_attn_bwd(P_(go), P_(value), P_(shapes_t), P_(ls), P_(loc), P_(attn), B, nv, H, D, L, nv, P, host,
@@ -38,10 +39,10 @@ def locattn():
                                          P_(None), P_(gl), P_(ga), 2, ops._stream()), 'bwd')
 def packed():
     ops.check(lib.mbv_ms_deform_attn_bwd_value_packed(P_(go), P_(loc), P_(attn), B, nv, H, D, L, nv, P, host, P_(G), 1, 544,
-                                                      ops._stream()), 'packed')
+                                                      P_(WS), WS.numel(), ops._stream()), 'packed')
 def packed_f32():
     ops.check(lib.mbv_ms_deform_attn_bwd_value_packed(P_(go), P_(loc), P_(attn), B, nv, H, D, L, nv, P, host, P_(gv), 0, 256,
-                                                      ops._stream()), 'packed')
+                                                      P_(WS), WS.numel(), ops._stream()), 'packed')
 def cast():
     G[:, :256].copy_(gv.view(-1, 256))
 

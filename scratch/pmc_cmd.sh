@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w && mkdir -p gpurun_out/pmc_f gpurun_out/pmc_w
-ARGS="bench.py --steps 4 --warmup 2 --no-kernel-profile --no-cpu-baseline"
+ARGS="bench.py --steps 4 --warmup 2 --no-kernel-profile --no-cpu-baseline --no-fp32"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 $ARGS > gpurun_out/pmc_f/bench.json 2> gpurun_out/pmc_f/bench.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 $ARGS > gpurun_out/pmc_w/bench.json 2> gpurun_out/pmc_w/bench.err
 F=$(find gpurun_out/pmc_f -name '*counter_collection.csv' | head -1)

@@ -125,8 +125,10 @@ def _packed_case(device, B, H, shapes, ld_extra, dt, loc_mode, seed=0):
     outs = []
     for _ in range(2):
         out = torch.full((B * nv, ld), 7.0, dtype=dt, device=device)
+        ws = torch.empty(lib.mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(B, H, L, nv), dtype=torch.uint8, device=device)
         ops.check(lib.mbv_ms_deform_attn_bwd_value_packed(ops._ptr(go_d), ops._ptr(loc_d), ops._ptr(attn_d), B, nv, H, D, L,
-                                                          nv, P, host, ops._ptr(out), ops._dt_flag(dt), ld, ops._stream()),
+                                                          nv, P, host, ops._ptr(out), ops._dt_flag(dt), ld, ops._ptr(ws),
+                                                          ws.numel(), ops._stream()),
                   'mbv_ms_deform_attn_bwd_value_packed')
         outs.append(out)
     torch.cuda.synchronize()
