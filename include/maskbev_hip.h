@@ -357,22 +357,25 @@ int mbv_uniform_points(const int64_t* seed, int64_t rows, int32_t n, float* out_
  *   16-bit GEMMs read.  zero_grad=1 clears grad in the same pass.
  *   fp16 loss scaling, without a host round trip: loss_scale (device f32 scalar, nullable) is the factor the loss was
  *   multiplied by — grad is divided by it on the fly; skip_flag (device i32, nullable) non-zero = the gradient held
- *   inf / nan: parameters, moments and shadow are left as they are and only zero_grad is honoured.
+ *   inf / nan: parameters, moments and shadow are left as they are and only zero_grad is honoured.  applied_steps
+ *   (device i32, nullable): the count of updates applied so far — the bias corrections then use t = *applied_steps + 1
+ *   instead of `step` (torch.amp.GradScaler skips optimizer.step() on an overflow: Adam's count must not advance).
  * mbv_grad_nonfinite: *flag |= 1 if any of grad[0..n) is inf or nan (torch.amp.GradScaler's found_inf).
  * mbv_loss_scale_update: GradScaler.update() on the device — flag set: scale = max(scale * backoff, 1), streak = 0;
- *   else streak += 1 and scale *= growth every growth_interval clean steps; clears the flag.
+ *   else streak += 1 and scale *= growth every growth_interval clean steps (and ++*applied_steps, nullable); clears
+ *   the flag.
  * mbv_refresh_shadow: shadow[i] = bf16 / half (param[i]) (after load_state_dict / broadcast).
  * mbv_colsum_accum: out[c] += sum_r g[r, c] for row-major g (rows, n), bf16 (is_bf16=1) or f32; f32 atomics.
  */
 int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int32_t shadow_dtype,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    float grad_scale, int32_t decoupled, int32_t zero_grad, const float* loss_scale,
-                   const int32_t* skip_flag, void* stream);
+                   const int32_t* skip_flag, const int32_t* applied_steps, void* stream);
 
 int mbv_grad_nonfinite(const float* grad, int64_t n, int32_t* flag, void* stream);
 
 int mbv_loss_scale_update(float* loss_scale, int32_t* clean_steps, int32_t* flag, float growth, float backoff,
-                          int32_t growth_interval, void* stream);
+                          int32_t growth_interval, int32_t* applied_steps, void* stream);
 
 int mbv_refresh_shadow(const float* param, void* shadow_bf16, int32_t shadow_dtype, int64_t n, void* stream);
 

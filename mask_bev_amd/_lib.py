@@ -68,9 +68,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_hungarian_padded': (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P]),
     'mbv_hungarian_wide_t': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
     'mbv_select_uncertain_points': (ctypes.c_int, [_P, _P, _L, _I, _I, _P, _P]),
-    'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P, _P, _P]),
+    'mbv_adamw_step': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _L, _F, _I, _I, _P, _P, _P, _P]),
     'mbv_grad_nonfinite': (ctypes.c_int, [_P, _L, _P, _P]),
-    'mbv_loss_scale_update': (ctypes.c_int, [_P, _P, _P, _F, _F, _I, _P]),
+    'mbv_loss_scale_update': (ctypes.c_int, [_P, _P, _P, _F, _F, _I, _P, _P]),
     'mbv_refresh_shadow': (ctypes.c_int, [_P, _P, _I, _L, _P]),
     'mbv_colsum_accum': (ctypes.c_int, [_P, _I, _L, _I, _P, _P]),
     'mbv_act_bwd_colsum': (ctypes.c_int, [_P, _P, _I, _I, _L, _I, _P, _P, _P]),

@@ -149,6 +149,8 @@ class LossScaler:
         self.scale = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.clean_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # updates actually APPLIED (an overflowed step is skipped): Adam's bias-correction count, read by k_adamw
+        self.applied_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
         self.growth_interval = int(growth_interval)
 
@@ -165,6 +167,7 @@ class LossScaler:
         lib = _lib.load()
         check(lib.mbv_loss_scale_update(self.scale.data_ptr(), self.clean_steps.data_ptr(), self.flag.data_ptr(),
                                         self.growth_factor, self.backoff_factor, self.growth_interval,
+                                        self.applied_steps.data_ptr(),
                                         torch.cuda.current_stream(self.device).cuda_stream), 'mbv_loss_scale_update')
 
     def get_scale(self) -> float:
@@ -172,12 +175,15 @@ class LossScaler:
 
     def state_dict(self):
         return dict(scale=self.get_scale(), clean_steps=int(self.clean_steps.item()),
+                    applied_steps=int(self.applied_steps.item()),
                     growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
                     growth_interval=self.growth_interval)
 
     def load_state_dict(self, sd):
         self.scale.fill_(float(sd['scale']))
         self.clean_steps.fill_(int(sd.get('clean_steps', 0)))
+        if 'applied_steps' in sd:
+            self.applied_steps.fill_(int(sd['applied_steps']))
         self.growth_factor = float(sd.get('growth_factor', self.growth_factor))
         self.backoff_factor = float(sd.get('backoff_factor', self.backoff_factor))
         self.growth_interval = int(sd.get('growth_interval', self.growth_interval))
@@ -191,7 +197,10 @@ class FlatAdam(torch.optim.Optimizer):
     Adjacent groups with identical hyper-parameters are fused into one launch.  ``step()`` also refreshes the 16-bit
     shadow and clears the gradient in the same pass (``zero_grad=True``).  With a :class:`LossScaler` (fp16 compute) the
     gradient is checked for inf / nan first, un-scaled inside the update kernel, and an overflowed step leaves
-    parameters and moments untouched (the bias-correction count still advances: it is a host integer)."""
+    parameters and moments untouched, and Adam's bias-correction count does not advance either: with a scaler the count
+    of APPLIED updates lives on the device (``LossScaler.applied_steps``, incremented by ``mbv_loss_scale_update``), as
+    ``torch.amp.GradScaler`` skipping ``optimizer.step()`` would leave torch's.  ``state_dict()['flat_state']['steps']``
+    is that count."""
 
     def __init__(self, arena: ParameterArena, groups: List[dict], lr: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 1e-2, decoupled: bool = True, zero_grad: bool = True,
@@ -255,7 +264,8 @@ class FlatAdam(torch.optim.Optimizer):
                                          float(self.grad_scale), 1 if self.decoupled else 0,
                                          1 if self.zero_grad_in_step else 0,
                                          0 if sc is None else sc.scale.data_ptr(),
-                                         0 if sc is None else sc.flag.data_ptr(), stream),
+                                         0 if sc is None else sc.flag.data_ptr(),
+                                         0 if sc is None else sc.applied_steps.data_ptr(), stream),
                       'mbv_adamw_step')
         if sc is not None:
             sc.update()
@@ -268,7 +278,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        sd['flat_state'] = dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, steps=self.steps)
+        steps = self.steps if self.scaler is None else int(self.scaler.applied_steps.item())
+        sd['flat_state'] = dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, steps=steps)
         if self.scaler is not None:
             sd['loss_scaler'] = self.scaler.state_dict()
         return sd
@@ -281,6 +292,8 @@ class FlatAdam(torch.optim.Optimizer):
             self.exp_avg.copy_(flat['exp_avg'])
             self.exp_avg_sq.copy_(flat['exp_avg_sq'])
             self.steps = int(flat['steps'])
+            if self.scaler is not None:
+                self.scaler.applied_steps.fill_(self.steps)
         elif sd.get('state'):
             # a torch.optim.Adam / AdamW state_dict (the reference's checkpoints, or a run saved without the arena):
             # its parameters are numbered in module.parameters() order = the order of the arena layout
@@ -300,6 +313,8 @@ class FlatAdam(torch.optim.Optimizer):
                     self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
                     steps = max(steps, int(st['step']))
             self.steps = steps
+            if self.scaler is not None:
+                self.scaler.applied_steps.fill_(steps)
         for pg, saved in zip(self.param_groups, sd.get('param_groups', [])):
             for k in ('lr', 'betas', 'eps', 'weight_decay'):
                 if k in saved:

@@ -19,6 +19,9 @@ struct AdamArgs {
   int shadow_kind;                 // MBV_DT_BF16 / MBV_DT_F16: storage of the weight shadow
   const float* loss_scale;         // device scalar (nullable): gradients arrive multiplied by it (fp16 loss scaling)
   const int* skip;                 // device flag (nullable): non-zero = the gradient held inf / nan, skip the update
+  const int* applied;              // device count of updates APPLIED so far (nullable): the bias corrections then use
+                                   //   t = *applied + 1 — torch.amp.GradScaler skips optimizer.step() on an overflow, so
+                                   //   Adam's step count must not advance there (a host count would)
 };
 
 __device__ __forceinline__ unsigned short shadow_bits(float p, int kind) {
@@ -53,6 +56,11 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float*
       if (t < n) grad[t] = 0.f;
     }
     return;
+  }
+  if (a.applied) {                 // bias corrections from the device-side count of applied updates
+    const double t = (double)(*a.applied + 1);
+    a.bias_correction1 = (float)(1.0 - pow((double)a.beta1, t));
+    a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 p = reinterpret_cast<float4*>(param)[i];
@@ -111,15 +119,18 @@ __global__ void __launch_bounds__(256) k_grad_nonfinite(const float* __restrict_
 // GradScaler.update(): overflow -> scale *= backoff, streak = 0; else streak += 1 and every `interval` clean steps
 // scale *= growth.  Clears the flag for the next step.
 __global__ void k_loss_scale_update(float* __restrict__ scale, int* __restrict__ streak, int* __restrict__ flag,
-                                    float growth, float backoff, int interval) {
+                                    float growth, float backoff, int interval, int* __restrict__ applied) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (*flag) {
     *scale = fmaxf(*scale * backoff, 1.f);
     *streak = 0;
-  } else if (++*streak >= interval) {
-    const float s = *scale * growth;
-    if (s <= 3.0e38f && s == s) *scale = s;
-    *streak = 0;
+  } else {
+    if (applied) ++*applied;       // this step's update was applied: Adam's step count advances
+    if (++*streak >= interval) {
+      const float s = *scale * growth;
+      if (s <= 3.0e38f && s == s) *scale = s;
+      *streak = 0;
+    }
   }
   *flag = 0;
 }
@@ -430,7 +441,8 @@ __global__ void __launch_bounds__(256) k_wgrad_small_group(const WgradGroupArgs 
 extern "C" int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                               int32_t shadow_dtype, int64_t n, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int64_t step, float grad_scale, int32_t decoupled, int32_t zero_grad,
-                              const float* loss_scale, const int32_t* skip_flag, void* stream) {
+                              const float* loss_scale, const int32_t* skip_flag, const int32_t* applied_steps,
+                              void* stream) {
   if (n < 0 || step < 1 || !param || !grad || !exp_avg || !exp_avg_sq) return MBV_ERR_BAD_ARG;
   if (n == 0) return MBV_OK;
   if ((reinterpret_cast<size_t>(param) | reinterpret_cast<size_t>(grad) | reinterpret_cast<size_t>(exp_avg) |
@@ -439,7 +451,7 @@ extern "C" int mbv_adamw_step(float* param, float* grad, float* exp_avg, float* 
   if (shadow_bf16 && (reinterpret_cast<size_t>(shadow_bf16) & 7)) return MBV_ERR_BAD_ARG;
   if (shadow_bf16 && shadow_dtype != MBV_DT_BF16 && shadow_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   AdamArgs a;
-  a.shadow_kind = shadow_dtype; a.loss_scale = loss_scale; a.skip = skip_flag;
+  a.shadow_kind = shadow_dtype; a.loss_scale = loss_scale; a.skip = skip_flag; a.applied = applied_steps;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
   a.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -466,11 +478,11 @@ extern "C" int mbv_grad_nonfinite(const float* grad, int64_t n, int32_t* flag, v
 }
 
 extern "C" int mbv_loss_scale_update(float* loss_scale, int32_t* clean_steps, int32_t* flag, float growth, float backoff,
-                                     int32_t growth_interval, void* stream) {
+                                     int32_t growth_interval, int32_t* applied_steps, void* stream) {
   if (!loss_scale || !clean_steps || !flag || growth < 1.f || backoff <= 0.f || backoff > 1.f || growth_interval < 1)
     return MBV_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_loss_scale_update, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_scale, clean_steps, flag,
-                     growth, backoff, growth_interval);
+                     growth, backoff, growth_interval, applied_steps);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

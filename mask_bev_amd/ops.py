@@ -1049,7 +1049,9 @@ def _pending_lists():
             torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred_grads(tid))
         except RuntimeError:
             return None
-        for old in [t for t in _PENDING if t < tid - 16]:       # leftovers of passes that never completed
+        # leftovers of passes that raised before their callback ran hold (g, x) activations alive: passes nest at most
+        # two deep here (the deferred heads' re-evaluation inside the step's backward), so anything four ids back is dead
+        for old in [t for t in _PENDING if t < tid - 4]:
             del _PENDING[old]
         lists = _PENDING[tid] = ([], [], [])
     return lists
@@ -1178,6 +1180,9 @@ def flush_deferred_grads(task_id: Optional[int] = None) -> None:
     """Issue the parameter-gradient work collected by backward pass ``task_id`` (default: by every pass that has some
     pending — callable directly; a no-op when nothing is pending)."""
     tids = [task_id] if task_id is not None else list(_PENDING)
+    if task_id is not None:          # passes nested INSIDE this one have ended: what they left (they raised) is dropped
+        for t in [t for t in _PENDING if t > task_id]:
+            del _PENDING[t]
     wg, cs, tn = [], [], []
     for t in tids:
         lists = _PENDING.pop(t, None)

@@ -51,12 +51,11 @@ def test_flat_adam_fp16_shadow_and_device_loss_scaler(device):
             assert torch.equal(arena.param, before) and torch.equal(opt.exp_avg, m_before)
             scale, streak = max(scale * 0.5, 1.0), 0
         else:
-            # torch's reference step; FlatAdam counts skipped steps in its bias correction (a host integer), so the
-            # reference is given the same count
-            for st in topt.state.values():
-                st['step'] = torch.as_tensor(float(opt.steps - 1))
+            # torch's reference step, untouched: a skipped step does not advance Adam's count in either (the device-side
+            # count of applied updates, LossScaler.applied_steps, drives k_adamw's bias corrections)
             topt.step()
             applied += 1
+            assert int(scaler.applied_steps.item()) == applied
             streak += 1
             if streak == 3:
                 scale, streak = scale * 2.0, 0
@@ -69,6 +68,7 @@ def test_flat_adam_fp16_shadow_and_device_loss_scaler(device):
     assert applied == 7
     sd = opt.state_dict()
     assert sd['loss_scaler']['scale'] == scale
+    assert sd['flat_state']['steps'] == 7 and sd['loss_scaler']['applied_steps'] == 7      # not the 9 calls
 
 
 def test_graphed_fp16_step_tracks_eager(device):
