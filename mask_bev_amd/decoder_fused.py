@@ -403,6 +403,7 @@ class _DecA(torch.autograd.Function):
         P.run()
         o2, lse = _self_attention_fwd(qkv[0], qkv[1], qkv[2], lc.b, lc.q, lc.h)
         ctx.lc = lc
+        ctx.set_materialize_grads(False)
         ctx.params = (wo, bo, g1, b1, w_in, b_in)
         ctx.save_for_backward(o1, sum1, stats1, x1, t1, qkv, o2, lse)
         return x1, o2
@@ -416,6 +417,10 @@ class _DecA(torch.autograd.Function):
         wo, bo, g1, b1, w_in, b_in = ctx.params
         dev = o1.device
         f32 = dict(dtype=torch.float32, device=dev)
+        if g_x1 is None:
+            g_x1 = torch.zeros((m, e), **f32)
+        if g_o2 is None:
+            g_o2 = torch.zeros((m, e), **f32)
         # K6 self-attention backward
         g_o2 = g_o2.reshape(m, e).to(torch.float32).contiguous()
         g_qkv = torch.empty((3, m, e), **f32)
@@ -553,6 +558,9 @@ class _DecB(torch.autograd.Function):
                                       lc.h, e // lc.h, ops._ptr(o1n), ops._ptr(lse), ops._ptr(ws), ws.numel(),
                                       ops._stream()), 'mbv_attn_fwd_ld')
         ctx.lc, ctx.nxt = lc, nxt
+        # no zero tensors for the outputs that carry no gradient (class scores, mask logits, the attention mask): autograd
+        # would otherwise MATERIALISE them for backward() — a 26 MB fill and a 1.6 MB bool fill per layer
+        ctx.set_materialize_grads(False)
         ctx.params = (wo, bo, g2, b2, w1, bb1, w2, bb2, g3, b3, nw_in, nb_in)
         ctx.save_for_backward(o2, sum2, stats2, x2, hid, sum3, stats3, t3, qc, mask, o1n, lse)
         cls3 = cls.view(b, q, ncls)
@@ -595,6 +603,8 @@ class _DecB(torch.autograd.Function):
                                       ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ldk, bf, ops._stream()),
                   'mbv_attn_bwd_ld')
             holder.written.add(nxt.slot)
+        if g_x3 is None:                  # (this layer's output fed nothing that needed a gradient)
+            g_x3 = torch.zeros((m, e), **f32)
         g_x3 = g_x3.reshape(m, e).to(torch.float32).contiguous()
         part_b = torch.empty((nblk, 3 * e + f), **f32)          # [bq' | b2 | bo | b1 (f)]
         part_ln3, part_ln2 = torch.empty((nblk, 2 * e), **f32), torch.empty((nblk, 2 * e), **f32)

@@ -12,6 +12,8 @@
 #include "bilinear.hpp"
 
 namespace {
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_now = wall_clock64(); atomicAdd(&g_stamps[i], t_now - t_prev); t_prev = t_now; } } while (0)
 
 constexpr int kBins = 2048;
 constexpr int kThreads = 512;
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hw = H * W;
-  // [stamps begin]
+  unsigned long long t_prev = wall_clock64();
   const float* s = src + (int64_t)src_index[row] * hw;
   if ((hw & 3) == 0) {
     // every 16-byte load of the map is issued before the first LDS store (one memory round trip, not four)
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     for (int i = tid; i < hw; i += kFusedThreads) tile[i] = s[i];
   }
   __syncthreads();
-  // [phase 0 map staged]
+  STAMP(0);
   const float* cr = RNG ? nullptr : coords + row * (int64_t)n * 2;
   const uint32_t stream = RNG ? row_stream(seed[0], row) : 0u;
   uint32_t keys[kKeysPerThread];
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // [phase 1 sampled]
+  STAMP(1);
   // -- radix select of the k-th smallest key (11 + 11 + 10 bits), keys in registers
   uint32_t prefix = 0, prefix_mask = 0;
   int krem = k;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
       if ((keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
     }
     __syncthreads();
-    // [phase 2 histogram]
+    STAMP(2);
     // cumulative search: thread t owns bins 4t … 4t + 3; wave totals through LDS (cnt_lt doubles as scratch)
     constexpr int PERB = kBins / kFusedThreads;
     int hb[PERB], hsum = 0;
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     prefix = s_prefix;
     krem = s_krem;
     prefix_mask |= (uint32_t)(nb - 1) << shift;
-    // [phase 3 bin search]
+    STAMP(3);
   }
   // -- compaction in index order: element (chunk j, thread t) has index j * kFusedThreads + t
   const uint32_t T = prefix;
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   }
   __syncthreads();
   float* orow = out_coords + row * (int64_t)(k + n_rand) * 2;
-  // [phase 4 positions]
+  STAMP(4);
   // The coordinates are produced a second time here (regenerated / re-read).  Hide that from the compiler: it
   // recognises the repeated pure computation and would otherwise keep all 80 coordinate values of the sampling
   // phase alive for reuse — 198 spilled VGPRs.
@@ -342,13 +344,13 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
       if (pos[u] >= 0) *reinterpret_cast<float2*>(orow + (int64_t)pos[u] * 2) = xy[u];
     __builtin_amdgcn_sched_barrier(0);
   }
-  // [phase 5 compaction]
+  STAMP(5);
   if (n_rand > 0) {
     const float2* rr = reinterpret_cast<const float2*>(rand_coords + row * (int64_t)n_rand * 2);
     float2* ot = reinterpret_cast<float2*>(orow + (int64_t)k * 2);
     for (int i = tid; i < n_rand; i += kFusedThreads) ot[i] = rr[i];
   }
-  // [phase 6 tail]
+  STAMP(6);
 }
 
 }  // namespace
@@ -394,4 +396,10 @@ extern "C" int mbv_uniform_points(const int64_t* seed, int64_t rows, int32_t n, 
                      rows, n, out_coords);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
+}
+
+extern "C" int k10_read_stamps(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+  return 0;
 }

@@ -22,7 +22,8 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_window_attn_bwd', r'k_window_attn_bwd', []),
     ('k_window_attn_fwd', r'k_window_attn_fwd', []),
     ('k_msda_bwd', r'k_msda_bwd_locattn', [r'k_msda_bwd_value<', r'k_msda_bwd_valueI']),
-    ('k_msda_bwd_value_fx', r'k_msda_bwd_value_fx', []),
+    ('k_msda_bwd_locattn', r'k_msda_bwd_locattn', []),
+    ('k_msda_bwd_value_fx', r'k_msda_bwd_value_fx', [r'k_msda_bwd_relayout']),
     ('k_rowchain', r'k_rowchain', []),
     ('k_msda_fwd_v4', r'k_msda_fwd', []),
     ('k_add_ln_bwd', r'k_add_ln_bwd', [r'k_ln_param_reduce']),
@@ -39,7 +40,7 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_point_sample_packed', r'k_point_sample_packed', []),
     ('k_mask_loss_rows_fwd', r'k_mask_loss_rows_fwd', []),
     ('k_mask_loss_rows_bwd', r'k_mask_loss_rows_bwd', []),
-    ('k_match_cost_terms', r'k_match_cost_terms', []),
+    ('k_match_cost_terms', r'k_match_terms', []),
     ('k_act_bwd_colsum', r'k_act_bwd_colsum', []),
     ('k_colsum', r'k_colsum<', []),
     ('k_ln_apply', r'k_ln_apply', []),

@@ -316,3 +316,27 @@ def test_workmodel_add_layernorm_bwd2_known_answer():
     k, bound, by, fl = W.MODELS['mbv_add_layernorm_bwd2'](args)
     assert (k, bound, fl) == ('k_add_ln_bwd', 'hbm', 0.0)
     assert by == 21504 * 256 * (4 + 2 + 0 + 4 + 4 + 2)
+
+
+def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
+    """Self-check of the measurement: in the committed bench line of this round every HBM-bound
+    family's PMC traffic per launch is at least 0.9 x the algorithmic bytes the work model charges — a model that
+    exceeds the measured traffic (round 2: shared ground-truth maps charged once per row) inflates `roofline.frac`.
+    The line also carries the contract's objects."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', '*bench_default.json')))
+    assert files, 'no committed bench line under profiles/r03'
+    line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['roofline']['bound'] in ('hbm', 'mfma') and 0 < line['roofline']['frac'] < 1
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] >= 1
+    checked = 0
+    for r in line['roofline_all']:
+        if r['bound'] != 'hbm' or not r.get('traffic'):
+            continue
+        assert r['traffic'] >= 0.9 * r['algorithmic_bytes'], (r['kernel'], r['traffic'], r['algorithmic_bytes'])
+        checked += 1
+    assert checked >= 20

@@ -221,6 +221,34 @@ def test_rowchain_rejects_bad_programs():
         DF.Program(16, 16, 1e-5, torch.bfloat16).gemm(1, 0, w, 64, 64)     # weight dtype != program dtype
 
 
+def _fragment_layout(w):
+    """dst[((t * KBN + kb) * 64 + lane) * 8 + j] = W[t * 16 + lane % 16][kb * 32 + 8 * (lane // 16) + j] (zero rows beyond W)."""
+    rows, cols = w.shape
+    tn, kbn = (rows + 15) // 16, cols // 32
+    pad = torch.zeros((tn * 16, cols), dtype=w.dtype, device=w.device)
+    pad[:rows] = w
+    # (t, m, kb, g, j) -> (t, kb, g, m, j): lane = g * 16 + m
+    return pad.view(tn, 16, kbn, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
+@pytest.mark.parametrize('shape', [(256, 256), (2048, 256), (256, 2048), (10, 64), (70, 96), (3, 32), (129, 160)])
+def test_fragment_group_layout(shape):
+    """Both orientations of the fragment-major copies, incl. matrices that are not whole 64 x 64 tiles, unaligned row
+    pitches and sub-matrix views (the scalar-load path of the kernel)."""
+    from mask_bev_amd import decoder_fused as DF
+    r, c = shape
+    w = _r((r, c), 5).to(torch.bfloat16)
+    assert torch.equal(DF.fragment_copy(w).t, _fragment_layout(w))
+    wt = _r((c, r), 6).to(torch.bfloat16)                      # logical W = wt^T
+    assert torch.equal(DF.fragment_copy(wt, transposed=True).t, _fragment_layout(wt.t().contiguous()))
+    big = _r((r + 3, c + 5), 7).to(torch.bfloat16)             # a view with an odd pitch and an odd start
+    v = big[1:1 + r, 3:3 + c]
+    assert torch.equal(DF.fragment_copy(v).t, _fragment_layout(v.contiguous()))
+    bigt = _r((c + 1, r + 7), 8).to(torch.bfloat16)
+    vt = bigt[1:1 + c, 5:5 + r]
+    assert torch.equal(DF.fragment_copy(vt, transposed=True).t, _fragment_layout(vt.t().contiguous()))
+
+
 def test_transpose_group():
     import ctypes
     from mask_bev_amd import _lib, ops
