@@ -330,7 +330,7 @@ int mbv_select_uncertain_points(const float* logits, const float* coords, int64_
 /* Fused K8 + K10: sample the n candidate points of each row from its source map and keep the k most uncertain,
  * without materialising the (rows, n) sampled logits (the whole of get_uncertain_point_coords_with_randomness,
  * mask2former_head.py:401-404).  src (N, H, W) f32 with H*W <= 16384; src_index (rows) i32 → source map of a row;
- * n <= 40960 candidates per row, given EITHER as coords (rows, n, 2) f32 in [0, 1] (seed NULL) OR generated in the
+ * n <= 40960 candidates per row, k <= 16384 of them kept, given EITHER as coords (rows, n, 2) f32 in [0, 1] (seed NULL) OR generated in the
  * kernel from the device-resident 64-bit *seed (coords NULL): point p of row r is mbv_uniform_points' value, so
  * the 1.2 GB candidate tensor of a training step is never written or read.  rand_coords (rows, n_rand, 2) f32
  * (nullable when n_rand == 0): the uniform tail, copied behind the selected points; out_coords

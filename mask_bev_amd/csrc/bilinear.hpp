@@ -37,7 +37,8 @@ __device__ __forceinline__ void bil_setup_clamped(float px, float py, int H, int
   const float lx = x - xf, ly = y - yf;
   const float wx0 = x0 >= 0 ? 1.f - lx : 0.f, wx1 = x0 + 1 < W ? lx : 0.f;
   const float wy0 = y0 >= 0 ? 1.f - ly : 0.f, wy1 = y0 + 1 < H ? ly : 0.f;
-  const int xa = max(x0, 0), xb = min(x0 + 1, W - 1), ya = max(y0, 0) * W, yb = min(y0 + 1, H - 1) * W;
+  // (24-bit multiplies: full rate, v_mul_lo_u32 is a quarter; the tile is at most 16 384 pixels)
+  const int xa = max(x0, 0), xb = min(x0 + 1, W - 1), ya = __mul24(max(y0, 0), W), yb = __mul24(min(y0 + 1, H - 1), W);
   b.w[0] = wy0 * wx0; b.w[1] = wy0 * wx1; b.w[2] = wy1 * wx0; b.w[3] = wy1 * wx1;
   b.o[0] = ya + xa; b.o[1] = ya + xb; b.o[2] = yb + xa; b.o[3] = yb + xb;
 }

@@ -119,10 +119,12 @@ __global__ void __launch_bounds__(kThreads) k_select_smallest_abs(const float* _
 // Fused form: sample the n candidate points of a row from its (H, W) logit map AND select the k most uncertain, in
 // one workgroup per row — the (rows, n) over-sampled logits (600 MB per step at 10 x B x Q rows, n = 37 632)
 // never exist in HBM.  The map sits in a 64 KB LDS tile (K8's layout), every thread keeps the |logit| keys of its
-// n / 1024 points in registers, the 3-pass radix select histograms them from there, and the compaction (same
-// order and tie rule as above) places a point from per-(chunk, wave) ballot counts, so the only barriers left are
-// the four of the select.  The uniform tail of the reference's sampling (rand_coords) is copied behind the
-// selected points, which removes the torch.cat of the two coordinate sets as well.
+// n / 1024 points in registers, a 3-pass radix select (11 + 10 + 10 bits) histograms them from there, and the
+// compaction (same order and tie rule as above) writes each selected candidate's INDEX to its output position in
+// LDS from per-(chunk, wave) ballot counts; a dense last pass turns the k indices into coordinates.  The uniform
+// tail of the reference's sampling (rand_coords) is copied behind the selected points, which removes the torch.cat
+// of the two coordinate sets as well.  The kernel is VALU-bound (5 400 VALU issue slots per thread, 55 % of them the
+// generator + bilinear set-up of the sampling loop); 64 VGPRs so that two workgroups share a CU.
 constexpr int kFusedThreads = 1024;
 constexpr int kKeysPerThread = 40;                       // n <= 40 960
 constexpr int kFusedWaves = kFusedThreads / 64;
@@ -153,14 +155,13 @@ __global__ void __launch_bounds__(256) k_uniform_points(const int64_t* __restric
 }
 
 template <bool RNG>
-__global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __restrict__ src,
+__global__ void __launch_bounds__(kFusedThreads, RNG ? 8 : 4) k_sample_select(const float* __restrict__ src,
                                                                  const int32_t* __restrict__ src_index,
                                                                  const float* __restrict__ coords,
                                                                  const int64_t* __restrict__ seed, int n, int k, int H,
                                                                  int W, const float* __restrict__ rand_coords,
                                                                  int n_rand, float* __restrict__ out_coords) {
   __shared__ __attribute__((aligned(16))) float tile[16384];
-  __shared__ int hist[kBins];
   __shared__ int cnt_lt[kKeysPerThread * kFusedWaves + 1], cnt_eq[kKeysPerThread * kFusedWaves + 1];
   __shared__ uint32_t s_prefix;
   __shared__ int s_krem;
@@ -196,15 +197,17 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   // batches of BATCH points: their coordinate loads are issued together (one HBM round trip per batch, not per
   // point); a scheduling barrier after every batch keeps the compiler from hoisting later batches' loads over the
   // 40 live key registers (it spilled 197 VGPRs without it)
-  constexpr int BATCH = RNG ? 2 : 8;
+  constexpr int BATCH = RNG ? 2 : 4;
 #pragma unroll
   for (int jb = 0; jb < kKeysPerThread; jb += BATCH) {
     float2 xy[BATCH];
+    const float* crb = cr;
+    if constexpr (!RNG) asm volatile("" : "+s"(crb));      // (an opaque copy per batch: the 40 loads were hoisted to the top — 283 spills)
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const int p = (jb + u) * kFusedThreads + tid;
       if constexpr (RNG) xy[u] = uniform_point(stream, p);
-      else xy[u] = p < n ? *reinterpret_cast<const float2*>(cr + (int64_t)p * 2) : make_float2(0.f, 0.f);
+      else xy[u] = *reinterpret_cast<const float2*>(crb + (int64_t)min(p, n - 1) * 2);   // clamped, not predicated (slots >= n get the sentinel key)
     }
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
@@ -220,32 +223,56 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
     __builtin_amdgcn_sched_barrier(0);
   }
   // [phase 1 sampled]
-  // -- radix select of the k-th smallest key (11 + 11 + 10 bits), keys in registers
+  // [wavephase 16 sampled]
+  // -- radix select of the k-th smallest key (11 + 10 + 10 bits below the sign bit, which |x| never sets), keys in registers.
+  // The histogram lives in the map's tile, dead by now, as FOUR replicas (lane % 4) of 2048 64-BIT counters: on gfx950
+  // a 32-bit LDS atomic costs ~200 clocks per wave instruction whatever the addresses (measured: 120 of them per
+  // thread were 169 us of a row's 203, the same on clustered and on spread keys), ds_add_u64 ~10.  A replica's bins
+  // are XOR-permuted by its number so that equal bins of different replicas sit in different banks.
+  __syncthreads();                                        // every wave is done sampling from the tile
+  // (opaque redefinition: keeps the histogram addresses of the first pass — 40 more live values — from being
+  // computed up in the sampling loop, where they spilled 229 VGPRs)
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) asm volatile("" : "+v"(keys[j]));
+  unsigned long long* rep = reinterpret_cast<unsigned long long*>(tile);
+  const uint32_t rep_key = (uint32_t)(lane & 3) * (2048u * 8u) + (((uint32_t)(lane & 3) * 8u) << 3);   // byte offset ^ rotation
+  char* rep_bytes = reinterpret_cast<char*>(tile);
   uint32_t prefix = 0, prefix_mask = 0;
   int krem = k;
-  const int shifts[3] = {21, 10, 0};
-  const int widths[3] = {11, 11, 10};
+  const int shifts[3] = {20, 10, 0};
+  const int widths[3] = {11, 10, 10};
   for (int pass = 0; pass < 3; ++pass) {
     const int shift = shifts[pass], nb = 1 << widths[pass];
-    for (int i = tid; i < kBins; i += kFusedThreads) hist[i] = 0;
+    {
+      float4* z = reinterpret_cast<float4*>(tile);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[tid + u * kFusedThreads] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
+    // [phase 10+pass zeroed]
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
       // slots beyond n hold the largest key (0xffffffff): counted in the top bin, they never reach the k-th smallest
       // (k <= n), so no validity test — and no 40 live lane masks — is needed from here on
-      if ((keys[j] & prefix_mask) == prefix) atomicAdd(&hist[(keys[j] >> shift) & (nb - 1)], 1);
+      const uint32_t bin = (keys[j] >> shift) & (uint32_t)(nb - 1);
+      if ((keys[j] & prefix_mask) == prefix)
+        atomicAdd(reinterpret_cast<unsigned long long*>(rep_bytes + ((bin << 3) ^ rep_key)), 1ull);
     }
     __syncthreads();
-    // [phase 2 histogram]
-    // cumulative search: thread t owns bins 4t … 4t + 3; wave totals through LDS (cnt_lt doubles as scratch)
-    constexpr int PERB = kBins / kFusedThreads;
-    int hb[PERB], hsum = 0;
+    // [phase 7+pass histogram]
+    // cumulative search: thread t owns bins 2t and 2t + 1 (adjacent in every replica: the permutation keeps bit 0);
+    // wave totals through LDS
+    constexpr int PERB = 2;
+    int hb[PERB] = {0, 0}, hsum = 0;
+    if (tid * PERB < nb) {
 #pragma unroll
-    for (int q = 0; q < PERB; ++q) {
-      const int bin = tid * PERB + q;
-      hb[q] = bin < nb ? hist[bin] : 0;
-      hsum += hb[q];
+      for (int r = 0; r < 4; ++r) {
+        const uint4 v = *reinterpret_cast<const uint4*>(rep + r * 2048 + ((tid * PERB) ^ (r * 8)));
+        hb[0] += (int)v.x;                                // (counts < 2^31: the low words)
+        hb[1] += (int)v.z;
+      }
     }
+    hsum = hb[0] + hb[1];
     int inc = hsum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -312,35 +339,31 @@ __global__ void __launch_bounds__(kFusedThreads) k_sample_select(const float* __
   __syncthreads();
   float* orow = out_coords + row * (int64_t)(k + n_rand) * 2;
   // [phase 4 positions]
-  // The coordinates are produced a second time here (regenerated / re-read).  Hide that from the compiler: it
-  // recognises the repeated pure computation and would otherwise keep all 80 coordinate values of the sampling
-  // phase alive for reuse — 198 spilled VGPRs.
+  // Two steps.  (1) every candidate that is selected writes its INDEX to its output position, in LDS (the tile again:
+  // the histogram is dead).  (2) the k selected indices are turned into coordinates — regenerated from the counter, or
+  // read from the candidate list — by threads that are all busy, and stored with consecutive addresses.  Producing
+  // the coordinates inside step 1 (the first version) ran the generator for all 40 slots of a thread to keep the one
+  // in four that is selected: 1 700 VALU instructions per thread of a kernel that is VALU-bound.
 #pragma unroll
-  for (int j = 0; j < kKeysPerThread; ++j) asm volatile("" : "+v"(keys[j]));   // same reason: the ballots below
-  uint32_t stream2 = stream;
-  const float* cr2 = cr;
-  asm volatile("" : "+s"(stream2));
-  asm volatile("" : "+s"(cr2));
+  for (int j = 0; j < kKeysPerThread; ++j) asm volatile("" : "+v"(keys[j]));   // (no reuse of the count loop's 80 masks)
+  uint32_t* sel = reinterpret_cast<uint32_t*>(tile);      // k <= 16 384 positions (checked by the host entry)
 #pragma unroll
-  for (int jb = 0; jb < kKeysPerThread; jb += BATCH) {
-    int pos[BATCH];
-    float2 xy[BATCH];
-#pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const int j = jb + u;
-      const int p = j * kFusedThreads + tid;
-      const bool is_lt = keys[j] < T, is_eq = keys[j] == T && T != 0xffffffffu;
-      const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
-      const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
-      const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
-      pos[u] = (is_lt || (is_eq && eq_before < krem)) ? lt_before + min(krem, eq_before) : -1;
-      if constexpr (RNG) xy[u] = uniform_point(stream2, p);
-      else if (pos[u] >= 0) xy[u] = *reinterpret_cast<const float2*>(cr2 + (int64_t)p * 2);
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const bool is_lt = keys[j] < T, is_eq = keys[j] == T && T != 0xffffffffu;
+    const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
+    const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
+    const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
+    if (is_lt || (is_eq && eq_before < krem)) sel[lt_before + min(krem, eq_before)] = (uint32_t)(j * kFusedThreads + tid);
+  }
+  __syncthreads();
+  {
+    float2* od = reinterpret_cast<float2*>(orow);
+#pragma unroll 2
+    for (int i = tid; i < k; i += kFusedThreads) {
+      const int p = (int)sel[i];
+      if constexpr (RNG) od[i] = uniform_point(stream, p);
+      else od[i] = *reinterpret_cast<const float2*>(cr + (int64_t)p * 2);
     }
-#pragma unroll
-    for (int u = 0; u < BATCH; ++u)
-      if (pos[u] >= 0) *reinterpret_cast<float2*>(orow + (int64_t)pos[u] * 2) = xy[u];
-    __builtin_amdgcn_sched_barrier(0);
   }
   // [phase 5 compaction]
   if (n_rand > 0) {
@@ -371,7 +394,7 @@ extern "C" int mbv_sample_select_uncertain(const float* src, const int32_t* src_
                                            void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (rows < 0 || n <= 0 || k <= 0 || k > n || H <= 0 || W <= 0 || n_rand < 0) return MBV_ERR_BAD_ARG;
-  if ((int64_t)H * W > 16384 || n > kKeysPerThread * kFusedThreads) return MBV_ERR_UNSUPPORTED;
+  if ((int64_t)H * W > 16384 || n > kKeysPerThread * kFusedThreads || k > 16384) return MBV_ERR_UNSUPPORTED;
   if (rows == 0) return MBV_OK;
   if (!src || !src_index || !out_coords || (n_rand > 0 && !rand_coords)) return MBV_ERR_BAD_ARG;
   if ((coords == nullptr) == (seed == nullptr)) return MBV_ERR_BAD_ARG;      // exactly one source of points

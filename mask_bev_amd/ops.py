@@ -1943,8 +1943,8 @@ def sample_select_uncertain(src: torch.Tensor, src_index: torch.Tensor, coords: 
     from the map ``src[src_index[r]]`` (H, W), keep the k with the smallest |logit|, append ``rand_coords[r]``.
     The candidates are either ``coords`` (R, n, 2) or — ``coords=None`` — generated inside the kernel from the
     device int64 ``seed`` (``num_candidates`` per row; equal to ``uniform_points(seed, R, n)``).  Returns
-    (R, k + n_rand, 2).  Falls back to the two-kernel form for maps larger than the 64 KB LDS tile or more than
-    40 960 candidates per row."""
+    (R, k + n_rand, 2).  Falls back to the two-kernel form for maps larger than the 64 KB LDS tile, more than
+    40 960 candidates or more than 16 384 selected points per row."""
     lib = _lib.load()
     _need_gpu(src, src_index, coords, rand_coords, seed)
     if (coords is None) == (seed is None):
@@ -1955,7 +1955,7 @@ def sample_select_uncertain(src: torch.Tensor, src_index: torch.Tensor, coords: 
     n = coords.shape[1] if coords is not None else int(num_candidates)
     h, w = src.shape[-2:]
     n_rand = 0 if rand_coords is None else rand_coords.shape[1]
-    if h * w > 16384 or n > 40960:
+    if h * w > 16384 or n > 40960 or k > 16384:
         if coords is None:
             coords = uniform_points(seed, r, n)
         coords = coords.float().contiguous()

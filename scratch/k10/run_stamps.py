@@ -1,6 +1,7 @@
 import ctypes, os, sys, torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, 'k10s.so'))
+REAL = os.environ.get('K10V', '') == 'real'
+lib = ctypes.CDLL(os.environ['K10LIB']) if 'K10LIB' in os.environ else ctypes.CDLL(os.path.join(here, '../../mask_bev_amd/libmaskbev_hip.so') if REAL else os.path.join(here, 'k10s%s.so' % os.environ.get('K10V', '')))
 dev = 'cuda'
 rows, n, k, H, W = 4000, 37632, 9408, 128, 128
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
@@ -21,8 +22,8 @@ def run():
     assert rc == 0, rc
 for _ in range(3): run()
 torch.cuda.synchronize()
-st = (ctypes.c_ulonglong * 16)()
-lib.k10_read_stamps(st, 1)
+st = (ctypes.c_ulonglong * 64)()
+if not REAL: lib.k10_read_stamps(st, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 e0.record(torch.cuda.default_stream())
@@ -32,7 +33,7 @@ t0 = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize()
 t1 = time.perf_counter()
-lib.k10_read_stamps(st, 1)
+if not REAL: lib.k10_read_stamps(st, 1)
 print('scale', scale, 'avg ms/launch (host clock, 10 launches)', (t1 - t0) * 100)
 tot = sum(st)
 for i, v in enumerate(st):

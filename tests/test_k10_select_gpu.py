@@ -26,7 +26,9 @@ def test_select_matches_topk(device, R, n, k):
 
 
 @pytest.mark.parametrize('R,n,k,H,W,n_rand', [(6, 37632, 9408, 128, 128, 3136), (3, 600, 150, 24, 20, 50),
-                                              (2, 513, 513, 7, 9, 0), (4, 40960, 1, 128, 128, 5)])
+                                              (2, 513, 513, 7, 9, 0), (4, 40960, 1, 128, 128, 5),
+                                              (3, 40960, 16384, 64, 64, 3),      # the most the fused kernel places in LDS
+                                              (2, 40000, 20000, 64, 64, 7)])     # beyond it: the two-kernel form
 def test_fused_sample_select_equals_two_kernel_form(device, R, n, k, H, W, n_rand):
     """The fused importance sampling returns exactly what K8 followed by K10 (+ cat of the uniform tail) returns."""
     from mask_bev_amd import ops
