@@ -386,10 +386,16 @@ class _DecA(torch.autograd.Function):
         stats1 = torch.empty((m, 2), **f32)
         x1 = torch.empty((m, e), **f32)
         t1 = torch.empty((m, e), **f32)
-        qkv = torch.empty((3, m, e), **f32)
+        # q / k / v in the compute dtype: the self-attention (K6) then runs its 16-bit MFMA form — 10 us instead of
+        # 26 backward, 14 -> 8 forward, for 100 x 100 scores per head — like the per-op path's
+        qkv = torch.empty((3, m, e), dtype=lc.dt, device=dev)
         w_o, w_i = lc.w(wo), lc.w(w_in)
         P = Program(m, lc.q, lc.eps, lc.wdt, 'A.fwd')
         P.load(0, o1, e)
+        o1f = o1
+        if o1.dtype != torch.float32:         # an f32 copy for the weight gradient of the output projection (one STORE
+            o1f = torch.empty((m, e), **f32)  # stage here instead of a conversion launch per layer in the backward pass)
+            P.store(0, o1f, e)
         P.gemm(1, 0, w_o, e, e, bias=bo)
         P.load(2, x0, e)
         P.ln(3, 2, 1, g1, b1, e, stats=stats1, save_sum=True)
@@ -405,7 +411,8 @@ class _DecA(torch.autograd.Function):
         ctx.lc = lc
         ctx.set_materialize_grads(False)
         ctx.params = (wo, bo, g1, b1, w_in, b_in)
-        ctx.save_for_backward(o1, sum1, stats1, x1, t1, qkv, o2, lse)
+        ctx.o1_dtype = o1.dtype
+        ctx.save_for_backward(o1f, sum1, stats1, x1, t1, qkv, o2, lse)
         return x1, o2
 
     @staticmethod
@@ -420,19 +427,19 @@ class _DecA(torch.autograd.Function):
         if g_x1 is None:
             g_x1 = torch.zeros((m, e), **f32)
         if g_o2 is None:
-            g_o2 = torch.zeros((m, e), **f32)
+            g_o2 = torch.zeros((m, e), dtype=o2.dtype, device=dev)
         # K6 self-attention backward
-        g_o2 = g_o2.reshape(m, e).to(torch.float32).contiguous()
+        g_o2 = g_o2.reshape(m, e).to(o2.dtype).contiguous()
         g_qkv = torch.empty((3, m, e), **f32)
         check(lib.mbv_attn_bwd(ops._ptr(qkv[0]), ops._ptr(qkv[1]), ops._ptr(qkv[2]), ops._ptr(None), ops._ptr(o2),
-                               ops._ptr(g_o2), ops._ptr(lse), 0, lc.b, lc.q, lc.q, lc.h, e // lc.h, ops._ptr(g_qkv[0]),
+                               ops._ptr(g_o2), ops._ptr(lse), _dt(o2), lc.b, lc.q, lc.q, lc.h, e // lc.h, ops._ptr(g_qkv[0]),
                                ops._ptr(g_qkv[1]), ops._ptr(g_qkv[2]), ops._stream()), 'mbv_attn_bwd')
         g_x1 = g_x1.reshape(m, e).to(torch.float32).contiguous()
         nblk = (m + ROWS - 1) // ROWS
         part_b = torch.empty((nblk, 4 * e), **f32)             # [bq | bk | bv | bo]
         part_ln = torch.empty((nblk, 2 * e), **f32)
         ds1 = torch.empty((m, e), **f32)
-        g_o1 = torch.empty((m, e), dtype=o1.dtype, device=dev)
+        g_o1 = torch.empty((m, e), dtype=ctx.o1_dtype, device=dev)
         tw = lc.tw
         P = Program(m, lc.q, lc.eps, lc.wdt, 'A.bwd')
         P.load(0, g_qkv[0], e)
@@ -507,6 +514,10 @@ class _DecB(torch.autograd.Function):
         P = Program(m, lc.q, lc.eps, lc.wdt, 'B.fwd')
         fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
         P.load(2, o2, e)
+        o2f = o2
+        if o2.dtype != torch.float32:         # (f32 copy for d(wo), as in _DecA)
+            o2f = torch.empty((m, e), **f32)
+            P.store(2, o2f, e)
         P.gemm(3, 2, w_o, e, e, bias=bo)
         P.load(4, x1, e)
         P.ln(0, 4, 3, g2, b2, e, stats=stats2, save_sum=True)          # x2 -> slot 0
@@ -562,7 +573,8 @@ class _DecB(torch.autograd.Function):
         # would otherwise MATERIALISE them for backward() — a 26 MB fill and a 1.6 MB bool fill per layer
         ctx.set_materialize_grads(False)
         ctx.params = (wo, bo, g2, b2, w1, bb1, w2, bb2, g3, b3, nw_in, nb_in)
-        ctx.save_for_backward(o2, sum2, stats2, x2, hid, sum3, stats3, t3, qc, mask, o1n, lse)
+        ctx.o2_dtype = o2.dtype
+        ctx.save_for_backward(o2f, sum2, stats2, x2, hid, sum3, stats3, t3, qc, mask, o1n, lse)
         cls3 = cls.view(b, q, ncls)
         ctx.mark_non_differentiable(cls3, mask_pred)
         outs = (x3.view(b, q, e), cls3, mask_pred)
@@ -610,7 +622,7 @@ class _DecB(torch.autograd.Function):
         part_ln3, part_ln2 = torch.empty((nblk, 2 * e), **f32), torch.empty((nblk, 2 * e), **f32)
         ds3, ds2 = torch.empty((m, e), **f32), torch.empty((m, e), **f32)
         dh = torch.empty((m, f), **f32)
-        g_o2 = torch.empty((m, e), **f32)
+        g_o2 = torch.empty((m, e), dtype=ctx.o2_dtype, device=dev)
         P = Program(m, lc.q, lc.eps, lc.wdt, 'B.bwd')
         fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
         if g_qc is not None:
