@@ -713,6 +713,16 @@ int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const
  *                  Directly followed by an MBV_RC_FFN_IO descriptor: p0 = hidden activations (rows x k f32, stride ld;
  *                  written forward, read backward), p1 = d(hidden) out (backward), p2 = (blocks, ld2) column partials of
  *                  d(hidden) (backward, nullable).  The output bias is left to the caller (e.g. a following LN's operand).
+ *   MBV_RC_SUM     dst = sum over j < k of p0[j * ld2 + row * ld + c] (f32): the parts a split launch stored.
+ * Split launches (mbv_rowchain_run_split, split = S > 1): S consecutive workgroups share a 16-row block, so that a
+ * 400-row decoder layer occupies S x 25 CUs instead of 25.  A stage whose flags bits 8..15 hold v > 0 runs only in
+ * workgroup v - 1 of its row block, every other stage in all S (redundantly: loads, the cheap products and norms).
+ * MBV_RC_FFN | MBV_RC_SLICE (k == 256 S): workgroup j computes the hidden units [256 j, 256 j + 256) and leaves its
+ * PARTIAL output in dst (workgroup 0 adds the output bias p1 of the descriptor; p2 is a K-MAJOR fragment copy and
+ * n % 16 == 0); MBV_RC_STORE | MBV_RC_SPLIT writes to
+ * p0 + j * ld2 elements.  A following launch adds the parts with MBV_RC_SUM — in part order, so the result does not
+ * depend on timing.  Per-block partial outputs (MBV_RC_COLSUM, LN_BWD's p1, the descriptor's p2) are indexed by ROW
+ * block in either form.
  * Data gradients dX = dY . W are MBV_RC_GEMM stages against transposed weight copies (mbv_transpose_group).
  * The program is copied into the kernel arguments (<= mbv_rowchain_max_stages() stages): nothing is retained. */
 #define MBV_RC_LOAD 0
@@ -724,11 +734,15 @@ int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const
 #define MBV_RC_COLSUM 6
 #define MBV_RC_FFN 7
 #define MBV_RC_FFN_IO 8
+#define MBV_RC_SUM 9
 #define MBV_RC_ACCUM 4
 #define MBV_RC_RELU 8
 #define MBV_RC_MASK 16
 #define MBV_RC_SAVE_SUM 32
+#define MBV_RC_SLICE 64  /* FFN stages */
+#define MBV_RC_SPLIT 64  /* STORE stages */
 #define MBV_RC_FRAG 128
+#define MBV_RC_OWNER(j) (((j) + 1) << 8) /* stage of workgroup j of a split launch only */
 #define MBV_TR_MAX 96
 typedef struct MbvRowStage {
   int32_t op;
@@ -742,10 +756,14 @@ int mbv_rowchain_max_stages(void);
 int mbv_rowchain_slots(void);
 int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
                      int32_t wdtype, void* stream);
+int mbv_rowchain_run_split(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
+                           int32_t wdtype, int32_t split, void* stream);
 /* Fragment-major copies of 16-bit weight matrices for the 16 x 16 x 32 MFMA B operand: for the logical (rows, cols) matrix
  * W, dst[((t * (cols / 32) + kb) * 64 + lane) * 8 + j] = W[t * 16 + lane % 16][kb * 32 + 8 * (lane / 16) + j], rows padded
- * with zeros to a multiple of 16; transposed[i] != 0: W[r][c] = src[c * ld + r] (the data-gradient operand), else
- * src[r * ld + c].  cols % 32 == 0.  dst holds ceil(rows / 16) * 16 * cols elements. */
+ * with zeros to a multiple of 16; transposed[i] & 1: W[r][c] = src[c * ld + r] (the data-gradient operand), else
+ * src[r * ld + c].  transposed[i] & 2: k-major block order — block (t, kb) at (kb * ceil(rows / 16) + t) instead of
+ * (t * (cols / 32) + kb) — the second weight of an MBV_RC_SLICE stage.  cols % 32 == 0.  dst holds
+ * ceil(rows / 16) * 16 * cols elements. */
 int mbv_fragment_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols,
                        const int32_t* ld, const int32_t* transposed, int32_t n, void* stream);
 /* dst[i] (cols, rows) = transpose of src[i] (rows, cols), n matrices of elem_size 2 or 4 bytes, <= MBV_TR_MAX per launch. */

@@ -146,10 +146,11 @@ __device__ __forceinline__ void st_load(const MbvRowStage& s, float* slots, cons
   }
 }
 
-__device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slots, int row0, int rows) {
+__device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slots, int row0, int rows, int sidx) {
   const float* src = slots + s.src * (RC_ROWS * RC_LD);
   const int dt = s.flags & 3, n = s.n;
   const bool accum = (s.flags & MBV_RC_ACCUM) != 0;
+  const int64_t part_off = (s.flags & MBV_RC_SPLIT) ? (int64_t)sidx * s.ld2 : 0;   // (elements) this workgroup's part
   if ((n & 3) == 0) {
     const int n4 = n >> 2;
 #pragma unroll
@@ -160,7 +161,7 @@ __device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slot
       const int row = row0 + r;
       if (row >= rows) continue;
       const float4 v = *reinterpret_cast<const float4*>(__builtin_assume_aligned(src + r * RC_LD + c, 16));
-      const int64_t o = (int64_t)row * s.ld + c;
+      const int64_t o = part_off + (int64_t)row * s.ld + c;
       if (dt == MBV_DT_F32) {
         G1 float* p = gpw<float>(s.p0) + o;
         if (accum) {
@@ -182,7 +183,7 @@ __device__ __forceinline__ void st_store(const MbvRowStage& s, const float* slot
       const int row = row0 + r;
       if (row >= rows) continue;
       const float v = src[r * RC_LD + c];
-      const int64_t o = (int64_t)row * s.ld + c;
+      const int64_t o = part_off + (int64_t)row * s.ld + c;
       if (dt == MBV_DT_F32) {
         G1 float* p = gpw<float>(s.p0) + o;
         *p = accum ? *p + v : v;
@@ -466,7 +467,7 @@ __device__ __forceinline__ void st_ln(const MbvRowStage& s, float* slots, int ro
 
 // dst = d(sum) of y = LN(sum) gamma + beta given g = src (dL/dy), sum = src2, stats p2; per-block partial
 // d(gamma) / d(beta) rows to p1 [block][2 n] (rows beyond `rows` hold zero gradients: the LOAD stage zero-fills)
-__device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, float* red, int row0, int rows) {
+__device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, float* red, int row0, int rows, int rb) {
   const float* G = slots + s.src * (RC_ROWS * RC_LD);
   const float* S = slots + s.src2 * (RC_ROWS * RC_LD);
   float* D = slots + s.dst * (RC_ROWS * RC_LD);
@@ -515,7 +516,7 @@ __device__ __forceinline__ void st_ln_bwd(const MbvRowStage& s, float* slots, fl
       }
     }
     __syncthreads();
-    G1 float* out = gpw<float>(s.p1) + (int64_t)blockIdx.x * 2 * n;
+    G1 float* out = gpw<float>(s.p1) + (int64_t)rb * 2 * n;
     const int i = threadIdx.x;                                // 2 n <= 512 threads
     if (i < 2 * n) {
       const int which = i / n, c = i - which * n;
@@ -545,9 +546,9 @@ __device__ __forceinline__ void st_add(const MbvRowStage& s, float* slots) {
 }
 
 // p0[block * ld + c] = sum over the block's rows of src[r][c]  (rows beyond `rows` are zero by construction)
-__device__ __forceinline__ void st_colsum(const MbvRowStage& s, const float* slots) {
+__device__ __forceinline__ void st_colsum(const MbvRowStage& s, const float* slots, int rb) {
   const float* A = slots + s.src * (RC_ROWS * RC_LD);
-  G1 float* out = gpw<float>(s.p0) + (int64_t)blockIdx.x * s.ld;
+  G1 float* out = gpw<float>(s.p0) + (int64_t)rb * s.ld;
   const int c = threadIdx.x;                                  // n <= 256 < 512 threads
   if (c < s.n) {
     float a = 0.f;
@@ -590,7 +591,7 @@ __device__ __forceinline__ f32x4 ffn_mma(const uint4* a, const uint4* b, f32x4 a
 
 template <int WDT>
 __device__ __forceinline__ void st_ffn(const MbvRowStage& s, const MbvRowStage& io, float* slots, float* red, int row0,
-                                       int rows) {
+                                       int rows, int rb) {
   if constexpr (WDT == MBV_DT_F32) {
     return;
   } else {
@@ -678,7 +679,7 @@ __device__ __forceinline__ void st_ffn(const MbvRowStage& s, const MbvRowStage& 
           if (bwd && part) {                                     // column partial of d(hidden): sum over the 16 rows
             colsum += __shfl_xor(colsum, 16, 64);
             colsum += __shfl_xor(colsum, 32, 64);
-            if (g == 0) part[(int64_t)blockIdx.x * io.ld2 + hcol] = colsum;
+            if (g == 0) part[(int64_t)rb * io.ld2 + hcol] = colsum;
           }
         }
       }
@@ -724,6 +725,153 @@ __device__ __forceinline__ void st_ffn(const MbvRowStage& s, const MbvRowStage& 
   }
 }
 
+// ---- MBV_RC_SUM: dst = sum over k parts of p0[j * ld2 + row * ld + c] (f32; the partial results that the workgroups of a
+// split launch stored with MBV_RC_SPLIT), in part order — the same sum whatever the launch's timing.
+__device__ __forceinline__ void st_sum(const MbvRowStage& s, float* slots, int row0, int rows) {
+  float* dst = slots + s.dst * (RC_ROWS * RC_LD);
+  const int n4 = s.n >> 2;
+  const G1 float* base = gp<float>(s.p0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * RC_NT;
+    if (i >= RC_ROWS * n4) continue;
+    const int r = i / n4, c = (i - r * n4) * 4;
+    int row = row0 + r;
+    const bool live = row < rows;
+    row = live ? row : rows - 1;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const G1 float* p = base + (int64_t)row * s.ld + c;
+#pragma unroll 8
+    for (int j = 0; j < s.k; ++j) {
+      const float4 v = __builtin_bit_cast(float4, gld16(p + (int64_t)j * s.ld2));
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(__builtin_assume_aligned(dst + r * RC_LD + c, 16)) = a;
+  }
+}
+
+// ---- MBV_RC_FFN | MBV_RC_SLICE: the workgroup `slice` of a split launch owns the 256 hidden units [256 slice, 256 slice
+// + 256) — wave w the 32 units behind 256 slice + 32 w — and leaves its PARTIAL output in dst (slice 0: plus the output
+// bias).  A wave's share is two 16-unit tiles of the first product (K = E) and one 32-deep k block of the second:
+// 2 x 8 + 16 fragment loads, ALL requested before the first multiply — one memory round trip per workgroup where the
+// whole-MLP form walks 32 dependent tiles per wave (21 us for 2048 hidden units; the other 231 CUs idle meanwhile).
+// Measured: 13.6 us for the stage — 5.9 us to get the 33 loads of every wave issued, 4.3 us more until the last fragment
+// has arrived: a CU draws ~25 GB/s of weights from L2 whatever the layout (k-major or strided made no difference), and
+// the 25 row blocks x 2 MB of the layer are 4.8 TB/s in aggregate.  Fewer bytes would need more rows per workgroup.
+template <int WDT>
+__device__ __forceinline__ void st_ffn_slice(const MbvRowStage& s, const MbvRowStage& io, float* slots, float* red, int row0,
+                                             int rows, int rb, int slice) {
+  if constexpr (WDT == MBV_DT_F32) {
+    return;
+  } else {
+    constexpr int HB = 40;                             // row stride (16-bit elements) of a wave's 16 x 32 hidden image: 80 B
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    const int E = s.n;
+    const bool bwd = (s.flags & MBV_RC_MASK) != 0;
+    const float* X = slots + s.src * (RC_ROWS * RC_LD);
+    unsigned short* himg = reinterpret_cast<unsigned short*>(slots + s.src2 * (RC_ROWS * RC_LD)) + wave * (RC_ROWS * HB);
+    double* acc64 = reinterpret_cast<double*>(red);
+    for (int i = threadIdx.x; i < RC_ROWS * RC_MAXC; i += RC_NT) acc64[i] = 0.0;
+    const G1 char* w1 = gp<char>(s.p0);
+    const G1 char* w2 = gp<char>(s.p2);
+    const G1 float* bias1 = gp<float>(s.p1);
+    const G1 float* hid_in = gp<float>(io.p0);
+    G1 float* hid_out = gpw<float>(bwd ? io.p1 : io.p0);
+    G1 float* part = gpw<float>(io.p2);
+    const int e_tiles = (E + 15) >> 4;
+    const int h0 = slice * 256 + wave * 32;            // the wave's first hidden unit
+    // the epilogue's operands first (loads return in order), then every weight fragment of the wave
+    float hv[2][4], bv[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int hcol = h0 + tt * 16 + m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = row0 + 4 * g + i;
+        row = row < rows ? row : rows - 1;
+        hv[tt][i] = bwd ? hid_in[(int64_t)row * io.ld + hcol] : 0.f;
+      }
+      const G1 float* bp1 = bias1 ? bias1 : reinterpret_cast<const G1 float*>(w1);
+      const float b = bp1[hcol];
+      bv[tt] = (!bwd && bias1) ? b : 0.f;
+    }
+    uint4 b1[2][8], b2[16];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const G1 char* base = w1 + ((int64_t)((h0 >> 4) + tt) * s.ld * 64 + lane) * 16;
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) b1[tt][kb] = gld16(base + (kb * 32 < E ? kb : 0) * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int tc = t < e_tiles ? t : e_tiles - 1;
+      b2[t] = gld16(w2 + (((int64_t)(h0 >> 5) * e_tiles + tc) * 64 + lane) * 16);       // k-major copy (E / 16 == e_tiles tiles per k block)
+    }
+    uint4 ax[8];
+    {
+      const float4* xr = reinterpret_cast<const float4*>(__builtin_assume_aligned(X + m * RC_LD + 8 * g, 16));
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (kb * 32 < E) {
+          const float4 r0 = xr[kb * 8], r1 = xr[kb * 8 + 1];
+          v = f32x8{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        }
+        if constexpr (WDT == MBV_DT_BF16) ax[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, bf16x8));
+        else ax[kb] = __builtin_bit_cast(uint4, __builtin_convertvector(v, f16x8));
+      }
+    }
+    __syncthreads();                                   // acc64 zeroed
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int hcol = h0 + tt * 16 + m;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = ffn_mma<WDT>(ax, b1[tt], acc);
+      float colsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i] + bv[tt];
+        if (bwd) v = hv[tt][i] > 0.f ? v : 0.f;
+        else v = fmaxf(v, 0.f);
+        const int row = row0 + 4 * g + i;
+        if (row >= rows) v = 0.f;
+        colsum += v;
+        himg[(4 * g + i) * HB + tt * 16 + m] = f32_to_16(v, WDT);
+        if (row < rows) hid_out[(int64_t)row * io.ld + hcol] = v;
+      }
+      if (bwd && part) {
+        colsum += __shfl_xor(colsum, 16, 64);
+        colsum += __shfl_xor(colsum, 32, 64);
+        if (g == 0) part[(int64_t)rb * io.ld2 + hcol] = colsum;
+      }
+    }
+    // the wave's own LDS writes: same-wave ordering
+    const uint4 ah = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(himg + m * HB + 8 * g, 16));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (t >= e_tiles) break;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (WDT == MBV_DT_BF16)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, b2[t]), acc, 0, 0, 0);
+      else
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, b2[t]), acc, 0, 0, 0);
+      const int col = t * 16 + m;
+      if (col < E) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&acc64[(4 * g + i) * RC_MAXC + ((col + 16 * g) & (RC_MAXC - 1))], (double)acc[i]);
+      }
+    }
+    __syncthreads();
+    float* Y = slots + s.dst * (RC_ROWS * RC_LD);
+    const G1 float* bias_out = (bwd || slice != 0) ? nullptr : gp<float>(io.p1);
+    for (int i = threadIdx.x; i < RC_ROWS * RC_MAXC; i += RC_NT) {
+      const int r = i >> 8, cc = i & 255;
+      if (cc < E) Y[r * RC_LD + cc] = (float)acc64[r * RC_MAXC + ((cc + 16 * (r >> 2)) & (RC_MAXC - 1))] + (bias_out ? bias_out[cc] : 0.f);
+    }
+  }
+}
+
 // barrier between stages: LDS traffic only (the prefetched global loads stay in flight across it)
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -751,7 +899,6 @@ __global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
   __shared__ uint32_t sprog[RC_PROG_WORDS];
   float* slots = rc_lds;
   float* red = rc_lds + RC_SLOTS * RC_ROWS * RC_LD;       // [2][16][256] scratch of the LayerNorm backward
-  const int row0 = blockIdx.x * RC_ROWS;
   {
     const __attribute__((address_space(4))) uint32_t* kp =
         (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -764,6 +911,11 @@ __global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
   const float eps = __uint_as_float(__builtin_amdgcn_readfirstlane(sprog[4]));
   int ng = (int)__builtin_amdgcn_readfirstlane(sprog[5]);        // first GEMM / first LOAD stage (host-computed, -1: none)
   int nl = (int)__builtin_amdgcn_readfirstlane(sprog[6]);
+  // split launches: `split` consecutive workgroups share a row block.  Stages without an owner (flags bits 8..15 == 0)
+  // run in all of them — redundantly, on CUs that would idle otherwise — the others only in workgroup owner - 1.
+  const int split = (int)__builtin_amdgcn_readfirstlane(sprog[7]);
+  const int rb = (int)blockIdx.x / split, sidx = (int)blockIdx.x - rb * split;
+  const int row0 = rb * RC_ROWS;
   GemmPre<WDT> gpre;
   LoadPre lpre;
   if (nl >= 0) {
@@ -778,6 +930,18 @@ __global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
     const MbvRowStage s = rc_stage(sprog, i);
     // `reserved`: the next GEMM stage (low byte) and the next LOAD stage (high byte) after this one, 0xff = none
     const int nxt_g = s.reserved & 0xff, nxt_l = (s.reserved >> 8) & 0xff;
+    const int owner = (s.flags >> 8) & 0xff;
+    if (owner != 0 && owner - 1 != sidx) {
+      // another workgroup's stage: only keep the prefetch chain consistent (the operands in flight are this stage's)
+      if (s.op == MBV_RC_LOAD && nxt_l != 0xff) {
+        const MbvRowStage nx = rc_stage(sprog, nxt_l);
+        load_prefetch(nx, lpre, row0, rows, q_mod);
+      } else if (s.op == MBV_RC_GEMM && nxt_g != 0xff) {
+        const MbvRowStage nx = rc_stage(sprog, nxt_g);
+        gemm_prefetch<WDT>(nx, gpre);
+      }
+      continue;
+    }
     switch (s.op) {
       case MBV_RC_LOAD:
         st_load(s, slots, lpre, row0, rows);
@@ -787,16 +951,17 @@ __global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
           load_prefetch(nx, lpre, row0, rows, q_mod);
         }
         break;
-      case MBV_RC_STORE: st_store(s, slots, row0, rows); break;
+      case MBV_RC_STORE: st_store(s, slots, row0, rows, sidx); break;
+      case MBV_RC_SUM: st_sum(s, slots, row0, rows); break;
       case MBV_RC_GEMM: {
         const MbvRowStage nx = rc_stage(sprog, nxt_g != 0xff ? nxt_g : i);
         st_gemm<WDT>(s, nxt_g != 0xff, nx, slots, gpre);
         break;
       }
       case MBV_RC_LN: st_ln(s, slots, row0, rows, eps); break;
-      case MBV_RC_LN_BWD: st_ln_bwd(s, slots, red, row0, rows); break;
+      case MBV_RC_LN_BWD: st_ln_bwd(s, slots, red, row0, rows, rb); break;
       case MBV_RC_ADD: st_add(s, slots); break;
-      case MBV_RC_COLSUM: st_colsum(s, slots); break;
+      case MBV_RC_COLSUM: st_colsum(s, slots, rb); break;
       case MBV_RC_FFN: {
         // the prefetch registers are dead across this stage (the host routes the prefetches AROUND an FFN stage: the
         // stage before it requests nothing, this stage requests the next GEMM / LOAD operands when it is done)
@@ -807,7 +972,8 @@ __global__ void __launch_bounds__(RC_NT) k_rowchain(const RowProgram P_unused) {
           lpre = undef_l;
         }
         const MbvRowStage io = rc_stage(sprog, i + 1);
-        st_ffn<WDT>(s, io, slots, red, row0, rows);
+        if (s.flags & MBV_RC_SLICE) st_ffn_slice<WDT>(s, io, slots, red, row0, rows, rb, sidx);
+        else st_ffn<WDT>(s, io, slots, red, row0, rows, rb);
         if (nxt_l != 0xff) {
           const MbvRowStage nx = rc_stage(sprog, nxt_l);
           load_prefetch(nx, lpre, row0, rows, q_mod);
@@ -931,7 +1097,10 @@ __global__ void __launch_bounds__(256) k_fragment_group(const FragArgs A) {
     const int t = tr * 4 + tt, kb = tc * 2 + kbb;
     if (t >= tn || kb >= kbn) continue;
     const uint4 q = *reinterpret_cast<const uint4*>(&tile[tt * 16 + (lane & 15)][kbb * 32 + 8 * (lane >> 4)]);
-    reinterpret_cast<uint4*>(e.dst)[((int64_t)t * kbn + kb) * 64 + lane] = q;
+    // mode bit 2: k-major — the 16-row tiles of ONE k block are consecutive (the second weight of a sliced MLP stage: a
+    // wave multiplies one k block against every tile, 16 KB in one piece instead of sixteen at a 64 KB stride)
+    const int64_t blk = (e.mode & 4) ? (int64_t)kb * tn + t : (int64_t)t * kbn + kb;
+    reinterpret_cast<uint4*>(e.dst)[blk * 64 + lane] = q;
   }
 }
 
@@ -942,19 +1111,26 @@ extern "C" int mbv_rowchain_slots(void) { return RC_SLOTS; }
 
 extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
                                 int32_t wdtype, void* stream_) {
+  return mbv_rowchain_run_split(stages, num_stages, rows, q_mod, eps, wdtype, 1, stream_);
+}
+
+extern "C" int mbv_rowchain_run_split(const MbvRowStage* stages, int32_t num_stages, int32_t rows, int32_t q_mod, float eps,
+                                      int32_t wdtype, int32_t split, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (!stages || num_stages <= 0 || num_stages > RC_MAX_STAGES || rows <= 0 || q_mod < 0) return MBV_ERR_BAD_ARG;
+  if (!stages || num_stages <= 0 || num_stages > RC_MAX_STAGES || rows <= 0 || q_mod < 0 || split < 1 || split > 64)
+    return MBV_ERR_BAD_ARG;
   if (wdtype != MBV_DT_F32 && wdtype != MBV_DT_BF16 && wdtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   RowProgram P;
   P.num_stages = num_stages; P.rows = rows; P.q_mod = q_mod; P.wdtype = wdtype; P.eps = eps;
   P.pad[0] = P.pad[1] = -1;                            // first GEMM / first LOAD stage, filled below
-  P.pad[2] = 0;
+  P.pad[2] = split;
   const int kq = wdtype == MBV_DT_F32 ? 16 : 32;          // reduction granularity of the MFMA k blocks
   const int wes = wdtype == MBV_DT_F32 ? 4 : 2;
   for (int i = 0; i < num_stages; ++i) {
     const MbvRowStage& s = stages[i];
     const int dt = s.flags & 3;
     auto slot_ok = [](int v) { return v >= 0 && v < RC_SLOTS; };
+    if (((s.flags >> 8) & 0xff) > split) return MBV_ERR_BAD_ARG;            // owned by a workgroup the launch does not have
     switch (s.op) {
       case MBV_RC_LOAD:
         if (!slot_ok(s.dst) || (!s.p0 && (!slot_ok(s.src) || !s.p1)) || s.n <= 0 || s.n > RC_MAXC || (s.n & 3) || dt > 2 ||
@@ -966,6 +1142,12 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
         if (!slot_ok(s.src) || !s.p0 || s.n <= 0 || s.n > RC_MAXC || dt > 2 || ((s.flags & MBV_RC_ACCUM) && dt != MBV_DT_F32))
           return MBV_ERR_BAD_ARG;
         if ((s.n & 3) == 0 && ((s.ld & 3) || (reinterpret_cast<size_t>(s.p0) & (dt == MBV_DT_F32 ? 15 : 7))))
+          return MBV_ERR_BAD_ARG;
+        if ((s.flags & MBV_RC_SPLIT) && (s.ld2 <= 0 || (s.ld2 & 3) || (s.flags & MBV_RC_ACCUM))) return MBV_ERR_BAD_ARG;
+        break;
+      case MBV_RC_SUM:
+        if (!slot_ok(s.dst) || !s.p0 || s.n <= 0 || s.n > RC_MAXC || (s.n & 3) || s.k < 1 || s.k > 64 || (s.ld & 3) ||
+            (s.ld2 & 3) || (reinterpret_cast<size_t>(s.p0) & 15))
           return MBV_ERR_BAD_ARG;
         break;
       case MBV_RC_GEMM:
@@ -1001,6 +1183,7 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
             s.n <= 0 || s.n > RC_MAXC || (s.n % 32) || s.k <= 0 || (s.k % 256) || s.ld * 32 < s.n || s.ld2 * 32 < s.k || (reinterpret_cast<size_t>(s.p0) & 15) || (reinterpret_cast<size_t>(s.p2) & 15) || !io.p0 ||
             io.ld < s.k || (bwd && !io.p1) || (io.p2 && io.ld2 < s.k))
           return MBV_ERR_BAD_ARG;
+        if (((s.flags >> 8) & 0xff) || ((s.flags & MBV_RC_SLICE) && s.k != 256 * split)) return MBV_ERR_BAD_ARG;   // (MLP stages have no owner)
         P.st[i] = s;
         ++i;
         P.st[i] = stages[i];
@@ -1034,7 +1217,7 @@ extern "C" int mbv_rowchain_run(const MbvRowStage* stages, int32_t num_stages, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const dim3 grid((unsigned)((rows + RC_ROWS - 1) / RC_ROWS)), block(RC_NT);
+  const dim3 grid((unsigned)((rows + RC_ROWS - 1) / RC_ROWS) * (unsigned)split), block(RC_NT);
   if (wdtype == MBV_DT_F32)
     hipLaunchKernelGGL(k_rowchain<MBV_DT_F32>, grid, block, lds, stream, P);
   else if (wdtype == MBV_DT_BF16)
@@ -1060,7 +1243,7 @@ extern "C" int mbv_fragment_group(const void* const* src, void* const* dst, cons
         return MBV_ERR_BAD_ARG;
       A.e[i].src = src[j]; A.e[i].dst = dst[j]; A.e[i].rows = rows[j]; A.e[i].cols = cols[j]; A.e[i].ld = ld[j];
       const bool vec = (ld[j] % 8) == 0 && (reinterpret_cast<size_t>(src[j]) & 15) == 0;
-      A.e[i].mode = (transposed[j] ? 1 : 0) | (vec ? 2 : 0);
+      A.e[i].mode = ((transposed[j] & 1) ? 1 : 0) | (vec ? 2 : 0) | ((transposed[j] & 2) ? 4 : 0);
       A.e[i].tile_begin = tiles;
       tiles += ((rows[j] + 63) / 64) * ((cols[j] + 63) / 64);
     }

@@ -30,8 +30,9 @@ import torch
 from . import _lib, ops
 from ._lib import MaskBevHipError, check
 
-OP_LOAD, OP_STORE, OP_GEMM, OP_LN, OP_LN_BWD, OP_ADD, OP_COLSUM, OP_FFN, OP_FFN_IO = range(9)
+OP_LOAD, OP_STORE, OP_GEMM, OP_LN, OP_LN_BWD, OP_ADD, OP_COLSUM, OP_FFN, OP_FFN_IO, OP_SUM = range(10)
 F_ACCUM, F_RELU, F_MASK, F_SAVE_SUM, F_FRAG = 4, 8, 16, 32, 128
+F_SLICE = F_SPLIT = 64
 ROWS = 16
 
 
@@ -57,15 +58,15 @@ class WRef:
     """A GEMM weight operand: a row-major matrix (f32 programs, tests) or a fragment-major 16-bit copy
     (``mbv_fragment_group``) of a logical (rows, cols) matrix."""
 
-    def __init__(self, tensor: torch.Tensor, rows: int, cols: int, frag: bool):
-        self.t, self.rows, self.cols, self.frag = tensor, rows, cols, frag
+    def __init__(self, tensor: torch.Tensor, rows: int, cols: int, frag: bool, kmajor: bool = False):
+        self.t, self.rows, self.cols, self.frag, self.kmajor = tensor, rows, cols, frag, kmajor
 
     @property
     def dtype(self):
         return self.t.dtype
 
 
-def fragment_copy(w: torch.Tensor, transposed: bool = False) -> WRef:
+def fragment_copy(w: torch.Tensor, transposed: bool = False, kmajor: bool = False) -> WRef:
     """Fragment-major copy of the 16-bit matrix ``w`` (or of its transpose): one launch; for tests / one-off use —
     the decoder refreshes all of its copies with one grouped launch per step (:class:`WeightCopies`)."""
     lib = _lib.load()
@@ -75,8 +76,8 @@ def fragment_copy(w: torch.Tensor, transposed: bool = False) -> WRef:
     dst = torch.empty(((rows + 15) // 16 * 16) * cols, dtype=w.dtype, device=w.device)
     P1, I1 = ctypes.c_void_p * 1, ctypes.c_int32 * 1
     check(lib.mbv_fragment_group(P1(w.data_ptr()), P1(dst.data_ptr()), I1(rows), I1(cols), I1(w.stride(0)),
-                                 I1(1 if transposed else 0), 1, ops._stream()), 'mbv_fragment_group')
-    return WRef(dst, rows, cols, True)
+                                 I1((1 if transposed else 0) | (2 if kmajor else 0)), 1, ops._stream()), 'mbv_fragment_group')
+    return WRef(dst, rows, cols, True, kmajor)
 
 
 class Program:
@@ -85,18 +86,37 @@ class Program:
 
     TIMING = None       # a list -> run() brackets every launch with events and appends (label, start, end) (scratch/time_k19.py)
 
-    def __init__(self, rows: int, q_mod: int, eps: float, wdtype: torch.dtype, label: str = ''):
+    def __init__(self, rows: int, q_mod: int, eps: float, wdtype: torch.dtype, label: str = '', split: int = 1):
+        """``split`` > 1: that many workgroups per 16-row block (``mbv_rowchain_run_split``); stages added inside
+        ``with P.only(j):`` run in workgroup j alone, all others in every workgroup of the block."""
         self.rows, self.q_mod, self.eps = int(rows), int(q_mod), float(eps)
         self.wdtype = wdtype
         self.label = label
+        self.split = int(split)
+        self.owner: Optional[int] = None
         self.stages: List[RowStage] = []
         self.keep: list = []
+
+    def only(self, j: int):
+        prog = self
+
+        class _Only:
+            def __enter__(self_inner):
+                self_inner.prev = prog.owner
+                prog.owner = j if prog.split > 1 else None
+
+            def __exit__(self_inner, *exc):
+                prog.owner = self_inner.prev
+                return False
+        return _Only()
 
     @property
     def blocks(self) -> int:
         return (self.rows + ROWS - 1) // ROWS
 
     def _add(self, op, dst=0, src=0, src2=-1, n=0, k=0, flags=0, ld=0, ld2=0, p0=None, p1=None, p2=None):
+        if self.owner is not None and op not in (OP_FFN, OP_FFN_IO):
+            flags |= (self.owner + 1) << 8
         self.stages.append(RowStage(op, dst, src, src2, 0, n, k, flags, ld, ld2, p0, p1, p2))
 
     def load(self, dst: int, t: torch.Tensor, n: int, col0: int = 0, add: Optional[torch.Tensor] = None):
@@ -112,6 +132,20 @@ class Program:
     def store(self, src: int, t: torch.Tensor, n: int, col0: int = 0, accum: bool = False):
         self.keep.append(t)
         self._add(OP_STORE, src=src, n=n, flags=_dt(t) | (F_ACCUM if accum else 0), ld=t.stride(0), p0=_addr(t, col0))
+
+    def store_part(self, src: int, parts: torch.Tensor, n: int):
+        """parts[j] (split, rows, n) f32 <- slot src of workgroup j of every row block (a split launch's partial results)."""
+        if parts.dim() != 3 or parts.shape[0] != self.split or parts.dtype != torch.float32 or not parts.is_contiguous():
+            raise MaskBevHipError('rowchain store_part: (split, rows, n) contiguous f32')
+        self.keep.append(parts)
+        self._add(OP_STORE, src=src, n=n, flags=_dt(parts) | F_SPLIT, ld=parts.stride(1), ld2=parts.stride(0), p0=_addr(parts))
+
+    def sum_parts(self, dst: int, parts: torch.Tensor, n: int):
+        """slot dst <- sum over j of parts[j] (in order)."""
+        if parts.dim() != 3 or parts.dtype != torch.float32 or not parts.is_contiguous():
+            raise MaskBevHipError('rowchain sum_parts: (parts, rows, n) contiguous f32')
+        self.keep.append(parts)
+        self._add(OP_SUM, dst=dst, n=n, k=parts.shape[0], ld=parts.stride(1), ld2=parts.stride(0), p0=_addr(parts))
 
     def gemm(self, dst: int, src: int, w: torch.Tensor, n: int, k: int, bias: Optional[torch.Tensor] = None,
              row0: int = 0, col0: int = 0, relu: bool = False, accum: bool = False, mask: int = -1, bias0: int = 0,
@@ -160,19 +194,24 @@ class Program:
     def ffn(self, dst: int, src: int, scratch: int, w_a: torch.Tensor, w_b: torch.Tensor, e: int, f: int,
             hid: torch.Tensor, bias_a: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
             backward: bool = False, d_hid: Optional[torch.Tensor] = None, partial: Optional[torch.Tensor] = None,
-            partial_col0: int = 0):
+            partial_col0: int = 0, sliced: bool = False):
         """The MLP pair as ONE stage with the hidden chunks spread over the waves (16-bit weights).
         forward: slot dst = relu(src @ w_a^T + bias_a) @ w_b^T (+ bias_out), w_a = W1 (f, e), w_b = W2 (e, f); the hidden
         activations go to ``hid`` (rows, f) f32.  backward: slot dst = ((src @ w_a^T) * (hid > 0)) @ w_b^T with
         w_a = W2^T (f, e), w_b = W1^T (e, f); d(hidden) goes to ``d_hid``, its per-block column sums to
-        ``partial[:, partial_col0:partial_col0 + f]``.  ``scratch``: first of 5 free consecutive slots."""
+        ``partial[:, partial_col0:partial_col0 + f]``.  ``scratch``: first of 5 free consecutive slots.
+        ``sliced`` (split launches, f == 256 * split): workgroup j computes hidden units [256 j, 256 j + 256) and slot dst
+        holds its PARTIAL result (j == 0: plus ``bias_out``) — store it with :meth:`store_part`."""
         if (not isinstance(w_a, WRef) or not isinstance(w_b, WRef) or not w_a.frag or not w_b.frag
                 or w_a.dtype != self.wdtype or w_b.dtype != self.wdtype or self.wdtype == torch.float32
                 or (w_a.rows, w_a.cols) != (f, e) or (w_b.rows, w_b.cols) != (e, f)):
             raise MaskBevHipError('rowchain ffn: fragment-major 16-bit weights (f, e) and (e, f) in the program dtype')
         self.keep += [w_a.t, w_b.t, hid, bias_a, bias_out, d_hid, partial]
-        dbg = 64 if os.environ.get('MBV_RC_FFN_DEBUG') == '1' else 0
-        self._add(OP_FFN, dst=dst, src=src, src2=scratch, n=e, k=f, flags=(F_MASK if backward else 0) | dbg, ld=e // 32,
+        if sliced and (f != 256 * self.split or not w_b.kmajor or w_a.kmajor or e % 16):
+            raise MaskBevHipError('rowchain ffn: a sliced stage needs f == 256 * split and a k-major second weight')
+        if not sliced and (w_a.kmajor or w_b.kmajor):
+            raise MaskBevHipError('rowchain ffn: k-major weight copies belong to sliced stages')
+        self._add(OP_FFN, dst=dst, src=src, src2=scratch, n=e, k=f, flags=(F_MASK if backward else 0) | (F_SLICE if sliced else 0), ld=e // 32,
                   ld2=f // 32, p0=_addr(w_a.t), p1=_addr(bias_a), p2=_addr(w_b.t))
         self._add(OP_FFN_IO, ld=hid.stride(0), ld2=0 if partial is None else partial.stride(0), p0=_addr(hid),
                   p1=_addr(d_hid if backward else bias_out), p2=_addr(partial, partial_col0))
@@ -187,8 +226,12 @@ class Program:
         if Program.TIMING is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        check(lib.mbv_rowchain_run(arr, n, self.rows, self.q_mod, self.eps, ops._dt_flag(self.wdtype), ops._stream()),
-              'mbv_rowchain_run')
+        if self.split > 1:
+            check(lib.mbv_rowchain_run_split(arr, n, self.rows, self.q_mod, self.eps, ops._dt_flag(self.wdtype), self.split,
+                                             ops._stream()), 'mbv_rowchain_run_split')
+        else:
+            check(lib.mbv_rowchain_run(arr, n, self.rows, self.q_mod, self.eps, ops._dt_flag(self.wdtype), ops._stream()),
+                  'mbv_rowchain_run')
         if ev is not None:
             ev[1].record()
             Program.TIMING.append((self.label, n, ev[0], ev[1]))
@@ -216,7 +259,8 @@ class WeightCopies:
         keep = []
         if dt == torch.float32:
             src_p, dst_p, rows_l, cols_l = [], [], [], []
-            for p, rows, tr in entries:
+            for ent in entries:
+                p, rows, tr = ent[:3]
                 w = p.detach()
                 if rows is not None:
                     w = w[rows[0]:rows[1]]
@@ -237,7 +281,9 @@ class WeightCopies:
                       'mbv_transpose_group')
             return
         src_p, dst_p, rows_l, cols_l, ld_l, tr_l = [], [], [], [], [], []
-        for p, rows, tr in entries:
+        for ent in entries:
+            p, rows, tr = ent[:3]
+            km = len(ent) > 3 and bool(ent[3])          # k-major block order (second weight of a sliced MLP stage)
             w = ops._compute_copy(p, dt)
             if rows is not None:
                 w = w[rows[0]:rows[1]]
@@ -251,8 +297,8 @@ class WeightCopies:
                 t = self.buf[key] = torch.empty(numel, dtype=dt, device=w.device)
             keep.append(w)
             src_p.append(w.data_ptr()); dst_p.append(t.data_ptr()); rows_l.append(lr); cols_l.append(lc)
-            ld_l.append(w.stride(0)); tr_l.append(1 if tr else 0)
-            self.ref[key] = WRef(t, lr, lc, True)
+            ld_l.append(w.stride(0)); tr_l.append((1 if tr else 0) | (2 if km else 0))
+            self.ref[key] = WRef(t, lr, lc, True, km)
         n = len(src_p)
         if n:
             PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
@@ -511,19 +557,35 @@ class _DecB(torch.autograd.Function):
         oc = head.mlp[2][0].shape[0]
         me = torch.empty((m, oc), dtype=head.mask_feature.dtype, device=dev)
         w_o, w_1, w_2 = lc.w(wo), lc.w(w1), lc.w(w2)
-        P = Program(m, lc.q, lc.eps, lc.wdt, 'B.fwd')
         fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+        # The MLP's 2 x 1 MB of weights behind ONE workgroup per 16 rows is 30 us of dependent loads on 25 CUs.  Split form:
+        # f / 256 workgroups per row block each take 256 hidden units (launch 1: the cheap stages before the MLP run in all
+        # of them), a second launch adds the parts and finishes the layer with its three independent branches (next
+        # layer's query projection | class head | mask-embedding MLP) in three workgroups.
+        S = ffn_split(f, e, lc.wdt)
+        split = S > 1
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'B1.fwd' if split else 'B.fwd', split=S)
         P.load(2, o2, e)
         o2f = o2
         if o2.dtype != torch.float32:         # (f32 copy for d(wo), as in _DecA)
             o2f = torch.empty((m, e), **f32)
-            P.store(2, o2f, e)
+            with P.only(0):
+                P.store(2, o2f, e)
         P.gemm(3, 2, w_o, e, e, bias=bo)
         P.load(4, x1, e)
         P.ln(0, 4, 3, g2, b2, e, stats=stats2, save_sum=True)          # x2 -> slot 0
-        P.store(4, sum2, e)
-        P.store(0, x2, e)
-        if fused_ffn:
+        with P.only(0):
+            P.store(4, sum2, e)
+            P.store(0, x2, e)
+        if split:
+            parts = torch.empty((S, m, e), **f32)
+            P.ffn(1, 0, 2, w_1, w_2, e, f, hid, bias_a=bb1, bias_out=bb2, sliced=True)
+            P.store_part(1, parts, e)
+            P.run()
+            P = Program(m, lc.q, lc.eps, lc.wdt, 'B2.fwd', split=3)
+            P.sum_parts(1, parts, e)                                       # y -> slot 1
+            P.load(0, x2, e)
+        elif fused_ffn:
             P.ffn(1, 0, 2, w_1, w_2, e, f, hid, bias_a=bb1, bias_out=bb2)    # y -> slot 1; scratch slots 2..6
         else:
             ch = 256
@@ -532,22 +594,25 @@ class _DecB(torch.autograd.Function):
                 P.gemm(2, 0, w_1, n, e, bias=bb1, row0=c, bias0=c, relu=True, out=hid, out_col0=c)
                 P.gemm(1, 2, w_2, e, n, bias=bb2 if c == 0 else None, col0=c, accum=c > 0)
         P.ln(2, 0, 1, g3, b3, e, stats=stats3, save_sum=True)          # x3 -> slot 2, the sum -> slot 0
-        P.store(0, sum3, e)
-        P.store(2, x3, e)
+        qc = t3 = None
+        with P.only(0):
+            P.store(0, sum3, e)
+            P.store(2, x3, e)
+            if nxt is not None:
+                t3 = torch.empty((m, e), **f32)
+                qc = torch.empty((m, e), dtype=nxt.holder.k_cat.dtype, device=dev)
+                P.load_slot_plus(0, 2, lc.qpos, e)
+                P.store(0, t3, e)
+                P.gemm(1, 0, lc.w(nxt.w_in), e, e, bias=nxt.b_in, row0=0, bias0=0, out=qc)
         # prediction heads (no gradient through here: ops._DeferredHeads re-evaluates them in one batched backward)
         P.ln(3, 2, -1, head.post_g, head.post_b, e)
-        P.gemm(4, 3, lc.w(head.cls_w), ncls, e, bias=head.cls_b, out=cls)
+        with P.only(1):
+            P.gemm(4, 3, lc.w(head.cls_w), ncls, e, bias=head.cls_b, out=cls)
         (m1w, m1b), (m2w, m2b), (m3w, m3b) = head.mlp
-        P.gemm(4, 3, lc.w(m1w), m1w.shape[0], e, bias=m1b, relu=True)
-        P.gemm(5, 4, lc.w(m2w), m2w.shape[0], m1w.shape[0], bias=m2b, relu=True)
-        P.gemm(4, 5, lc.w(m3w), oc, m2w.shape[0], bias=m3b, out=me)
-        qc = t3 = None
-        if nxt is not None:
-            t3 = torch.empty((m, e), **f32)
-            qc = torch.empty((m, e), dtype=nxt.holder.k_cat.dtype, device=dev)
-            P.load_slot_plus(3, 2, lc.qpos, e)
-            P.store(3, t3, e)
-            P.gemm(4, 3, lc.w(nxt.w_in), e, e, bias=nxt.b_in, row0=0, bias0=0, out=qc)
+        with P.only(2):
+            P.gemm(5, 3, lc.w(m1w), m1w.shape[0], e, bias=m1b, relu=True)
+            P.gemm(6, 5, lc.w(m2w), m2w.shape[0], m1w.shape[0], bias=m2b, relu=True)
+            P.gemm(5, 6, lc.w(m3w), oc, m2w.shape[0], bias=m3b, out=me)
         P.run()
         b, q = lc.b, lc.q
         with torch.no_grad():
@@ -623,23 +688,36 @@ class _DecB(torch.autograd.Function):
         ds3, ds2 = torch.empty((m, e), **f32), torch.empty((m, e), **f32)
         dh = torch.empty((m, f), **f32)
         g_o2 = torch.empty((m, e), dtype=ctx.o2_dtype, device=dev)
-        P = Program(m, lc.q, lc.eps, lc.wdt, 'B.bwd')
         fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+        S = ffn_split(f, e, lc.wdt)
+        split = S > 1
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'B1.bwd' if split else 'B.bwd', split=S)
         if g_qc is not None:
             P.load(2, g_qc, e)
-            P.colsum(2, part_b, e, 0)
+            with P.only(0):
+                P.colsum(2, part_b, e, 0)
             P.gemm(3, 2, lc.wt(nxt.w_in, (0, e)), e, e)
-            P.store(3, lc.dpos(g_x3), e, accum=True)
+            with P.only(0):
+                P.store(3, lc.dpos(g_x3), e, accum=True)        # (an accumulating store: exactly one workgroup)
             P.load(4, g_x3, e)
             P.add(3, 3, 4, e)
         else:
             P.load(3, g_x3, e)
         P.load(4, sum3, e)
         P.ln_bwd(0, 3, 4, g3, stats3, e, partial=part_ln3)              # ds3 -> slot 0
-        P.store(0, ds3, e)
-        P.colsum(0, part_b, e, e)
+        with P.only(0):
+            P.store(0, ds3, e)
+            P.colsum(0, part_b, e, e)
         w2t, w1t = lc.wt(w2), lc.wt(w1)                         # (f, e) and (e, f)
-        if fused_ffn:
+        if split:
+            parts = torch.empty((S, m, e), **f32)
+            P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part_b, partial_col0=3 * e, sliced=True)
+            P.store_part(1, parts, e)
+            P.run()
+            P = Program(m, lc.q, lc.eps, lc.wdt, 'B2.bwd')
+            P.sum_parts(1, parts, e)
+            P.load(0, ds3, e)
+        elif fused_ffn:
             P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part_b, partial_col0=3 * e)
         else:
             ch = 256
@@ -673,6 +751,12 @@ class _DecB(torch.autograd.Function):
             gnb = _partial_grad(nb_in, (0, e), part_b, 0, e, ni[17])
         return (None, None, None, ds2.view(ctx.in_shapes[0]), g_o2.view(ctx.in_shapes[1]), None, gwo, gbo, gg2, gb2, gw1, gbb1, gw2, gbb2, gg3,
                 gb3, gnw, gnb)
+
+
+def ffn_split(f: int, e: int, dt: torch.dtype) -> int:
+    """Workgroups per row block of the decoder MLP's split launches (1: the one-workgroup stage / the staged f32 form)."""
+    fused = dt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+    return f // 256 if (fused and os.environ.get('MBV_RC_SPLIT', '1') != '0') else 1
 
 
 def enabled() -> bool:

@@ -502,17 +502,19 @@ class Mask2FormerHead(nn.Module):
         # the chains' GEMM operands (fragment-major 16-bit copies; with a graph also the transposed ones for the data
         # gradients): one grouped launch per step
         ents = [(self.cls_embed.weight, None, False)] + [(self.mask_embed[j].weight, None, False) for j in (0, 2, 4)]
+        # (the MLP's second weight — forward W2, backward W1^T — in k-major block order when its stage is split over CUs)
+        km = DF.ffn_split(layers[0].ffn.layers[0][0].out_features, e, dt) > 1
         for i, layer in enumerate(layers):
             ca, sa = layer.cross_attn.attn, layer.self_attn.attn
             fc1, fc2 = layer.ffn.layers[0][0], layer.ffn.layers[1]
             ents += [(ca.out_proj.weight, None, False), (sa.in_proj_weight, None, False), (sa.out_proj.weight, None, False),
-                     (fc1.weight, None, False), (fc2.weight, None, False)]
+                     (fc1.weight, None, False), (fc2.weight, None, False, km)]
             if i > 0:
                 ents.append((ca.in_proj_weight, None, False))
             if need_grad:
                 ents += [(ca.out_proj.weight, None, True), (sa.in_proj_weight, (0, e), True),
                          (sa.in_proj_weight, (e, 2 * e), True), (sa.in_proj_weight, (2 * e, 3 * e), True),
-                         (sa.out_proj.weight, None, True), (fc1.weight, None, True), (fc2.weight, None, True)]
+                         (sa.out_proj.weight, None, True), (fc1.weight, None, True, km), (fc2.weight, None, True)]
                 if i > 0:
                     ents.append((ca.in_proj_weight, (0, e), True))
         tw.refresh(ents, dt)

@@ -203,6 +203,102 @@ def test_rowchain_ffn_stage(wdt, rows, e, f):
     assert bool((part[:, :8] == 9.0).all())
 
 
+@pytest.mark.parametrize('wdt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('rows,e,f', [(400, 256, 2048), (37, 160, 512), (16, 32, 256)])
+def test_rowchain_split_launch(wdt, rows, e, f):
+    """A split launch (f / 256 workgroups per row block: MBV_RC_SLICE, MBV_RC_SPLIT, stage owners) followed by the launch
+    that adds the parts (MBV_RC_SUM) equals the one-workgroup MLP stage: same hidden activations bit for bit, the output up
+    to the summation order of the partial products; forward and backward.  Stages with an owner run once: the ACCUM
+    store of workgroup 1 adds exactly once, the GEMMs of workgroups 0 and 2 see their own operands (the prefetch chain
+    steps over stages that belong to other workgroups)."""
+    from mask_bev_amd import decoder_fused as DF
+    dev = torch.device('cuda', 0)
+    S = f // 256
+    x = _r((rows, e), 41)
+    w1, b1 = _r((f, e), 42, 0.1), _r((f,), 43)
+    w2, b2 = _r((e, f), 44, 0.05), _r((e,), 45)
+    wa, wb = _r((e, e), 46, 0.1).to(wdt), _r((e, e), 47, 0.1).to(wdt)
+    fa, fb = DF.fragment_copy(wa), DF.fragment_copy(wb)
+    w1c, w2c = DF.fragment_copy(w1.to(wdt)), DF.fragment_copy(w2.to(wdt))
+
+    def one(split):
+        hid = torch.full((rows, f), -7.0, device=dev)
+        y = torch.empty((rows, e), device=dev)
+        ga, gb = torch.empty((rows, e), device=dev), torch.empty((rows, e), device=dev)
+        acc = torch.ones((rows, e), device=dev)
+        if split == 1:
+            P = DF.Program(rows, rows, 1e-5, wdt)
+            P.load(0, x, e)
+            P.gemm(2, 0, fa, e, e, out=ga)
+            P.store(0, acc, e, accum=True)
+            P.gemm(3, 0, fb, e, e, out=gb)
+            P.ffn(1, 0, 2, w1c, w2c, e, f, hid, bias_a=b1, bias_out=b2)
+            P.store(1, y, e)
+            P.run()
+        else:
+            parts = torch.full((split, rows, e), float('nan'), device=dev)
+            P = DF.Program(rows, rows, 1e-5, wdt, split=split)
+            P.load(0, x, e)
+            with P.only(0):
+                P.gemm(2, 0, fa, e, e, out=ga)
+            with P.only(min(1, split - 1)):
+                P.store(0, acc, e, accum=True)
+            with P.only(split - 1):
+                P.gemm(3, 0, fb, e, e, out=gb)
+            P.ffn(1, 0, 2, w1c, DF.fragment_copy(w2.to(wdt), kmajor=True), e, f, hid, bias_a=b1, bias_out=b2, sliced=True)
+            P.store_part(1, parts, e)
+            P.run()
+            P = DF.Program(rows, rows, 1e-5, wdt)
+            P.sum_parts(1, parts, e)
+            P.store(1, y, e)
+            P.run()
+        torch.cuda.synchronize()
+        return hid, y, ga, gb, acc
+
+    ref, got = one(1), one(S)
+    assert torch.equal(ref[0], got[0])                                   # hidden activations
+    assert float((ref[1] - got[1]).abs().max()) < 1e-5 * float(ref[1].abs().max())
+    assert torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3]) and torch.equal(ref[4], got[4])
+    # backward
+    hid = ref[0]
+    g = _r((rows, e), 48)
+    nblk = (rows + 15) // 16
+    w2t, w1t = DF.fragment_copy(w2.to(wdt), transposed=True), DF.fragment_copy(w1.to(wdt), transposed=True)
+
+    def bwd(split):
+        dh = torch.full((rows, f), -7.0, device=dev)
+        part = torch.full((nblk, f), 9.0, device=dev)
+        csum = torch.full((nblk, e), 9.0, device=dev)
+        dx = torch.empty((rows, e), device=dev)
+        if split == 1:
+            P = DF.Program(rows, rows, 1e-5, wdt)
+            P.load(0, g, e)
+            P.colsum(0, csum, e)
+            P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part)
+            P.store(1, dx, e)
+            P.run()
+        else:
+            parts = torch.full((split, rows, e), float('nan'), device=dev)
+            P = DF.Program(rows, rows, 1e-5, wdt, split=split)
+            P.load(0, g, e)
+            with P.only(0):
+                P.colsum(0, csum, e)
+            P.ffn(1, 0, 2, w2t, DF.fragment_copy(w1.to(wdt), transposed=True, kmajor=True), e, f, hid, backward=True, d_hid=dh,
+                  partial=part, sliced=True)
+            P.store_part(1, parts, e)
+            P.run()
+            P = DF.Program(rows, rows, 1e-5, wdt)
+            P.sum_parts(1, parts, e)
+            P.store(1, dx, e)
+            P.run()
+        torch.cuda.synchronize()
+        return dh, part, csum, dx
+
+    ref, got = bwd(1), bwd(S)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+    assert float((ref[3] - got[3]).abs().max()) < 1e-5 * float(ref[3].abs().max())
+
+
 def test_rowchain_rejects_bad_programs():
     from mask_bev_amd import decoder_fused as DF
     from mask_bev_amd._lib import MaskBevHipError
@@ -239,6 +335,9 @@ def test_fragment_group_layout(shape):
     r, c = shape
     w = _r((r, c), 5).to(torch.bfloat16)
     assert torch.equal(DF.fragment_copy(w).t, _fragment_layout(w))
+    tn, kbn = (r + 15) // 16, c // 32                            # k-major: block (t, kb) at kb * tn + t
+    km = _fragment_layout(w).view(tn, kbn, 512).transpose(0, 1).reshape(-1)
+    assert torch.equal(DF.fragment_copy(w, kmajor=True).t, km)
     wt = _r((c, r), 6).to(torch.bfloat16)                      # logical W = wt^T
     assert torch.equal(DF.fragment_copy(wt, transposed=True).t, _fragment_layout(wt.t().contiguous()))
     big = _r((r + 3, c + 5), 7).to(torch.bfloat16)             # a view with an odd pitch and an odd start
