@@ -288,7 +288,8 @@ class _DeferredHeads(torch.autograd.Function):
         dl.copy_(full.permute(1, 0, 2, 3))
         dl = dl.view(b, nd * q, hw)
         # re-evaluate the small head on all D*B*Q rows with a graph, in the per-layer forward's precision
-        small = b * q * c <= ops._SMALL_F32_ROWS * c
+        # (the row-chain decoder evaluates its heads with 16-bit operands whatever the row count: so does this)
+        small = b * q * c <= ops._SMALL_F32_ROWS * c and not getattr(head, '_deferred_lowp_heads', False)
         adt = head._deferred_autocast
         with torch.enable_grad(), torch.autocast('cuda', dtype=adt or torch.bfloat16,
                                                  enabled=(adt is not None) and not small, cache_enabled=False):
@@ -462,6 +463,7 @@ class Mask2FormerHead(nn.Module):
             cls_list.append(cls_pred)
             mask_list.append(mask_pred)
         if deferred:
+            self._deferred_lowp_heads = False
             self._deferred_autocast = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None
             outs = _DeferredHeads.apply(self, torch.stack(cls_list, 0), mask_features, *feats_q)
             cls_list, mask_list = list(outs[0].unbind(0)), list(outs[1:])
@@ -555,6 +557,7 @@ class Mask2FormerHead(nn.Module):
                 cls_list.append(cls_pred)
                 mask_list.append(mask_pred)
         if deferred:
+            self._deferred_lowp_heads = dt != torch.float32
             self._deferred_autocast = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None
             outs = _DeferredHeads.apply(self, torch.stack(cls_list, 0), mask_features, *feats_q)
             cls_list, mask_list = list(outs[0].unbind(0)), list(outs[1:])

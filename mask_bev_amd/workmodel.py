@@ -79,7 +79,21 @@ def _rowchain(a) -> Work:
         elif st.op == 7:                    # FFN pair: both weights once, the hidden activations (and their gradient)
             by += 2.0 * st.n * st.k * wes + rows * st.k * 4.0 * (2.0 if st.flags & 16 else 1.0)
             fl += 4.0 * rows * st.n * st.k
+        elif st.op == 9:                    # SUM of a split launch's parts
+            by += rows * st.n * 4.0 * st.k
     return ('k_rowchain', 'hbm', by, fl)
+
+
+def _rowchain_split(a) -> Work:
+    """The split form: the same stage list (a stage runs once whoever owns it; stages without an owner are REPEATED in
+    every workgroup of a row block, which is not algorithmic work); MBV_RC_SPLIT stores write one part per workgroup."""
+    name, bound, by, fl = _rowchain(a)
+    stages, n, rows, split = a[0], _i(a[1]), _i(a[2]), _i(a[6])
+    for i in range(n):
+        st = stages[i]
+        if st.op == 1 and (st.flags & 64):
+            by += rows * st.n * 4.0 * (split - 1)
+    return (name, bound, by, fl)
 
 
 def _point_rows(rows: int, pts: int) -> float:
@@ -197,6 +211,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
     'mbv_ms_deform_attn_bwd_value_packed': _msda_value_packed,
     'mbv_rowchain_run': _rowchain,
+    'mbv_rowchain_run_split': _rowchain_split,
     'mbv_attn_fwd': lambda a: _attn(a, False, False),
     'mbv_attn_fwd_ld': lambda a: _attn(a, False, True),
     'mbv_attn_bwd': lambda a: _attn(a, True, False),
