@@ -62,25 +62,32 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float*
     a.bias_correction1 = (float)(1.0 - pow((double)a.beta1, t));
     a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
   }
+  // Streaming accesses: every array is read once and written once per step and is far larger than the caches (6.8 GB at the
+  // bench size), so loads and stores carry the non-temporal hint — 1.33 -> 1.25 ms measured; a second row per thread in
+  // flight was slower (1.37 ms).
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned short us4 __attribute__((ext_vector_type(4)));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 p = reinterpret_cast<float4*>(param)[i];
-    const float4 g = reinterpret_cast<const float4*>(grad)[i];
-    float4 m = reinterpret_cast<float4*>(exp_avg)[i];
-    float4 v = reinterpret_cast<float4*>(exp_avg_sq)[i];
-    adam_one(p.x, g.x, m.x, v.x, a);
-    adam_one(p.y, g.y, m.y, v.y, a);
-    adam_one(p.z, g.z, m.z, v.z, a);
-    adam_one(p.w, g.w, m.w, v.w, a);
-    reinterpret_cast<float4*>(param)[i] = p;
-    reinterpret_cast<float4*>(exp_avg)[i] = m;
-    reinterpret_cast<float4*>(exp_avg_sq)[i] = v;
+    f4 p = __builtin_nontemporal_load(reinterpret_cast<const f4*>(param) + i);
+    const f4 g = __builtin_nontemporal_load(reinterpret_cast<const f4*>(grad) + i);
+    f4 m = __builtin_nontemporal_load(reinterpret_cast<const f4*>(exp_avg) + i);
+    f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(exp_avg_sq) + i);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float pc = p[c], mc = m[c], vc = v[c];
+      adam_one(pc, g[c], mc, vc, a);
+      p[c] = pc; m[c] = mc; v[c] = vc;
+    }
+    __builtin_nontemporal_store(p, reinterpret_cast<f4*>(param) + i);
+    __builtin_nontemporal_store(m, reinterpret_cast<f4*>(exp_avg) + i);
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(exp_avg_sq) + i);
     if (shadow) {
-      ushort4 s;
+      us4 s;
       s.x = shadow_bits(p.x, a.shadow_kind); s.y = shadow_bits(p.y, a.shadow_kind);
       s.z = shadow_bits(p.z, a.shadow_kind); s.w = shadow_bits(p.w, a.shadow_kind);
-      reinterpret_cast<ushort4*>(shadow)[i] = s;
+      reinterpret_cast<us4*>(shadow)[i] = s;              // (read again by the next forward: a normal store)
     }
-    if (a.zero_grad) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.zero_grad) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f4*>(grad) + i);
   }
   // ragged tail (< 4 elements)
   const long t = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
