@@ -1572,7 +1572,24 @@ class _SharedKVProject(torch.autograd.Function):
             grads[1] = dk2.mm(wk).view_as(key_in)
         if ctx.needs_input_grad[2]:
             grads[2] = dv2.mm(wv).view_as(val_in).to(val_in.dtype)
-        # weight / bias gradients of all n layers: one f32-accumulating GEMM and one column-sum pass per operand ...
+        # weight / bias gradients.  Arena parameters: every layer's k / v rows take their product straight into the
+        # gradient rows (strided column blocks of dk_cat / dv_cat; the 16-bit products and the column sums join the
+        # grouped launches at the end of the pass) — per level that was 2 fills, 2 GEMMs + 2 part sums, 2 column sums
+        # and a multi-tensor add: 9 launches of 5-20 us.
+        def _arena(p):
+            return getattr(p, '_mbv_arena', False) and p.grad is not None and p.grad.dtype == torch.float32
+        if (os.environ.get('MBV_SKV_DIRECT', '1') != '0'
+                and all(_arena(ctx.params[i]) and ctx.needs_input_grad[3 + i] for i in range(2 * n))):
+            for j in range(n):
+                w, b_ = ctx.params[2 * j], ctx.params[2 * j + 1]
+                for g2, x2, r0 in ((dk2, key2, e), (dv2, val2, 2 * e)):
+                    _wgrad_into(w.grad[r0:r0 + e], g2[:, j * e:(j + 1) * e], x2, None, persistent=True)
+                    if not _defer_colsum(g2, b_.grad[r0:r0 + e], t, e, n * e, offset=j * e):
+                        _colsum_now(g2, b_.grad[r0:r0 + e], t, e, n * e, offset=j * e)
+                _fire_grad_hooks(w)
+                _fire_grad_hooks(b_)
+            return tuple(grads)
+        # ... otherwise: one f32-accumulating GEMM and one column-sum pass per operand ...
         gw = torch.zeros((2, n * e, e), dtype=torch.float32, device=dk.device)
         gb = torch.zeros((2, n * e), dtype=torch.float32, device=dk.device)
         _wgrad_into(gw[0], dk2, key2)

@@ -58,8 +58,9 @@ def test_attention_fwd_bwd(device, B, Q, L, heads, D, masked, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('arena', [False, True])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
-def test_shared_kv_attention_equals_separate_projections(device, dt):
+def test_shared_kv_attention_equals_separate_projections(device, dt, arena):
     """ops.shared_kv_project + attention_shared_kv (one key GEMM and one value GEMM for three layers, K6 reading and
     writing columns of the shared matrices in place) vs three independent linear → attention chains: outputs and the
     gradients of the memory, the queries and the packed in_proj parameters."""
@@ -80,6 +81,13 @@ def test_shared_kv_attention_equals_separate_projections(device, dt):
         q_l = [q.clone().requires_grad_() for q in qs]
         for p in ws + bs:
             p.grad = None
+            p._mbv_arena = False
+        if shared and arena:
+            # arena parameters: f32 gradients that exist before the pass and ACCUMULATE (start them at 1.0) — the k / v rows
+            # take their products in place, the 16-bit ones through the grouped launch at the end of the pass
+            for p in ws + bs:
+                p.grad = torch.ones_like(p, dtype=torch.float32)
+                p._mbv_arena = True
         outs = []
         if shared:
             holder, token = ops.shared_kv_project(k_in, v_in, list(zip(ws, bs)))
@@ -91,8 +99,10 @@ def test_shared_kv_attention_equals_separate_projections(device, dt):
                 v = torch.nn.functional.linear(v_in, ws[j][2 * E:].to(dt), bs[j][2 * E:].to(dt))
                 outs.append(ops.attention(q_l[j], k, v, blocked, H))
         torch.autograd.backward(outs, [g.to(o.dtype) for g, o in zip(gos, outs)])
+        torch.cuda.synchronize()
+        off = 1.0 if (shared and arena) else 0.0
         return ([o.detach().float() for o in outs], k_in.grad.float(), v_in.grad.float(), [q.grad.float() for q in q_l],
-                [w.grad.clone() for w in ws], [b.grad.clone() for b in bs])
+                [w.grad.clone() - off for w in ws], [b.grad.clone() - off for b in bs])
 
     a, b = run(True), run(False)
     tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
