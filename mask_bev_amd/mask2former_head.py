@@ -394,19 +394,19 @@ class Mask2FormerHead(nn.Module):
     def forward(self, x: List[torch.Tensor], batch_data_samples=None):
         bs = x[0].shape[0]
         mask_features, memories = self.pixel_decoder(x)
-        dec_in, dec_pos = [], []
+        dec_in, dec_pos, dec_key = [], [], []
+        # key = memory + pos, shared by the 3 layers of a level; under autocast one cast per level instead of one per
+        # (layer, projection): the K / V GEMMs read these copies
+        adt = (torch.get_autocast_dtype('cuda') if (torch.is_autocast_enabled('cuda') and memories[0].is_cuda)
+               else memories[0].dtype)
         for i in range(self.num_transformer_feat_level):
             m = memories[i]
             h, w = m.shape[-2:]
-            dec_in.append(m.flatten(2).transpose(1, 2) + self.level_embed.weight[i].view(1, 1, -1))
             dec_pos.append(sine_positional_encoding(h, w, self.decoder_embed_dims // 2, m.device)
                            .flatten(2).transpose(1, 2))
-        dec_key = [a + b for a, b in zip(dec_in, dec_pos)]     # key = memory + pos, shared by the 3 layers of a level
-        if torch.is_autocast_enabled('cuda') and dec_in[0].is_cuda:
-            # one cast per level instead of one per (layer, projection): the K / V GEMMs read these copies
-            adt = torch.get_autocast_dtype('cuda')
-            dec_in = [t.to(adt) for t in dec_in]
-            dec_key = [t.to(adt) for t in dec_key]
+            a, k = ops.level_inputs(m, self.level_embed.weight, i, dec_pos[-1], adt)
+            dec_in.append(a)
+            dec_key.append(k)
         query_feat = self.query_feat.weight.unsqueeze(0).expand(bs, -1, -1)
         query_embed = self.query_embed.weight.unsqueeze(0).expand(bs, -1, -1)
         cls_list, mask_list = [], []

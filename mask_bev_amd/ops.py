@@ -1620,6 +1620,51 @@ class _SharedKVProject(torch.autograd.Function):
         return tuple(grads)
 
 
+class _LevelInputs(torch.autograd.Function):
+    """Decoder inputs of one memory level: ``value = tokens(memory) + level_row`` and ``key = value + pos`` in the compute
+    dtype (mask2former_head.py:518-527: flatten + level_embed add, + positional encoding in the layer).  One node instead
+    of add / add / cast / cast: its backward is one sum of the two 16-bit gradients and a column sum into the embedding
+    row — autograd's version was 2 casts, 2 adds, a two-stage ``sum`` with a device memset, ``select_backward``'s zeros +
+    copy and an ``add_`` per level, several of them blit nodes with 15-60 us of idle stream around them in a graph."""
+
+    @staticmethod
+    def forward(ctx, memory, level_weight, index, pos, dtype):
+        b, c = memory.shape[:2]
+        x = memory.flatten(2).transpose(1, 2) + level_weight[index].view(1, 1, -1)        # (B, L, C) f32
+        key = x + pos
+        ctx.index, ctx.mem_shape, ctx.mem_dtype = index, memory.shape, memory.dtype
+        ctx.level_weight = level_weight
+        return x.to(dtype), key.to(dtype)
+
+    @staticmethod
+    def backward(ctx, g_in, g_key):
+        w, i = ctx.level_weight, ctx.index
+        b, c = ctx.mem_shape[:2]
+        if g_in is None and g_key is None:
+            return None, None, None, None, None
+        if g_in is None or g_key is None:
+            g = (g_in if g_key is None else g_key).float()
+        else:
+            g = torch.add(g_in.float(), g_key)                         # (B, L, C) f32
+        g_mem = g.transpose(1, 2).reshape(ctx.mem_shape).to(ctx.mem_dtype) if ctx.needs_input_grad[0] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            g2 = g.reshape(-1, c)
+            if getattr(w, '_mbv_arena', False) and w.grad is not None and w.grad.dtype == torch.float32 and g2.is_cuda:
+                colsum_accum(g2, w.grad[i], persistent=True)
+                _fire_grad_hooks(w)
+            else:
+                g_w = torch.zeros_like(w)
+                g_w[i] = g2.sum(0).to(w.dtype)
+        return g_mem, g_w, None, None, None
+
+
+def level_inputs(memory: torch.Tensor, level_weight: torch.Tensor, index: int, pos: torch.Tensor, dtype: torch.dtype):
+    """(value tokens, key tokens) of memory level ``index`` in ``dtype``: memory (B, C, H, W), level_weight (levels, C),
+    pos (1 or B, H*W, C)."""
+    return _LevelInputs.apply(memory, level_weight, index, pos, dtype)
+
+
 def shared_kv_project(key_in: torch.Tensor, val_in: torch.Tensor, packed_params) -> tuple:
     """``packed_params``: [(in_proj_weight (3E, E), in_proj_bias (3E,)), ...] of the layers that attend to this memory.
     Returns (holder, token) for :func:`attention_shared_kv`."""

@@ -340,3 +340,25 @@ def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
         assert r['traffic'] >= 0.9 * r['algorithmic_bytes'], (r['kernel'], r['traffic'], r['algorithmic_bytes'])
         checked += 1
     assert checked >= 20
+
+
+def test_level_inputs_node_equals_the_plain_ops():
+    """ops.level_inputs (one autograd node for flatten + level-embedding add + positional add + casts,
+    mask2former_head.py:518-527) against the four plain ops, values and gradients (CPU: the non-arena branch)."""
+    import torch
+    from mask_bev_amd import ops
+    torch.manual_seed(3)
+    mem = torch.randn(2, 8, 3, 5, requires_grad=True)
+    lw = torch.randn(3, 8, requires_grad=True)
+    pos = torch.randn(1, 15, 8)
+    a, k = ops.level_inputs(mem, lw, 1, pos, torch.float32)
+    ga, gk = torch.randn_like(a), torch.randn_like(k)
+    torch.autograd.backward([a, k], [ga, gk])
+    g_mem, g_lw = mem.grad.clone(), lw.grad.clone()
+    mem.grad = lw.grad = None
+    a2 = mem.flatten(2).transpose(1, 2) + lw[1].view(1, 1, -1)
+    k2 = a2 + pos
+    torch.autograd.backward([a2, k2], [ga, gk])
+    assert torch.equal(a, a2) and torch.equal(k, k2)
+    assert torch.allclose(g_mem, mem.grad, atol=1e-6) and torch.allclose(g_lw, lw.grad, atol=1e-5)
+    assert float(g_lw[0].abs().max()) == 0.0 and float(g_lw[2].abs().max()) == 0.0
