@@ -103,7 +103,7 @@ class Program:
         class _Only:
             def __enter__(self_inner):
                 self_inner.prev = prog.owner
-                prog.owner = j if prog.split > 1 else None
+                prog.owner = (j % prog.split) if prog.split > 1 else None
 
             def __exit__(self_inner, *exc):
                 prog.owner = self_inner.prev
@@ -436,22 +436,29 @@ class _DecA(torch.autograd.Function):
         # 26 backward, 14 -> 8 forward, for 100 x 100 scores per head — like the per-op path's
         qkv = torch.empty((3, m, e), dtype=lc.dt, device=dev)
         w_o, w_i = lc.w(wo), lc.w(w_in)
-        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.fwd')
+        # three workgroups per row block: each one of the q / k / v projections and a share of the stores
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.fwd', split=spread(3))
         P.load(0, o1, e)
         o1f = o1
         if o1.dtype != torch.float32:         # an f32 copy for the weight gradient of the output projection (one STORE
             o1f = torch.empty((m, e), **f32)  # stage here instead of a conversion launch per layer in the backward pass)
-            P.store(0, o1f, e)
+            with P.only(0):
+                P.store(0, o1f, e)
         P.gemm(1, 0, w_o, e, e, bias=bo)
         P.load(2, x0, e)
         P.ln(3, 2, 1, g1, b1, e, stats=stats1, save_sum=True)
-        P.store(2, sum1, e)
-        P.store(3, x1, e)
+        with P.only(2):
+            P.store(2, sum1, e)
+            P.store(3, x1, e)
         P.load_slot_plus(0, 3, lc.qpos, e)                      # x1 + positions: the q / k input
-        P.store(0, t1, e)
-        P.gemm(1, 0, w_i, e, e, bias=b_in, row0=0, bias0=0, out=qkv[0])
-        P.gemm(2, 0, w_i, e, e, bias=b_in, row0=e, bias0=e, out=qkv[1])
-        P.gemm(4, 3, w_i, e, e, bias=b_in, row0=2 * e, bias0=2 * e, out=qkv[2])      # (row offsets: multiples of 16)
+        with P.only(1):
+            P.store(0, t1, e)
+        with P.only(0):
+            P.gemm(1, 0, w_i, e, e, bias=b_in, row0=0, bias0=0, out=qkv[0])
+        with P.only(1):
+            P.gemm(2, 0, w_i, e, e, bias=b_in, row0=e, bias0=e, out=qkv[1])
+        with P.only(2):
+            P.gemm(4, 3, w_i, e, e, bias=b_in, row0=2 * e, bias0=2 * e, out=qkv[2])      # (row offsets: multiples of 16)
         P.run()
         o2, lse = _self_attention_fwd(qkv[0], qkv[1], qkv[2], lc.b, lc.q, lc.h)
         ctx.lc = lc
@@ -487,24 +494,31 @@ class _DecA(torch.autograd.Function):
         ds1 = torch.empty((m, e), **f32)
         g_o1 = torch.empty((m, e), dtype=ctx.o1_dtype, device=dev)
         tw = lc.tw
-        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.bwd')
+        # two workgroups per row block: one takes the last product, the other the column sums and the stores
+        P = Program(m, lc.q, lc.eps, lc.wdt, 'A.bwd', split=spread(2))
         P.load(0, g_qkv[0], e)
-        P.colsum(0, part_b, e, 0)
+        with P.only(1):
+            P.colsum(0, part_b, e, 0)
         P.gemm(1, 0, lc.wt(w_in, (0, e)), e, e)
         P.load(2, g_qkv[1], e)
-        P.colsum(2, part_b, e, e)
+        with P.only(1):
+            P.colsum(2, part_b, e, e)
         P.gemm(1, 2, lc.wt(w_in, (e, 2 * e)), e, e, accum=True)
-        P.store(1, lc.dpos(g_x1), e, accum=True)                # d(positions) of this layer's self-attention
+        with P.only(1):
+            P.store(1, lc.dpos(g_x1), e, accum=True)            # d(positions) of this layer's self-attention (ONE workgroup)
         P.load(3, g_qkv[2], e)
-        P.colsum(3, part_b, e, 2 * e)
+        with P.only(1):
+            P.colsum(3, part_b, e, 2 * e)
         P.gemm(1, 3, lc.wt(w_in, (2 * e, 3 * e)), e, e, accum=True)
         P.load(4, g_x1, e)
         P.add(1, 1, 4, e)
         P.load(5, sum1, e)
         P.ln_bwd(6, 1, 5, g1, stats1, e, partial=part_ln)
-        P.store(6, ds1, e)
-        P.colsum(6, part_b, e, 3 * e)
-        P.gemm(0, 6, lc.wt(wo), e, e, out=g_o1)
+        with P.only(1):
+            P.store(6, ds1, e)
+            P.colsum(6, part_b, e, 3 * e)
+        with P.only(0):
+            P.gemm(0, 6, lc.wt(wo), e, e, out=g_o1)
         P.run()
         ni = ctx.needs_input_grad
         gw_in = _sum_grads(_sum_grads(_weight_grad(w_in, (0, e), g_qkv[0], t1, ni[7]),
@@ -574,8 +588,9 @@ class _DecB(torch.autograd.Function):
         P.gemm(3, 2, w_o, e, e, bias=bo)
         P.load(4, x1, e)
         P.ln(0, 4, 3, g2, b2, e, stats=stats2, save_sum=True)          # x2 -> slot 0
-        with P.only(0):
+        with P.only(1):
             P.store(4, sum2, e)
+        with P.only(2):
             P.store(0, x2, e)
         if split:
             parts = torch.empty((S, m, e), **f32)
@@ -694,10 +709,10 @@ class _DecB(torch.autograd.Function):
         P = Program(m, lc.q, lc.eps, lc.wdt, 'B1.bwd' if split else 'B.bwd', split=S)
         if g_qc is not None:
             P.load(2, g_qc, e)
-            with P.only(0):
+            with P.only(1):
                 P.colsum(2, part_b, e, 0)
             P.gemm(3, 2, lc.wt(nxt.w_in, (0, e)), e, e)
-            with P.only(0):
+            with P.only(2):
                 P.store(3, lc.dpos(g_x3), e, accum=True)        # (an accumulating store: exactly one workgroup)
             P.load(4, g_x3, e)
             P.add(3, 3, 4, e)
@@ -705,8 +720,9 @@ class _DecB(torch.autograd.Function):
             P.load(3, g_x3, e)
         P.load(4, sum3, e)
         P.ln_bwd(0, 3, 4, g3, stats3, e, partial=part_ln3)              # ds3 -> slot 0
-        with P.only(0):
+        with P.only(3):
             P.store(0, ds3, e)
+        with P.only(4):
             P.colsum(0, part_b, e, e)
         w2t, w1t = lc.wt(w2), lc.wt(w1)                         # (f, e) and (e, f)
         if split:
@@ -714,7 +730,7 @@ class _DecB(torch.autograd.Function):
             P.ffn(1, 0, 2, w2t, w1t, e, f, hid, backward=True, d_hid=dh, partial=part_b, partial_col0=3 * e, sliced=True)
             P.store_part(1, parts, e)
             P.run()
-            P = Program(m, lc.q, lc.eps, lc.wdt, 'B2.bwd')
+            P = Program(m, lc.q, lc.eps, lc.wdt, 'B2.bwd', split=spread(2))
             P.sum_parts(1, parts, e)
             P.load(0, ds3, e)
         elif fused_ffn:
@@ -730,9 +746,11 @@ class _DecB(torch.autograd.Function):
         P.add(1, 1, 0, e)
         P.load(2, sum2, e)
         P.ln_bwd(3, 1, 2, g2, stats2, e, partial=part_ln2)
-        P.store(3, ds2, e)
-        P.colsum(3, part_b, e, 2 * e)
-        P.gemm(4, 3, lc.wt(wo), e, e, out=g_o2)
+        with P.only(1):
+            P.store(3, ds2, e)
+            P.colsum(3, part_b, e, 2 * e)
+        with P.only(0):
+            P.gemm(4, 3, lc.wt(wo), e, e, out=g_o2)
         P.run()
         ni = ctx.needs_input_grad         # lc, head, nxt, x1, o2, token, wo, bo, g2, b2, w1, bb1, w2, bb2, g3, b3, nw_in, nb_in
         gwo = _weight_grad(wo, None, ds2, o2, ni[6])
@@ -751,6 +769,14 @@ class _DecB(torch.autograd.Function):
             gnb = _partial_grad(nb_in, (0, e), part_b, 0, e, ni[17])
         return (None, None, None, ds2.view(ctx.in_shapes[0]), g_o2.view(ctx.in_shapes[1]), None, gwo, gbo, gg2, gb2, gw1, gbb1, gw2, gbb2, gg3,
                 gb3, gnw, gnb)
+
+
+def spread(n: int) -> int:
+    """Workgroups per row block of the programs WITHOUT a sliced stage (``n`` asked for): stores, column sums and
+    independent products move to different workgroups of the block, every workgroup repeating the stages they depend
+    on — a 128 KB weight block is ~2 us of one CU's L2 bandwidth, a store stage ~1.2 us, and 231 CUs are idle.
+    MBV_RC_SPREAD=0: one workgroup per block (A/B)."""
+    return n if os.environ.get('MBV_RC_SPREAD', '1') != '0' else 1
 
 
 def ffn_split(f: int, e: int, dt: torch.dtype) -> int:
