@@ -302,7 +302,6 @@ __global__ void __launch_bounds__(kFusedThreads, RNG ? 8 : 4) k_sample_select(co
   }
   // -- compaction in index order: element (chunk j, thread t) has index j * kFusedThreads + t
   const uint32_t T = prefix;
-  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) {
     const unsigned long long m_lt = __ballot(keys[j] < T), m_eq = __ballot(keys[j] == T && T != 0xffffffffu);
@@ -347,13 +346,28 @@ __global__ void __launch_bounds__(kFusedThreads, RNG ? 8 : 4) k_sample_select(co
 #pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) asm volatile("" : "+v"(keys[j]));   // (no reuse of the count loop's 80 masks)
   uint32_t* sel = reinterpret_cast<uint32_t*>(tile);      // k <= 16 384 positions (checked by the host entry)
+  // selected elements in front of chunk (j, wave): all smaller keys + the threshold-equal ones still taken; lane j of a
+  // wave keeps its wave's entry of chunk j (one LDS read per lane, one v_readlane per chunk below)
+  int my_base = 0, my_eq = 0;
+  if (lane < kKeysPerThread) {
+    my_eq = cnt_eq[lane * kFusedWaves + wave];
+    my_base = cnt_lt[lane * kFusedWaves + wave] + min(krem, my_eq);
+  }
 #pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) {
-    const bool is_lt = keys[j] < T, is_eq = keys[j] == T && T != 0xffffffffu;
-    const unsigned long long m_lt = __ballot(is_lt), m_eq = __ballot(is_eq);
-    const int lt_before = cnt_lt[j * kFusedWaves + wave] + __popcll(m_lt & below);
-    const int eq_before = cnt_eq[j * kFusedWaves + wave] + __popcll(m_eq & below);
-    if (is_lt || (is_eq && eq_before < krem)) sel[lt_before + min(krem, eq_before)] = (uint32_t)(j * kFusedThreads + tid);
+    const bool is_lt = keys[j] < T;
+    const unsigned long long m_lt = __ballot(is_lt);
+    const unsigned long long m_eq = __ballot(keys[j] == T && T != 0xffffffffu);
+    const int base = __builtin_amdgcn_readlane(my_base, j);
+    int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_lt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_lt, 0u));
+    bool take = is_lt;
+    if (m_eq != 0ull) {                                   // (wave-uniform, rare: a key equal to the threshold in this chunk)
+      const int eq_here = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_eq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_eq, 0u));
+      const int room = max(krem - __builtin_amdgcn_readlane(my_eq, j), 0);      // threshold-equal keys this chunk may still take
+      pos += min(room, eq_here);
+      take = is_lt || (((m_eq >> lane) & 1ull) && eq_here < room);
+    }
+    if (take) sel[pos] = (uint32_t)(j * kFusedThreads + tid);
   }
   __syncthreads();
   {
