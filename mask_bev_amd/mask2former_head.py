@@ -762,10 +762,17 @@ class Mask2FormerHead(nn.Module):
             num_total_masks = self.world_size_fn(num_total_masks)
         num_total_masks = num_total_masks.clamp(min=1.0)[0]
 
-        sums = ops.mask_loss_rows(pred, tgt)              # K13: (D*g, 4) = Σ σ·t, Σ σ, Σ t, Σ bce in one pass
-        dice = (2 * sums[:, 0] + 1.0) / (sums[:, 1] + sums[:, 2] + 1.0)
-        loss_dice = self.loss_dice_weight * (1 - dice).view(d, g).sum(1) / (num_total_masks + eps)
-        loss_mask = self.loss_mask_weight * sums[:, 3].view(d, g).sum(1) / (num_total_masks * p + eps)
+        if pred.is_cuda and os.environ.get('MBV_LOSS_NODE', '1') != '0':
+            # K13's row sums (Σ σ·t, Σ σ, Σ t, Σ bce in one pass) and the dice / BCE algebra on them as one autograd node
+            with torch.no_grad():
+                c_dice = self.loss_dice_weight / (num_total_masks + eps)
+                c_mask = self.loss_mask_weight / (num_total_masks * p + eps)
+            loss_dice, loss_mask = ops.mask_dice_bce(pred, tgt, d, c_dice, c_mask)
+        else:
+            sums = ops.mask_loss_rows(pred, tgt)              # K13: (D*g, 4) = Σ σ·t, Σ σ, Σ t, Σ bce in one pass
+            dice = (2 * sums[:, 0] + 1.0) / (sums[:, 1] + sums[:, 2] + 1.0)
+            loss_dice = self.loss_dice_weight * (1 - dice).view(d, g).sum(1) / (num_total_masks + eps)
+            loss_mask = self.loss_mask_weight * sums[:, 3].view(d, g).sum(1) / (num_total_masks * p + eps)
 
         out = LossDict(loss_cls=loss_cls[-1], loss_mask=loss_mask[-1], loss_dice=loss_dice[-1], loss_height=0)
         for i in range(d - 1):

@@ -2071,6 +2071,61 @@ def mask_loss_rows(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
     return _MaskLossRows.apply(logits, targets)
 
 
+class _MaskDiceBce(torch.autograd.Function):
+    """Dice and BCE losses of D decoder outputs from the point-sampled logits in one node: K13's row sums, then
+    ``dice = (2 Σσt + 1) / (Σσ + Σt + 1)``, ``loss_dice[i] = c_dice Σ_rows (1 - dice)``, ``loss_mask[i] = c_mask Σ_rows Σbce``
+    (mmdet DiceLoss / CrossEntropyLoss(use_sigmoid) as configured at mask2former_head.py:96-110, reduced per decoder
+    output).  Written as ops autograd spends ≈ 30 launches on the backward of this algebra over 4 000-element tensors
+    (slice gradients materialise zeros + copies); here the gradient of the four sums is assembled analytically."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, d, c_dice, c_mask):
+        lib = _lib.load()
+        _need_gpu(logits, targets)
+        x = logits.float().contiguous()
+        t = targets.float().contiguous()
+        if x.shape != t.shape or x.dim() != 2 or x.shape[0] % d:
+            raise MaskBevHipError('mask_dice_bce: (D * g, points) logits and targets')
+        rows = x.shape[0]
+        sums = torch.empty((rows, 4), dtype=torch.float32, device=x.device)
+        check(lib.mbv_mask_loss_rows_fwd(_ptr(x), _ptr(t), rows, x.shape[1], _ptr(sums), _stream()),
+              'mbv_mask_loss_rows_fwd')
+        den = sums[:, 1] + sums[:, 2] + 1.0
+        dice = (2.0 * sums[:, 0] + 1.0) / den
+        loss_dice = (1.0 - dice).view(d, rows // d).sum(1) * c_dice
+        loss_mask = sums[:, 3].reshape(d, rows // d).sum(1) * c_mask
+        ctx.save_for_backward(x, t, den, dice)
+        ctx.consts = (d, c_dice, c_mask)
+        ctx.in_dtype = logits.dtype
+        return loss_dice, loss_mask
+
+    @staticmethod
+    def backward(ctx, g_dice, g_mask):
+        lib = _lib.load()
+        x, t, den, dice = ctx.saved_tensors
+        d, c_dice, c_mask = ctx.consts
+        rows = x.shape[0]
+        g = rows // d
+        zero = None
+        if g_dice is None or g_mask is None:
+            zero = torch.zeros(d, dtype=torch.float32, device=x.device)
+        gd = ((g_dice if g_dice is not None else zero).float() * c_dice).view(d, 1).expand(d, g).reshape(rows)
+        gm = ((g_mask if g_mask is not None else zero).float() * c_mask).view(d, 1).expand(d, g).reshape(rows)
+        r = gd / den
+        g_s12 = r * dice
+        grad_sums = torch.stack((r * -2.0, g_s12, g_s12, gm), 1).contiguous()
+        dx = torch.empty_like(x)
+        check(lib.mbv_mask_loss_rows_bwd(_ptr(x), _ptr(t), _ptr(grad_sums), rows, x.shape[1], _ptr(dx), _stream()),
+              'mbv_mask_loss_rows_bwd')
+        return dx.to(ctx.in_dtype), None, None, None, None
+
+
+def mask_dice_bce(logits: torch.Tensor, targets: torch.Tensor, d: int, c_dice, c_mask):
+    """(D * g, points) sampled logits / targets → (loss_dice (D,), loss_mask (D,)); ``c_dice`` / ``c_mask``: the loss
+    weights over their averaging factors (floats or 0-dim device tensors that need no gradient)."""
+    return _MaskDiceBce.apply(logits, targets, int(d), c_dice, c_mask)
+
+
 # --------------------------------------------------------------------------------------
 # K12 fused residual-add + LayerNorm
 # --------------------------------------------------------------------------------------

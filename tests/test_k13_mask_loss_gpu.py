@@ -37,3 +37,29 @@ def test_match_cost_terms(device):
     assert torch.allclose(terms.double(), want, rtol=2e-6, atol=2e-6)
     assert torch.allclose(sums[..., 0].double(), F.softplus(xd).sum(-1), rtol=1e-5)
     assert torch.allclose(sums[..., 1].double(), xd.sigmoid().sum(-1), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dice_bce_node_equals_the_row_sums_algebra(device):
+    """ops.mask_dice_bce (K13 + the dice / BCE algebra as one autograd node with an analytic gradient of the four sums)
+    against ops.mask_loss_rows followed by the same algebra through autograd: values and the gradient of the logits."""
+    import torch
+    from mask_bev_amd import ops
+    torch.manual_seed(5)
+    d, g, p = 4, 13, 777
+    x = (torch.randn(d * g, p, device=device) * 3).requires_grad_()
+    t = (torch.rand(d * g, p, device=device) > 0.6).float()
+    c_dice = torch.tensor(5.0 / 401.0, device=device)
+    c_mask = 5.0 / (400.0 * p + 1.0)
+    gd, gm = torch.randn(d, device=device), torch.randn(d, device=device)
+    ld, lm = ops.mask_dice_bce(x, t, d, c_dice, c_mask)
+    torch.autograd.backward([ld, lm], [gd, gm])
+    got = x.grad.clone()
+    x.grad = None
+    sums = ops.mask_loss_rows(x, t)
+    dice = (2 * sums[:, 0] + 1.0) / (sums[:, 1] + sums[:, 2] + 1.0)
+    ld2 = (1 - dice).view(d, g).sum(1) * c_dice
+    lm2 = sums[:, 3].view(d, g).sum(1) * c_mask
+    torch.autograd.backward([ld2, lm2], [gd, gm])
+    assert torch.allclose(ld, ld2, rtol=1e-6, atol=1e-7) and torch.allclose(lm, lm2, rtol=1e-6, atol=1e-7)
+    assert float((got - x.grad).abs().max()) <= 1e-6 * float(x.grad.abs().max()) + 1e-12
