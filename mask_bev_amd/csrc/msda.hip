@@ -16,6 +16,15 @@
 
 namespace {
 
+// XCD-aware block order (blocks b and b + 8 share an XCD and its L2): every XCD walks a CONTIGUOUS eighth of the block
+// index.  The gather kernels below index (batch, query, head) linearly and neighbouring queries sample neighbouring
+// value pixels: round-robin, every XCD touched every band of every value map and fetched it for itself (PMC: 135 MB
+// per call for a 22 MB map); contiguous, an XCD's L2 sees half a sample's queries and their band of one map.
+__device__ __forceinline__ int64_t xcd_block(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, x = bid & 7, s = bid >> 3;
+  return (int64_t)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s);
+}
+
 struct Corner {
   int off[4];    // element offset of the 4 corners within the level's (h*w, H, D) slab, -1 = outside
   float wgt[4];  // bilinear weights
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(256) k_msda_fwd_v4(const float* __restrict__ v
                                                      const float* __restrict__ loc, const float* __restrict__ attn,
                                                      int64_t total4, int num_value, int heads, int dim, int levels,
                                                      int num_query, int points, float* __restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const int d4n = dim >> 2;
   const int d4 = (int)(idx % d4n);
@@ -985,7 +994,7 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
                                                           float* __restrict__ grad_attn) {
   constexpr int dim = 32;
   const int stride_pix = heads * dim;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const bool live = idx < total8;                     // total8 is a multiple of 8: a group of 8 lanes is all in or out
   const int64_t sidx = live ? idx : total8 - 1;
   const int d4 = (int)(sidx & 7);
