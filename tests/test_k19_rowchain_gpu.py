@@ -410,3 +410,57 @@ def test_fused_decoder_equals_unfused_path(device, monkeypatch, dtype, arena):
     assert g_f.keys() == g_u.keys()
     worst = max((rel(g_f[k], g_u[k]), k) for k in g_u)
     assert worst[0] < tg, worst
+
+
+def test_fragment_group_more_entries_than_one_launch_takes():
+    """mbv_fragment_group splits its entry list into launches of MBV_TR_MAX (96): 130 small matrices of mixed shapes and
+    orientations in one call (the decoder refreshes 130 copies per step)."""
+    import ctypes
+    from mask_bev_amd import _lib, ops
+    lib = _lib.load()
+    srcs, wants, rows_l, cols_l, tr_l = [], [], [], [], []
+    for i in range(130):
+        r, c = 16 * (1 + i % 5) + (i % 3), 32 * (1 + i % 4)
+        tr = i % 2
+        w = _r((c, r) if tr else (r, c), 100 + i).to(torch.bfloat16)
+        srcs.append(w)
+        wants.append(_fragment_layout(w.t().contiguous() if tr else w))
+        rows_l.append(r); cols_l.append(c); tr_l.append(tr)
+    dsts = [torch.empty_like(w) for w in wants]
+    n = len(srcs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+    ops.check(lib.mbv_fragment_group(PA(*[s.data_ptr() for s in srcs]), PA(*[d.data_ptr() for d in dsts]), IA(*rows_l),
+                                     IA(*cols_l), IA(*[s.stride(0) for s in srcs]), IA(*tr_l), n, ops._stream()),
+              'mbv_fragment_group')
+    torch.cuda.synchronize()
+    for i, (d, w) in enumerate(zip(dsts, wants)):
+        assert torch.equal(d, w), i
+
+
+def test_split_launch_with_an_owned_load_stage():
+    """A LOAD stage (slot + positional rows) owned by one workgroup of a split launch: the others step over it and the
+    operand prefetch chain (next LOAD / next GEMM requested one stage ahead) still hands every stage its own operands."""
+    from mask_bev_amd import decoder_fused as DF
+    dev = torch.device('cuda', 0)
+    rows, e, q, wdt = 90, 64, 30, torch.bfloat16
+    x, pos, x2 = _r((rows, e), 61), _r((q, e), 62), _r((rows, e), 63)
+    fa, fb = DF.fragment_copy(_r((e, e), 64, 0.1).to(wdt)), DF.fragment_copy(_r((e, e), 65, 0.1).to(wdt))
+
+    def run(split):
+        a, b, c = (torch.empty((rows, e), device=dev) for _ in range(3))
+        P = DF.Program(rows, q, 1e-5, wdt, split=split)
+        P.load(0, x, e)
+        with P.only(0):
+            P.load_slot_plus(1, 0, pos, e)          # owned LOAD (slot 0 + positional rows at r % q)
+            P.gemm(2, 1, fa, e, e, out=a)
+        P.load(3, x2, e)                            # a LOAD every workgroup runs, behind the owned one
+        with P.only(1):
+            P.gemm(4, 3, fb, e, e, out=b)
+        with P.only(2):
+            P.gemm(5, 0, fb, e, e, out=c)
+        P.run()
+        torch.cuda.synchronize()
+        return a, b, c
+
+    ref, got = run(1), run(3)
+    assert all(torch.equal(u, v) for u, v in zip(ref, got))

@@ -151,3 +151,33 @@ def test_shared_kv_attention_bench_shape_bf16(device):
         assert torch.equal(dv, v.grad.float().bfloat16().float())
     # the untouched slot of the shared gradient matrices was never written by slots 0 and 2
     assert holder.written == {0, 2}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('arena', [False, True])
+def test_level_inputs_node_on_the_gpu(device, arena):
+    """ops.level_inputs in the compute dtype against the plain ops (flatten + level-embedding row + positions, two casts):
+    values, the memory gradient, and the embedding-row gradient — returned (plain parameter) or accumulated into the arena
+    gradient's row through the grouped column sums."""
+    from mask_bev_amd import ops
+    torch.manual_seed(4)
+    mem = torch.randn(2, 32, 6, 10, device=device, requires_grad=True)
+    lw = torch.randn(3, 32, device=device, requires_grad=True)
+    pos = torch.randn(1, 60, 32, device=device)
+    dt = torch.bfloat16
+    ga, gk = torch.randn(2, 60, 32, device=device).to(dt), torch.randn(2, 60, 32, device=device).to(dt)
+    if arena:
+        lw.grad = torch.ones_like(lw)
+        lw._mbv_arena = True
+    a, k = ops.level_inputs(mem, lw, 2, pos, dt)
+    torch.autograd.backward([a, k], [ga, gk])
+    torch.cuda.synchronize()
+    g_mem, g_lw = mem.grad.clone(), lw.grad.clone() - (1.0 if arena else 0.0)
+    mem.grad = None
+    lw2 = lw.detach().clone().requires_grad_()
+    a2 = mem.flatten(2).transpose(1, 2) + lw2[2].view(1, 1, -1)
+    k2 = a2 + pos
+    torch.autograd.backward([a2.to(dt), k2.to(dt)], [ga, gk])
+    assert torch.equal(a, a2.to(dt)) and torch.equal(k, k2.to(dt))
+    assert torch.allclose(g_mem, mem.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(g_lw, lw2.grad, rtol=1e-4, atol=1e-4)
