@@ -60,6 +60,8 @@ def parse():
                     help='N > 1: log, per step, the bytes and host launch time of every gradient all-reduce piece relative '
                          'to the graph replays / the encoder backward it is meant to hide under (any backend; with '
                          'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
+    ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B runs: set a path selector of mask_bev_amd/switches.py (recorded in config.switches)')
     return ap.parse_args()
 
 
@@ -268,6 +270,10 @@ def roofline_entry(kernel, bound, avg_ms, launches_per_step, nbytes, flops, traf
 
 def main():
     args = parse()
+    from mask_bev_amd import switches
+    for item in args.switch:
+        name, _, value = item.partition('=')
+        switches.set_value(name.strip().lower(), value.strip())
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_baseline_worker, args.workload, args.cpu_threads, args.cpu_baseline_budget_s)
         return
@@ -451,7 +457,8 @@ def main():
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
                         step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, replica_param_checksum_spread=replica_spread,
-                        final_loss=final_loss),
+                        final_loss=final_loss,
+                        switches={k: v for k, v in switches._values.items() if v != switches.defaults()[k]}),
             roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,
             step_roofline=step_roof)
         if fp32_line is not None:

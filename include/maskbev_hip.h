@@ -198,11 +198,11 @@ int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int
  * of the f64 form, all levels in one launch, order-independent (integer) sums.  The scale is taken per block from
  * L1 = sum over queries of (|attention weights| of the level) x (largest |grad_out| of the block's channels), an upper
  * bound of every pixel's sum for any sampling pattern, so the 32-bit halves cannot wrap; addends are rounded to
- * 2^-30 of that bound's power of two.  head_dim == 32, num_points == 4, every level map <= 8192 pixels,
- * host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
+ * 2^-30 of that bound's power of two.  head_dim == 32, num_points == 4, every level map <= 4096
+ * pixels (the limit of the split backward, whose location / weight part the caller runs next), host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
  * consecutive (batch, value) rows — e.g. straight into the first H*D columns of the 16-bit matrix
  * [d value | d offsets | d logits] whose product with [Wv; Wo; Wa] is d(x).  Every element of that block is written
- * (no zero fill needed).  `_supported` returns 1 when the shape qualifies (and MBV_MSDA_PACKED != 0).  A first launch
+ * (no zero fill needed).  `_supported` returns 1 when the shape qualifies.  A first launch
  * re-lays grad_out (by 4-channel group), the locations and the weights (by level) into the caller's workspace
  * (`_workspace_bytes`), so that every block of the accumulation kernel reads contiguous streams (full cache lines).
  * Replaces the same mmcv backward as mbv_ms_deform_attn_bwd (value part). */
@@ -693,7 +693,7 @@ int mbv_gemm16_tn_group(const void* const* g, const void* const* x, float* const
  * (mbv_rowchain_slots() slots of 16 x 256 f32) between stages.  Stage operations:
  *   MBV_RC_LOAD    dst <- rows of p0 (dtype = flags & 3, row stride ld) [+ f32 p1 at row (r % q_mod), stride ld2];
  *                  p0 == NULL: the base operand is slot `src` (then p1 is required).  Rows >= `rows` load as zeros.
- *   MBV_RC_STORE   rows of p0 <- src (dtype = flags & 3, stride ld); MBV_RC_ACCUM: p0 += src (f32).
+ *   MBV_RC_STORE   rows of p0 <- src (dtype = flags & 3, stride ld); MBV_RC_ACCUM: p0 += src (f32; in a split launch only with an owner — BAD_ARG otherwise).
  *   MBV_RC_GEMM    dst = act((ACCUM ? dst : 0) + src (16 x k) . W^T + bias), W = p0 (n, k) row-major with row stride ld in
  *                  the program's weight dtype, bias = p1 f32 or NULL; MBV_RC_RELU; MBV_RC_MASK: result zeroed where
  *                  slot src2 <= 0 (ReLU backward).  f32 weights: exact f32 MFMA; 16-bit weights: activations rounded to

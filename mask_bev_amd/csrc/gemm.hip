@@ -22,7 +22,6 @@
 // in the workspace, then one small reduction launch) applied in f32 on the way; ATOMIC — f32 atomic adds of the
 // accumulators straight into the destination (weight gradients accumulate in the parameter arena; each
 // wave-instruction adds two 128-byte row segments, the full-rate shape of MI355X_MICROARCH.md §Global float atomics).
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -668,12 +667,10 @@ static int gemm16_launch_s(int layout, int atomic, int epi, int dtype, const Gem
 // workgroups x tile bytes, 151 MB instead of 33 MB per launch.)
 static const int SHAPE_BM[2] = {128, 256}, SHAPE_BN[2] = {128, 128};
 
-// Which block shape a problem gets.  MBV_GEMM_TILE=0/1/2 forces one (A/B runs).  Otherwise: the largest shape that
-// still (a) wastes little of its tiles on the edges of the (gm x gn) output and (b) leaves at least ~2 workgroup
-// slots per CU busy (the weight gradients make up for small outputs with their split over the tokens).
+// Which block shape a problem gets: the largest shape that still (a) wastes little of its tiles on the edges of the
+// (gm x gn) output and (b) leaves at least ~2 workgroup slots per CU busy (the weight gradients make up for small
+// outputs with their split over the tokens).
 static int gemm16_pick_shape(int atomic, long long gm, long long gn, long long work_units) {
-  const char* e = getenv("MBV_GEMM_TILE");
-  if (e && e[0] >= '0' && e[0] <= '1') return e[0] - '0';
   auto eff = [&](int s) {
     const long long tm = (gm + SHAPE_BM[s] - 1) / SHAPE_BM[s], tn = (gn + SHAPE_BN[s] - 1) / SHAPE_BN[s];
     return (double)(gm * gn) / (double)(tm * SHAPE_BM[s] * tn * SHAPE_BN[s]);
@@ -704,7 +701,7 @@ static void gemm16_split(GemmArgs& a, int splits, long long contraction, int bat
   int s = splits;
   if (s <= 0) {
     const long long tiles = (long long)a.ntm * a.ntn * batch;
-    static const int target = [] { const char* e = getenv("MBV_GEMM_SPLIT_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    constexpr int target = 512;         // about two workgroups per CU (256 and 1024 measured slower on the step's shapes)
     s = (int)((target + tiles - 1) / tiles);
     if (s > total_steps * KB / 256) s = total_steps * KB / 256;
   }
@@ -860,7 +857,7 @@ extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, 
   // a bit-reproducible sum; needs a contiguous dw, 16-byte alignment and a workspace for the parts
   if (accumulate && a.splits > 1 && batch == 1 && workspace && lddw == k && (n * k) % 4 == 0 &&
       (reinterpret_cast<size_t>(workspace) & 15) == 0 &&
-      workspace_bytes >= (size_t)a.splits * (size_t)n * (size_t)k * 4 && !getenv("MBV_GEMM_TN_ATOMIC")) {
+      workspace_bytes >= (size_t)a.splits * (size_t)n * (size_t)k * 4) {
     GemmArgs b = a;
     b.c = workspace;
     b.ssplit = n * k;
@@ -879,11 +876,8 @@ extern "C" int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, 
 }
 
 // ---- grouped weight gradients (see k_gemm16_tn_group) -------------------------------------------------------------
-// Token depth of one work item: MBV_GEMM_GROUP_DEPTH (A/B runs), default 4096.
-static int tn_group_depth() {
-  static const int d = [] { const char* e = getenv("MBV_GEMM_GROUP_DEPTH"); return e && atoi(e) >= 256 ? atoi(e) : 4096; }();
-  return d;
-}
+// Token depth of one work item (2048 / 8192 measured slower over the step's 62 products).
+static constexpr int tn_group_depth() { return 4096; }
 
 static void tn_group_split(int64_t m, int& splits, int& ksteps) {
   const int total_steps = (int)((m + KB - 1) / KB);

@@ -10,7 +10,6 @@
 // Forward is a gather (L2-resident value maps); backward scatters grad_value with f32 atomics
 // (1.06 GB of adds per layer at B=4 → bounded by the ≈1.3 TB/s chip-wide atomic rate)
 // and reduces grad_location / grad_weight over the D lanes with in-wave shuffles.
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -362,11 +361,6 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_banded(const float* __restric
   }
 }
 
-// Banded backward, 4 channels per lane (head_dim = 32): 8 lanes share a (query, head) and a lane owns one 16-byte
-// piece of the 128-byte pixel rows, exactly as in k_msda_fwd_v4.  Against one channel per lane this divides the
-// bilinear set-up, the header loads and the cross-lane reductions of the location / weight gradients by four and puts
-// 128 queries instead of 32 in flight per workgroup (a workgroup's queries take a quarter of the dependent
-// memory round trips); the LDS atomics stay one ds_add_f64 per (corner, channel).
 // sum over each aligned group of 8 lanes, result in EVERY lane of the group
 __device__ __forceinline__ float group8_allsum(float v) {
 #define MBV_DPP_ADD(ctrl, bmask)                                                                              \
@@ -379,158 +373,6 @@ __device__ __forceinline__ float group8_allsum(float v) {
   return v + hi + lo;       // banks 1, 3 receive the quad below, banks 0, 2 the quad above
 }
 
-__device__ __forceinline__ float group8_sum_dpp(float v) {
-#define MBV_DPP_ADD(ctrl, bmask)                                                                              \
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, bmask, true));
-  MBV_DPP_ADD(0xB1, 0xf)    // quad_perm [1,0,3,2]: + lane ^ 1
-  MBV_DPP_ADD(0x4E, 0xf)    // quad_perm [2,3,0,1]: + lane ^ 2   (every lane holds its quad's sum)
-  MBV_DPP_ADD(0x114, 0xa)   // row_shr:4 into banks 1 and 3: lanes 4-7 (12-15) += lanes 0-3 (8-11)
-#undef MBV_DPP_ADD
-  return v;                 // lanes 4..7 of every aligned group of 8 hold the group's sum
-}
-
-__global__ void __launch_bounds__(1024) k_msda_bwd_banded4(const float* __restrict__ grad_out,
-                                                          const float* __restrict__ value,
-                                                          const float* __restrict__ loc, const float* __restrict__ attn,
-                                                          MsdaBands cfg, int num_value, int heads, int points, int ablate,
-                                                          float* __restrict__ grad_value, float* __restrict__ grad_loc,
-                                                          float* __restrict__ grad_attn) {
-  constexpr int dim = 32;
-  __shared__ double map[16384];
-  int level = 0;
-  while (level + 1 < cfg.levels && (int)blockIdx.x >= cfg.block_begin[level + 1]) ++level;
-  const int local = blockIdx.x - cfg.block_begin[level];
-  const int chunks = cfg.chunks[level], bands = cfg.bands[level];
-  const int chunk = local % chunks, band = (local / chunks) % bands, bh = local / (chunks * bands);
-  const int hd = bh % heads, b = bh / heads;
-  const int h = cfg.h[level], w = cfg.w[level], lstart = cfg.lstart[level], levels = cfg.levels;
-  const int R0 = band * cfg.band_rows[level], R1 = min(h, R0 + cfg.band_rows[level]);
-  const int map_n = (R1 - R0) * w * dim;
-  for (int i = threadIdx.x; i < map_n; i += 1024) map[i] = 0.0;
-  int rbeg[8], rend[8], total = 0;
-#pragma unroll
-  for (int lq = 0; lq < 8; ++lq) {
-    rbeg[lq] = rend[lq] = 0;
-    if (lq < levels) {
-      const int hq = cfg.h[lq], wq = cfg.w[lq];
-      auto first_row = [&](int R) {          // smallest y with reference row >= R
-        const int num = 2 * hq * R - h;
-        int y = num <= 0 ? 0 : (num + 2 * h - 1) / (2 * h);
-        return y > hq ? hq : y;
-      };
-      rbeg[lq] = cfg.lstart[lq] + first_row(R0) * wq;
-      rend[lq] = cfg.lstart[lq] + (R1 >= h ? hq : first_row(R1)) * wq;
-      total += rend[lq] - rbeg[lq];
-    }
-  }
-  const int per = (total + chunks - 1) / chunks;
-  const int i0 = min(total, chunk * per), i1 = min(total, i0 + per);
-  const int d4 = threadIdx.x & 7, slot = threadIdx.x >> 3;      // 128 query slots of 8 lanes
-  const int stride_pix = heads * dim;
-  const int64_t slab = ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + d4 * 4;
-  const int band_px = (R1 - R0) * w;
-  __syncthreads();
-  constexpr int U = 2;     // 16-byte gathers: 2 points x 4 corners x 4 registers in flight per lane
-  const int nq_mine = i1 - i0;
-  for (int n0 = 0; n0 < nq_mine; n0 += 128) {                  // wave-uniform trip count
-    const int n = n0 + slot;
-    const bool qlive = n < nq_mine;
-    int qi = i0 + (qlive ? n : nq_mine - 1);
-    int q = 0;
-#pragma unroll
-    for (int lq = 0; lq < 8; ++lq) {
-      const int cnt = rend[lq] - rbeg[lq];
-      if (qi >= 0 && qi < cnt) q = rbeg[lq] + qi;
-      qi -= cnt;
-    }
-    const int64_t qh = ((int64_t)b * num_value + q) * heads + hd;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + d4 * 4);
-    for (int p0 = 0; p0 < points; p0 += U) {
-      bool live[U];
-      int64_t kk[U];
-      float lx[U], ly[U], aw[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        live[u] = qlive && p0 + u < points;
-        kk[u] = (qh * levels + level) * points + (p0 + u < points ? p0 + u : points - 1);
-        lx[u] = loc[kk[u] * 2];
-        ly[u] = loc[kk[u] * 2 + 1];
-        aw[u] = attn[kk[u]];
-      }
-      Corner c[U];
-      bool inside[U];
-      float4 v[U][4];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        inside[u] = bilinear_setup(lx[u], ly[u], h, w, 1, c[u]);              // offsets in pixels
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (inside[u] && c[u].off[j] >= 0 && !(ablate & 4))
-            v[u][j] = *reinterpret_cast<const float4*>(value + slab + (int64_t)c[u].off[j] * stride_pix);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float g_w = 0.f, g_x = 0.f, g_y = 0.f;
-        if (inside[u]) {
-          const float a = aw[u];
-          if (live[u]) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int off = c[u].off[j];
-              if (off >= 0) {
-                const float wj = c[u].wgt[j] * a;
-                const int rel = off - R0 * w;
-                if (rel >= 0 && rel < band_px) {
-                  if (ablate & 1) continue;
-                  double* m = &map[rel * dim + d4 * 4];
-                  atomicAdd(m, (double)(wj * go.x));
-                  atomicAdd(m + 1, (double)(wj * go.y));
-                  atomicAdd(m + 2, (double)(wj * go.z));
-                  atomicAdd(m + 3, (double)(wj * go.w));
-                } else {
-                  if (ablate & 2) continue;
-                  float* gv = grad_value + slab + (int64_t)off * stride_pix;
-                  atomicAdd(gv, wj * go.x);
-                  atomicAdd(gv + 1, wj * go.y);
-                  atomicAdd(gv + 2, wj * go.z);
-                  atomicAdd(gv + 3, wj * go.w);
-                }
-              }
-            }
-          }
-          // sum over this lane's 4 channels of go . v_j for each corner, then the bilinear combinations
-          float s[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            s[j] = go.x * v[u][j].x + go.y * v[u][j].y + go.z * v[u][j].z + go.w * v[u][j].w;
-          const float uh = 1.f - c[u].lh, uw = 1.f - c[u].lw;
-          g_w = c[u].wgt[0] * s[0] + c[u].wgt[1] * s[1] + c[u].wgt[2] * s[2] + c[u].wgt[3] * s[3];
-          const float gh = -uw * s[0] - c[u].lw * s[1] + uw * s[2] + c[u].lw * s[3];
-          const float gw = -uh * s[0] + uh * s[1] - c[u].lh * s[2] + c[u].lh * s[3];
-          g_x = (float)w * gw * a;
-          g_y = (float)h * gh * a;
-        }
-        if (ablate & 8) continue;
-        g_w = group8_sum_dpp(g_w);
-        g_x = group8_sum_dpp(g_x);
-        g_y = group8_sum_dpp(g_y);
-        if (live[u] && d4 == 7) {
-          grad_attn[kk[u]] = g_w;
-          grad_loc[kk[u] * 2] = g_x;
-          grad_loc[kk[u] * 2 + 1] = g_y;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const int64_t gbase = ((int64_t)b * num_value + lstart + R0 * w) * stride_pix + hd * dim;
-  for (int i = threadIdx.x; i < map_n; i += 1024) {
-    const double v = map[i];
-    if (v != 0.0) atomicAdd(grad_value + gbase + (int64_t)(i / dim) * stride_pix + (i % dim), (float)v);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Backward with no global atomics at all (head_dim = 32, every level map <= 4096 pixels), two independent parts:
@@ -554,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
                                                         const float* __restrict__ loc, const float* __restrict__ attn,
                                                         int level, int levels, int h, int w, int lstart, int num_value,
                                                         int num_query, int heads, int points_rt,
-                                                        float* __restrict__ grad_value, int ablate) {
+                                                        float* __restrict__ grad_value) {
   constexpr int dim = 32, CG = 4;
   const int points = P > 0 ? P : points_rt;
   extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
@@ -625,13 +467,6 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
           const int off = c.off[j];
           if (off < 0) continue;
           const float wj = c.wgt[j] * aw[u];
-          if (ablate & 2) continue;
-          if (ablate & 4) {                     // timing experiment: one f32 -> f64 conversion instead of four
-            const double d = (double)(wj * go.x);
-            atomicAdd(&map[off], d); atomicAdd(&map[npix + off], d); atomicAdd(&map[2 * npix + off], d);
-            atomicAdd(&map[3 * npix + off], d);
-            continue;
-          }
           atomicAdd(&map[off], (double)(wj * go.x));
           atomicAdd(&map[npix + off], (double)(wj * go.y));
           atomicAdd(&map[2 * npix + off], (double)(wj * go.z));
@@ -641,97 +476,12 @@ __global__ void __launch_bounds__(1024) k_msda_bwd_value(const float* __restrict
     }
   }
   __syncthreads();
-  if (ablate & 1) return;
   float* gv = grad_value + ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + split * CG;
   for (int i = threadIdx.x; i < npix; i += 1024)
     *reinterpret_cast<float4*>(gv + (int64_t)i * stride_pix) =
         make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
 }
 
-// The same kernel with NEIGHBOUR MERGING (P = 4): lanes are consecutive queries, i.e. neighbouring pixels of a map
-// row, and deformable offsets vary smoothly over the map (at initialisation they are identical for all queries): the
-// right-hand corners of lane i's sample are then the left-hand corners of lane i + 1's.  Before the adds, every lane
-// looks at its left neighbour's right-corner offset (one DPP wave shift); where it equals its own left-corner offset
-// it adds the neighbour's contribution to its own and the neighbour skips that corner — up to 8 of the 16 f64 LDS adds
-// per sample go away (the kernel is bound by exactly those adds).  Lanes that do not match (row ends,
-// rough offsets) add as before; the sums are the same addends in another order (f64).  Pure VALU exchanges: DPP
-// wave_shr / wave_shl, no LDS traffic.
-__device__ __forceinline__ int dpp_from_left_i(int v, int fill) {      // lane i receives lane i-1's v; lane 0: fill
-  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ float dpp_from_left_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int dpp_from_right_i(int v, int fill) {     // lane i receives lane i+1's v; lane 63: fill
-  return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
-}
-
-__global__ void __launch_bounds__(1024) k_msda_bwd_value_merge(const float* __restrict__ grad_out,
-                                                              const float* __restrict__ loc,
-                                                              const float* __restrict__ attn, int level, int levels,
-                                                              int h, int w, int lstart, int num_value, int num_query,
-                                                              int heads, float* __restrict__ grad_value) {
-  constexpr int dim = 32, CG = 4, P = 4;
-  extern __shared__ __attribute__((aligned(16))) double map[];      // [CG][h * w]
-  const int nbh = gridDim.x >> 3;
-  const int split = blockIdx.x / nbh, bhid = blockIdx.x - split * nbh;
-  const int hd = bhid % heads, b = bhid / heads;
-  const int npix = h * w, stride_pix = heads * dim;
-  for (int i = threadIdx.x; i < CG * npix; i += 1024) map[i] = 0.0;
-  __syncthreads();
-  for (int q0 = 0; q0 < num_query; q0 += 1024) {            // wave-uniform trip count: the DPP exchanges need it
-    const int q = q0 + (int)threadIdx.x;
-    const bool live = q < num_query;
-    const int64_t qh = ((int64_t)b * num_query + (live ? q : 0)) * heads + hd;
-    float4 go = *reinterpret_cast<const float4*>(grad_out + qh * dim + split * CG);
-    if (!live) go = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t kb = (qh * levels + level) * P;
-    const float4 l01 = *reinterpret_cast<const float4*>(loc + kb * 2);
-    const float4 l23 = *reinterpret_cast<const float4*>(loc + kb * 2 + 4);
-    const float4 a4 = *reinterpret_cast<const float4*>(attn + kb);
-    const float lx[4] = {l01.x, l01.z, l23.x, l23.z}, ly[4] = {l01.y, l01.w, l23.y, l23.w};
-    const float aw[4] = {a4.x, a4.y, a4.z, a4.w};
-    // the left neighbour's gradient row (constant over the samples of this query)
-    const float gpx = dpp_from_left_f(go.x), gpy = dpp_from_left_f(go.y), gpz = dpp_from_left_f(go.z),
-                gpw = dpp_from_left_f(go.w);
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      Corner c;
-      const bool ok = live && bilinear_setup(lx[u], ly[u], h, w, 1, c);          // offsets in pixels
-      if (!ok) { c.off[0] = c.off[1] = c.off[2] = c.off[3] = -1; c.wgt[0] = c.wgt[1] = c.wgt[2] = c.wgt[3] = 0.f; }
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {                          // the two map rows of the sample: corners (2r, 2r + 1)
-        const int offL = c.off[2 * r], offR = c.off[2 * r + 1];
-        const float wL = c.wgt[2 * r] * aw[u], wR = c.wgt[2 * r + 1] * aw[u];
-        const int offRp = dpp_from_left_i(offR, -2);
-        const float wRp = dpp_from_left_f(wR);
-        const int take = (offL >= 0 && offRp == offL) ? 1 : 0;      // this lane adds its left neighbour's right corner
-        const int given = dpp_from_right_i(take, 0);                // the right neighbour adds this lane's right corner
-        if (offL >= 0) {
-          double v0 = (double)(wL * go.x), v1 = (double)(wL * go.y), v2 = (double)(wL * go.z), v3 = (double)(wL * go.w);
-          if (take) {
-            v0 += (double)(wRp * gpx); v1 += (double)(wRp * gpy); v2 += (double)(wRp * gpz); v3 += (double)(wRp * gpw);
-          }
-          atomicAdd(&map[offL], v0);
-          atomicAdd(&map[npix + offL], v1);
-          atomicAdd(&map[2 * npix + offL], v2);
-          atomicAdd(&map[3 * npix + offL], v3);
-        }
-        if (offR >= 0 && !given) {
-          atomicAdd(&map[offR], (double)(wR * go.x));
-          atomicAdd(&map[npix + offR], (double)(wR * go.y));
-          atomicAdd(&map[2 * npix + offR], (double)(wR * go.z));
-          atomicAdd(&map[3 * npix + offR], (double)(wR * go.w));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  float* gv = grad_value + ((int64_t)b * num_value + lstart) * stride_pix + hd * dim + split * CG;
-  for (int i = threadIdx.x; i < npix; i += 1024)
-    *reinterpret_cast<float4*>(gv + (int64_t)i * stride_pix) =
-        make_float4((float)map[i], (float)map[npix + i], (float)map[2 * npix + i], (float)map[3 * npix + i]);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // d(value) with PACKED FIXED-POINT LDS accumulators (round 3; 16-bit compute modes).
@@ -1084,8 +834,7 @@ extern "C" int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial
 }
 
 extern "C" int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int64_t* spatial_shapes_host) {
-  const char* banded = getenv("MBV_MSDA_BWD_BANDED");
-  if (!spatial_shapes_host || head_dim != 32 || num_levels <= 0 || num_levels > 8 || (banded && banded[0] == '1')) return 0;
+  if (!spatial_shapes_host || head_dim != 32 || num_levels <= 0 || num_levels > 8) return 0;
   for (int l = 0; l < num_levels; ++l) {
     const int64_t h = spatial_shapes_host[2 * l], w = spatial_shapes_host[2 * l + 1];
     if (h <= 0 || w <= 0 || h * w > 4096) return 0;
@@ -1112,7 +861,7 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
   part &= 3;
   if (part < 1 || level_mask < 0 || level_mask > 255 || (level_mask && part != 1)) return MBV_ERR_BAD_ARG;
   {
-    // no global atomics (see k_msda_bwd_value); MBV_MSDA_BWD_BANDED=1 keeps the banded form (A/B switch)
+    // no global atomics (see k_msda_bwd_value); maps of more than 4096 pixels take the banded form below
     bool fits = mbv_ms_deform_attn_bwd_split(head_dim, num_levels, spatial_shapes_host) != 0 &&
                 ((reinterpret_cast<size_t>(grad_out) | reinterpret_cast<size_t>(value) |
                   reinterpret_cast<size_t>(grad_value) | reinterpret_cast<size_t>(sampling_loc) |
@@ -1134,32 +883,21 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value_merge),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_done = true;
       }
       const int which = part;
-      const int ablate = getenv("MBV_MSDA_ABLATE") ? atoi(getenv("MBV_MSDA_ABLATE")) : 0;     // timing experiments only
-      // A/B switch, default OFF: measured 166 -> 156 us with identical offsets for all queries, 218 -> 225 us with random
-      // ones — an f64 LDS atomic costs ~13 cycles per WAVE instruction whatever its active lanes, so emptying most lanes
-      // of half the instructions buys little
-      const char* me = getenv("MBV_MSDA_MERGE");
-      const bool merge = me && me[0] == '1' && !ablate;
       for (int l = num_levels - 1; l >= 0 && (which & 1); --l) {      // finest (longest) level first
         if (level_mask && !((level_mask >> l) & 1)) continue;
         const dim3 grid((unsigned)(batch * num_heads * 8)), block(1024);
         const size_t lds = (size_t)lv.h[l] * lv.w[l] * 4 * sizeof(double);
-        if (num_points == 4 && merge)
-          hipLaunchKernelGGL(k_msda_bwd_value_merge, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
-                             num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, grad_value);
-        else if (num_points == 4)
+        if (num_points == 4)
           hipLaunchKernelGGL(k_msda_bwd_value<4>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
                              num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
-                             grad_value, ablate);
+                             grad_value);
         else
           hipLaunchKernelGGL(k_msda_bwd_value<0>, grid, block, lds, stream, grad_out, sampling_loc, attn_weight, l,
                              num_levels, lv.h[l], lv.w[l], lv.lstart[l], num_value, num_query, num_heads, num_points,
-                             grad_value, ablate);
+                             grad_value);
         MBV_CHECK_LAUNCH();
       }
       if (which & 2) {
@@ -1196,17 +934,6 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
     }
     if (ok && lstart == num_value) {
       cfg.block_begin[num_levels] = blocks;
-      // A/B switch: the four-channels-per-lane form (measured equal, 0.40 ms: cheaper set-up and LDS adds, but its
-      // out-of-band global atomics are 16-byte pieces instead of whole 128-byte rows — see DESIGN.md K5)
-      const char* four = getenv("MBV_MSDA_BWD_4CH");
-      if (head_dim == 32 && four && four[0] == '1' &&
-          ((reinterpret_cast<size_t>(grad_out) | reinterpret_cast<size_t>(value)) & 15) == 0) {
-        hipLaunchKernelGGL(k_msda_bwd_banded4, dim3((unsigned)blocks), dim3(1024), 0, stream, grad_out, value,
-                           sampling_loc, attn_weight, cfg, num_value, num_heads, num_points,
-                           getenv("MBV_MSDA_ABLATE") ? atoi(getenv("MBV_MSDA_ABLATE")) : 0, grad_value, grad_loc, grad_attn);
-        MBV_CHECK_LAUNCH();
-        return MBV_OK;
-      }
       hipLaunchKernelGGL(k_msda_bwd_banded, dim3((unsigned)blocks), dim3(1024), 0, stream, grad_out, value, sampling_loc,
                          attn_weight, cfg, num_value, num_heads, head_dim, num_points, grad_value, grad_loc, grad_attn);
       MBV_CHECK_LAUNCH();
@@ -1225,13 +952,9 @@ extern "C" int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, i
                                                              int32_t num_query, const int64_t* spatial_shapes_host) {
   if (!spatial_shapes_host || head_dim != 32 || num_points != 4 || num_levels <= 0 || num_levels > 8) return 0;
   if (num_query <= 0 || num_query > (1 << 18)) return 0;            // >= 12 fractional bits
-  const char* off = getenv("MBV_MSDA_PACKED");
-  if (off && off[0] == '0') return 0;
-  for (int l = 0; l < num_levels; ++l) {
-    const int64_t h = spatial_shapes_host[2 * l], w = spatial_shapes_host[2 * l + 1];
-    if (h <= 0 || w <= 0 || h * w > 8192) return 0;                 // one 64 KB plane at most
-  }
-  return 1;
+  // The caller follows the packed value part with the location / weight part of the split backward (part = 2), which
+  // exists only in the no-global-atomics form: every level map <= 4096 pixels (one 32 KB plane of packed pairs here).
+  return mbv_ms_deform_attn_bwd_split(head_dim, num_levels, spatial_shapes_host);
 }
 
 extern "C" size_t mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(int32_t batch, int32_t num_heads, int32_t num_levels,

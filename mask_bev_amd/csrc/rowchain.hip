@@ -1144,6 +1144,8 @@ extern "C" int mbv_rowchain_run_split(const MbvRowStage* stages, int32_t num_sta
         if ((s.n & 3) == 0 && ((s.ld & 3) || (reinterpret_cast<size_t>(s.p0) & (dt == MBV_DT_F32 ? 15 : 7))))
           return MBV_ERR_BAD_ARG;
         if ((s.flags & MBV_RC_SPLIT) && (s.ld2 <= 0 || (s.ld2 & 3) || (s.flags & MBV_RC_ACCUM))) return MBV_ERR_BAD_ARG;
+        // an unowned accumulating store of a split launch would be added once per workgroup of the row block (and race)
+        if ((s.flags & MBV_RC_ACCUM) && split > 1 && ((s.flags >> 8) & 0xff) == 0) return MBV_ERR_BAD_ARG;
         break;
       case MBV_RC_SUM:
         if (!slot_ok(s.dst) || !s.p0 || s.n <= 0 || s.n > RC_MAXC || (s.n & 3) || s.k < 1 || s.k > 64 || (s.ld & 3) ||

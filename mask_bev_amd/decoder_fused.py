@@ -22,12 +22,11 @@ copies, activations rounded to that type per GEMM, f32 accumulation (what autoca
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import List, Optional
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, switches
 from ._lib import MaskBevHipError, check
 
 OP_LOAD, OP_STORE, OP_GEMM, OP_LN, OP_LN_BWD, OP_ADD, OP_COLSUM, OP_FFN, OP_FFN_IO, OP_SUM = range(10)
@@ -130,6 +129,9 @@ class Program:
         self._add(OP_LOAD, dst=dst, src=src, n=n, ld2=add.stride(0), p1=_addr(add))
 
     def store(self, src: int, t: torch.Tensor, n: int, col0: int = 0, accum: bool = False):
+        if accum and self.split > 1 and self.owner is None:
+            # every one of the `split` workgroups of a row block would do the same non-atomic read-modify-write
+            raise MaskBevHipError('rowchain store: an accumulating store of a split launch needs an owner (P.only(j))')
         self.keep.append(t)
         self._add(OP_STORE, src=src, n=n, flags=_dt(t) | (F_ACCUM if accum else 0), ld=t.stride(0), p0=_addr(t, col0))
 
@@ -255,7 +257,12 @@ class WeightCopies:
 
     def refresh(self, entries, dt: torch.dtype):
         lib = _lib.load()
-        self.ref = {}
+        # Entries are replaced, not wiped: a forward under no_grad (a sanity validation, an extra eager step) between a
+        # training forward and its backward lists no transposed operands, and that backward still looks its own up.
+        # They stay valid — the weights only change in the optimizer step, after the backward.
+        if getattr(self, '_dt', None) != dt:
+            self.ref = {}
+            self._dt = dt
         keep = []
         if dt == torch.float32:
             src_p, dst_p, rows_l, cols_l = [], [], [], []
@@ -571,7 +578,7 @@ class _DecB(torch.autograd.Function):
         oc = head.mlp[2][0].shape[0]
         me = torch.empty((m, oc), dtype=head.mask_feature.dtype, device=dev)
         w_o, w_1, w_2 = lc.w(wo), lc.w(w1), lc.w(w2)
-        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and switches.get('rc_ffn')
         # The MLP's 2 x 1 MB of weights behind ONE workgroup per 16 rows is 30 us of dependent loads on 25 CUs.  Split form:
         # f / 256 workgroups per row block each take 256 hidden units (launch 1: the cheap stages before the MLP run in all
         # of them), a second launch adds the parts and finishes the layer with its three independent branches (next
@@ -703,7 +710,7 @@ class _DecB(torch.autograd.Function):
         ds3, ds2 = torch.empty((m, e), **f32), torch.empty((m, e), **f32)
         dh = torch.empty((m, f), **f32)
         g_o2 = torch.empty((m, e), dtype=ctx.o2_dtype, device=dev)
-        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
+        fused_ffn = lc.wdt != torch.float32 and f % 256 == 0 and e % 32 == 0 and switches.get('rc_ffn')
         S = ffn_split(f, e, lc.wdt)
         split = S > 1
         P = Program(m, lc.q, lc.eps, lc.wdt, 'B1.bwd' if split else 'B.bwd', split=S)
@@ -776,14 +783,14 @@ def spread(n: int) -> int:
     independent products move to different workgroups of the block, every workgroup repeating the stages they depend
     on — a 128 KB weight block is ~2 us of one CU's L2 bandwidth, a store stage ~1.2 us, and 231 CUs are idle.
     MBV_RC_SPREAD=0: one workgroup per block (A/B)."""
-    return n if os.environ.get('MBV_RC_SPREAD', '1') != '0' else 1
+    return n if switches.get('rc_spread') else 1
 
 
 def ffn_split(f: int, e: int, dt: torch.dtype) -> int:
     """Workgroups per row block of the decoder MLP's split launches (1: the one-workgroup stage / the staged f32 form)."""
-    fused = dt != torch.float32 and f % 256 == 0 and e % 32 == 0 and os.environ.get('MBV_RC_FFN', '1') != '0'
-    return f // 256 if (fused and os.environ.get('MBV_RC_SPLIT', '1') != '0') else 1
+    fused = dt != torch.float32 and f % 256 == 0 and e % 32 == 0 and switches.get('rc_ffn')
+    return f // 256 if (fused and switches.get('rc_split')) else 1
 
 
 def enabled() -> bool:
-    return os.environ.get('MBV_DECODER_FUSED', '1') != '0'
+    return switches.get('decoder_fused')

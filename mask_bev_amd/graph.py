@@ -32,13 +32,12 @@ the capture (PyTorch emits its "AccumulateGrad node's stream does not match" war
 """
 from __future__ import annotations
 
-import os
 import time
 from typing import Dict, Optional
 
 import torch
 
-from . import ops
+from . import ops, switches
 from .mask_bev_module import MaskBevModule
 
 
@@ -124,12 +123,12 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss_static = self._forward_backward_head()
-        # A/B switch MBV_TN_OVERLAP=1 (one GPU only): the grouped weight-gradient launch of the early stages (≈ 0.65 ms,
+        # A/B switch `switches.tn_overlap` (one GPU only): the grouped weight-gradient launch of the early stages (≈ 0.65 ms,
         # nobody's input inside the graph) is taken out of the capture and issued after the replay on a side stream,
         # beside the eager encoder backward; the captured operands stay alive in the graph's pool (held here), so their
         # addresses are the replay's.  MEASURED SLOWER — 28.3 vs 27.7 ms: the MFMA / L2-heavy launch slows the
         # latency-bound per-pillar walks it runs beside by more than it hides (as the optimizer pass did).
-        self._late_tn = [] if (reducer is None and os.environ.get('MBV_TN_OVERLAP', '0') == '1') else None
+        self._late_tn = [] if (reducer is None and switches.get('tn_overlap')) else None
         self._tn_stream = torch.cuda.Stream(device=dev) if self._late_tn is not None else None
         self.graph_late = torch.cuda.CUDAGraph()
         ops.set_tn_sink(self._late_tn)

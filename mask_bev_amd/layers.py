@@ -7,14 +7,13 @@ are organised around channels-last (B, H, W, C) token maps, which is what the gf
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, switches
 
 
 def trunc_normal_(t: torch.Tensor, std: float = 0.02) -> torch.Tensor:
@@ -51,7 +50,7 @@ class LayerNorm(nn.LayerNorm):
             if (gemm_input and torch.is_autocast_enabled('cuda')
                     and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES):
                 out_dtype = torch.get_autocast_dtype('cuda')
-            if fanout and os.environ.get('MBV_LN_FANOUT', '1') == '0':
+            if fanout and not switches.get('ln_fanout'):
                 y = ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, branch_bias=residual_bias)
                 return y, y
             return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum,
@@ -172,7 +171,7 @@ def conv1x1(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     which made every decoder layer after it — and the gradients — irreproducible)."""
     b, c, h, w = x.shape
     if (not x.is_contiguous() and x.is_cuda and x.permute(0, 2, 3, 1).is_contiguous()
-            and os.environ.get('MBV_CONV1X1_TOKENS', '1') != '0'):
+            and switches.get('conv1x1_tokens')):
         # a channels-last map (the backbone's stage outputs are (B, H, W, C) tokens seen through a permute): the GEMM
         # reads the token matrix as its transposed operand and writes NCHW; its backward returns token-major gradients
         y = ops.conv1x1_tokens(x.permute(0, 2, 3, 1).reshape(b, h * w, c), conv.weight.view(conv.weight.shape[0], c),
@@ -326,7 +325,7 @@ class MultiScaleDeformableAttention(nn.Module):
         h, l, p = self.num_heads, self.num_levels, self.num_points
         if (spatial_shapes is not None and query.is_cuda and query.dtype == torch.float32
                 and query_pos.shape[0] == 1 and sum(hh * ww for hh, ww in spatial_shapes) == n
-                and ops.msda_prepare_supported(l, p) and os.environ.get('MBV_MSDA_FUSED', '1') != '0'):
+                and ops.msda_prepare_supported(l, p) and switches.get('msda_fused')):
             out = ops.msda_query_side(query, query_pos, reference_points, self.value_proj, self.sampling_offsets,
                                       self.attention_weights, h, l, p, spatial_shapes, shapes_t, level_start)
             out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)

@@ -8,7 +8,6 @@ mask_bev/models/head/mask_bev_panoptic_head.py:98-215.
 from __future__ import annotations
 
 import contextlib
-import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -16,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, switches
 from .layers import ConvGN, FFN, conv1x1, LayerNorm, Linear, MultiScaleDeformableAttention, MultiheadAttention, sine_positional_encoding
 
 
@@ -159,7 +158,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return mask_feature, tail[:self.num_outs]
 
     def _tail_stream(self, device):
-        if device.type != 'cuda' or not torch.is_grad_enabled() or os.environ.get('MBV_TAIL_STREAM', '1') == '0':
+        if device.type != 'cuda' or not torch.is_grad_enabled() or not switches.get('tail_stream'):
             return None
         st = self._tail_streams.get(device)
         if st is None:
@@ -231,11 +230,6 @@ class PointSource:
         if self.gen is None:
             return torch.rand(*shape, device=self.device)
         return torch.rand(*shape, generator=self.gen).to(self.device)
-
-
-def _point_sample(inp: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
-    """inp (N, C, H, W), pts (N, P, 2) in [0, 1] → (N, C, P); bilinear, align_corners=False."""
-    return F.grid_sample(inp, 2.0 * pts.unsqueeze(2) - 1.0, align_corners=False).squeeze(3)
 
 
 class _DeferredHeads(torch.autograd.Function):
@@ -368,7 +362,7 @@ class Mask2FormerHead(nn.Module):
         self.point_seed: Optional[int] = None          # tests set this to share points with the oracle
         self._iota_cache: Dict = {}
         self._side_streams: Dict = {}
-        self.overlap_matcher = os.environ.get('MBV_OVERLAP_MATCHER', '1') != '0'
+        self.overlap_matcher = switches.get('overlap_matcher')
         # GT masks are float32 {0, 1} by the reference's batch contract (semantic_kitti_transforms.py:77-81);
         # set False to sample arbitrary-valued maps through the generic f32 path
         self.binary_gt_masks = True
@@ -417,7 +411,7 @@ class Mask2FormerHead(nn.Module):
         self._mask_stack = stack
         # training on the GPU: the heads run layer by layer WITHOUT a graph and get one batched backward (_DeferredHeads)
         deferred = (stack is not None and self.training and torch.is_grad_enabled()
-                    and os.environ.get('MBV_DEFERRED_HEADS', '1') != '0')
+                    and switches.get('deferred_heads'))
         feats_q = [query_feat]
 
         def heads(qf, size, slot):
@@ -435,7 +429,7 @@ class Mask2FormerHead(nn.Module):
         layers = self.transformer_decoder.layers
         shared = [None] * len(layers)
         if (ops.shared_kv_supported(self.num_queries, mask_features.device)
-                and os.environ.get('MBV_SHARED_KV', '1') != '0'):
+                and switches.get('shared_kv')):
             for lvl in range(nl):
                 idx = [i for i in range(len(layers)) if i % nl == lvl]
                 holder, token = ops.shared_kv_project(
@@ -480,6 +474,13 @@ class Mask2FormerHead(nn.Module):
         f = layers[0].ffn.layers[0][0].out_features
         oc = self.mask_embed[4].out_features
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
+        # What a program can hold (mbv_rowchain_max_stages() = 64 stages, 256-column products): the class head is one
+        # GEMM stage (<= 256 classes); the MLP is ONE stage in its fused form (16-bit weights, f % 256 == 0, at most 64
+        # slices) and f / 256 chunks of 3 forward / 5 backward stages otherwise — beyond 2048 hidden units that form
+        # does not fit beside the layer's other ~20 stages, and such a head takes the per-op path.
+        fused_ffn = dt != torch.float32 and f % 256 == 0 and e % 32 == 0 and switches.get('rc_ffn')
+        if self.cls_embed.out_features > 256 or (f > 16384 if fused_ffn else f > 2048):
+            return False
         return (DF.enabled() and mask_features.is_cuda and all(s is not None for s in shared)
                 and (deferred or not torch.is_grad_enabled())
                 and e % 32 == 0 and e <= 256 and f % 32 == 0 and oc % 4 == 0 and oc <= 256
@@ -691,7 +692,7 @@ class Mask2FormerHead(nn.Module):
         # counts as padding only if it has label 0 AND an empty mask AND every later column is padding too.
         def real_cols():             # evaluated on the matcher's stream: nothing else needs it
             if not (nq == ng <= 128 and isinstance(gt_flat, ops.PackedMasks)
-                    and os.environ.get('MBV_K9_PADDED', '1') != '0'):
+                    and switches.get('k9_padded')):
                 return None
             real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                  # (B, G)
             last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)            # (B,) = K
@@ -762,7 +763,7 @@ class Mask2FormerHead(nn.Module):
             num_total_masks = self.world_size_fn(num_total_masks)
         num_total_masks = num_total_masks.clamp(min=1.0)[0]
 
-        if pred.is_cuda and os.environ.get('MBV_LOSS_NODE', '1') != '0':
+        if pred.is_cuda and switches.get('loss_node'):
             # K13's row sums (Σ σ·t, Σ σ, Σ t, Σ bce in one pass) and the dice / BCE algebra on them as one autograd node
             with torch.no_grad():
                 c_dice = self.loss_dice_weight / (num_total_masks + eps)

@@ -7,13 +7,12 @@ There is no CPU fallback — tensors must live on a ROCm device.
 from __future__ import annotations
 
 import ctypes
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, switches
 from ._lib import MaskBevHipError, check
 
 
@@ -552,7 +551,8 @@ _MSDA_SIDE = {}
 def msda_value_packed_ok(dims, host) -> bool:
     """Whether d(value) of this shape can take the packed fixed-point form (mbv_ms_deform_attn_bwd_value_packed)."""
     b, nv, nh, d, nl, nq, npnt = dims
-    return bool(host is not None and _lib.load().mbv_ms_deform_attn_bwd_value_packed_supported(d, nl, npnt, nq, host))
+    return bool(host is not None and switches.get('msda_packed')
+                and _lib.load().mbv_ms_deform_attn_bwd_value_packed_supported(d, nl, npnt, nq, host))
 
 
 def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn,
@@ -575,7 +575,7 @@ def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, ho
 
 def _msda_backward_f64(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn):
     """K5 backward.  The no-atomics form has two independent parts — d(value), bound by the LDS f64-atomic rate, and
-    d(location) / d(weight), bound by L2 gathers.  MBV_MSDA_BWD_OVERLAP=1 puts them on two streams; measured inside the
+    d(location) / d(weight), bound by L2 gathers.  `switches.msda_bwd_overlap` puts them on two streams; measured inside the
     HIP-graph step the fork / join edges cost more than the overlap returns (34.17 vs 33.88 ms per step), so the
     default is one stream.  The side stream only touches buffers that were allocated on the current stream and
     outlive the join."""
@@ -584,7 +584,7 @@ def _msda_backward_f64(lib, g_out, value, shapes_t, level_start, loc, attn, dims
     args = (_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq,
             npnt, host, _ptr(g_value), _ptr(g_loc), _ptr(g_attn))
     split = host is not None and lib.mbv_ms_deform_attn_bwd_split(d, nl, host)
-    if not split or os.environ.get('MBV_MSDA_BWD_OVERLAP', '0') != '1':
+    if not split or not switches.get('msda_bwd_overlap'):
         check(lib.mbv_ms_deform_attn_bwd(*args, 3, _stream()), 'mbv_ms_deform_attn_bwd')
         return
     main = torch.cuda.current_stream()
@@ -815,19 +815,19 @@ _ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
 
 
 def gemm16_enabled() -> bool:
-    """A/B switch: MBV_GEMM16=0 sends every Linear back to the library GEMM."""
+    """A/B switch: `switches.gemm16 = '0'` sends every Linear back to the library GEMM."""
     import os
-    return os.environ.get('MBV_GEMM16', '1') != '0'
+    return switches.get('gemm16') != '0'
 
 
 def gemm16_policy() -> str:
-    """Which Linear work runs on K17 (csrc/gemm.hip) instead of the library GEMM.  MBV_GEMM16 =
+    """Which Linear work runs on K17 (csrc/gemm.hip) instead of the library GEMM.  `switches.gemm16` =
     ``auto`` (default): the fused forms — FFN input layer + activation, FFN output layer's data gradient + activation
     backward + bias gradient — and the arena-accumulating weight gradient, for token counts where K17 measured at or
     above the library (scratch/bench_gemm.py, profiles/r02); ``all``: every eligible Linear, forward and backward;
     ``0``: none (the round-1 path)."""
     import os
-    v = os.environ.get('MBV_GEMM16', 'auto')
+    v = switches.get('gemm16')
     return {'1': 'auto', '0': 'none'}.get(v, v)
 
 
@@ -835,8 +835,8 @@ def gemm16_policy() -> str:
 # (scratch/bench_gemm.py on the bench shapes, profiles/r02/c_gemm_shapes.txt).  The fused FFN forms pay down to 4096
 # tokens (Swin stage 3): the K17 GEMM alone is slower there than the library's, but it replaces GEMM + GELU forward and
 # GEMM + activation-backward/column-sum pass backward — step A/B 8192 / 4096 / 1024: 29.19 / 28.92 / 30.51 ms
-_TN_MAX_IN = int(os.environ.get('MBV_TN_MAX_IN', '1536'))      # widest input of a Linear whose weight gradient K17 takes
-_K17_MIN_TOKENS = {'fused': int(os.environ.get('MBV_K17_FUSED_MIN', '4096')), 'wgrad': 4096}
+def _k17_min_tokens(kind: str) -> Optional[int]:
+    return {'fused': switches.get('k17_fused_min'), 'wgrad': 4096}.get(kind)
 
 
 def _k17_wants(kind: str, tokens: int) -> bool:
@@ -845,7 +845,8 @@ def _k17_wants(kind: str, tokens: int) -> bool:
         return False
     if pol == 'all':
         return True
-    return kind in _K17_MIN_TOKENS and tokens >= _K17_MIN_TOKENS[kind]
+    floor = _k17_min_tokens(kind)
+    return floor is not None and tokens >= floor
 
 
 def _gemm16_ok(*ts: torch.Tensor) -> bool:
@@ -1029,8 +1030,9 @@ def colsum_accum(g2: torch.Tensor, out: torch.Tensor, persistent: bool = False):
 # gradients — are collected and issued as a few grouped launches (mbv_wgrad_small_f32_group, mbv_colsum_accum_group)
 # from an autograd-engine callback at the end of that pass: ≈ 140 launches of 5-12 us with the chip mostly idle become
 # four that fill it.  Only accumulations into ARENA gradients are deferred (nothing reads those before the pass ends).
-# `MBV_WGRAD_GROUP=0` keeps the per-layer launches (A/B).
+# `switches.wgrad_group = False` keeps the per-layer launches (A/B).
 _PENDING: dict = {}          # autograd graph-task id -> ([small weight gradients], [column sums]) of that backward pass
+_PENDING_MAX = 32            # entries kept at most: nesting depth of re-entrant passes + leftovers of passes that raised
 
 
 def _pending_lists():
@@ -1038,7 +1040,7 @@ def _pending_lists():
     or None outside a pass / with the switch off.  Keyed by the engine's graph-task id: a re-entrant pass (the deferred
     heads re-evaluate a sub-graph inside the outer backward) flushes its own work, and what a pass that raised left
     behind is never mistaken for the next pass's work."""
-    if os.environ.get('MBV_WGRAD_GROUP', '1') == '0':
+    if not switches.get('wgrad_group'):
         return None
     tid = torch._C._current_graph_task_id()
     if tid < 0:
@@ -1049,10 +1051,13 @@ def _pending_lists():
             torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred_grads(tid))
         except RuntimeError:
             return None
-        # leftovers of passes that raised before their callback ran hold (g, x) activations alive: passes nest at most
-        # two deep here (the deferred heads' re-evaluation inside the step's backward), so anything four ids back is dead
-        for old in [t for t in _PENDING if t < tid - 4]:
-            del _PENDING[old]
+        # Leftovers of passes that raised before their callback ran hold (g, x) activations alive.  A live pass cannot be
+        # told from a dead one by its id (an outer pass stays live while any number of inner passes come and go, each
+        # with a higher id), but every pass that ENDS removes its entry, so the entries that exist are the nesting
+        # depth plus the leaked ones: only when far more exist than passes can nest are the oldest dropped.
+        if len(_PENDING) >= _PENDING_MAX:
+            for old in sorted(_PENDING)[:len(_PENDING) - _PENDING_MAX + 1]:
+                del _PENDING[old]
         lists = _PENDING[tid] = ([], [], [])
     return lists
 
@@ -1070,10 +1075,10 @@ def _defer_small_wgrad(g2, x2, acc, bias_acc) -> bool:
 
 
 def _tn_group_mode() -> str:
-    """MBV_TN_GROUP: ``1`` (default) — the K17 weight gradients of a backward pass are collected and issued as grouped
+    """`switches.tn_group`: ``1`` (default) — the K17 weight gradients of a backward pass are collected and issued as grouped
     launches at its end (mbv_gemm16_tn_group); ``all`` — every 16-bit arena weight gradient with at least 512 tokens joins
     the group, also those the per-layer policy leaves to the library (few tokens, wide inputs); ``0`` — per-layer launches."""
-    return os.environ.get('MBV_TN_GROUP', '1')
+    return switches.get('tn_group')
 
 
 def _defer_tn_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor) -> bool:
@@ -1240,7 +1245,7 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     t = g2.shape[0]
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
             and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):
-        per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= _TN_MAX_IN or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
+        per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= switches.get('tn_max_in') or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
         # few-token 16-bit products (the decoder's 400-row output projections: a 256 x 256 result over 400 rows) are a
         # handful of work items of the grouped launch; alone, the library ran them as ONE 256 x 256 tile — 30 us each
         few = t <= 512 and gemm16_policy() == 'auto'       # (Swin stage 4's 1024-token layers stay with the library: measured)
@@ -1578,7 +1583,7 @@ class _SharedKVProject(torch.autograd.Function):
         # and a multi-tensor add: 9 launches of 5-20 us.
         def _arena(p):
             return getattr(p, '_mbv_arena', False) and p.grad is not None and p.grad.dtype == torch.float32
-        if (os.environ.get('MBV_SKV_DIRECT', '1') != '0'
+        if (switches.get('skv_direct')
                 and all(_arena(ctx.params[i]) and ctx.needs_input_grad[3 + i] for i in range(2 * n))):
             for j in range(n):
                 w, b_ = ctx.params[2 * j], ctx.params[2 * j + 1]
@@ -2447,7 +2452,7 @@ class _GroupNorm(torch.autograd.Function):
 
 def group_norm_supported(x: torch.Tensor, groups: int) -> bool:
     return (x.is_cuda and x.dim() == 4 and x.dtype in _ACT_DTYPES and x.shape[1] % groups == 0
-            and (x.shape[2] * x.shape[3]) % 4 == 0 and os.environ.get('MBV_GROUPNORM', '1') != '0')
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and switches.get('groupnorm'))
 
 
 def group_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float = 1e-5,
@@ -2525,7 +2530,7 @@ class _MergeLayerNorm(torch.autograd.Function):
 
 def merge_layernorm_supported(x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
-            and add_layernorm_supported(4 * x.shape[3]) and os.environ.get('MBV_MERGE_LN', '1') != '0')
+            and add_layernorm_supported(4 * x.shape[3]) and switches.get('merge_ln'))
 
 
 def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,

@@ -8,14 +8,13 @@ addressing instead of materialising five layout copies per block.
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, switches
 from .layers import FFN, LayerNorm, Linear, PatchEmbed, PatchMerging, trunc_normal_
 
 
@@ -183,6 +182,6 @@ class CustomSwinTransformer(nn.Module):
             if i in self.out_indices:
                 # (B, C, H, W) as the reference returns it, but as a VIEW of the channels-last map: the head's 1 x 1
                 # convolutions read it as tokens (layers.conv1x1), so no NCHW copy is made — forward or backward
-                outs.append(out.permute(0, 3, 1, 2) if out.is_cuda and os.environ.get('MBV_CONV1X1_TOKENS', '1') != '0'
+                outs.append(out.permute(0, 3, 1, 2) if out.is_cuda and switches.get('conv1x1_tokens')
                             else out.permute(0, 3, 1, 2).contiguous())
         return outs

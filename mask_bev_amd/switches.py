@@ -1,0 +1,105 @@
+"""Path selectors of the product, in ONE place and independent of the process environment.
+
+Every alternative path the package can take (a per-op form next to a fused kernel, a grouped launch next to per-layer
+launches) is selected by a named value here.  The defaults are the measured-best configuration DESIGN.md documents;
+nothing in the product path reads ``os.environ`` for them, so two runs of the same build compute the same thing whatever
+shell they were started from.  Tests that compare two forms of one operation use ``override(...)`` (a context manager),
+A/B timing scripts under ``scratch/`` call ``load_from_env()`` explicitly.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import Any, Dict
+
+_DEFAULTS: Dict[str, Any] = {
+    # --- decoder ---------------------------------------------------------------------------------------------------
+    'decoder_fused': True,        # K19 row chains for the transformer decoder's query side (False: per-op path)
+    'rc_ffn': True,               # the MLP pair as one FFN stage of a row chain
+    'rc_split': True,             # MLP stage sliced over f / 256 workgroups
+    'rc_spread': True,            # independent stages of a program spread over 2-3 workgroups
+    'deferred_heads': True,       # prediction heads' backward as one batched pass
+    'shared_kv': True,            # one key / value projection per memory level
+    'skv_direct': True,           # shared-K/V weight gradients straight into the arena rows
+    # --- launch structure ------------------------------------------------------------------------------------------
+    'tail_stream': True,          # FPN tail on a second stream
+    'overlap_matcher': True,      # matcher branch beside the importance sampling
+    'loss_node': True,            # dice / BCE algebra as one autograd node
+    'tn_overlap': False,          # early stages' grouped weight gradients beside the encoder backward (measured slower)
+    'msda_bwd_overlap': False,    # K5 backward's two parts on two streams (measured slower)
+    'wgrad_group': True,          # grouped small-token weight gradients / column sums at the end of a backward pass
+    'tn_group': '1',              # '0' | '1' | 'all': which K17 weight gradients join the grouped launch
+    # --- kernels selected over a library / ATen form ----------------------------------------------------------------
+    'gemm16': 'auto',             # '0' | 'auto' | 'all': which Linear work runs on K17
+    'tn_max_in': 1536,            # widest input of a Linear whose weight gradient K17 takes
+    'k17_fused_min': 4096,        # fewest tokens of an FFN that takes the fused K17 pair
+    'ln_fanout': True,
+    'conv1x1_tokens': True,
+    'msda_fused': True,
+    'msda_packed': True,          # packed fixed-point value gradient in the 16-bit modes
+    'k9_padded': True,
+    'groupnorm': True,
+    'merge_ln': True,
+    'tuned_gemms': True,
+    'pfn_fused': True,            # PFN Linears inside the K2 kernels (False: library GEMMs around them)
+    'swin_fused': True,           # LN1 -> qkv -> window attention -> proj -> residual -> LN2 as one kernel (K20)
+}
+
+_values: Dict[str, Any] = dict(_DEFAULTS)
+
+
+def get(name: str) -> Any:
+    return _values[name]
+
+
+def defaults() -> Dict[str, Any]:
+    return dict(_DEFAULTS)
+
+
+def _coerce(name: str, value: Any) -> Any:
+    d = _DEFAULTS[name]
+    if isinstance(d, bool):
+        if isinstance(value, str):
+            return value not in ('0', '', 'false', 'False')
+        return bool(value)
+    if isinstance(d, int):
+        return int(value)
+    return str(value)
+
+
+def set_value(name: str, value: Any) -> None:
+    if name not in _DEFAULTS:
+        raise KeyError(f'unknown switch {name!r}')
+    _values[name] = _coerce(name, value)
+
+
+@contextlib.contextmanager
+def override(**kw: Any):
+    """``with switches.override(decoder_fused=False): ...`` — for tests that compare two forms of one operation."""
+    old = {k: _values[k] for k in kw}
+    try:
+        for k, v in kw.items():
+            set_value(k, v)
+        yield
+    finally:
+        _values.update(old)
+
+
+def load_from_env(prefix: str = 'MBV_') -> Dict[str, Any]:
+    """A/B scripts only (``scratch/``): take ``MBV_<NAME>=value`` settings from the environment.  Never called by the
+    package, bench.py or the launcher."""
+    taken = {}
+    for k in _DEFAULTS:
+        e = os.environ.get(prefix + k.upper())
+        if e is not None:
+            set_value(k, e)
+            taken[k] = _values[k]
+    return taken
+
+
+def patch(monkeypatch, **kw: Any) -> None:
+    """pytest helper: set values through a ``monkeypatch`` fixture (restored at the end of the test)."""
+    for k, v in kw.items():
+        if k not in _DEFAULTS:
+            raise KeyError(f'unknown switch {k!r}')
+        monkeypatch.setitem(_values, k, _coerce(k, v))

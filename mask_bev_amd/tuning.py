@@ -28,14 +28,16 @@ from typing import Optional
 
 import torch
 
+from . import switches
+
 DEFAULT_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned', 'gemm_gfx950.csv')
 
 
 def use_tuned_gemms(table: Optional[str] = None) -> bool:
     """Look GEMM solutions up in ``table`` (default: the committed gfx950 table).  Returns whether the table was
-    accepted.  ``MBV_TUNED_GEMMS=0`` disables it; an explicit ``PYTORCH_TUNABLEOP_ENABLED`` in the environment is
+    accepted.  ``switches.tuned_gemms = False`` disables it; an explicit ``PYTORCH_TUNABLEOP_ENABLED`` in the environment is
     left alone (the user is driving TunableOp themselves)."""
-    if os.environ.get('MBV_TUNED_GEMMS', '1') == '0' or 'PYTORCH_TUNABLEOP_ENABLED' in os.environ:
+    if not switches.get('tuned_gemms') or 'PYTORCH_TUNABLEOP_ENABLED' in os.environ:
         return False
     if not torch.cuda.is_available():
         return False

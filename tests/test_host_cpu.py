@@ -26,6 +26,30 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.mbv_voxelize_workspace_bytes(120000, 4, 512 * 512) > 4 * 4 * 120000
 
 
+def test_product_library_reads_no_environment():
+    """The shipped library selects no code path from the process environment: it imports no
+    `getenv` / `secure_getenv`, holds no `MBV_*` variable name, and the package's path selectors live in
+    mask_bev_amd/switches.py, which only `load_from_env()` (A/B scripts) connects to `os.environ`."""
+    import subprocess
+    from mask_bev_amd import build, switches
+    lib = build.build()
+    syms = subprocess.run(['nm', '-D', lib], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in syms
+    blob = open(lib, 'rb').read()
+    assert not re.findall(rb'MBV_[A-Z0-9_]{3,}', blob)
+    pkg = os.path.join(ROOT, 'mask_bev_amd')
+    for name in sorted(os.listdir(pkg)):
+        if name.endswith('.py') and name not in ('switches.py', 'build.py'):
+            src = open(os.path.join(pkg, name)).read()
+            assert not re.findall(r"environ[^\n]*MBV_", src), name
+    assert switches.get('decoder_fused') is True and switches.defaults() == switches._values
+    with switches.override(decoder_fused='0', gemm16='all'):
+        assert switches.get('decoder_fused') is False and switches.get('gemm16') == 'all'
+    assert switches.get('decoder_fused') is True and switches.get('gemm16') == 'auto'
+    with pytest.raises(KeyError):
+        switches.set_value('no_such_switch', 1)
+
+
 def test_product_path_refuses_cpu_tensors():
     from mask_bev_amd import ops
     from mask_bev_amd._lib import MaskBevHipError

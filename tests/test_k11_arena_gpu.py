@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+from mask_bev_amd import switches
 
 pytestmark = pytest.mark.gpu
 
@@ -307,8 +308,8 @@ def test_grouped_gradient_work_equals_per_layer_launches(device, monkeypatch):
     batch = (scans, (labels.to(device), gt.to(device)))
     grads = {}
     for mode in ('0', '1'):
-        monkeypatch.setenv('MBV_WGRAD_GROUP', mode)
-        monkeypatch.setenv('MBV_TN_GROUP', mode)
+        switches.patch(monkeypatch, wgrad_group=mode)
+        switches.patch(monkeypatch, tn_group=mode)
         torch.manual_seed(0)
         m = MaskBevModule(**kw).to(device).train()
         m.log_scalars = False

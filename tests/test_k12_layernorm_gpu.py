@@ -3,6 +3,7 @@ pre-LN form (sum returned and used) and direct accumulation of the affine gradie
 import pytest
 import torch
 import torch.nn.functional as F
+from mask_bev_amd import switches
 
 pytestmark = pytest.mark.gpu
 
@@ -137,7 +138,7 @@ def test_patch_merging_module_equals_unfused_path(device, monkeypatch):
         m.norm.bias.normal_()
     res = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('MBV_MERGE_LN', mode)
+        switches.patch(monkeypatch, merge_ln=mode)
         x = torch.randn(2, 16, 20, 96, device=device, generator=torch.Generator(device=device).manual_seed(3)).requires_grad_()
         for p in m.parameters():
             p.grad = None
@@ -146,7 +147,7 @@ def test_patch_merging_module_equals_unfused_path(device, monkeypatch):
         res[mode] = (y.detach(), x.grad, m.norm.weight.grad.clone(), m.norm.bias.grad.clone(), m.reduction.weight.grad.clone())
     for a, b in zip(res['1'], res['0']):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
-    monkeypatch.setenv('MBV_MERGE_LN', '1')
+    switches.patch(monkeypatch, merge_ln='1')
     y = m(torch.randn(1, 7, 9, 96, device=device))
     assert tuple(y.shape) == (1, 4, 5, 192)
 

@@ -6,6 +6,7 @@ import math
 
 import pytest
 import torch
+from mask_bev_amd import switches
 
 gpu = pytest.mark.gpu
 
@@ -238,7 +239,7 @@ def test_fused_ffn_matches_unfused_layers(act, monkeypatch):
     g0 = torch.randn(2, rows // 2, c, device=_dev()).to(torch.bfloat16)
 
     def run(policy):
-        monkeypatch.setenv('MBV_GEMM16', policy)
+        switches.patch(monkeypatch, gemm16=policy)
         torch.manual_seed(5)
         m = layers.FFN(c, 4 * c, act=act).to(_dev())
         arena = ParameterArena([('ffn', m)])

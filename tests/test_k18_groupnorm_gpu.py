@@ -5,6 +5,7 @@ tensor's largest entry; 16-bit outputs one rounding of the type (bf16 2^-8, fp16
 import pytest
 import torch
 import torch.nn.functional as F
+from mask_bev_amd import switches
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +69,7 @@ def test_conv_gn_module_equals_torch_path(device, monkeypatch):
             m.gn.bias.normal_()
         res = {}
         for mode in ('1', '0'):
-            monkeypatch.setenv('MBV_GROUPNORM', mode)
+            switches.patch(monkeypatch, groupnorm=mode)
             gen = torch.Generator(device=device).manual_seed(5)
             x = torch.randn(2, 48, 24, 16, device=device, generator=gen).requires_grad_()
             add = torch.randn(2, 64, 12, 8, device=device, generator=gen).requires_grad_() if with_add else None

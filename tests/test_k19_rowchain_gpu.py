@@ -8,6 +8,7 @@
   through the fused path by default."""
 import pytest
 import torch
+from mask_bev_amd import switches
 
 pytestmark = pytest.mark.gpu
 
@@ -315,6 +316,23 @@ def test_rowchain_rejects_bad_programs():
         P.run()
     with pytest.raises(MaskBevHipError):
         DF.Program(16, 16, 1e-5, torch.bfloat16).gemm(1, 0, w, 64, 64)     # weight dtype != program dtype
+    # an accumulating store of a split launch without an owner would be added once per workgroup of the row block:
+    # refused by the host-side builder and, for callers of the C ABI, by the library (MBV_ERR_BAD_ARG)
+    acc = torch.zeros((16, 64), device='cuda')
+    P = DF.Program(16, 16, 1e-5, torch.float32, split=2)
+    P.load(0, x, 64)
+    with pytest.raises(MaskBevHipError):
+        P.store(0, acc, 64, accum=True)
+    with P.only(1):
+        P.store(0, acc, 64, accum=True)          # owned: fine
+    P.run()
+    P = DF.Program(16, 16, 1e-5, torch.float32, split=2)
+    P.load(0, x, 64)
+    with P.only(0):
+        P.store(0, acc, 64, accum=True)
+    P.stages[-1].flags &= 0xff                   # strip the owner behind the builder's back
+    with pytest.raises(MaskBevHipError):
+        P.run()
 
 
 def _fragment_layout(w):
@@ -368,7 +386,7 @@ def _run_model(device, dtype, fused, monkeypatch, arena):
     from mask_bev_amd.mask_bev_module import MaskBevModule
     from oracle import maskbev_oracle as O
     from tests.util_cfg import random_gt, random_scans, tiny_kwargs
-    monkeypatch.setenv('MBV_DECODER_FUSED', '1' if fused else '0')
+    switches.patch(monkeypatch, decoder_fused='1' if fused else '0')
     okw = tiny_kwargs()
     kw = dict(okw, compute_dtype=dtype)
     sd = O.make_state_dict(O.make_cfg(**okw), 7)
@@ -410,6 +428,30 @@ def test_fused_decoder_equals_unfused_path(device, monkeypatch, dtype, arena):
     assert g_f.keys() == g_u.keys()
     worst = max((rel(g_f[k], g_u[k]), k) for k in g_u)
     assert worst[0] < tg, worst
+
+
+def test_no_grad_forward_between_training_forward_and_backward(device):
+    """A forward under no_grad through the same head between a training forward and its backward (a sanity validation,
+    the bench's extra eager steps) refreshes the chains' weight copies WITHOUT the transposed operands; the pending
+    backward must still find its own (WeightCopies.refresh used to wipe them -> KeyError)."""
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+    okw = tiny_kwargs()
+    torch.manual_seed(3)
+    m = MaskBevModule(**dict(okw, compute_dtype='bf16')).to(device).train()
+    m.flatten_parameters()
+    scans = [s.to(device) for s in random_scans(okw, [3000, 2000], seed=2)]
+    labels, gt = random_gt(okw, 2, 3, seed=4)
+    batch = (scans, (labels.to(device), gt.to(device)))
+    loss = m.training_step(batch, 0)
+    with torch.no_grad():
+        m(scans)                                   # the interleaved inference pass
+    m.scale_loss(loss).backward()
+    from mask_bev_amd import ops
+    ops.flush_deferred_grads()
+    torch.cuda.synchronize()
+    g = m._panoptic_head._panoptic_head.transformer_decoder.layers[0].ffn.layers[1].weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
 
 
 def test_fragment_group_more_entries_than_one_launch_takes():

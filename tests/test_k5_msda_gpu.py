@@ -161,3 +161,47 @@ def test_msda_value_gradient_packed_worst_case_range(device):
     got, ref, gmax = _packed_case(device, 1, 8, [(16, 16), (32, 32), (64, 64)], 0, torch.float32, 'one_pixel')
     assert float(ref.abs().max()) > 1000.0
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_msda_layer_with_a_level_beyond_the_split_backward(device, dt):
+    """A 72 x 72 level (5 184 pixels) is beyond the no-global-atomics backward (<= 4 096 pixels per level), so the packed
+    value gradient — whose location / weight part is that backward's second half — must report itself unsupported and
+    the layer's 16-bit backward must take the general path instead of raising.  Gradients against the same
+    layer in f32."""
+    import ctypes
+    from mask_bev_amd import _lib
+    from mask_bev_amd.layers import MultiScaleDeformableAttention
+    shapes = [(72, 72), (36, 36)]
+    host = (ctypes.c_int64 * 4)(72, 72, 36, 36)
+    lib = _lib.load()
+    n = sum(h * w for h, w in shapes)
+    assert lib.mbv_ms_deform_attn_bwd_split(32, 2, host) == 0
+    assert lib.mbv_ms_deform_attn_bwd_value_packed_supported(32, 2, 4, n, host) == 0
+    ok = (ctypes.c_int64 * 4)(64, 64, 36, 36)
+    assert lib.mbv_ms_deform_attn_bwd_value_packed_supported(32, 2, 4, 64 * 64 + 36 * 36, ok) == 1
+    torch.manual_seed(0)
+    m = MultiScaleDeformableAttention(256, 8, 2, 4).to(device)
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.02)
+        m.attention_weights.weight.normal_(0, 0.05)
+    g = torch.Generator(device=device).manual_seed(1)
+    x0 = torch.randn(1, n, 256, device=device, generator=g)
+    pos = torch.randn(1, n, 256, device=device, generator=g)
+    ref_pts = torch.rand(n, 2, device=device, generator=g)
+    shapes_t = torch.tensor(shapes, dtype=torch.int64, device=device)
+    level_start = torch.tensor([0, 72 * 72], dtype=torch.int64, device=device)
+    gy = torch.randn(1, n, 256, device=device, generator=g)
+    res = {}
+    for mode in (torch.float32, dt):
+        x = x0.clone().requires_grad_()
+        for p in m.parameters():
+            p.grad = None
+        with torch.autocast('cuda', dtype=dt, enabled=mode != torch.float32):
+            y = m(x, pos, ref_pts, shapes, shapes_t, level_start)
+        (y.float() * gy).sum().backward()
+        res[mode] = (y.detach().float(), x.grad.clone(), m.value_proj.weight.grad.clone())
+    tol = 4e-2 if dt == torch.bfloat16 else 1e-2
+    for a, b in zip(res[dt], res[torch.float32]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).norm() / b.norm()) < tol

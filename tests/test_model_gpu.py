@@ -5,6 +5,7 @@ import torch
 
 from oracle import maskbev_oracle as O
 from tests.util_cfg import random_gt, random_scans, tiny_kwargs
+from mask_bev_amd import switches
 
 pytestmark = pytest.mark.gpu
 
@@ -389,11 +390,11 @@ def test_deferred_heads_backward_equals_per_layer_backward(device, dtype, monkey
     grads, losses = {}, {}
     # the fused query side (K19) requires the deferred heads; this test is about the heads, so both runs use the
     # per-op decoder (the fused one is compared with it in tests/test_k19_rowchain_gpu.py)
-    monkeypatch.setenv('MBV_DECODER_FUSED', '0')
+    switches.patch(monkeypatch, decoder_fused='0')
     scans = random_scans(kw, [3000, 2000], seed=2)
     labels, gt = random_gt(kw, 2, 3, seed=4)
     for mode in ('1', '0'):
-        monkeypatch.setenv('MBV_DEFERRED_HEADS', mode)
+        switches.patch(monkeypatch, deferred_heads=mode)
         m, cfg, sd = _build(kw, device, seed=7)
         head = m._panoptic_head._panoptic_head
         head.num_points = 256
