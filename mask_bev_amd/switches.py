@@ -41,8 +41,6 @@ _DEFAULTS: Dict[str, Any] = {
     'groupnorm': True,
     'merge_ln': True,
     'tuned_gemms': True,
-    'pfn_fused': True,            # PFN Linears inside the K2 kernels (False: library GEMMs around them)
-    'swin_fused': True,           # LN1 -> qkv -> window attention -> proj -> residual -> LN2 as one kernel (K20)
 }
 
 _values: Dict[str, Any] = dict(_DEFAULTS)
