@@ -214,6 +214,7 @@ def pfn_decorate(p: Pillars, voxel_size: Sequence[float], pc_range: Sequence[flo
     lib = _lib.load()
     dim = int(p.points.shape[1])
     dev = p.points.device
+    _lib.WORK_HINT['pfn_rows'] = int(p.num_rows)
     rows = torch.empty((p.num_rows, dim + 7), dtype=torch.float32, device=dev)
     row_pillar = torch.empty((p.num_rows,), dtype=torch.int64, device=dev)
     vx, vy, vz = [float(v) for v in voxel_size]
@@ -240,6 +241,7 @@ class _PillarFeatureNet(torch.autograd.Function):
         dev = rows.device
         n_layers = len(params) // 5
         k = int(rows.shape[0])
+        _lib.WORK_HINT['pfn_rows'] = k          # (read by workmodel.py under bench.py's hook only)
         count = float(v * p)
         st = _stream()
         with torch.autocast('cuda', enabled=False):

@@ -204,7 +204,75 @@ def _colsum_group(a) -> Work:
     return ('k_colsum_group', 'hbm', by, 0.0)
 
 
+def _pfn(a, kernel: str, rows_per_unit: float, pillars_per_unit: float, iv: int, iu: int) -> Work:
+    """K2b per-pillar kernels: `rows_per_unit` (K, U) and `pillars_per_unit` (V, U) f32 tensors read or written once.
+    The row count K is not an argument of these calls (rows live behind row_start): bench.py leaves it in WORK_HINT."""
+    from . import _lib
+    k = _lib.WORK_HINT.get('pfn_rows', 0)
+    v, u = _i(a[iv]), _i(a[iu])
+    return (kernel, 'hbm', (rows_per_unit * k + pillars_per_unit * v) * u * 4.0, 0.0)
+
+
+def _decorate(a) -> Work:
+    from . import _lib
+    k, dim = _lib.WORK_HINT.get('pfn_rows', 0), _i(a[1])
+    return ('k_pfn_decorate', 'hbm', k * (dim * 4.0 + (dim + 7) * 4.0 + 8.0 + 4.0), 0.0)     # point, row, row_pillar, index
+
+
+def _voxelize(a) -> Work:
+    """K1: every point read once (point_dim f32) and its (cell, index) key pair written / read by the sort passes'
+    first and last step; pillar outputs (coors, counts, 32 point indices per pillar) and the dense cell map."""
+    n, dim, batch, gx, gy = _i(a[2]), _i(a[1]), _i(a[4]), _i(a[14]), _i(a[15])
+    pillars = _i(a[20])
+    return ('k_voxelize (22 launches)', 'hbm', n * (dim * 4.0 + 16.0 + 8.0) + pillars * (16.0 + 4.0 + 128.0 + 4.0)
+            + batch * gx * gy * 4.0, 0.0)
+
+
+def _msda_prepare(a, bwd: bool) -> Work:
+    if bwd:
+        b, nq, heads, levels, pts, lo = (_i(a[i]) for i in (4, 5, 6, 7, 8, 9))
+        per = b * nq * heads * levels * pts
+        return ('k_msda_prepare_bwd', 'hbm', per * (12.0 + 4.0) + per * 3.0 * (2.0 if lo else 4.0), 0.0)
+    lo, b, nq, heads, levels, pts = (_i(a[i]) for i in (2, 5, 6, 7, 8, 9))
+    per = b * nq * heads * levels * pts
+    return ('k_msda_prepare_fwd', 'hbm', per * 3.0 * (2.0 if lo else 4.0) + per * 12.0, 0.0)
+
+
+def _copy_group(a, kernel: str, es_index: int) -> Work:
+    rows, cols, n = a[2], a[3], _i(a[6] if kernel == 'k_fragment_group' else a[4])
+    es = 2.0 if kernel == 'k_fragment_group' else float(_i(a[es_index]))
+    return (kernel, 'hbm', sum(2.0 * rows[j] * cols[j] * es for j in range(n)), 0.0)
+
+
+# ---- work of the library calls torch makes for the path (bench.py's dispatch-mode timer) -----------------------------
+def gemm_work(m: int, n: int, k: int, batch: int, es_in: float, es_out: float, extra_bytes: float = 0.0) -> Tuple[float, float]:
+    return batch * ((m * k + k * n) * es_in + m * n * es_out) + extra_bytes, 2.0 * batch * m * n * k
+
+
 MODELS: Dict[str, Callable[[tuple], Work]] = {
+    'mbv_voxelize': _voxelize,
+    'mbv_pfn_decorate': lambda a: _decorate(a),
+    # stats: y read (+ written when t is added); apply: y read, a written (not for the last layer), m written
+    'mbv_pfn_stats': lambda a: _pfn(a, 'k_pfn_stats', 2.0 if a[1] else 1.0, 3.0 if a[1] else 1.0, 5, 6),
+    'mbv_pfn_apply_max': lambda a: _pfn(a, 'k_pfn_apply_max', 2.0 if a[9] else 1.0, 3.0 if a[10] else 2.0, 6, 7),
+    # route: y, dA (when present) read, dz written; dM, y_pad, dz_pad per pillar.  bn: y, dz read, dy written
+    'mbv_pfn_bwd_route': lambda a: _pfn(a, 'k_pfn_bwd_route', 3.0 if _i(a[7]) else 2.0, 4.0, 12, 13),
+    'mbv_pfn_bwd_bn': lambda a: _pfn(a, 'k_pfn_bwd_bn', 3.0, 4.0, 12, 13),
+    'mbv_msda_prepare_fwd': lambda a: _msda_prepare(a, False),
+    'mbv_msda_prepare_bwd': lambda a: _msda_prepare(a, True),
+    'mbv_msda_prepare_bwd_ld': lambda a: _msda_prepare(a, True),
+    'mbv_msda_query_inputs': lambda a: ('k_msda_query_inputs', 'hbm',
+                                        _i(a[2]) * _i(a[4]) * (4.0 + 2.0 + 2.0) + _i(a[3]) * _i(a[4]) * 4.0, 0.0),
+    'mbv_fragment_group': lambda a: _copy_group(a, 'k_fragment_group', 0),
+    'mbv_transpose_group': lambda a: _copy_group(a, 'k_transpose_group', 5),
+    'mbv_hungarian_padded': lambda a: ('k_hungarian', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 4.0 + _i(a[1]) * _i(a[2]) * 4.0, 0.0),
+    'mbv_uniform_points': lambda a: ('k_uniform_points', 'hbm', _i(a[1]) * _i(a[2]) * 8.0, 0.0),
+    'mbv_pack_binary_masks': lambda a: ('k_pack_binary', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * (4.0 + 1.0 / 8.0), 0.0),
+    'mbv_attn_mask_from_logits': lambda a: ('k_attn_mask', 'hbm',
+                                            _i(a[2]) * (_i(a[3]) * _i(a[4]) * (2.0 if _i(a[1]) else 4.0) + _i(a[5]) * _i(a[6])), 0.0),
+    'mbv_gemm16_nt_acc': lambda a: ('k_gemm16<NT,acc>', 'mfma',
+                                    _i(a[11]) * ((_i(a[3]) + _i(a[4])) * _i(a[5]) * 2.0 + 2.0 * _i(a[3]) * _i(a[4]) * 4.0),
+                                    2.0 * _i(a[11]) * _i(a[3]) * _i(a[4]) * _i(a[5])),
     'mbv_window_attn_fwd': lambda a: _window_attn(a, False),
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
     'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
@@ -258,3 +326,97 @@ def peak_of(bound: str) -> Tuple[float, str]:
     if bound == 'mfma_f32':
         return MFMA_F32_TFLOPS, 'TFLOP/s'
     return HBM_PEAK_GBS, 'GB/s'
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Library work torch issues for the path: hipBLASLt GEMMs, MIOpen convolutions, ATen element-wise / reduction kernels.
+# bench.py times them with the same HIP-event brackets as the C-ABI calls, through a TorchDispatchMode that sees every
+# ATen operator of the instrumented eager step (forward, the autograd engine's backward, the optimizer glue), so that
+# `roofline_all` prices the WHOLE step and not only this repository's kernels.
+# ---------------------------------------------------------------------------------------------------------------------
+_NO_KERNEL = ('aten::empty', 'aten::new_empty', 'aten::as_strided', 'aten::detach', 'aten::alias', 'aten::_unsafe_view',
+              'aten::view', 'aten::_reshape_alias', 'aten::resize_', 'aten::set_', 'aten::lift_fresh', 'aten::is_',
+              'aten::sym_', 'aten::record_stream', 'aten::_local_scalar_dense', 'aten::stride', 'aten::size',
+              'aten::_to_copy_view', 'prim::', 'aten::_has_', 'aten::is_same_size', 'aten::_nested')
+_REDUCTIONS = ('sum', 'mean', 'amax', 'amin', 'max', 'min', 'softmax', 'norm', 'sort', 'topk', 'cumsum', 'argmax', 'argmin',
+               'nll_loss', 'var', 'std', 'prod', 'all', 'any', 'logsumexp')
+
+
+def _tensors(x, out):
+    import torch
+    if isinstance(x, torch.Tensor):
+        out.append(x)
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            _tensors(y, out)
+
+
+def _nbytes(ts) -> float:
+    return float(sum(t.numel() * t.element_size() for t in ts))
+
+
+def aten_work(func, args, kwargs, result, cuda_only: bool = True):
+    """(family, bound, bytes, flops) of one ATen operator call, or None when it launches nothing (views, allocations).
+    GEMMs: 2 M N K flops, operands + result bytes (hipBLASLt; family by operand dtype).  Convolutions: MIOpen.  Everything
+    else: a streaming kernel that reads its tensor arguments and writes its results once."""
+    import torch
+    name = func._schema.name
+    if getattr(func, 'is_view', False) or name.startswith(_NO_KERNEL):
+        return None
+    ins, outs = [], []
+    _tensors(list(args) + list((kwargs or {}).values()), ins)
+    _tensors(result, outs)
+    if cuda_only:
+        ins = [t for t in ins if t.is_cuda]
+        outs = [t for t in outs if t.is_cuda]
+    if not ins and not outs:
+        return None
+    short = name.split('::')[-1]
+    if short in ('mm', 'addmm', 'bmm', 'baddbmm', '_scaled_mm'):
+        mats = [t for t in ins if t.dim() >= 2][-2:]
+        if len(mats) == 2:
+            a, b = mats
+            batch = a.shape[0] if a.dim() == 3 else 1
+            m, k, n = a.shape[-2], a.shape[-1], b.shape[-1]
+            f32 = a.dtype == torch.float32
+            by = _nbytes(ins) + _nbytes(outs)
+            return ('hipblaslt_f32' if f32 else 'hipblaslt_16bit', 'mfma_f32' if f32 else 'mfma', by, 2.0 * batch * m * n * k)
+    if short in ('convolution', 'convolution_backward', 'miopen_convolution', 'cudnn_convolution', '_convolution'):
+        bwd = short == 'convolution_backward'
+        x = ins[1] if bwd else ins[0]
+        w = ins[2] if bwd else ins[1]
+        o = ins[0] if bwd else outs[0]
+        cout, cin_g, kh, kw = w.shape[0], w.shape[1], w.shape[-2], w.shape[-1]
+        fl = 2.0 * o.shape[0] * cout * o.shape[-2] * o.shape[-1] * cin_g * kh * kw
+        f32 = x.dtype == torch.float32
+        return ('miopen_conv', 'mfma_f32' if f32 else 'mfma', _nbytes(ins) + _nbytes(outs), fl * (2.0 if bwd else 1.0))
+    # in-place / out= variants name their destination among the inputs: it is written once more
+    family = 'aten_reduce' if any(r in short for r in _REDUCTIONS) else 'aten_elementwise'
+    seen = {t.data_ptr() for t in ins}
+    by = _nbytes(ins) + _nbytes([t for t in outs if t.data_ptr() not in seen]) \
+        + _nbytes([t for t in outs if t.data_ptr() in seen and func._schema.is_mutable])
+    return (family, 'hbm', by, 0.0)
+
+
+def aten_timer(records: list):
+    """A TorchDispatchMode that brackets every kernel-launching ATen call with HIP events on the current stream and
+    appends ``((family, bound, bytes, flops), start, end)`` to ``records`` (bench.py only)."""
+    import torch
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class _Timer(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            name = func._schema.name
+            if getattr(func, 'is_view', False) or name.startswith(_NO_KERNEL):
+                return func(*args, **kwargs)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = func(*args, **kwargs)
+            b.record()
+            work = aten_work(func, args, kwargs, out)
+            if work is not None:
+                records.append((work, a, b))
+            return out
+
+    return _Timer()

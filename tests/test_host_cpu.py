@@ -331,6 +331,41 @@ def test_workmodel_prices_every_instrumented_entry_point():
     assert by == (4096 * (768 + 768) + 400 * (256 + 256)) * 2.0 + 2 * (768 * 768 + 256 * 256) * 4.0
 
 
+def test_workmodel_prices_library_calls_known_answers():
+    """The families bench.py prices through its dispatch mode: hipBLASLt GEMMs by operand dtype with
+    2 M N K flops, MIOpen convolutions, streaming ATen kernels by the bytes of their tensors; views and allocations
+    launch nothing.  The C-ABI models added in round 4 (PFN, K1, K16) against their shapes."""
+    import ctypes
+    from mask_bev_amd import _lib, workmodel as W
+    A = torch.ops.aten
+    x, w, b = torch.zeros(100, 64), torch.zeros(32, 64), torch.zeros(32)
+    fam, bound, by, fl = W.aten_work(A.addmm.default, (b, x, w.t()), {}, torch.zeros(100, 32), cuda_only=False)
+    assert (fam, bound, fl) == ('hipblaslt_f32', 'mfma_f32', 2.0 * 100 * 32 * 64)
+    assert by == (100 * 64 + 64 * 32 + 32 + 100 * 32) * 4
+    xb = torch.zeros(4, 100, 64, dtype=torch.bfloat16)
+    fam, bound, by, fl = W.aten_work(A.bmm.default, (xb, xb.transpose(1, 2)), {}, torch.zeros(4, 100, 100, dtype=torch.bfloat16),
+                                     cuda_only=False)
+    assert (fam, bound, fl) == ('hipblaslt_16bit', 'mfma', 2.0 * 4 * 100 * 100 * 64)
+    img, ker = torch.zeros(2, 8, 16, 16), torch.zeros(4, 8, 3, 3)
+    fam, bound, by, fl = W.aten_work(A.convolution.default, (img, ker, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1), {},
+                                     torch.zeros(2, 4, 16, 16), cuda_only=False)
+    assert (fam, fl) == ('miopen_conv', 2.0 * 2 * 4 * 16 * 16 * 8 * 9)
+    fam, bound, by, fl = W.aten_work(A.add.Tensor, (x, x), {}, torch.zeros(100, 64), cuda_only=False)
+    assert (fam, bound, by, fl) == ('aten_elementwise', 'hbm', 3 * 100 * 64 * 4, 0.0)
+    assert W.aten_work(A.sum.default, (x,), {}, torch.zeros(()), cuda_only=False)[0] == 'aten_reduce'
+    assert W.aten_work(A.view.default, (x, [64, 100]), {}, x.view(64, 100), cuda_only=False) is None
+    assert W.aten_work(A.empty.memory_format, ([3, 3],), {}, torch.empty(3, 3), cuda_only=False) is None
+    # K2b kernels: K rows from the hint, V pillars and U units from the arguments
+    _lib.WORK_HINT['pfn_rows'] = 1000
+    P = ctypes.c_void_p
+    k, bound, by, fl = W.MODELS['mbv_pfn_stats']((P(1), P(2), P(3), P(4), P(5), 200, 64, 32, P(6), None))
+    assert (k, bound) == ('k_pfn_stats', 'hbm') and by == (2 * 1000 + 3 * 200) * 64 * 4
+    assert W.MODELS['mbv_pfn_stats']((P(1), P(None), P(3), P(4), P(5), 200, 64, 32, P(6), None))[2] == (1000 + 200) * 64 * 4
+    assert W.MODELS['mbv_pfn_bwd_bn']((None,) * 12 + (200, 128, 32, None, None))[2] == (3 * 1000 + 4 * 200) * 128 * 4
+    assert W.MODELS['mbv_msda_prepare_fwd']((None, None, 1, None, None, 4, 5376, 8, 3, 4, None, None, None))[2] == \
+        4 * 5376 * 8 * 3 * 4 * (3 * 2 + 12)
+
+
 def test_workmodel_add_layernorm_bwd2_known_answer():
     """K12's backward with two gradients of y: bf16 dy2 beside an f32 dy, no residual-path gradient, 16-bit dx copy."""
     import ctypes
@@ -349,9 +384,20 @@ def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
     The line also carries the contract's objects."""
     import glob
     import json
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', '*bench_default.json')))
-    assert files, 'no committed bench line under profiles/r03'
+    rounds = sorted(d for d in glob.glob(os.path.join(ROOT, 'profiles', 'r*')) if glob.glob(os.path.join(d, '*bench_default.json')))
+    assert rounds, 'no committed bench line under profiles/'
+    files = sorted(glob.glob(os.path.join(rounds[-1], '*bench_default.json')))
     line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    if os.path.basename(rounds[-1]) >= 'r04':
+        # round 4: the table prices the WHOLE step (library GEMMs, MIOpen, ATen kernels, PFN, K1 included): the families'
+        # time per step adds up to at least 0.9 of the measured step, and `roofline` is the family that costs the most
+        total = sum(r['total_ms_per_step'] for r in line['roofline_all'])
+        assert total >= 0.9 * line['ms_per_step'], (total, line['ms_per_step'])
+        assert abs(line['roofline_coverage'] - total / line['ms_per_step']) < 1e-6
+        assert line['roofline']['kernel'] == max(line['roofline_all'], key=lambda r: r['total_ms_per_step'])['kernel']
+        assert {'hipblaslt_16bit', 'aten_elementwise', 'k_pfn_bwd_route', 'k_hungarian'} <= {r['kernel'] for r in line['roofline_all']}
+        assert line['cpu_baseline']['sample'].startswith('n = 1 scan') and '3 timed iterations' in line['cpu_baseline']['sample']
+        assert line['fp32']['roofline']['kernel'] and line['fp32']['roofline_coverage'] > 0.8
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in line, key
