@@ -604,10 +604,13 @@ def forward_head(cfg, sd: SD, decoder_out: Tensor, mask_feature: Tensor, target_
     return cls_pred, mask_pred, attn_mask
 
 
-def head_forward(cfg, sd: SD, feats: List[Tensor], prefix: str = HEAD, return_parts: bool = False):
-    """Mask2FormerHead.forward, mask2former_head.py:474-562 → (cls_list, mask_list, [None]*n)."""
+def head_forward(cfg, sd: SD, feats: List[Tensor], prefix: str = HEAD, return_parts: bool = False, pixel_decoder=None):
+    """Mask2FormerHead.forward, mask2former_head.py:474-562 → (cls_list, mask_list, [None]*n).  ``pixel_decoder``:
+    optional callable feats -> (mask_features, memories) in place of the restated MSDeformAttnPixelDecoder (the second
+    head fixture pins this function against the reference with a stand-in that is independent of this file)."""
     bs = feats[0].shape[0]
-    mask_features, memories = pixel_decoder_forward(cfg, sd, feats, prefix + 'pixel_decoder.')
+    mask_features, memories = (pixel_decoder(feats) if pixel_decoder is not None
+                               else pixel_decoder_forward(cfg, sd, feats, prefix + 'pixel_decoder.'))
     nl = cfg.pd_levels
     dec_in, dec_pos = [], []
     for i in range(nl):

@@ -170,6 +170,28 @@ class PixelDecoderShim(nn.Module):
         return O.pixel_decoder_forward(self.cfg_ns, sd, feats)
 
 
+class LinearPixelDecoderShim(nn.Module):
+    """A pixel decoder that owes NOTHING to the oracle: fixed random 1 x 1 linear maps of the backbone features —
+    mask_features = W_m feats[0], memories = (W_0 feats[3], W_1 feats[2], W_2 feats[1]) (coarse to fine, the order mmdet's
+    MSDeformAttnPixelDecoder returns).  With it the head fixture pins the reference's Mask2FormerHead.forward / loss
+    independently of ``O.pixel_decoder_forward`` (the first fixture's stand-in IS the oracle's restatement)."""
+
+    def __init__(self, in_channels, feat, out, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.wm = nn.Parameter(torch.randn(out, in_channels[0], generator=g) / math.sqrt(in_channels[0]))
+        self.wl = nn.ParameterList([nn.Parameter(torch.randn(feat, c, generator=g) / math.sqrt(c))
+                                    for c in (in_channels[3], in_channels[2], in_channels[1])])
+
+    def init_weights(self):
+        pass
+
+    def forward(self, feats):
+        mask_features = torch.einsum('oc,bchw->bohw', self.wm, feats[0])
+        memories = [torch.einsum('oc,bchw->bohw', w, f) for w, f in zip(self.wl, (feats[3], feats[2], feats[1]))]
+        return mask_features, memories
+
+
 class InstanceData:
     def __init__(self, **kw):
         self.__dict__.update(kw)
@@ -257,6 +279,11 @@ def _install_shims(state):
         def build(self, cfg, default_args=None):
             t = cfg['type'].split('.')[-1]
             if t == 'MSDeformAttnPixelDecoder':
+                if state.get('pd_kind') == 'linear':
+                    c = state['cfg']
+                    e = c.embed_dim
+                    state['pd'] = LinearPixelDecoderShim([e, 2 * e, 4 * e, 8 * e], c.head_feat, c.head_out, seed=77)
+                    return state['pd']
                 return PixelDecoderShim(state['cfg'], state['sd'])
             if t == 'HungarianAssigner':
                 return _Assigner(state['cfg'])
@@ -393,6 +420,10 @@ def golden_head(ref_head_mod, name, seed, with_loss=True):
         cls_list, mask_list, _ = head.forward(feats, metas)
     out = {f'feat{i}': f for i, f in enumerate(feats)}
     out.update({'sd.' + k: v for k, v in sd.items() if k.startswith(O.HEAD)})
+    if STATE.get('pd_kind') == 'linear':           # the stand-in's own maps travel with the fixture
+        out['pd_lin.wm'] = STATE['pd'].wm
+        for i, w in enumerate(STATE['pd'].wl):
+            out[f'pd_lin.w{i}'] = w
     out.update({f'cls{i}': c for i, c in enumerate(cls_list)})
     out.update({f'mask{i}': m for i, m in enumerate(mask_list)})
     if with_loss:
@@ -424,3 +455,5 @@ if __name__ == '__main__':
     golden_swin(swin, 'swin_nonsquare_pad_44x36.npz', (44, 36), 5, 8, 4, (2, 2, 2, 2), (1, 2, 4, 8), seed=2)
     head_mod = _load_ref('ref_m2f_head', 'mask_bev/models/networks/mask2former_head/mask2former_head.py')
     golden_head(head_mod, 'mask2former_head_q6.npz', seed=3)
+    STATE['pd_kind'] = 'linear'
+    golden_head(head_mod, 'mask2former_head_linpd_q6.npz', seed=5)

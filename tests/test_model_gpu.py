@@ -258,16 +258,23 @@ def test_16bit_whole_model_against_fp32_oracle(device, capsys, dtype):
     scans = random_scans(okw, [3000, 2000], seed=2)
     labels, gt = random_gt(okw, 2, 3, seed=4)
     dscans = [s.to(device) for s in scans]
-    with torch.no_grad():
-        cls, masks, _ = m(dscans)
-    loss = m.training_step((dscans, (labels.to(device), gt.to(device))), 1)
-    m.scale_loss(loss).backward()
     sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
             for k, v in sd.items()}
-    cls_ref, masks_ref, _ = O.model_forward(cfg, sd_g, scans, training=True)
-    loss_ref = O.total_loss(O.loss_dict(cfg, cls_ref, masks_ref, labels, gt, O.PointSource(11)))
+    cls_ref, masks_ref, loss_ref, blocked_ref, _ = _oracle_with_decisions(cfg, sd_g, scans, labels, gt, 11)
     loss_ref.backward()
-    errs = {}
+    from mask_bev_amd import ops
+    ops.TEACHER.clear()
+    ops.TEACHER.update(blocked=[t.to(device) for t in blocked_ref], replace=False)     # count the flips, change nothing
+    try:
+        with torch.no_grad():
+            cls, masks, _ = m(dscans)
+        torch.cuda.synchronize()
+        flips = [int(x) for x in ops.TEACHER.get('blocked_flips', [])]
+    finally:
+        ops.TEACHER.clear()
+    loss = m.training_step((dscans, (labels.to(device), gt.to(device))), 1)
+    m.scale_loss(loss).backward()
+    errs = {'attention-mask bits that differ from the oracle\'s, per decoder layer': flips}
     errs['mask_logits_final'] = _rel(masks[-1].float().cpu(), masks_ref[-1].detach())
     errs['mask_logits_worst_layer'] = max(_rel(masks[i].float().cpu(), masks_ref[i].detach()) for i in range(10))
     errs['cls_logits_worst_layer'] = max(_rel(cls[i].float().cpu(), cls_ref[i].detach()) for i in range(10))
@@ -296,6 +303,135 @@ def test_16bit_whole_model_against_fp32_oracle(device, capsys, dtype):
     assert errs['cls_logits_worst_layer'] < TOL['logits_any_layer']
     assert errs['loss'] < TOL['loss']
     assert worst < TOL['grad'] and worst_l2 < TOL['grad_l2']
+
+
+def _oracle_with_decisions(cfg, sd_g, scans, labels, gt, seed):
+    """The fp32 oracle's forward + loss, and the DECISIONS it took on the way: the ten attention masks of
+    Mask2FormerHead._forward_head (mask2former_head.py:460-470, after the all-blocked-row rule of :538-539) and the
+    Hungarian assignment of every (decoder output, image)."""
+    import scipy.optimize
+    masks_seen, pairs = [], []
+    fh, lsa = O.forward_head, scipy.optimize.linear_sum_assignment
+
+    def forward_head(*a, **k):
+        out = fh(*a, **k)
+        masks_seen.append(out[2])          # head_forward applies the unblock rule to this tensor IN PLACE afterwards
+        return out
+
+    def linear_sum_assignment(cost, *a, **k):
+        r, c = lsa(cost, *a, **k)
+        pairs.append((tuple(cost.shape), r.copy(), c.copy()))
+        return r, c
+
+    O.forward_head, scipy.optimize.linear_sum_assignment = forward_head, linear_sum_assignment
+    try:
+        cls_ref, masks_ref, _ = O.model_forward(cfg, sd_g, scans, training=True)
+        loss_ref = O.total_loss(O.loss_dict(cfg, cls_ref, masks_ref, labels, gt, O.PointSource(seed)))
+    finally:
+        O.forward_head, scipy.optimize.linear_sum_assignment = fh, lsa
+    b = len(scans)
+    blocked = []
+    for am in masks_seen:                  # (B * heads, Q, L) bool, identical over the heads -> (B, 1, Q, L)
+        bh, q, l = am.shape
+        blocked.append(am.view(b, bh // b, q, l)[:, :1].contiguous())
+    nq = pairs[0][0][0]
+    assignment = torch.full((len(pairs), nq), -1, dtype=torch.int32)
+    for i, (_, r, c) in enumerate(pairs):  # decoder-output major, image minor: the order of ops.hungarian's problems
+        assignment[i, torch.from_numpy(r)] = torch.from_numpy(c).to(torch.int32)
+    return cls_ref, masks_ref, loss_ref, blocked, assignment
+
+
+# Teacher-forced bounds (VERDICT r03 #6): with the oracle's attention masks and assignment injected no decision can
+# flip, and what is left is ROUNDING of the 16-bit operands through 24 Swin blocks + 6 deformable layers + 9 decoder layers.
+# Measured on MI355X (round 4; max |x - ref| / max |ref|, gradients in the L2 norm):
+#   bf16  final mask logits 1.5e-2, worst decoder output 1.8e-2 (mask) / 4.9e-2 (class), loss 3.9e-4, gradients
+#         3.6e-3 .. 7.7e-2 (worst: the (C, ny, nx) LayerNorm weight of the encoder, the end of the backward chain) —
+#         the free-running run of the same inputs: 1.9e-2, 5.3e-2 / 2.0e-1, 5.7e-4, .. 1.1e-1; it flips 18 of 6 576
+#         attention-mask bits ([1, 0, 8, 0, 1, 4, 0, 2, 2] per layer) and no assignment in a real column.  So the FINAL
+#         logits' 1.5-2e-2 is rounding (8 significand bits through 39 layers), the intermediate layers' 5e-2 / 2e-1 were flips.
+#   fp16  2.2e-3, 3.3e-3 / 3.1e-3, 1.2e-4, gradients 6e-4 .. 3.0e-2; free-running flips 1 bit.
+# The 1e-2 / 2e-2 (bf16) and 2e-3 / 4e-3 (fp16) VERDICT r03 proposed for this test are NOT met: rounding alone exceeds them.
+TEACHER_TOL = {'bf16': dict(final=2.5e-2, layer_mask=3e-2, layer_cls=8e-2, loss=2e-3, grad_l2=1.2e-1),
+               'fp16': dict(final=4e-3, layer_mask=6e-3, layer_cls=6e-3, loss=1e-3, grad_l2=5e-2)}
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_16bit_whole_model_teacher_forced(device, capsys, dtype):
+    """The 16-bit product with the oracle's DECISIONS injected (ops.TEACHER: the ten attention masks and the Hungarian
+    assignment of the fp32 oracle, same weights / inputs / sampling points): every decoder output, the loss and the
+    gradients then differ from the oracle by operand rounding only — the free-running test above carries flips of
+    `sigmoid(logit) < 0.5`, of ReLU gates downstream of them and of the assignment on top.  Also reports how many mask
+    bits / assignments the free-running product WOULD have taken differently."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    TOL = TEACHER_TOL[dtype]
+    okw = tiny_kwargs()
+    cfg = O.make_cfg(**okw)
+    cfg.num_points = 256
+    sd = O.make_state_dict(cfg, 7)
+    scans = random_scans(okw, [3000, 2000], seed=2)
+    labels, gt = random_gt(okw, 2, 3, seed=4)
+    sd_g = {k: (v.clone().requires_grad_() if v.is_floating_point() and 'running_' not in k else v.clone())
+            for k, v in sd.items()}
+    cls_ref, masks_ref, loss_ref, blocked, assignment = _oracle_with_decisions(cfg, sd_g, scans, labels, gt, 11)
+    loss_ref.backward()
+    m = MaskBevModule(**dict(okw, compute_dtype=dtype))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device).train()
+    grad_scale = 1.0
+    if dtype == 'fp16':
+        m.flatten_parameters()
+        m._loss_scaler.scale.fill_(256.0)
+        grad_scale = 256.0
+    head = m._panoptic_head._panoptic_head
+    head.num_points, head.point_seed = 256, 11
+    dscans = [s.to(device) for s in scans]
+    ops.TEACHER.clear()
+    ops.TEACHER.update(blocked=[t.to(device) for t in blocked], assignment=assignment.to(device), replace=True)
+    try:
+        cls, masks, _ = m(dscans)
+        loss = m.loss(m.compute_loss(cls, masks, labels.to(device), gt.to(device)))
+        m.scale_loss(loss).backward()
+        ops.flush_deferred_grads()
+        torch.cuda.synchronize()
+        mask_flips = [int(x) for x in ops.TEACHER.get('blocked_flips', [])]
+        # assignments that differ in a REAL ground-truth column (the padded all-zero columns are interchangeable: K9 hands
+        # them out in ascending order, scipy in its own — same loss)
+        raw = ops.TEACHER['assignment_raw'].cpu().view(-1, labels.shape[0], assignment.shape[1])
+        real = ((labels != 0) | gt.flatten(2).any(-1))                                     # (B, G)
+        want = assignment.view_as(raw)
+        is_real = lambda a: torch.gather(real.unsqueeze(0).expand(a.shape[0], -1, -1), 2, a.clamp(min=0).long()) & (a >= 0)
+        assign_flips = int(((raw != want) & (is_real(raw) | is_real(want))).sum())
+    finally:
+        ops.TEACHER.clear()
+    assert len(mask_flips) == 9 and len(blocked) == 10      # (the tenth mask, behind the last layer, has no consumer)
+    errs = dict(final=_rel(masks[-1].float().cpu(), masks_ref[-1].detach()),
+                layer_mask=max(_rel(masks[i].float().cpu(), masks_ref[i].detach()) for i in range(10)),
+                layer_cls=max(_rel(cls[i].float().cpu(), cls_ref[i].detach()) for i in range(10)),
+                loss=abs(float(loss.detach()) - float(loss_ref.detach())) / abs(float(loss_ref.detach())))
+    got = dict(m.named_parameters())
+    worst_l2 = 0.0
+    for k in ['_encoder._voxel_encoder.pfn_layers.0.linear.weight', '_encoder._layer_norm.weight',
+              '_backbone._backbone.patch_embed.projection.weight',
+              '_backbone._backbone.stages.2.blocks.0.ffn.layers.1.weight',
+              '_panoptic_head._panoptic_head.pixel_decoder.encoder.layers.1.self_attn.value_proj.weight',
+              '_panoptic_head._panoptic_head.transformer_decoder.layers.2.cross_attn.attn.in_proj_weight',
+              '_panoptic_head._panoptic_head.mask_embed.4.weight', '_panoptic_head._panoptic_head.query_feat.weight']:
+        g, r = got[k].grad.float().cpu() / grad_scale, sd_g[k].grad
+        assert bool(torch.isfinite(g).all()), k
+        e2 = float((g - r).norm() / r.norm().clamp(min=1e-12))
+        errs['grad_l2 ' + k.split('.', 2)[-1][-48:]] = round(e2, 4)
+        worst_l2 = max(worst_l2, e2)
+    with capsys.disabled():
+        print(f'\n{dtype} TEACHER-FORCED whole-model errors vs the fp32 oracle '
+              f'(free-running it would have flipped {sum(mask_flips)} of {sum(t.numel() for t in blocked[:9])} mask bits: '
+              f'{mask_flips}; {assign_flips} of {raw.numel()} assignments in a real column):')
+        for k, v in errs.items():
+            print(f'  {k}: {v}')
+    assert errs['final'] < TOL['final']
+    assert errs['layer_mask'] < TOL['layer_mask'] and errs['layer_cls'] < TOL['layer_cls']
+    assert errs['loss'] < TOL['loss']
+    assert worst_l2 < TOL['grad_l2']
 
 
 def test_bench_configuration_runs_eager_and_graphed(device):

@@ -61,6 +61,32 @@ def test_mask2former_head_forward_matches_reference():
         torch.testing.assert_close(mask_list[i], g[f'mask{i}'], rtol=1e-4, atol=2e-4)
 
 
+def test_mask2former_head_matches_reference_with_independent_pixel_decoder():
+    """The same reference class on a second fixture whose pixel-decoder stand-in owes nothing to the oracle (fixed random
+    1 x 1 linear maps of the backbone features, tests/golden/make_golden.py LinearPixelDecoderShim; the first fixture's
+    stand-in is ``O.pixel_decoder_forward`` itself): forward of all five decoder outputs and all 20 loss terms."""
+    g = _load('mask2former_head_linpd_q6.npz')
+    cfg = _head_cfg()
+    sd = {k[3:]: v for k, v in g.items() if k.startswith('sd.')}
+    feats = [g[f'feat{i}'] for i in range(4)]
+
+    def linear_pixel_decoder(fs):
+        mf = torch.einsum('oc,bchw->bohw', g['pd_lin.wm'], fs[0])
+        return mf, [torch.einsum('oc,bchw->bohw', g[f'pd_lin.w{i}'], f) for i, f in enumerate((fs[3], fs[2], fs[1]))]
+
+    cls_list, mask_list, _ = O.head_forward(cfg, sd, feats, pixel_decoder=linear_pixel_decoder)
+    for i in range(5):
+        torch.testing.assert_close(cls_list[i], g[f'cls{i}'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(mask_list[i], g[f'mask{i}'], rtol=1e-4, atol=2e-4)
+    torch.manual_seed(int(g['loss_seed']))
+    ld = O.loss_dict(cfg, [g[f'cls{i}'] for i in range(5)], [g[f'mask{i}'] for i in range(5)], g['labels_gt'], g['masks_gt'],
+                     O.PointSource(None))
+    keys = [str(k) for k in g['loss_keys']]
+    assert list(ld.keys()) == keys
+    for k, ref in zip(keys, g['loss_vals'].tolist()):
+        assert float(ld[k]) == pytest.approx(ref, rel=1e-5, abs=1e-6), k
+
+
 def test_mask2former_loss_matches_reference():
     """Mask2FormerHead.loss of the reference (mask2former_head.py:246-298,326-426; random points drawn from
     the global RNG in the reference's order) == oracle.loss_dict, every one of the 20 terms."""
