@@ -59,6 +59,8 @@ def parse():
                     help='N > 1: log, per step, the bytes and host launch time of every gradient all-reduce piece relative '
                          'to the graph replays / the encoder backward it is meant to hide under (any backend; with '
                          'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
+    ap.add_argument('--aten-detail', default=None, metavar='FILE',
+                    help='write the per-operator times of the ATen calls of the instrumented step (name, shapes, call site)')
     ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set a path selector of mask_bev_amd/switches.py (recorded in config.switches)')
     return ap.parse_args()
@@ -158,7 +160,7 @@ def cpu_baseline(workload: str, module, budget_s: float):
                 rows=rows)
 
 
-def kernel_profile(model, opt, batch, steps: int = 2):
+def kernel_profile(model, opt, batch, steps: int = 2, detail_file=None):
     """HIP-event duration of every C-ABI call of `steps` eager training steps (after one untimed eager step), on the
     stream the kernels are launched on, with the algorithmic work of each call (mask_bev_amd/workmodel.py).
     Runs AFTER the timed region: the timed steps replay HIP graphs, which cannot carry per-kernel events.
@@ -221,13 +223,23 @@ def kernel_profile(model, opt, batch, steps: int = 2):
     try:
         # every ATen operator of the step (hipBLASLt GEMMs, MIOpen convolutions, element-wise / reduction kernels) is
         # bracketed the same way through a dispatch mode, so that the table prices the whole step
-        with workmodel.aten_timer(records):
+        detail = [] if detail_file else None
+        with workmodel.aten_timer(records, detail):
             state['spin'] = lambda: spin_ms(min(1.3 * t_host * 1e3, 400.0))
             for i in range(steps):
                 one(1 + i)
                 torch.cuda.synchronize()
     finally:
         lib.hook = None
+    if detail_file:
+        per = {}
+        for name, shapes, where, a, b in detail:
+            e = per.setdefault((name, str(shapes), where), [0, 0.0])
+            e[0] += 1
+            e[1] += max(a.elapsed_time(b) - empty_ms, 0.0)
+        rows = sorted(([k[0], k[1], k[2], v[0] / steps, v[1] / steps * 1e3] for k, v in per.items()), key=lambda r: -r[4])
+        with open(detail_file, 'w') as fh:
+            json.dump(rows, fh, indent=0)
     agg = {}
     for (kernel, bound, nbytes, flops), a, b in records:
         e = agg.setdefault(kernel, dict(kernel=kernel, bound=bound, launches=0, ms=0.0, bytes=0.0, flops=0.0))
@@ -431,7 +443,7 @@ def main():
     final_loss = float(loss.detach())
     profile = {}
     if world == 1 and not args.no_kernel_profile:
-        profile = kernel_profile(model, opt, pool[0])
+        profile = kernel_profile(model, opt, pool[0], detail_file=args.aten_detail)
     fp32_line = None
     if world == 1 and args.dtype != 'fp32' and not args.no_fp32 and not args.no_graph and not args.no_arena:
         try:

@@ -398,7 +398,7 @@ def aten_work(func, args, kwargs, result, cuda_only: bool = True):
     return (family, 'hbm', by, 0.0)
 
 
-def aten_timer(records: list):
+def aten_timer(records: list, detail: list = None):
     """A TorchDispatchMode that brackets every kernel-launching ATen call with HIP events on the current stream and
     appends ``((family, bound, bytes, flops), start, end)`` to ``records`` (bench.py only)."""
     import torch
@@ -417,6 +417,13 @@ def aten_timer(records: list):
             work = aten_work(func, args, kwargs, out)
             if work is not None:
                 records.append((work, a, b))
+                if detail is not None:       # per-operator view for hunting the tail (bench.py --aten-detail)
+                    ts = []
+                    _tensors(list(args), ts)
+                    import traceback
+                    where = next((f'{fr.filename.split("/")[-1]}:{fr.lineno}' for fr in reversed(traceback.extract_stack(limit=14))
+                                  if 'mask_bev_amd' in fr.filename and 'workmodel' not in fr.filename), '?')
+                    detail.append((name, [tuple(t.shape) for t in ts[:3]], where, a, b))
             return out
 
     return _Timer()
