@@ -436,7 +436,7 @@ int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, i
  * mask_bev/models/head/mask_bev_panoptic_head.py:119-176) and the decoder's post_norm
  * (mask2former_head.py:448), forward and backward.
  * a, b: (rows, C) f32 or bf16 (`*_bf16` flags; b nullable = plain LayerNorm); gamma, beta (C) f32; C % 4 == 0,
- * C <= 2048 (mbv_add_layernorm_supported).  fwd writes sum_out = a + b (f32, the tensor the backward needs; may be
+ * C <= 2048 (mbv_add_layernorm_supported; the patch-merging form below takes 4 c <= 3072).  fwd writes sum_out = a + b (f32, the tensor the backward needs; may be
  * NULL only for a lone f32 `a`, which then serves as the saved input), y in f32 or bf16, mean / rstd (rows) f32.
  * bwd: dy (rows, C) f32/bf16, ds nullable (gradient reaching the sum from the residual path), s = the saved sum;
  * writes dx (rows, C) f32 (the gradient of a and of b), optionally the same in 16 bits (dx_lo, of dx_lo_dtype), and

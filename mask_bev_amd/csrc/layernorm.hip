@@ -294,12 +294,15 @@ int iters_for(int C) {
   if (C <= 512) return 2;
   if (C <= 1024) return 4;
   if (C <= 2048) return 8;
+  if (C <= 3072) return 12;        // patch merging in front of Swin stage 4: 4 x 768 channels (round 4; it fell back to ATen)
   return 0;
 }
 
 }  // namespace
 
-extern "C" int mbv_add_layernorm_supported(int32_t C) { return iters_for(C) ? 1 : 0; }
+// (the add + LayerNorm entry points stop at 2048 channels: with three partial sums per channel — dgamma, dbeta, dbranch —
+// 3072 channels would need 72 KB of LDS accumulators; the merging form has two)
+extern "C" int mbv_add_layernorm_supported(int32_t C) { return (C <= 2048 && iters_for(C)) ? 1 : 0; }
 
 // one 512-thread block per CU for the widest rows, two for C <= 1024 (per-row LDS accumulation), up to four for narrow ones
 extern "C" int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C) {
@@ -320,7 +323,8 @@ static int add_ln_fwd_launch(const LnIo& io, int it, int64_t rows, int32_t C, fl
     case 1: hipLaunchKernelGGL(k_add_ln_fwd<1>, grid, block, 0, st, io, (long)rows, C, eps); break;
     case 2: hipLaunchKernelGGL(k_add_ln_fwd<2>, grid, block, 0, st, io, (long)rows, C, eps); break;
     case 4: hipLaunchKernelGGL(k_add_ln_fwd<4>, grid, block, 0, st, io, (long)rows, C, eps); break;
-    default: hipLaunchKernelGGL(k_add_ln_fwd<8>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    case 8: hipLaunchKernelGGL(k_add_ln_fwd<8>, grid, block, 0, st, io, (long)rows, C, eps); break;
+    default: hipLaunchKernelGGL(k_add_ln_fwd<12>, grid, block, 0, st, io, (long)rows, C, eps); break;
   }
   MBV_CHECK_LAUNCH();
   return MBV_OK;
@@ -329,7 +333,7 @@ static int add_ln_fwd_launch(const LnIo& io, int it, int64_t rows, int32_t C, fl
 extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
                                      int32_t y_bf16, float* mean, float* rstd, void* stream) {
-  const int it = iters_for(C);
+  const int it = C <= 2048 ? iters_for(C) : 0;
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
   if (rows == 0) return MBV_OK;
@@ -357,7 +361,8 @@ static int add_ln_bwd_launch(LnBwdIo io, int it, int64_t rows, int32_t C, int32_
     case 1: hipLaunchKernelGGL(k_add_ln_bwd<1>, grid, block, lds, st, io, (long)rows, C); break;
     case 2: hipLaunchKernelGGL(k_add_ln_bwd<2>, grid, block, lds, st, io, (long)rows, C); break;
     case 4: hipLaunchKernelGGL(k_add_ln_bwd<4>, grid, block, lds, st, io, (long)rows, C); break;
-    default: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
+    case 8: hipLaunchKernelGGL(k_add_ln_bwd<8>, grid, block, lds, st, io, (long)rows, C); break;
+    default: hipLaunchKernelGGL(k_add_ln_bwd<12>, grid, block, lds, st, io, (long)rows, C); break;
   }
   MBV_CHECK_LAUNCH();
   if (direct) return MBV_OK;
@@ -381,7 +386,7 @@ extern "C" int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const voi
                                       const float* gamma, int64_t rows, int32_t C, float* dx, void* dx_lo,
                                       int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
                                       float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream) {
-  const int it = iters_for(C);
+  const int it = C <= 2048 ? iters_for(C) : 0;
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
   if (!dgamma || !dbeta) return MBV_ERR_BAD_ARG;

@@ -2558,7 +2558,8 @@ class _MergeLayerNorm(torch.autograd.Function):
 
 def merge_layernorm_supported(x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
-            and add_layernorm_supported(4 * x.shape[3]) and switches.get('merge_ln'))
+            and bool(_lib.load().mbv_merge_layernorm_supported(int(x.shape[1]), int(x.shape[2]), int(x.shape[3])))
+            and switches.get('merge_ln'))
 
 
 def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,

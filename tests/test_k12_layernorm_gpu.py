@@ -96,7 +96,7 @@ def _unfold_ref(x):
     return u.transpose(1, 2).reshape(b, h // 2, w // 2, 4 * c)
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 12, 48), (4, 32, 32, 192), (1, 10, 6, 384), (3, 4, 4, 512), (2, 64, 64, 192)])
+@pytest.mark.parametrize('shape', [(2, 8, 12, 48), (4, 32, 32, 192), (1, 10, 6, 384), (3, 4, 4, 512), (2, 64, 64, 192), (4, 32, 32, 768)])
 @pytest.mark.parametrize('out_dt', [torch.float32, torch.bfloat16, torch.float16])
 def test_merge_layernorm(device, shape, out_dt):
     """K12 with patch-merging addressing against nn.Unfold + F.layer_norm in f64: forward, dx (scattered back into the
