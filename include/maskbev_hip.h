@@ -425,9 +425,30 @@ int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const floa
 /* Matching-cost terms (mmdet CrossEntropyLossCost(use_sigmoid) + DiceCost on the sampled points,
  * mask2former_head.py:199-205): logits (groups, queries, points) f32 → terms (groups, 3, queries, points) f32 =
  * [softplus(-x), softplus(x), sigmoid(x)] — one batched GEMM against the sampled ground truth then gives all three
- * cost matrices — and row_sums (groups*queries, 2) = [sum softplus(x), sum sigmoid(x)]. */
-int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points, float* terms,
-                         float* row_sums, void* stream);
+ * cost matrices — and row_sums (groups*queries, 2) = [sum softplus(x), sum sigmoid(x)].  ones_row != 0: a group has
+ * 3 * queries + 1 rows, the last one all ones, so that the same GEMM also returns the targets' row sums. */
+int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points, int32_t ones_row,
+                         float* terms, float* row_sums, void* stream);
+
+/* The matching cost matrices from those products (HungarianAssigner's ClassificationCost 2.0 + CrossEntropyLossCost 5.0 +
+ * DiceCost 5.0 as configured at mask_bev/models/head/mask_bev_panoptic_head.py and evaluated at mask2former_head.py:199-210):
+ * cls (groups, queries, classes_plus_one) f32 logits, labels (batch, targets) i64, prod (groups, 3 * queries + 1, targets)
+ * f32 = terms . sampled targets (ones row last), row_sums as above; group = (decoder output, image), image fastest.
+ * cost (groups, queries, targets) f32. */
+int mbv_match_cost(const float* cls, const int64_t* labels, const float* prod, const float* row_sums, int64_t groups,
+                   int32_t queries, int32_t targets, int32_t classes_plus_one, int32_t batch, int32_t points, float* cost,
+                   void* stream);
+
+/* Classification loss of all decoder outputs (mmdet CrossEntropyLoss(class_weight), avg_factor = sum of the targets' class
+ * weights: mask2former_head.py:393-404): cls (outputs, batch * queries, classes_plus_one) f32, assigned (outputs, batch,
+ * queries) i32 = ground-truth column or -1 (→ label classes_plus_one - 1, "no object"), labels (batch, targets) i64.
+ * loss (outputs) f32, weight_sum (outputs) f32 (kept for the backward); grad_cls has the shape of cls. */
+int mbv_cls_loss_fwd(const float* cls, const int32_t* assigned, const int64_t* labels, const float* class_weight,
+                     int32_t outputs, int32_t batch, int32_t queries, int32_t targets, int32_t classes_plus_one,
+                     float loss_weight, float eps, float* loss, float* weight_sum, void* stream);
+int mbv_cls_loss_bwd(const float* cls, const int32_t* assigned, const int64_t* labels, const float* class_weight,
+                     const float* weight_sum, const float* grad_loss, int32_t outputs, int32_t batch, int32_t queries,
+                     int32_t targets, int32_t classes_plus_one, float loss_weight, float eps, float* grad_cls, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K12 — fused residual-add + LayerNorm over the last (channel) axis of token-major activations.

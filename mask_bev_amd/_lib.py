@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 
 class MaskBevHipError(RuntimeError):
@@ -96,7 +96,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_instance_ids': (ctypes.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_expand_instance_masks': (ctypes.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_matched_mask_iou': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'mbv_match_cost_terms': (ctypes.c_int, [_P, _L, _I, _I, _P, _P, _P]),
+    'mbv_match_cost_terms': (ctypes.c_int, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    'mbv_match_cost': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    'mbv_cls_loss_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'mbv_cls_loss_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     'mbv_packed_mask_words': (_L, [_I, _I]),
     'mbv_pack_binary_masks': (ctypes.c_int, [_P, _L, _I, _I, _P, _P]),
     'mbv_point_sample_packed_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

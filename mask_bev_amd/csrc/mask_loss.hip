@@ -97,15 +97,20 @@ __global__ void __launch_bounds__(kThreads) k_mask_loss_rows_bwd(const float* __
 // cost matrices, plus the row sums of terms[1] and terms[2] (the "against 0" constant and the dice denominator).
 // Replaces five elementwise passes and two reductions of mmdet's CrossEntropyLossCost / DiceCost as used at
 // mask2former_head.py:199-205.
-__global__ void __launch_bounds__(kThreads) k_match_terms(const float* __restrict__ x, int q, int p,
+__global__ void __launch_bounds__(kThreads) k_match_terms(const float* __restrict__ x, int q, int p, int ones_row,
                                                           float* __restrict__ terms, float* __restrict__ sums) {
   __shared__ float red[2][kThreads / 64];
   const long row = blockIdx.x;                      // = group * q + query
   const long group = row / q, query = row - group * q;
   const float* xr = x + row * p;
-  float* t0 = terms + ((group * 3 + 0) * q + query) * p;
-  float* t1 = terms + ((group * 3 + 1) * q + query) * p;
-  float* t2 = terms + ((group * 3 + 2) * q + query) * p;
+  // ones_row: a group has 3 q + 1 rows, the last one all ones — the same GEMM against the sampled ground truth then also
+  // returns its row sums (the dice denominator's target part), which used to be a 200 MB reduction launch of its own
+  float* tg = terms + group * (3L * q + (ones_row ? 1 : 0)) * p;
+  float* t0 = tg + (0L * q + query) * p;
+  float* t1 = tg + (1L * q + query) * p;
+  float* t2 = tg + (2L * q + query) * p;
+  if (ones_row && query == 0)
+    for (int i = threadIdx.x; i < p; i += kThreads) tg[3L * q * p + i] = 1.0f;
   float s1 = 0.f, s2 = 0.f;
   auto point = [&](float v, float& pos, float& neg, float& sig) {
     const float e = __expf(-fabsf(v));
@@ -144,7 +149,125 @@ __global__ void __launch_bounds__(kThreads) k_match_terms(const float* __restric
   }
 }
 
+// Matching cost of every (query, ground-truth column) pair from the batched GEMM's products (mask2former_head.py:199-205
+// with mmdet's ClassificationCost 2.0, CrossEntropyLossCost(use_sigmoid) 5.0, DiceCost(pred_act, eps 1) 5.0):
+//   cost = -2 softmax(cls)[label] + 5 (pos.t + sum(neg) - neg.t) / P + 5 (1 - (2 sig.t + 1) / (sum(sig) + sum(t) + 1))
+// prod (groups, 3 q + 1, G) = [pos; neg; sig; ones] . t, sums (groups, q, 2) = [sum neg, sum sig]; group = (decoder
+// output, image) with the image index fastest.  One launch instead of a softmax, a gather and ~ 20 element-wise ATen launches.
+__global__ void __launch_bounds__(256) k_match_cost(const float* __restrict__ cls, const int64_t* __restrict__ labels,
+                                                    const float* __restrict__ prod, const float* __restrict__ sums,
+                                                    long total, int q, int g, int k1, int batch, float inv_points,
+                                                    float* __restrict__ cost) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % g);
+  const long qi = (i / g) % q, grp = i / ((long)g * q);
+  const int b = (int)(grp % batch);
+  const float* c = cls + (grp * q + qi) * k1;
+  float mx = c[0];
+  for (int k = 1; k < k1; ++k) mx = fmaxf(mx, c[k]);
+  float den = 0.f;
+  for (int k = 0; k < k1; ++k) den += __expf(c[k] - mx);
+  const int lab = (int)labels[(long)b * g + col];
+  const float prob = __expf(c[lab] - mx) / den;
+  const float* pg = prod + grp * (3L * q + 1) * g;
+  const float pos = pg[(0L * q + qi) * g + col], neg = pg[(1L * q + qi) * g + col], sig = pg[(2L * q + qi) * g + col];
+  const float tsum = pg[3L * q * g + col];
+  const float s_neg = sums[(grp * q + qi) * 2], s_sig = sums[(grp * q + qi) * 2 + 1];
+  const float cls_cost = -prob * 2.0f;
+  const float bce = (pos + s_neg - neg) * inv_points;
+  const float dice = 1.0f - (2.0f * sig + 1.0f) / (s_sig + tsum + 1.0f);
+  cost[i] = cls_cost + 5.0f * bce + 5.0f * dice;
+}
+
+// Class-weighted cross entropy of one decoder output per workgroup (mmdet CrossEntropyLoss with class_weight,
+// reduction by avg_factor = sum of the class weights of the targets: mask2former_head.py:393-404).  Row n = (image, query)
+// takes the label of its assigned ground-truth column, or `num_classes` (no object) when unassigned.
+//   fwd: loss[d] = lw * sum_n w[y_n] (-log softmax(x_n)[y_n]) / (sum_n w[y_n] + eps);  wsum[d] = sum_n w[y_n]
+//   bwd: dx[n][k] = g[d] lw w[y_n] (softmax(x_n)[k] - [k == y_n]) / (wsum[d] + eps)
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_cls_loss(const float* __restrict__ cls, const int32_t* __restrict__ assigned,
+                                                  const int64_t* __restrict__ labels, const float* __restrict__ cw,
+                                                  int rows, int q, int g, int k1, float lw, float eps,
+                                                  float* __restrict__ loss, float* __restrict__ wsum,
+                                                  const float* __restrict__ gout, float* __restrict__ dcls) {
+  __shared__ double red[2][4];
+  const int d = blockIdx.x;
+  double s_l = 0.0, s_w = 0.0;
+  float scale = 0.f;
+  if constexpr (BWD) scale = gout[d] * lw / (wsum[d] + eps);
+  for (int n = threadIdx.x; n < rows; n += 256) {
+    const float* x = cls + ((long)d * rows + n) * k1;
+    const int a = assigned[(long)d * rows + n];
+    const int y = a >= 0 ? (int)labels[(long)(n / q) * g + a] : k1 - 1;
+    float mx = x[0];
+    for (int k = 1; k < k1; ++k) mx = fmaxf(mx, x[k]);
+    float den = 0.f;
+    for (int k = 0; k < k1; ++k) den += __expf(x[k] - mx);
+    const float w = cw[y];
+    if constexpr (BWD) {
+      float* dx = dcls + ((long)d * rows + n) * k1;
+      for (int k = 0; k < k1; ++k) dx[k] = scale * w * (__expf(x[k] - mx) / den - (k == y ? 1.f : 0.f));
+    } else {
+      s_l += (double)(w * (mx + __logf(den) - x[y]));
+      s_w += (double)w;
+    }
+  }
+  if constexpr (!BWD) {
+    s_l = wave_sum_d(s_l);
+    s_w = wave_sum_d(s_w);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s_l; red[1][wave] = s_w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double l = red[0][0] + red[0][1] + red[0][2] + red[0][3], w = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      wsum[d] = (float)w;
+      loss[d] = (float)((double)lw * l / (w + (double)eps));
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mbv_match_cost(const float* cls, const int64_t* labels, const float* prod, const float* row_sums,
+                              int64_t groups, int32_t queries, int32_t targets, int32_t classes_plus_one, int32_t batch,
+                              int32_t points, float* cost, void* stream) {
+  if (groups < 0 || queries <= 0 || targets <= 0 || classes_plus_one <= 0 || batch <= 0 || points <= 0) return MBV_ERR_BAD_ARG;
+  if (groups == 0) return MBV_OK;
+  if (!cls || !labels || !prod || !row_sums || !cost || groups % batch) return MBV_ERR_BAD_ARG;
+  const long total = (long)groups * queries * targets;
+  hipLaunchKernelGGL(k_match_cost, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cls, labels,
+                     prod, row_sums, total, queries, targets, classes_plus_one, batch, 1.0f / (float)points, cost);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_cls_loss_fwd(const float* cls, const int32_t* assigned, const int64_t* labels, const float* class_weight,
+                                int32_t outputs, int32_t batch, int32_t queries, int32_t targets, int32_t classes_plus_one,
+                                float loss_weight, float eps, float* loss, float* weight_sum, void* stream) {
+  if (outputs < 0 || batch <= 0 || queries <= 0 || targets <= 0 || classes_plus_one <= 0) return MBV_ERR_BAD_ARG;
+  if (outputs == 0) return MBV_OK;
+  if (!cls || !assigned || !labels || !class_weight || !loss || !weight_sum) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_cls_loss<false>, dim3((unsigned)outputs), dim3(256), 0, (hipStream_t)stream, cls, assigned, labels,
+                     class_weight, batch * queries, queries, targets, classes_plus_one, loss_weight, eps, loss, weight_sum,
+                     (const float*)nullptr, (float*)nullptr);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_cls_loss_bwd(const float* cls, const int32_t* assigned, const int64_t* labels, const float* class_weight,
+                                const float* weight_sum, const float* grad_loss, int32_t outputs, int32_t batch,
+                                int32_t queries, int32_t targets, int32_t classes_plus_one, float loss_weight, float eps,
+                                float* grad_cls, void* stream) {
+  if (outputs < 0 || batch <= 0 || queries <= 0 || targets <= 0 || classes_plus_one <= 0) return MBV_ERR_BAD_ARG;
+  if (outputs == 0) return MBV_OK;
+  if (!cls || !assigned || !labels || !class_weight || !weight_sum || !grad_loss || !grad_cls) return MBV_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_cls_loss<true>, dim3((unsigned)outputs), dim3(256), 0, (hipStream_t)stream, cls, assigned, labels,
+                     class_weight, batch * queries, queries, targets, classes_plus_one, loss_weight, eps, (float*)nullptr,
+                     const_cast<float*>(weight_sum), grad_loss, grad_cls);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
 
 extern "C" int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t rows, int32_t points,
                                       float* out_sums, void* stream) {
@@ -170,14 +293,14 @@ extern "C" int mbv_mask_loss_rows_bwd(const float* logits, const float* targets,
   return MBV_OK;
 }
 
-extern "C" int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points, float* terms,
-                                    float* row_sums, void* stream) {
+extern "C" int mbv_match_cost_terms(const float* logits, int64_t groups, int32_t queries, int32_t points,
+                                    int32_t ones_row, float* terms, float* row_sums, void* stream) {
   if (groups < 0 || queries <= 0 || points <= 0) return MBV_ERR_BAD_ARG;
   if (groups == 0) return MBV_OK;
   if (!logits || !terms || !row_sums) return MBV_ERR_BAD_ARG;
   if (groups * queries > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_match_terms, dim3((unsigned)(groups * queries)), dim3(kThreads), 0, (hipStream_t)stream, logits,
-                     queries, points, terms, row_sums);
+                     queries, points, ones_row ? 1 : 0, terms, row_sums);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

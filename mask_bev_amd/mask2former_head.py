@@ -637,13 +637,19 @@ class Mask2FormerHead(nn.Module):
                               self._iota(d * b * nq, dev, div=nq)).view(d, b, nq, -1)            # (D, B, Q, P)
         gp = self._sample_gt(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
                              self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)             # (D, B, G, P)
+        gpt = gp.reshape(d * b, ng, -1).transpose(1, 2)                                       # (DB, P, G)
+        if cls.is_cuda and switches.get('loss_glue'):
+            # K13: the cost terms with an all-ones row behind them — ONE batched GEMM against the sampled ground truth then
+            # gives the three cost matrices AND the targets' row sums — and one launch that turns the products, the class
+            # logits and the labels into the cost matrices (was: softmax, gather, a 200 MB row reduction, ~ 20 ATen launches)
+            terms, sums = ops.match_cost_terms(mp.reshape(d * b, nq, -1), ones_row=True)      # (DB, 3Q + 1, P), (DB, Q, 2)
+            return ops.match_cost(cls, labels_gt, torch.matmul(terms, gpt), sums, self.num_points)
         prob = cls.softmax(-1)
         lab = labels_gt.view(1, b, 1, ng).expand(d, b, nq, ng)
         cls_cost = -torch.gather(prob, 3, lab) * 2.0                                            # (D, B, Q, G)
         # K13: softplus(-x), softplus(x), sigmoid(x) and two row sums in one pass over the sampled logits; the three
         # cost matrices come from ONE batched GEMM against the sampled ground truth
         terms, sums = ops.match_cost_terms(mp.reshape(d * b, nq, -1))                         # (DB, 3Q, P), (DB, Q, 2)
-        gpt = gp.reshape(d * b, ng, -1).transpose(1, 2)                                       # (DB, P, G)
         prod = torch.matmul(terms, gpt).view(d, b, 3, nq, ng)
         pos_gp, neg_gp, sig_gp = prod[:, :, 0], prod[:, :, 1], prod[:, :, 2]
         sums = sums.view(d, b, nq, 2)
@@ -750,11 +756,16 @@ class Mask2FormerHead(nn.Module):
             tgt = self._sample_gt(gt_flat, gt_index, coords, rows)                               # (D*g, P)
 
         # classification loss (class-weighted CE, avg_factor = sum of the class weights of the targets)
-        labels = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, safe),
-                             torch.full_like(safe, self.num_classes))
         class_weight = self._const(dev, self.class_weight)
-        ce = F.cross_entropy(cls.flatten(0, 2), labels.flatten(), weight=class_weight, reduction='none').view(d, -1)
-        loss_cls = self.loss_cls_weight * ce.sum(1) / (class_weight[labels].view(d, -1).sum(1) + eps)
+        if cls.is_cuda and switches.get('loss_glue'):
+            # K13: labels from the assignment, weighted cross entropy and its normaliser per decoder output in one launch
+            # (and one for the gradient) instead of where / gather / log_softmax / nll_loss / index / sums
+            loss_cls = ops.cls_loss(cls, assigned, labels_gt, class_weight, self.loss_cls_weight, eps)
+        else:
+            labels = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, safe),
+                                 torch.full_like(safe, self.num_classes))
+            ce = F.cross_entropy(cls.flatten(0, 2), labels.flatten(), weight=class_weight, reduction='none').view(d, -1)
+            loss_cls = self.loss_cls_weight * ce.sum(1) / (class_weight[labels].view(d, -1).sum(1) + eps)
 
         # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image; reduce_mean over ranks (:388) is the
         # identity for equal per-rank batches (drop_last=True), see ddp.py

@@ -2570,14 +2570,71 @@ def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, e
 
 
 @torch.no_grad()
-def match_cost_terms(logits: torch.Tensor):
-    """logits (G, Q, P) f32 sampled mask logits → (terms (G, 3Q, P) f32 = [softplus(-x); softplus(x); sigmoid(x)]
-    stacked along the query axis, row_sums (G, Q, 2) = [Σ softplus(x), Σ sigmoid(x)]) in one pass (K13)."""
+def match_cost_terms(logits: torch.Tensor, ones_row: bool = False):
+    """logits (G, Q, P) f32 sampled mask logits → (terms (G, 3Q [+ 1], P) f32 = [softplus(-x); softplus(x); sigmoid(x)
+    [; ones]] stacked along the query axis, row_sums (G, Q, 2) = [Σ softplus(x), Σ sigmoid(x)]) in one pass (K13)."""
     lib = _lib.load()
     _need_gpu(logits)
     x = logits.float().contiguous()
     g, q, p = x.shape
-    terms = torch.empty((g, 3 * q, p), dtype=torch.float32, device=x.device)
+    terms = torch.empty((g, 3 * q + (1 if ones_row else 0), p), dtype=torch.float32, device=x.device)
     sums = torch.empty((g, q, 2), dtype=torch.float32, device=x.device)
-    check(lib.mbv_match_cost_terms(_ptr(x), g, q, p, _ptr(terms), _ptr(sums), _stream()), 'mbv_match_cost_terms')
+    check(lib.mbv_match_cost_terms(_ptr(x), g, q, p, 1 if ones_row else 0, _ptr(terms), _ptr(sums), _stream()),
+          'mbv_match_cost_terms')
     return terms, sums
+
+
+@torch.no_grad()
+def match_cost(cls: torch.Tensor, labels_gt: torch.Tensor, prod: torch.Tensor, sums: torch.Tensor, num_points: int):
+    """The (D*B, Q, G) matching costs from the products of :func:`match_cost_terms` (``ones_row=True``) with the sampled
+    ground truth: cls (D, B, Q, K+1) f32 logits, labels_gt (B, G) i64, prod (D*B, 3Q + 1, G) — one launch (K13)."""
+    lib = _lib.load()
+    d, b, q, k1 = cls.shape
+    g = int(labels_gt.shape[1])
+    cls, labels_gt, prod, sums = cls.float().contiguous(), labels_gt.contiguous(), prod.contiguous(), sums.contiguous()
+    _need_gpu(cls, labels_gt, prod, sums)
+    if tuple(prod.shape) != (d * b, 3 * q + 1, g) or labels_gt.dtype != torch.int64:
+        raise MaskBevHipError('match_cost: prod (D*B, 3Q+1, G) and int64 labels expected')
+    cost = torch.empty((d * b, q, g), dtype=torch.float32, device=cls.device)
+    check(lib.mbv_match_cost(_ptr(cls), _ptr(labels_gt), _ptr(prod), _ptr(sums), d * b, q, g, k1, b, int(num_points),
+                             _ptr(cost), _stream()), 'mbv_match_cost')
+    return cost
+
+
+class _ClsLoss(torch.autograd.Function):
+    """Class-weighted cross entropy of all decoder outputs against the assignment, one launch each way (K13)."""
+
+    @staticmethod
+    def forward(ctx, cls, assigned, labels_gt, class_weight, loss_weight, eps):
+        lib = _lib.load()
+        d, b, q, k1 = cls.shape
+        g = int(labels_gt.shape[1])
+        x = cls.float().contiguous()
+        assigned = assigned.to(torch.int32).contiguous()
+        labels_gt, class_weight = labels_gt.contiguous(), class_weight.float().contiguous()
+        _need_gpu(x, assigned, labels_gt, class_weight)
+        loss = torch.empty(d, dtype=torch.float32, device=x.device)
+        wsum = torch.empty(d, dtype=torch.float32, device=x.device)
+        check(lib.mbv_cls_loss_fwd(_ptr(x), _ptr(assigned), _ptr(labels_gt), _ptr(class_weight), d, b, q, g, k1,
+                                   float(loss_weight), float(eps), _ptr(loss), _ptr(wsum), _stream()), 'mbv_cls_loss_fwd')
+        ctx.save_for_backward(x, assigned, labels_gt, class_weight, wsum)
+        ctx.meta = (d, b, q, g, k1, float(loss_weight), float(eps), cls.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        lib = _lib.load()
+        x, assigned, labels_gt, class_weight, wsum = ctx.saved_tensors
+        d, b, q, g, k1, lw, eps, dt = ctx.meta
+        dx = torch.empty_like(x)
+        check(lib.mbv_cls_loss_bwd(_ptr(x), _ptr(assigned), _ptr(labels_gt), _ptr(class_weight), _ptr(wsum),
+                                   _ptr(g_loss.float().contiguous()), d, b, q, g, k1, lw, eps, _ptr(dx), _stream()),
+              'mbv_cls_loss_bwd')
+        return dx.to(dt), None, None, None, None, None
+
+
+def cls_loss(cls: torch.Tensor, assigned: torch.Tensor, labels_gt: torch.Tensor, class_weight: torch.Tensor,
+             loss_weight: float, eps: float) -> torch.Tensor:
+    """(D,) classification losses: cls (D, B, Q, K+1), assigned (D, B, Q) i32 (ground-truth column or -1), labels_gt
+    (B, G) i64, class_weight (K+1,) — mmdet CrossEntropyLoss(class_weight) with avg_factor = Σ class weights of the targets."""
+    return _ClsLoss.apply(cls, assigned, labels_gt, class_weight, loss_weight, eps)

@@ -317,6 +317,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_merge_layernorm_bwd': lambda a: _merge_ln(a, True),
     'mbv_colsum_accum': lambda a: ('k_colsum', 'hbm', _i(a[2]) * _i(a[3]) * (2.0 if _i(a[1]) else 4.0), 0.0),
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
+    'mbv_match_cost': lambda a: ('k_match_cost', 'hbm',
+                                 _i(a[4]) * ((3.0 * _i(a[5]) + 1) * _i(a[6]) + _i(a[5]) * _i(a[6])) * 4.0, 0.0),
+    'mbv_cls_loss_fwd': lambda a: ('k_cls_loss', 'hbm', _i(a[4]) * _i(a[5]) * _i(a[6]) * (_i(a[8]) * 4.0 + 4.0), 0.0),
+    'mbv_cls_loss_bwd': lambda a: ('k_cls_loss', 'hbm', _i(a[6]) * _i(a[7]) * _i(a[8]) * (_i(a[10]) * 8.0 + 4.0), 0.0),
 }
 
 

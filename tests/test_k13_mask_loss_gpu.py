@@ -63,3 +63,57 @@ def test_dice_bce_node_equals_the_row_sums_algebra(device):
     torch.autograd.backward([ld2, lm2], [gd, gm])
     assert torch.allclose(ld, ld2, rtol=1e-6, atol=1e-7) and torch.allclose(lm, lm2, rtol=1e-6, atol=1e-7)
     assert float((got - x.grad).abs().max()) <= 1e-6 * float(x.grad.abs().max()) + 1e-12
+
+
+def test_match_cost_single_launch_equals_the_torch_form(device):
+    """mbv_match_cost (+ the ones row of mbv_match_cost_terms) against the expression it replaces in
+    Mask2FormerHead._match_cost: -2 softmax(cls)[label] + 5 BCE + 5 dice on the sampled points (mask2former_head.py:199-210)."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(3)
+    d, b, q, ng, p, k1 = 3, 2, 10, 7, 96, 3
+    cls = torch.randn(d, b, q, k1, generator=g).to(device)
+    labels = torch.randint(0, k1 - 1, (b, ng), generator=g).to(device)
+    mp = (torch.randn(d * b, q, p, generator=g) * 3).to(device)
+    gp = torch.rand(d * b, ng, p, generator=g).to(device)
+    gpt = gp.transpose(1, 2)
+    # the torch form
+    prob = cls.softmax(-1)
+    cls_cost = -torch.gather(prob, 3, labels.view(1, b, 1, ng).expand(d, b, q, ng)) * 2.0
+    terms, sums = ops.match_cost_terms(mp)
+    prod = torch.matmul(terms, gpt).view(d, b, 3, q, ng)
+    s = sums.view(d, b, q, 2)
+    bce = (prod[:, :, 0] + s[..., 0:1] - prod[:, :, 1]) / p
+    dice = 1 - (2 * prod[:, :, 2] + 1.0) / (s[..., 1:2] + gp.view(d, b, ng, p).sum(-1)[..., None, :] + 1.0)
+    ref = (cls_cost + 5.0 * bce + 5.0 * dice).flatten(0, 1)
+    # one launch
+    terms1, sums1 = ops.match_cost_terms(mp, ones_row=True)
+    assert torch.equal(sums1, sums) and torch.equal(terms1[:, :3 * q], terms) and bool((terms1[:, 3 * q] == 1).all())
+    got = ops.match_cost(cls, labels, torch.matmul(terms1, gpt), sums1, p)
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
+
+
+def test_cls_loss_single_launch_equals_cross_entropy(device):
+    """mbv_cls_loss_fwd / _bwd against F.cross_entropy(weight=class_weight, reduction='none') summed per decoder output and
+    divided by the summed class weights of the targets (mask2former_head.py:393-404), unmatched queries -> 'no object'."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(5)
+    d, b, q, ng, k1 = 4, 3, 9, 6, 3
+    cls = torch.randn(d, b, q, k1, generator=g).to(device).requires_grad_()
+    labels_gt = torch.randint(0, k1 - 1, (b, ng), generator=g).to(device)
+    assigned = torch.randint(-1, ng, (d, b, q), generator=g).to(torch.int32).to(device)
+    cw = torch.tensor([1.0, 0.7, 0.1], device=device)
+    gout = torch.randn(d, generator=g).to(device)
+    eps = float(torch.finfo(torch.float32).eps)
+    loss = ops.cls_loss(cls, assigned, labels_gt, cw, 2.0, eps)
+    (loss * gout).sum().backward()
+    got_grad = cls.grad.clone()
+    cls.grad = None
+    matched = assigned >= 0
+    lab = torch.where(matched, torch.gather(labels_gt.view(1, b, ng).expand(d, b, ng), 2, assigned.clamp(min=0).long()),
+                      torch.full_like(assigned, k1 - 1, dtype=torch.int64))
+    ce = F.cross_entropy(cls.flatten(0, 2), lab.flatten(), weight=cw, reduction='none').view(d, -1)
+    ref = 2.0 * ce.sum(1) / (cw[lab].view(d, -1).sum(1) + eps)
+    (ref * gout).sum().backward()
+    assert torch.allclose(loss, ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got_grad, cls.grad, rtol=1e-4, atol=1e-6)
