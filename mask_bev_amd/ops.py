@@ -818,7 +818,6 @@ _ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
 
 def gemm16_enabled() -> bool:
     """A/B switch: `switches.gemm16 = '0'` sends every Linear back to the library GEMM."""
-    import os
     return switches.get('gemm16') != '0'
 
 
@@ -1778,9 +1777,19 @@ class _MaskLogits(torch.autograd.Function):
                 raise MaskBevHipError('mask_logits: the output slot must be a contiguous f32 (B, Q, H, W) tensor')
         else:
             out = torch.empty((b, q, h, w), dtype=dt, device=f.device)
-        rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), _dt_flag(dt), b, q, c, h * w, _ptr(out),
-                                     1 if out.dtype == torch.float32 else 0, _stream())
-        check(rc, 'mbv_mask_logits_fwd')
+        hw = h * w
+        if (dt in _GEMM16_DT and gemm16_enabled() and c % 8 == 0 and hw % 8 == 0 and e.data_ptr() % 16 == 0
+                and f.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and c * hw * 2 < 0x7fff0000):
+            # the same contraction as a batched NN product of K17: E (Q, C) . F (C, HW) with F's pixels contiguous is
+            # exactly its K-strided operand form (LDS-DMA + ds_read_b64_tr_b16: no 2-byte transposing LDS stores) —
+            # 15.7 against 26.9 us per launch at the bench shape, same sums (scratch/bench_k7.py)
+            check(lib.mbv_gemm16_nn(_ptr(e), _ptr(f), _ptr(out), None, None, q, c, hw, c, hw, hw, 0, _GEMM16_DT[dt],
+                                    1 if out.dtype == torch.float32 else 0, 0, b, q * c, c * hw, q * hw, None, 0, _stream()),
+                  'mbv_gemm16_nn')
+        else:
+            rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), _dt_flag(dt), b, q, c, hw, _ptr(out),
+                                         1 if out.dtype == torch.float32 else 0, _stream())
+            check(rc, 'mbv_mask_logits_fwd')
         ctx.save_for_backward(e, f)
         ctx.embed_dtype = mask_embed.dtype
         return out
