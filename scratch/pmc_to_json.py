@@ -45,6 +45,23 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_colsum', r'k_colsum<', []),
     ('k_ln_apply', r'k_ln_apply', []),
     ('k_ln_bwd_dense', r'k_ln_bwd_dense', []),
+    # round 4: the families bench.py prices beyond this repository's attention / GEMM / loss kernels
+    ('k_pfn_stats', r'k_pfn_stats', []),
+    ('k_pfn_apply_max', r'k_pfn_apply_max', []),
+    ('k_pfn_bwd_route', r'k_pfn_bwd_route', []),
+    ('k_pfn_bwd_bn', r'k_pfn_bwd_bn', []),
+    ('k_pfn_decorate', r'k_pfn_decorate', []),
+    ('k_msda_prepare_fwd', r'k_msda_prepare_fwd', []),
+    ('k_msda_prepare_bwd', r'k_msda_prepare_bwd', []),
+    ('k_match_cost', r'k_match_cost', []),
+    ('k_attn_mask', r'k_attn_mask', []),
+    ('k_pack_binary', r'k_pack_binary', []),
+    # library kernels by operand type (Tensile names: _BBS_ / _BSS_ / _HHS_ / _HSS_ = 16-bit inputs, _S_B_ / _SB_ = f32)
+    ('hipblaslt_16bit', r'^Cijk_.*_(BBS|BSS|HHS|HSS|BS|HS)_', []),
+    ('hipblaslt_f32', r'^Cijk_.*_S_B_', []),
+    ('miopen_conv', r'^igemm_', [r'batched_transpose', r'SubTensorOp']),
+    ('aten_reduce', r'at::native::reduce_kernel|softmax|at::native::.*sort', []),
+    ('aten_elementwise', r'at::native::(vectorized_|elementwise_kernel|unrolled_|.*CatArray|.*index_|.*_scatter_gather|.*upsample)', []),
 ]
 
 
