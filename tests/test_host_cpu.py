@@ -407,6 +407,12 @@ def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
     for r in line['roofline_all']:
         if r['bound'] != 'hbm' or not r.get('traffic'):
             continue
+        if r['kernel'] == 'k_hungarian':
+            # K9's padded-column form reads only the REAL ground-truth columns of each cost matrix (their number is a
+            # device tensor); the model charges the whole matrix as an upper bound.  One wavefront per problem: the family
+            # is latency-bound at 0.000 of HBM peak either way, no fraction is inflated by it.
+            assert r['frac'] < 0.01
+            continue
         assert r['traffic'] >= 0.9 * r['algorithmic_bytes'], (r['kernel'], r['traffic'], r['algorithmic_bytes'])
         checked += 1
     assert checked >= 20
