@@ -268,8 +268,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_hungarian_padded': lambda a: ('k_hungarian', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 4.0 + _i(a[1]) * _i(a[2]) * 4.0, 0.0),
     'mbv_uniform_points': lambda a: ('k_uniform_points', 'hbm', _i(a[1]) * _i(a[2]) * 8.0, 0.0),
     'mbv_pack_binary_masks': lambda a: ('k_pack_binary', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * (4.0 + 1.0 / 8.0), 0.0),
+    # the bilinear resize reads four taps per OUTPUT pixel: a 16 x 16 mask of a 128 x 128 map touches 1 024 of its 16 384 logits
     'mbv_attn_mask_from_logits': lambda a: ('k_attn_mask', 'hbm',
-                                            _i(a[2]) * (_i(a[3]) * _i(a[4]) * (2.0 if _i(a[1]) else 4.0) + _i(a[5]) * _i(a[6])), 0.0),
+                                            _i(a[2]) * (min(_i(a[3]) * _i(a[4]), 4 * _i(a[5]) * _i(a[6]))
+                                                        * (2.0 if _i(a[1]) else 4.0) + _i(a[5]) * _i(a[6])), 0.0),
     'mbv_gemm16_nt_acc': lambda a: ('k_gemm16<NT,acc>', 'mfma',
                                     _i(a[11]) * ((_i(a[3]) + _i(a[4])) * _i(a[5]) * 2.0 + 2.0 * _i(a[3]) * _i(a[4]) * 4.0),
                                     2.0 * _i(a[11]) * _i(a[3]) * _i(a[4]) * _i(a[5])),
