@@ -792,5 +792,14 @@ def ffn_split(f: int, e: int, dt: torch.dtype) -> int:
     return f // 256 if (fused and switches.get('rc_split')) else 1
 
 
-def enabled() -> bool:
-    return switches.get('decoder_fused')
+def enabled(dtype: torch.dtype = torch.bfloat16) -> bool:
+    """Whether the row-chain decoder is wanted for compute dtype ``dtype`` (`switches.decoder_fused`).  In fp32 the chains'
+    GEMM stages are exact-f32 MFMA products of 16-row blocks (25 workgroups, 32 MAC / clk / SIMD): 54 launches of ~ 110 us
+    against the per-op path's few-row library GEMMs — 69.0 vs 72.1 scans/s for the fp32 step (round 4), so 'auto' keeps
+    the chains to the 16-bit modes."""
+    mode = str(switches.get('decoder_fused'))
+    if mode in ('0', 'False'):
+        return False
+    if mode in ('1', 'True'):
+        return True
+    return dtype != torch.float32

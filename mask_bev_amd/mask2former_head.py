@@ -481,7 +481,7 @@ class Mask2FormerHead(nn.Module):
         fused_ffn = dt != torch.float32 and f % 256 == 0 and e % 32 == 0 and switches.get('rc_ffn')
         if self.cls_embed.out_features > 256 or (f > 16384 if fused_ffn else f > 2048):
             return False
-        return (DF.enabled() and mask_features.is_cuda and all(s is not None for s in shared)
+        return (DF.enabled(dt) and mask_features.is_cuda and all(s is not None for s in shared)
                 and (deferred or not torch.is_grad_enabled())
                 and e % 32 == 0 and e <= 256 and f % 32 == 0 and oc % 4 == 0 and oc <= 256
                 and self.mask_embed[0].out_features <= 256 and self.mask_embed[2].out_features <= 256

@@ -42,10 +42,14 @@ def test_product_library_reads_no_environment():
         if name.endswith('.py') and name not in ('switches.py', 'build.py'):
             src = open(os.path.join(pkg, name)).read()
             assert not re.findall(r"environ[^\n]*MBV_", src), name
-    assert switches.get('decoder_fused') is True and switches.defaults() == switches._values
-    with switches.override(decoder_fused='0', gemm16='all'):
-        assert switches.get('decoder_fused') is False and switches.get('gemm16') == 'all'
-    assert switches.get('decoder_fused') is True and switches.get('gemm16') == 'auto'
+    assert switches.get('decoder_fused') == 'auto' and switches.defaults() == switches._values
+    with switches.override(decoder_fused='0', gemm16='all', shared_kv='0'):
+        assert switches.get('decoder_fused') == '0' and switches.get('gemm16') == 'all' and switches.get('shared_kv') is False
+    assert switches.get('decoder_fused') == 'auto' and switches.get('gemm16') == 'auto' and switches.get('shared_kv') is True
+    from mask_bev_amd import decoder_fused as DF
+    assert DF.enabled(torch.bfloat16) and DF.enabled(torch.float16) and not DF.enabled(torch.float32)
+    with switches.override(decoder_fused='1'):
+        assert DF.enabled(torch.float32)
     with pytest.raises(KeyError):
         switches.set_value('no_such_switch', 1)
 
