@@ -5,7 +5,9 @@ torch.  Its default heuristic is not the fastest solution for a third of this mo
 token matrices against 192…3072-wide weights; weight gradients with K = tokens): ``tuned/gemm_gfx950.csv`` holds the
 solution index that PyTorch's TunableOp measured fastest for each of the 108 GEMM signatures of the
 ``semantic_kitti_512`` step at 4 scans per GPU (38.9 → 38.1 ms per step).  Only the *selection* changes — every
-entry is a stock hipBLASLt solution (or ``Default``).
+entry is a stock hipBLASLt solution (or ``Default``).  Round 4 added the 100 signatures of the same step in fp32
+(``bench.py --dtype fp32`` under the command below, starting from the committed file): the fp32 step is library-GEMM
+bound (26.7 of 55 ms) and went from 72.6 to 75.7 scans/s with the measured selections (93 of the 100 are not the default).
 
 ``use_tuned_gemms()`` switches TunableOp on in look-up-only mode.  Shapes that are not in the table, or a table
 whose validator lines (PyTorch / ROCm / hipBLASLt versions, GPU architecture) do not match the running stack, fall
