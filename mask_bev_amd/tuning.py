@@ -7,7 +7,10 @@ solution index that PyTorch's TunableOp measured fastest for each of the 108 GEM
 ``semantic_kitti_512`` step at 4 scans per GPU (38.9 → 38.1 ms per step).  Only the *selection* changes — every
 entry is a stock hipBLASLt solution (or ``Default``).  Round 4 added the 100 signatures of the same step in fp32
 (``bench.py --dtype fp32`` under the command below, starting from the committed file): the fp32 step is library-GEMM
-bound (26.7 of 55 ms) and went from 72.6 to 75.7 scans/s with the measured selections (93 of the 100 are not the default).
+bound (26.7 of 55 ms) and went from 72.6 to 75.7 scans/s with the measured selections (93 of the 100 are not the default);
+the fp16 step's 55 signatures were added the same way (fp16 now equals bf16 within the noise).  Re-tuning the bf16 step
+from the committed table hit a hipBLASLt candidate that faults on this ROCm (memory access fault, like the pinned
+``tn_256_100_16384_B_4``): the bf16 entries are the earlier rounds'.
 
 ``use_tuned_gemms()`` switches TunableOp on in look-up-only mode.  Shapes that are not in the table, or a table
 whose validator lines (PyTorch / ROCm / hipBLASLt versions, GPU architecture) do not match the running stack, fall
