@@ -670,6 +670,12 @@ int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, 
                   int64_t stride_g, int64_t stride_x, int64_t stride_dw, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* d(coarse map) of `F.interpolate(coarse, size=(h, w), mode='bilinear', align_corners=False)` — the adjoint K18's fused
+ * FPN step owes its added map (ATen upsample_bilinear2d_backward): grad_out (planes, h, w) → grad_in (planes, in_h, in_w), any
+ * MBV_DT_* storage types; gather form, no atomics, every output written once. */
+int mbv_upsample_bilinear_bwd(const void* grad_out, int32_t grad_dtype, int64_t planes, int32_t h, int32_t w, int32_t in_h,
+                              int32_t in_w, void* grad_in, int32_t in_dtype, void* stream);
+
 /* K18 — GroupNorm of NCHW maps fused with its surroundings in mmcv's ConvModule (conv -> GroupNorm(32) [-> ReLU]) as
  * the pixel decoder builds it (mask_bev/models/head/mask_bev_panoptic_head.py:119-123 -> mmdet MSDeformAttnPixelDecoder
  * input_convs / lateral_convs / output_convs) and the FPN step  lateral + F.interpolate(previous, bilinear,

@@ -120,6 +120,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                      _P]),
     'mbv_attn_bwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     'mbv_msda_query_inputs': (ctypes.c_int, [_P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    'mbv_upsample_bilinear_bwd': (ctypes.c_int, [_P, _I, _L, _I, _I, _I, _I, _P, _I, _P]),
     'mbv_groupnorm_supported': (ctypes.c_int, [_I, _I, _I, _I]),
     'mbv_groupnorm_workspace_bytes': (c_size_t, [_L, _I, _I, _I, _I]),
     'mbv_groupnorm_fwd': (ctypes.c_int, [_P, _I, _L, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P,

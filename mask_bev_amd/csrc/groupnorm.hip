@@ -260,7 +260,57 @@ int gn_chunks(int64_t planes, int64_t hw) {
 
 bool kind_ok(int k) { return k == MBV_DT_F32 || k == MBV_DT_BF16 || k == MBV_DT_F16; }
 
+// d(added map) of the fused FPN step: the adjoint of ATen's upsample_bilinear2d (align_corners = False) in GATHER form.
+// A thread owns one pixel (Y, X) of the coarse (ah, aw) plane and walks the fine pixels whose two source taps can touch
+// it — src(y) = scale (y + 0.5) - 0.5 in (Y - 1, Y + 1) — evaluating up_axis exactly as the forward did: no atomics, every
+// output written once, the fine gradient read ~ once from HBM (its 4 x 4 neighbourhoods overlap in L1 / L2).  ATen's
+// scatter kernel for the same adjoint took 78 us on the step's (4, 256, 128, 128) -> (64, 64) map, + 8 us for the cast.
+__global__ void __launch_bounds__(256) k_upsample_bilinear_bwd(const void* __restrict__ gy, int gy_kind, long planes,
+                                                               int H, int W, int ah, int aw, void* __restrict__ out,
+                                                               int out_kind) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)ah * aw;
+  if (idx >= planes * per) return;
+  const long plane = idx / per;
+  const int Y = (int)((idx - plane * per) / aw), X = (int)(idx - plane * per - (long)Y * aw);
+  const float sh = (float)ah / (float)H, sw = (float)aw / (float)W;
+  // fine rows / columns whose source position lies in (Y - 1, Y + 1): a superset by one on each side, filtered below
+  int y_lo = (int)floorf(((float)Y - 0.5f) / sh - 0.5f) - 1, y_hi = (int)ceilf(((float)Y + 1.5f) / sh - 0.5f) + 1;
+  int x_lo = (int)floorf(((float)X - 0.5f) / sw - 0.5f) - 1, x_hi = (int)ceilf(((float)X + 1.5f) / sw - 0.5f) + 1;
+  y_lo = y_lo < 0 ? 0 : y_lo; x_lo = x_lo < 0 ? 0 : x_lo;
+  y_hi = y_hi > H - 1 ? H - 1 : y_hi; x_hi = x_hi > W - 1 ? W - 1 : x_hi;
+  const long base = plane * (long)H * W;
+  float acc = 0.f;
+  for (int y = y_lo; y <= y_hi; ++y) {
+    int y0, ys; float ly;
+    up_axis(sh, y, ah, y0, ys, ly);
+    const float wy = (y0 == Y ? 1.f - ly : 0.f) + (y0 + ys == Y ? ly : 0.f);     // (ys == 0: both taps are y0 — weights add up)
+    if (wy == 0.f) continue;
+    for (int x = x_lo; x <= x_hi; ++x) {
+      int x0, xs; float lx;
+      up_axis(sw, x, aw, x0, xs, lx);
+      const float wx = (x0 == X ? 1.f - lx : 0.f) + (x0 + xs == X ? lx : 0.f);
+      if (wx != 0.f) acc += wy * wx * ld1(gy, gy_kind, base + (long)y * W + x);
+    }
+  }
+  if (out_kind == MBV_DT_F32) reinterpret_cast<float*>(out)[idx] = acc;
+  else reinterpret_cast<unsigned short*>(out)[idx] = out_kind == MBV_DT_BF16 ? f32_to_bf16_rne(acc) : (unsigned short)f32_to_h16(acc);
+}
+
 }  // namespace
+
+extern "C" int mbv_upsample_bilinear_bwd(const void* grad_out, int32_t grad_dtype, int64_t planes, int32_t h, int32_t w,
+                                         int32_t in_h, int32_t in_w, void* grad_in, int32_t in_dtype, void* stream) {
+  if (planes < 0 || h <= 0 || w <= 0 || in_h <= 0 || in_w <= 0) return MBV_ERR_BAD_ARG;
+  if (planes == 0) return MBV_OK;
+  if (!grad_out || !grad_in || grad_dtype < 0 || grad_dtype > 2 || in_dtype < 0 || in_dtype > 2) return MBV_ERR_BAD_ARG;
+  const long total = planes * (long)in_h * in_w;
+  if (total > 0x7fffffffL * 256) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_upsample_bilinear_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, grad_dtype, (long)planes, h, w, in_h, in_w, grad_in, in_dtype);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
 
 extern "C" int mbv_groupnorm_supported(int32_t channels, int32_t groups, int32_t h, int32_t w) {
   return (channels > 0 && groups > 0 && channels % groups == 0 && h > 0 && w > 0 && ((int64_t)h * w) % 4 == 0) ? 1 : 0;

@@ -2483,7 +2483,10 @@ class _GroupNorm(torch.autograd.Function):
         gadd = None
         if add_meta is not None and ctx.needs_input_grad[6]:
             shape, adt = add_meta                 # the added map entered through F.interpolate(bilinear, align_corners=False)
-            gadd = torch.ops.aten.upsample_bilinear2d_backward(gy, [h, wd], list(shape), False, None, None).to(adt)
+            gadd = torch.empty(shape, dtype=adt, device=gy.device)
+            check(lib.mbv_upsample_bilinear_bwd(_ptr(gy), _dt_flag(gy.dtype), int(shape[0]) * int(shape[1]), h, wd,
+                                                int(shape[2]), int(shape[3]), _ptr(gadd), _dt_flag(adt), _stream()),
+                  'mbv_upsample_bilinear_bwd')
         return dx, dgamma, dbeta, None, None, None, gadd, None
 
 

@@ -313,6 +313,8 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
     'mbv_colsum_accum_group': lambda a: _colsum_group(a),
     'mbv_gemm16_tn_group': lambda a: _tn_group(a),
+    'mbv_upsample_bilinear_bwd': lambda a: ('k_upsample_bilinear_bwd', 'hbm',
+                                            _i(a[2]) * (_i(a[3]) * _i(a[4]) * _sz(a[1]) + _i(a[5]) * _i(a[6]) * _sz(a[8])), 0.0),
     'mbv_groupnorm_fwd': lambda a: _groupnorm(a, False),
     'mbv_groupnorm_bwd': lambda a: _groupnorm(a, True),
     'mbv_merge_layernorm_fwd': lambda a: _merge_ln(a, False),

@@ -80,3 +80,22 @@ def test_conv_gn_module_equals_torch_path(device, monkeypatch):
             res[mode] = [y.detach(), x.grad] + [p.grad.clone() for p in m.parameters()] + ([add.grad] if with_add else [])
         for a, b in zip(res['1'], res['0']):
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())), (relu, with_add)
+
+
+@pytest.mark.parametrize('fine,coarse', [((16, 16), (8, 8)), ((20, 12), (7, 5)), ((9, 30), (3, 10)), ((5, 7), (5, 7)),
+                                         ((12, 8), (1, 1)), ((128, 128), (64, 64))])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_upsample_bilinear_backward_gather_form(device, fine, coarse, dt):
+    """mbv_upsample_bilinear_bwd (the adjoint K18's fused FPN step owes its added map, gather form) against autograd through
+    F.interpolate(bilinear, align_corners=False) in f64 — exact 2x, non-integer ratios, identity and a 1 x 1 source."""
+    from mask_bev_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(fine) + sum(coarse))
+    planes = 6
+    gy = torch.randn(planes, *fine, generator=g).to(device).to(dt)
+    a = torch.zeros(1, planes, *coarse, dtype=torch.float64, device=device, requires_grad=True)
+    (F.interpolate(a, size=fine, mode='bilinear', align_corners=False) * gy.double().unsqueeze(0)).sum().backward()
+    out = torch.empty(planes, *coarse, dtype=torch.float32, device=device)
+    ops.check(lib.mbv_upsample_bilinear_bwd(ops._ptr(gy), ops._dt_flag(dt), planes, fine[0], fine[1], coarse[0], coarse[1],
+                                            ops._ptr(out), 0, ops._stream()), 'mbv_upsample_bilinear_bwd')
+    assert torch.allclose(out.double(), a.grad[0], rtol=1e-5, atol=1e-5 * float(a.grad.abs().max()))
