@@ -278,6 +278,7 @@ class _PillarFeatureNet(torch.autograd.Function):
                 saved.append((a_prev, apad_prev, m_prev, y, ypad, scale, shift, mean, rstd, w, g.float()))
                 a_prev, apad_prev, m_prev = a, apad, m
         ctx.saved = saved
+        ctx.params = params
         ctx.meta = (row_start, num_points, v, p, training, count, [t.dtype for t in params])
         return m_prev
 
@@ -322,8 +323,25 @@ class _PillarFeatureNet(torch.autograd.Function):
                     sapad = dypad.mm(wa)
                     dm = dt.mm(wb)
                 grads[5 * l] = gw.to(dtypes[5 * l])
-        ctx.saved = None
+            # arena parameters: the 3 x 3 small gradients join the end-of-pass grouped accumulate (a (1, n) "column sum")
+            # instead of one AccumulateGrad add_ launch each
+            for i, g in enumerate(grads):
+                if g is not None:
+                    grads[i] = _param_grad_or_defer(ctx.params[i], g)
+        ctx.saved = ctx.params = None
         return (d_rows,) + (None,) * 7 + tuple(grads)
+
+
+def _param_grad_or_defer(p: torch.Tensor, g: torch.Tensor):
+    """The gradient ``g`` of parameter ``p`` for autograd — or None when ``p`` lives in the arena and the add into its
+    f32 gradient was queued with the pass's grouped accumulate launch (ops.flush_deferred_grads)."""
+    if (getattr(p, '_mbv_arena', False) and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+            and g.is_cuda and g.numel() == p.grad.numel() and g.numel() < (1 << 31)):
+        gf = g.float().contiguous()
+        if _defer_colsum(gf.view(1, -1), p.grad.view(-1), 1, gf.numel(), gf.numel()):
+            _fire_grad_hooks(p)
+            return None
+    return g.to(p.dtype)
 
 
 def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torch.Tensor:
@@ -989,8 +1007,11 @@ def _wgrad(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
         return g2.t().mm(x2).float()
     c = t // s                          # rows per chunk; the ragged tail (< s rows) is one more small GEMM
     gw = torch.bmm(g2[:s * c].view(s, c, -1).transpose(1, 2), x2[:s * c].view(s, c, -1)).sum(0, dtype=torch.float32)
-    if s * c < t:
-        gw = gw + g2[s * c:].t().mm(x2[s * c:]).float()
+    if s * c < t:                       # (the tail's product accumulates through the GEMM's beta = 1: no add launch)
+        if g2.dtype == torch.float32:
+            gw = torch.addmm(gw, g2[s * c:].t(), x2[s * c:])
+        else:
+            gw = gw + g2[s * c:].t().mm(x2[s * c:]).float()
     return gw
 
 
