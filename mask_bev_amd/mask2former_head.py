@@ -117,13 +117,15 @@ class MSDeformAttnPixelDecoder(nn.Module):
         n, nl = self.num_input_levels, self.num_encoder_levels
         shapes = tuple((int(feats[n - i - 1].shape[2]), int(feats[n - i - 1].shape[3])) for i in range(nl))
         ref, pos, shapes_t, level_start = self._geometry(shapes, feats[0].device)
-        tokens, lvl_pos = [], []
+        tokens = []
         for i in range(nl):
             proj = self.input_convs[i](feats[n - i - 1])
             tokens.append(proj.flatten(2).transpose(1, 2))
-            lvl_pos.append(pos[i] + self.level_encoding.weight[i].view(1, 1, -1))
         q = torch.cat(tokens, 1)
-        qpos = torch.cat(lvl_pos, 1)
+        if q.is_cuda:
+            qpos = ops.level_positions(self.level_encoding.weight, pos[:nl])
+        else:
+            qpos = torch.cat([pos[i] + self.level_encoding.weight[i].view(1, 1, -1) for i in range(nl)], 1)
         q_branch = None
         nlay = len(self.encoder.layers)
         for li, layer in enumerate(self.encoder.layers):

@@ -1686,6 +1686,46 @@ class _LevelInputs(torch.autograd.Function):
         return g_mem, g_w, None, None, None
 
 
+class _LevelPositions(torch.autograd.Function):
+    """Query positions of the pixel decoder's encoder: ``cat_i(pos_i + level_encoding[i])`` over the levels' tokens
+    (mmdet MSDeformAttnPixelDecoder: ``level_positional_encoding = level_encoding.weight[i] + pos_i``).  One node: the
+    backward is three row-range column sums that join the pass's grouped accumulate (arena) — autograd's version was a
+    ``sum`` per level, ``select_backward``'s zeros + copy per level, two adds of the (3, C) pieces and an ``add_``."""
+
+    @staticmethod
+    def forward(ctx, weight, lengths, *pos):
+        ctx.lengths = lengths
+        ctx.weight = weight
+        out = torch.cat([p + weight[i].view(1, 1, -1) for i, p in enumerate(pos)], 1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, lengths = ctx.weight, ctx.lengths
+        c = g.shape[-1]
+        g2 = g.reshape(-1, c) if g.shape[0] == 1 else g.sum(0)
+        g2 = g2.contiguous()
+        direct = (getattr(w, '_mbv_arena', False) and w.grad is not None and w.grad.dtype == torch.float32
+                  and w.grad.is_contiguous() and g2.is_cuda and g2.dtype in _ACT_DTYPES)
+        gw = None if direct else torch.zeros_like(w)
+        start = 0
+        for i, n in enumerate(lengths):
+            if direct:
+                if not _defer_colsum(g2, w.grad[i], n, c, c, offset=start * c):
+                    _colsum_now(g2, w.grad[i], n, c, c, offset=start * c)
+            else:
+                gw[i] = g2[start:start + n].sum(0).to(w.dtype)
+            start += n
+        if direct:
+            _fire_grad_hooks(w)
+        return (gw, None) + (None,) * len(lengths)
+
+
+def level_positions(weight: torch.Tensor, pos) -> torch.Tensor:
+    """(1, sum_i N_i, C): ``pos[i] (1, N_i, C) + weight[i]`` concatenated over the levels."""
+    return _LevelPositions.apply(weight, tuple(int(p.shape[1]) for p in pos), *pos)
+
+
 def level_inputs(memory: torch.Tensor, level_weight: torch.Tensor, index: int, pos: torch.Tensor, dtype: torch.dtype):
     """(value tokens, key tokens) of memory level ``index`` in ``dtype``: memory (B, C, H, W), level_weight (levels, C),
     pos (1 or B, H*W, C)."""

@@ -117,7 +117,10 @@ def test_loss_and_gradients_match_oracle_nonsquare_200_queries(device):
     for k in ['_encoder._layer_norm.weight', '_backbone._backbone.patch_embed.projection.weight',
               '_panoptic_head._panoptic_head.transformer_decoder.layers.2.cross_attn.attn.in_proj_weight',
               '_panoptic_head._panoptic_head.mask_embed.4.weight', '_panoptic_head._panoptic_head.query_feat.weight',
-              '_panoptic_head._panoptic_head.cls_embed.weight']:
+              '_panoptic_head._panoptic_head.cls_embed.weight',
+              # the two level-embedding parameters (single-node forms ops.level_positions / ops.level_inputs)
+              '_panoptic_head._panoptic_head.pixel_decoder.level_encoding.weight',
+              '_panoptic_head._panoptic_head.level_embed.weight']:
         g, r = got[k].grad.cpu(), sd_g[k].grad
         assert r is not None and _rel(g, r) < 5e-3, k
 
