@@ -439,6 +439,25 @@ int mbv_match_cost(const float* cls, const int64_t* labels, const float* prod, c
                    int32_t queries, int32_t targets, int32_t classes_plus_one, int32_t batch, int32_t points, float* cost,
                    void* stream);
 
+/* The same costs without the term planes and without a library GEMM (K13c, csrc/match_products.hip): the products
+ * x . t and sigmoid(x) . t and the row sums come from ONE kernel that evaluates the terms per 32-point chunk, splits them
+ * into IEEE-half pairs (22 significant bits) and contracts them on v_mfma_f32_32x32x16_f16 with f32 accumulation.
+ * logits (groups, queries, points) f32 = the sampled mask logits, targets (groups, targets_n, points) f32 = the sampled
+ * ground truth (any values in [0, 1]); both 16-byte aligned.  A group's points are cut into `splits` slices (one workgroup
+ * each: choose groups * splits ~ 2 workgroups per CU; 1 <= splits <= ceil(points / 32)); slice s of group n writes
+ *   prod[n][s] (2 * queries + 1, targets_n + 1) f32 = [x ; sigmoid(x) ; ones] . [t ; ones]^T   and
+ *   neg_sums[n][s] (queries) f32 = sum softplus(x),
+ * which mbv_match_cost_split adds in slice order (no atomics: bit-reproducible) into cost (groups, queries, targets) f32 =
+ * -2 softmax(cls)[label] + 5 (sum softplus(x) - x . t) / points + 5 (1 - (2 sigmoid(x) . t + 1) / (sum sigmoid(x) + sum t + 1)).
+ * Supported (mbv_match_products_supported != 0): 2 * queries + 1 <= 224, targets_n + 1 <= 128, points % 8 == 0; otherwise
+ * MBV_ERR_UNSUPPORTED and the caller keeps mbv_match_cost_terms + a GEMM + mbv_match_cost. */
+int mbv_match_products_supported(int32_t queries, int32_t targets_n, int32_t points);
+int mbv_match_products(const float* logits, const float* targets, int64_t groups, int32_t queries, int32_t targets_n,
+                       int32_t points, int32_t splits, float* prod, float* neg_sums, void* stream);
+int mbv_match_cost_split(const float* cls, const int64_t* labels, const float* prod, const float* neg_sums, int64_t groups,
+                         int32_t queries, int32_t targets, int32_t classes_plus_one, int32_t batch, int32_t points,
+                         int32_t splits, float* cost, void* stream);
+
 /* Classification loss of all decoder outputs (mmdet CrossEntropyLoss(class_weight), avg_factor = sum of the targets' class
  * weights: mask2former_head.py:393-404): cls (outputs, batch * queries, classes_plus_one) f32, assigned (outputs, batch,
  * queries) i32 = ground-truth column or -1 (→ label classes_plus_one - 1, "no object"), labels (batch, targets) i64.

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 
 class MaskBevHipError(RuntimeError):
@@ -98,6 +98,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_matched_mask_iou': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_match_cost_terms': (ctypes.c_int, [_P, _L, _I, _I, _I, _P, _P, _P]),
     'mbv_match_cost': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    'mbv_match_products_supported': (ctypes.c_int, [_I, _I, _I]),
+    'mbv_match_products': (ctypes.c_int, [_P, _P, _L, _I, _I, _I, _I, _P, _P, _P]),
+    'mbv_match_cost_split': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mbv_cls_loss_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     'mbv_cls_loss_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     'mbv_packed_mask_words': (_L, [_I, _I]),

@@ -639,6 +639,12 @@ class Mask2FormerHead(nn.Module):
                               self._iota(d * b * nq, dev, div=nq)).view(d, b, nq, -1)            # (D, B, Q, P)
         gp = self._sample_gt(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
                              self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)             # (D, B, G, P)
+        if (cls.is_cuda and switches.get('loss_glue') and switches.get('match_fused')
+                and ops.match_products_supported(nq, ng, mp.shape[-1])):
+            # K13c: the products x·t, sigmoid(x)·t and every row sum from one kernel (terms evaluated per 32-point chunk,
+            # split into half pairs, contracted on MFMA) — the (DB, 3Q + 1, P) term planes and the f32 GEMM are gone
+            prod, neg = ops.match_products(mp.reshape(d * b, nq, -1), gp.reshape(d * b, ng, -1))
+            return ops.match_cost_split(cls, labels_gt, prod, neg, self.num_points)
         gpt = gp.reshape(d * b, ng, -1).transpose(1, 2)                                       # (DB, P, G)
         if cls.is_cuda and switches.get('loss_glue'):
             # K13: the cost terms with an all-ones row behind them — ONE batched GEMM against the sampled ground truth then

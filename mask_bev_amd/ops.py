@@ -2674,6 +2674,50 @@ def match_cost(cls: torch.Tensor, labels_gt: torch.Tensor, prod: torch.Tensor, s
     return cost
 
 
+def match_products_supported(queries: int, targets: int, points: int) -> bool:
+    return bool(_lib.load().mbv_match_products_supported(int(queries), int(targets), int(points)))
+
+
+@torch.no_grad()
+def match_products(logits: torch.Tensor, targets: torch.Tensor, splits: Optional[int] = None):
+    """Sampled mask logits (N, Q, P) f32 and sampled ground truth (N, G, P) f32 → the sliced products (N, S, 2Q + 1, G + 1) =
+    [x ; sigmoid(x) ; 1] · [t ; 1]ᵀ and softplus sums (N, S, Q) of K13c: no term planes, no library GEMM.  S slices of the
+    points per group, by default ≈ two workgroups per CU over all groups."""
+    lib = _lib.load()
+    x, t = logits.float().contiguous(), targets.float().contiguous()
+    _need_gpu(x, t)
+    n, q, p = x.shape
+    g = int(t.shape[1])
+    if tuple(t.shape) != (n, g, p):
+        raise MaskBevHipError('match_products: logits (N, Q, P) and targets (N, G, P) expected')
+    chunks = (p + 31) // 32
+    if splits is None:
+        splits = max(1, min(chunks, 512 // max(n, 1)))
+    prod = torch.empty((n, splits, 2 * q + 1, g + 1), dtype=torch.float32, device=x.device)
+    neg = torch.empty((n, splits, q), dtype=torch.float32, device=x.device)
+    check(lib.mbv_match_products(_ptr(x), _ptr(t), n, q, g, p, int(splits), _ptr(prod), _ptr(neg), _stream()),
+          'mbv_match_products')
+    return prod, neg
+
+
+@torch.no_grad()
+def match_cost_split(cls: torch.Tensor, labels_gt: torch.Tensor, prod: torch.Tensor, neg: torch.Tensor, num_points: int):
+    """The (D*B, Q, G) matching costs from :func:`match_products`' slices: cls (D, B, Q, K+1) f32, labels_gt (B, G) i64."""
+    lib = _lib.load()
+    d, b, q, k1 = cls.shape
+    g = int(labels_gt.shape[1])
+    cls, labels_gt = cls.float().contiguous(), labels_gt.contiguous()
+    _need_gpu(cls, labels_gt, prod, neg)
+    splits = int(prod.shape[1])
+    if (tuple(prod.shape) != (d * b, splits, 2 * q + 1, g + 1) or tuple(neg.shape) != (d * b, splits, q)
+            or labels_gt.dtype != torch.int64 or not prod.is_contiguous() or not neg.is_contiguous()):
+        raise MaskBevHipError('match_cost_split: prod (D*B, S, 2Q+1, G+1), neg (D*B, S, Q) and int64 labels expected')
+    cost = torch.empty((d * b, q, g), dtype=torch.float32, device=cls.device)
+    check(lib.mbv_match_cost_split(_ptr(cls), _ptr(labels_gt), _ptr(prod), _ptr(neg), d * b, q, g, k1, b, int(num_points),
+                                   splits, _ptr(cost), _stream()), 'mbv_match_cost_split')
+    return cost
+
+
 class _ClsLoss(torch.autograd.Function):
     """Class-weighted cross entropy of all decoder outputs against the assignment, one launch each way (K13)."""
 

@@ -26,6 +26,7 @@ _DEFAULTS: Dict[str, Any] = {
     'tail_stream': True,          # FPN tail on a second stream
     'overlap_matcher': True,      # matcher branch beside the importance sampling
     'loss_node': True,            # dice / BCE algebra as one autograd node
+    'match_fused': True,          # matcher products on MFMA from half pairs, terms never written (K13c)
     'loss_glue': True,            # matching-cost assembly and the class loss as single launches (K13)
     'tn_overlap': False,          # early stages' grouped weight gradients beside the encoder backward (measured slower)
     'msda_bwd_overlap': False,    # K5 backward's two parts on two streams (measured slower)

@@ -323,6 +323,14 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_match_cost_terms': lambda a: ('k_match_cost_terms', 'hbm', _i(a[1]) * _i(a[2]) * _i(a[3]) * 16.0, 0.0),
     'mbv_match_cost': lambda a: ('k_match_cost', 'hbm',
                                  _i(a[4]) * ((3.0 * _i(a[5]) + 1) * _i(a[6]) + _i(a[5]) * _i(a[6])) * 4.0, 0.0),
+    # K13c: reads the sampled logits and targets once, writes the sliced products; 2 (2Q + 1)(G + 1) P flops x 3 half products
+    'mbv_match_products': lambda a: ('k_match_products', 'hbm',
+                                     _i(a[2]) * ((_i(a[3]) + _i(a[4])) * _i(a[5]) * 4.0
+                                                 + _i(a[6]) * ((2.0 * _i(a[3]) + 1) * (_i(a[4]) + 1) + _i(a[3])) * 4.0),
+                                     _i(a[2]) * 6.0 * (2.0 * _i(a[3]) + 1) * (_i(a[4]) + 1) * _i(a[5])),
+    'mbv_match_cost_split': lambda a: ('k_match_cost', 'hbm',
+                                       _i(a[4]) * (_i(a[10]) * ((2.0 * _i(a[5]) + 1) * (_i(a[6]) + 1) + _i(a[5]))
+                                                   + _i(a[5]) * _i(a[6])) * 4.0, 0.0),
     'mbv_cls_loss_fwd': lambda a: ('k_cls_loss', 'hbm', _i(a[4]) * _i(a[5]) * _i(a[6]) * (_i(a[8]) * 4.0 + 4.0), 0.0),
     'mbv_cls_loss_bwd': lambda a: ('k_cls_loss', 'hbm', _i(a[6]) * _i(a[7]) * _i(a[8]) * (_i(a[10]) * 8.0 + 4.0), 0.0),
 }

@@ -93,6 +93,56 @@ def test_match_cost_single_launch_equals_the_torch_form(device):
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize('shape', [(3, 2, 10, 7, 96, None), (2, 2, 100, 100, 12544 // 4, None), (1, 3, 37, 5, 200, 3),
+                                   (2, 1, 111, 127, 40, 1), (1, 2, 16, 31, 1000, 32), (1, 1, 1, 1, 8, None)])
+def test_match_products_on_half_pairs_equal_float64_products(device, shape):
+    """K13c (mbv_match_products + mbv_match_cost_split): the matcher's products on MFMA from IEEE-half pairs, sliced over the
+    points, against the float64 evaluation of mask2former_head.py:199-210 — every row / column tile count, a trailing
+    partial chunk (P % 32 != 0), one slice and as many slices as chunks, fractional targets, large logits."""
+    from mask_bev_amd import ops
+    d, b, q, ng, p, splits = shape
+    g = torch.Generator().manual_seed(11 + q)
+    k1 = 3
+    assert ops.match_products_supported(q, ng, p)
+    cls = torch.randn(d, b, q, k1, generator=g).to(device)
+    labels = torch.randint(0, k1 - 1, (b, ng), generator=g).to(device)
+    mp = (torch.randn(d * b, q, p, generator=g) * 6).to(device)
+    mp[0, 0, :4] = torch.tensor([90.0, -90.0, 1e-6, 7e4], device=device)[:min(4, p)]
+    gp = torch.rand(d * b, ng, p, generator=g).to(device)
+    gp[:, ::2] = (gp[:, ::2] > 0.5).float()                      # half the columns binary, as inside a mask
+    prod, neg = ops.match_products(mp, gp, splits=splits)
+    x64, t64 = mp.double().clamp(-6e4, 6e4), gp.double()
+    assert torch.allclose(prod.sum(1)[:, :q, :ng].double(), x64 @ t64.transpose(1, 2), rtol=2e-6, atol=2e-4)
+    assert torch.allclose(prod.sum(1)[:, q:2 * q, :ng].double(), x64.sigmoid() @ t64.transpose(1, 2), rtol=2e-6, atol=1e-5)
+    assert torch.allclose(prod.sum(1)[:, 2 * q, :ng].double(), t64.sum(-1), rtol=2e-6, atol=1e-5)
+    assert torch.allclose(prod.sum(1)[:, q:2 * q, ng].double(), x64.sigmoid().sum(-1), rtol=2e-6, atol=1e-5)
+    assert torch.allclose(neg.sum(1).double(), F.softplus(x64).sum(-1), rtol=2e-6, atol=1e-5)
+    got = ops.match_cost_split(cls, labels, prod, neg, p)
+    prob = cls.double().softmax(-1)
+    cls_cost = -torch.gather(prob, 3, labels.view(1, b, 1, ng).expand(d, b, q, ng)) * 2.0
+    xt = (x64 @ t64.transpose(1, 2)).view(d, b, q, ng)
+    st = (x64.sigmoid() @ t64.transpose(1, 2)).view(d, b, q, ng)
+    bce = (F.softplus(x64).sum(-1).view(d, b, q, 1) - xt) / p
+    dice = 1 - (2 * st + 1.0) / (x64.sigmoid().sum(-1).view(d, b, q, 1) + t64.sum(-1).view(d, b, 1, ng) + 1.0)
+    ref = (cls_cost + 5.0 * bce + 5.0 * dice).flatten(0, 1)
+    got, ref = got.double().flatten(0, 1)[1:], ref.flatten(0, 1)[1:]     # row 0 holds the 7e4 logit: its f32 sums cancel
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
+    # same inputs, other slicing: the products are the same sums in another order
+    prod2, neg2 = ops.match_products(mp, gp, splits=1)
+    assert torch.allclose(prod2.sum(1), prod.sum(1), rtol=1e-5, atol=5e-3)      # f32 sums of up to 3 136 O(10) terms
+    # and the launch is reproducible bit for bit
+    prod3, neg3 = ops.match_products(mp, gp, splits=splits)
+    assert torch.equal(prod3, prod) and torch.equal(neg3, neg)
+
+
+def test_match_products_unsupported_shapes_are_refused(device):
+    from mask_bev_amd import ops
+    assert not ops.match_products_supported(112, 10, 64) and not ops.match_products_supported(10, 128, 64)
+    assert not ops.match_products_supported(10, 10, 100)
+    with pytest.raises(ops.MaskBevHipError):
+        ops.match_products(torch.zeros(1, 112, 64, device=device), torch.zeros(1, 10, 64, device=device))
+
+
 def test_cls_loss_single_launch_equals_cross_entropy(device):
     """mbv_cls_loss_fwd / _bwd against F.cross_entropy(weight=class_weight, reduction='none') summed per decoder output and
     divided by the summed class weights of the targets (mask2former_head.py:393-404), unmatched queries -> 'no object'."""
