@@ -103,21 +103,24 @@ __global__ void __launch_bounds__(kThreads, 2)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
-  Raw ra[2], rt[2];
-  auto fetch = [&](int c) {
-    const int k0 = c * kChunk + blk * 8;
-    const bool in = c < c1 && k0 < p;                   // p % 8 == 0: a block is inside or outside as a whole
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (in && a_row[j] >= 0) ra[j] = load8(a_ptr[j] + (long)c * kChunk);
-      if (in && t_row[j] >= 0) rt[j] = load8(t_ptr[j] + (long)c * kChunk);
-    }
-  };
-  fetch(c0);
   const int ks_u = blk >> 1, h_u = blk & 1;
   const int ntiles = (cols_t + 31) >> 5;
 
-  for (int c = c0; c < c1; ++c) {
+  // two register stages of raw chunks: while chunk c is converted and multiplied, the loads of chunks c + 1 and c + 2 are
+  // in flight (one chunk of a workgroup is 25 KB; a single stage left the loop waiting on HBM latency every chunk)
+  struct Stage {
+    Raw a[2], t[2];
+  };
+  auto fetch = [&](int c, Stage& st) {
+    const bool in = c < c1 && c * kChunk + blk * 8 < p;   // p % 8 == 0: a block is inside or outside as a whole
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (in && a_row[j] >= 0) st.a[j] = load8(a_ptr[j] + (long)c * kChunk);
+      if (in && t_row[j] >= 0) st.t[j] = load8(t_ptr[j] + (long)c * kChunk);
+    }
+  };
+
+  auto chunk = [&](int c, Stage& st) {
     const bool in = c * kChunk + blk * 8 < p;
     // ---- convert this chunk's logits and targets into fragment-ordered half pairs ----
 #pragma unroll
@@ -125,18 +128,20 @@ __global__ void __launch_bounds__(kThreads, 2)
       if (a_row[j] >= 0) {
         h8 xh, xl, sh, sl;
         if (in) {
-          float v[8] = {ra[j].v[0].x, ra[j].v[0].y, ra[j].v[0].z, ra[j].v[0].w,
-                        ra[j].v[1].x, ra[j].v[1].y, ra[j].v[1].z, ra[j].v[1].w};
+          float v[8] = {st.a[j].v[0].x, st.a[j].v[0].y, st.a[j].v[0].z, st.a[j].v[0].w,
+                        st.a[j].v[1].x, st.a[j].v[1].y, st.a[j].v[1].z, st.a[j].v[1].w};
           float sg[8];
           float sn = 0.f;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            v[i] = fminf(fmaxf(v[i], -60000.f), 60000.f);         // half's range; the costs saturate long before
-            const float e = __expf(-fabsf(v[i]));
+            // the raw v_exp_f32 / v_rcp_f32 / v_log_f32 (1 ulp): 1 + e lies in (1, 2], no denormal or range handling is
+            // needed, and libm's forms of the three cost more VALU issue slots than everything else in this loop
+            v[i] = __builtin_amdgcn_fmed3f(v[i], -60000.f, 60000.f);   // half's range; the costs saturate long before
+            const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(v[i]));
             const float d = 1.0f + e;
-            const float inv = __frcp_rn(d);
+            const float inv = __builtin_amdgcn_rcpf(d);
             sg[i] = v[i] >= 0.f ? inv : e * inv;
-            sn += fmaxf(v[i], 0.f) + __logf(d);
+            sn = fmaf(__builtin_amdgcn_logf(d), 0.6931471805599453f, sn + fmaxf(v[i], 0.f));
           }
           s_neg[j] += sn;
           split8(v, xh, xl);
@@ -154,8 +159,8 @@ __global__ void __launch_bounds__(kThreads, 2)
       if (t_row[j] >= 0) {
         h8 th, tl;
         if (in) {
-          const float v[8] = {rt[j].v[0].x, rt[j].v[0].y, rt[j].v[0].z, rt[j].v[0].w,
-                              rt[j].v[1].x, rt[j].v[1].y, rt[j].v[1].z, rt[j].v[1].w};
+          const float v[8] = {st.t[j].v[0].x, st.t[j].v[0].y, st.t[j].v[0].z, st.t[j].v[0].w,
+                              st.t[j].v[1].x, st.t[j].v[1].y, st.t[j].v[1].z, st.t[j].v[1].w};
           split8(v, th, tl);
         } else {
 #pragma unroll
@@ -176,29 +181,35 @@ __global__ void __launch_bounds__(kThreads, 2)
       if (tid < 4) lds_a[slot((2 * q) >> 5, b4 >> 1, 0, (2 * q) & 31, b4 & 1)] = val;
       else lds_t[slot(g >> 5, b4 >> 1, 0, g & 31, b4 & 1)] = val;
     }
-    fetch(c + 1);                                       // the next chunk's loads fly over the matrix phase
+    fetch(c + 2, st);                                   // this stage is free again
     __syncthreads();
-    // ---- C += A_hi B_hi + A_hi B_lo + A_lo B_hi; wave = column tile ----
+    // ---- C += A_hi B_hi + A_hi B_lo + A_lo B_hi; wave = column tile.  The three products of a row tile go back to back
+    //      into the same accumulator (same-opcode accumulate chains issue without a stall) so that only one pair of A
+    //      fragments is live: the registers that buys hold the second load stage ----
     if (wave < ntiles) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const h8 bh = lds_t[slot(wave, ks, 0, lane, 0)];
         const h8 bl = lds_t[slot(wave, ks, 1, lane, 0)];
-        h8 ah[MT], al[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          ah[m] = lds_a[slot(m, ks, 0, lane, 0)];
-          al[m] = lds_a[slot(m, ks, 1, lane, 0)];
+          const h8 ah = lds_a[slot(m, ks, 0, lane, 0)];
+          const h8 al = lds_a[slot(m, ks, 1, lane, 0)];
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
       }
     }
     __syncthreads();
+  };
+
+  Stage s0, s1;
+  fetch(c0, s0);
+  fetch(c0 + 1, s1);
+  for (int c = c0; c < c1; c += 2) {
+    chunk(c, s0);
+    if (c + 1 < c1) chunk(c + 1, s1);
   }
 
   // ---- this slice's partial products and softplus sums ----

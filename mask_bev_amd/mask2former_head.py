@@ -389,6 +389,12 @@ class Mask2FormerHead(nn.Module):
 
     def forward(self, x: List[torch.Tensor], batch_data_samples=None):
         bs = x[0].shape[0]
+        # fork point of the loss's target preparation (see loss()): everything it reads — the batch's labels and masks —
+        # exists before the head starts, so it may run underneath the pixel decoder and the decoder layers
+        self._early_event = None
+        if x[0].is_cuda and self.training and torch.is_grad_enabled() and switches.get('early_targets'):
+            self._early_event = torch.cuda.Event()
+            self._early_event.record(torch.cuda.current_stream(x[0].device))
         mask_features, memories = self.pixel_decoder(x)
         dec_in, dec_pos, dec_key = [], [], []
         # key = memory + pos, shared by the 3 layers of a level; under autocast one cast per level instead of one per
@@ -567,6 +573,25 @@ class Mask2FormerHead(nn.Module):
         return cls_list, mask_list, [None for _ in cls_list]
 
     # ------------------------------------------------------------------ loss
+    def _stream_for(self, name: str, device):
+        key = (name, str(device))
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = torch.cuda.Stream(device=device)
+        return st
+
+    @torch.no_grad()
+    def _real_cols(self, labels_gt, gt_flat, d, b, nq, ng):
+        """Per problem, the count K of real ground-truth columns for K9's padded mode (None: solve the square problem).  The
+        dataset pads the instance list to num_queries with all-zero masks of label 0; a column counts as padding only if it
+        has label 0 AND an empty mask AND every later column is padding too."""
+        if not (nq == ng <= 128 and isinstance(gt_flat, ops.PackedMasks) and switches.get('k9_padded')):
+            return None
+        dev = labels_gt.device
+        real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                      # (B, G)
+        last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)                # (B,) = K
+        return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()
+
     def _iota(self, n: int, device, div: int = 1, mod: int = 0) -> torch.Tensor:
         key = (n, div, mod, str(device))
         t = self._iota_cache.get(key)
@@ -627,9 +652,10 @@ class Mask2FormerHead(nn.Module):
         return ops.point_sample(gt, src_index, coords, coord_index)
 
     @torch.no_grad()
-    def _match_cost(self, cls, masks_flat, labels_gt, gt_flat, match_coords):
+    def _match_cost(self, cls, masks_flat, labels_gt, gp, match_coords):
         """Matching costs of ALL decoder outputs and images at once (mask2former_head.py:154-210).
-        cls (D, B, Q, K+1); masks_flat (D*B*Q, H, W); match_coords (D*B, P, 2).  Costs 2*(-softmax cls) +
+        cls (D, B, Q, K+1); masks_flat (D*B*Q, H, W); gp (D*B*G, P) the ground truth sampled at match_coords (D*B, P, 2)
+        (:meth:`_matcher_targets`).  Costs 2*(-softmax cls) +
         5*BCE + 5*dice on the sampled points; the D*B assignment problems are then solved on the device by one
         launch of K9 — no device→host copy, no scipy."""
         d, b, nq = cls.shape[:3]
@@ -637,8 +663,7 @@ class Mask2FormerHead(nn.Module):
         dev = cls.device
         mp = ops.point_sample(masks_flat, self._iota(d * b * nq, dev), match_coords,
                               self._iota(d * b * nq, dev, div=nq)).view(d, b, nq, -1)            # (D, B, Q, P)
-        gp = self._sample_gt(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_coords,
-                             self._iota(d * b * ng, dev, div=ng)).view(d, b, ng, -1)             # (D, B, G, P)
+        gp = gp.view(d, b, ng, -1)                                                               # (D, B, G, P)
         if (cls.is_cuda and switches.get('loss_glue') and switches.get('match_fused')
                 and ops.match_products_supported(nq, ng, mp.shape[-1])):
             # K13c: the products x·t, sigmoid(x)·t and every row sum from one kernel (terms evaluated per 32-point chunk,
@@ -692,44 +717,48 @@ class Mask2FormerHead(nn.Module):
         if stacked is None:
             stacked = torch.stack([mk.float() for mk in all_mask_preds], 0)
         masks_flat = stacked.flatten(0, 2)                                                       # (D*B*Q, H, W)
-        if packed_gt is not None:                         # K14 produced the bit-packed targets directly (batch.py)
-            gt_flat = packed_gt
-        else:
-            gt_flat = masks_gt.float().flatten(0, 1)                                             # (B*G, ny, nx)
-            if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
-                gt_flat = ops.pack_binary_masks(gt_flat)  # {0,1} by the batch contract: 32 KB per 512x512 mask
-        pts = PointSource(dev, self.point_seed)
-        match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
-        cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gt_flat, match_c)
-        # The dataset pads the instance list to num_queries with all-zero masks of label 0: those cost columns are
-        # identical, and K9 solves the equivalent rectangular problem of the real columns (ops.hungarian).  A column
-        # counts as padding only if it has label 0 AND an empty mask AND every later column is padding too.
-        def real_cols():             # evaluated on the matcher's stream: nothing else needs it
-            if not (nq == ng <= 128 and isinstance(gt_flat, ops.PackedMasks)
-                    and switches.get('k9_padded')):
-                return None
-            real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                  # (B, G)
-            last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)            # (B,) = K
-            return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()
-        # K9 is latency-bound (one wavefront per problem).  When every query gets matched (G >= Q, the dataset's
-        # padding convention) nothing of the importance sampling below depends on the assignment, so K9 runs on
-        # a side stream underneath it.
-        overlap = m == nq and self.overlap_matcher
-        main = torch.cuda.current_stream()
+        # Everything of the loss that depends on the BATCH only — the packed targets, the uniform points, the targets sampled
+        # at the matcher's points, the count of real columns — is issued on a stream that forks where the head's forward began
+        # (the event forward() recorded): in the captured step it is a parallel branch underneath the pixel decoder and the
+        # decoder layers instead of ≈ 0.25 ms in front of the matcher.
+        early = getattr(self, '_early_event', None)
+        self._early_event = None
+        prep = self._stream_for('prep', dev) if (early is not None and cls.is_cuda) else None
+        main = torch.cuda.current_stream() if cls.is_cuda else None
+        if prep is not None:
+            prep.wait_event(early)
+        with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
+            if packed_gt is not None:                     # K14 produced the bit-packed targets directly (batch.py)
+                gt_flat = packed_gt
+            else:
+                gt_flat = masks_gt.float().flatten(0, 1)                                         # (B*G, ny, nx)
+                if self.binary_gt_masks and gt_flat.shape[1] * gt_flat.shape[2] <= 1024 * 1024:
+                    gt_flat = ops.pack_binary_masks(gt_flat)  # {0,1} by the batch contract: 32 KB per 512x512 mask
+            pts = PointSource(dev, self.point_seed)
+            match_c, over_c, rand_c = self._draw_points(pts, d, b, g)
+            with torch.no_grad():
+                gp_match = self._sample_gt(gt_flat, self._iota(d * b * ng, dev, mod=b * ng), match_c,
+                                           self._iota(d * b * ng, dev, div=ng))                   # (D*B*G, P)
+            real_k = self._real_cols(labels_gt, gt_flat, d, b, nq, ng)
+        if prep is not None:
+            main.wait_stream(prep)
+        # K9 is latency-bound (one wavefront per problem) and the cost kernels in front of it are short.  When every query
+        # gets matched (G >= Q, the dataset's padding convention) nothing of the importance sampling below depends on the
+        # assignment, so the whole matcher — sampling the logits at its points, K13c, K9 — runs on a side stream underneath it.
+        overlap = m == nq and self.overlap_matcher and cls.is_cuda
         if overlap:
-            side = self._side_streams.get(dev)
-            if side is None:
-                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-            # every buffer the side stream touches is allocated on the main stream and outlives the join below,
+            side = self._stream_for('matcher', dev)
+            # every buffer the side stream's result lives in is allocated on the main stream and outlives the join below,
             # so no record_stream bookkeeping is needed (it also upsets a later HIP-graph capture)
-            cost = cost.float().contiguous()
             assigned = torch.empty((d * b, nq), dtype=torch.int32, device=dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.hungarian(cost, out=assigned, real_cols=real_cols())
+                cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gp_match, match_c)
+                ops.hungarian(cost.float().contiguous(), out=assigned, real_cols=real_k)
             assigned = assigned.view(d, b, nq)
         else:
-            assigned = ops.hungarian(cost, real_cols=real_cols()).view(d, b, nq)                   # (D, B, Q) i32
+            cost = self._match_cost(cls, masks_flat.detach(), labels_gt, gp_match, match_c)
+            assigned = ops.hungarian(cost, real_cols=real_k).view(d, b, nq)                       # (D, B, Q) i32
             matched = assigned >= 0
             safe = assigned.clamp(min=0).long()
 

@@ -25,6 +25,7 @@ _DEFAULTS: Dict[str, Any] = {
     # --- launch structure ------------------------------------------------------------------------------------------
     'tail_stream': True,          # FPN tail on a second stream
     'overlap_matcher': True,      # matcher branch beside the importance sampling
+    'early_targets': True,        # the loss's batch-only preparation forks where the head's forward began
     'loss_node': True,            # dice / BCE algebra as one autograd node
     'match_fused': True,          # matcher products on MFMA from half pairs, terms never written (K13c)
     'loss_glue': True,            # matching-cost assembly and the class loss as single launches (K13)
