@@ -245,6 +245,14 @@ int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int32_t is_bf1
                          const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
                          int32_t num_levels, int32_t num_points, float* loc, float* attn, void* stream);
 
+/* Same with (batch, query) row strides (elements) for the two inputs — they can then be column blocks of ONE projection
+ * GEMM's output, [offsets | logits] — and optional f32 biases (H*L*P*2) / (H*L*P) added to the loaded values in f32, for a
+ * GEMM that left them out.  With L*P % 4 == 0 both pointers and strides must keep 4-element alignment. */
+int mbv_msda_prepare_fwd_ld(const void* offsets, int64_t ld_offsets, const void* logits, int64_t ld_logits,
+                            const float* bias_offsets, const float* bias_logits, int32_t is_bf16, const float* ref_points,
+                            const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
+                            int32_t num_levels, int32_t num_points, float* loc, float* attn, void* stream);
+
 int mbv_msda_prepare_bwd(const float* grad_loc, const float* grad_attn, const float* attn,
                          const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query, int32_t num_heads,
                          int32_t num_levels, int32_t num_points, int32_t out_bf16, void* grad_offsets,

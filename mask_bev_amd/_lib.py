@@ -45,6 +45,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                                  c_size_t, _P, _P, _P]),
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
     'mbv_msda_prepare_fwd': (ctypes.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'mbv_msda_prepare_fwd_ld': (ctypes.c_int, [_P, _L, _P, _L, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_msda_prepare_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_msda_prepare_bwd_ld': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

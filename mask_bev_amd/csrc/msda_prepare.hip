@@ -93,14 +93,22 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_msda_prepare_fwd(const T* __restrict__ off, const T* __restrict__ logit,
                                                           const float* __restrict__ ref, Norm nrm, long rows,
                                                           int num_query, int heads, int levels, int points,
-                                                          float* __restrict__ loc, float* __restrict__ attn) {
+                                                          float* __restrict__ loc, float* __restrict__ attn,
+                                                          long ld_off, long ld_logit, const float* __restrict__ b_off,
+                                                          const float* __restrict__ b_logit) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const int lp = levels * points;
-  const int n = (int)((i / heads) % num_query);
+  const long tok = i / heads;
+  const int head = (int)(i - tok * heads);
+  const int n = (int)(tok % num_query);
   const float rx = ref[2 * n], ry = ref[2 * n + 1];
-  const T* o = off + i * lp * 2;
-  const T* a = logit + i * lp;
+  const T* o = off + tok * ld_off + (long)head * lp * 2;
+  const T* a = logit + tok * ld_logit + (long)head * lp;
+  // the projections' biases, when the GEMM in front left them out (one GEMM for both projections has no single bias vector
+  // of the library's epilogue type): added here in f32
+  const float* bo = b_off ? b_off + (long)head * lp * 2 : nullptr;
+  const float* ba = b_logit ? b_logit + (long)head * lp : nullptr;
   float v[kMaxLP];
   float m = -INFINITY;
   const bool vec = (lp & 3) == 0;               // uniform: whole rows move as 8 / 16-byte pieces
@@ -113,6 +121,11 @@ __global__ void __launch_bounds__(256) k_msda_prepare_fwd(const T* __restrict__ 
   } else {
 #pragma unroll
     for (int k = 0; k < kMaxLP; ++k) v[k] = k < lp ? ldf<T>(a + k) : -INFINITY;
+  }
+  if (ba) {
+#pragma unroll
+    for (int k = 0; k < kMaxLP; ++k)
+      if (k < lp) v[k] += ba[k];
   }
 #pragma unroll
   for (int k = 0; k < kMaxLP; ++k) m = fmaxf(m, v[k]);
@@ -134,6 +147,10 @@ __global__ void __launch_bounds__(256) k_msda_prepare_fwd(const T* __restrict__ 
         float o8[8], r8[8];
         ld4<T>(o + 2 * k, o8);
         ld4<T>(o + 2 * k + 4, o8 + 4);
+        if (bo) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += bo[2 * k + e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int l = (k + e) / points;
@@ -151,8 +168,8 @@ __global__ void __launch_bounds__(256) k_msda_prepare_fwd(const T* __restrict__ 
     if (k < lp) {
       const int l = k / points;
       ao[k] = v[k] * inv;
-      lo[2 * k] = rx + round_like<T>(ldf<T>(o + 2 * k) / nrm.w[l]);
-      lo[2 * k + 1] = ry + round_like<T>(ldf<T>(o + 2 * k + 1) / nrm.h[l]);
+      lo[2 * k] = rx + round_like<T>((ldf<T>(o + 2 * k) + (bo ? bo[2 * k] : 0.f)) / nrm.w[l]);
+      lo[2 * k + 1] = ry + round_like<T>((ldf<T>(o + 2 * k + 1) + (bo ? bo[2 * k + 1] : 0.f)) / nrm.h[l]);
     }
   }
 }
@@ -276,12 +293,22 @@ extern "C" int mbv_msda_prepare_supported(int32_t num_levels, int32_t num_points
   return num_levels >= 1 && num_levels <= 8 && num_points >= 1 && num_levels * num_points <= kMaxLP;
 }
 
-extern "C" int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int32_t is_bf16, const float* ref_points,
-                                    const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query,
-                                    int32_t num_heads, int32_t num_levels, int32_t num_points, float* loc, float* attn,
-                                    void* stream) {
+extern "C" int mbv_msda_prepare_fwd_ld(const void* offsets, int64_t ld_offsets, const void* logits, int64_t ld_logits,
+                                       const float* bias_offsets, const float* bias_logits, int32_t is_bf16,
+                                       const float* ref_points, const int64_t* spatial_shapes_host, int32_t batch,
+                                       int32_t num_query, int32_t num_heads, int32_t num_levels, int32_t num_points,
+                                       float* loc, float* attn, void* stream) {
   if (batch <= 0 || num_query <= 0 || num_heads <= 0) return MBV_ERR_BAD_ARG;
+  if (ld_offsets < (int64_t)num_heads * num_levels * num_points * 2 || ld_logits < (int64_t)num_heads * num_levels * num_points)
+    return MBV_ERR_BAD_ARG;
   if (!mbv_msda_prepare_supported(num_levels, num_points)) return MBV_ERR_UNSUPPORTED;
+  {   // the vector path reads 4 elements at a time: rows and the two base pointers must keep that alignment
+    const size_t es = is_bf16 ? 2 : 4;
+    if ((num_levels * num_points) % 4 == 0 &&
+        (((reinterpret_cast<size_t>(offsets) | reinterpret_cast<size_t>(logits)) & (4 * es - 1)) != 0 ||
+         (ld_offsets % 4) != 0 || (ld_logits % 4) != 0))
+      return MBV_ERR_BAD_ARG;
+  }
   if (!offsets || !logits || !ref_points || !loc || !attn) return MBV_ERR_BAD_ARG;
   Norm n;
   if (!fill_norm(spatial_shapes_host, num_levels, n)) return MBV_ERR_BAD_ARG;
@@ -290,17 +317,31 @@ extern "C" int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int
   if (is_bf16 == MBV_DT_F16)
     hipLaunchKernelGGL(k_msda_prepare_fwd<_Float16>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const _Float16*>(offsets), reinterpret_cast<const _Float16*>(logits),
-                       ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn);
+                       ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn, (long)ld_offsets,
+                       (long)ld_logits, bias_offsets, bias_logits);
   else if (is_bf16)
     hipLaunchKernelGGL(k_msda_prepare_fwd<unsigned short>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned short*>(offsets), reinterpret_cast<const unsigned short*>(logits),
-                       ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn);
+                       ref_points, n, rows, num_query, num_heads, num_levels, num_points, loc, attn, (long)ld_offsets,
+                       (long)ld_logits, bias_offsets, bias_logits);
   else
     hipLaunchKernelGGL(k_msda_prepare_fwd<float>, grid, block, 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(offsets), reinterpret_cast<const float*>(logits), ref_points, n,
-                       rows, num_query, num_heads, num_levels, num_points, loc, attn);
+                       rows, num_query, num_heads, num_levels, num_points, loc, attn, (long)ld_offsets, (long)ld_logits,
+                       bias_offsets, bias_logits);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
+}
+
+extern "C" int mbv_msda_prepare_fwd(const void* offsets, const void* logits, int32_t is_bf16, const float* ref_points,
+                                    const int64_t* spatial_shapes_host, int32_t batch, int32_t num_query,
+                                    int32_t num_heads, int32_t num_levels, int32_t num_points, float* loc, float* attn,
+                                    void* stream) {
+  const int64_t lp = (int64_t)num_levels * num_points;
+  if (!offsets || !logits) return MBV_ERR_BAD_ARG;
+  return mbv_msda_prepare_fwd_ld(offsets, num_heads * lp * 2, logits, num_heads * lp, nullptr, nullptr, is_bf16,
+                                 ref_points, spatial_shapes_host, batch, num_query, num_heads, num_levels, num_points, loc,
+                                 attn, stream);
 }
 
 extern "C" int mbv_msda_prepare_bwd_ld(const float* grad_loc, const float* grad_attn, const float* attn,

@@ -319,15 +319,17 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, query_pos: torch.Tensor, reference_points: torch.Tensor,
                 spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor,
-                add_identity: bool = True, defer_out_bias: bool = False):
-        """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y)."""
+                add_identity: bool = True, defer_out_bias: bool = False, pos_share=None, pos_share_index: int = 0):
+        """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y).
+        ``pos_share``: an ``ops.PosGradShare`` common to a chain of layers that add the same ``query_pos``."""
         b, n, e = query.shape
         h, l, p = self.num_heads, self.num_levels, self.num_points
         if (spatial_shapes is not None and query.is_cuda and query.dtype == torch.float32
                 and query_pos.shape[0] == 1 and sum(hh * ww for hh, ww in spatial_shapes) == n
                 and ops.msda_prepare_supported(l, p) and switches.get('msda_fused')):
             out = ops.msda_query_side(query, query_pos, reference_points, self.value_proj, self.sampling_offsets,
-                                      self.attention_weights, h, l, p, spatial_shapes, shapes_t, level_start)
+                                      self.attention_weights, h, l, p, spatial_shapes, shapes_t, level_start,
+                                      pos_share=pos_share, pos_share_index=pos_share_index)
             out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)
             return out + query if add_identity else out
         q = query + query_pos

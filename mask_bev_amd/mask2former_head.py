@@ -29,7 +29,8 @@ class _DeformEncoderLayer(nn.Module):
         self.ffn = FFN(embed_dims, ffn_channels, act='relu')
         self.norms = nn.ModuleList([LayerNorm(embed_dims), LayerNorm(embed_dims)])
 
-    def forward(self, q, pos, ref, shapes, shapes_t, level_start, q_branch=None, fanout=False):
+    def forward(self, q, pos, ref, shapes, shapes_t, level_start, q_branch=None, fanout=False, pos_share=None,
+                pos_share_index=0):
         """post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12).  A LayerNorm output has two
         consumers — the next residual add and the next branch: it is handed on as a PAIR of tensors over one buffer
         (``q`` for the residual, ``q_branch`` for the branch) so that K12's backward receives the two gradients
@@ -39,7 +40,8 @@ class _DeformEncoderLayer(nn.Module):
         d1, d2 = ops.bias_grad_deferrable(ob, c), ops.bias_grad_deferrable(fb, c)
         q_branch = q if q_branch is None else q_branch
         q, qb = self.norms[0](q, self.self_attn(q_branch, pos, ref, shapes, shapes_t, level_start, add_identity=False,
-                                                defer_out_bias=d1), residual_bias=ob if d1 else None, fanout=True)
+                                                defer_out_bias=d1, pos_share=pos_share, pos_share_index=pos_share_index),
+                              residual_bias=ob if d1 else None, fanout=True)
         return self.norms[1](q, self.ffn(qb, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None,
                              fanout=fanout)
 
@@ -128,11 +130,15 @@ class MSDeformAttnPixelDecoder(nn.Module):
             qpos = torch.cat([pos[i] + self.level_encoding.weight[i].view(1, 1, -1) for i in range(nl)], 1)
         q_branch = None
         nlay = len(self.encoder.layers)
+        # one d(pos) product for the chain of layers instead of one per layer (ops.PosGradShare)
+        share = (ops.PosGradShare(nlay) if (q.is_cuda and torch.is_grad_enabled() and qpos.requires_grad and nlay > 1
+                                            and switches.get('pos_share')) else None)
         for li, layer in enumerate(self.encoder.layers):
+            kw = dict(pos_share=share, pos_share_index=li)
             if li + 1 < nlay:
-                q, q_branch = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch, fanout=True)
+                q, q_branch = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch, fanout=True, **kw)
             else:
-                q = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch)
+                q = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch, **kw)
         outs = [t.transpose(1, 2).reshape(bs, -1, h, w) for t, (h, w) in
                 zip(torch.split(q, [h * w for h, w in shapes], dim=1), shapes)]
         # The FPN tail (lateral / output convolutions, mask-feature projection) runs on a second stream and is joined

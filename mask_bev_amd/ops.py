@@ -675,6 +675,39 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes, shapes_t: torch.Tensor, 
                                attention_weights.float(), host)
 
 
+class PosGradShare:
+    """d(pos) of the pixel decoder's encoder layers, taken once.  Every layer adds the same positional map to its query, so
+    d(pos) = Σ_layers (Σ_batch G_l[:, E:]) · [Wo_l; Wa_l] — per layer a batch sum, a (N, 3HLP) x (3HLP, E) product and an
+    accumulation into the running gradient.  With a share, layer l only stores its batch sum into column block l of one
+    (N, layers · 3HLP) matrix; the layer whose backward runs LAST (index 0: the first of the forward) multiplies the whole
+    matrix with the stacked weights — one product with a 6x longer contraction — and returns it as its d(pos); the others
+    return none.  Valid because the layers form a chain: every layer's backward has run when layer 0's does (checked)."""
+
+    def __init__(self, layers: int):
+        self.layers = int(layers)
+        self.weights = [None] * self.layers          # [Wo; Wa] of each layer in the compute dtype, (3HLP, E)
+        self.sums = None                             # (N, layers * 3HLP)
+        self.written = set()
+
+    def store(self, index: int, block: torch.Tensor, weight: torch.Tensor):
+        """block (B, N, 3HLP) strided view of G → its batch sum into column block ``index``."""
+        b, n, w = block.shape
+        if self.sums is None:
+            self.sums = torch.empty((n, self.layers * w), dtype=block.dtype if block.dtype in _LO_DTYPES else torch.float32,
+                                    device=block.device)
+        torch.sum(block, 0, out=self.sums[:, index * w:(index + 1) * w])
+        self.weights[index] = weight
+        self.written.add(index)
+
+    def finish(self) -> torch.Tensor:
+        if len(self.written) != self.layers:
+            raise MaskBevHipError(f'PosGradShare: {len(self.written)} of {self.layers} layers ran their backward')
+        od = {} if self.sums.dtype == torch.float32 else dict(out_dtype=torch.float32)
+        out = torch.mm(self.sums, torch.cat(self.weights, 0), **od)
+        self.sums, self.weights, self.written = None, [None] * self.layers, set()
+        return out
+
+
 class _MSDAQuerySide(torch.autograd.Function):
     """The query side of the pixel decoder's deformable self-attention as ONE autograd node:
 
@@ -689,41 +722,56 @@ class _MSDAQuerySide(torch.autograd.Function):
     (mask_bev_panoptic_head.py:127-136); replaces 3 GEMMs + 3 column sums + 9 element-wise launches per layer."""
 
     @staticmethod
-    def forward(ctx, x, pos, ref, wv, bv, wo, bo, wa, ba, heads, levels, points, shapes_host, shapes_t, level_start):
+    def forward(ctx, x, pos, ref, wv, bv, wo, bo, wa, ba, heads, levels, points, shapes_host, shapes_t, level_start,
+                share=None, share_index=0):
         lib = _lib.load()
+        ctx.share = (share, int(share_index))
         _need_gpu(x, pos, ref, wv, wo, wa)
         b, n, e = x.shape
         d = e // heads
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
         if dt not in _ACT_DTYPES:
             raise MaskBevHipError('msda_query_side supports f32, bf16 and fp16 compute')
+        lo, la = heads * levels * points * 2, heads * levels * points
         with torch.autocast('cuda', enabled=False):
             qb = torch.empty(x.shape, dtype=dt, device=x.device)
-            wvc, woc, wac = _compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)
+            # [Wv; Wo; Wa] (E + 2HLP + HLP, E) in the compute dtype, once: the backward's single data-gradient GEMM reads it
+            # whole, and its last two blocks make offsets and attention logits ONE projection of q here
+            wcat = torch.cat([_compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)], 0)
+            wvc = wcat[:e]
             pos_rows = pos.numel() // e
             if (dt in _LO_DTYPES and x.dtype == torch.float32 and pos.dtype == torch.float32 and x.is_contiguous()
                     and pos.is_contiguous() and e % 4 == 0 and (b * n) % pos_rows == 0):
                 xb = torch.empty(x.shape, dtype=dt, device=x.device)      # both 16-bit GEMM inputs in one pass over x
                 check(lib.mbv_msda_query_inputs(_ptr(x), _ptr(pos), b * n, pos_rows, e, _dt_flag(dt), _ptr(xb), _ptr(qb),
                                                 _stream()), 'mbv_msda_query_inputs')
-                # the value map is consumed in f32 (K5): accumulate and store it in f32, no 16-bit round trip + cast
-                value = torch.addmm(bv.float(), xb.view(b * n, e), wvc.t(), out_dtype=torch.float32).view(b, n, e)
+                # the value map is consumed in f32 (K5): accumulate and store it in f32, no 16-bit round trip + cast.  K17 takes
+                # the f32 bias in its epilogue (the library's addmm first copies the broadcast bias into the f32 result)
+                bvf = bv.float().contiguous()
+                if gemm16_policy() != 'none' and _gemm16_ok(xb.view(b * n, e), wvc) and bvf.data_ptr() % 16 == 0:
+                    value = gemm16_nt(xb.view(b * n, e), wvc, bvf, out_dtype=torch.float32).view(b, n, e)
+                else:
+                    value = torch.addmm(bvf, xb.view(b * n, e), wvc.t(), out_dtype=torch.float32).view(b, n, e)
             else:
                 xb = x.to(dt)
                 torch.add(x, pos, out=qb)                 # the sum, stored in the compute dtype by the same launch
                 value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
-            off = torch.nn.functional.linear(qb, woc, _compute_copy(bo, dt)).contiguous()
-            logit = torch.nn.functional.linear(qb, wac, _compute_copy(ba, dt)).contiguous()
+            # [offsets | logits] = q . [Wo; Wa]^T without the biases: K16 adds them in f32 on load
+            ol = torch.mm(qb.view(b * n, e), wcat[e:].t())
         host = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
         ref32 = ref.to(torch.float32).contiguous()
         loc = torch.empty((b, n, heads, levels, points, 2), dtype=torch.float32, device=x.device)
         attn = torch.empty((b, n, heads, levels, points), dtype=torch.float32, device=x.device)
-        check(lib.mbv_msda_prepare_fwd(_ptr(off), _ptr(logit), _dt_flag(dt), _ptr(ref32), host, b, n,
-                                       heads, levels, points, _ptr(loc), _ptr(attn), _stream()), 'mbv_msda_prepare_fwd')
+        esz = ol.element_size()
+        check(lib.mbv_msda_prepare_fwd_ld(_ptr(ol), lo + la, ctypes.c_void_p(ol.data_ptr() + lo * esz), lo + la,
+                                          _ptr(bo.float().contiguous()), _ptr(ba.float().contiguous()), _dt_flag(dt),
+                                          _ptr(ref32), host, b, n, heads, levels, points, _ptr(loc), _ptr(attn), _stream()),
+              'mbv_msda_prepare_fwd_ld')
+        del ol
         out = torch.empty((b, n, e), dtype=torch.float32, device=x.device)
         check(lib.mbv_ms_deform_attn_fwd(_ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, n,
                                          heads, d, levels, n, points, _ptr(out), _stream()), 'mbv_ms_deform_attn_fwd')
-        ctx.save_for_backward(xb, qb, value, loc, attn, shapes_t, level_start, wvc, woc, wac)
+        ctx.save_for_backward(xb, qb, value, loc, attn, shapes_t, level_start, wcat)
         ctx.params = (wv, bv, wo, bo, wa, ba)
         ctx.meta = (heads, levels, points, host, tuple(shapes_host), dt, x.dtype, pos.dtype, tuple(pos.shape))
         return out
@@ -731,7 +779,7 @@ class _MSDAQuerySide(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        xb, qb, value, loc, attn, shapes_t, level_start, wvc, woc, wac = ctx.saved_tensors
+        xb, qb, value, loc, attn, shapes_t, level_start, wcat = ctx.saved_tensors
         wv, bv, wo, bo, wa, ba = ctx.params
         heads, levels, points, host, shapes_host, dt, x_dtype, pos_dtype, pos_shape = ctx.meta
         b, n, e = xb.shape
@@ -761,18 +809,23 @@ class _MSDAQuerySide(torch.autograd.Function):
                                           _dt_flag(dt), ctypes.c_void_p(g.data_ptr() + e * esz), width,
                                           ctypes.c_void_p(g.data_ptr() + (e + lo) * esz), width, _stream()),
               'mbv_msda_prepare_bwd_ld')
-        wcat = torch.cat([wvc, woc, wac], 0)                              # (width, E)
         od = {} if dt == torch.float32 else dict(out_dtype=torch.float32)
         gx = gpos = None
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g, wcat, **od).view(b, n, e).to(x_dtype)
         if ctx.needs_input_grad[1]:                                       # pos is broadcast over the batch
             # (a 16-bit sum accumulates in f32 and rounds once on the way out: the same value as an f32 sum + cast, one launch)
-            gq_sum = g.view(b, n, width)[:, :, e:].sum(0) if dt in _LO_DTYPES else g.view(b, n, width)[:, :, e:].sum(0, dtype=torch.float32)
-            gpos = torch.mm(gq_sum, wcat[e:], **od).view(1, n, e)
-            if tuple(pos_shape) != (1, n, e):
-                gpos = gpos.sum_to_size(pos_shape) if len(pos_shape) == 3 else gpos.reshape(pos_shape)
-            gpos = gpos.to(pos_dtype)
+            share, share_index = ctx.share
+            if share is not None:
+                share.store(share_index, g.view(b, n, width)[:, :, e:], wcat[e:])
+                gpos = share.finish().view(1, n, e) if share_index == 0 else None
+            else:
+                gq_sum = g.view(b, n, width)[:, :, e:].sum(0) if dt in _LO_DTYPES else g.view(b, n, width)[:, :, e:].sum(0, dtype=torch.float32)
+                gpos = torch.mm(gq_sum, wcat[e:], **od).view(1, n, e)
+            if gpos is not None:
+                if tuple(pos_shape) != (1, n, e):
+                    gpos = gpos.sum_to_size(pos_shape) if len(pos_shape) == 3 else gpos.reshape(pos_shape)
+                gpos = gpos.to(pos_dtype)
         x2, q2 = xb.view(t, e), qb.view(t, e)
         cols = ((0, e, x2), (e, e + lo, q2), (e + lo, width, q2))
         grads = [None] * 6
@@ -814,17 +867,17 @@ class _MSDAQuerySide(torch.autograd.Function):
             for j, bia in enumerate((bv, bo, ba)):
                 if not deferred[j]:
                     _fire_grad_hooks(bia)
-        return (gx, gpos, None) + tuple(grads) + (None,) * 6
+        return (gx, gpos, None) + tuple(grads) + (None,) * 8
 
 
 def msda_query_side(x, pos, ref, value_proj, sampling_offsets, attention_weights, heads, levels, points, spatial_shapes,
-                    shapes_t, level_start):
+                    shapes_t, level_start, pos_share=None, pos_share_index=0):
     """x (B, N, E) f32, pos (1, N, E) → the deformable-attention output (B, N, E) f32 before ``output_proj``; the three
     ``nn.Linear`` modules supply the parameters (checkpoint keys unchanged).  See :class:`_MSDAQuerySide`."""
     host = tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDAQuerySide.apply(x, pos, ref, value_proj.weight, value_proj.bias, sampling_offsets.weight,
                                 sampling_offsets.bias, attention_weights.weight, attention_weights.bias, heads, levels,
-                                points, host, shapes_t, level_start)
+                                points, host, shapes_t, level_start, pos_share, pos_share_index)
 
 
 # --------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ _DEFAULTS: Dict[str, Any] = {
     'k17_fused_min': 4096,        # fewest tokens of an FFN that takes the fused K17 pair
     'ln_fanout': True,
     'conv1x1_tokens': True,
+    'pos_share': True,            # one d(pos) product for the pixel decoder's six layers (ops.PosGradShare)
     'msda_fused': True,
     'msda_packed': True,          # packed fixed-point value gradient in the 16-bit modes
     'k9_padded': True,

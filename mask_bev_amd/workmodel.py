@@ -259,6 +259,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_pfn_bwd_route': lambda a: _pfn(a, 'k_pfn_bwd_route', 3.0 if _i(a[7]) else 2.0, 4.0, 12, 13),
     'mbv_pfn_bwd_bn': lambda a: _pfn(a, 'k_pfn_bwd_bn', 3.0, 4.0, 12, 13),
     'mbv_msda_prepare_fwd': lambda a: _msda_prepare(a, False),
+    'mbv_msda_prepare_fwd_ld': lambda a: _msda_prepare((None, None) + tuple(a[6:7]) + (None, None) + tuple(a[9:14]), False),
     'mbv_msda_prepare_bwd': lambda a: _msda_prepare(a, True),
     'mbv_msda_prepare_bwd_ld': lambda a: _msda_prepare(a, True),
     'mbv_msda_query_inputs': lambda a: ('k_msda_query_inputs', 'hbm',

@@ -10,6 +10,7 @@ TRACE=$(find $P -name '*kernel_trace.csv' | head -1)
 STATS=$(find $P -name '*kernel_stats.csv' | head -1)
 PYTHONPATH=. python scratch/trace_agg.py $TRACE 45 > $P/agg.txt 2>&1
 cp $STATS $P/kernel_stats.csv
+PYTHONPATH=. python scratch/trace_seq.py $TRACE > $P/seq.txt 2>&1
 rm -f $TRACE
 find $P -name '*.db' -delete
 tail -75 $P/agg.txt
