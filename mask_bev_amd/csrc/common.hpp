@@ -43,6 +43,12 @@ typedef __bf16 lo16_t;
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
 
+// v_rcp_f32 / v_log_f32 as they are (1 ulp), for arguments known to be normal numbers away from 0: `1.0f / x`, `__frcp_rn` and
+// `__logf` compile to the IEEE division sequence (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) and to a logarithm
+// with denormal scaling — 10 and 8 issue slots that a VALU-bound epilogue pays per element.
+__device__ __forceinline__ float mbv_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float mbv_ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 static inline size_t mbv_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Zero / byte-fill device memory with a KERNEL.  hipMemsetAsync issued from inside this library was observed not

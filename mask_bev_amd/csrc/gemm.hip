@@ -208,7 +208,7 @@ __device__ __forceinline__ float gelu_cdf_parts(float z, float& dens) {
   // Phi(z) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 in erf), sharing exp(-z^2/2) with the density
   const float e = __expf(-0.5f * z * z);
   const float az = fabsf(z) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.f + 0.3275911f * az);
+  const float t = mbv_rcp(1.f + 0.3275911f * az);            // argument in [1, inf)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float half_tail = 0.5f * poly * e;
   dens = 0.3989422804014327f * e;

@@ -19,12 +19,12 @@ __device__ __forceinline__ void acc_point(float x, float t, float& s_it, float& 
   // launch against ≈ 70 us of HBM time): 1 + e lies in (1, 2], where v_log_f32 / v_rcp_f32 are good to ≈ 1e-7
   // absolute — invisible in sums of 12 544 O(1) terms
   const float e = __expf(-fabsf(x));                  // in (0, 1]
-  const float inv = __frcp_rn(1.0f + e);
+  const float inv = mbv_rcp(1.0f + e);
   const float sig = x >= 0.f ? inv : e * inv;
   s_it += sig * t;
   s_p += sig;
   s_t += t;
-  s_b += fmaxf(x, 0.f) - x * t + __logf(1.0f + e);
+  s_b += fmaxf(x, 0.f) - x * t + mbv_ln(1.0f + e);
 }
 
 __global__ void __launch_bounds__(kThreads) k_mask_loss_rows_fwd(const float* __restrict__ x, const float* __restrict__ t,
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(kThreads) k_mask_loss_rows_fwd(const float* __
 
 __device__ __forceinline__ float grad_point(float x, float t, float g0, float g1, float g3) {
   const float e = __expf(-fabsf(x));
-  const float inv = 1.0f / (1.0f + e);
+  const float inv = mbv_rcp(1.0f + e);                // argument in (1, 2]
   const float sig = x >= 0.f ? inv : e * inv;
   return sig * (1.0f - sig) * (g0 * t + g1) + g3 * (sig - t);
 }

@@ -296,7 +296,7 @@ __device__ __forceinline__ float act_grad(float z, float g) {
   // costs one exp, one rcp and a degree-5 Horner chain instead of libm's erff.
   const float e = __expf(-0.5f * z * z);
   const float az = fabsf(z) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.f + 0.3275911f * az);
+  const float t = mbv_rcp(1.f + 0.3275911f * az);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float half_tail = 0.5f * poly * e;                       // 0.5 erfc(|z| / sqrt 2)
   const float cdf = z >= 0.f ? 1.f - half_tail : half_tail;
