@@ -498,6 +498,12 @@ int64_t mbv_add_layernorm_bwd_blocks(int64_t rows, int32_t C);
 int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                           const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y, int32_t y_bf16,
                           float* mean, float* rstd, void* stream);
+/* Same forward with a second copy of y in another storage type (y2 nullable): a post-LN layer's output has two consumers
+ * — the next residual add takes it in f32, the branch GEMM that follows in 16 bits — and the cast launch between them goes.
+ * The two copies hold the same f32 value rounded to their types; their gradients return through dy / dy2 of the backward. */
+int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+                           const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y, int32_t y_bf16,
+                           void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream);
 int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
                           void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,

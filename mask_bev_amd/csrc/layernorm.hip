@@ -75,6 +75,8 @@ struct LnIo {
   void* y; int y_bf16;
   float* mean; float* rstd;
   MergeGeom mg;                      // mg.on: a is the f32 (B, H, W, C) map the rows are gathered from (b, s null)
+  void* y2; int y2_kind;             // optional second copy of y in another storage type (post-LN: f32 for the next residual
+                                     // add, 16 bits for the branch GEMM that follows): no cast launch in between
 };
 
 // ITERS float4 per lane: C <= 256 * ITERS, C % 4 == 0
@@ -129,6 +131,7 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(LnIo io, long rows, int C, f
       o.z = (x[i].z - mean) * rstd * g.z + be.z;
       o.w = (x[i].w - mean) * rstd * g.w + be.w;
       store4(io.y, io.y_bf16, base + 4 * v, o);
+      if (io.y2) store4(io.y2, io.y2_kind, base + 4 * v, o);
     }
   }
 }
@@ -330,16 +333,27 @@ static int add_ln_fwd_launch(const LnIo& io, int it, int64_t rows, int32_t C, fl
   return MBV_OK;
 }
 
+extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
+                                      int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream);
+
 extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
                                      int32_t y_bf16, float* mean, float* rstd, void* stream) {
+  return mbv_add_layernorm_fwd2(a, a_bf16, b, b_bf16, gamma, beta, rows, C, eps, sum_out, y, y_bf16, nullptr, 0, mean, rstd,
+                                stream);
+}
+
+extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
+                                      int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream) {
   const int it = C <= 2048 ? iters_for(C) : 0;
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
   if (rows == 0) return MBV_OK;
   if (!a || !gamma || !beta || !y || !mean || !rstd) return MBV_ERR_BAD_ARG;
   if (!sum_out && (b || a_bf16)) return MBV_ERR_BAD_ARG;       // the backward needs the f32 LN input
-  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd, MergeGeom{}};
+  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd, MergeGeom{}, y2, y2_dtype};
   return add_ln_fwd_launch(io, it, rows, C, eps, (hipStream_t)stream);
 }
 

@@ -39,9 +39,12 @@ class LayerNorm(nn.LayerNorm):
     returns ``(y, y')``, the same values for two consumers (post-LN: the next residual add and the next branch)."""
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, gemm_input: bool = False,
-                return_sum: bool = False, residual_bias: Optional[torch.Tensor] = None, fanout: bool = False):
+                return_sum: bool = False, residual_bias: Optional[torch.Tensor] = None, fanout: bool = False,
+                branch_gemm: bool = False):
         """``residual_bias``: the bias Parameter of the Linear that produced ``residual`` when that layer was run with
-        ``skip_bias_grad=True`` — its gradient (the column sums of d(residual)) is accumulated by this op."""
+        ``skip_bias_grad=True`` — its gradient (the column sums of d(residual)) is accumulated by this op.
+        ``branch_gemm`` (with ``fanout``): the second tensor only feeds GEMM layers — under 16-bit autocast it is written in
+        the autocast dtype by the same launch."""
         c = x.shape[-1]
         if (x.is_cuda and len(self.normalized_shape) == 1 and self.weight is not None and self.bias is not None
                 and ops.add_layernorm_supported(c) and x.dtype in ops._ACT_DTYPES
@@ -53,8 +56,12 @@ class LayerNorm(nn.LayerNorm):
             if fanout and not switches.get('ln_fanout'):
                 y = ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, branch_bias=residual_bias)
                 return y, y
+            branch_dtype = None
+            if (fanout and branch_gemm and torch.is_autocast_enabled('cuda')
+                    and torch.get_autocast_dtype('cuda') in ops._LO_DTYPES and switches.get('ln_branch_lowp')):
+                branch_dtype = torch.get_autocast_dtype('cuda')
             return ops.add_layernorm(x, residual, self.weight, self.bias, self.eps, out_dtype, return_sum,
-                                     branch_bias=residual_bias, fanout=fanout)
+                                     branch_bias=residual_bias, fanout=fanout, branch_dtype=branch_dtype)
         if residual_bias is not None:
             residual = ops.accumulate_bias_grad(residual, residual_bias)      # the deferred gradient must not be lost
         s = x if residual is None else x + residual

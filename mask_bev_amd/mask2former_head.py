@@ -41,7 +41,7 @@ class _DeformEncoderLayer(nn.Module):
         q_branch = q if q_branch is None else q_branch
         q, qb = self.norms[0](q, self.self_attn(q_branch, pos, ref, shapes, shapes_t, level_start, add_identity=False,
                                                 defer_out_bias=d1, pos_share=pos_share, pos_share_index=pos_share_index),
-                              residual_bias=ob if d1 else None, fanout=True)
+                              residual_bias=ob if d1 else None, fanout=True, branch_gemm=True)
         return self.norms[1](q, self.ffn(qb, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None,
                              fanout=fanout)
 

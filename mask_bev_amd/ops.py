@@ -2291,7 +2291,7 @@ def add_layernorm_supported(channels: int) -> bool:
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, weight, bias, eps, out_dtype, branch_bias=None, fanout=False):
+    def forward(ctx, a, b, weight, bias, eps, out_dtype, branch_bias=None, fanout=False, branch_dtype=None):
         lib = _lib.load()
         _need_gpu(a, b, weight, bias)
         ctx.branch_bias = branch_bias
@@ -2312,16 +2312,25 @@ class _AddLayerNorm(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=a.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
         w, bb = weight.contiguous(), bias.contiguous()
-        check(lib.mbv_add_layernorm_fwd(_ptr(a2), _dt_flag(a2.dtype), _ptr(b2),
-                                        (_dt_flag(b2.dtype) if b2 is not None else 0), _ptr(w), _ptr(bb), rows, c,
-                                        float(eps), _ptr(s), _ptr(y), _dt_flag(out_dtype), _ptr(mean),
-                                        _ptr(rstd), _stream()), 'mbv_add_layernorm_fwd')
+        # fanout with a branch dtype: the branch consumer's copy of y is written in ITS storage type by the same launch
+        y_branch = None
+        if fanout and branch_dtype is not None and branch_dtype != out_dtype:
+            if branch_dtype not in ok:
+                raise MaskBevHipError('add_layernorm: branch dtype must be f32, bf16 or fp16')
+            y_branch = torch.empty(a2.shape, dtype=branch_dtype, device=a.device)
+        check(lib.mbv_add_layernorm_fwd2(_ptr(a2), _dt_flag(a2.dtype), _ptr(b2),
+                                         (_dt_flag(b2.dtype) if b2 is not None else 0), _ptr(w), _ptr(bb), rows, c,
+                                         float(eps), _ptr(s), _ptr(y), _dt_flag(out_dtype), _ptr(y_branch),
+                                         _dt_flag(branch_dtype) if y_branch is not None else 0, _ptr(mean),
+                                         _ptr(rstd), _stream()), 'mbv_add_layernorm_fwd2')
         ctx.save_for_backward(a2 if s is None else s, mean, rstd, w)
         ctx.weight, ctx.bias = weight, bias
         ctx.dtypes = (a.dtype, None if b is None else b.dtype)
         ctx.set_materialize_grads(False)
         # fanout: y leaves as two tensors over one buffer — one per consumer (the next residual add, the next branch) — so
         # that their gradients come back separately and K12's backward adds them on load (no autograd add launch)
+        if y_branch is not None:
+            return y, s, y_branch
         return y, s, (y.view_as(y) if fanout else None)   # s is None for a lone f32 input (it IS the input)
 
     @staticmethod
@@ -2340,7 +2349,7 @@ class _AddLayerNorm(torch.autograd.Function):
                 _fire_grad_hooks(bb)
             ga = None if gs is None else gs.to(da)
             gb = None if (gs is None or db is None) else gs.to(db)
-            return ga, gb, None, None, None, None, None, None
+            return ga, gb, None, None, None, None, None, None, None
         c = s.shape[-1]
         rows = s.numel() // c
         gy = gy.contiguous()
@@ -2394,7 +2403,7 @@ class _AddLayerNorm(torch.autograd.Function):
             dgamma, dbeta = dgamma.to(weight.dtype), dbeta.to(bias.dtype)
         ga = dx_lo if da in _LO_DTYPES else dx
         gb = None if db is None else (dx_lo if db in _LO_DTYPES else dx)
-        return ga, gb, dgamma, dbeta, None, None, None, None
+        return ga, gb, dgamma, dbeta, None, None, None, None, None
 
 
 class _BiasAct(torch.autograd.Function):
@@ -2470,16 +2479,18 @@ def bias_grad_deferrable(bias: Optional[torch.Tensor], channels: int) -> bool:
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor,
                   eps: float = 1e-5, out_dtype: Optional[torch.dtype] = None, return_sum: bool = False,
-                  branch_bias: Optional[torch.Tensor] = None, fanout: bool = False):
+                  branch_bias: Optional[torch.Tensor] = None, fanout: bool = False,
+                  branch_dtype: Optional[torch.dtype] = None):
     """``y = LayerNorm_C(a + b)`` over the last axis in one pass (K12); ``b=None`` is a plain LayerNorm.
     ``out_dtype`` (default: the autocast dtype when autocast is on and the consumer is a GEMM — pass it explicitly —
     else f32) is the storage type of y; statistics and the sum are f32.  With ``return_sum`` the f32 sum ``a + b``
     (the new residual stream of a pre-LN block) is returned as well: ``(y, s)``.  ``fanout`` (post-LN layers, instead
     of ``return_sum``): returns ``(y, y')`` — the same values as two tensors, one for each of y's two consumers, whose
-    gradients the backward kernel then adds on load instead of autograd adding them with a launch of its own."""
+    gradients the backward kernel then adds on load instead of autograd adding them with a launch of its own; with
+    ``branch_dtype`` y' is stored in that type (the 16-bit input of the branch GEMM) by the same launch."""
     if out_dtype is None:
         out_dtype = torch.float32
-    y, s, y2 = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias, fanout)
+    y, s, y2 = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias, fanout, branch_dtype)
     if fanout:
         return y, y2
     return (y, a if s is None else s) if return_sum else y

@@ -152,6 +152,13 @@ def _add_ln(a, bwd: bool) -> Work:
     return ('k_add_ln_fwd', 'hbm', by, 0.0)
 
 
+def _add_ln_fwd2(a) -> Work:
+    """mbv_add_layernorm_fwd2: as the forward, plus the second copy of y."""
+    name, bound, by, fl = _add_ln(tuple(a[:12]) + tuple(a[14:]), False)
+    rows, c = _i(a[6]), _i(a[7])
+    return (name, bound, by + (rows * c * (2 if _i(a[13]) else 4) if _i(a[12]) else 0), fl)
+
+
 def _add_ln_bwd2(a) -> Work:
     """mbv_add_layernorm_bwd2: dy (+ dy2) (+ ds) and the f32 sum read, dx (+ its 16-bit copy) written."""
     rows, c = _i(a[10]), _i(a[11])
@@ -291,6 +298,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_gemm16_nn': lambda a: _gemm16(a, 'nn'),
     'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
+    'mbv_add_layernorm_fwd2': lambda a: _add_ln_fwd2(a),
     'mbv_add_layernorm_bwd': lambda a: _add_ln(a, True),
     'mbv_add_layernorm_bwd2': lambda a: _add_ln_bwd2(a),
     # importance sampling: every row's (H, W) f32 map is read once; the 3x over-sampled candidates never touch HBM

@@ -186,3 +186,34 @@ def test_add_layernorm_fanout_adds_the_two_gradients_on_load(device, shape, dt2)
     ar2 = a.detach().double().requires_grad_()
     (F.layer_norm(ar2 + b.detach().double(), (c,), w.detach().double(), bias.detach().double(), 1e-5) * g1.double()).sum().backward()
     assert close(a2.grad, ar2.grad, 3e-5)
+
+
+@pytest.mark.parametrize('shape,dt2', [((4, 5376, 256), torch.bfloat16), ((300, 192), torch.float16), ((37, 768), torch.bfloat16)])
+def test_add_layernorm_fanout_branch_copy_in_16_bits(device, shape, dt2):
+    """``fanout`` with ``branch_dtype`` (mbv_add_layernorm_fwd2): the branch consumer's copy of y is written in 16 bits by the
+    same launch — the f32 y rounded to nearest, a tensor of its own — and its 16-bit gradient is added to the f32 one on
+    load by the backward kernel; against F.layer_norm in f64."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    c = shape[-1]
+    a = (torch.randn(shape, generator=g) * 2 + 0.5).to(device).requires_grad_()
+    b = torch.randn(shape, generator=g).to(device).requires_grad_()
+    w = (torch.rand(c, generator=g) + 0.5).to(device).requires_grad_()
+    bias = torch.randn(c, generator=g).to(device).requires_grad_()
+    g1 = torch.randn(shape, generator=g).to(device)
+    g2 = torch.randn(shape, generator=g).to(device).to(dt2)
+    ar, br, wr, biasr = (t.detach().double().requires_grad_() for t in (a, b, w, bias))
+    yr = F.layer_norm(ar + br, (c,), wr, biasr, 1e-5)
+    (yr * (g1.double() + g2.double())).sum().backward()
+    y, y2 = ops.add_layernorm(a, b, w, bias, 1e-5, torch.float32, fanout=True, branch_dtype=dt2)
+    assert y.dtype == torch.float32 and y2.dtype == dt2 and y.data_ptr() != y2.data_ptr()
+    assert torch.equal(y2, y.to(dt2))
+    assert torch.allclose(y.double(), yr, rtol=2e-5, atol=2e-5)
+    torch.autograd.backward([y, y2], [g1, g2])
+
+    def close(got, want, t):
+        return float((got.double() - want).abs().max()) <= t * (float(want.abs().max()) + 1e-12)
+
+    for got, want in ((a.grad, ar.grad), (b.grad, br.grad)):
+        assert close(got, want, 3e-5)
+    assert close(w.grad, wr.grad, 1e-4) and close(bias.grad, biasr.grad, 1e-4)
