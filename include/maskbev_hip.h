@@ -312,6 +312,15 @@ int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const 
                          const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
                          int64_t num_src_maps, float* grad_src, void* stream);
 
+/* The same backward for a STACK of maps, (outer, inner, rows) of them, each sampled exactly once (num_rows == outer * inner *
+ * rows, H*W <= 16384): the gradient of map (o, n, r) is stored at row (n, o, r) of grad_src — the two leading axes exchanged
+ * — in f32, bf16 or fp16 (out_dtype).  The stacked mask logits of the D decoder outputs, (D, B, Q, H, W), hand their
+ * gradient to the batched backward of the prediction heads sample-major and in the GEMM's operand type: no permute + cast
+ * pass over the 262 MB gradient (mask2former_head.py:406-424 → :459). */
+int mbv_point_sample_bwd_stack(const float* grad_out, const int32_t* src_index, const float* coords,
+                               const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H, int32_t W,
+                               int32_t outer, int32_t inner, int32_t rows, void* grad_src, int32_t out_dtype, void* stream);
+
 /* Binary ({0, 1}-valued) maps packed 32 pixels per word, and K8's forward on the packed form: a whole
  * 512 x 512 ground-truth mask is 32 KB and is staged in LDS by the workgroup that samples it.
  * The batch contract of the reference makes GT masks float32 {0, 1}

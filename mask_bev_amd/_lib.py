@@ -66,6 +66,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_window_attn_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
     'mbv_point_sample_fwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'mbv_point_sample_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P]),
+    'mbv_point_sample_bwd_stack': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     'mbv_hungarian': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),
     'mbv_hungarian_padded': (ctypes.c_int, [_P, _I, _I, _I, _P, _P, _P]),
     'mbv_hungarian_wide_t': (ctypes.c_int, [_P, _I, _I, _I, _P, _P]),

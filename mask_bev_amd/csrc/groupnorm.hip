@@ -43,8 +43,8 @@ __device__ __forceinline__ void st4(void* base, int kind, long elem, float4 v) {
   }
   uint2 u;
   if (kind == MBV_DT_BF16) {
-    u.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
-    u.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+    u.x = pack_bf16x2(v.x, v.y);
+    u.y = pack_bf16x2(v.z, v.w);
   } else {
     u.x = f32_to_h16(v.x) | (f32_to_h16(v.y) << 16);
     u.y = f32_to_h16(v.z) | (f32_to_h16(v.w) << 16);

@@ -61,8 +61,8 @@ __device__ __forceinline__ void st4<float>(float* p, const float* v) {
 template <>
 __device__ __forceinline__ void st4<unsigned short>(unsigned short* p, const float* v) {
   uint2 u;
-  u.x = (unsigned)f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
-  u.y = (unsigned)f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = u;
 }
 

@@ -275,8 +275,8 @@ __device__ __forceinline__ void store4t<float>(float* p, float4 v) { *reinterpre
 template <>
 __device__ __forceinline__ void store4t<unsigned short>(unsigned short* p, float4 v) {
   uint2 u;
-  u.x = (unsigned)f32_to_bf16_rne(v.x) | ((unsigned)f32_to_bf16_rne(v.y) << 16);
-  u.y = (unsigned)f32_to_bf16_rne(v.z) | ((unsigned)f32_to_bf16_rne(v.w) << 16);
+  u.x = pack_bf16x2(v.x, v.y);
+  u.y = pack_bf16x2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = u;
 }
 

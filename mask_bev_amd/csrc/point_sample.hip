@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
                                                                const int32_t* __restrict__ src_index,
                                                                const float* __restrict__ coords,
                                                                const int32_t* __restrict__ coord_index, int P, int H,
-                                                               int W, float* __restrict__ grad_src) {
+                                                               int W, void* __restrict__ grad_src, int out_kind,
+                                                               int perm_outer, int perm_inner, int perm_rows) {
   // f64 accumulators: on gfx950 an LDS ds_add_f32 wave instruction takes ≈ 192 cycles (the lanes are serialised),
   // ds_add_f64 / ds_add_u64 ≈ 9-16 (scratch/ubench/lds_atomic.hip) — the f32 form of this kernel ran 1.0 ms, bound
   // by exactly that.  128 KB for a 128 x 128 map; the sum is also order-independent to f32 precision.
@@ -218,12 +219,36 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
     }
   }
   __syncthreads();
-  float* dst = grad_src + (int64_t)src_index[g] * hw;
+  // destination row: the source map's own, or — perm_outer > 0 — with its two leading axes exchanged: map
+  // (o, n, r) of an (outer, inner, rows) stack goes to row (n, o, r) (the stacked decoder outputs (D, B, Q) stored sample-major)
+  int64_t row = src_index[g];
+  if (perm_outer > 0) {
+    const int64_t r = row % perm_rows, on = row / perm_rows;
+    const int64_t o = on / perm_inner, n = on - o * perm_inner;
+    row = (n * perm_outer + o) * perm_rows + r;
+  }
+  if (out_kind == MBV_DT_F32) {
+    float* dst = reinterpret_cast<float*>(grad_src) + row * hw;
+    if ((hw & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(dst + i) = make_float4((float)tile[i], (float)tile[i + 1], (float)tile[i + 2], (float)tile[i + 3]);
+    } else {
+      for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (float)tile[i];
+    }
+    return;
+  }
+  unsigned short* dst = reinterpret_cast<unsigned short*>(grad_src) + row * hw;
+  auto lo2 = [&](double a, double b2) -> unsigned {
+    const float x = (float)a, y = (float)b2;
+    if (out_kind == MBV_DT_F16)
+      return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)y) << 16);
+    return pack_bf16x2(x, y);
+  };
   if ((hw & 3) == 0) {
     for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
-      *reinterpret_cast<float4*>(dst + i) = make_float4((float)tile[i], (float)tile[i + 1], (float)tile[i + 2], (float)tile[i + 3]);
+      *reinterpret_cast<uint2*>(dst + i) = make_uint2(lo2(tile[i], tile[i + 1]), lo2(tile[i + 2], tile[i + 3]));
   } else {
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (float)tile[i];
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (unsigned short)(lo2(tile[i], 0.0) & 0xffffu);
   }
 }
 
@@ -308,6 +333,23 @@ extern "C" int mbv_point_sample_packed_fwd(const uint32_t* packed, const int32_t
   return MBV_OK;
 }
 
+extern "C" int mbv_point_sample_bwd_stack(const float* grad_out, const int32_t* src_index, const float* coords,
+                                          const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H,
+                                          int32_t W, int32_t outer, int32_t inner, int32_t rows, void* grad_src,
+                                          int32_t out_dtype, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_rows <= 0 || num_points <= 0 || H <= 0 || W <= 0 || outer <= 0 || inner <= 0 || rows <= 0) return MBV_ERR_BAD_ARG;
+  if (!grad_out || !src_index || !coords || !coord_index || !grad_src) return MBV_ERR_BAD_ARG;
+  if (out_dtype != MBV_DT_F32 && out_dtype != MBV_DT_BF16 && out_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
+  // every map of the stack is sampled exactly once (no zero fill), in the LDS-tile form
+  if ((int64_t)num_rows != (int64_t)outer * inner * rows || num_rows > 65535 || (int64_t)H * W > kTileFloats)
+    return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3(num_rows), dim3(1024), 0, stream, grad_out, src_index, coords,
+                     coord_index, num_points, H, W, grad_src, out_dtype, outer, inner, rows);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
 extern "C" int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_index, const float* coords,
                                     const int32_t* coord_index, int32_t num_rows, int32_t num_points, int32_t H,
                                     int32_t W, int64_t num_src_maps, float* grad_src, void* stream_) {
@@ -324,7 +366,7 @@ extern "C" int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_in
   if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;
   if (lds_form) {
     hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3(num_rows), dim3(1024), 0, stream, grad_out, src_index, coords,
-                       coord_index, num_points, H, W, grad_src);
+                       coord_index, num_points, H, W, grad_src, MBV_DT_F32, 0, 0, 0);
   } else {
     hipLaunchKernelGGL(k_point_sample_bwd_atomic, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream,
                        grad_out, src_index, coords, coord_index, num_points, H, W, grad_src);

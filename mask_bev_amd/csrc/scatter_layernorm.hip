@@ -186,7 +186,7 @@ __device__ __forceinline__ unsigned pack_lo2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) |
            ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
   else
-    return (unsigned)f32_to_bf16_rne(a) | ((unsigned)f32_to_bf16_rne(b) << 16);
+    return pack_bf16x2(a, b);
 }
 template <int KIND>
 __device__ __forceinline__ void unpack_lo2(unsigned u, float& a, float& b) {

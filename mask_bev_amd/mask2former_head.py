@@ -269,6 +269,17 @@ class _DeferredHeads(torch.autograd.Function):
         hh, ww = mask_feature.shape[-2:]
         hw = hh * ww
         dt = mask_feature.dtype
+        # K8's backward may have left the gradient sample-major in the operand type already (ops.StackGradSink): then what
+        # arrives here are views of the sink's token; anything else means other gradients were added — ordinary path, plus
+        # the sink's share
+        sink = getattr(head, '_stack_sink', None)
+        sunk = None
+        if sink is not None and sink.grad is not None:
+            sunk, sink.grad = sink.grad, None
+            if sunk.dtype != dt or tuple(sunk.shape) != (b, nd, q, hw):
+                raise ops.MaskBevHipError('deferred heads: the stacked gradient sink holds another layout')
+        if sunk is not None and all(sink.is_token(g) for g in d_masks):
+            return _DeferredHeads._finish(ctx, d_cls, sunk.view(b, nd * q, hw))
         # stacked logit gradient (D, B, Q, H, W): the slices handed back by ops.stack_slices are views of one buffer
         g0 = d_masks[0]
         full = None
@@ -288,7 +299,19 @@ class _DeferredHeads(torch.autograd.Function):
             full = torch.stack(parts, 0).view(nd, b, q, hw)
         dl = torch.empty((b, nd, q, hw), dtype=dt, device=full.device)       # per sample: D*Q rows, one cast+permute
         dl.copy_(full.permute(1, 0, 2, 3))
-        dl = dl.view(b, nd * q, hw)
+        if sunk is not None:
+            dl += sunk
+        return _DeferredHeads._finish(ctx, d_cls, dl.view(b, nd * q, hw))
+
+    @staticmethod
+    def _finish(ctx, d_cls, dl):
+        """dl (B, D*Q, H*W): the stacked logit gradient, sample-major, in the mask features' dtype."""
+        head, nd = ctx.head, ctx.nd
+        mask_feature, *query_feats = ctx.saved_tensors
+        b, q, c = query_feats[0].shape
+        hh, ww = mask_feature.shape[-2:]
+        hw = hh * ww
+        dt = mask_feature.dtype
         # re-evaluate the small head on all D*B*Q rows with a graph, in the per-layer forward's precision
         # (the row-chain decoder evaluates its heads with 16-bit operands whatever the row count: so does this)
         small = b * q * c <= ops._SMALL_F32_ROWS * c and not getattr(head, '_deferred_lowp_heads', False)
@@ -299,7 +322,7 @@ class _DeferredHeads(torch.autograd.Function):
             y = head.transformer_decoder.post_norm(q_all)
             cls_re = head.cls_embed(y)
             e_re = head.mask_embed(y)                                                      # (D, B, Q, C)
-        e_b = torch.empty((b, nd, q, c), dtype=dt, device=full.device)
+        e_b = torch.empty((b, nd, q, c), dtype=dt, device=dl.device)
         e_b.copy_(e_re.detach().permute(1, 0, 2, 3))
         e_b = e_b.view(b, nd * q, c)
         ff = mask_feature.reshape(b, c, hw)
@@ -423,9 +446,13 @@ class Mask2FormerHead(nn.Module):
         stack = torch.empty((nd, bs, self.num_queries) + tuple(mask_features.shape[-2:]), dtype=torch.float32,
                             device=mask_features.device) if mask_features.is_cuda else None
         self._mask_stack = stack
+        self._stack_sink = None
         # training on the GPU: the heads run layer by layer WITHOUT a graph and get one batched backward (_DeferredHeads)
         deferred = (stack is not None and self.training and torch.is_grad_enabled()
                     and switches.get('deferred_heads'))
+        if deferred and switches.get('stack_grad_sink'):
+            # K8's backward writes the stacked logit gradient where and how _DeferredHeads reads it (ops.StackGradSink)
+            self._stack_sink = ops.StackGradSink(nd, bs, self.num_queries, mask_features.dtype, mask_features.device)
         feats_q = [query_feat]
 
         def heads(qf, size, slot):
@@ -720,6 +747,7 @@ class Mask2FormerHead(nn.Module):
         eps = torch.finfo(torch.float32).eps
         cls = torch.stack([c.float() for c in all_cls_scores], 0)                                # (D, B, Q, K+1)
         stacked = ops.stack_slices(getattr(self, '_mask_stack', None), list(all_mask_preds))
+        stack_is_buffer = stacked is not None
         if stacked is None:
             stacked = torch.stack([mk.float() for mk in all_mask_preds], 0)
         masks_flat = stacked.flatten(0, 2)                                                       # (D*B*Q, H, W)
@@ -785,7 +813,9 @@ class Mask2FormerHead(nn.Module):
                                                      num_candidates=int(p * self.oversample_ratio))
             else:
                 coords = ops.sample_select_uncertain(masks_flat.detach(), pred_index, over_c, n_unc, rand_c)
-        pred = ops.point_sample(masks_flat, pred_index, coords, rows)                            # (D*g, P), grads
+        # (the sink applies when the stack IS the heads' buffer and every map is sampled: all queries matched)
+        sink = getattr(self, '_stack_sink', None) if (stack_is_buffer and m == nq) else None
+        pred = ops.point_sample(masks_flat, pred_index, coords, rows, grad_sink=sink)            # (D*g, P), grads
         if overlap:                                     # join the matcher
             main.wait_stream(side)
             matched = assigned >= 0

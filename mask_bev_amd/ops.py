@@ -1982,11 +1982,30 @@ TEACHER: dict = {}
 # --------------------------------------------------------------------------------------
 # K8 indexed bilinear point sampling (loss / matcher)
 # --------------------------------------------------------------------------------------
+class StackGradSink:
+    """Side channel for the gradient of the stacked mask logits (D, B, Q, H, W).  Autograd requires that gradient in the
+    stack's own shape and type — f32, decoder-output-major — while its only consumer, the batched backward of the
+    prediction heads (mask2former_head._DeferredHeads), wants it sample-major in the GEMM operand type: a 262 MB permute +
+    cast pass.  With a sink armed, K8's backward stores the gradient in THAT form here and hands autograd a zero-stride
+    token of the required shape; the consumer checks that what reached it is the token (nothing else contributed a
+    gradient) and takes ``grad``; otherwise it finds ``grad`` unset or the token replaced and uses the ordinary tensors."""
+
+    def __init__(self, outer: int, inner: int, rows: int, dtype: torch.dtype, device):
+        self.dims = (int(outer), int(inner), int(rows))
+        self.dtype = dtype
+        self.token = torch.zeros((), dtype=torch.float32, device=device)
+        self.grad = None            # (inner, outer, rows, H*W) in `dtype`, written by K8's backward
+
+    def is_token(self, g) -> bool:
+        return (g is not None and g.data_ptr() == self.token.data_ptr() and all(s == 0 for s in g.stride()))
+
+
 class _PointSample(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, src, src_index, coords, coord_index):
+    def forward(ctx, src, src_index, coords, coord_index, sink=None):
         lib = _lib.load()
+        ctx.sink = sink
         _need_gpu(src, src_index, coords, coord_index)
         src, coords = src.contiguous(), coords.contiguous()
         n_src, h, w = src.shape
@@ -2009,23 +2028,33 @@ class _PointSample(torch.autograd.Function):
         n_src, h, w = ctx.dims
         grad_out = grad_out.to(torch.float32).contiguous()
         g, p = grad_out.shape
-        g_src = torch.empty((n_src, h, w), dtype=torch.float32, device=grad_out.device)
         _lib.WORK_HINT['point_sample'] = (int(n_src), int(coords.shape[0]))
+        sink = ctx.sink
+        if sink is not None:
+            o, n, r = sink.dims
+            if g == n_src == o * n * r and g <= 65535 and h * w <= 16384:
+                sink.grad = torch.empty((n, o, r, h * w), dtype=sink.dtype, device=grad_out.device)
+                check(lib.mbv_point_sample_bwd_stack(_ptr(grad_out), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p,
+                                                     h, w, o, n, r, _ptr(sink.grad), _dt_flag(sink.dtype), _stream()),
+                      'mbv_point_sample_bwd_stack')
+                return sink.token.expand(n_src, h, w), None, None, None, None
+        g_src = torch.empty((n_src, h, w), dtype=torch.float32, device=grad_out.device)
         rc = lib.mbv_point_sample_bwd(_ptr(grad_out), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p, h, w, n_src,
                                       _ptr(g_src), _stream())
         check(rc, 'mbv_point_sample_bwd')
-        return g_src, None, None, None
+        return g_src, None, None, None, None
 
 
 def point_sample(src: torch.Tensor, src_index: torch.Tensor, coords: torch.Tensor,
-                 coord_index: torch.Tensor) -> torch.Tensor:
+                 coord_index: torch.Tensor, grad_sink: Optional[StackGradSink] = None) -> torch.Tensor:
     """out[g, p] = bilinear(src[src_index[g]], coords[coord_index[g], p]) — mmcv ``point_sample`` semantics
     (grid_sample at 2p-1, align_corners=False, zero padding) without gathering the maps first (K8).
-    src (N, H, W); indices int32 (G,), ``src_index`` without duplicates; coords (*, P, 2) in [0, 1] as (x, y)."""
+    src (N, H, W); indices int32 (G,), ``src_index`` without duplicates; coords (*, P, 2) in [0, 1] as (x, y).
+    ``grad_sink``: see :class:`StackGradSink` (src is then a stack of which every map is sampled)."""
     src, coords = src.float(), coords.float()
     n = int(src_index.shape[0])
     if n <= 65535:
-        return _PointSample.apply(src, src_index, coords, coord_index)
+        return _PointSample.apply(src, src_index, coords, coord_index, grad_sink)
     return torch.cat([_PointSample.apply(src, src_index[i:i + 65535], coords, coord_index[i:i + 65535])
                       for i in range(0, n, 65535)], 0)
 

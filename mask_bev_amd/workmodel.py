@@ -312,6 +312,9 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_point_sample_fwd': lambda a: _point_sample(a, 'k_point_sample_fwd_lds', 4.0),
     'mbv_point_sample_bwd': lambda a: ('k_point_sample_bwd_lds', 'hbm',
                                        _i(a[8]) * _i(a[6]) * _i(a[7]) * 4.0 + _point_rows(_i(a[4]), _i(a[5])), 0.0),
+    'mbv_point_sample_bwd_stack': lambda a: ('k_point_sample_bwd_lds', 'hbm',
+                                             _i(a[4]) * _i(a[6]) * _i(a[7]) * (4.0 if _i(a[12]) == 0 else 2.0)
+                                             + _point_rows(_i(a[4]), _i(a[5])), 0.0),
     'mbv_point_sample_packed_fwd': lambda a: _point_sample(a, 'k_point_sample_packed', 1.0 / 8.0),
     'mbv_mask_loss_rows_fwd': lambda a: ('k_mask_loss_rows_fwd', 'hbm', _i(a[2]) * _i(a[3]) * 8.0, 0.0),
     'mbv_mask_loss_rows_bwd': lambda a: ('k_mask_loss_rows_bwd', 'hbm', _i(a[3]) * _i(a[4]) * 12.0, 0.0),

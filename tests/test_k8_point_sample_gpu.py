@@ -75,3 +75,32 @@ def test_pack_binary_masks_bits(device, H, W):
     padded[:, :H * W] = bits
     want = (padded.reshape(5, nw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
     assert np.array_equal(words, want)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+def test_stack_gradient_sink_equals_permute_and_cast(device, dt):
+    """mbv_point_sample_bwd_stack (ops.StackGradSink): the gradient of a (D, B, Q, H, W) stack of which every map is sampled
+    once, stored sample-major (B, D, Q, H*W) in f32 / bf16 / fp16 by K8's backward itself — equal to the ordinary f32
+    gradient permuted and rounded; autograd receives a zero-stride token of the stack's shape."""
+    from mask_bev_amd import ops
+    g = torch.Generator().manual_seed(17)
+    d, b, q, h, w, p = 3, 2, 5, 16, 24, 64
+    n = d * b * q
+    src = torch.randn(n, h, w, generator=g).to(device).requires_grad_()
+    idx = torch.randperm(n, generator=g).to(torch.int32).to(device)          # every map once, any order
+    coords = torch.rand(d * b, p, 2, generator=g).to(device)
+    cidx = (idx // q).to(torch.int32)
+    gout = torch.randn(n, p, generator=g).to(device)
+    (ops.point_sample(src, idx, coords, cidx) * gout).sum().backward()
+    want = src.grad.view(d, b, q, h * w).permute(1, 0, 2, 3).to(dt)
+    src2 = src.detach().clone().requires_grad_()
+    sink = ops.StackGradSink(d, b, q, dt, device)
+    (ops.point_sample(src2, idx, coords, cidx, grad_sink=sink) * gout).sum().backward()
+    assert sink.grad is not None and sink.grad.dtype == dt and tuple(sink.grad.shape) == (b, d, q, h * w)
+    assert torch.equal(sink.grad, want)
+    assert float(src2.grad.abs().max()) == 0.0            # the token: zeros of the stack's shape
+    # a subset of the maps: the sink does not apply, the ordinary gradient is returned
+    src3 = src.detach().clone().requires_grad_()
+    sink3 = ops.StackGradSink(d, b, q, dt, device)
+    (ops.point_sample(src3, idx[:7], coords, cidx[:7], grad_sink=sink3) * gout[:7]).sum().backward()
+    assert sink3.grad is None and float(src3.grad.abs().max()) > 0.0
