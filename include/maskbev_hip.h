@@ -509,10 +509,18 @@ int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t 
                           float* mean, float* rstd, void* stream);
 /* Same forward with a second copy of y in another storage type (y2 nullable): a post-LN layer's output has two consumers
  * — the next residual add takes it in f32, the branch GEMM that follows in 16 bits — and the cast launch between them goes.
- * The two copies hold the same f32 value rounded to their types; their gradients return through dy / dy2 of the backward. */
-int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
+ * The two copies hold the same f32 value rounded to their types; their gradients return through dy / dy2 of the backward.
+ * b_rows > 0 (a divisor of rows): b has only b_rows rows and repeats — a per-sample map added to every sample of the batch
+ * (the gradient of such a b is the batch sum of dx: the caller's to take).  0 or rows: b has `rows` rows. */
+int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, int64_t b_rows, const float* gamma,
                            const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y, int32_t y_bf16,
                            void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream);
+
+/* acc (C, R) f32 += the batch sum of g (batch, R, C) f32, transposed: the gradient of a per-sample token map that was added to
+ * every sample, accumulated into the (1, C, H, W) parameter it is a transposed view of — the backbone's absolute position
+ * embedding (mask_bev/models/networks/swin/swin.py:579-586, added at :750-760); one pass instead of a batch reduction and a
+ * transposed accumulate. */
+int mbv_transposed_batch_sum_accum(const float* g, int32_t batch, int64_t R, int32_t C, float* acc, void* stream);
 int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,
                           const float* mean, const float* rstd, const float* gamma, int64_t rows, int32_t C, float* dx,
                           void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,

@@ -86,7 +86,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_add_layernorm_supported': (ctypes.c_int, [_I]),
     'mbv_add_layernorm_bwd_blocks': (_L, [_L, _I]),
     'mbv_add_layernorm_fwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P, _P, _I, _P, _P, _P]),
-    'mbv_add_layernorm_fwd2': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P, _P, _I, _P, _I, _P, _P, _P]),
+    'mbv_add_layernorm_fwd2': (ctypes.c_int, [_P, _I, _P, _I, _L, _P, _P, _L, _I, _F, _P, _P, _I, _P, _I, _P, _P, _P]),
+    'mbv_transposed_batch_sum_accum': (ctypes.c_int, [_P, _I, _L, _I, _P, _P]),
     'mbv_add_layernorm_bwd': (ctypes.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P, _P,
                                              _I, _P]),
     'mbv_add_layernorm_bwd2': (ctypes.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P,

@@ -75,6 +75,7 @@ struct LnIo {
   void* y; int y_bf16;
   float* mean; float* rstd;
   MergeGeom mg;                      // mg.on: a is the f32 (B, H, W, C) map the rows are gathered from (b, s null)
+  long b_mod;                        // > 0: b has b_mod rows and repeats (row % b_mod): a per-sample map added to every sample
   void* y2; int y2_kind;             // optional second copy of y in another storage type (post-LN: f32 for the next residual
                                      // add, 16 bits for the branch GEMM that follows): no cast launch in between
 };
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_add_ln_fwd(LnIo io, long rows, int C, f
       x[i] = io.mg.on ? merge_load(reinterpret_cast<const float*>(io.a), io.mg, row, v)
                       : load4(io.a, io.a_bf16, base + 4 * v);
       if (io.b) {
-        const float4 t = load4(io.b, io.b_bf16, base + 4 * v);
+        const float4 t = load4(io.b, io.b_bf16, (io.b_mod ? (row % io.b_mod) * C : base) + 4 * v);
         x[i].x += t.x; x[i].y += t.y; x[i].z += t.z; x[i].w += t.w;
       }
       if (io.s) *reinterpret_cast<float4*>(io.s + base + 4 * v) = x[i];
@@ -301,7 +302,51 @@ int iters_for(int C) {
   return 0;
 }
 
+// acc[c][r] += sum_b g[b][r][c]: the gradient of a per-sample (R, C) token map that was added to every sample, accumulated
+// into the parameter it is a transposed view of ((1, C, H, W) absolute position embedding: swin.py:579-586 / :750-760).
+// 32 x 32 tiles through LDS: reads run along c, writes along r.
+template <typename T>
+__global__ void __launch_bounds__(256) k_transposed_batch_sum(const T* __restrict__ g, int batch, long R, int C,
+                                                              float* __restrict__ acc) {
+  __shared__ float tile[32][33];
+  const long r0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < batch; ++b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long r = r0 + ty + 8 * k;
+      const int c = c0 + tx;
+      if (r < R && c < C) {
+        const T v = g[((long)b * R + r) * C + c];
+        s[k] += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = s[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k;
+    const long r = r0 + tx;
+    if (r < R && c < C) acc[(long)c * R + r] += tile[tx][ty + 8 * k];
+  }
+}
+
 }  // namespace
+
+// g (batch, R, C) f32 → acc (C, R) f32 += the batch sum, transposed.
+extern "C" int mbv_transposed_batch_sum_accum(const float* g, int32_t batch, int64_t R, int32_t C, float* acc, void* stream) {
+  if (batch <= 0 || R <= 0 || C <= 0) return MBV_ERR_BAD_ARG;
+  if (!g || !acc) return MBV_ERR_BAD_ARG;
+  if ((R + 31) / 32 > 0x7fffffffL || (C + 31) / 32 > 65535) return MBV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_transposed_batch_sum<float>, dim3((unsigned)((R + 31) / 32), (unsigned)((C + 31) / 32)), dim3(256), 0,
+                     (hipStream_t)stream, g, batch, (long)R, C, acc);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
 
 // (the add + LayerNorm entry points stop at 2048 channels: with three partial sums per channel — dgamma, dbeta, dbranch —
 // 3072 channels would need 72 KB of LDS accumulators; the merging form has two)
@@ -333,27 +378,31 @@ static int add_ln_fwd_launch(const LnIo& io, int it, int64_t rows, int32_t C, fl
   return MBV_OK;
 }
 
-extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
-                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
-                                      int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream);
+extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, int64_t b_rows,
+                                      const float* gamma, const float* beta, int64_t rows, int32_t C, float eps,
+                                      float* sum_out, void* y, int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean,
+                                      float* rstd, void* stream);
 
 extern "C" int mbv_add_layernorm_fwd(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
                                      int32_t y_bf16, float* mean, float* rstd, void* stream) {
-  return mbv_add_layernorm_fwd2(a, a_bf16, b, b_bf16, gamma, beta, rows, C, eps, sum_out, y, y_bf16, nullptr, 0, mean, rstd,
-                                stream);
+  return mbv_add_layernorm_fwd2(a, a_bf16, b, b_bf16, 0, gamma, beta, rows, C, eps, sum_out, y, y_bf16, nullptr, 0, mean,
+                                rstd, stream);
 }
 
-extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, const float* gamma,
-                                      const float* beta, int64_t rows, int32_t C, float eps, float* sum_out, void* y,
-                                      int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean, float* rstd, void* stream) {
+extern "C" int mbv_add_layernorm_fwd2(const void* a, int32_t a_bf16, const void* b, int32_t b_bf16, int64_t b_rows,
+                                      const float* gamma, const float* beta, int64_t rows, int32_t C, float eps,
+                                      float* sum_out, void* y, int32_t y_bf16, void* y2, int32_t y2_dtype, float* mean,
+                                      float* rstd, void* stream) {
   const int it = C <= 2048 ? iters_for(C) : 0;
+  if (b_rows < 0 || (b_rows > 0 && (!b || rows % b_rows))) return MBV_ERR_BAD_ARG;
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
   if (rows == 0) return MBV_OK;
   if (!a || !gamma || !beta || !y || !mean || !rstd) return MBV_ERR_BAD_ARG;
   if (!sum_out && (b || a_bf16)) return MBV_ERR_BAD_ARG;       // the backward needs the f32 LN input
-  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd, MergeGeom{}, y2, y2_dtype};
+  LnIo io{a, b, a_bf16, b_bf16, gamma, beta, sum_out, y, y_bf16, mean, rstd, MergeGeom{}, b_rows == rows ? 0 : b_rows, y2,
+          y2_dtype};
   return add_ln_fwd_launch(io, it, rows, C, eps, (hipStream_t)stream);
 }
 

@@ -2331,9 +2331,16 @@ class _AddLayerNorm(torch.autograd.Function):
         if weight.dtype != torch.float32 or bias.dtype != torch.float32:
             raise MaskBevHipError('add_layernorm: f32 affine parameters')
         a2 = a.contiguous()
-        b2 = None if b is None else b.contiguous()
-        if b2 is not None and b2.shape != a2.shape:
+        b_rows = 0
+        if b is not None and b.shape != a.shape:
             raise MaskBevHipError('add_layernorm: a and b must have the same shape')
+        if b is not None and b.dim() >= 2 and b.shape[0] > 1 and b.stride(0) == 0 and b[0].is_contiguous():
+            # one per-sample map expanded over the batch (ops.pos_tokens): read with its row index modulo, never materialised;
+            # the gradient it gets back is the full-batch dx — the expanding op reduces it
+            b2 = b[0]
+            b_rows = b2.numel() // c
+        else:
+            b2 = None if b is None else b.contiguous()
         rows = a2.numel() // c
         need_sum = b2 is not None or a2.dtype != torch.float32
         s = torch.empty(a2.shape, dtype=torch.float32, device=a.device) if need_sum else None
@@ -2348,7 +2355,7 @@ class _AddLayerNorm(torch.autograd.Function):
                 raise MaskBevHipError('add_layernorm: branch dtype must be f32, bf16 or fp16')
             y_branch = torch.empty(a2.shape, dtype=branch_dtype, device=a.device)
         check(lib.mbv_add_layernorm_fwd2(_ptr(a2), _dt_flag(a2.dtype), _ptr(b2),
-                                         (_dt_flag(b2.dtype) if b2 is not None else 0), _ptr(w), _ptr(bb), rows, c,
+                                         (_dt_flag(b2.dtype) if b2 is not None else 0), b_rows, _ptr(w), _ptr(bb), rows, c,
                                          float(eps), _ptr(s), _ptr(y), _dt_flag(out_dtype), _ptr(y_branch),
                                          _dt_flag(branch_dtype) if y_branch is not None else 0, _ptr(mean),
                                          _ptr(rstd), _stream()), 'mbv_add_layernorm_fwd2')
@@ -2523,6 +2530,46 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
     if fanout:
         return y, y2
     return (y, a if s is None else s) if return_sum else y
+
+
+class _PosTokens(torch.autograd.Function):
+    """The (1, C, H, W) absolute position embedding as (B, H, W, C) tokens: ONE transposed (1, H, W, C) copy seen through a
+    stride-0 batch axis (K12 adds it to the patch tokens inside the first block's LayerNorm launch without materialising
+    it), whose backward takes the full-batch gradient and accumulates its batch sum, transposed back, into the parameter's
+    gradient in one pass — instead of a broadcast add forward and a batch reduction + a transposed accumulate backward.
+    /root/reference: mask_bev/models/networks/swin/swin.py:579-586 (parameter), :750-760 (the add)."""
+
+    @staticmethod
+    def forward(ctx, ape, batch, h, w):
+        c = int(ape.shape[1])           # the reference flattens the (rows, cols) map row-major into h * w tokens, whatever they are
+        if int(ape.shape[2]) * int(ape.shape[3]) != h * w:
+            raise MaskBevHipError('pos_tokens: the embedding has another number of positions')
+        ctx.ape = ape
+        ctx.dims = (int(batch), c, h, w)
+        t = ape.detach().flatten(2).transpose(1, 2).reshape(1, h, w, c).contiguous()
+        return t.expand(int(batch), h, w, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        ape = ctx.ape
+        b, c, h, w = ctx.dims
+        g = g.float().contiguous()
+        direct = (getattr(ape, '_mbv_arena', False) and ape.grad is not None and ape.grad.dtype == torch.float32
+                  and ape.grad.is_contiguous())
+        acc = ape.grad if direct else torch.zeros((1, c, h * w), dtype=torch.float32, device=g.device)
+        check(lib.mbv_transposed_batch_sum_accum(_ptr(g), b, h * w, c, _ptr(acc), _stream()),
+              'mbv_transposed_batch_sum_accum')
+        if direct:
+            _fire_grad_hooks(ape)
+            return None, None, None, None
+        return acc.view(ape.shape).to(ape.dtype), None, None, None
+
+
+def pos_tokens(ape: torch.Tensor, batch: int, h: int, w: int) -> torch.Tensor:
+    """ape (1, C, rows, cols) → (batch, h, w, C) tokens (rows * cols == h * w) over a stride-0 batch axis (:class:`_PosTokens`)."""
+    _need_gpu(ape)
+    return _PosTokens.apply(ape, int(batch), int(h), int(w))
 
 
 class _Conv1x1Tokens(torch.autograd.Function):

@@ -93,10 +93,11 @@ class SwinBlockSequence(nn.Module):
             for i in range(depth)])
         self.downsample = downsample
 
-    def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None):
+    def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None, pending: Optional[torch.Tensor] = None):
         """→ (input of the next stage, this stage's output — normalised by ``out_norm`` when given; the last
-        residual add of the stage is fused into that LayerNorm)."""
-        pending = pending_bias = None
+        residual add of the stage is fused into that LayerNorm).  ``pending``: a term still to be added to ``x`` (the
+        absolute position embedding in front of the first stage); the first block's LayerNorm launch adds it."""
+        pending_bias = None
         last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
             x, pending, pending_bias = blk(x, pending, pending_bias, defer_ffn_bias=(i < last or out_norm is not None))
@@ -165,6 +166,7 @@ class CustomSwinTransformer(nn.Module):
         the detached leaf the stage actually consumed (its ``.grad`` is the gradient to continue with)."""
         x = self.patch_embed(x)                                    # (B, H, W, E)
         b, h, w, e = x.shape
+        pos_pending = None
         if self.use_abs_pos_embed:
             ape = self.absolute_pos_embed
             w_, h_ = ape.shape[2:4]                                # swin.py:750 — (w, h) on purpose
@@ -172,13 +174,19 @@ class CustomSwinTransformer(nn.Module):
                 ape = F.interpolate(ape, size=(h, w), mode='bicubic', align_corners=False)
             # the reference flattens the (rows, cols) map row-major into the token axis, whatever h, w are
             # (made contiguous first: the broadcast add of the transposed view ran at 1.8 TB/s, 84 us per step)
-            x = x + ape.flatten(2).transpose(1, 2).reshape(1, h, w, e).contiguous()
+            if (x.is_cuda and ape is self.absolute_pos_embed and switches.get('pos_fused') and len(self.stages[0].blocks) > 0
+                    and (cut is None or cut['stage'] > 0) and ops.add_layernorm_supported(e)):
+                # the add rides on the first block's LayerNorm launch; the gradient takes one transposing pass (ops.pos_tokens)
+                pos_pending = ops.pos_tokens(ape, b, h, w)
+            else:
+                x = x + ape.flatten(2).transpose(1, 2).reshape(1, h, w, e).contiguous()
         outs = []
         for i, stage in enumerate(self.stages):
             if cut is not None and i == cut['stage']:
                 cut['x_in'] = x
                 x = cut['x_leaf'] = x.detach().requires_grad_()
-            x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None)
+            x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None,
+                           pending=pos_pending if i == 0 else None)
             if i in self.out_indices:
                 # (B, C, H, W) as the reference returns it, but as a VIEW of the channels-last map: the head's 1 x 1
                 # convolutions read it as tokens (layers.conv1x1), so no NCHW copy is made — forward or backward

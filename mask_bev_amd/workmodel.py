@@ -154,6 +154,7 @@ def _add_ln(a, bwd: bool) -> Work:
 
 def _add_ln_fwd2(a) -> Work:
     """mbv_add_layernorm_fwd2: as the forward, plus the second copy of y."""
+    a = tuple(a[:4]) + tuple(a[5:])                     # without b_rows: the forward's argument order + (y2, y2_dtype)
     name, bound, by, fl = _add_ln(tuple(a[:12]) + tuple(a[14:]), False)
     rows, c = _i(a[6]), _i(a[7])
     return (name, bound, by + (rows * c * (2 if _i(a[13]) else 4) if _i(a[12]) else 0), fl)
@@ -299,6 +300,8 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
     'mbv_add_layernorm_fwd2': lambda a: _add_ln_fwd2(a),
+    'mbv_transposed_batch_sum_accum': lambda a: ('k_transposed_batch_sum', 'hbm',
+                                                 (_i(a[1]) + 2.0) * _i(a[2]) * _i(a[3]) * 4.0, 0.0),
     'mbv_add_layernorm_bwd': lambda a: _add_ln(a, True),
     'mbv_add_layernorm_bwd2': lambda a: _add_ln_bwd2(a),
     # importance sampling: every row's (H, W) f32 map is read once; the 3x over-sampled candidates never touch HBM

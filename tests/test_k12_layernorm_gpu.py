@@ -217,3 +217,30 @@ def test_add_layernorm_fanout_branch_copy_in_16_bits(device, shape, dt2):
     for got, want in ((a.grad, ar.grad), (b.grad, br.grad)):
         assert close(got, want, 3e-5)
     assert close(w.grad, wr.grad, 1e-4) and close(bias.grad, biasr.grad, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(4, 16, 24, 96), (2, 5, 7, 192)])
+def test_position_tokens_ride_on_the_layernorm_launch(device, shape):
+    """ops.pos_tokens + K12's repeating ``b`` (mbv_add_layernorm_fwd2 b_rows; mbv_transposed_batch_sum_accum): the (1, C, rows,
+    cols) absolute position embedding added to (B, H, W, C) patch tokens inside the LayerNorm launch, its gradient the batch
+    sum of dx transposed back — against the explicit broadcast add + F.layer_norm in f64 (swin.py:750-760)."""
+    from mask_bev_amd import ops
+    b, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(device).requires_grad_()
+    ape = torch.randn(1, c, w, h, generator=g).to(device).requires_grad_()          # (w, h) on purpose, as the reference has it
+    gam = (torch.rand(c, generator=g) + 0.5).to(device).requires_grad_()
+    bet = torch.randn(c, generator=g).to(device).requires_grad_()
+    gy = torch.randn(shape, generator=g).to(device)
+    gs = torch.randn(shape, generator=g).to(device)
+    pos = ops.pos_tokens(ape, b, h, w)
+    assert pos.shape == x.shape and pos.stride(0) == 0
+    y, s = ops.add_layernorm(x, pos, gam, bet, 1e-5, torch.float32, return_sum=True)
+    torch.autograd.backward([y, s], [gy, gs])
+    xr, ar, gr, br = (t.detach().double().requires_grad_() for t in (x, ape, gam, bet))
+    sr = xr + ar.flatten(2).transpose(1, 2).reshape(1, h, w, c)
+    yr = F.layer_norm(sr, (c,), gr, br, 1e-5)
+    torch.autograd.backward([yr, sr], [gy.double(), gs.double()])
+    assert torch.allclose(y.double(), yr, rtol=2e-5, atol=2e-5) and torch.allclose(s.double(), sr, rtol=1e-6, atol=1e-6)
+    for got, want in ((x.grad, xr.grad), (ape.grad, ar.grad), (gam.grad, gr.grad), (bet.grad, br.grad)):
+        assert float((got.double() - want).abs().max()) <= 1e-4 * (float(want.abs().max()) + 1e-12)

@@ -119,6 +119,9 @@ def test_loss_and_gradients_match_oracle_nonsquare_200_queries(device):
               '_panoptic_head._panoptic_head.mask_embed.4.weight', '_panoptic_head._panoptic_head.query_feat.weight',
               '_panoptic_head._panoptic_head.cls_embed.weight',
               # the two level-embedding parameters (single-node forms ops.level_positions / ops.level_inputs)
+              # the backbone's absolute position embedding (added inside the first block's K12 launch, gradient through
+              # mbv_transposed_batch_sum_accum: ops.pos_tokens)
+              '_backbone._backbone.absolute_pos_embed',
               '_panoptic_head._panoptic_head.pixel_decoder.level_encoding.weight',
               '_panoptic_head._panoptic_head.level_embed.weight']:
         g, r = got[k].grad.cpu(), sd_g[k].grad
