@@ -843,6 +843,9 @@ int mbv_rowchain_run_split(const MbvRowStage* stages, int32_t num_stages, int32_
  * ceil(rows / 16) * 16 * cols elements. */
 int mbv_fragment_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols,
                        const int32_t* ld, const int32_t* transposed, int32_t n, void* stream);
+/* dst[i] = src[i], bytes[i] bytes each: the pieces of several small concatenations (the k / v rows of three decoder layers'
+ * packed in_proj parameters, mask2former_head.py:535-560 → nn.MultiheadAttention) in one launch. */
+int mbv_copy_group(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
 /* dst[i] (cols, rows) = transpose of src[i] (rows, cols), n matrices of elem_size 2 or 4 bytes, <= MBV_TR_MAX per launch. */
 int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols, int32_t n,
                         int32_t elem_size, void* stream);

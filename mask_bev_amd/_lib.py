@@ -60,6 +60,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_rowchain_run': (ctypes.c_int, [_P, _I, _I, _I, _F, _I, _P]),
     'mbv_rowchain_run_split': (ctypes.c_int, [_P, _I, _I, _I, _F, _I, _I, _P]),
     'mbv_transpose_group': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    'mbv_copy_group': (ctypes.c_int, [_P, _P, _P, _I, _P]),
     'mbv_fragment_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_window_attn_lse_elems': (_L, [_I, _I, _I, _I, _I]),
     'mbv_window_attn_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -1255,6 +1255,60 @@ extern "C" int mbv_fragment_group(const void* const* src, void* const* dst, cons
   return MBV_OK;
 }
 
+// ---- grouped contiguous copies: the pieces of several small concatenations in one launch -----------------------------------
+namespace {
+constexpr int MBV_CP_MAX = 48;
+constexpr int MBV_CP_CHUNK = 16384;          // bytes per workgroup
+struct CpEntry {
+  const void* src;
+  void* dst;
+  long bytes;
+  int block_begin;
+};
+struct CpArgs {
+  int n;
+  CpEntry e[MBV_CP_MAX];
+};
+__global__ void __launch_bounds__(256) k_copy_group(const CpArgs A) {
+  int ei = 0;
+  for (int i = 1; i < A.n; ++i)
+    if ((int)blockIdx.x >= A.e[i].block_begin) ei = i;
+  const CpEntry& e = A.e[ei];
+  const long off = (long)((int)blockIdx.x - e.block_begin) * MBV_CP_CHUNK;
+  const long len = e.bytes - off < MBV_CP_CHUNK ? e.bytes - off : MBV_CP_CHUNK;
+  const char* s = reinterpret_cast<const char*>(e.src) + off;
+  char* d = reinterpret_cast<char*>(e.dst) + off;
+  if (((reinterpret_cast<size_t>(s) | reinterpret_cast<size_t>(d)) & 15) == 0) {
+    const long n16 = len >> 4;
+    for (long i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (long i = (n16 << 4) + threadIdx.x; i < len; i += 256) d[i] = s[i];
+  } else {
+    for (long i = threadIdx.x; i < len; i += 256) d[i] = s[i];
+  }
+}
+}  // namespace
+
+extern "C" int mbv_copy_group(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!src || !dst || !bytes || n < 0) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < n; base += MBV_CP_MAX) {
+    CpArgs A;
+    A.n = n - base < MBV_CP_MAX ? n - base : MBV_CP_MAX;
+    long blocks = 0;
+    for (int i = 0; i < A.n; ++i) {
+      const int j = base + i;
+      if (!src[j] || !dst[j] || bytes[j] <= 0) return MBV_ERR_BAD_ARG;
+      A.e[i].src = src[j]; A.e[i].dst = dst[j]; A.e[i].bytes = bytes[j];
+      A.e[i].block_begin = (int)blocks;
+      blocks += (bytes[j] + MBV_CP_CHUNK - 1) / MBV_CP_CHUNK;
+      if (blocks > 0x7fffffffL) return MBV_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_copy_group, dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    MBV_CHECK_LAUNCH();
+  }
+  return MBV_OK;
+}
+
 extern "C" int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols,
                                    int32_t n, int32_t elem_size, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

@@ -1618,10 +1618,27 @@ class _SharedKVProject(torch.autograd.Function):
         e = key_in.shape[-1]
         dt = key_in.dtype
         ws, bs = wb[0::2], wb[1::2]
-        wk = torch.cat([_compute_copy(w, dt)[e:2 * e] for w in ws], 0)           # (n*E, E)
-        wv = torch.cat([_compute_copy(w, dt)[2 * e:3 * e] for w in ws], 0)
-        bk = torch.cat([_compute_copy(b_, dt)[e:2 * e] for b_ in bs], 0)
-        bv = torch.cat([_compute_copy(b_, dt)[2 * e:3 * e] for b_ in bs], 0)
+        wc, bc = [_compute_copy(w, dt) for w in ws], [_compute_copy(b_, dt) for b_ in bs]
+        if key_in.is_cuda and all(t.is_contiguous() for t in wc + bc):
+            # the k / v rows of the n layers' packed parameters → (n*E, E) / (n*E) operands: 4 n pieces, ONE launch (was 4 cats)
+            wk = torch.empty((n * e, e), dtype=dt, device=key_in.device)
+            wv = torch.empty((n * e, e), dtype=dt, device=key_in.device)
+            bk = torch.empty((n * e,), dtype=dt, device=key_in.device)
+            bv = torch.empty((n * e,), dtype=dt, device=key_in.device)
+            src, dst, nb = [], [], []
+            for j in range(n):
+                for full, out, r0 in ((wc[j], wk, e), (wc[j], wv, 2 * e), (bc[j], bk, e), (bc[j], bv, 2 * e)):
+                    src.append(full[r0:r0 + e].data_ptr())
+                    dst.append(out[j * e:(j + 1) * e].data_ptr())
+                    nb.append(full[r0:r0 + e].numel() * full.element_size())
+            k = len(src)
+            check(_lib.load().mbv_copy_group((ctypes.c_void_p * k)(*src), (ctypes.c_void_p * k)(*dst),
+                                             (ctypes.c_int64 * k)(*nb), k, _stream()), 'mbv_copy_group')
+        else:
+            wk = torch.cat([w[e:2 * e] for w in wc], 0)           # (n*E, E)
+            wv = torch.cat([w[2 * e:3 * e] for w in wc], 0)
+            bk = torch.cat([b_[e:2 * e] for b_ in bc], 0)
+            bv = torch.cat([b_[2 * e:3 * e] for b_ in bc], 0)
         with torch.autocast('cuda', enabled=False):
             holder.k_cat = torch.nn.functional.linear(key_in, wk, bk)
             holder.v_cat = torch.nn.functional.linear(val_in.to(dt), wv, bv)
