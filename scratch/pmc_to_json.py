@@ -53,7 +53,12 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_pfn_decorate', r'k_pfn_decorate', []),
     ('k_msda_prepare_fwd', r'k_msda_prepare_fwd', []),
     ('k_msda_prepare_bwd', r'k_msda_prepare_bwd', []),
+    ('k_match_products', r'k_match_products', []),
     ('k_match_cost', r'k_match_cost', []),
+    ('k_copy_group', r'k_copy_group', []),
+    ('k_transposed_batch_sum', r'k_transposed_batch_sum', []),
+    ('k_upsample_bilinear_bwd', r'k_upsample_bilinear_bwd', []),
+    ('k_cls_loss', r'k_cls_loss', []),
     ('k_attn_mask', r'k_attn_mask', []),
     ('k_pack_binary', r'k_pack_binary', []),
     # library kernels by operand type (Tensile names: _BBS_ / _BSS_ / _HHS_ / _HSS_ = 16-bit inputs, _S_B_ / _SB_ = f32)
