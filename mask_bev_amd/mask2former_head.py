@@ -155,6 +155,11 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with ctx:
             tail = list(outs)
             for j, i in enumerate(range(n - nl - 1, -1, -1)):
+                if side is not None and feats[i].dtype in ops._LO_DTYPES:
+                    # a 16-bit map would be saved as it is by the convolution node below, whose backward runs on this stream:
+                    # give that node a tensor of this stream's pool (see swin.CustomSwinTransformer.forward)
+                    feats = list(feats)
+                    feats[i] = feats[i].clone()
                 # K18: GroupNorm + up-sampled add of the coarser level in one pass, stored for the 3 x 3 convolution
                 y = self.lateral_convs[j](feats[i], add_upsampled=tail[-1], conv_input=True)
                 # outputs beyond num_outs only feed the next FPN step / the mask-feature projection (convolutions)

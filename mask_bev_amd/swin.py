@@ -93,7 +93,8 @@ class SwinBlockSequence(nn.Module):
             for i in range(depth)])
         self.downsample = downsample
 
-    def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None, pending: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, out_norm: Optional[nn.Module] = None, pending: Optional[torch.Tensor] = None,
+                out_gemm_input: bool = False):
         """→ (input of the next stage, this stage's output — normalised by ``out_norm`` when given; the last
         residual add of the stage is fused into that LayerNorm).  ``pending``: a term still to be added to ``x`` (the
         absolute position embedding in front of the first stage); the first block's LayerNorm launch adds it."""
@@ -102,7 +103,9 @@ class SwinBlockSequence(nn.Module):
         for i, blk in enumerate(self.blocks):
             x, pending, pending_bias = blk(x, pending, pending_bias, defer_ffn_bias=(i < last or out_norm is not None))
         if out_norm is not None:
-            out, x = out_norm(x, pending, return_sum=True, residual_bias=pending_bias)
+            # ``out_gemm_input``: the stage output only feeds 1 x 1 convolutions (GEMMs) — under 16-bit autocast K12 stores it
+            # in that type, what those GEMMs would cast it to anyway
+            out, x = out_norm(x, pending, return_sum=True, residual_bias=pending_bias, gemm_input=out_gemm_input)
         else:
             x = x if pending is None else x + pending
             out = x
@@ -185,8 +188,14 @@ class CustomSwinTransformer(nn.Module):
             if cut is not None and i == cut['stage']:
                 cut['x_in'] = x
                 x = cut['x_leaf'] = x.detach().requires_grad_()
+            # Stage outputs 1.. feed the head's input convolutions — GEMMs on the stream that produced them — and leave in the
+            # autocast dtype (three cast launches per step).  Stage 0's feeds the FPN tail, which the pixel decoder runs on a
+            # second stream: a 16-bit map produced HERE would be saved by a node whose backward runs THERE, and its block — freed
+            # to this stream's pool when that node releases it — could be handed out again while the other stream still reads
+            # it (seen as NaNs in lateral_convs.0's weight gradient).  It stays f32; its cast is the tail stream's own tensor.
             x, out = stage(x, getattr(self, f'norm{i}') if i in self.out_indices else None,
-                           pending=pos_pending if i == 0 else None)
+                           pending=pos_pending if i == 0 else None,
+                           out_gemm_input=bool(i > 0 and switches.get('stage_out_lowp')))
             if i in self.out_indices:
                 # (B, C, H, W) as the reference returns it, but as a VIEW of the channels-last map: the head's 1 x 1
                 # convolutions read it as tokens (layers.conv1x1), so no NCHW copy is made — forward or backward
