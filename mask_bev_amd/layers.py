@@ -326,7 +326,8 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, query_pos: torch.Tensor, reference_points: torch.Tensor,
                 spatial_shapes: Sequence[Tuple[int, int]], shapes_t: torch.Tensor, level_start: torch.Tensor,
-                add_identity: bool = True, defer_out_bias: bool = False, pos_share=None, pos_share_index: int = 0):
+                add_identity: bool = True, defer_out_bias: bool = False, pos_share=None, pos_share_index: int = 0,
+                wcat=None):
         """query (B, N, E) un-positioned (also the value source); reference_points (N, 2) in [0, 1] (x, y).
         ``pos_share``: an ``ops.PosGradShare`` common to a chain of layers that add the same ``query_pos``."""
         b, n, e = query.shape
@@ -336,7 +337,7 @@ class MultiScaleDeformableAttention(nn.Module):
                 and ops.msda_prepare_supported(l, p) and switches.get('msda_fused')):
             out = ops.msda_query_side(query, query_pos, reference_points, self.value_proj, self.sampling_offsets,
                                       self.attention_weights, h, l, p, spatial_shapes, shapes_t, level_start,
-                                      pos_share=pos_share, pos_share_index=pos_share_index)
+                                      pos_share=pos_share, pos_share_index=pos_share_index, wcat=wcat)
             out = self.output_proj(out, skip_bias_grad=defer_out_bias and not add_identity)
             return out + query if add_identity else out
         q = query + query_pos

@@ -30,7 +30,7 @@ class _DeformEncoderLayer(nn.Module):
         self.norms = nn.ModuleList([LayerNorm(embed_dims), LayerNorm(embed_dims)])
 
     def forward(self, q, pos, ref, shapes, shapes_t, level_start, q_branch=None, fanout=False, pos_share=None,
-                pos_share_index=0):
+                pos_share_index=0, wcat=None):
         """post-LN: LN(q + branch(q)), the add fused into the LayerNorm kernel (K12).  A LayerNorm output has two
         consumers — the next residual add and the next branch: it is handed on as a PAIR of tensors over one buffer
         (``q`` for the residual, ``q_branch`` for the branch) so that K12's backward receives the two gradients
@@ -40,7 +40,8 @@ class _DeformEncoderLayer(nn.Module):
         d1, d2 = ops.bias_grad_deferrable(ob, c), ops.bias_grad_deferrable(fb, c)
         q_branch = q if q_branch is None else q_branch
         q, qb = self.norms[0](q, self.self_attn(q_branch, pos, ref, shapes, shapes_t, level_start, add_identity=False,
-                                                defer_out_bias=d1, pos_share=pos_share, pos_share_index=pos_share_index),
+                                                defer_out_bias=d1, pos_share=pos_share, pos_share_index=pos_share_index,
+                                                wcat=wcat),
                               residual_bias=ob if d1 else None, fanout=True, branch_gemm=True)
         return self.norms[1](q, self.ffn(qb, add_identity=False, defer_out_bias=d2), residual_bias=fb if d2 else None,
                              fanout=fanout)
@@ -133,8 +134,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
         # one d(pos) product for the chain of layers instead of one per layer (ops.PosGradShare)
         share = (ops.PosGradShare(nlay) if (q.is_cuda and torch.is_grad_enabled() and qpos.requires_grad and nlay > 1
                                             and switches.get('pos_share')) else None)
+        # the layers' stacked projection weights [Wv; Wo; Wa] in the compute dtype: 18 pieces, one launch
+        wcats = None
+        if q.is_cuda and q.dtype == torch.float32 and switches.get('msda_fused'):
+            cdt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else q.dtype
+            wcats = ops.msda_weight_stacks([l.self_attn for l in self.encoder.layers], cdt)
         for li, layer in enumerate(self.encoder.layers):
-            kw = dict(pos_share=share, pos_share_index=li)
+            kw = dict(pos_share=share, pos_share_index=li, wcat=None if wcats is None else wcats[li])
             if li + 1 < nlay:
                 q, q_branch = layer(q, qpos, ref, shapes, shapes_t, level_start, q_branch=q_branch, fanout=True, **kw)
             else:

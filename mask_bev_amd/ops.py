@@ -723,7 +723,7 @@ class _MSDAQuerySide(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, ref, wv, bv, wo, bo, wa, ba, heads, levels, points, shapes_host, shapes_t, level_start,
-                share=None, share_index=0):
+                share=None, share_index=0, wcat=None):
         lib = _lib.load()
         ctx.share = (share, int(share_index))
         _need_gpu(x, pos, ref, wv, wo, wa)
@@ -737,7 +737,8 @@ class _MSDAQuerySide(torch.autograd.Function):
             qb = torch.empty(x.shape, dtype=dt, device=x.device)
             # [Wv; Wo; Wa] (E + 2HLP + HLP, E) in the compute dtype, once: the backward's single data-gradient GEMM reads it
             # whole, and its last two blocks make offsets and attention logits ONE projection of q here
-            wcat = torch.cat([_compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)], 0)
+            if wcat is None or wcat.dtype != dt or tuple(wcat.shape) != (e + lo + la, e):
+                wcat = torch.cat([_compute_copy(wv, dt), _compute_copy(wo, dt), _compute_copy(wa, dt)], 0)
             wvc = wcat[:e]
             pos_rows = pos.numel() // e
             if (dt in _LO_DTYPES and x.dtype == torch.float32 and pos.dtype == torch.float32 and x.is_contiguous()
@@ -867,17 +868,46 @@ class _MSDAQuerySide(torch.autograd.Function):
             for j, bia in enumerate((bv, bo, ba)):
                 if not deferred[j]:
                     _fire_grad_hooks(bia)
-        return (gx, gpos, None) + tuple(grads) + (None,) * 8
+        return (gx, gpos, None) + tuple(grads) + (None,) * 9
+
+
+@torch.no_grad()
+def msda_weight_stacks(attns, dtype) -> Optional[List[torch.Tensor]]:
+    """[Wv; Wo; Wa] (E + 2HLP + HLP, E) in ``dtype`` for every deformable-attention module of a chain, all pieces copied by
+    ONE launch (mbv_copy_group) instead of one concatenation per layer; None when that does not apply."""
+    if not attns or not attns[0].value_proj.weight.is_cuda:
+        return None
+    dev = attns[0].value_proj.weight.device
+    src, dst, nb, outs, keep = [], [], [], [], []
+    for a in attns:
+        parts = [_compute_copy(m.weight, dtype) for m in (a.value_proj, a.sampling_offsets, a.attention_weights)]
+        keep.append(parts)              # per-call casts (parameters outside an arena) must outlive the launch below
+        if any(not p.is_contiguous() or p.dtype != dtype for p in parts):
+            return None
+        rows, e = sum(int(p.shape[0]) for p in parts), int(parts[0].shape[1])
+        out = torch.empty((rows, e), dtype=dtype, device=dev)
+        r0 = 0
+        for p in parts:
+            src.append(p.data_ptr())
+            dst.append(out[r0:r0 + p.shape[0]].data_ptr())
+            nb.append(p.numel() * p.element_size())
+            r0 += int(p.shape[0])
+        outs.append(out)
+    k = len(src)
+    check(_lib.load().mbv_copy_group((ctypes.c_void_p * k)(*src), (ctypes.c_void_p * k)(*dst), (ctypes.c_int64 * k)(*nb), k,
+                                     _stream()), 'mbv_copy_group')
+    del keep
+    return outs
 
 
 def msda_query_side(x, pos, ref, value_proj, sampling_offsets, attention_weights, heads, levels, points, spatial_shapes,
-                    shapes_t, level_start, pos_share=None, pos_share_index=0):
+                    shapes_t, level_start, pos_share=None, pos_share_index=0, wcat=None):
     """x (B, N, E) f32, pos (1, N, E) → the deformable-attention output (B, N, E) f32 before ``output_proj``; the three
     ``nn.Linear`` modules supply the parameters (checkpoint keys unchanged).  See :class:`_MSDAQuerySide`."""
     host = tuple((int(h), int(w)) for h, w in spatial_shapes)
     return _MSDAQuerySide.apply(x, pos, ref, value_proj.weight, value_proj.bias, sampling_offsets.weight,
                                 sampling_offsets.bias, attention_weights.weight, attention_weights.bias, heads, levels,
-                                points, host, shapes_t, level_start, pos_share, pos_share_index)
+                                points, host, shapes_t, level_start, pos_share, pos_share_index, wcat)
 
 
 # --------------------------------------------------------------------------------------
