@@ -1947,6 +1947,12 @@ class _MaskLogits(torch.autograd.Function):
             check(lib.mbv_gemm16_nn(_ptr(e), _ptr(f), _ptr(out), None, None, q, c, hw, c, hw, hw, 0, _GEMM16_DT[dt],
                                     1 if out.dtype == torch.float32 else 0, 0, b, q * c, c * hw, q * hw, None, 0, _stream()),
                   'mbv_gemm16_nn')
+        elif dt == torch.float32 and switches.get('k7_f32_library'):
+            # f32: the library's batched product (0.76 of the f32 MFMA peak on this shape); K7's own exact-f32 form streams
+            # E through L2 per 128-pixel slab and sits at 0.07 of HBM — 179 against ≈ 35 us per launch in the fp32 step
+            # (through .data: like the raw-pointer launches around it, the store must not count as an in-place update of the
+            # stacked buffer this slot is a view of)
+            torch.bmm(e, f.view(b, c, hw), out=out.data.view(b, q, hw))
         else:
             rc = lib.mbv_mask_logits_fwd(_ptr(e), _ptr(f), _dt_flag(dt), b, q, c, hw, _ptr(out),
                                          1 if out.dtype == torch.float32 else 0, _stream())
