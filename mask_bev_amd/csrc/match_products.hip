@@ -34,12 +34,16 @@ __device__ __forceinline__ int slot(int tile, int ks, int part, int r, int h) {
   return (((tile * 2 + ks) * 2 + part) << 6) + r + 32 * h;
 }
 
+// v = hi + lo with hi = half(v) and lo = half(v - hi), two values per conversion (v_cvt_pkrtz_f16_f32: round toward zero —
+// whatever hi leaves, lo carries; lo's own truncation is 2^-21 of v).  As instructions: pack, 2 unpacks, a packed subtract, pack.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float* v, h8& hi, h8& lo) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 a = (_Float16)v[j];
-    hi[j] = a;
-    lo[j] = (_Float16)(v[j] - (float)a);
+  for (int j = 0; j < 8; j += 2) {
+    const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(v[j], v[j + 1]));
+    const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(v[j] - (float)a[0], v[j + 1] - (float)a[1]));
+    hi[j] = a[0]; hi[j + 1] = a[1];
+    lo[j] = b[0]; lo[j + 1] = b[1];
   }
 }
 
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(kThreads, 2)
           float v[8] = {st.a[j].v[0].x, st.a[j].v[0].y, st.a[j].v[0].z, st.a[j].v[0].w,
                         st.a[j].v[1].x, st.a[j].v[1].y, st.a[j].v[1].z, st.a[j].v[1].w};
           float sg[8];
-          float sn = 0.f;
+          float sn = 0.f, dprod = 1.f;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             // the raw v_exp_f32 / v_rcp_f32 / v_log_f32 (1 ulp): 1 + e lies in (1, 2], no denormal or range handling is
@@ -141,9 +145,10 @@ __global__ void __launch_bounds__(kThreads, 2)
             const float d = 1.0f + e;
             const float inv = __builtin_amdgcn_rcpf(d);
             sg[i] = v[i] >= 0.f ? inv : e * inv;
-            sn = fmaf(__builtin_amdgcn_logf(d), 0.6931471805599453f, sn + fmaxf(v[i], 0.f));
+            sn += fmaxf(v[i], 0.f);
+            dprod *= d;                                       // in (1, 256]: one logarithm for the eight points
           }
-          s_neg[j] += sn;
+          s_neg[j] += fmaf(__builtin_amdgcn_logf(dprod), 0.6931471805599453f, sn);
           split8(v, xh, xl);
           split8(sg, sh, sl);
         } else {

@@ -553,9 +553,10 @@ class NextCross:
 
 
 class HeadSpec:
-    def __init__(self, post_g, post_b, cls_w, cls_b, mlp, mask_feature, out_slot):
+    def __init__(self, post_g, post_b, cls_w, cls_b, mlp, mask_feature, out_slot, index: int = -1):
         self.post_g, self.post_b, self.cls_w, self.cls_b, self.mlp = post_g, post_b, cls_w, cls_b, mlp
         self.mask_feature, self.out_slot = mask_feature, out_slot
+        self.index = index           # which decoder output this layer produces (the batched heads' backward keys on it)
 
 
 class _DecB(torch.autograd.Function):
@@ -656,6 +657,7 @@ class _DecB(torch.autograd.Function):
                                       lc.h, e // lc.h, ops._ptr(o1n), ops._ptr(lse), ops._ptr(ws), ws.numel(),
                                       ops._stream()), 'mbv_attn_fwd_ld')
         ctx.lc, ctx.nxt = lc, nxt
+        ctx.head_index = head.index
         # no zero tensors for the outputs that carry no gradient (class scores, mask logits, the attention mask): autograd
         # would otherwise MATERIALISE them for backward() — a 26 MB fill and a 1.6 MB bool fill per layer
         ctx.set_materialize_grads(False)
@@ -702,8 +704,13 @@ class _DecB(torch.autograd.Function):
                                       ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ldk, bf, ops._stream()),
                   'mbv_attn_bwd_ld')
             holder.written.add(nxt.slot)
-        if g_x3 is None:                  # (this layer's output fed nothing that needed a gradient)
-            g_x3 = torch.zeros((m, e), **f32)
+        # the batched heads' share of d(x3), left in the layer context instead of on the autograd edge (mask2former_head.
+        # _DeferredHeads.backward): added by the program below while it loads the gradient
+        g_heads = lc.dpos_holder.get('gq', {}).pop(ctx.head_index, None)
+        if g_heads is not None:
+            g_heads = g_heads.reshape(m, e).to(torch.float32).contiguous()
+        if g_x3 is None:                  # (this layer's output fed nothing else that needed a gradient)
+            g_x3, g_heads = (g_heads, None) if g_heads is not None else (torch.zeros((m, e), **f32), None)
         g_x3 = g_x3.reshape(m, e).to(torch.float32).contiguous()
         part_b = torch.empty((nblk, 3 * e + f), **f32)          # [bq' | b2 | bo | b1 (f)]
         part_ln3, part_ln2 = torch.empty((nblk, 2 * e), **f32), torch.empty((nblk, 2 * e), **f32)
@@ -725,6 +732,9 @@ class _DecB(torch.autograd.Function):
             P.add(3, 3, 4, e)
         else:
             P.load(3, g_x3, e)
+        if g_heads is not None:
+            P.load(4, g_heads, e)
+            P.add(3, 3, 4, e)
         P.load(4, sum3, e)
         P.ln_bwd(0, 3, 4, g3, stats3, e, partial=part_ln3)              # ds3 -> slot 0
         with P.only(3):

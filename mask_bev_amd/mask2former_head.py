@@ -346,6 +346,15 @@ class _DeferredHeads(torch.autograd.Function):
             grads.append(d_cls.to(cls_re.dtype))
         torch.autograd.backward(roots, grads)                # parameter gradients accumulate where they always do
         gq = q_all.grad
+        # Row-chain decoder: the gradient of decoder output i (i = 1 .. D - 2) also reaches its producer from the next layer;
+        # handed over through the layer context, the producer's backward program adds it while it loads that gradient — not
+        # autograd with a launch per layer.  Output 0 is the query parameter, output D - 1 has no other consumer.
+        stash = getattr(head, '_gq_stash', None)
+        if stash is not None and nd > 2 and switches.get('gq_stash'):
+            box = stash.setdefault('gq', {})
+            for i in range(1, nd - 1):
+                box[i] = gq[i]
+            return (None, None, d_f, gq[0]) + (None,) * (nd - 2) + (gq[nd - 1],)
         return (None, None, d_f) + tuple(gq[i] for i in range(nd))
 
 
@@ -458,6 +467,7 @@ class Mask2FormerHead(nn.Module):
                             device=mask_features.device) if mask_features.is_cuda else None
         self._mask_stack = stack
         self._stack_sink = None
+        self._gq_stash = None
         # training on the GPU: the heads run layer by layer WITHOUT a graph and get one batched backward (_DeferredHeads)
         deferred = (stack is not None and self.training and torch.is_grad_enabled()
                     and switches.get('deferred_heads'))
@@ -574,6 +584,7 @@ class Mask2FormerHead(nn.Module):
                     ents.append((ca.in_proj_weight, (0, e), True))
         tw.refresh(ents, dt)
         holder = {}
+        self._gq_stash = holder if deferred else None
         qpos = DF.QueryPositions.apply(self.query_embed.weight, holder)
         f = layers[0].ffn.layers[0][0].out_features
         lc = DF.LayerCtx(bs, q, e, self.num_heads, f, layers[0].norms[0].eps, dt, tw, holder, qpos)
@@ -592,7 +603,7 @@ class Mask2FormerHead(nn.Module):
                 x1, o2 = DF._DecA.apply(lc, x, o1, ca.out_proj.weight, ca.out_proj.bias, layer.norms[0].weight,
                                         layer.norms[0].bias, sa.in_proj_weight, sa.in_proj_bias)
                 head = DF.HeadSpec(post.weight, post.bias, self.cls_embed.weight, self.cls_embed.bias, mlp, mask_features,
-                                   None if stack is None else stack[i + 1])
+                                   None if stack is None else stack[i + 1], index=i + 1)
                 nxt, token, nw, nb = None, None, None, None
                 if i + 1 < len(layers):
                     hn, token, slotn = shared[i + 1]

@@ -19,6 +19,7 @@ _DEFAULTS: Dict[str, Any] = {
     'rc_ffn': True,               # the MLP pair as one FFN stage of a row chain
     'rc_split': True,             # MLP stage sliced over f / 256 workgroups
     'rc_spread': True,            # independent stages of a program spread over 2-3 workgroups
+    'gq_stash': True,             # the batched heads' query gradients join the row-chain backward programs (no autograd adds)
     'stack_grad_sink': True,      # K8 backward stores the stacked logit gradient as the deferred heads read it
     'deferred_heads': True,       # prediction heads' backward as one batched pass
     'shared_kv': True,            # one key / value projection per memory level
