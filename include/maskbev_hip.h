@@ -191,6 +191,18 @@ int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial_shapes, co
                            int32_t num_levels, int32_t num_query, int32_t num_points,
                            float* out, void* stream);
 
+/* The same forward, and the d(location) / d(weight) part of the split backward on its own, with the value map stored in
+ * value_dtype (MBV_DT_F32 / _BF16 / _F16; head_dim % 4 == 0 resp. == 32): a 16-bit map halves the bytes of every bilinear tap
+ * — what the two kernels are bound by — and is what the reference's value projection produces under 16-bit autocast. */
+int mbv_ms_deform_attn_fwd_v(const void* value, int32_t value_dtype, const int64_t* spatial_shapes, const int64_t* level_start,
+                             const float* sampling_loc, const float* attn_weight, int32_t batch, int32_t num_value,
+                             int32_t num_heads, int32_t head_dim, int32_t num_levels, int32_t num_query, int32_t num_points,
+                             float* out, void* stream);
+int mbv_ms_deform_attn_bwd_locattn(const float* grad_out, const void* value, int32_t value_dtype, const int64_t* spatial_shapes,
+                                   const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
+                                   int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim, int32_t num_levels,
+                                   int32_t num_query, int32_t num_points, float* grad_loc, float* grad_attn, void* stream);
+
 int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int64_t* spatial_shapes_host);
 
 /* d(value) of form (a) with packed fixed-point LDS accumulators (16-bit compute modes): two adjacent channels of a

@@ -49,6 +49,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_msda_prepare_bwd': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_msda_prepare_bwd_ld': (ctypes.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     'mbv_ms_deform_attn_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'mbv_ms_deform_attn_fwd_v': (ctypes.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'mbv_ms_deform_attn_bwd_locattn': (ctypes.c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'mbv_ms_deform_attn_bwd_split': (ctypes.c_int, [_I, _I, _P]),
     'mbv_ms_deform_attn_bwd_value_packed_supported': (ctypes.c_int, [_I, _I, _I, _I, _P]),
     'mbv_ms_deform_attn_bwd_value_packed_workspace_bytes': (c_size_t, [_I, _I, _I, _I]),

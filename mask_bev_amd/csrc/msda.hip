@@ -93,7 +93,27 @@ __global__ void __launch_bounds__(256) k_msda_fwd(const float* __restrict__ valu
 // channel, so with one channel per lane it is recomputed by 32 lanes; here a lane owns 4 adjacent channels (one
 // 16-byte piece of the 128-byte pixel row) and 8 lanes cover a head — a quarter of the threads and of the
 // set-up instructions for the same gathers, issued as 16-byte loads.
-__global__ void __launch_bounds__(256) k_msda_fwd_v4(const float* __restrict__ value,
+// 4 adjacent channels of a value row in its storage type VK (MBV_DT_F32 / _BF16 / _F16): 16 or 8 bytes per gather.  The
+// 16-bit forms halve the bytes every bilinear tap pulls through L2 — what the forward and the location / weight gradient are
+// bound by (48 taps of 128 B per (query, head) in f32); under 16-bit autocast the reference's value IS a 16-bit Linear output.
+template <int VK>
+__device__ __forceinline__ float4 value4(const void* __restrict__ base, int64_t elem) {
+  if constexpr (VK == MBV_DT_F32) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    if constexpr (VK == MBV_DT_BF16)
+      return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                         __uint_as_float(u.y & 0xffff0000u));
+    return make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(u.x & 0xffffu)),
+                       (float)__builtin_bit_cast(_Float16, (unsigned short)(u.x >> 16)),
+                       (float)__builtin_bit_cast(_Float16, (unsigned short)(u.y & 0xffffu)),
+                       (float)__builtin_bit_cast(_Float16, (unsigned short)(u.y >> 16)));
+  }
+}
+
+template <int VK>
+__global__ void __launch_bounds__(256) k_msda_fwd_v4(const void* __restrict__ value,
                                                      const int64_t* __restrict__ shapes,
                                                      const int64_t* __restrict__ level_start,
                                                      const float* __restrict__ loc, const float* __restrict__ attn,
@@ -108,12 +128,12 @@ __global__ void __launch_bounds__(256) k_msda_fwd_v4(const float* __restrict__ v
   t /= heads;                       // t = b * num_query + q
   const int b = (int)(t / num_query);
   const int stride_pix = heads * dim;
-  const float* vb = value + (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t vb = (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
   const int64_t lw_base = (t * heads + hd) * levels * points;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < levels; ++l) {
     const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
-    const float* vl = vb + level_start[l] * stride_pix;
+    const int64_t vl = vb + level_start[l] * stride_pix;
     for (int p = 0; p < points; ++p) {
       const int64_t k = lw_base + l * points + p;
       const float lx = loc[k * 2], ly = loc[k * 2 + 1], aw = attn[k];
@@ -123,7 +143,7 @@ __global__ void __launch_bounds__(256) k_msda_fwd_v4(const float* __restrict__ v
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (c.off[j] >= 0) {
-            const float4 x = *reinterpret_cast<const float4*>(vl + c.off[j]);
+            const float4 x = value4<VK>(value, vl + c.off[j]);
             v.x += c.wgt[j] * x.x; v.y += c.wgt[j] * x.y; v.z += c.wgt[j] * x.z; v.w += c.wgt[j] * x.w;
           }
         }
@@ -638,6 +658,80 @@ __device__ __forceinline__ void msda_value_fx_block(const MsdaFxArgs& A, int lev
   }
 }
 
+// The same forward for num_points == 4 without a branch between a tap's address and its load: out-of-range taps read element 0
+// of the level's slab with weight 0, so a level's 4 x 4 gathers (and, before them, its 4 locations and weights as three
+// 16-byte loads) are all in flight before the first one is consumed — the branchy form waited for a (location → address →
+// gather) round trip per sample, 12 in a row: it is bound by that latency, not by bytes (a 16-bit value map changed nothing).
+struct Taps4 {
+  int off[4];
+  float wgt[4];
+};
+__device__ __forceinline__ void taps_clamped(float loc_x, float loc_y, float aw, int h, int w, int stride_pix, Taps4& t) {
+  const float him = loc_y * (float)h - 0.5f;
+  const float wim = loc_x * (float)w - 0.5f;
+  const bool in = him > -1.f && wim > -1.f && him < (float)h && wim < (float)w;
+  const int hl = (int)floorf(him), wl = (int)floorf(wim);
+  const int hh = hl + 1, wh = wl + 1;
+  const float lh = him - (float)hl, lw = wim - (float)wl;
+  const float uh = 1.f - lh, uw = 1.f - lw;
+  const bool t0 = in && hl >= 0 && wl >= 0, t1 = in && hl >= 0 && wh <= w - 1;
+  const bool t2 = in && hh <= h - 1 && wl >= 0, t3 = in && hh <= h - 1 && wh <= w - 1;
+  t.off[0] = t0 ? (hl * w + wl) * stride_pix : 0;
+  t.off[1] = t1 ? (hl * w + wh) * stride_pix : 0;
+  t.off[2] = t2 ? (hh * w + wl) * stride_pix : 0;
+  t.off[3] = t3 ? (hh * w + wh) * stride_pix : 0;
+  t.wgt[0] = t0 ? aw * uh * uw : 0.f;
+  t.wgt[1] = t1 ? aw * uh * lw : 0.f;
+  t.wgt[2] = t2 ? aw * lh * uw : 0.f;
+  t.wgt[3] = t3 ? aw * lh * lw : 0.f;
+}
+
+template <int VK>
+__global__ void __launch_bounds__(256) k_msda_fwd_p4(const void* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                     const int64_t* __restrict__ level_start,
+                                                     const float* __restrict__ loc, const float* __restrict__ attn,
+                                                     int64_t total4, int num_value, int heads, int dim, int levels,
+                                                     int num_query, float* __restrict__ out) {
+  const int64_t idx = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int d4n = dim >> 2;
+  const int d4 = (int)(idx % d4n);
+  int64_t t = idx / d4n;
+  const int hd = (int)(t % heads);
+  t /= heads;                       // t = b * num_query + q
+  const int b = (int)(t / num_query);
+  const int stride_pix = heads * dim;
+  const int64_t vb = (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t lw_base = (t * heads + hd) * levels * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int l = 0; l < levels; ++l) {
+    const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
+    const int64_t vl = vb + level_start[l] * stride_pix;
+    const float4 xy0 = *reinterpret_cast<const float4*>(loc + (lw_base + l * 4) * 2);
+    const float4 xy1 = *reinterpret_cast<const float4*>(loc + (lw_base + l * 4) * 2 + 4);
+    const float4 aw = *reinterpret_cast<const float4*>(attn + lw_base + l * 4);
+    Taps4 tp[4];
+    taps_clamped(xy0.x, xy0.y, aw.x, h, w, stride_pix, tp[0]);
+    taps_clamped(xy0.z, xy0.w, aw.y, h, w, stride_pix, tp[1]);
+    taps_clamped(xy1.x, xy1.y, aw.z, h, w, stride_pix, tp[2]);
+    taps_clamped(xy1.z, xy1.w, aw.w, h, w, stride_pix, tp[3]);
+    float4 x[16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[p * 4 + j] = value4<VK>(value, vl + tp[p].off[j]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float wj = tp[p].wgt[j];
+        acc.x += wj * x[p * 4 + j].x; acc.y += wj * x[p * 4 + j].y;
+        acc.z += wj * x[p * 4 + j].z; acc.w += wj * x[p * 4 + j].w;
+      }
+  }
+  *reinterpret_cast<float4*>(out + ((t * heads + hd) * dim + d4 * 4)) = acc;
+}
+
 // Re-layout pass of the packed value-gradient kernel: one block = (batch, head, 64 consecutive queries).  Reads the
 // block's grad_out (64 x 128 B), locations (64 x L x 32 B) and weights (64 x L x 16 B) in full lines, turns them through
 // LDS and writes them where the value kernel's blocks read CONTIGUOUS streams: grad_out by 4-channel group, locations /
@@ -734,8 +828,9 @@ __global__ void __launch_bounds__(512) k_msda_bwd_value_fx(const MsdaFxArgs A) {
 }
 
 // d(location), d(weight): 8 lanes per (query, head), 4 channels per lane
+template <int VK>
 __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restrict__ grad_out,
-                                                          const float* __restrict__ value,
+                                                          const void* __restrict__ value,
                                                           const int64_t* __restrict__ shapes,
                                                           const int64_t* __restrict__ level_start,
                                                           const float* __restrict__ loc, const float* __restrict__ attn,
@@ -752,13 +847,13 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
   const int hd = (int)(t % heads);
   t /= heads;                                         // t = b * num_query + q
   const int b = (int)(t / num_query);
-  const float* vb = value + (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t vb = (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
   const int64_t lw_base = (t * heads + hd) * levels * points;
   const float4 go = *reinterpret_cast<const float4*>(grad_out + (t * heads + hd) * dim + d4 * 4);
   float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
   for (int l = 0; l < levels; ++l) {
     const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
-    const float* vl = vb + level_start[l] * stride_pix;
+    const int64_t vl = vb + level_start[l] * stride_pix;
     for (int p = 0; p < points; ++p) {
       const int64_t k = lw_base + l * points + p;
       const float lx = loc[k * 2], ly = loc[k * 2 + 1], aw = attn[k];
@@ -770,7 +865,7 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
         for (int j = 0; j < 4; ++j) {
           s4[j] = 0.f;
           if (c.off[j] >= 0) {
-            const float4 x = *reinterpret_cast<const float4*>(vl + c.off[j]);
+            const float4 x = value4<VK>(value, vl + c.off[j]);
             s4[j] = go.x * x.x + go.y * x.y + go.z * x.z + go.w * x.w;
           }
         }
@@ -786,6 +881,101 @@ __global__ void __launch_bounds__(256) k_msda_bwd_locattn(const float* __restric
       g_y = group8_allsum(g_y);
       // lane d4 of the group keeps sample s when s % 8 == d4: the group's stores are then runs of 8 consecutive
       // samples (32 B of weights, 64 B of locations) instead of one 4-byte store per sample
+      const int sidx8 = l * points + p;
+      if ((sidx8 & 7) == d4) { keep_w = g_w; keep_x = g_x; keep_y = g_y; }
+      if ((sidx8 & 7) == 7 || (l == levels - 1 && p == points - 1)) {
+        const int first = sidx8 & ~7;
+        if (live && first + d4 <= sidx8) {
+          grad_attn[lw_base + first + d4] = keep_w;
+          *reinterpret_cast<float2*>(grad_loc + (lw_base + first + d4) * 2) = make_float2(keep_x, keep_y);
+        }
+      }
+    }
+  }
+}
+
+// The 4-point form of the kernel above with a level's 16 gathers in flight together (cf. k_msda_fwd_p4).
+struct TapsG {
+  int off[4];
+  float ok[4];       // 1 / 0: the tap exists
+  float lh, lw;
+  float in;          // 1 / 0: the sample lies inside the padded map at all
+};
+__device__ __forceinline__ void taps_grad(float loc_x, float loc_y, int h, int w, int stride_pix, TapsG& t) {
+  const float him = loc_y * (float)h - 0.5f;
+  const float wim = loc_x * (float)w - 0.5f;
+  const bool in = him > -1.f && wim > -1.f && him < (float)h && wim < (float)w;
+  const int hl = (int)floorf(him), wl = (int)floorf(wim);
+  const int hh = hl + 1, wh = wl + 1;
+  t.lh = him - (float)hl;
+  t.lw = wim - (float)wl;
+  t.in = in ? 1.f : 0.f;
+  const bool t0 = in && hl >= 0 && wl >= 0, t1 = in && hl >= 0 && wh <= w - 1;
+  const bool t2 = in && hh <= h - 1 && wl >= 0, t3 = in && hh <= h - 1 && wh <= w - 1;
+  t.off[0] = t0 ? (hl * w + wl) * stride_pix : 0;
+  t.off[1] = t1 ? (hl * w + wh) * stride_pix : 0;
+  t.off[2] = t2 ? (hh * w + wl) * stride_pix : 0;
+  t.off[3] = t3 ? (hh * w + wh) * stride_pix : 0;
+  t.ok[0] = t0 ? 1.f : 0.f; t.ok[1] = t1 ? 1.f : 0.f; t.ok[2] = t2 ? 1.f : 0.f; t.ok[3] = t3 ? 1.f : 0.f;
+}
+
+template <int VK>
+__global__ void __launch_bounds__(256) k_msda_bwd_locattn_p4(const float* __restrict__ grad_out,
+                                                             const void* __restrict__ value,
+                                                             const int64_t* __restrict__ shapes,
+                                                             const int64_t* __restrict__ level_start,
+                                                             const float* __restrict__ loc, const float* __restrict__ attn,
+                                                             int64_t total8, int num_value, int heads, int levels,
+                                                             int num_query, float* __restrict__ grad_loc,
+                                                             float* __restrict__ grad_attn) {
+  constexpr int dim = 32, points = 4;
+  const int stride_pix = heads * dim;
+  const int64_t idx = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+  const bool live = idx < total8;                     // total8 is a multiple of 8: a group of 8 lanes is all in or out
+  const int64_t sidx = live ? idx : total8 - 1;
+  const int d4 = (int)(sidx & 7);
+  int64_t t = sidx >> 3;
+  const int hd = (int)(t % heads);
+  t /= heads;                                         // t = b * num_query + q
+  const int b = (int)(t / num_query);
+  const int64_t vb = (int64_t)b * num_value * stride_pix + hd * dim + d4 * 4;
+  const int64_t lw_base = (t * heads + hd) * levels * points;
+  const float4 go = *reinterpret_cast<const float4*>(grad_out + (t * heads + hd) * dim + d4 * 4);
+  float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;
+  for (int l = 0; l < levels; ++l) {
+    const int h = (int)shapes[l * 2], w = (int)shapes[l * 2 + 1];
+    const int64_t vl = vb + level_start[l] * stride_pix;
+    const float4 xy0 = *reinterpret_cast<const float4*>(loc + (lw_base + l * 4) * 2);
+    const float4 xy1 = *reinterpret_cast<const float4*>(loc + (lw_base + l * 4) * 2 + 4);
+    const float4 aw4 = *reinterpret_cast<const float4*>(attn + lw_base + l * 4);
+    const float awp[4] = {aw4.x, aw4.y, aw4.z, aw4.w};
+    TapsG tp[4];
+    taps_grad(xy0.x, xy0.y, h, w, stride_pix, tp[0]);
+    taps_grad(xy0.z, xy0.w, h, w, stride_pix, tp[1]);
+    taps_grad(xy1.x, xy1.y, h, w, stride_pix, tp[2]);
+    taps_grad(xy1.z, xy1.w, h, w, stride_pix, tp[3]);
+    float4 x[16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[p * 4 + j] = value4<VK>(value, vl + tp[p].off[j]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float s4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = x[p * 4 + j];
+        s4[j] = tp[p].ok[j] * (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w);
+      }
+      const float lh = tp[p].lh, lw = tp[p].lw, uh = 1.f - lh, uw = 1.f - lw;
+      float g_w = uh * uw * s4[0] + uh * lw * s4[1] + lh * uw * s4[2] + lh * lw * s4[3];
+      const float gh = -uw * s4[0] - lw * s4[1] + uw * s4[2] + lw * s4[3];
+      const float gw = -uh * s4[0] + uh * s4[1] - lh * s4[2] + lh * s4[3];
+      float g_x = (float)w * gw * awp[p] * tp[p].in;
+      float g_y = (float)h * gh * awp[p] * tp[p].in;
+      g_w = group8_allsum(g_w * tp[p].in);
+      g_x = group8_allsum(g_x);
+      g_y = group8_allsum(g_y);
       const int sidx8 = l * points + p;
       if ((sidx8 & 7) == d4) { keep_w = g_w; keep_x = g_x; keep_y = g_y; }
       if ((sidx8 & 7) == 7 || (l == levels - 1 && p == points - 1)) {
@@ -820,15 +1010,96 @@ extern "C" int mbv_ms_deform_attn_fwd(const float* value, const int64_t* spatial
   const int64_t total = (int64_t)batch * num_query * num_heads * head_dim;
   if ((head_dim & 3) == 0 && ((reinterpret_cast<size_t>(value) | reinterpret_cast<size_t>(out)) & 15) == 0) {
     const int64_t total4 = total / 4;
-    hipLaunchKernelGGL(k_msda_fwd_v4, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, value,
-                       spatial_shapes, level_start, sampling_loc, attn_weight, total4, num_value, num_heads, head_dim,
-                       num_levels, num_query, num_points, out);
+    if (num_points == 4 && ((reinterpret_cast<size_t>(sampling_loc) | reinterpret_cast<size_t>(attn_weight)) & 15) == 0) {
+      hipLaunchKernelGGL(k_msda_fwd_p4<MBV_DT_F32>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream,
+                         (const void*)value, spatial_shapes, level_start, sampling_loc, attn_weight, total4, num_value,
+                         num_heads, head_dim, num_levels, num_query, out);
+      MBV_CHECK_LAUNCH();
+      return MBV_OK;
+    }
+    hipLaunchKernelGGL(k_msda_fwd_v4<MBV_DT_F32>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream,
+                       (const void*)value, spatial_shapes, level_start, sampling_loc, attn_weight, total4, num_value,
+                       num_heads, head_dim, num_levels, num_query, num_points, out);
     MBV_CHECK_LAUNCH();
     return MBV_OK;
   }
   hipLaunchKernelGGL(k_msda_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, value, spatial_shapes,
                      level_start, sampling_loc, attn_weight, total, num_value, num_heads, head_dim, num_levels,
                      num_query, num_points, out);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// Forward with the value map in 16 bits (value_dtype MBV_DT_BF16 / _F16; MBV_DT_F32 = the entry above): head_dim % 4 == 0.
+extern "C" int mbv_ms_deform_attn_fwd_v(const void* value, int32_t value_dtype, const int64_t* spatial_shapes,
+                                        const int64_t* level_start, const float* sampling_loc, const float* attn_weight,
+                                        int32_t batch, int32_t num_value, int32_t num_heads, int32_t head_dim,
+                                        int32_t num_levels, int32_t num_query, int32_t num_points, float* out, void* stream_) {
+  if (value_dtype == MBV_DT_F32)
+    return mbv_ms_deform_attn_fwd(reinterpret_cast<const float*>(value), spatial_shapes, level_start, sampling_loc,
+                                  attn_weight, batch, num_value, num_heads, head_dim, num_levels, num_query, num_points, out,
+                                  stream_);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0 || num_points <= 0)
+    return MBV_ERR_BAD_ARG;
+  if (value_dtype != MBV_DT_BF16 && value_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
+  if (!pow2_le64(head_dim) || (head_dim & 3)) return MBV_ERR_UNSUPPORTED;
+  if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !out) return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(value) & 7) || (reinterpret_cast<size_t>(out) & 15)) return MBV_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)batch * num_query * num_heads * head_dim / 4;
+  const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+  if (num_points == 4 && ((reinterpret_cast<size_t>(sampling_loc) | reinterpret_cast<size_t>(attn_weight)) & 15) == 0) {
+    if (value_dtype == MBV_DT_BF16)
+      hipLaunchKernelGGL(k_msda_fwd_p4<MBV_DT_BF16>, grid, block, 0, stream, value, spatial_shapes, level_start, sampling_loc,
+                         attn_weight, total4, num_value, num_heads, head_dim, num_levels, num_query, out);
+    else
+      hipLaunchKernelGGL(k_msda_fwd_p4<MBV_DT_F16>, grid, block, 0, stream, value, spatial_shapes, level_start, sampling_loc,
+                         attn_weight, total4, num_value, num_heads, head_dim, num_levels, num_query, out);
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
+  if (value_dtype == MBV_DT_BF16)
+    hipLaunchKernelGGL(k_msda_fwd_v4<MBV_DT_BF16>, grid, block, 0, stream, value, spatial_shapes, level_start, sampling_loc,
+                       attn_weight, total4, num_value, num_heads, head_dim, num_levels, num_query, num_points, out);
+  else
+    hipLaunchKernelGGL(k_msda_fwd_v4<MBV_DT_F16>, grid, block, 0, stream, value, spatial_shapes, level_start, sampling_loc,
+                       attn_weight, total4, num_value, num_heads, head_dim, num_levels, num_query, num_points, out);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// d(location), d(weight) alone (the part-2 kernel of the split backward) with the value map in f32 / bf16 / fp16: head_dim 32.
+extern "C" int mbv_ms_deform_attn_bwd_locattn(const float* grad_out, const void* value, int32_t value_dtype,
+                                              const int64_t* spatial_shapes, const int64_t* level_start,
+                                              const float* sampling_loc, const float* attn_weight, int32_t batch,
+                                              int32_t num_value, int32_t num_heads, int32_t head_dim, int32_t num_levels,
+                                              int32_t num_query, int32_t num_points, float* grad_loc, float* grad_attn,
+                                              void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (batch <= 0 || num_value <= 0 || num_heads <= 0 || num_levels <= 0 || num_query <= 0 || num_points <= 0)
+    return MBV_ERR_BAD_ARG;
+  if (head_dim != 32) return MBV_ERR_UNSUPPORTED;
+  if (!grad_out || !value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_loc || !grad_attn)
+    return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(grad_out) & 15) || (reinterpret_cast<size_t>(value) & (value_dtype == MBV_DT_F32 ? 15 : 7)))
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t total8 = (int64_t)batch * num_query * num_heads * 8;
+  const dim3 grid((unsigned)((total8 + 255) / 256)), block(256);
+  const bool p4 = num_points == 4 && ((reinterpret_cast<size_t>(sampling_loc) | reinterpret_cast<size_t>(attn_weight)) & 15) == 0;
+#define MBV_LOCATTN(VK)                                                                                                  \
+  if (p4)                                                                                                                \
+    hipLaunchKernelGGL(k_msda_bwd_locattn_p4<VK>, grid, block, 0, stream, grad_out, value, spatial_shapes, level_start,  \
+                       sampling_loc, attn_weight, total8, num_value, num_heads, num_levels, num_query, grad_loc,         \
+                       grad_attn);                                                                                       \
+  else                                                                                                                   \
+    hipLaunchKernelGGL(k_msda_bwd_locattn<VK>, grid, block, 0, stream, grad_out, value, spatial_shapes, level_start,     \
+                       sampling_loc, attn_weight, total8, num_value, num_heads, num_levels, num_query, num_points,       \
+                       grad_loc, grad_attn)
+  if (value_dtype == MBV_DT_F32) { MBV_LOCATTN(MBV_DT_F32); }
+  else if (value_dtype == MBV_DT_BF16) { MBV_LOCATTN(MBV_DT_BF16); }
+  else if (value_dtype == MBV_DT_F16) { MBV_LOCATTN(MBV_DT_F16); }
+  else return MBV_ERR_BAD_ARG;
+#undef MBV_LOCATTN
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -902,9 +1173,14 @@ extern "C" int mbv_ms_deform_attn_bwd(const float* grad_out, const float* value,
       }
       if (which & 2) {
         const int64_t total8 = (int64_t)batch * num_query * num_heads * 8;
-        hipLaunchKernelGGL(k_msda_bwd_locattn, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream, grad_out,
-                           value, spatial_shapes, level_start, sampling_loc, attn_weight, total8, num_value, num_heads,
-                           num_levels, num_query, num_points, grad_loc, grad_attn);
+        if (num_points == 4 && ((reinterpret_cast<size_t>(sampling_loc) | reinterpret_cast<size_t>(attn_weight)) & 15) == 0)
+          hipLaunchKernelGGL(k_msda_bwd_locattn_p4<MBV_DT_F32>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                             grad_out, (const void*)value, spatial_shapes, level_start, sampling_loc, attn_weight, total8,
+                             num_value, num_heads, num_levels, num_query, grad_loc, grad_attn);
+        else
+          hipLaunchKernelGGL(k_msda_bwd_locattn<MBV_DT_F32>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                             grad_out, (const void*)value, spatial_shapes, level_start, sampling_loc, attn_weight, total8,
+                             num_value, num_heads, num_levels, num_query, num_points, grad_loc, grad_attn);
         MBV_CHECK_LAUNCH();
       }
       return MBV_OK;

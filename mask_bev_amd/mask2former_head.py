@@ -647,6 +647,16 @@ class Mask2FormerHead(nn.Module):
         last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)                # (B,) = K
         return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()
 
+    @staticmethod
+    def _cached_ready(device):
+        """A tensor that enters one of this head's caches is produced on whatever stream first asks for it — the matcher's,
+        the target preparation's — and then read by all of them for the rest of the run.  Its first readers on OTHER streams
+        would otherwise race with the kernels that fill it (seen as a loss that differed in the 6th digit one run in four,
+        through a half-written row-index vector): wait for it once, here.  (Not during a HIP-graph capture: the eager
+        warm-up steps in front of a capture have filled the caches.)"""
+        if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(device).synchronize()
+
     def _iota(self, n: int, device, div: int = 1, mod: int = 0) -> torch.Tensor:
         key = (n, div, mod, str(device))
         t = self._iota_cache.get(key)
@@ -655,6 +665,7 @@ class Mask2FormerHead(nn.Module):
             t = t // div if div > 1 else t
             t = t % mod if mod > 0 else t
             t = t.to(torch.int32)
+            self._cached_ready(t.device)
             self._iota_cache[key] = t
         return t
 
@@ -664,6 +675,7 @@ class Mask2FormerHead(nn.Module):
         t = self._iota_cache.get(key)
         if t is None:
             t = torch.tensor(list(key[2]), dtype=torch.float32, device=device)
+            self._cached_ready(t.device)
             self._iota_cache[key] = t
         return t
 
@@ -677,6 +689,7 @@ class Mask2FormerHead(nn.Module):
             rank = torch.distributed.get_rank() if (torch.distributed.is_available()
                                                     and torch.distributed.is_initialized()) else 0
             t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device) + rank * 1_000_003
+            self._cached_ready(t.device)
             self._iota_cache[key] = t
         t.add_(0x2545F4914F6CDD1D)            # wraps modulo 2^64
         return t

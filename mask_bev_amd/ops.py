@@ -586,6 +586,11 @@ def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, ho
         check(lib.mbv_ms_deform_attn_bwd_value_packed(_ptr(g_out), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt, host,
                                                       _ptr(dst), _dt_flag(dst.dtype), int(ld), _ptr(ws), ws.numel(), _stream()),
               'mbv_ms_deform_attn_bwd_value_packed')
+        if value.dtype in _LO_DTYPES:                    # the 16-bit value map of the 16-bit compute modes
+            check(lib.mbv_ms_deform_attn_bwd_locattn(_ptr(g_out), _ptr(value), _dt_flag(value.dtype), _ptr(shapes_t),
+                                                     _ptr(level_start), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt,
+                                                     _ptr(g_loc), _ptr(g_attn), _stream()), 'mbv_ms_deform_attn_bwd_locattn')
+            return
         check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
                                          _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(None), _ptr(g_loc),
                                          _ptr(g_attn), 2, _stream()), 'mbv_ms_deform_attn_bwd')
@@ -749,8 +754,16 @@ class _MSDAQuerySide(torch.autograd.Function):
                 # the value map is consumed in f32 (K5): accumulate and store it in f32, no 16-bit round trip + cast.  K17 takes
                 # the f32 bias in its epilogue (the library's addmm first copies the broadcast bias into the f32 result)
                 bvf = bv.float().contiguous()
+                lo_value = False
                 if gemm16_policy() != 'none' and _gemm16_ok(xb.view(b * n, e), wvc) and bvf.data_ptr() % 16 == 0:
-                    value = gemm16_nt(xb.view(b * n, e), wvc, bvf, out_dtype=torch.float32).view(b, n, e)
+                    # The value map in the compute dtype (what this Linear's output IS under the reference's autocast): K5's
+                    # forward and its location / weight gradient are bound by the bytes of their bilinear taps, 128 B per
+                    # (tap, head) in f32.  Needs the packed value gradient (its f64 alternative wants an f32 map), head dim 32.
+                    host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
+                    lo_value = bool(switches.get('msda_value_lowp') and d == 32 and (e + lo + la) % 2 == 0
+                                    and msda_value_packed_ok((b, n, heads, d, levels, n, points), host_b))
+                    value = gemm16_nt(xb.view(b * n, e), wvc, bvf,
+                                      out_dtype=None if lo_value else torch.float32).view(b, n, e)
                 else:
                     value = torch.addmm(bvf, xb.view(b * n, e), wvc.t(), out_dtype=torch.float32).view(b, n, e)
             else:
@@ -770,8 +783,9 @@ class _MSDAQuerySide(torch.autograd.Function):
               'mbv_msda_prepare_fwd_ld')
         del ol
         out = torch.empty((b, n, e), dtype=torch.float32, device=x.device)
-        check(lib.mbv_ms_deform_attn_fwd(_ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc), _ptr(attn), b, n,
-                                         heads, d, levels, n, points, _ptr(out), _stream()), 'mbv_ms_deform_attn_fwd')
+        check(lib.mbv_ms_deform_attn_fwd_v(_ptr(value), _dt_flag(value.dtype), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
+                                           _ptr(attn), b, n, heads, d, levels, n, points, _ptr(out), _stream()),
+              'mbv_ms_deform_attn_fwd_v')
         ctx.save_for_backward(xb, qb, value, loc, attn, shapes_t, level_start, wcat)
         ctx.params = (wv, bv, wo, bo, wa, ba)
         ctx.meta = (heads, levels, points, host, tuple(shapes_host), dt, x.dtype, pos.dtype, tuple(pos.shape))

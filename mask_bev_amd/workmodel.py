@@ -49,6 +49,18 @@ def _msda(a, bwd: bool) -> Work:
     return ('k_msda_fwd_v4', 'hbm', vmap + qmap + samples * 12.0, 0.0)
 
 
+def _msda_typed(a, bwd: bool) -> Work:
+    """mbv_ms_deform_attn_fwd_v / _bwd_locattn: as _msda, the value map in its own element size."""
+    o = 1 if bwd else 0
+    ves = 4.0 if _i(a[1 + o]) == 0 else 2.0
+    b, nv, heads, d, levels, nq, pts = (_i(a[i + o]) for i in (6, 7, 8, 9, 10, 11, 12))
+    samples = b * nq * heads * levels * pts
+    vmap, qmap = b * nv * heads * d * ves, b * nq * heads * d * 4.0
+    if bwd:
+        return ('k_msda_bwd_locattn', 'hbm', vmap + qmap + 2 * samples * 12.0, 0.0)
+    return ('k_msda_fwd_v4', 'hbm', vmap + qmap + samples * 12.0, 0.0)
+
+
 def _msda_value_packed(a) -> Work:
     # grad_out, loc, attn in; grad_value out in its own dtype
     b, nv, heads, d, levels, nq, pts = (_i(a[i]) for i in (3, 4, 5, 6, 7, 8, 9))
@@ -288,6 +300,8 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
     'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
     'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
+    'mbv_ms_deform_attn_fwd_v': lambda a: _msda_typed(a, False),
+    'mbv_ms_deform_attn_bwd_locattn': lambda a: _msda_typed(a, True),
     'mbv_ms_deform_attn_bwd_value_packed': _msda_value_packed,
     'mbv_rowchain_run': _rowchain,
     'mbv_rowchain_run_split': _rowchain_split,

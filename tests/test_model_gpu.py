@@ -553,7 +553,10 @@ def test_deferred_heads_backward_equals_per_layer_backward(device, dtype, monkey
         loss.backward()
         losses[mode] = float(loss.detach())
         grads[mode] = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
-    assert abs(losses['1'] - losses['0']) <= 1e-6 * abs(losses['0'])          # forward values are the same tensors
+    # Forward values are the same tensors up to ONE library effect: MIOpen's bf16 3 x 3 forward of the FPN output convolution
+    # was seen to differ from run to run in the last bf16 bit of one image (same process, same inputs: scratch/dbg_tail.py
+    # prints the first tensor that differs), which moves the loss by 1.7e-6 relative one run in four.  fp32 repeats exactly.
+    assert abs(losses['1'] - losses['0']) <= (1e-6 if dtype == 'fp32' else 1e-5) * abs(losses['0'])
     assert grads['1'].keys() == grads['0'].keys()
     tol = 1e-4 if dtype == 'fp32' else 3e-2
     for k in grads['0']:
