@@ -418,14 +418,17 @@ def aten_work(func, args, kwargs, result, cuda_only: bool = True):
     if not ins and not outs:
         return None
     short = name.split('::')[-1]
+    short_out = str(getattr(func, '_overloadname', '')) == 'out' or (kwargs or {}).get('out') is not None
     if short in ('mm', 'addmm', 'bmm', 'baddbmm', '_scaled_mm'):
-        mats = [t for t in ins if t.dim() >= 2][-2:]
+        # (an out= variant names its destination among the arguments: not an operand)
+        dst = {t.data_ptr() for t in outs}
+        mats = [t for t in ins if t.dim() >= 2 and not (short_out and t.data_ptr() in dst)][-2:]
         if len(mats) == 2:
             a, b = mats
             batch = a.shape[0] if a.dim() == 3 else 1
             m, k, n = a.shape[-2], a.shape[-1], b.shape[-1]
             f32 = a.dtype == torch.float32
-            by = _nbytes(ins) + _nbytes(outs)
+            by = _nbytes([t for t in ins if not (short_out and t.data_ptr() in dst)]) + _nbytes(outs)
             return ('hipblaslt_f32' if f32 else 'hipblaslt_16bit', 'mfma_f32' if f32 else 'mfma', by, 2.0 * batch * m * n * k)
     if short in ('convolution', 'convolution_backward', 'miopen_convolution', 'cudnn_convolution', '_convolution'):
         bwd = short == 'convolution_backward'

@@ -351,6 +351,11 @@ def test_workmodel_prices_library_calls_known_answers():
                                      cuda_only=False)
     assert (fam, bound, fl) == ('hipblaslt_16bit', 'mfma', 2.0 * 4 * 100 * 100 * 64)
     img, ker = torch.zeros(2, 8, 16, 16), torch.zeros(4, 8, 3, 3)
+    # the out= form names its destination among the arguments: not an operand, counted once
+    e, fm, dst = torch.zeros(4, 100, 256), torch.zeros(4, 256, 1024), torch.zeros(4, 100, 1024)
+    fam, bound, by, fl = W.aten_work(A.bmm.out, (e, fm), {'out': dst}, dst, cuda_only=False)
+    assert (fam, bound) == ('hipblaslt_f32', 'mfma_f32') and fl == 2.0 * 4 * 100 * 1024 * 256
+    assert by == 4.0 * (e.numel() + fm.numel() + dst.numel())
     fam, bound, by, fl = W.aten_work(A.convolution.default, (img, ker, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1), {},
                                      torch.zeros(2, 4, 16, 16), cuda_only=False)
     assert (fam, fl) == ('miopen_conv', 2.0 * 2 * 4 * 16 * 16 * 8 * 9)
