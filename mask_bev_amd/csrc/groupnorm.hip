@@ -281,6 +281,36 @@ __global__ void __launch_bounds__(256) k_upsample_bilinear_bwd(const void* __res
   y_hi = y_hi > H - 1 ? H - 1 : y_hi; x_hi = x_hi > W - 1 ? W - 1 : x_hi;
   const long base = plane * (long)H * W;
   float acc = 0.f;
+  constexpr int KW = 8;
+  if (y_hi - y_lo < KW && x_hi - x_lo < KW) {
+    // the adjoint is separable: the row and column weights of the window once per thread (≤ 8 + 8 evaluations of up_axis
+    // instead of one per visited pixel), then every load of a window row before its first use
+    float wy[KW], wx[KW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      int p0, ps; float l;
+      const int y = y_lo + i, x = x_lo + i;
+      up_axis(sh, y <= y_hi ? y : y_hi, ah, p0, ps, l);
+      wy[i] = y <= y_hi ? (p0 == Y ? 1.f - l : 0.f) + (p0 + ps == Y ? l : 0.f) : 0.f;
+      up_axis(sw, x <= x_hi ? x : x_hi, aw, p0, ps, l);
+      wx[i] = x <= x_hi ? (p0 == X ? 1.f - l : 0.f) + (p0 + ps == X ? l : 0.f) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      if (wy[i] == 0.f) continue;                       // (also rows beyond y_hi)
+      const long row = base + (long)(y_lo + i) * W;
+      float g[KW];
+#pragma unroll
+      for (int j = 0; j < KW; ++j) g[j] = wx[j] != 0.f ? ld1(gy, gy_kind, row + x_lo + j) : 0.f;
+      float r = 0.f;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) r += wx[j] * g[j];
+      acc += wy[i] * r;
+    }
+    if (out_kind == MBV_DT_F32) reinterpret_cast<float*>(out)[idx] = acc;
+    else reinterpret_cast<unsigned short*>(out)[idx] = out_kind == MBV_DT_BF16 ? f32_to_bf16_rne(acc) : (unsigned short)f32_to_h16(acc);
+    return;
+  }
   for (int y = y_lo; y <= y_hi; ++y) {
     int y0, ys; float ly;
     up_axis(sh, y, ah, y0, ys, ly);
