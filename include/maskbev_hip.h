@@ -107,6 +107,15 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
  *                       the SUM over the padded copies; sums = (sum dz, sum dz*xhat) f64 → d beta, d gamma
  *   mbv_pfn_bwd_bn      BatchNorm backward in place (dz → dy, dz_pad → summed dy_pad), dt[v] = sum_r dy[r] + dy_pad[v]
  */
+/* K2c — the PFNLayer's `nn.Linear(in, out, bias=False)` (same reference lines) as a streaming exact-f32 GEMM for M >> C, N:
+ * weight_is_nk != 0: y (m, n) = x (m, c) . w^T, w (n, c) with row stride ldw (forward; ldw > c reads a column block of a wider
+ * weight: the [a | max] halves of a layer);  == 0: y (m, n) = x (m, c) . w, w (c, n) with row stride ldw (data gradient).
+ * x, y contiguous f32; c <= 128, n in {32, 64, 96, 128} (mbv_skinny_gemm_f32_supported); c % 4 == 0 needs a 16-byte aligned x.
+ * v_mfma_f32_32x32x2_f32 with the weight held in registers and 32-row tiles of x through wave-private LDS. */
+int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int32_t out_cols);
+int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
+                        int32_t weight_is_nk, void* stream);
+
 int mbv_pfn_stats(float* y, const float* t, float* y_pad, const int32_t* row_start, const int32_t* num_points,
                   int64_t num_pillars, int32_t units, int32_t max_points, double* sums, void* stream);
 

@@ -1,0 +1,170 @@
+// K2c — streaming f32 GEMM for the PillarFeatureNet's Linear layers.
+//
+// mmdet3d `PFNLayer.linear` (`nn.Linear(in, out, bias=False)`, /root/reference: mask_bev/models/encoders/mask_bev_encoders.py:
+// 70-72 → mmdet3d PillarFeatureNet, restated at oracle/maskbev_oracle.py:233-253) on the compact rows of the real points:
+//   Y (M, N) = X (M, C) . W^T      forward           (W (N, C), row stride ldw: the [a | max] halves of a layer's weight are views)
+//   dX (M, N) = dY (M, C) . W      data gradient     (W (C, N))
+// with M = 440 668 rows at the bench batch and C, N <= 128: 100-340 MB streamed for 0.6-7 GFLOP, exact f32.  The library's f32
+// kernels ran these at 2.4-3.3 TB/s (47-104 us each, 0.6 ms per step).  Here a wave owns 32-row tiles of X: the tile goes through a
+// wave-private LDS image (no workgroup barrier anywhere), the whole of W sits in the wave's registers as MFMA B fragments for the
+// whole launch, and the products are v_mfma_f32_32x32x2_f32 (exact f32).  The contraction index is permuted — lane half h takes
+// k in [h C/2, (h + 1) C/2) — so that a lane's A operands of four consecutive steps are ONE 16-byte LDS read; the next tile's
+// global loads are issued before the current tile's products.  Bounds: the f32 MFMA rate (64 -> 128: 46 us) or HBM (10 -> 64: 22 us).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+
+// CPH = padded contraction length / 2 (a multiple of 4), NTW = 32-column tiles per wave
+template <int CPH, int NTW, bool WT, bool VEC>     // VEC: c % 4 == 0 (16-byte tile loads); WT: B(k, n) = W[n * ldw + k] (forward), else W[k * ldw + n] (data gradient)
+__global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, long m, int c, int n, int ldw) {
+  extern __shared__ float lds[];
+  constexpr int CP = 2 * CPH, S = CP + 4;                 // row stride (words): conflict-free 16-byte reads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  float* img = lds + wave * 32 * S;
+  const int n0 = blockIdx.y * NTW * 32;
+
+  // B fragments of the wave's columns, for the whole launch
+  float b[CPH][NTW];
+#pragma unroll
+  for (int s = 0; s < CPH; ++s) {
+    const int k = h * CPH + s;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = n0 + t * 32 + r;
+      b[s][t] = (k < c && col < n) ? (WT ? w[(long)col * ldw + k] : w[(long)k * ldw + col]) : 0.f;
+    }
+  }
+  // zero the image once: the pad columns (k >= c) stay zero
+  for (int i = lane; i < 32 * S; i += 64) img[i] = 0.f;
+
+  const long tiles = (m + 31) / 32;
+  const long stride = (long)gridDim.x * kWaves;
+  constexpr bool vec = VEC;
+  constexpr int NV = VEC ? CP / 8 : 1;                    // float4 per lane of a full 32 x CP tile
+  constexpr int NS = VEC ? 1 : CP / 2;                    // scalar form (c % 4 != 0): 32 c / 64 values per lane
+  float4 pre[NV];
+  float pres[NS];
+  auto fetch = [&](long tile) {
+    const long base = tile * 32 * (long)c, end = m * (long)c;
+    if constexpr (vec) {
+      const int per_row = c >> 2;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int f = i * 64 + lane;                      // float4 index inside the tile's 32 x c block
+        const long g = base + 4L * f;
+        pre[i] = (f < 32 * per_row && g + 3 < end) ? *reinterpret_cast<const float4*>(x + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int f = i * 64 + lane;
+        const long g = base + f;
+        pres[i] = (f < 32 * c && g < end) ? x[g] : 0.f;
+      }
+    }
+  };
+  auto stage = [&]() {
+    if constexpr (vec) {
+      const int per_row = c >> 2;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int f = i * 64 + lane;
+        if (f < 32 * per_row) {
+          const int row = f / per_row, q = f - row * per_row;
+          *reinterpret_cast<float4*>(img + row * S + 4 * q) = pre[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int f = i * 64 + lane;
+        if (f < 32 * c) {
+          const int row = f / c, q = f - row * c;
+          img[row * S + q] = pres[i];
+        }
+      }
+    }
+  };
+
+  long tile = (long)blockIdx.x * kWaves + wave;
+  if (tile < tiles) fetch(tile);
+  for (; tile < tiles; tile += stride) {
+    __builtin_amdgcn_wave_barrier();
+    stage();
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the image is written
+    if (tile + stride < tiles) fetch(tile + stride);
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // the lane's contraction indices are h * CPH + [0, CPH): with the permuted order its A operands are contiguous.
+    // (the image holds row-major [row][k]; half 1's block starts CPH words into the row)
+#pragma unroll
+    for (int j = 0; j < CPH / 4; ++j) {
+      const float4 a4 = *reinterpret_cast<const float4*>(img + r * S + h * CPH + 4 * j);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b[4 * j + s][t], acc[t], 0, 0, 0);
+    }
+    const long row0 = tile * 32;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = n0 + t * 32 + r;
+      if (col < n) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < m) y[row * n + col] = acc[t][i];
+        }
+      }
+    }
+  }
+}
+
+template <int CPH, int NTW>
+int launch(int wt, const float* x, const float* w, float* y, long m, int c, int n, int ldw, hipStream_t st) {
+  const long tiles = (m + 31) / 32;
+  long bx = (tiles + kWaves - 1) / kWaves;
+  if (bx > 512) bx = 512;
+  const dim3 grid((unsigned)bx, (unsigned)((n + NTW * 32 - 1) / (NTW * 32))), block(64 * kWaves);
+  const size_t lds = (size_t)kWaves * 32 * (2 * CPH + 4) * sizeof(float);
+  const bool vec = (c & 3) == 0;
+  if (wt && vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
+  else if (wt) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, false>), grid, block, lds, st, x, w, y, m, c, n, ldw);
+  else if (vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
+  else hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, false>), grid, block, lds, st, x, w, y, m, c, n, ldw);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+}  // namespace
+
+extern "C" int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int32_t out_cols) {
+  return m > 0 && contraction >= 1 && contraction <= 128 && out_cols >= 32 && out_cols <= 128 && out_cols % 32 == 0 &&
+         m * (int64_t)(contraction > out_cols ? contraction : out_cols) < 0x7fffffffffLL;
+}
+
+// weight_is_nk != 0: y (m, n) = x (m, c) . w^T with w (n, c), row stride ldw;  == 0: y (m, n) = x (m, c) . w with w (c, n), row stride ldw.
+extern "C" int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
+                                   int32_t weight_is_nk, void* stream) {
+  if (m < 0 || c <= 0 || n <= 0 || ldw <= 0) return MBV_ERR_BAD_ARG;
+  if (m == 0) return MBV_OK;
+  if (!mbv_skinny_gemm_f32_supported(m, c, n)) return MBV_ERR_UNSUPPORTED;
+  if (!x || !w || !y) return MBV_ERR_BAD_ARG;
+  if ((c & 3) == 0 && (reinterpret_cast<size_t>(x) & 15)) return MBV_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  // register budget: CPH x NTW weight fragments <= 128; 64-column groups for the long contractions
+  if (c <= 16) return n <= 64 ? launch<8, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st) : launch<8, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st);
+  if (c <= 64) return n <= 64 ? launch<32, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st) : launch<32, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st);
+  return launch<64, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st);
+}

@@ -252,14 +252,14 @@ class _PillarFeatureNet(torch.autograd.Function):
                 w = w.float()
                 u = int(w.shape[0])
                 if l == 0:
-                    y = a_prev.mm(w.t())
+                    y = _pfn_mm(a_prev, w, True)
                     ypad = torch.zeros((v, u), dtype=torch.float32, device=dev)     # W . 0
                     t = None
                 else:
                     ca = int(a_prev.shape[1])
-                    y = a_prev.mm(w[:, :ca].t())
-                    ypad = apad_prev.mm(w[:, :ca].t())
-                    t = m_prev.mm(w[:, ca:].t())
+                    y = _pfn_mm(a_prev, w[:, :ca], True)
+                    ypad = _pfn_mm(apad_prev, w[:, :ca], True)
+                    t = _pfn_mm(m_prev, w[:, ca:], True)
                 sums = torch.empty(2 * u, dtype=torch.float64, device=dev)
                 check(lib.mbv_pfn_stats(_ptr(y), _ptr(t), _ptr(ypad), _ptr(row_start), _ptr(num_points), v, u, p,
                                         _ptr(sums), st), 'mbv_pfn_stats')
@@ -319,9 +319,9 @@ class _PillarFeatureNet(torch.autograd.Function):
                     ca = int(a_prev.shape[1])
                     wa, wb = w[:, :ca], w[:, ca:]
                     gw = torch.cat([_wgrad(dy, a_prev) + _wgrad(dypad, apad_prev), _wgrad(dt, m_prev)], dim=1)
-                    da = dy.mm(wa)
-                    sapad = dypad.mm(wa)
-                    dm = dt.mm(wb)
+                    da = _pfn_mm(dy, wa, False)
+                    sapad = _pfn_mm(dypad, wa, False)
+                    dm = _pfn_mm(dt, wb, False)
                 grads[5 * l] = gw.to(dtypes[5 * l])
             # arena parameters: the 3 x 3 small gradients join the end-of-pass grouped accumulate (a (1, n) "column sum")
             # instead of one AccumulateGrad add_ launch each
@@ -330,6 +330,26 @@ class _PillarFeatureNet(torch.autograd.Function):
                     grads[i] = _param_grad_or_defer(ctx.params[i], g)
         ctx.saved = ctx.params = None
         return (d_rows,) + (None,) * 7 + tuple(grads)
+
+
+_PFN_SKINNY_MIN_ROWS = 8192
+
+
+def _pfn_mm(x: torch.Tensor, w: torch.Tensor, weight_is_nk: bool) -> torch.Tensor:
+    """``x @ w.t()`` (weight_is_nk) or ``x @ w`` for the PFN's f32 Linears: K2c for the long row counts (w may be a column
+    block of a wider weight — only its row stride has to be regular), the library otherwise."""
+    m, c = x.shape
+    n = int(w.shape[0] if weight_is_nk else w.shape[1])
+    lib = _lib.load()
+    if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and m >= _PFN_SKINNY_MIN_ROWS
+            and x.is_contiguous() and w.stride(1) == 1 and (w.shape[1] if weight_is_nk else w.shape[0]) == c
+            and switches.get('pfn_skinny') and lib.mbv_skinny_gemm_f32_supported(m, c, n)
+            and (c % 4 != 0 or x.data_ptr() % 16 == 0)):
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        check(lib.mbv_skinny_gemm_f32(_ptr(x), _ptr(w), _ptr(y), m, c, n, int(w.stride(0)), 1 if weight_is_nk else 0,
+                                      _stream()), 'mbv_skinny_gemm_f32')
+        return y
+    return x.mm(w.t() if weight_is_nk else w)
 
 
 def _param_grad_or_defer(p: torch.Tensor, g: torch.Tensor):

@@ -314,6 +314,9 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
     'mbv_add_layernorm_fwd2': lambda a: _add_ln_fwd2(a),
+    'mbv_skinny_gemm_f32': lambda a: ('k_skinny_f32', 'hbm',
+                                      (_i(a[3]) * (_i(a[4]) + _i(a[5])) + _i(a[4]) * _i(a[5])) * 4.0,
+                                      2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
     'mbv_copy_group': lambda a: ('k_copy_group', 'hbm', 2.0 * sum(int(a[2][j]) for j in range(_i(a[3]))), 0.0),
     'mbv_transposed_batch_sum_accum': lambda a: ('k_transposed_batch_sum', 'hbm',
                                                  (_i(a[1]) + 2.0) * _i(a[2]) * _i(a[3]) * 4.0, 0.0),

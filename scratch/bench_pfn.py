@@ -16,7 +16,8 @@ pil = enc._voxel_layer.pillars(scans, prefilter=True)
 print('rows', pil.num_rows, 'pillars', pil.num_pillars)
 go = torch.randn(pil.num_pillars, 128, device=dev)
 res = {}
-for mode in (False, True):
+for mode in (False, True):                          # library f32 GEMMs, then K2c
+    switches.set_value('pfn_skinny', mode)
     for p in enc._voxel_encoder.parameters():
         p.grad = None
     out = enc._voxel_encoder(pil)

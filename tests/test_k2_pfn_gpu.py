@@ -101,3 +101,29 @@ def test_fourier_encoder_matches_dense_oracle(device, group):
               '_encoder._voxel_encoder.pfn_layers.0.linear.weight', '_encoder._voxel_encoder.pfn_layers.1.norm.weight']:
         g, r = got[k].grad.cpu(), sd_g[k].grad
         assert float((g - r).abs().max() / r.abs().max().clamp(min=1e-9)) < 1e-3, k
+
+
+@pytest.mark.parametrize('m,c,n,ldw,nk', [(440668 // 8, 64, 128, 128, True), (5000, 10, 64, 10, True), (5000, 11, 64, 11, True),
+                                         (33, 64, 64, 128, True), (4097, 128, 64, 128, False), (9000, 64, 64, 128, False),
+                                         (9000, 128, 128, 128, False), (70, 16, 32, 16, True), (1000, 64, 96, 64, True)])
+def test_skinny_gemm_f32_equals_float64_product(device, m, c, n, ldw, nk):
+    """K2c (mbv_skinny_gemm_f32): x (m, c) . w^T / x . w in exact f32 on MFMA for every register-tile instantiation, row tails,
+    contraction lengths that are not multiples of 4, and a weight that is a column block of a wider matrix."""
+    from mask_bev_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + c + n)
+    x = torch.randn(m, c, generator=g).to(device)
+    if nk:
+        wfull = torch.randn(n, ldw, generator=g).to(device)
+        w = wfull[:, ldw - c:]                                   # the LAST c columns: a strided view with an offset
+        ref = x.double() @ w.double().t()
+    else:
+        wfull = torch.randn(c, ldw, generator=g).to(device)
+        w = wfull[:, :n]
+        ref = x.double() @ w.double()
+    assert lib.mbv_skinny_gemm_f32_supported(m, c, n)
+    y = torch.full((m, n), float('nan'), device=device)
+    ops.check(lib.mbv_skinny_gemm_f32(ops._ptr(x), ops._ptr(w), ops._ptr(y), m, c, n, int(w.stride(0)), 1 if nk else 0,
+                                      ops._stream()), 'mbv_skinny_gemm_f32')
+    assert torch.isfinite(y).all()
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, c ** 0.5)
