@@ -19,11 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWaves = 4;
 
 // CPH = padded contraction length / 2 (a multiple of 4), NTW = 32-column tiles per wave
-template <int CPH, int NTW, bool WT, bool VEC>     // VEC: c % 4 == 0 (16-byte tile loads); WT: B(k, n) = W[n * ldw + k] (forward), else W[k * ldw + n] (data gradient)
+template <int CPH, int NTW, bool WT, bool VEC>     // VEC: c == 2 CPH exactly (16-byte tile loads, shifts for the row / column split); WT: B(k, n) = W[n * ldw + k] (forward), else W[k * ldw + n] (data gradient)
 __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ y, long m, int c, int n, int ldw) {
   extern __shared__ float lds[];
-  constexpr int CP = 2 * CPH, S = CP + 4;                 // row stride (words): conflict-free 16-byte reads
+  constexpr int CP = 2 * CPH;
+  constexpr int S = (CP > NTW * 32 ? CP : NTW * 32) + 4;  // row stride (words): conflict-free 16-byte reads; the image also
+                                                          // turns the 32 x (32 NTW) result tile into whole rows on its way out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   float* img = lds + wave * 32 * S;
@@ -31,13 +33,28 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
 
   // B fragments of the wave's columns, for the whole launch
   float b[CPH][NTW];
-#pragma unroll
-  for (int s = 0; s < CPH; ++s) {
-    const int k = h * CPH + s;
+  if (WT && VEC && (ldw & 3) == 0 && (reinterpret_cast<size_t>(w) & 15) == 0) {
+    // a lane's CPH contraction indices are consecutive in its weight row: 16-byte loads (a quarter of the requests — with 2 048
+    // waves fetching the same 32 KB, the dword form of this prologue cost as much as the products of a short launch)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int col = n0 + t * 32 + r;
-      b[s][t] = (k < c && col < n) ? (WT ? w[(long)col * ldw + k] : w[(long)k * ldw + col]) : 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < CPH / 4; ++s4) {
+        const float4 v = col < n ? *reinterpret_cast<const float4*>(w + (long)col * ldw + h * CPH + 4 * s4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[4 * s4][t] = v.x; b[4 * s4 + 1][t] = v.y; b[4 * s4 + 2][t] = v.z; b[4 * s4 + 3][t] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < CPH; ++s) {
+      const int k = h * CPH + s;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = n0 + t * 32 + r;
+        b[s][t] = (k < c && col < n) ? (WT ? w[(long)col * ldw + k] : w[(long)k * ldw + col]) : 0.f;
+      }
     }
   }
   // zero the image once: the pad columns (k >= c) stay zero
@@ -53,12 +70,10 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
   auto fetch = [&](long tile) {
     const long base = tile * 32 * (long)c, end = m * (long)c;
     if constexpr (vec) {
-      const int per_row = c >> 2;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int f = i * 64 + lane;                      // float4 index inside the tile's 32 x c block
-        const long g = base + 4L * f;
-        pre[i] = (f < 32 * per_row && g + 3 < end) ? *reinterpret_cast<const float4*>(x + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const long g = base + 4L * (i * 64 + lane);       // float4 index inside the tile's 32 x CP block
+        pre[i] = g + 3 < end ? *reinterpret_cast<const float4*>(x + g) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
@@ -71,14 +86,11 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
   };
   auto stage = [&]() {
     if constexpr (vec) {
-      const int per_row = c >> 2;
+      constexpr int per_row = CP / 4;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int f = i * 64 + lane;
-        if (f < 32 * per_row) {
-          const int row = f / per_row, q = f - row * per_row;
-          *reinterpret_cast<float4*>(img + row * S + 4 * q) = pre[i];
-        }
+        *reinterpret_cast<float4*>(img + (f / per_row) * S + 4 * (f % per_row)) = pre[i];
       }
     } else {
 #pragma unroll
@@ -107,26 +119,38 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     // the lane's contraction indices are h * CPH + [0, CPH): with the permuted order its A operands are contiguous.
     // (the image holds row-major [row][k]; half 1's block starts CPH words into the row)
+    float4 a_cur = *reinterpret_cast<const float4*>(img + r * S + h * CPH);
 #pragma unroll
     for (int j = 0; j < CPH / 4; ++j) {
-      const float4 a4 = *reinterpret_cast<const float4*>(img + r * S + h * CPH + 4 * j);
+      const float4 a4 = a_cur;
+      if (j + 1 < CPH / 4) a_cur = *reinterpret_cast<const float4*>(img + r * S + h * CPH + 4 * (j + 1));   // one read ahead
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b[4 * j + s][t], acc[t], 0, 0, 0);
     }
+    // the result leaves as whole 16-byte pieces of its rows: 32 x (32 NTW) floats through the wave's image (its x tile is
+    // consumed) — 8 NTW stores per lane instead of 16 NTW scattered ones, few enough for the next tile's loads, issued before
+    // them, to be waited for without draining the stores too
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) img[((i & 3) + 8 * (i >> 2) + 4 * h) * S + t * 32 + r] = acc[t][i];
+    __builtin_amdgcn_wave_barrier();
     const long row0 = tile * 32;
+    constexpr int per_out = NTW * 8;                    // float4 per result row
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = n0 + t * 32 + r;
-      if (col < n) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (row < m) y[row * n + col] = acc[t][i];
-        }
-      }
+    for (int i = 0; i < NTW * 4; ++i) {
+      const int f = i * 64 + lane, row = f / per_out, q = f % per_out;
+      const int col = n0 + 4 * q;
+      if (row0 + row < m && col < n)
+        *reinterpret_cast<float4*>(y + (row0 + row) * n + col) = *reinterpret_cast<const float4*>(img + row * S + 4 * q);
+    }
+    if constexpr (!vec) {                               // the pad columns of the x image must read as zero again
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < 32 * S; i += 64) img[i] = 0.f;
     }
   }
 }
@@ -137,8 +161,8 @@ int launch(int wt, const float* x, const float* w, float* y, long m, int c, int 
   long bx = (tiles + kWaves - 1) / kWaves;
   if (bx > 512) bx = 512;
   const dim3 grid((unsigned)bx, (unsigned)((n + NTW * 32 - 1) / (NTW * 32))), block(64 * kWaves);
-  const size_t lds = (size_t)kWaves * 32 * (2 * CPH + 4) * sizeof(float);
-  const bool vec = (c & 3) == 0;
+  const size_t lds = (size_t)kWaves * 32 * ((2 * CPH > NTW * 32 ? 2 * CPH : NTW * 32) + 4) * sizeof(float);
+  const bool vec = c == 2 * CPH && (reinterpret_cast<size_t>(x) & 15) == 0;
   if (wt && vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
   else if (wt) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, false>), grid, block, lds, st, x, w, y, m, c, n, ldw);
   else if (vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
@@ -161,7 +185,7 @@ extern "C" int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int
   if (m == 0) return MBV_OK;
   if (!mbv_skinny_gemm_f32_supported(m, c, n)) return MBV_ERR_UNSUPPORTED;
   if (!x || !w || !y) return MBV_ERR_BAD_ARG;
-  if ((c & 3) == 0 && (reinterpret_cast<size_t>(x) & 15)) return MBV_ERR_UNSUPPORTED;
+  if ((n & 3) || (reinterpret_cast<size_t>(y) & 15)) return MBV_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   // register budget: CPH x NTW weight fragments <= 128; 64-column groups for the long contractions
   if (c <= 16) return n <= 64 ? launch<8, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st) : launch<8, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st);

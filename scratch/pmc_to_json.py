@@ -54,6 +54,7 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_msda_prepare_fwd', r'k_msda_prepare_fwd', []),
     ('k_msda_prepare_bwd', r'k_msda_prepare_bwd', []),
     ('k_match_products', r'k_match_products', []),
+    ('k_skinny_f32', r'k_skinny_f32', []),
     ('k_match_cost', r'k_match_cost', []),
     ('k_copy_group', r'k_copy_group', []),
     ('k_transposed_batch_sum', r'k_transposed_batch_sum', []),
