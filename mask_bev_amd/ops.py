@@ -20,7 +20,16 @@ def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream() -> ctypes.c_void_p:
+    """The current stream's handle for the C ABI.  Through torch's raw accessors when they exist: `torch.cuda.current_stream()`
+    builds a Stream object behind three Python-level device look-ups — 9 us a call, and every launch of the eager sections of a
+    step asks."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -252,14 +261,14 @@ class _PillarFeatureNet(torch.autograd.Function):
                 w = w.float()
                 u = int(w.shape[0])
                 if l == 0:
-                    y = _pfn_mm(a_prev, w, True)
+                    y = _pfn_mm(a_prev, w, True, st)
                     ypad = torch.zeros((v, u), dtype=torch.float32, device=dev)     # W . 0
                     t = None
                 else:
                     ca = int(a_prev.shape[1])
-                    y = _pfn_mm(a_prev, w[:, :ca], True)
-                    ypad = _pfn_mm(apad_prev, w[:, :ca], True)
-                    t = _pfn_mm(m_prev, w[:, ca:], True)
+                    y = _pfn_mm(a_prev, w[:, :ca], True, st)
+                    ypad = _pfn_mm(apad_prev, w[:, :ca], True, st)
+                    t = _pfn_mm(m_prev, w[:, ca:], True, st)
                 sums = torch.empty(2 * u, dtype=torch.float64, device=dev)
                 check(lib.mbv_pfn_stats(_ptr(y), _ptr(t), _ptr(ypad), _ptr(row_start), _ptr(num_points), v, u, p,
                                         _ptr(sums), st), 'mbv_pfn_stats')
@@ -319,9 +328,9 @@ class _PillarFeatureNet(torch.autograd.Function):
                     ca = int(a_prev.shape[1])
                     wa, wb = w[:, :ca], w[:, ca:]
                     gw = torch.cat([_wgrad(dy, a_prev) + _wgrad(dypad, apad_prev), _wgrad(dt, m_prev)], dim=1)
-                    da = _pfn_mm(dy, wa, False)
-                    sapad = _pfn_mm(dypad, wa, False)
-                    dm = _pfn_mm(dt, wb, False)
+                    da = _pfn_mm(dy, wa, False, st)
+                    sapad = _pfn_mm(dypad, wa, False, st)
+                    dm = _pfn_mm(dt, wb, False, st)
                 grads[5 * l] = gw.to(dtypes[5 * l])
             # arena parameters: the 3 x 3 small gradients join the end-of-pass grouped accumulate (a (1, n) "column sum")
             # instead of one AccumulateGrad add_ launch each
@@ -335,19 +344,20 @@ class _PillarFeatureNet(torch.autograd.Function):
 _PFN_SKINNY_MIN_ROWS = 8192
 
 
-def _pfn_mm(x: torch.Tensor, w: torch.Tensor, weight_is_nk: bool) -> torch.Tensor:
+def _pfn_mm(x: torch.Tensor, w: torch.Tensor, weight_is_nk: bool, stream=None) -> torch.Tensor:
     """``x @ w.t()`` (weight_is_nk) or ``x @ w`` for the PFN's f32 Linears: K2c for the long row counts (w may be a column
-    block of a wider weight — only its row stride has to be regular), the library otherwise."""
+    block of a wider weight — only its row stride has to be regular), the library otherwise.  (This runs in the eager
+    section in front of the captured step, where host time is step time: the shape test is arithmetic here — the library
+    repeats it — and the caller hands the stream over.)"""
     m, c = x.shape
     n = int(w.shape[0] if weight_is_nk else w.shape[1])
-    lib = _lib.load()
     if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and m >= _PFN_SKINNY_MIN_ROWS
             and x.is_contiguous() and w.stride(1) == 1 and (w.shape[1] if weight_is_nk else w.shape[0]) == c
-            and switches.get('pfn_skinny') and lib.mbv_skinny_gemm_f32_supported(m, c, n)
-            and (c % 4 != 0 or x.data_ptr() % 16 == 0)):
+            and 1 <= c <= 128 and 32 <= n <= 128 and n % 32 == 0 and switches.get('pfn_skinny')):
         y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        check(lib.mbv_skinny_gemm_f32(_ptr(x), _ptr(w), _ptr(y), m, c, n, int(w.stride(0)), 1 if weight_is_nk else 0,
-                                      _stream()), 'mbv_skinny_gemm_f32')
+        check(_lib.load().mbv_skinny_gemm_f32(_ptr(x), _ptr(w), _ptr(y), m, c, n, int(w.stride(0)),
+                                              1 if weight_is_nk else 0, stream if stream is not None else _stream()),
+              'mbv_skinny_gemm_f32')
         return y
     return x.mm(w.t() if weight_is_nk else w)
 
