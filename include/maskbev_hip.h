@@ -116,6 +116,21 @@ int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int32_t out_co
 int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
                         int32_t weight_is_nk, void* stream);
 
+/* The forward of ALL PFN layers behind one call (the launches above + K2c, issued from inside): the eager section in front of
+ * the captured step pays the host's time per launch.  rows (num_rows, in_features) f32 = the decorated compact rows;
+ * weights[l] (units[l], in_features) for l = 0 and (units[l], 2 * units[l-1]) behind it ([a | max], mmdet3d PFNLayer);
+ * gammas / betas / running_means / running_vars: the layer's BatchNorm1d (running statistics updated in place when training).
+ * Every tensor of the pass lives in `workspace` (f32) at the offsets (in floats) mbv_pfn_forward_layout writes — 11 per
+ * layer: y, y_pad, t, sums (2 units doubles), scale, shift, mean, rstd, a, a_pad, m; -1 = none — and returns the total for;
+ * the last layer's m (num_pillars, units) is the result.  units[l] in {32, 64, 96, 128}, in_features <= 128, <= 8 layers. */
+int64_t mbv_pfn_forward_layout(int64_t num_rows, int64_t num_pillars, const int32_t* units, int32_t num_layers,
+                               int64_t* offsets);
+int mbv_pfn_forward(const float* rows, int32_t in_features, const int32_t* row_start, const int32_t* num_points,
+                    int64_t num_rows, int64_t num_pillars, int32_t max_points, const float* const* weights,
+                    const float* const* gammas, const float* const* betas, float* const* running_means,
+                    float* const* running_vars, const int32_t* units, int32_t num_layers, float eps, float momentum,
+                    int32_t training, float* workspace, int64_t workspace_floats, void* stream);
+
 int mbv_pfn_stats(float* y, const float* t, float* y_pad, const int32_t* row_start, const int32_t* num_points,
                   int64_t num_pillars, int32_t units, int32_t max_points, double* sums, void* stream);
 

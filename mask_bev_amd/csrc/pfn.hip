@@ -491,3 +491,86 @@ extern "C" int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, flo
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
+
+// ---- the whole forward of the PFN layers behind ONE call ------------------------------------------------------------------
+// The layers' forward is 8-9 launches each (two or three Linears, statistics, BatchNorm finalisation, apply + max) and runs in
+// the eager section in front of the captured step, where the host's time per launch IS step time (0.9 ms of host work for
+// 0.4 ms of kernels, scratch/time_encoder_host.py): issued from here it is one boundary crossing.  Every tensor of the
+// forward — and everything the backward wants — lives in ONE caller-provided f32 workspace at the offsets
+// mbv_pfn_forward_layout reports (11 per layer, in floats, -1 = the layer has no such tensor):
+//   0 y (K, U)   1 y_pad (V, U)   2 t (V, U)   3 sums (2 U doubles)   4 scale   5 shift   6 mean   7 rstd (U each)
+//   8 a (K, U)   9 a_pad (V, U)   10 m (V, U)
+extern "C" int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
+                                   int32_t weight_is_nk, void* stream);
+
+static int64_t pfn_align(int64_t floats) { return (floats + 63) / 64 * 64; }        // 256-byte pieces
+
+extern "C" int64_t mbv_pfn_forward_layout(int64_t num_rows, int64_t num_pillars, const int32_t* units, int32_t num_layers,
+                                          int64_t* offsets) {
+  if (num_rows < 0 || num_pillars < 0 || !units || num_layers <= 0) return -1;
+  int64_t off = 0;
+  for (int l = 0; l < num_layers; ++l) {
+    const int64_t u = units[l];
+    if (u <= 0) return -1;
+    const bool last = l == num_layers - 1;
+    const int64_t sizes[11] = {num_rows * u, num_pillars * u, l > 0 ? num_pillars * u : -1, 4 * u, u, u, u, u,
+                               last ? -1 : num_rows * u, last ? -1 : num_pillars * u, num_pillars * u};
+    for (int j = 0; j < 11; ++j) {
+      if (offsets) offsets[l * 11 + j] = sizes[j] < 0 ? -1 : off;
+      if (sizes[j] >= 0) off += pfn_align(sizes[j]);
+    }
+  }
+  return off;
+}
+
+extern "C" int mbv_pfn_forward(const float* rows, int32_t in_features, const int32_t* row_start, const int32_t* num_points,
+                               int64_t num_rows, int64_t num_pillars, int32_t max_points, const float* const* weights,
+                               const float* const* gammas, const float* const* betas, float* const* running_means,
+                               float* const* running_vars, const int32_t* units, int32_t num_layers, float eps,
+                               float momentum, int32_t training, float* workspace, int64_t workspace_floats, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_layers <= 0 || num_layers > 8 || !units || !weights || !gammas || !betas || !running_means || !running_vars)
+    return MBV_ERR_BAD_ARG;
+  if (num_rows <= 0 || num_pillars <= 0 || max_points <= 0 || in_features <= 0) return MBV_ERR_BAD_ARG;
+  if (!rows || !row_start || !num_points || !workspace) return MBV_ERR_BAD_ARG;
+  int64_t offs[8 * 11];
+  const int64_t need = mbv_pfn_forward_layout(num_rows, num_pillars, units, num_layers, offs);
+  if (need < 0) return MBV_ERR_BAD_ARG;
+  if (workspace_floats < need) return MBV_ERR_WORKSPACE;
+  const double count = (double)num_pillars * (double)max_points;
+  const float* a_prev = rows;
+  const float* apad_prev = nullptr;
+  const float* m_prev = nullptr;
+  int c_prev = in_features;
+  for (int l = 0; l < num_layers; ++l) {
+    const int u = units[l];
+    if (int rc = pfn_check(num_pillars, u, max_points)) return rc;
+    if (!weights[l] || !gammas[l] || !betas[l] || !running_means[l] || !running_vars[l]) return MBV_ERR_BAD_ARG;
+    const int64_t* o = offs + l * 11;
+    float* y = workspace + o[0];
+    float* ypad = workspace + o[1];
+    float* t = o[2] >= 0 ? workspace + o[2] : nullptr;
+    double* sums = reinterpret_cast<double*>(workspace + o[3]);
+    float *scale = workspace + o[4], *shift = workspace + o[5], *mean = workspace + o[6], *rstd = workspace + o[7];
+    float* a = o[8] >= 0 ? workspace + o[8] : nullptr;
+    float* apad = o[9] >= 0 ? workspace + o[9] : nullptr;
+    float* m = workspace + o[10];
+    const int ldw = l == 0 ? c_prev : 2 * c_prev;          // layers behind the first read [a | max]: (U, 2 C)
+    if (int rc = mbv_skinny_gemm_f32(a_prev, weights[l], y, num_rows, c_prev, u, ldw, 1, stream_)) return rc;
+    if (l == 0) {
+      MBV_CHECK_HIP(mbv_fill_async(ypad, 0, sizeof(float) * (size_t)num_pillars * u, stream));      // W . 0
+    } else {
+      if (int rc = mbv_skinny_gemm_f32(apad_prev, weights[l], ypad, num_pillars, c_prev, u, ldw, 1, stream_)) return rc;
+      if (int rc = mbv_skinny_gemm_f32(m_prev, weights[l] + c_prev, t, num_pillars, c_prev, u, ldw, 1, stream_)) return rc;
+    }
+    if (int rc = mbv_pfn_stats(y, t, ypad, row_start, num_points, num_pillars, u, max_points, sums, stream_)) return rc;
+    if (int rc = mbv_pfn_bn_finalize(sums, count, gammas[l], betas[l], eps, momentum, training, running_means[l],
+                                     running_vars[l], u, scale, shift, mean, rstd, stream_))
+      return rc;
+    if (int rc = mbv_pfn_apply_max(y, ypad, scale, shift, row_start, num_points, num_pillars, u, max_points, a, apad, m,
+                                   stream_))
+      return rc;
+    a_prev = a; apad_prev = apad; m_prev = m; c_prev = u;
+  }
+  return MBV_OK;
+}

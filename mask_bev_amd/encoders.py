@@ -95,8 +95,7 @@ class PillarFeatureNet(nn.Module):
         out = ops.pfn_layers(rows, p, layers, self.training)                                # K2b
         if self.training:
             with torch.no_grad():
-                for l in self.pfn_layers:
-                    l.norm.num_batches_tracked.add_(1)
+                torch._foreach_add_([l.norm.num_batches_tracked for l in self.pfn_layers], 1)      # one launch
         return out
 
 
