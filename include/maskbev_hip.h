@@ -115,6 +115,9 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
 int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int32_t out_cols);
 int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
                         int32_t weight_is_nk, void* stream);
+/* y (m, n) = x (m, c) . w^T + add[index[row]] (add (*, n) f32, index (m) i64): the forward form with a gathered row addend. */
+int mbv_skinny_gemm_f32_addrows(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
+                                const float* add, const int64_t* index, void* stream);
 
 /* The forward of ALL PFN layers behind one call (the launches above + K2c, issued from inside): the eager section in front of
  * the captured step pays the host's time per launch.  rows (num_rows, in_features) f32 = the decorated compact rows;
@@ -122,11 +125,15 @@ int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int
  * gammas / betas / running_means / running_vars: the layer's BatchNorm1d (running statistics updated in place when training).
  * Every tensor of the pass lives in `workspace` (f32) at the offsets (in floats) mbv_pfn_forward_layout writes — 11 per
  * layer: y, y_pad, t, sums (2 units doubles), scale, shift, mean, rstd, a, a_pad, m; -1 = none — and returns the total for;
- * the last layer's m (num_pillars, units) is the result.  units[l] in {32, 64, 96, 128}, in_features <= 128, <= 8 layers. */
+ * the last layer's m (num_pillars, units) is the result.  units[l] in {32, 64, 96, 128}, in_features <= 128, <= 8 layers.
+ * row_pillar (num_rows) i64, nullable: the pillar of every row (mbv_pfn_decorate writes it).  Given, a layer's pillar term
+ * W_b . max is added to y inside the Linear's launch (mbv_skinny_gemm_f32_addrows) and the BatchNorm statistics are a
+ * streaming column-sum pass over y; without it the per-pillar walk of mbv_pfn_stats does both. */
 int64_t mbv_pfn_forward_layout(int64_t num_rows, int64_t num_pillars, const int32_t* units, int32_t num_layers,
                                int64_t* offsets);
 int mbv_pfn_forward(const float* rows, int32_t in_features, const int32_t* row_start, const int32_t* num_points,
-                    int64_t num_rows, int64_t num_pillars, int32_t max_points, const float* const* weights,
+                    const int64_t* row_pillar, int64_t num_rows, int64_t num_pillars, int32_t max_points,
+                    const float* const* weights,
                     const float* const* gammas, const float* const* betas, float* const* running_means,
                     float* const* running_vars, const int32_t* units, int32_t num_layers, float eps, float momentum,
                     int32_t training, float* workspace, int64_t workspace_floats, void* stream);

@@ -45,7 +45,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                                  c_size_t, _P, _P, _P]),
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
     'mbv_pfn_forward_layout': (ctypes.c_int64, [_L, _L, _P, _I, _P]),
-    'mbv_pfn_forward': (ctypes.c_int, [_P, _I, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _L, _P]),
+    'mbv_pfn_forward': (ctypes.c_int, [_P, _I, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _L, _P]),
+    'mbv_skinny_gemm_f32_addrows': (ctypes.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'mbv_skinny_gemm_f32_supported': (ctypes.c_int, [_L, _I, _I]),
     'mbv_skinny_gemm_f32': (ctypes.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'mbv_msda_prepare_fwd': (ctypes.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

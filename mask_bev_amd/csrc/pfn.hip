@@ -106,18 +106,39 @@ __global__ void __launch_bounds__(256) k_pfn_stats(float* __restrict__ Y, const 
   }
 }
 
+// Σ over the rows of (nparts, 2 U) partial sums → one row, in a fixed order: a workgroup takes 32 columns, 32 part-lanes each
+// (lane j adds the parts congruent to j modulo 32), then the lanes' sums meet in LDS.
+__global__ void __launch_bounds__(1024) k_pfn_fold_parts(const double* __restrict__ parts, int nparts, int U2,
+                                                         double* __restrict__ out) {
+  __shared__ double red[32][33];
+  const int c = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  double a = 0.0;
+  if (col < U2)
+    for (int p = j; p < nparts; p += 32) a += parts[(long)p * U2 + col];
+  red[j][c] = a;
+  __syncthreads();
+  if (j == 0 && col < U2) {
+    double s = 0.0;
+    for (int k = 0; k < 32; ++k) s += red[k][c];
+    out[col] = s;
+  }
+}
+
 // mean / var → scale, shift (+ running-stat update); one workgroup
 __global__ void k_pfn_finalize(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                const float* __restrict__ beta, float eps, float momentum, int training,
                                float* __restrict__ running_mean, float* __restrict__ running_var, int U,
                                float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-                               float* __restrict__ rstd_out) {
+                               float* __restrict__ rstd_out, int nparts) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= U) return;
   float mean, var;
   if (training) {
-    const double m = sums[c] / count;
-    double vv = sums[U + c] / count - m * m;
+    double s0 = 0.0, s1 = 0.0;                     // nparts rows of (2 U) partial sums, added in a fixed order
+    for (int p = 0; p < nparts; ++p) { s0 += sums[(long)p * 2 * U + c]; s1 += sums[(long)p * 2 * U + U + c]; }
+    const double m = s0 / count;
+    double vv = s1 / count - m * m;
     if (vv < 0.0) vv = 0.0;
     mean = (float)m;
     var = (float)vv;
@@ -440,7 +461,7 @@ extern "C" int mbv_pfn_bn_finalize(const double* sums, double count, const float
   if (!sums || !gamma || !beta || !running_mean || !running_var || !scale || !shift || !mean || !rstd)
     return MBV_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pfn_finalize, dim3((units + 63) / 64), dim3(64), 0, stream, sums, count, gamma, beta, eps,
-                     momentum, training, running_mean, running_var, units, scale, shift, mean, rstd);
+                     momentum, training, running_mean, running_var, units, scale, shift, mean, rstd, 1);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -492,6 +513,91 @@ extern "C" int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, flo
   return MBV_OK;
 }
 
+// ---- BatchNorm statistics as a STREAM ------------------------------------------------------------------------------------
+// With the pillar term already inside y (K2c's gathered addend), Σ y and Σ y² over the real rows no longer need the pillar
+// structure: a column-sum pass at streaming rate (k_pfn_stats walks pillar by pillar, lane = channel, and rewrites y: 1.1-2.2
+// TB/s).  A thread owns 4 adjacent channels; f32 partials are folded into f64 every 64 rows; every block leaves one row of
+// (2 U) doubles — added in a fixed order by k_pfn_finalize, no atomics.  The last blocks take the padded rows instead: pillar p's
+// representative row y_pad[p] (+ t[p], stored back) counts P - n_p times.
+constexpr int kStatRowBlocks = 512, kStatPadBlocks = 256, kStatParts = kStatRowBlocks + kStatPadBlocks;
+
+__global__ void __launch_bounds__(256) k_pfn_colstats(const float* __restrict__ Y, long K, float* __restrict__ Ypad,
+                                                      const float* __restrict__ T, const int* __restrict__ num_points,
+                                                      long V, int U, int P, double* __restrict__ parts) {
+  __shared__ double red[2][256][4];
+  const int u4 = U >> 2;                                  // threads per row
+  const int sub = threadIdx.x % u4, lanes_rows = 256 / u4, rsub = threadIdx.x / u4;
+  const bool active = rsub < lanes_rows;
+  double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  int since = 0;
+  auto fold = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ds[k] += s[k]; dq[k] += q[k]; s[k] = 0.f; q[k] = 0.f; }
+    since = 0;
+  };
+  if ((int)blockIdx.x < kStatRowBlocks) {
+    const long per = (K + kStatRowBlocks - 1) / kStatRowBlocks;
+    const long r0 = (long)blockIdx.x * per, r1 = r0 + per < K ? r0 + per : K;
+    if (active) {
+      for (long r = r0 + rsub; r < r1; r += 4L * lanes_rows) {          // four rows in flight per thread
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long rr = r + (long)j * lanes_rows;
+          v[j] = rr < r1 ? *reinterpret_cast<const float4*>(Y + rr * U + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[0] += v[j].x; s[1] += v[j].y; s[2] += v[j].z; s[3] += v[j].w;
+          q[0] += v[j].x * v[j].x; q[1] += v[j].y * v[j].y; q[2] += v[j].z * v[j].z; q[3] += v[j].w * v[j].w;
+        }
+        if (++since == 16) fold();
+      }
+    }
+  } else {
+    const int pb = (int)blockIdx.x - kStatRowBlocks;
+    const long per = (V + kStatPadBlocks - 1) / kStatPadBlocks;
+    const long p0 = (long)pb * per, p1 = p0 + per < V ? p0 + per : V;
+    if (active) {
+      for (long p = p0 + rsub; p < p1; p += 4L * lanes_rows) {             // four pillars in flight per thread
+        float4 v[4], t[4];
+        int np[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long pp = p + (long)j * lanes_rows;
+          const bool in = pp < p1;
+          v[j] = in ? *reinterpret_cast<const float4*>(Ypad + pp * U + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+          t[j] = (in && T) ? *reinterpret_cast<const float4*>(T + pp * U + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+          np[j] = in ? num_points[pp] : P;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long pp = p + (long)j * lanes_rows;
+          v[j].x += t[j].x; v[j].y += t[j].y; v[j].z += t[j].z; v[j].w += t[j].w;
+          if (T && pp < p1) *reinterpret_cast<float4*>(Ypad + pp * U + 4 * sub) = v[j];
+          const float mult = (float)(P - np[j]);
+          s[0] += mult * v[j].x; s[1] += mult * v[j].y; s[2] += mult * v[j].z; s[3] += mult * v[j].w;
+          q[0] += mult * v[j].x * v[j].x; q[1] += mult * v[j].y * v[j].y; q[2] += mult * v[j].z * v[j].z;
+          q[3] += mult * v[j].w * v[j].w;
+        }
+        if (++since == 16) fold();
+      }
+    }
+  }
+  fold();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = ds[k]; red[1][threadIdx.x][k] = dq[k]; }
+  __syncthreads();
+  // the threads of one channel group: sub, sub + u4, ...: channel c = 4 sub + k
+  for (int i = threadIdx.x; i < 2 * U; i += 256) {
+    const int half = i / U, c = i - half * U, sb = c >> 2, k = c & 3;
+    double a = 0.0;
+    for (int j = 0; j < lanes_rows; ++j) a += red[half][j * u4 + sb][k];
+    parts[(long)blockIdx.x * 2 * U + i] = a;
+  }
+}
+
 // ---- the whole forward of the PFN layers behind ONE call ------------------------------------------------------------------
 // The layers' forward is 8-9 launches each (two or three Linears, statistics, BatchNorm finalisation, apply + max) and runs in
 // the eager section in front of the captured step, where the host's time per launch IS step time (0.9 ms of host work for
@@ -513,7 +619,7 @@ extern "C" int64_t mbv_pfn_forward_layout(int64_t num_rows, int64_t num_pillars,
     const int64_t u = units[l];
     if (u <= 0) return -1;
     const bool last = l == num_layers - 1;
-    const int64_t sizes[11] = {num_rows * u, num_pillars * u, l > 0 ? num_pillars * u : -1, 4 * u, u, u, u, u,
+    const int64_t sizes[11] = {num_rows * u, num_pillars * u, l > 0 ? num_pillars * u : -1, (int64_t)(kStatParts + 1) * 4 * u, u, u, u, u,
                                last ? -1 : num_rows * u, last ? -1 : num_pillars * u, num_pillars * u};
     for (int j = 0; j < 11; ++j) {
       if (offsets) offsets[l * 11 + j] = sizes[j] < 0 ? -1 : off;
@@ -523,8 +629,12 @@ extern "C" int64_t mbv_pfn_forward_layout(int64_t num_rows, int64_t num_pillars,
   return off;
 }
 
+extern "C" int mbv_skinny_gemm_f32_addrows(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n,
+                                           int32_t ldw, const float* add, const int64_t* index, void* stream);
+
 extern "C" int mbv_pfn_forward(const float* rows, int32_t in_features, const int32_t* row_start, const int32_t* num_points,
-                               int64_t num_rows, int64_t num_pillars, int32_t max_points, const float* const* weights,
+                               const int64_t* row_pillar, int64_t num_rows, int64_t num_pillars, int32_t max_points,
+                               const float* const* weights,
                                const float* const* gammas, const float* const* betas, float* const* running_means,
                                float* const* running_vars, const int32_t* units, int32_t num_layers, float eps,
                                float momentum, int32_t training, float* workspace, int64_t workspace_floats, void* stream_) {
@@ -556,17 +666,37 @@ extern "C" int mbv_pfn_forward(const float* rows, int32_t in_features, const int
     float* apad = o[9] >= 0 ? workspace + o[9] : nullptr;
     float* m = workspace + o[10];
     const int ldw = l == 0 ? c_prev : 2 * c_prev;          // layers behind the first read [a | max]: (U, 2 C)
-    if (int rc = mbv_skinny_gemm_f32(a_prev, weights[l], y, num_rows, c_prev, u, ldw, 1, stream_)) return rc;
+    const bool stream_stats = row_pillar != nullptr && (u & 3) == 0 && 256 % (u >> 2) == 0;
     if (l == 0) {
+      if (int rc = mbv_skinny_gemm_f32(a_prev, weights[l], y, num_rows, c_prev, u, ldw, 1, stream_)) return rc;
       MBV_CHECK_HIP(mbv_fill_async(ypad, 0, sizeof(float) * (size_t)num_pillars * u, stream));      // W . 0
     } else {
-      if (int rc = mbv_skinny_gemm_f32(apad_prev, weights[l], ypad, num_pillars, c_prev, u, ldw, 1, stream_)) return rc;
+      // the pillar term t = W_b . max first: with the streamed statistics y leaves K2c with t[pillar(row)] already added
       if (int rc = mbv_skinny_gemm_f32(m_prev, weights[l] + c_prev, t, num_pillars, c_prev, u, ldw, 1, stream_)) return rc;
+      if (stream_stats) {
+        if (int rc = mbv_skinny_gemm_f32_addrows(a_prev, weights[l], y, num_rows, c_prev, u, ldw, t, row_pillar, stream_)) return rc;
+      } else {
+        if (int rc = mbv_skinny_gemm_f32(a_prev, weights[l], y, num_rows, c_prev, u, ldw, 1, stream_)) return rc;
+      }
+      if (int rc = mbv_skinny_gemm_f32(apad_prev, weights[l], ypad, num_pillars, c_prev, u, ldw, 1, stream_)) return rc;
     }
-    if (int rc = mbv_pfn_stats(y, t, ypad, row_start, num_points, num_pillars, u, max_points, sums, stream_)) return rc;
-    if (int rc = mbv_pfn_bn_finalize(sums, count, gammas[l], betas[l], eps, momentum, training, running_means[l],
-                                     running_vars[l], u, scale, shift, mean, rstd, stream_))
-      return rc;
+    if (stream_stats) {
+      hipLaunchKernelGGL(k_pfn_colstats, dim3(kStatParts), dim3(256), 0, stream, y, (long)num_rows, ypad, t, num_points,
+                         (long)num_pillars, u, max_points, sums);
+      MBV_CHECK_LAUNCH();
+      // parts → one row (stored behind the parts), then the usual finalisation
+      double* total = sums + (size_t)kStatParts * 2 * u;
+      hipLaunchKernelGGL(k_pfn_fold_parts, dim3((2 * u + 31) / 32), dim3(1024), 0, stream, sums, kStatParts, 2 * u, total);
+      MBV_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_pfn_finalize, dim3((u + 63) / 64), dim3(64), 0, stream, total, count, gammas[l], betas[l], eps, momentum,
+                         training, running_means[l], running_vars[l], u, scale, shift, mean, rstd, 1);
+      MBV_CHECK_LAUNCH();
+    } else {
+      if (int rc = mbv_pfn_stats(y, t, ypad, row_start, num_points, num_pillars, u, max_points, sums, stream_)) return rc;
+      if (int rc = mbv_pfn_bn_finalize(sums, count, gammas[l], betas[l], eps, momentum, training, running_means[l],
+                                       running_vars[l], u, scale, shift, mean, rstd, stream_))
+        return rc;
+    }
     if (int rc = mbv_pfn_apply_max(y, ypad, scale, shift, row_start, num_points, num_pillars, u, max_points, a, apad, m,
                                    stream_))
       return rc;

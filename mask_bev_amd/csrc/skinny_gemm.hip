@@ -19,9 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWaves = 4;
 
 // CPH = padded contraction length / 2 (a multiple of 4), NTW = 32-column tiles per wave
-template <int CPH, int NTW, bool WT, bool VEC>     // VEC: c == 2 CPH exactly (16-byte tile loads, shifts for the row / column split); WT: B(k, n) = W[n * ldw + k] (forward), else W[k * ldw + n] (data gradient)
+// ADD: y[row] += add[index[row]] on the way out (the PFNLayer's W_b . max(pillar) term: one (pillars, N) product gathered per row
+// instead of a second pass over y that adds it)
+template <int CPH, int NTW, bool WT, bool VEC, bool ADD = false>     // VEC: c == 2 CPH exactly (16-byte tile loads, shifts for the row / column split); WT: B(k, n) = W[n * ldw + k] (forward), else W[k * ldw + n] (data gradient)
 __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ y, long m, int c, int n, int ldw) {
+                                                            float* __restrict__ y, long m, int c, int n, int ldw,
+                                                            const float* __restrict__ add = nullptr,
+                                                            const int64_t* __restrict__ index = nullptr) {
   extern __shared__ float lds[];
   constexpr int CP = 2 * CPH;
   constexpr int S = (CP > NTW * 32 ? CP : NTW * 32) + 4;  // row stride (words): conflict-free 16-byte reads; the image also
@@ -112,6 +116,10 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the image is written
     if (tile + stride < tiles) fetch(tile + stride);
+    // (ADD) the addend row of tile row (lane & 31): rows of a tile are handed round by shuffles on the way out, so every
+    // gathered load below depends on nothing but this one
+    long my_index = 0;
+    if constexpr (ADD) my_index = tile * 32 + (lane & 31) < m ? index[tile * 32 + (lane & 31)] : 0;
     f32x16 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -141,12 +149,36 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
     __builtin_amdgcn_wave_barrier();
     const long row0 = tile * 32;
     constexpr int per_out = NTW * 8;                    // float4 per result row
+    if constexpr (ADD) {
+      // all gathered addend pieces of the tile first (NTW * 4 independent 16-byte loads per lane), then the stores
+      float4 tadd[NTW * 4];
 #pragma unroll
-    for (int i = 0; i < NTW * 4; ++i) {
-      const int f = i * 64 + lane, row = f / per_out, q = f % per_out;
-      const int col = n0 + 4 * q;
-      if (row0 + row < m && col < n)
-        *reinterpret_cast<float4*>(y + (row0 + row) * n + col) = *reinterpret_cast<const float4*>(img + row * S + 4 * q);
+      for (int i = 0; i < NTW * 4; ++i) {
+        const int f = i * 64 + lane, row = f / per_out, q = f % per_out;
+        const int col = n0 + 4 * q;
+        const int lo = __shfl((int)(my_index & 0xffffffffL), row), hi = __shfl((int)(my_index >> 32), row);
+        const long pil = ((long)hi << 32) | (unsigned)lo;
+        tadd[i] = (row0 + row < m && col < n) ? *reinterpret_cast<const float4*>(add + pil * n + col)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NTW * 4; ++i) {
+        const int f = i * 64 + lane, row = f / per_out, q = f % per_out;
+        const int col = n0 + 4 * q;
+        if (row0 + row < m && col < n) {
+          float4 v = *reinterpret_cast<const float4*>(img + row * S + 4 * q);
+          v.x += tadd[i].x; v.y += tadd[i].y; v.z += tadd[i].z; v.w += tadd[i].w;
+          *reinterpret_cast<float4*>(y + (row0 + row) * n + col) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NTW * 4; ++i) {
+        const int f = i * 64 + lane, row = f / per_out, q = f % per_out;
+        const int col = n0 + 4 * q;
+        if (row0 + row < m && col < n)
+          *reinterpret_cast<float4*>(y + (row0 + row) * n + col) = *reinterpret_cast<const float4*>(img + row * S + 4 * q);
+      }
     }
     if constexpr (!vec) {                               // the pad columns of the x image must read as zero again
       __builtin_amdgcn_wave_barrier();
@@ -156,17 +188,25 @@ __global__ void __launch_bounds__(64 * kWaves) k_skinny_f32(const float* __restr
 }
 
 template <int CPH, int NTW>
-int launch(int wt, const float* x, const float* w, float* y, long m, int c, int n, int ldw, hipStream_t st) {
+int launch(int wt, const float* x, const float* w, float* y, long m, int c, int n, int ldw, hipStream_t st,
+           const float* add = nullptr, const int64_t* index = nullptr) {
   const long tiles = (m + 31) / 32;
   long bx = (tiles + kWaves - 1) / kWaves;
   if (bx > 512) bx = 512;
   const dim3 grid((unsigned)bx, (unsigned)((n + NTW * 32 - 1) / (NTW * 32))), block(64 * kWaves);
   const size_t lds = (size_t)kWaves * 32 * ((2 * CPH > NTW * 32 ? 2 * CPH : NTW * 32) + 4) * sizeof(float);
   const bool vec = c == 2 * CPH && (reinterpret_cast<size_t>(x) & 15) == 0;
-  if (wt && vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
-  else if (wt) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, false>), grid, block, lds, st, x, w, y, m, c, n, ldw);
-  else if (vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, true>), grid, block, lds, st, x, w, y, m, c, n, ldw);
-  else hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, false>), grid, block, lds, st, x, w, y, m, c, n, ldw);
+  if (add) {                                             // (forward form only)
+    if (!wt) return MBV_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, true, true>), grid, block, lds, st, x, w, y, m, c, n, ldw, add, index);
+    else hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, false, true>), grid, block, lds, st, x, w, y, m, c, n, ldw, add, index);
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
+  if (wt && vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, true>), grid, block, lds, st, x, w, y, m, c, n, ldw, nullptr, nullptr);
+  else if (wt) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, true, false>), grid, block, lds, st, x, w, y, m, c, n, ldw, nullptr, nullptr);
+  else if (vec) hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, true>), grid, block, lds, st, x, w, y, m, c, n, ldw, nullptr, nullptr);
+  else hipLaunchKernelGGL((k_skinny_f32<CPH, NTW, false, false>), grid, block, lds, st, x, w, y, m, c, n, ldw, nullptr, nullptr);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -178,6 +218,26 @@ extern "C" int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int
          m * (int64_t)(contraction > out_cols ? contraction : out_cols) < 0x7fffffffffLL;
 }
 
+static int skinny_dispatch(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
+                           int32_t weight_is_nk, const float* add, const int64_t* index, hipStream_t st) {
+  if (c <= 16) return n <= 64 ? launch<8, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st, add, index)
+                              : launch<8, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st, add, index);
+  if (c <= 64) return n <= 64 ? launch<32, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st, add, index)
+                              : launch<32, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st, add, index);
+  return launch<64, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st, add, index);
+}
+
+// y (m, n) = x (m, c) . w^T + add[index[row]]: the forward form with a gathered row addend (add (*, n) f32, index (m) i64).
+extern "C" int mbv_skinny_gemm_f32_addrows(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n,
+                                           int32_t ldw, const float* add, const int64_t* index, void* stream) {
+  if (m < 0 || c <= 0 || n <= 0 || ldw <= 0) return MBV_ERR_BAD_ARG;
+  if (m == 0) return MBV_OK;
+  if (!mbv_skinny_gemm_f32_supported(m, c, n)) return MBV_ERR_UNSUPPORTED;
+  if (!x || !w || !y || !add || !index) return MBV_ERR_BAD_ARG;
+  if ((n & 3) || ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(add)) & 15)) return MBV_ERR_UNSUPPORTED;
+  return skinny_dispatch(x, w, y, m, c, n, ldw, 1, add, index, (hipStream_t)stream);
+}
+
 // weight_is_nk != 0: y (m, n) = x (m, c) . w^T with w (n, c), row stride ldw;  == 0: y (m, n) = x (m, c) . w with w (c, n), row stride ldw.
 extern "C" int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,
                                    int32_t weight_is_nk, void* stream) {
@@ -186,9 +246,6 @@ extern "C" int mbv_skinny_gemm_f32(const float* x, const float* w, float* y, int
   if (!mbv_skinny_gemm_f32_supported(m, c, n)) return MBV_ERR_UNSUPPORTED;
   if (!x || !w || !y) return MBV_ERR_BAD_ARG;
   if ((n & 3) || (reinterpret_cast<size_t>(y) & 15)) return MBV_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
   // register budget: CPH x NTW weight fragments <= 128; 64-column groups for the long contractions
-  if (c <= 16) return n <= 64 ? launch<8, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st) : launch<8, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st);
-  if (c <= 64) return n <= 64 ? launch<32, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st) : launch<32, 4>(weight_is_nk, x, w, y, m, c, n, ldw, st);
-  return launch<64, 2>(weight_is_nk, x, w, y, m, c, n, ldw, st);
+  return skinny_dispatch(x, w, y, m, c, n, ldw, weight_is_nk, nullptr, nullptr, (hipStream_t)stream);
 }

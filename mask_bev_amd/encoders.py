@@ -85,14 +85,14 @@ class PillarFeatureNet(nn.Module):
         self.point_cloud_range = [float(v) for v in point_cloud_range]
 
     def forward(self, p: Pillars) -> torch.Tensor:
-        rows, _ = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)              # K2a: (K, D+7)
-        return self.forward_rows(rows, p)
+        rows, row_pillar = ops.pfn_decorate(p, self.voxel_size, self.point_cloud_range)     # K2a: (K, D+7)
+        return self.forward_rows(rows, p, row_pillar)
 
-    def forward_rows(self, rows: torch.Tensor, p: Pillars) -> torch.Tensor:
+    def forward_rows(self, rows: torch.Tensor, p: Pillars, row_pillar: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The PFN layers on already decorated compact rows (K, in_channels + 7)."""
         layers = [(l.linear.weight, l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var, l.norm.eps,
                    l.norm.momentum) for l in self.pfn_layers]
-        out = ops.pfn_layers(rows, p, layers, self.training)                                # K2b
+        out = ops.pfn_layers(rows, p, layers, self.training, row_pillar)                    # K2b
         if self.training:
             with torch.no_grad():
                 torch._foreach_add_([l.norm.num_batches_tracked for l in self.pfn_layers], 1)      # one launch

@@ -244,7 +244,7 @@ class _PillarFeatureNet(torch.autograd.Function):
     statistics / pillar indices must not lose precision."""
 
     @staticmethod
-    def forward(ctx, rows, row_start, num_points, v, p, training, eps, momentum, *params):
+    def forward(ctx, rows, row_start, num_points, v, p, training, eps, momentum, row_pillar, *params):
         lib = _lib.load()
         _need_gpu(rows, row_start, num_points)
         dev = rows.device
@@ -271,7 +271,11 @@ class _PillarFeatureNet(torch.autograd.Function):
             total = int(lib.mbv_pfn_forward_layout(k, v, uarr, n, offs))
             ws = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
             ptrs = [(ctypes.c_void_p * n)(*[params[5 * l + j].data_ptr() for l in range(n)]) for j in range(5)]
-            check(lib.mbv_pfn_forward(_ptr(rows), int(rows.shape[1]), _ptr(row_start), _ptr(num_points), k, v, p, ptrs[0],
+            rp = None
+            if (row_pillar is not None and row_pillar.dtype == torch.int64 and row_pillar.is_contiguous()
+                    and int(row_pillar.shape[0]) == k and switches.get('pfn_stream_stats')):
+                rp = row_pillar          # the pillar term inside the Linear's launch, the statistics as a streaming pass
+            check(lib.mbv_pfn_forward(_ptr(rows), int(rows.shape[1]), _ptr(row_start), _ptr(num_points), _ptr(rp), k, v, p, ptrs[0],
                                       ptrs[1], ptrs[2], ptrs[3], ptrs[4], uarr, n, float(eps), float(momentum),
                                       1 if training else 0, _ptr(ws), total, st), 'mbv_pfn_forward')
             ctx.saved = None
@@ -378,7 +382,7 @@ class _PillarFeatureNet(torch.autograd.Function):
                 if g is not None:
                     grads[i] = _param_grad_or_defer(ctx.params[i], g)
         ctx.saved = ctx.params = ctx.packed = None
-        return (d_rows,) + (None,) * 7 + tuple(grads)
+        return (d_rows,) + (None,) * 8 + tuple(grads)
 
 
 _PFN_SKINNY_MIN_ROWS = 8192
@@ -414,15 +418,18 @@ def _param_grad_or_defer(p: torch.Tensor, g: torch.Tensor):
     return g.to(p.dtype)
 
 
-def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool) -> torch.Tensor:
+def pfn_layers(rows: torch.Tensor, p: 'Pillars', layers, training: bool,
+               row_pillar: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PFNLayer stack on the compact decorated rows (K2b).  ``layers``: sequence of (weight, bn_weight, bn_bias,
-    running_mean, running_var, eps, momentum); running buffers are updated in place in training mode."""
+    running_mean, running_var, eps, momentum); running buffers are updated in place in training mode.  ``row_pillar`` (K,)
+    i64, the pillar of every row (:func:`pfn_decorate` returns it): lets the one-call forward add a layer's pillar term inside
+    its Linear and take the BatchNorm statistics as a streaming pass."""
     flat = []
     for (w, g, b, rm, rv, _eps, _mom) in layers:
         flat += [w, g, b, rm, rv]
     eps, mom = layers[0][5], layers[0][6]
     return _PillarFeatureNet.apply(rows, p.row_start, p.num_points, p.num_pillars, p.max_points, training, eps, mom,
-                                   *flat)
+                                   row_pillar, *flat)
 
 
 # --------------------------------------------------------------------------------------

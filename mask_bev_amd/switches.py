@@ -46,6 +46,7 @@ _DEFAULTS: Dict[str, Any] = {
     'ln_fanout': True,
     'conv1x1_tokens': True,
     'pos_share': True,            # one d(pos) product for the pixel decoder's six layers (ops.PosGradShare)
+    'pfn_stream_stats': True,     # pillar term inside the Linear's launch + streaming BatchNorm statistics (one-call forward)
     'pfn_one_call': True,         # all PFN layers' forward behind one C-ABI call (host time of the eager section)
     'pfn_skinny': True,           # the PFN's f32 Linears on K2c (streaming exact-f32 MFMA GEMM)
     'msda_value_lowp': True,      # K5's value map in the compute dtype (16-bit modes)

@@ -52,10 +52,10 @@ def _msda(a, bwd: bool) -> Work:
 def _pfn_forward(a) -> Work:
     """mbv_pfn_forward: per layer the Linear(s) (rows read, y written), the statistics pass (y read), apply + max (y read, a
     written): one family, `k_pfn_forward`, for the 8-9 launches per layer it issues."""
-    k, v, n = _i(a[4]), _i(a[5]), _i(a[13])
+    k, v, n = _i(a[5]), _i(a[6]), _i(a[14])
     c, by, fl = _i(a[1]), 0.0, 0.0
     for l in range(n):
-        u = int(a[12][l])
+        u = int(a[13][l])
         last = l == n - 1
         by += (k * (c + u) + k * u + k * u + (0 if last else k * u) + 6.0 * v * u) * 4.0
         fl += 2.0 * k * c * u + (4.0 * v * c * u if l else 0.0)
@@ -329,6 +329,9 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
     'mbv_add_layernorm_fwd2': lambda a: _add_ln_fwd2(a),
     'mbv_pfn_forward': lambda a: _pfn_forward(a),
+    'mbv_skinny_gemm_f32_addrows': lambda a: ('k_skinny_f32', 'hbm',
+                                              (_i(a[3]) * (_i(a[4]) + _i(a[5])) + _i(a[4]) * _i(a[5])) * 4.0,
+                                              2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
     'mbv_skinny_gemm_f32': lambda a: ('k_skinny_f32', 'hbm',
                                       (_i(a[3]) * (_i(a[4]) + _i(a[5])) + _i(a[4]) * _i(a[5])) * 4.0,
                                       2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
