@@ -19,9 +19,13 @@ def _rel(a, b):
                                                     ([128, 128, 128], 32, [6000], True),
                                                     ([64, 128], 4, [1500, 10, 900], True),
                                                     ([32, 32, 32], 8, [2500], False)])
-def test_pfn_matches_dense_oracle(device, chans, P, sizes, training, pc_dim):
-    from mask_bev_amd import ops
+@pytest.mark.parametrize('path', ['stream', 'walk', 'layers'])
+def test_pfn_matches_dense_oracle(device, chans, P, sizes, training, pc_dim, path, monkeypatch):
+    """path: 'stream' = the one-call forward with the pillar term inside K2c and streamed BatchNorm statistics (the default),
+    'walk' = the one-call forward with the per-pillar statistics walk, 'layers' = one C-ABI call per kernel."""
+    from mask_bev_amd import ops, switches
     from mask_bev_amd.encoders import PillarFeatureNet
+    switches.patch(monkeypatch, pfn_stream_stats=(path == 'stream'), pfn_one_call=(path != 'layers'))
     kw = dict(x_range=(-10, 10), y_range=(-10, 10), z_range=(-3, 1), voxel_size=0.25, num_queries=4, max_num_points=P,
               encoder_feat_channels=chans, backbone_embed_dim=48, head_feat_channels=128, head_out_channels=128,
               pc_point_dim=pc_dim)      # 3 = xyz only (Waymo, mask_bev_module.py:74): a 10-channel decoration
