@@ -756,6 +756,19 @@ int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, floa
                   int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w, int64_t stride_o, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* mbv_gemm16_nn with the bias gradient's reduction left to the caller: `parts` (mbv_gemm16_nn_part_rows(m, k, batch), k)
+ * f32, contiguous, 16-byte aligned, parts_bytes >= mbv_gemm16_nn_workspace_bytes(m, k, batch), receives one partial
+ * column-sum row per 64 output rows (every element written); the column sum is their sum over the rows.  A backward pass
+ * hands the rows of all its fused data gradients to ONE mbv_colsum_accum_group launch at its end instead of a small
+ * reduction launch behind every GEMM (same reference lines as mbv_gemm16_nn: the fc1 bias gradient of mmcv's FFN,
+ * mask_bev/models/networks/swin/swin.py:347-355). */
+int64_t mbv_gemm16_nn_part_rows(int64_t m, int64_t k, int32_t batch);
+
+int mbv_gemm16_nn_parts(const void* g, const void* w, void* out, const void* aux, float* parts, size_t parts_bytes,
+                        int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux,
+                        int32_t dtype, int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w,
+                        int64_t stride_o, void* stream);
+
 size_t mbv_gemm16_tn_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 int mbv_gemm16_tn(const void* g, const void* x, void* dw, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldx,

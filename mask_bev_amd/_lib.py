@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 
 class MaskBevHipError(RuntimeError):
@@ -130,6 +130,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gemm16_nn_workspace_bytes': (c_size_t, [_L, _L, _I]),
     'mbv_gemm16_nn': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _L, _L, _L, _P,
                                      c_size_t, _P]),
+    'mbv_gemm16_nn_part_rows': (ctypes.c_int64, [_L, _L, _I]),
+    'mbv_gemm16_nn_parts': (ctypes.c_int, [_P, _P, _P, _P, _P, c_size_t, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _L,
+                                           _L, _L, _P]),
     'mbv_gemm16_tn_workspace_bytes': (c_size_t, [_L, _L, _L]),
     'mbv_gemm16_tn': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _I, _L, _L, _L, _P, c_size_t,
                                      _P]),

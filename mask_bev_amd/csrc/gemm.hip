@@ -775,11 +775,19 @@ extern "C" size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t ba
   return (size_t)((m + 63) / 64 + 4) * (size_t)k * 4 * (size_t)(batch > 0 ? batch : 1);
 }
 
-// out (m, k) = act'(aux) * (g (m, n) . w (n, k));  colsum (k) += column sums of out
-extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, float* colsum, int64_t m,
-                             int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux, int32_t dtype,
-                             int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w,
-                             int64_t stride_o, void* workspace, size_t workspace_bytes, void* stream) {
+// Partial column-sum rows an mbv_gemm16_nn of this shape leaves in its workspace: one per 64 output rows of a tile row.
+extern "C" int64_t mbv_gemm16_nn_part_rows(int64_t m, int64_t k, int32_t batch) {
+  if (m <= 0 || k <= 0 || batch <= 0) return 0;
+  const int BM = SHAPE_BM[gemm16_pick_shape(0, m, k, batch)];
+  return (int64_t)(BM / 64) * ((m + BM - 1) / BM) * batch;
+}
+
+// out (m, k) = act'(aux) * (g (m, n) . w (n, k));  colsum (k) += column sums of out.  parts_only: the per-wave-row partial
+// sums stay in `workspace` ((mbv_gemm16_nn_part_rows, k) f32, every element written) and the caller reduces them later.
+static int gemm16_nn_impl(const void* g, const void* w, void* out, const void* aux, float* colsum, bool parts_only, int64_t m,
+                          int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux, int32_t dtype,
+                          int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w,
+                          int64_t stride_o, void* workspace, size_t workspace_bytes, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !w || !out) return MBV_ERR_BAD_ARG;
   if (dtype < 0 || dtype > 1 || act < 0 || act > 2 || (act && !aux)) return MBV_ERR_BAD_ARG;
   if ((n & 7) || (k & 7) || (ldg & 7) || (ldw & 7) || (ldo & 7) || (ldaux & 7) || ldg < n || ldw < k || ldo < k)
@@ -788,12 +796,13 @@ extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void
        reinterpret_cast<size_t>(aux) | reinterpret_cast<size_t>(workspace)) & 15)
     return MBV_ERR_UNSUPPORTED;
   if (!fits_2g(m, ldg) || !fits_2g(n, ldw)) return MBV_ERR_UNSUPPORTED;
-  if (colsum && (!workspace || workspace_bytes < mbv_gemm16_nn_workspace_bytes(m, k, batch))) return MBV_ERR_WORKSPACE;
+  const bool sums = colsum != nullptr || parts_only;
+  if (sums && (!workspace || workspace_bytes < mbv_gemm16_nn_workspace_bytes(m, k, batch))) return MBV_ERR_WORKSPACE;
   if (m == 0 || batch == 0) return MBV_OK;
   const int shape = gemm16_pick_shape(0, m, k, batch);
   const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
   GemmArgs a = {};
-  a.a = g; a.b = w; a.c = out; a.aux = aux; a.colsum_rows = colsum ? reinterpret_cast<float*>(workspace) : nullptr;
+  a.a = g; a.b = w; a.c = out; a.aux = aux; a.colsum_rows = sums ? reinterpret_cast<float*>(workspace) : nullptr;
   a.gm = (int)m; a.gn = (int)k; a.gk = (int)n;
   a.lda = (int)ldg; a.ldb = (int)ldw; a.ldc = (int)ldo; a.ldx = (int)ldaux;
   a.sa = stride_g; a.sb = stride_w; a.sc = stride_o;
@@ -802,7 +811,7 @@ extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void
   a.out_f32 = out_f32;
   const int rc = gemm16_launch(shape, 1, 0, act == 0 ? EPI_NONE : (act == 1 ? EPI_DRELU : EPI_DGELU), dtype, a, batch,
                                (hipStream_t)stream);
-  if (rc != MBV_OK || !colsum) return rc;
+  if (rc != MBV_OK || !colsum || parts_only) return rc;
   const int rows = (BM / 64) * a.ntm * batch;
   int gy = rows / 16;
   if (gy < 1) gy = 1;
@@ -811,6 +820,25 @@ extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void
                      reinterpret_cast<const float*>(workspace), rows, (int)k, colsum);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
+}
+
+extern "C" int mbv_gemm16_nn(const void* g, const void* w, void* out, const void* aux, float* colsum, int64_t m,
+                             int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux, int32_t dtype,
+                             int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g, int64_t stride_w,
+                             int64_t stride_o, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm16_nn_impl(g, w, out, aux, colsum, false, m, n, k, ldg, ldw, ldo, ldaux, dtype, out_f32, act, batch, stride_g,
+                        stride_w, stride_o, workspace, workspace_bytes, stream);
+}
+
+// mbv_gemm16_nn whose column sums are left as partial rows: parts (mbv_gemm16_nn_part_rows(m, k, batch), k) f32, contiguous,
+// 16-byte aligned, at least mbv_gemm16_nn_workspace_bytes(m, k, batch) long; their sum over the rows is the column sum.
+extern "C" int mbv_gemm16_nn_parts(const void* g, const void* w, void* out, const void* aux, float* parts, size_t parts_bytes,
+                                   int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldaux,
+                                   int32_t dtype, int32_t out_f32, int32_t act, int32_t batch, int64_t stride_g,
+                                   int64_t stride_w, int64_t stride_o, void* stream) {
+  if (!parts) return MBV_ERR_BAD_ARG;
+  return gemm16_nn_impl(g, w, out, aux, nullptr, true, m, n, k, ldg, ldw, ldo, ldaux, dtype, out_f32, act, batch, stride_g,
+                        stride_w, stride_o, parts, parts_bytes, stream);
 }
 
 // accumulate != 0:  dw (n, k) f32 += g (m, n)^T . x (m, k), the sum over m split over workgroups (f32 atomic adds)

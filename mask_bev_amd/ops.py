@@ -1089,6 +1089,18 @@ def gemm16_nn(g: torch.Tensor, w: torch.Tensor, act: Optional[str] = None, aux: 
     out = torch.empty((m, k), dtype=od, device=g.device)
     if colsum is not None and (colsum.dtype != torch.float32 or not colsum.is_contiguous()):
         raise MaskBevHipError('gemm16_nn: colsum must be contiguous f32')
+    if colsum is not None and switches.get('nn_colsum_defer') and _defer_ok():
+        # inside a backward pass the per-wave-row partial sums join the pass's grouped column-sum launch (one small
+        # reduction launch per fused data gradient less: 16 per step); the rows live in a tensor of their own until then
+        rows = int(lib.mbv_gemm16_nn_part_rows(m, k, 1))
+        parts = torch.empty(int(lib.mbv_gemm16_nn_workspace_bytes(m, k, 1)) // 4, dtype=torch.float32, device=g.device)
+        check(lib.mbv_gemm16_nn_parts(_ptr(g), _ptr(w), _ptr(out), _ptr(aux if a else None), _ptr(parts), parts.numel() * 4,
+                                      m, n, k, g.stride(0), w.stride(0), k, aux.stride(0) if a else 0,
+                                      _GEMM16_DT[g.dtype], int(od == torch.float32), a, 1, 0, 0, 0, _stream()),
+              'mbv_gemm16_nn_parts')
+        if not _defer_colsum(parts, colsum, rows, k, k):
+            _colsum_now(parts, colsum, rows, k, k)
+        return out
     ws = _workspace(lib.mbv_gemm16_nn_workspace_bytes(m, k, 1), g.device) if colsum is not None else None
     check(lib.mbv_gemm16_nn(_ptr(g), _ptr(w), _ptr(out), _ptr(aux if a else None), _ptr(colsum), m, n, k, g.stride(0),
                             w.stride(0), k, aux.stride(0) if a else 0, _GEMM16_DT[g.dtype],

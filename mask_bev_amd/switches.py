@@ -35,6 +35,7 @@ _DEFAULTS: Dict[str, Any] = {
     'msda_bwd_overlap': False,    # K5 backward's two parts on two streams (measured slower)
     'wgrad_group': True,          # grouped small-token weight gradients / column sums at the end of a backward pass
     'tn_group': '1',              # '0' | '1' | 'all': which K17 weight gradients join the grouped launch
+    'nn_colsum_defer': True,      # a fused data gradient's bias column sums join the pass's grouped column-sum launch
     # --- kernels selected over a library / ATen form ----------------------------------------------------------------
     'gemm16': 'auto',             # '0' | 'auto' | 'all': which Linear work runs on K17
     'tn_max_in': 1536,            # widest input of a Linear whose weight gradient K17 takes

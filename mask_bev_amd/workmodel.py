@@ -162,6 +162,10 @@ def _gemm16(a, layout: str) -> Work:
         m, n, k, f32 = _i(a[5]), _i(a[6]), _i(a[7]), _i(a[13])
         by = (m * n + n * k) * 2.0 + m * k * (4 if f32 else 2) + (m * k * 2.0 if _i(a[14]) else 0.0)
         return ('k_gemm16<NN>', 'mfma', by, 2.0 * m * n * k * max(1, _i(a[15])))
+    if layout == 'nn_parts':         # (g, w, out, aux, parts, parts_bytes, m, n, k, ldg, ldw, ldo, ldaux, dtype, out_f32, act, batch, ...)
+        m, n, k, f32 = _i(a[6]), _i(a[7]), _i(a[8]), _i(a[14])
+        by = (m * n + n * k) * 2.0 + m * k * (4 if f32 else 2) + (m * k * 2.0 if _i(a[15]) else 0.0)
+        return ('k_gemm16<NN>', 'mfma', by, 2.0 * m * n * k * max(1, _i(a[16])))
     m, n, k = _i(a[3]), _i(a[4]), _i(a[5])
     return ('k_gemm16<TN>', 'mfma', (m * n + m * k) * 2.0 + n * k * 4.0 * 2, 2.0 * m * n * k * max(1, _i(a[13])))
 
@@ -325,6 +329,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_attn_bwd_ld': lambda a: _attn(a, True, True),
     'mbv_gemm16_nt': lambda a: _gemm16(a, 'nt'),
     'mbv_gemm16_nn': lambda a: _gemm16(a, 'nn'),
+    'mbv_gemm16_nn_parts': lambda a: _gemm16(a, 'nn_parts'),
     'mbv_gemm16_tn': lambda a: _gemm16(a, 'tn'),
     'mbv_add_layernorm_fwd': lambda a: _add_ln(a, False),
     'mbv_add_layernorm_fwd2': lambda a: _add_ln_fwd2(a),

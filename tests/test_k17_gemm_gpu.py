@@ -267,6 +267,40 @@ def test_fused_ffn_matches_unfused_layers(act, monkeypatch):
 
 
 @gpu
+def test_ffn_bias_gradient_deferred_rows_equal_immediate_reduction(monkeypatch):
+    """mbv_gemm16_nn_parts: inside a backward pass the fused data gradient leaves its per-wave-row column sums as rows of
+    a tensor that joins the pass's grouped column-sum launch; the fc1 bias gradient equals the immediate reduction's (the
+    two add the same f32 partial rows in a different order) and the sum of d(hidden) the library path forms."""
+    from mask_bev_amd import layers, ops
+    from mask_bev_amd.arena import ParameterArena
+    c, rows = 192, 8200            # 8200 rows: a ragged last tile (its dead wave rows must contribute zeros)
+    torch.manual_seed(11)
+    x0 = torch.randn(rows, c, device=_dev())
+    g0 = torch.randn(rows, c, device=_dev()).to(torch.bfloat16)
+
+    def run(defer):
+        switches.patch(monkeypatch, nn_colsum_defer=defer)
+        torch.manual_seed(5)
+        m = layers.FFN(c, 4 * c, act='gelu').to(_dev())
+        arena = ParameterArena([('ffn', m)])
+        x = x0.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = m(x, add_identity=False)
+        y.backward(g0)
+        return m.layers[0][0].bias.grad.clone(), arena.grad.clone()
+
+    b_def, a_def = run(True)
+    b_now, a_now = run(False)
+    assert b_def.abs().max() > 0
+    assert (b_def - b_now).abs().max() <= 1e-5 * b_now.abs().max()
+    assert (a_def - a_now).abs().max() <= 1e-5 * a_now.abs().max()
+    lib = ops._lib.load()
+    for m_, k_ in ((8200, 768), (64, 8), (65536, 768), (129, 192)):
+        r = lib.mbv_gemm16_nn_part_rows(m_, k_, 1)
+        assert (m_ + 63) // 64 <= r and r * k_ * 4 <= lib.mbv_gemm16_nn_workspace_bytes(m_, k_, 1)
+
+
+@gpu
 def test_mask_logit_backward_products():
     """ops.mask_logits_backward: d_embed = dl . F^T (split-K NT, f32 atomics) and d_feature = E^T . dl (batched TN)
     at the deferred-head shape of the bench (rows = 10 outputs x 100 queries, C = 256) on a reduced pixel count."""
