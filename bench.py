@@ -61,6 +61,8 @@ def parse():
                          'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
     ap.add_argument('--aten-detail', default=None, metavar='FILE',
                     help='write the per-operator times of the ATen calls of the instrumented step (name, shapes, call site)')
+    ap.add_argument('--gemm-table', default=None, metavar='CSV',
+                    help='a TunableOp selection table other than the committed one (A/B of a re-tuned table)')
     ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set a path selector of mask_bev_amd/switches.py (recorded in config.switches)')
     return ap.parse_args()
@@ -372,7 +374,7 @@ def main():
 
     torch.manual_seed(420)
     kw = synthetic.module_kwargs(args.workload, args.batch, compute_dtype=args.dtype)
-    tuned = tuning.use_tuned_gemms()     # hipBLASLt solution table for this step's GEMM shapes (look-up only)
+    tuned = tuning.use_tuned_gemms(args.gemm_table)     # hipBLASLt solution table for this step's GEMM shapes (look-up only)
     model = MaskBevModule(**kw).to(device)
     model.train()
     model.log_scalars = False           # scalar logging is host-side bookkeeping, not the path
