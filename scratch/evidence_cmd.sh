@@ -8,7 +8,7 @@ bash scratch/pmc_cmd.sh > gpurun_out/ev/pmc.log 2>&1; cp gpurun_out/pmc_hbm_traf
 mkdir -p profiles/r04; cp gpurun_out/pmc_hbm_traffic.json profiles/r04/pmc_hbm_traffic.json      # the bench line below reads it
 timeout 900 python3 bench.py > gpurun_out/ev/bench_default.json 2> gpurun_out/ev/bench_default.err; tail -c 300 gpurun_out/ev/bench_default.json
 bash scratch/prof_cmd.sh > gpurun_out/ev/prof.log 2>&1
-cp gpurun_out/prof_c/kernel_stats.csv gpurun_out/ev/kernel_stats.csv; cp gpurun_out/prof_c/agg.txt gpurun_out/ev/kernel_trace_by_step.txt; cp gpurun_out/prof_c/bench.json gpurun_out/ev/bench_under_rocprof.json
+cp gpurun_out/prof_c/seq.txt gpurun_out/ev/kernel_sequence_one_step.txt; cp gpurun_out/prof_c/kernel_stats.csv gpurun_out/ev/kernel_stats.csv; cp gpurun_out/prof_c/agg.txt gpurun_out/ev/kernel_trace_by_step.txt; cp gpurun_out/prof_c/bench.json gpurun_out/ev/bench_under_rocprof.json
 bash scratch/phase_cmd.sh > gpurun_out/ev/phase.log 2>&1; cp gpurun_out/prof_p/phases.txt gpurun_out/ev/phases.txt
 # fp32: the precision the reference trains in
 PROF_OUT=prof_f32 bash scratch/prof_cmd.sh --dtype fp32 > gpurun_out/ev/prof_f32.log 2>&1
@@ -19,5 +19,7 @@ for cfg in "--dtype fp16" "--distribution uniform"; do
   timeout 600 python3 bench.py $cfg --no-cpu-baseline --no-kernel-profile --no-fp32 > gpurun_out/ev/bench_$name.json 2> gpurun_out/ev/bench_$name.err
   python3 -c "import json,sys; d=json.loads(open('gpurun_out/ev/bench_$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'])"
 done
+# derived busy counters per kernel (VALUBusy / SALUBusy, MfmaUtil / LDSBankConflict: two more --pmc passes)
+bash scratch/pmc_busy_cmd.sh > gpurun_out/ev/pmc_busy.log 2>&1; cp gpurun_out/pmc_b/pmc_busy.csv gpurun_out/ev/pmc_busy.csv
 python3 scratch/show_bench.py gpurun_out/ev/bench_default.json 12
 head -24 gpurun_out/ev/kernel_trace_by_step.txt

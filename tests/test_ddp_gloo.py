@@ -1,7 +1,7 @@
 """World-size-2 gloo test of the data-parallel path: bucketed, backward-overlapped gradient averaging gives the
 same parameters on both ranks and the same update as a single process seeing the whole batch."""
 import os
-import socket
+import tempfile
 
 import pytest
 import torch
@@ -11,11 +11,30 @@ from torch import nn
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous FILE, not a TCP port: a port found free here can be taken (or still sit in TIME_WAIT) by the time the
+    ranks bind it — seen once as a failed rendezvous of the third test of a run; gloo picks its own pair ports."""
+    fd, path = tempfile.mkstemp(prefix='mbv_gloo_rdv_')
+    os.close(fd)
+    os.unlink(path)                       # the FileStore creates it; a stale file of an earlier run would confuse it
+    _RDV_FILES.append(path)
+    return path
+
+
+_RDV_FILES = []
+
+
+@pytest.fixture(autouse=True)
+def _remove_rendezvous_files():
+    yield
+    while _RDV_FILES:
+        try:
+            os.unlink(_RDV_FILES.pop())
+        except OSError:
+            pass
+
+
+def _init_gloo(rank, world, rdv):
+    dist.init_process_group('gloo', init_method=f'file://{rdv}', rank=rank, world_size=world)
 
 
 def _model():
@@ -24,8 +43,7 @@ def _model():
 
 
 def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_gloo(rank, world, port)
     from mask_bev_amd.ddp import GradientAllReducer, reduce_scalars, shard_scans
     torch.manual_seed(100 + rank)            # different init per rank: construction must broadcast rank 0's
     m = nn.Sequential(nn.Linear(8, 32), nn.ReLU(), nn.BatchNorm1d(32), nn.Linear(32, 16), nn.ReLU(), nn.Linear(16, 1))
@@ -84,8 +102,7 @@ def test_gradient_allreduce_world2_matches_single_process():
 
 
 def _arena_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_gloo(rank, world, port)
     from mask_bev_amd.arena import ParameterArena
     from mask_bev_amd.ddp import GradientAllReducer
     torch.manual_seed(100 + rank)
@@ -137,8 +154,7 @@ def test_arena_allreduce_world2_matches_single_process():
 def _ranges_worker(rank, world, port, out):
     """The staged exchange of graph.py: sub-module ranges reduced as their gradients complete, one of them from a
     post-accumulate hook fired inside backward."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_gloo(rank, world, port)
     from mask_bev_amd.arena import ParameterArena
     from mask_bev_amd.ddp import GradientAllReducer
     torch.manual_seed(100 + rank)
@@ -214,8 +230,7 @@ def test_arena_range_of_rejects_interleaved_parameters():
 def _worker_unused(rank, world, port, out):
     """Ranks with DIFFERENT sets of unused parameters: rank 1 never uses the `extra` branch.  The buckets must still be
     all-reduced in the same order on both ranks (index order), or the collectives pair up wrongly / hang."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_gloo(rank, world, port)
     from mask_bev_amd.ddp import GradientAllReducer
 
     class Net(nn.Module):

@@ -9,7 +9,6 @@ factor inside k_adamw.  Checked per step, exactly (a + b is commutative, so the 
   * the replicas hold bit-identical parameters after 3 steps (checksum spread 0) although they see different scans.
 Reference: /root/reference: train_mask_bev.py:92-96 (Lightning `strategy='ddp'`), SURVEY.md §2b C1-C6."""
 import os
-import socket
 
 import pytest
 import torch
@@ -17,20 +16,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _rank(rank, world, port, out_dir):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # file rendezvous (``port`` is a path under the test's tmp_path): a TCP port found free in the parent can be gone by
+    # the time the ranks bind it
+    dist.init_process_group('gloo', init_method=f'file://{port}', rank=rank, world_size=world)
     from mask_bev_amd.ddp import GradientAllReducer
     from mask_bev_amd.graph import GraphedTrainStep
     from mask_bev_amd.mask_bev_module import MaskBevModule
@@ -106,7 +99,7 @@ def _rank(rank, world, port, out_dir):
 
 def test_two_rank_graph_step_reduces_the_arena(tmp_path):
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    world, port = 2, str(tmp_path / 'rendezvous')
     mp.spawn(_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
