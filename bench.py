@@ -61,6 +61,9 @@ def parse():
                          'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
     ap.add_argument('--aten-detail', default=None, metavar='FILE',
                     help='write the per-operator times of the ATen calls of the instrumented step (name, shapes, call site)')
+    ap.add_argument('--grad-wire', default='f32', choices=['f32', 'bf16'],
+                    help='N > 1: type the gradient all-reduce travels in (bf16 = half the xGMI bytes, sums formed in bf16; '
+                         'default f32 = the exact in-place exchange)')
     ap.add_argument('--gemm-table', default=None, metavar='CSV',
                     help='a TunableOp selection table other than the committed one (A/B of a re-tuned table)')
     ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
@@ -384,7 +387,8 @@ def main():
     reducer = None
     if world > 1:
         from mask_bev_amd.ddp import GradientAllReducer
-        reducer = GradientAllReducer(model, bucket_mb=64.0)
+        reducer = GradientAllReducer(model, bucket_mb=64.0,
+                                     grad_dtype=torch.bfloat16 if args.grad_wire == 'bf16' else None)
         if getattr(model, '_arena', None) is not None:
             model._arena.refresh_shadow()       # the construction-time parameter broadcast wrote the f32 arena
             # arena gradients are accumulated in place, once per USE of a parameter (a packed in_proj weight is used
@@ -519,7 +523,7 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic' if args.distribution == 'lidar' else 'synthetic (uniform x/y points)',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, replica_param_checksum_spread=replica_spread,
+                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if world > 1 else None), replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss,
                         switches={k: v for k, v in switches._values.items() if v != switches.defaults()[k]}),
             roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,

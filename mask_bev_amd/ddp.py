@@ -40,6 +40,19 @@ class _Bucket:
         self.offsets: List[int] = []
 
 
+class _WireHandle:
+    """An arena chunk reduced in a 16-bit wire type: ``wait()`` orders the current stream behind the collective and
+    writes the sum back into the f32 arena view."""
+    __slots__ = ('work', 'wire', 'view')
+
+    def __init__(self, work, wire, view):
+        self.work, self.wire, self.view = work, wire, view
+
+    def wait(self):
+        self.work.wait()
+        self.view.copy_(self.wire)
+
+
 class GradientAllReducer:
     """Bucketed, backward-overlapped gradient averaging for ``module``'s parameters."""
 
@@ -167,17 +180,21 @@ class GradientAllReducer:
         ``no_sync(True)`` because collectives must not be issued during capture / replay."""
         self.finish()
 
+    def _reduce_chunk(self, arena, lo: int, hi: int):
+        """One asynchronous SUM all-reduce over arena.grad[lo:hi].  ``grad_dtype`` (bf16 / fp16) set: the chunk travels in
+        that type — half the bytes on every xGMI link — through a staging copy that :meth:`finish_arena` writes back
+        (the sum is formed in the wire type: an opt-in trade of gradient bits for link time; default = f32, in place)."""
+        view = arena.grad[lo:hi]
+        if self.grad_dtype is None or self.grad_dtype == view.dtype:
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        wire = view.to(self.grad_dtype)
+        work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return _WireHandle(work, wire, view)
+
     def start_arena(self, arena, names, chunk_mb: float = 256.0) -> list:
         """Launch SUM all-reduces over the named arena segments' gradients (arena.py) in contiguous chunks — no
         bucket copies; asynchronous on RCCL's stream, ordered after the work already queued on this stream."""
-        handles = []
-        step = max(1, int(chunk_mb * 1024 * 1024) // 4)
-        for name in names:
-            a, b = arena.segments[name]
-            for lo in range(a, b, step):
-                handles.append(dist.all_reduce(arena.grad[lo:min(b, lo + step)], op=dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True))
-        return handles
+        return self.start_ranges(arena, [arena.segments[name] for name in names], chunk_mb)
 
     def start_ranges(self, arena, ranges, chunk_mb: float = 256.0) -> list:
         """Like :meth:`start_arena` for explicit element ranges [(lo, hi), ...] of the arena gradient — the parts
@@ -186,8 +203,7 @@ class GradientAllReducer:
         step = max(1, int(chunk_mb * 1024 * 1024) // 4)
         for a, b in ranges:
             for lo in range(a, b, step):
-                handles.append(dist.all_reduce(arena.grad[lo:min(b, lo + step)], op=dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True))
+                handles.append(self._reduce_chunk(arena, lo, min(b, lo + step)))
         return handles
 
     def finish_arena(self, arena, handles: list, optimizer=None):

@@ -151,6 +151,51 @@ def test_arena_allreduce_world2_matches_single_process():
     assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-6)
 
 
+def _wire_worker(rank, world, port, out):
+    _init_gloo(rank, world, port)
+    from mask_bev_amd.arena import ParameterArena
+    from mask_bev_amd.ddp import GradientAllReducer
+    res = {}
+    for wire in (None, torch.bfloat16):
+        torch.manual_seed(100 + rank)
+        enc, bb, head = nn.Linear(8, 32), nn.Linear(32, 16), nn.Linear(16, 1)
+        m = nn.Sequential(enc, nn.ReLU(), bb, nn.ReLU(), head)
+        red = GradientAllReducer(m, bucket_mb=0.001, grad_dtype=wire)     # broadcasts rank 0's parameters: same start both times
+        red.no_sync(True)
+        arena = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None)
+        torch.manual_seed(7)
+        x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
+        idx = list(range(rank, 8, world))
+        arena.zero_grad()
+        ((m(x_all[idx]) - y_all[idx]) ** 2).mean().backward()
+        local = arena.grad.clone()
+        handles = red.start_ranges(arena, [arena.segments['head'], arena.segments['backbone']], chunk_mb=0.0005)
+        handles += red.start_arena(arena, ('encoder',), chunk_mb=0.0005)
+        red.finish_arena(arena, handles)
+        res['f32' if wire is None else 'bf16'] = arena.grad.clone()
+        res['local'] = local
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_arena_allreduce_in_a_16_bit_wire_type():
+    """``grad_dtype=torch.bfloat16``: the arena chunks of the graph step travel as bf16 (half the link bytes) and come back
+    into the f32 gradient: identical on both ranks, equal to the bf16 sum of the bf16-rounded local gradients, within bf16
+    rounding of the exact mean; the default (None) stays the exact in-place f32 exchange."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_wire_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert torch.equal(a['bf16'], b['bf16']) and torch.equal(a['f32'], b['f32'])
+    exact = (a['local'] + b['local']) / 2
+    assert torch.allclose(a['f32'], exact, rtol=1e-6, atol=1e-7)
+    want = ((a['local'].bfloat16() + b['local'].bfloat16()).float()) / 2
+    assert torch.equal(a['bf16'], want)
+    assert (a['bf16'] - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()
+    assert not torch.equal(a['bf16'], a['f32'])
+
+
 def _ranges_worker(rank, world, port, out):
     """The staged exchange of graph.py: sub-module ranges reduced as their gradients complete, one of them from a
     post-accumulate hook fired inside backward."""
