@@ -421,12 +421,356 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn(const float* __restrict__ Y,
   }
 }
 
+// backward 2 with a lane = 4 ADJACENT channels: a wave instruction covers 64 / (U / 4) whole rows (4 at 64 units, 2 at 128) as
+// 16-byte accesses instead of one row as 4-byte accesses — a quarter of the memory instructions for the same bytes (these walks
+// are bound by vector-memory instructions in flight).  Row loads are unconditional on a clamped row index; the row
+// groups' partial sums of a pillar meet through two shuffles.  U4 = U / 4 in {8, 16, 32}.
+template <int U4>
+__global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
+                                                       float* __restrict__ DZ, float* __restrict__ DZpad,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                       double count, int training,
+                                                       const int32_t* __restrict__ row_start,
+                                                       const int32_t* __restrict__ num_points, int V, int P,
+                                                       float* __restrict__ dT) {
+  constexpr int U = 4 * U4, RPW = 64 / U4, NI = 8 / RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs4 = *reinterpret_cast<const float4*>(rstd + c);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 gs = make_float4(gm.x * rs4.x, gm.y * rs4.y, gm.z * rs4.z, gm.w * rs4.w);
+  float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), c2 = c1;
+  if (training) {
+    c1 = make_float4((float)(sums[c] / count), (float)(sums[c + 1] / count), (float)(sums[c + 2] / count), (float)(sums[c + 3] / count));
+    c2 = make_float4((float)(sums[U + c] / count), (float)(sums[U + c + 1] / count), (float)(sums[U + c + 2] / count),
+                     (float)(sums[U + c + 3] / count));
+  }
+  const float4* Y4 = reinterpret_cast<const float4*>(Y);
+  float4* DZ4 = reinterpret_cast<float4*>(DZ);
+  const float4* YP4 = reinterpret_cast<const float4*>(Ypad);
+  float4* DP4 = reinterpret_cast<float4*>(DZpad);
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  if (v >= V) return;
+  // Two pillars deep: while pillar v is computed and stored, the first 8 rows (and the padded row) of the wave's NEXT pillar
+  // are already in flight — the compiler cannot hoist them above this pillar's stores itself (DZ is updated in place) — and the
+  // header (n, row_start) of the pillar after that is requested.  Every load is unconditional on a clamped index.
+  auto load_rows = [&](int64_t rs, int n, int j0, float4 (&y)[NI], float4 (&dz)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = j0 + i * RPW + rg;
+      const int64_t at = (rs + (r < n ? r : n - 1)) * U4 + sub;
+      y[i] = Y4[at];
+      dz[i] = DZ4[at];
+    }
+  };
+  const int vlast = V - 1;
+  int n = num_points[v];
+  int64_t rs = row_start[v];
+  int v1 = v + vstride < V ? v + vstride : vlast;
+  int n1 = num_points[v1];
+  int64_t rs1 = row_start[v1];
+  float4 y[NI], dz[NI], yn[NI], dzn[NI];
+  load_rows(rs, n, 0, y, dz);
+  float4 ypv = YP4[(int64_t)v * U4 + sub], dzpv = DP4[(int64_t)v * U4 + sub];
+  for (; v < V; v += vstride) {
+    // header two pillars ahead, rows + padded row one pillar ahead
+    const int v2 = v + 2 * vstride < V ? v + 2 * vstride : vlast;
+    const int n2 = num_points[v2];
+    const int64_t rs2 = row_start[v2];
+    load_rows(rs1, n1, 0, yn, dzn);
+    const float4 ypn = YP4[(int64_t)v1 * U4 + sub], dzpn = DP4[(int64_t)v1 * U4 + sub];
+    const float mult = (float)(P - n);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < n; j0 += 8) {
+      if (j0) load_rows(rs, n, j0, y, dz);               // pillars of more than 8 rows: the later chunks as they come
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = j0 + i * RPW + rg;
+        if (r < n) {
+          float4 dy;
+          dy.x = gs.x * (dz[i].x - c1.x - (y[i].x - mu.x) * rs4.x * c2.x);
+          dy.y = gs.y * (dz[i].y - c1.y - (y[i].y - mu.y) * rs4.y * c2.y);
+          dy.z = gs.z * (dz[i].z - c1.z - (y[i].z - mu.z) * rs4.z * c2.z);
+          dy.w = gs.w * (dz[i].w - c1.w - (y[i].w - mu.w) * rs4.w * c2.w);
+          DZ4[(rs + r) * U4 + sub] = dy;
+          acc.x += dy.x; acc.y += dy.y; acc.z += dy.z; acc.w += dy.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = U4; o < 64; o <<= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (rg == 0) {
+      float4 dyp;
+      dyp.x = gs.x * (dzpv.x - mult * c1.x - mult * (ypv.x - mu.x) * rs4.x * c2.x);
+      dyp.y = gs.y * (dzpv.y - mult * c1.y - mult * (ypv.y - mu.y) * rs4.y * c2.y);
+      dyp.z = gs.z * (dzpv.z - mult * c1.z - mult * (ypv.z - mu.z) * rs4.z * c2.z);
+      dyp.w = gs.w * (dzpv.w - mult * c1.w - mult * (ypv.w - mu.w) * rs4.w * c2.w);
+      DP4[(int64_t)v * U4 + sub] = dyp;
+      if (dT) *reinterpret_cast<float4*>(dT + (int64_t)v * U + c) = make_float4(acc.x + dyp.x, acc.y + dyp.y, acc.z + dyp.z, acc.w + dyp.w);
+    }
+    n = n1; rs = rs1; n1 = n2; rs1 = rs2; v1 = v2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { y[i] = yn[i]; dz[i] = dzn[i]; }
+    ypv = ypn; dzpv = dzpn;
+  }
+}
+
+// apply + max with the 4-channel lane map of k_pfn_bwd_bn_v4 (a wave instruction = 64 / U4 whole rows, 16-byte accesses,
+// the wave's next pillar in flight while this one is computed); the row groups' maxima meet through shuffles.
+template <int U4>
+__global__ void __launch_bounds__(256) k_pfn_apply_max_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const int32_t* __restrict__ row_start,
+                                                          const int32_t* __restrict__ num_points, int V, int P,
+                                                          float* __restrict__ A, float* __restrict__ Apad,
+                                                          float* __restrict__ M) {
+  constexpr int RPW = 64 / U4, NI = 8 / RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+  const float4* Y4 = reinterpret_cast<const float4*>(Y);
+  const float4* YP4 = reinterpret_cast<const float4*>(Ypad);
+  float4* A4 = reinterpret_cast<float4*>(A);
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  if (v >= V) return;
+  auto load_rows = [&](int64_t rs, int n, int j0, float4 (&y)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = j0 + i * RPW + rg;
+      y[i] = Y4[(rs + (r < n ? r : n - 1)) * U4 + sub];
+    }
+  };
+  auto act = [&](const float4& y) {
+    return make_float4(fmaxf(y.x * sc.x + sh.x, 0.f), fmaxf(y.y * sc.y + sh.y, 0.f), fmaxf(y.z * sc.z + sh.z, 0.f),
+                       fmaxf(y.w * sc.w + sh.w, 0.f));
+  };
+  const int vlast = V - 1;
+  int n = num_points[v];
+  int64_t rs = row_start[v];
+  int v1 = v + vstride < V ? v + vstride : vlast;
+  int n1 = num_points[v1];
+  int64_t rs1 = row_start[v1];
+  float4 y[NI], yn[NI];
+  load_rows(rs, n, 0, y);
+  float4 ypv = YP4[(int64_t)v * U4 + sub];
+  for (; v < V; v += vstride) {
+    const int v2 = v + 2 * vstride < V ? v + 2 * vstride : vlast;
+    const int n2 = num_points[v2];
+    const int64_t rs2 = row_start[v2];
+    load_rows(rs1, n1, 0, yn);
+    const float4 ypn = YP4[(int64_t)v1 * U4 + sub];
+    const float4 ap = act(ypv);
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int j0 = 0; j0 < n; j0 += 8) {
+      if (j0) load_rows(rs, n, j0, y);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = j0 + i * RPW + rg;
+        if (r < n) {
+          const float4 a = act(y[i]);
+          if (A) A4[(rs + r) * U4 + sub] = a;
+          mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = U4; o < 64; o <<= 1) {
+      mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
+      mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
+    }
+    if (rg == 0) {
+      if (n < P) { mx.x = fmaxf(mx.x, ap.x); mx.y = fmaxf(mx.y, ap.y); mx.z = fmaxf(mx.z, ap.z); mx.w = fmaxf(mx.w, ap.w); }
+      if (Apad) *reinterpret_cast<float4*>(Apad + (int64_t)v * (4 * U4) + c) = ap;
+      *reinterpret_cast<float4*>(M + (int64_t)v * (4 * U4) + c) = mx;
+    }
+    n = n1; rs = rs1; n1 = n2; rs1 = rs2; v1 = v2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) y[i] = yn[i];
+    ypv = ypn;
+  }
+}
+
+// backward 1 (route dM through the max, relu', BatchNorm-backward sums) with the same lane map and pillar pipeline.  The
+// arg-max of a channel is the FIRST maximal real row (torch.max's first-index rule on the dense tensor): inside a lane rows
+// arrive in ascending order (strict >), across the row groups a tie goes to the smaller row index.
+template <int U4>
+__global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          float* __restrict__ DZ, int has_dA, const float* __restrict__ SApad,
+                                                          const float* __restrict__ dM,
+                                                          const int32_t* __restrict__ row_start,
+                                                          const int32_t* __restrict__ num_points, int V, int P,
+                                                          float* __restrict__ DZpad, double* __restrict__ sums) {
+  constexpr int U = 4 * U4, RPW = 64 / U4, NI = 8 / RPW;
+  __shared__ double red[kWavesPerBlock][2 * U];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
+  const float4 sc4 = *reinterpret_cast<const float4*>(scale + c), sh4 = *reinterpret_cast<const float4*>(shift + c);
+  const float4 mu4 = *reinterpret_cast<const float4*>(mean + c), rs4 = *reinterpret_cast<const float4*>(rstd + c);
+  const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rsd[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  const float4* Y4 = reinterpret_cast<const float4*>(Y);
+  float4* DZ4 = reinterpret_cast<float4*>(DZ);
+  const float4* YP4 = reinterpret_cast<const float4*>(Ypad);
+  const float4* DM4 = reinterpret_cast<const float4*>(dM);
+  const float4* SA4 = reinterpret_cast<const float4*>(SApad ? SApad : dM);       // some readable address when absent
+  const int vstride = gridDim.x * kWavesPerBlock;
+  int v = blockIdx.x * kWavesPerBlock + wave;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (v < V) {
+    auto load_rows = [&](int64_t rs, int n, int j0, float4 (&y)[NI], float4 (&g)[NI], bool want_g) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = j0 + i * RPW + rg;
+        const int64_t at = (rs + (r < n ? r : n - 1)) * U4 + sub;
+        y[i] = Y4[at];
+        if (want_g) g[i] = DZ4[at];
+      }
+    };
+    const bool dA = has_dA != 0;
+    const int vlast = V - 1;
+    int n = num_points[v];
+    int64_t rs = row_start[v];
+    int v1 = v + vstride < V ? v + vstride : vlast;
+    int n1 = num_points[v1];
+    int64_t rs1 = row_start[v1];
+    float4 y[NI], g[NI], yn[NI], gn[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { g[i] = zero4; gn[i] = zero4; }
+    load_rows(rs, n, 0, y, g, dA);
+    float4 ypv = YP4[(int64_t)v * U4 + sub], dmv = DM4[(int64_t)v * U4 + sub], gpv = SA4[(int64_t)v * U4 + sub];
+    for (; v < V; v += vstride) {
+      const int v2 = v + 2 * vstride < V ? v + 2 * vstride : vlast;
+      const int n2 = num_points[v2];
+      const int64_t rs2 = row_start[v2];
+      load_rows(rs1, n1, 0, yn, gn, dA);
+      const float4 ypn = YP4[(int64_t)v1 * U4 + sub], dmn = DM4[(int64_t)v1 * U4 + sub], gpn = SA4[(int64_t)v1 * U4 + sub];
+      const float yp[4] = {ypv.x, ypv.y, ypv.z, ypv.w}, dm[4] = {dmv.x, dmv.y, dmv.z, dmv.w};
+      const float gp[4] = {SApad ? gpv.x : 0.f, SApad ? gpv.y : 0.f, SApad ? gpv.z : 0.f, SApad ? gpv.w : 0.f};
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int arg[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+      // pass 1: arg-max over the real rows (the first chunk stays in registers for pass 2)
+      {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = i * RPW + rg;
+          if (r < n) {
+            const float yy[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float a = fmaxf(yy[k] * sc[k] + sh[k], 0.f);
+              if (a > mx[k]) { mx[k] = a; arg[k] = r; }
+            }
+          }
+        }
+        for (int j0 = 8; j0 < n; j0 += 8) {
+          float4 yl[NI], gl[NI];
+          load_rows(rs, n, j0, yl, gl, false);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int r = j0 + i * RPW + rg;
+            if (r < n) {
+              const float yy[4] = {yl[i].x, yl[i].y, yl[i].z, yl[i].w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float a = fmaxf(yy[k] * sc[k] + sh[k], 0.f);
+                if (a > mx[k]) { mx[k] = a; arg[k] = r; }
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = U4; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float om = __shfl_xor(mx[k], o, 64);
+          const int oa = __shfl_xor(arg[k], o, 64);
+          if (om > mx[k] || (om == mx[k] && oa < arg[k])) { mx[k] = om; arg[k] = oa; }
+        }
+      }
+      bool pad_wins[4];
+      float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pad_wins[k] = (n < P) && (fmaxf(yp[k] * sc[k] + sh[k], 0.f) > mx[k]);
+      // pass 2: dz = relu'(a) * (dA + routed dM), BatchNorm-backward sums
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        if (j0) load_rows(rs, n, j0, y, g, dA);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = j0 + i * RPW + rg;
+          if (r < n) {
+            const float yy[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+            const float gi[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
+            float dz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float a = yy[k] * sc[k] + sh[k];
+              float gg = dA ? gi[k] : 0.f;
+              if (!pad_wins[k] && r == arg[k]) gg += dm[k];
+              dz[k] = a > 0.f ? gg : 0.f;
+              f1[k] += dz[k];
+              f2[k] += dz[k] * (yy[k] - mu[k]) * rsd[k];
+            }
+            DZ4[(rs + r) * U4 + sub] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          }
+        }
+      }
+      if (rg == 0) {                                   // the padded row: once per pillar
+        float dzp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float gpp = gp[k];
+          if (pad_wins[k]) gpp += dm[k];
+          dzp[k] = (yp[k] * sc[k] + sh[k]) > 0.f ? gpp : 0.f;
+          f1[k] += dzp[k];
+          f2[k] += dzp[k] * (yp[k] - mu[k]) * rsd[k];
+        }
+        *reinterpret_cast<float4*>(DZpad + (int64_t)v * U + c) = make_float4(dzp[0], dzp[1], dzp[2], dzp[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s1[k] += f1[k]; s2[k] += f2[k]; }
+      n = n1; rs = rs1; n1 = n2; rs1 = rs2; v1 = v2;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) { y[i] = yn[i]; g[i] = gn[i]; }
+      ypv = ypn; dmv = dmn; gpv = gpn;
+    }
+  }
+  // the row groups' channel sums meet through shuffles, the waves' in LDS; one set of channel atomics per workgroup
+#pragma unroll
+  for (int o = U4; o < 64; o <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[k] += __shfl_xor(s1[k], o, 64); s2[k] += __shfl_xor(s2[k], o, 64); }
+  if (rg == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[wave][c + k] = s1[k]; red[wave][U + c + k] = s2[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * U; i += blockDim.x) atomicAdd(&sums[i], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+}
+
 int grid_for(int64_t v) {
   const int64_t need = (v + kWavesPerBlock - 1) / kWavesPerBlock;
   return (int)(need < kBlocks ? (need > 0 ? need : 1) : kBlocks);
 }
 
 }  // namespace
+
+// The 4-channel lane map (k_pfn_*_v4) takes 32 / 64 / 128 units and 16-byte aligned tensors (null = absent).
+template <typename... Ps>
+static bool pfn_v4_ok(int32_t units, Ps... ptrs) {
+  size_t bits = 0;
+  ((bits |= reinterpret_cast<size_t>(ptrs)), ...);
+  return (bits & 15) == 0 && (units == 32 || units == 64 || units == 128);
+}
 
 #define MBV_PFN_DISPATCH(KERNEL, ...)                                                                  \
   if (units <= 64) hipLaunchKernelGGL((KERNEL<1>), dim3(grid_for(num_pillars)), dim3(256), 0, stream, __VA_ARGS__); \
@@ -474,6 +818,15 @@ extern "C" int mbv_pfn_apply_max(const float* y, const float* y_pad, const float
   if (int rc = pfn_check(num_pillars, units, max_points)) return rc;
   if (num_pillars == 0) return MBV_OK;
   if (!y || !y_pad || !scale || !shift || !row_start || !num_points || !m) return MBV_ERR_BAD_ARG;
+  if (pfn_v4_ok(units, y, y_pad, scale, shift, a, a_pad, m)) {
+    const dim3 grid(grid_for(num_pillars)), block(256);
+#define MBV_V4(U4) hipLaunchKernelGGL((k_pfn_apply_max_v4<U4>), grid, block, 0, stream, y, y_pad, scale, shift, row_start, \
+                                      num_points, (int)num_pillars, max_points, a, a_pad, m)
+    if (units == 32) MBV_V4(8); else if (units == 64) MBV_V4(16); else MBV_V4(32);
+#undef MBV_V4
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
   MBV_PFN_DISPATCH(k_pfn_apply_max, y, y_pad, scale, shift, row_start, num_points, (int)num_pillars, max_points, units,
                    a, a_pad, m)
   MBV_CHECK_LAUNCH();
@@ -492,6 +845,15 @@ extern "C" int mbv_pfn_bwd_route(const float* y, const float* y_pad, const float
   if (num_pillars == 0) return MBV_OK;
   if (!y || !y_pad || !scale || !shift || !mean || !rstd || !dz || !dm || !row_start || !num_points || !dz_pad)
     return MBV_ERR_BAD_ARG;
+  if (pfn_v4_ok(units, y, y_pad, scale, shift, mean, rstd, dz, sum_da_pad, dm, dz_pad)) {
+    const dim3 grid(grid_for(num_pillars)), block(256);
+#define MBV_V4(U4) hipLaunchKernelGGL((k_pfn_bwd_route_v4<U4>), grid, block, 0, stream, y, y_pad, scale, shift, mean, rstd, dz, \
+                                      has_da, sum_da_pad, dm, row_start, num_points, (int)num_pillars, max_points, dz_pad, sums)
+    if (units == 32) MBV_V4(8); else if (units == 64) MBV_V4(16); else MBV_V4(32);
+#undef MBV_V4
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
   MBV_PFN_DISPATCH(k_pfn_bwd_route, y, y_pad, scale, shift, mean, rstd, dz, has_da, sum_da_pad, dm, row_start,
                    num_points, (int)num_pillars, max_points, units, dz_pad, sums)
   MBV_CHECK_LAUNCH();
@@ -507,6 +869,20 @@ extern "C" int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, flo
   if (num_pillars == 0) return MBV_OK;
   if (!y || !y_pad || !dz || !dz_pad || !mean || !rstd || !gamma || !sums || !row_start || !num_points)
     return MBV_ERR_BAD_ARG;
+  if (pfn_v4_ok(units, y, y_pad, dz, dz_pad, mean, rstd, gamma, dt)) {
+    const dim3 grid(grid_for(num_pillars)), block(256);
+    if (units == 32)
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<8>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+                         training, row_start, num_points, (int)num_pillars, max_points, dt);
+    else if (units == 64)
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<16>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+                         training, row_start, num_points, (int)num_pillars, max_points, dt);
+    else
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<32>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+                         training, row_start, num_points, (int)num_pillars, max_points, dt);
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
   MBV_PFN_DISPATCH(k_pfn_bwd_bn, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count, training, row_start, num_points,
                    (int)num_pillars, max_points, units, dt)
   MBV_CHECK_LAUNCH();
