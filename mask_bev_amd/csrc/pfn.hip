@@ -20,6 +20,7 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlocks = 2048;     // persistent-style grid: one set of channel atomics per workgroup
 constexpr int kChunk = 8;         // rows of a pillar in flight per wave
+constexpr int kChunk128 = 8;      // ... of the 4-channel lane map at 128 units (4 — fewer registers, three waves per SIMD — measured 4-8 % slower)
 
 // CPL = channels per lane (1 for 64 channels, 2 for 128)
 template <int CPL>
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn(const float* __restrict__ Y,
 // 16-byte accesses instead of one row as 4-byte accesses — a quarter of the memory instructions for the same bytes (these walks
 // are bound by vector-memory instructions in flight).  Row loads are unconditional on a clamped row index; the row
 // groups' partial sums of a pillar meet through two shuffles.  U4 = U / 4 in {8, 16, 32}.
-template <int U4>
+template <int U4, int CH>
 __global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
                                                        float* __restrict__ DZ, float* __restrict__ DZpad,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__
                                                        const int32_t* __restrict__ row_start,
                                                        const int32_t* __restrict__ num_points, int V, int P,
                                                        float* __restrict__ dT) {
-  constexpr int U = 4 * U4, RPW = 64 / U4, NI = 8 / RPW;
+  constexpr int U = 4 * U4, RPW = 64 / U4, NI = CH / RPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
   const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs4 = *reinterpret_cast<const float4*>(rstd + c);
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__
     const float4 ypn = YP4[(int64_t)v1 * U4 + sub], dzpn = DP4[(int64_t)v1 * U4 + sub];
     const float mult = (float)(P - n);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = 0; j0 < n; j0 += 8) {
+    for (int j0 = 0; j0 < n; j0 += CH) {
       if (j0) load_rows(rs, n, j0, y, dz);               // pillars of more than 8 rows: the later chunks as they come
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -522,14 +523,14 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__
 
 // apply + max with the 4-channel lane map of k_pfn_bwd_bn_v4 (a wave instruction = 64 / U4 whole rows, 16-byte accesses,
 // the wave's next pillar in flight while this one is computed); the row groups' maxima meet through shuffles.
-template <int U4>
+template <int U4, int CH>
 __global__ void __launch_bounds__(256) k_pfn_apply_max_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const int32_t* __restrict__ row_start,
                                                           const int32_t* __restrict__ num_points, int V, int P,
                                                           float* __restrict__ A, float* __restrict__ Apad,
                                                           float* __restrict__ M) {
-  constexpr int RPW = 64 / U4, NI = 8 / RPW;
+  constexpr int RPW = 64 / U4, NI = CH / RPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
   const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
@@ -567,7 +568,7 @@ __global__ void __launch_bounds__(256) k_pfn_apply_max_v4(const float* __restric
     const float4 ypn = YP4[(int64_t)v1 * U4 + sub];
     const float4 ap = act(ypv);
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    for (int j0 = 0; j0 < n; j0 += 8) {
+    for (int j0 = 0; j0 < n; j0 += CH) {
       if (j0) load_rows(rs, n, j0, y);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(256) k_pfn_apply_max_v4(const float* __restric
 // backward 1 (route dM through the max, relu', BatchNorm-backward sums) with the same lane map and pillar pipeline.  The
 // arg-max of a channel is the FIRST maximal real row (torch.max's first-index rule on the dense tensor): inside a lane rows
 // arrive in ascending order (strict >), across the row groups a tie goes to the smaller row index.
-template <int U4>
+template <int U4, int CH>
 __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restrict__ Y, const float* __restrict__ Ypad,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
                                                           const int32_t* __restrict__ row_start,
                                                           const int32_t* __restrict__ num_points, int V, int P,
                                                           float* __restrict__ DZpad, double* __restrict__ sums) {
-  constexpr int U = 4 * U4, RPW = 64 / U4, NI = 8 / RPW;
+  constexpr int U = 4 * U4, RPW = 64 / U4, NI = CH / RPW;
   __shared__ double red[kWavesPerBlock][2 * U];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % U4, rg = lane / U4, c = 4 * sub;
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
             }
           }
         }
-        for (int j0 = 8; j0 < n; j0 += 8) {
+        for (int j0 = CH; j0 < n; j0 += CH) {
           float4 yl[NI], gl[NI];
           load_rows(rs, n, j0, yl, gl, false);
 #pragma unroll
@@ -702,7 +703,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) pad_wins[k] = (n < P) && (fmaxf(yp[k] * sc[k] + sh[k], 0.f) > mx[k]);
       // pass 2: dz = relu'(a) * (dA + routed dM), BatchNorm-backward sums
-      for (int j0 = 0; j0 < n; j0 += 8) {
+      for (int j0 = 0; j0 < n; j0 += CH) {
         if (j0) load_rows(rs, n, j0, y, g, dA);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -820,9 +821,9 @@ extern "C" int mbv_pfn_apply_max(const float* y, const float* y_pad, const float
   if (!y || !y_pad || !scale || !shift || !row_start || !num_points || !m) return MBV_ERR_BAD_ARG;
   if (pfn_v4_ok(units, y, y_pad, scale, shift, a, a_pad, m)) {
     const dim3 grid(grid_for(num_pillars)), block(256);
-#define MBV_V4(U4) hipLaunchKernelGGL((k_pfn_apply_max_v4<U4>), grid, block, 0, stream, y, y_pad, scale, shift, row_start, \
+#define MBV_V4(U4, CH) hipLaunchKernelGGL((k_pfn_apply_max_v4<U4, CH>), grid, block, 0, stream, y, y_pad, scale, shift, row_start, \
                                       num_points, (int)num_pillars, max_points, a, a_pad, m)
-    if (units == 32) MBV_V4(8); else if (units == 64) MBV_V4(16); else MBV_V4(32);
+    if (units == 32) MBV_V4(8, 8); else if (units == 64) MBV_V4(16, 8); else MBV_V4(32, kChunk128);
 #undef MBV_V4
     MBV_CHECK_LAUNCH();
     return MBV_OK;
@@ -847,9 +848,9 @@ extern "C" int mbv_pfn_bwd_route(const float* y, const float* y_pad, const float
     return MBV_ERR_BAD_ARG;
   if (pfn_v4_ok(units, y, y_pad, scale, shift, mean, rstd, dz, sum_da_pad, dm, dz_pad)) {
     const dim3 grid(grid_for(num_pillars)), block(256);
-#define MBV_V4(U4) hipLaunchKernelGGL((k_pfn_bwd_route_v4<U4>), grid, block, 0, stream, y, y_pad, scale, shift, mean, rstd, dz, \
+#define MBV_V4(U4, CH) hipLaunchKernelGGL((k_pfn_bwd_route_v4<U4, CH>), grid, block, 0, stream, y, y_pad, scale, shift, mean, rstd, dz, \
                                       has_da, sum_da_pad, dm, row_start, num_points, (int)num_pillars, max_points, dz_pad, sums)
-    if (units == 32) MBV_V4(8); else if (units == 64) MBV_V4(16); else MBV_V4(32);
+    if (units == 32) MBV_V4(8, 8); else if (units == 64) MBV_V4(16, 8); else MBV_V4(32, kChunk128);
 #undef MBV_V4
     MBV_CHECK_LAUNCH();
     return MBV_OK;
@@ -872,13 +873,13 @@ extern "C" int mbv_pfn_bwd_bn(const float* y, const float* y_pad, float* dz, flo
   if (pfn_v4_ok(units, y, y_pad, dz, dz_pad, mean, rstd, gamma, dt)) {
     const dim3 grid(grid_for(num_pillars)), block(256);
     if (units == 32)
-      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<8>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<8, 8>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
                          training, row_start, num_points, (int)num_pillars, max_points, dt);
     else if (units == 64)
-      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<16>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<16, 8>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
                          training, row_start, num_points, (int)num_pillars, max_points, dt);
     else
-      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<32>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
+      hipLaunchKernelGGL((k_pfn_bwd_bn_v4<32, kChunk128>), grid, block, 0, stream, y, y_pad, dz, dz_pad, mean, rstd, gamma, sums, count,
                          training, row_start, num_points, (int)num_pillars, max_points, dt);
     MBV_CHECK_LAUNCH();
     return MBV_OK;
