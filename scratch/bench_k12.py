@@ -2,7 +2,10 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from mask_bev_amd import ops, _lib
+from mask_bev_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])          # another build of the library (A/B of two kernels)
+from mask_bev_amd import ops
 from _timeit import timeit
 dev = torch.device('cuda', 0)
 lib = _lib.load()
@@ -22,4 +25,5 @@ for rows, c in ((65536, 192), (16384, 384), (4096, 768), (1024, 1536), (21504, 2
     a = torch.randn(rows, c, device=dev); b = torch.randn(rows, c, device=dev).bfloat16()
     tf = timeit(lambda: lib.mbv_add_layernorm_fwd(P(a), 0, P(b), 1, P(gam), P(bet), rows, c, 1e-5, P(so), P(y), 1, P(mean), P(rstd), S()))
     byf = rows * c * (4 + 2 + 4 + 2)
+    torch.cuda.synchronize()
     print(f'rows {rows:6d} C {c:5d}  bwd {tb:6.1f} us ({by / tb / 1e6:5.2f} TB/s, blocks {nblk})   fwd {tf:6.1f} us ({byf / tf / 1e6:5.2f} TB/s)', flush=True)
