@@ -11,11 +11,14 @@ from _timeit import timeit
 lib = _lib.load()
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-mats = [torch.randn(21504, 1024, device=dev).bfloat16() for _ in range(5)]
-mats += [torch.randn(65536, 192, device=dev).bfloat16() for _ in range(2)]
-mats += [torch.randn(1024, 576, device=dev) for _ in range(12)]
-mats += [torch.randn(512, 2304, device=dev) for _ in range(12)]
-mats += [torch.randn(4096, 256, device=dev).bfloat16() for _ in range(10)]
+# the eager step's largest group (scratch/dump_colsum_mix.py): 319 entries, 464 MB, a few of 8-25 MB and a long tail below 1 MB
+mats = [torch.randn(65536, 192, device=dev).bfloat16(), torch.randn(16384, 256, device=dev)]
+mats += [torch.randn(1024, 6144, device=dev).bfloat16() for _ in range(2)]
+mats += [torch.randn(21504, 256, device=dev).bfloat16() for _ in range(6)]
+mats += [torch.randn(16384, 256, device=dev).bfloat16() for _ in range(10)]
+mats += [torch.randn(1024, 192, device=dev) for _ in range(150)]
+mats += [torch.randn(512, 384, device=dev) for _ in range(100)]
+mats += [torch.randn(400, 256, device=dev).bfloat16() for _ in range(49)]
 outs = [torch.zeros(m.shape[1], device=dev) for m in mats]
 n = len(mats)
 PA, IA, LA = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
