@@ -97,6 +97,9 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
  * slots → concat) reached from MaskBevEncoder.encode (mask_bev/models/encoders/mask_bev_encoders.py:70-72,
  * 119-120).  The Linear parts stay library GEMMs (y = a_prev W_a^T, t = max_prev W_b^T, y_pad = a_pad_prev W_a^T).
  * All tensors f32; `units` <= 128 channels; rows of pillar v are [row_start[v], row_start[v] + num_points[v]).
+ * With 32 / 64 / 128 units and 16-byte aligned tensors the walks (apply_max, bwd_route, bwd_bn) give a lane four adjacent
+ * channels: a wave instruction covers 64 / (units / 4) whole rows, and the wave's next pillar is requested while this one is
+ * computed (pfn.hip k_pfn_*_v4); other unit counts take the lane = channel kernels.  Same results either way.
  *   mbv_pfn_stats       y[r] += t[v], y_pad[v] += t[v] (when t != NULL); sums[0:U] = sum y, sums[U:2U] = sum y^2
  *                       over all V * max_points rows (padded rows weighted by their multiplicity), f64
  *   mbv_pfn_bn_finalize batch (training != 0) or running statistics → scale, shift, mean, rstd; updates the

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_bn_v4(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = j0 + i * RPW + rg;
-      const int64_t at = (rs + (r < n ? r : n - 1)) * U4 + sub;
+      const int64_t at = (rs + (r < n ? r : (n > 0 ? n - 1 : 0))) * U4 + sub;
       y[i] = Y4[at];
       dz[i] = DZ4[at];
     }
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) k_pfn_apply_max_v4(const float* __restric
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = j0 + i * RPW + rg;
-      y[i] = Y4[(rs + (r < n ? r : n - 1)) * U4 + sub];
+      y[i] = Y4[(rs + (r < n ? r : (n > 0 ? n - 1 : 0))) * U4 + sub];
     }
   };
   auto act = [&](const float4& y) {
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int r = j0 + i * RPW + rg;
-        const int64_t at = (rs + (r < n ? r : n - 1)) * U4 + sub;
+        const int64_t at = (rs + (r < n ? r : (n > 0 ? n - 1 : 0))) * U4 + sub;
         y[i] = Y4[at];
         if (want_g) g[i] = DZ4[at];
       }
