@@ -643,17 +643,28 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
     int v1 = v + vstride < V ? v + vstride : vlast;
     int n1 = num_points[v1];
     int64_t rs1 = row_start[v1];
-    float4 y[NI], g[NI], yn[NI], gn[NI];
+    float4 y[NI], g[NI], yn[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { g[i] = zero4; gn[i] = zero4; }
-    load_rows(rs, n, 0, y, g, dA);
-    float4 ypv = YP4[(int64_t)v * U4 + sub], dmv = DM4[(int64_t)v * U4 + sub], gpv = SA4[(int64_t)v * U4 + sub];
+    for (int i = 0; i < NI; ++i) g[i] = zero4;
+    load_rows(rs, n, 0, y, g, false);
     for (; v < V; v += vstride) {
       const int v2 = v + 2 * vstride < V ? v + 2 * vstride : vlast;
       const int n2 = num_points[v2];
       const int64_t rs2 = row_start[v2];
-      load_rows(rs1, n1, 0, yn, gn, dA);
-      const float4 ypn = YP4[(int64_t)v1 * U4 + sub], dmn = DM4[(int64_t)v1 * U4 + sub], gpn = SA4[(int64_t)v1 * U4 + sub];
+      // (this pillar's padded row, dM and dA_pad are asked for here, not a pillar ahead: they are first used behind pass 1,
+      // and the twelve registers of a second set cost the kernel a wave per SIMD)
+      const float4 ypv = YP4[(int64_t)v * U4 + sub], dmv = DM4[(int64_t)v * U4 + sub], gpv = SA4[(int64_t)v * U4 + sub];
+      if (dA) {                                          // dA of THIS pillar: used in pass 2, in flight during pass 1
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = i * RPW + rg;
+          g[i] = DZ4[(rs + (r < n ? r : (n > 0 ? n - 1 : 0))) * U4 + sub];
+        }
+      }
+      {
+        float4 gdummy[NI];
+        load_rows(rs1, n1, 0, yn, gdummy, false);        // the next pillar's rows of y
+      }
       const float yp[4] = {ypv.x, ypv.y, ypv.z, ypv.w}, dm[4] = {dmv.x, dmv.y, dmv.z, dmv.w};
       const float gp[4] = {SApad ? gpv.x : 0.f, SApad ? gpv.y : 0.f, SApad ? gpv.z : 0.f, SApad ? gpv.w : 0.f};
       float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -741,8 +752,7 @@ __global__ void __launch_bounds__(256) k_pfn_bwd_route_v4(const float* __restric
       for (int k = 0; k < 4; ++k) { s1[k] += f1[k]; s2[k] += f2[k]; }
       n = n1; rs = rs1; n1 = n2; rs1 = rs2; v1 = v2;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) { y[i] = yn[i]; g[i] = gn[i]; }
-      ypv = ypn; dmv = dmn; gpv = gpn;
+      for (int i = 0; i < NI; ++i) y[i] = yn[i];
     }
   }
   // the row groups' channel sums meet through shuffles, the waves' in LDS; one set of channel atomics per workgroup
