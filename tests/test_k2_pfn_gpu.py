@@ -18,7 +18,10 @@ def _rel(a, b):
 @pytest.mark.parametrize('chans,P,sizes,training', [([32, 32, 32], 8, [3000, 2000], True),
                                                     ([128, 128, 128], 32, [6000], True),
                                                     ([64, 128], 4, [1500, 10, 900], True),
-                                                    ([32, 32, 32], 8, [2500], False)])
+                                                    ([32, 32, 32], 8, [2500], False),
+                                                    # unit counts outside {32, 64, 128}: the lane = channel walk kernels
+                                                    # (the 4-channel lane map takes the three sizes above) and library Linears
+                                                    ([48, 96], 8, [2000, 700], True)])
 @pytest.mark.parametrize('path', ['stream', 'walk', 'layers'])
 def test_pfn_matches_dense_oracle(device, chans, P, sizes, training, pc_dim, path, monkeypatch):
     """path: 'stream' = the one-call forward with the pillar term inside K2c and streamed BatchNorm statistics (the default),
