@@ -15,8 +15,10 @@ Extra objects on the line:
                 the optimizer kernel run eagerly inside the timed region and are timed there; the kernels inside the
                 replayed HIP graphs cannot carry events, so every C-ABI call of two eager steps run right AFTER the
                 timed region is bracketed by events instead (mask_bev_amd/workmodel.py holds the work of each call).
-                `roofline_all` lists every instrumented kernel, ranked by time per step; `traffic` is the measured HBM
-                bytes per launch from the PMC passes kept in `roofline_traffic_source` (null when not measured).
+                `traffic` is the measured HBM bytes per launch from the PMC passes kept in `roofline_traffic_source`
+                (null when not measured).  The printed line stays under 4 KB (`compact_line`): it carries `roofline`,
+                `roofline_top` (the five families that cost the most time) and `roofline_worst`; the table of EVERY
+                instrumented family of both dtypes (`roofline_all`) goes to `--detail-out` (gpurun_out/bench_detail.json).
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample:
                 1 warm-up + 3 iterations, forward and forward+backward, at 6 threads (the reference's setting).
   fp32          the same step in fp32 — the precision the reference trains in — timed the same way (20 steps).
@@ -66,6 +68,9 @@ def parse():
                          'default f32 = the exact in-place exchange)')
     ap.add_argument('--gemm-table', default=None, metavar='CSV',
                     help='a TunableOp selection table other than the committed one (A/B of a re-tuned table)')
+    ap.add_argument('--detail-out', default=None, metavar='FILE',
+                    help='where the full record (roofline_all of both dtypes, every cpu_baseline row) is written; '
+                         'default gpurun_out/bench_detail.json — the printed line carries the summary only')
     ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set a path selector of mask_bev_amd/switches.py (recorded in config.switches)')
     return ap.parse_args()
@@ -338,6 +343,100 @@ def roofline_entry(kernel, bound, avg_ms, launches_per_step, nbytes, flops, traf
                 algorithmic_bytes=nbytes, algorithmic_flops=flops, timing=source)
 
 
+LINE_LIMIT = 4096      # the driver keeps the tail of stdout: the ONE JSON line must fit it whole (a 35.8 KB
+                       # line with `roofline_all` x 2 dtypes came back `parsed: null`)
+
+
+def _short(x, digits=6):
+    """Floats to `digits` significant digits (the line is read by people and parsers, not re-used as input)."""
+    if isinstance(x, float):
+        return float(f'{x:.{digits}g}')
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+def _roofline_object(r):
+    """The contract's `roofline` object + the few fields that say which kernel it is and what it costs per step."""
+    if not isinstance(r, dict) or 'frac' not in r:
+        return r
+    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_ms', 'launches_per_step',
+            'total_ms_per_step', 'algorithmic_bytes', 'algorithmic_flops')
+    return {k: r.get(k) for k in keep}
+
+
+def compact_line(full: dict, detail_path=None) -> dict:
+    """The ONE line rank 0 prints last: every key of the bench contract, `roofline` (dominant family), `roofline_coverage`,
+    `step_roofline`, the reference-precision `fp32` figure with its own `roofline`, `cpu_baseline` (one row), and — instead
+    of the per-family tables, which go to `detail_path` — the five families that cost the most time and the one that sits
+    furthest below its roofline.  Always shorter than LINE_LIMIT bytes: optional pieces are dropped in a fixed order
+    until it is."""
+    top = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+           'vs_baseline', 'dtype', 'data')
+    line = {k: full.get(k) for k in top}
+    cfg = dict(full.get('config') or {})
+    line['config'] = cfg
+    line['roofline'] = _roofline_object(full.get('roofline'))
+    ranked = full.get('roofline_all') or []
+    if ranked:
+        line['roofline_top'] = [dict(kernel=r['kernel'], bound=r['bound'], frac=r['frac'],
+                                     ms_per_step=r['total_ms_per_step']) for r in ranked[:5]]
+        priced = [r for r in ranked if r.get('frac') and r['total_ms_per_step'] >= 0.05]
+        if priced:
+            w = min(priced, key=lambda r: r['frac'])
+            line['roofline_worst'] = dict(kernel=w['kernel'], bound=w['bound'], frac=w['frac'],
+                                          ms_per_step=w['total_ms_per_step'])
+    line['roofline_coverage'] = full.get('roofline_coverage')
+    line['roofline_traffic_source'] = full.get('roofline_traffic_source')
+    line['roofline_detail'] = detail_path
+    sr = full.get('step_roofline')
+    if sr:
+        line['step_roofline'] = {k: sr[k] for k in ('flops_per_scan', 'bytes_per_scan', 'achieved_tflops', 'frac_mfma',
+                                                    'achieved_gbs', 'frac_hbm') if k in sr}
+    f32 = full.get('fp32')
+    if f32:
+        line['fp32'] = {k: (_roofline_object(v) if k == 'roofline' else v) for k, v in f32.items()
+                        if k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'roofline',
+                                 'roofline_coverage', 'error')}
+    if full.get('collectives'):
+        line['collectives'] = full['collectives']
+    cb = full.get('cpu_baseline')
+    if cb:
+        cb = dict(cb)
+        rows = cb.pop('rows', None) or []
+        if rows:
+            r = rows[0]
+            cb['row'] = {k: r.get(k) for k in ('threads', 'iterations', 'fwd_bwd_s', 'fwd_s', 'fwd_scans_per_s', 'note')}
+        line['cpu_baseline'] = cb
+    line = _short(line)
+    for drop in (('collectives', 'schedule'), ('roofline_top',), ('cpu_baseline', 'row'), ('fp32', 'roofline'),
+                 ('roofline_worst',), ('config', 'switches'), ('step_roofline',)):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        node = line
+        for k in drop[:-1]:
+            node = node.get(k) or {}
+        node.pop(drop[-1], None)
+    assert len(json.dumps(line)) < LINE_LIMIT, 'bench line over the limit'
+    return line
+
+
+def write_detail(full: dict, path=None):
+    """The whole record (every family of both dtypes, every CPU-baseline row) as a JSON file beside the run; returns
+    the path written, relative to the repository, or None when it cannot be written (never fatal)."""
+    path = path or os.path.join('gpurun_out', 'bench_detail.json')
+    try:
+        target = path if os.path.isabs(path) else os.path.join(ROOT, path)
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        with open(target, 'w') as fh:
+            json.dump(full, fh)
+        return path
+    except OSError:
+        return None
+
+
 def main():
     args = parse()
     from mask_bev_amd import switches
@@ -523,7 +622,7 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic' if args.distribution == 'lidar' else 'synthetic (uniform x/y points)',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if world > 1 else None), replica_param_checksum_spread=replica_spread,
+                        step='fwd + Hungarian loss + bwd + AdamW; inputs device-resident', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if world > 1 else None), replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss,
                         switches={k: v for k, v in switches._values.items() if v != switches.defaults()[k]}),
             roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,
@@ -549,7 +648,8 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line['cpu_baseline'] = dict(value=None, unit='scans/s', cores=os.cpu_count(), kind='port',
                                             sample=f'failed: {type(e).__name__}: {e}')
-        print(json.dumps(line), flush=True)
+        detail_path = write_detail(line, args.detail_out)
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

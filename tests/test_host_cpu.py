@@ -397,6 +397,15 @@ def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
     assert rounds, 'no committed bench line under profiles/'
     files = sorted(glob.glob(os.path.join(rounds[-1], '*bench_default.json')))
     line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    if 'roofline_all' not in line:
+        # round 5 on: the printed line is the summary (< 4 KB, test below); the per-family tables of the same run sit
+        # beside it as `*bench_detail.json` (bench.py --detail-out)
+        assert len(open(files[-1]).read().strip().splitlines()[-1]) < 4096
+        detail = files[-1].replace('bench_default.json', 'bench_detail.json')
+        assert os.path.exists(detail), detail
+        full = json.load(open(detail))
+        assert abs(full['value'] - line['value']) <= 1e-4 * line['value'] and full['roofline']['kernel'] == line['roofline']['kernel']
+        line = full
     if os.path.basename(rounds[-1]) >= 'r04':
         # round 4: the table prices the WHOLE step (library GEMMs, MIOpen, ATen kernels, PFN, K1 included): the families'
         # time per step adds up to at least 0.9 of the measured step, and `roofline` is the family that costs the most
@@ -429,6 +438,44 @@ def test_committed_bench_line_traffic_not_below_algorithmic_bytes():
         assert r['traffic'] >= floor * r['algorithmic_bytes'], (r['kernel'], r['traffic'], r['algorithmic_bytes'])
         checked += 1
     assert checked >= 20
+
+
+def test_bench_line_fits_the_drivers_tail_and_keeps_the_contract():
+    """the driver parses the LAST stdout line of bench.py from a bounded tail; round 4's 35.8 KB line
+    (`roofline_all` of two dtypes) came back `parsed: null`.  `bench.compact_line` builds the printed line from the full
+    record: here from round 4's committed full record (the shape every later run produces), and from one inflated with
+    long tables, switches and a collectives schedule — always < 4 096 bytes, always with the contract's keys."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, 'profiles', 'r04', 'f_bench_default.json')).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 30_000            # the record that did not parse
+    required = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+    line = bench.compact_line(full, 'gpurun_out/bench_detail.json')
+    text = json.dumps(line)
+    assert len(text) < 4096, len(text)
+    for k in required:
+        assert k in line, k
+    assert abs(line['value'] - full['value']) < 1e-3 * full['value'] and line['dtype'] == 'bf16'
+    assert set(line['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert line['roofline']['kernel'] == full['roofline']['kernel']
+    assert abs(line['roofline']['frac'] - line['roofline']['achieved'] / line['roofline']['peak']) < 1e-4
+    assert set(line['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'} and 'rows' not in line['cpu_baseline']
+    assert line['fp32']['value'] and line['fp32']['roofline']['kernel'] == 'hipblaslt_f32' and 'roofline_all' not in line['fp32']
+    assert 'roofline_all' not in line and line['roofline_detail'] == 'gpurun_out/bench_detail.json'
+    assert len(line['roofline_top']) == 5 and line['roofline_top'][0]['kernel'] == line['roofline']['kernel']
+    assert 'step_roofline' in line and 0 < line['step_roofline']['frac_hbm'] < 1
+    # a pathological record: the optional pieces go, the contract stays
+    fat = json.loads(json.dumps(full))
+    fat['config']['switches'] = {f'switch_{i}': 'x' * 40 for i in range(60)}
+    fat['collectives'] = dict(backend='nccl', bytes_per_step=1, note='n' * 300,
+                              schedule=[dict(mark='m' * 30, ms=1.0, mb=2.0) for _ in range(80)])
+    fat['cpu_baseline']['rows'] = fat['cpu_baseline']['rows'] * 8
+    line = bench.compact_line(fat, None)
+    assert len(json.dumps(line)) < 4096
+    for k in required:
+        assert k in line, k
+    assert line['roofline']['frac'] > 0 and line['cpu_baseline']['value'] > 0
 
 
 def test_level_inputs_node_equals_the_plain_ops():
