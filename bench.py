@@ -583,10 +583,12 @@ def main():
                 # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
                 'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
         # HBM bytes per launch measured with the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
-        # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload and build: profiles/r04/pmc_hbm_traffic.json
-        traffic, traffic_file = {}, os.path.join('profiles', 'r04', 'pmc_hbm_traffic.json')
-        if not os.path.exists(os.path.join(ROOT, traffic_file)):
-            traffic_file = os.path.join('profiles', 'r03', 'pmc_hbm_traffic.json')
+        # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload: profiles/rNN/pmc_hbm_traffic.json
+        traffic, traffic_file = {}, None
+        for rnd in ('r05', 'r04', 'r03'):                      # the latest round that holds a PMC pass of this workload
+            traffic_file = os.path.join('profiles', rnd, 'pmc_hbm_traffic.json')
+            if os.path.exists(os.path.join(ROOT, traffic_file)):
+                break
         if (args.workload == 'semantic_kitti_512' and args.batch == 4 and not args.no_arena and io == 2.0
                 and args.distribution == 'lidar' and os.path.exists(os.path.join(ROOT, traffic_file))):
             with open(os.path.join(ROOT, traffic_file)) as fh:

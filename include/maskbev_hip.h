@@ -100,6 +100,11 @@ int mbv_pfn_decorate(const float* points, int32_t point_dim, const int32_t* pill
  * With 32 / 64 / 128 units and 16-byte aligned tensors the walks (apply_max, bwd_route, bwd_bn) give a lane four adjacent
  * channels: a wave instruction covers 64 / (units / 4) whole rows, and the wave's next pillar is requested while this one is
  * computed (pfn.hip k_pfn_*_v4); other unit counts take the lane = channel kernels.  Same results either way.
+ * PRECONDITION of every mbv_pfn_* entry and of mbv_pfn_decorate: 1 <= num_points[v] <= max_points for every pillar v <
+ * num_pillars (K1 never emits an empty pillar: a pillar exists because a point fell into its cell).  The walks request a
+ * pillar's first rows unconditionally on a clamped index and the decoration reads slot num_points - 1; num_points lives on
+ * the device, so the library cannot check it per call — an empty pillar is the caller's error (reads one row past the
+ * compact rows for an empty LAST pillar).
  *   mbv_pfn_stats       y[r] += t[v], y_pad[v] += t[v] (when t != NULL); sums[0:U] = sum y, sums[U:2U] = sum y^2
  *                       over all V * max_points rows (padded rows weighted by their multiplicity), f64
  *   mbv_pfn_bn_finalize batch (training != 0) or running statistics → scale, shift, mean, rstd; updates the

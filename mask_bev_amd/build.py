@@ -62,6 +62,7 @@ def _compile_one(src: str, verbose: bool) -> str:
     stamp = _stamp(src, flags)
     if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return obj
+    LAST_BUILD['recompiled'].append(src)
     cmd = [_hipcc(), '-c', os.path.join(CSRC, src), '-o', obj] + flags
     if verbose:
         print(' '.join(cmd), flush=True)
@@ -71,8 +72,14 @@ def _compile_one(src: str, verbose: bool) -> str:
     return obj
 
 
+# what the last build() call did: 'stamp hit' (every object's source + flag hash matched, nothing compiled),
+# 'recompiled' (the listed translation units were compiled) — printed by __graft_entry__.build()
+LAST_BUILD = {'mode': None, 'recompiled': [], 'linked': False}
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(BUILD_DIR, exist_ok=True)
+    LAST_BUILD.update(mode=None, recompiled=[], linked=False)
     if force:
         for f in os.listdir(BUILD_DIR):
             os.remove(os.path.join(BUILD_DIR, f))
@@ -85,6 +92,8 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        LAST_BUILD['linked'] = True
+    LAST_BUILD['mode'] = 'recompiled' if LAST_BUILD['recompiled'] else ('relinked' if LAST_BUILD['linked'] else 'stamp hit')
     return LIB_PATH
 
 

@@ -97,6 +97,7 @@ class GradientAllReducer:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         self._active = self.arena is None
         self._next = 0                      # buckets are launched in index order on every rank
+        self.debug_pending = None           # tests: [(RangeReady, (lo, hi)), ...] checked by start_ranges
         self.sync_parameters()
         self._reset()
 
@@ -110,18 +111,35 @@ class GradientAllReducer:
             arena.refresh_shadow()
 
     @torch.no_grad()
-    def sync_buffers(self):
+    def sync_buffers_begin(self):
+        """Launch the broadcast of rank 0's floating-point buffers (the PFN's BatchNorm running statistics: < 2 KB) as ONE
+        asynchronous collective on the communication stream and return a handle for :meth:`sync_buffers_end` — nothing
+        here waits on the host, so the step's kernels behind it are issued at once."""
         if not self.broadcast_buffers:
-            return
+            return None
         bufs = [b for b in self.module.buffers() if b.is_floating_point()]
         if not bufs:
-            return
+            return None
         flat = torch.cat([b.reshape(-1).float() for b in bufs])
-        dist.broadcast(flat, src=0, group=self.group)
+        work = dist.broadcast(flat, src=0, group=self.group, async_op=True)
+        return work, flat, bufs
+
+    @torch.no_grad()
+    def sync_buffers_end(self, handle) -> None:
+        """Order the current stream behind the broadcast and write rank 0's values into the buffers."""
+        if handle is None:
+            return
+        work, flat, bufs = handle
+        work.wait()
         off = 0
         for b in bufs:
             b.copy_(flat[off:off + b.numel()].view_as(b))
             off += b.numel()
+
+    def sync_buffers(self):
+        """Lightning's ``strategy='ddp'`` default (``broadcast_buffers=True``): every forward starts from rank 0's
+        buffers (/root/reference: train_mask_bev.py:92-96).  Eager step: begin + end back to back."""
+        self.sync_buffers_end(self.sync_buffers_begin())
 
     def _reset(self):
         for b in self.buckets:
@@ -201,6 +219,13 @@ class GradientAllReducer:
         of a segment whose backward has already finished (graph.py launches them while the rest still runs)."""
         handles = []
         step = max(1, int(chunk_mb * 1024 * 1024) // 4)
+        if self.debug_pending is not None:
+            # debug flag (tests): a range may only go on the wire when no RangeReady guard still waits for one of its
+            # parameters' gradients in this backward pass
+            for guard, (ga, gb) in self.debug_pending:
+                if guard.pending() and not guard.fired and any(a < gb and ga < b for a, b in ranges):
+                    raise RuntimeError(f'start_ranges: range ({ga}, {gb}) launched while {len(guard.pending())} of its '
+                                       f'parameters have not accumulated their gradient')
         for a, b in ranges:
             for lo in range(a, b, step):
                 handles.append(self._reduce_chunk(arena, lo, min(b, lo + step)))
@@ -227,6 +252,45 @@ class GradientAllReducer:
         """Switch the hook-driven buckets off (gradient accumulation steps, HIP-graph capture / replay).  With a
         parameter arena they are never on."""
         self._active = (not flag) and self.arena is None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+class RangeReady:
+    """Fires ``callback()`` ONCE per backward pass, when EVERY parameter of a contiguous arena range has announced its
+    gradient (post-accumulate hooks; the arena's direct-accumulation kernels announce through ``ops._fire_grad_hooks``).
+    A range holds several parameters (a LayerNorm's weight and bias, a Linear's weight and bias): launching its in-place
+    all-reduce from ONE parameter's hook races with the accumulation of the others — autograd accumulates a layer's
+    parameters in no promised order (1 failure in 8 runs of the gloo test).  A parameter that is
+    announced twice in one pass (K3's backward is) counts once — so the guard is for parameters with ONE use per pass
+    (a packed in_proj weight is accumulated three times: its range goes out after the pass).  ``arm()`` before each backward, ``remove()`` after."""
+
+    def __init__(self, params, callback):
+        self.params = [p for p in params if p.requires_grad]
+        self.callback = callback
+        self._seen, self._fired = set(), False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._announce) for p in self.params]
+
+    def arm(self):
+        self._seen, self._fired = set(), False
+        return self
+
+    @property
+    def fired(self) -> bool:
+        return self._fired
+
+    def pending(self):
+        """Parameters of the range that have not announced a gradient in this pass."""
+        return [p for p in self.params if id(p) not in self._seen]
+
+    def _announce(self, p):
+        self._seen.add(id(p))
+        if not self._fired and len(self._seen) == len(self.params):
+            self._fired = True
+            self.callback()
 
     def remove(self):
         for h in self._hooks:

@@ -38,6 +38,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops, switches
+from .ddp import RangeReady
 from .mask_bev_module import MaskBevModule
 
 
@@ -155,6 +156,7 @@ class GraphedTrainStep:
             feats = m._backbone(self._x_in, cut=cut)
             early = list(feats[:cut['stage']])
             leaves = [f.detach().requires_grad_() for f in early]
+            m._panoptic_head._panoptic_head.announce_targets(self.labels, self.masks)      # static buffers, filled before the replay
             cls, masks, heights = m._panoptic_head(leaves + list(feats[cut['stage']:]))
         loss = m.loss(m.compute_loss(cls, masks, self.labels, self.masks, heights, None))
         m.scale_loss(loss).backward()          # fp16: times the device-side loss scale (a captured multiply)
@@ -181,10 +183,14 @@ class GraphedTrainStep:
     def step(self, batch) -> torch.Tensor:
         m = self.m
         scans, labels, masks, _ = m._unpack(batch)
-        if self.reducer is not None:
-            self.reducer.sync_buffers()
         with m._autocast():                                # eager: K1 → K2 → K3 (into the static buffer)
             x = self._rows(m._encoder(scans, patch=self._patch, out=self.x_static.detach()))
+        # Buffer broadcast (DDP's broadcast_buffers: the PFN's BatchNorm running statistics, < 2 KB).  In training mode the
+        # forward only WRITES them, so the exchange does not have to sit in front of the eager encoder as a blocking
+        # collective: rank 0's statistics of THIS step go out asynchronously right behind the encoder
+        # forward and are written into every rank's buffers after both graphs are queued — the replicas' buffers are equal
+        # when the step ends (DDP: when the next one starts).
+        buffers = self.reducer.sync_buffers_begin() if self.reducer is not None else None
         if labels.data_ptr() != self.labels.data_ptr():
             self.labels.copy_(labels)
         if isinstance(masks, ops.PackedMasks):
@@ -209,6 +215,8 @@ class GraphedTrainStep:
             handles = self.reducer.start_ranges(self.arena, self._ranges_head)
         mark('graph 2 replay')
         self.graph_late.replay()                           # backward of the earlier backbone stages
+        if buffers is not None:
+            self.reducer.sync_buffers_end(buffers)
         if overlap:
             mark('all-reduce: earlier backbone stages + patch projection', nb(self._ranges_late))
             handles += self.reducer.start_ranges(self.arena, self._ranges_late)
@@ -219,17 +227,19 @@ class GraphedTrainStep:
             ln_range = self.arena.range_of(ln)
             early = []
 
-            def launch_ln(_p):          # the hook may be announced more than once per backward: launch once
-                if not early:
-                    mark('all-reduce: encoder LayerNorm affine (from its gradient hook)', nb([ln_range]))
-                    early.extend(self.reducer.start_ranges(self.arena, [ln_range]))
+            def launch_ln():            # once per backward, when BOTH affine gradients have been announced
+                mark('all-reduce: encoder LayerNorm affine (from its gradient hooks)', nb([ln_range]))
+                early.extend(self.reducer.start_ranges(self.arena, [ln_range]))
 
-            hook = ln.bias.register_post_accumulate_grad_hook(launch_ln)
+            # the range holds weight AND bias: it goes on the wire when every parameter in it has announced itself
+            # (RangeReady), not from one parameter's hook — K3's backward writes both in one launch before it fires the
+            # hooks (ops.py, _ScatterLayerNorm.backward), and this no longer depends on that
+            guard = RangeReady(list(ln.parameters()), launch_ln).arm()
             try:
                 mark('encoder backward (eager)')
                 x.backward(self.x_static.grad)             # eager: backward of K3 / K2
             finally:
-                hook.remove()
+                guard.remove()
             a, b = self.arena.segments['encoder']
             rest = [(a, b)] if not early else [(a, ln_range[0]), (ln_range[1], b)]
             rest = [r for r in rest if r[1] > r[0]]

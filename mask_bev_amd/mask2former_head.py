@@ -436,14 +436,34 @@ class Mask2FormerHead(nn.Module):
         mask_pred, blocked = ops.mask_logits(mask_embed, mask_feature, target_size, out)
         return cls_pred, mask_pred, blocked
 
+    @staticmethod
+    def _target_key(t):
+        if isinstance(t, ops.PackedMasks):
+            t = t.words
+        if not torch.is_tensor(t) or not t.is_cuda:
+            return None
+        return (t.data_ptr(), tuple(t.shape), t.dtype)
+
+    def announce_targets(self, gt_labels, gt_masks) -> None:
+        """The caller's promise that these device tensors — the ones it will hand to `loss()` — are complete in the
+        current stream's order NOW, before `forward()` starts.  Only then may the loss's target preparation fork from
+        the start of the head's forward (see loss()): targets that are stacked from a list inside `loss()`, moved to the
+        device after `forward()`, or produced by anything launched later would be read by the side stream before their
+        producers ran.  `MaskBevModule._step` and the HIP-graph step announce; a bare `forward()` +
+        `compute_loss()` pair does not, and then the preparation stays on the caller's stream."""
+        keys = (self._target_key(gt_labels), self._target_key(gt_masks))
+        self._announced_targets = keys if None not in keys else None
+
     def forward(self, x: List[torch.Tensor], batch_data_samples=None):
         bs = x[0].shape[0]
         # fork point of the loss's target preparation (see loss()): everything it reads — the batch's labels and masks —
         # exists before the head starts, so it may run underneath the pixel decoder and the decoder layers
         self._early_event = None
-        if x[0].is_cuda and self.training and torch.is_grad_enabled() and switches.get('early_targets'):
-            self._early_event = torch.cuda.Event()
-            self._early_event.record(torch.cuda.current_stream(x[0].device))
+        announced, self._announced_targets = getattr(self, '_announced_targets', None), None
+        if (announced is not None and x[0].is_cuda and self.training and torch.is_grad_enabled()
+                and switches.get('early_targets')):
+            self._early_event = (torch.cuda.Event(), announced)
+            self._early_event[0].record(torch.cuda.current_stream(x[0].device))
         mask_features, memories = self.pixel_decoder(x)
         dec_in, dec_pos, dec_key = [], [], []
         # key = memory + pos, shared by the 3 layers of a level; under autocast one cast per level instead of one per
@@ -792,6 +812,13 @@ class Mask2FormerHead(nn.Module):
         # decoder layers instead of ≈ 0.25 ms in front of the matcher.
         early = getattr(self, '_early_event', None)
         self._early_event = None
+        if early is not None:
+            # the fork is only taken for the very tensors announced before forward() (announce_targets): anything else —
+            # list targets stacked above, tensors that reached the device after the head started — is ordered by the
+            # caller's stream, so its preparation stays there
+            early, announced = early
+            if announced != (self._target_key(labels_gt), self._target_key(packed_gt if packed_gt is not None else masks_gt)):
+                early = None
         prep = self._stream_for('prep', dev) if (early is not None and cls.is_cuda) else None
         main = torch.cuda.current_stream() if cls.is_cuda else None
         if prep is not None:

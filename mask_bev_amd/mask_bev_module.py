@@ -272,6 +272,8 @@ class MaskBevModule(_Base):
     def _step(self, batch, batch_idx, mode: str):
         x, labels_gt, masks_gt, metadata = self._unpack(batch)
         batch_size = len(x)
+        # the batch's targets exist before the forward starts: the head may prepare them beside its own forward
+        self._panoptic_head._panoptic_head.announce_targets(labels_gt, masks_gt)
         cls, masks, heights = self.forward(x)
         loss_dict = self.compute_loss(cls, masks, labels_gt, masks_gt, heights, None)
         loss = self.loss(loss_dict)

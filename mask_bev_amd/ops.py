@@ -886,7 +886,13 @@ class _MSDAQuerySide(torch.autograd.Function):
         host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
         g = torch.empty((t, width), dtype=dt, device=dev)                 # [d value | d offsets | d logits]
         dims = (b, n, heads, d, levels, n, points)
-        if dt in _LO_DTYPES and width % 2 == 0 and msda_value_packed_ok(dims, host_b):
+        packed = dt in _LO_DTYPES and width % 2 == 0 and msda_value_packed_ok(dims, host_b)
+        if value.dtype in _LO_DTYPES and not packed:
+            # the forward stored the value map in 16 bits on the promise of the packed gradient; the f64 form reads the
+            # map as f32 — were a switch flipped between the two halves it would read out of bounds
+            raise MaskBevHipError('MSDA backward: the forward kept a 16-bit value map, which only the packed value gradient '
+                                  'reads, and that path is unavailable now (switch changed between forward and backward?)')
+        if packed:
             # 16-bit compute: K5's value gradient is accumulated in packed fixed point (the attention weights are
             # K16's softmax outputs) and stored straight into the first E columns of G in its dtype — no f32
             # d(value) tensor, no cast pass
@@ -2115,24 +2121,7 @@ def mask_logits(mask_embed: torch.Tensor, mask_feature: torch.Tensor, target_siz
     rc = lib.mbv_attn_mask_from_logits(_ptr(src), _dt_flag(src.dtype), b * q, h, w, th, tw,
                                        _ptr(blocked), _stream())
     check(rc, 'mbv_attn_mask_from_logits')
-    teacher = TEACHER.get('blocked')
-    if teacher is not None:                      # test hook, see TEACHER
-        i = TEACHER.get('blocked_i', 0)
-        TEACHER['blocked_i'] = i + 1
-        if i < len(teacher) and teacher[i].shape == blocked.shape:
-            TEACHER.setdefault('blocked_flips', []).append((teacher[i] != blocked).sum())
-            if TEACHER.get('replace', True):
-                blocked = teacher[i]
     return logits, blocked
-
-
-# Test hook for the teacher-forced 16-bit parity test (tests/test_model_gpu.py); empty in normal operation.  The model has
-# two kinds of DISCONTINUITIES between its layers — the next layer's attention mask `sigmoid(logit) < 0.5` and the
-# Hungarian assignment — and a 16-bit run can only be compared with the fp32 oracle at rounding level when both take the
-# oracle's decisions: 'blocked' = list of (B, 1, Q, L) bool masks used instead of the computed ones, in call order
-# ('blocked_flips' collects how many bits differed); 'assignment' = (N, R) int32 taken instead of K9's result (which is
-# kept in 'assignment_raw'); 'replace': False only records the differences.
-TEACHER: dict = {}
 
 
 # --------------------------------------------------------------------------------------
@@ -2282,24 +2271,15 @@ def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None,
         if real_cols.numel() != n or not real_cols.is_cuda:
             raise MaskBevHipError('hungarian: real_cols must be a device tensor with one entry per problem')
         check(lib.mbv_hungarian_padded(_ptr(cost), n, r, c, _ptr(real_cols), _ptr(out), _stream()), 'mbv_hungarian_padded')
-        return _teach_assignment(out)
+        return out
     out.fill_(-1)
     if max(r, c) > 128 and r > c:         # wide problems are solved from global memory in (rows <= cols) orientation
         cost_t = cost.transpose(1, 2).contiguous()
         rc = lib.mbv_hungarian_wide_t(_ptr(cost_t), n, r, c, _ptr(out), _stream())
         check(rc, 'mbv_hungarian_wide_t')
-        return _teach_assignment(out)
+        return out
     rc = lib.mbv_hungarian(_ptr(cost), n, r, c, _ptr(out), _stream())
     check(rc, 'mbv_hungarian')
-    return _teach_assignment(out)
-
-
-def _teach_assignment(out: torch.Tensor) -> torch.Tensor:
-    teacher = TEACHER.get('assignment')
-    if teacher is not None and teacher.shape == out.shape:       # test hook, see TEACHER
-        TEACHER['assignment_raw'] = out.clone()
-        if TEACHER.get('replace', True):
-            out.copy_(teacher)
     return out
 
 

@@ -5,8 +5,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"; rm -rf gpurun_out/ev; mkdir -p gpurun_out/ev
 bash scratch/pmc_cmd.sh > gpurun_out/ev/pmc.log 2>&1; cp gpurun_out/pmc_hbm_traffic.json gpurun_out/pmc_hbm_traffic.csv gpurun_out/ev/
-mkdir -p profiles/r04; cp gpurun_out/pmc_hbm_traffic.json profiles/r04/pmc_hbm_traffic.json      # the bench line below reads it
-timeout 900 python3 bench.py > gpurun_out/ev/bench_default.json 2> gpurun_out/ev/bench_default.err; tail -c 300 gpurun_out/ev/bench_default.json
+mkdir -p profiles/r05; cp gpurun_out/pmc_hbm_traffic.json profiles/r05/pmc_hbm_traffic.json      # the bench line below reads it
+timeout 900 python3 bench.py --detail-out gpurun_out/ev/bench_detail.json > gpurun_out/ev/bench_default.json 2> gpurun_out/ev/bench_default.err; tail -c 300 gpurun_out/ev/bench_default.json
 bash scratch/prof_cmd.sh > gpurun_out/ev/prof.log 2>&1
 cp gpurun_out/prof_c/seq.txt gpurun_out/ev/kernel_sequence_one_step.txt; cp gpurun_out/prof_c/kernel_stats.csv gpurun_out/ev/kernel_stats.csv; cp gpurun_out/prof_c/agg.txt gpurun_out/ev/kernel_trace_by_step.txt; cp gpurun_out/prof_c/bench.json gpurun_out/ev/bench_under_rocprof.json
 bash scratch/phase_cmd.sh > gpurun_out/ev/phase.log 2>&1; cp gpurun_out/prof_p/phases.txt gpurun_out/ev/phases.txt

@@ -218,12 +218,17 @@ def _ranges_worker(rank, world, port, out):
     torch.manual_seed(7)
     x_all, y_all = torch.randn(8, 8), torch.randn(8, 1)
     idx = list(range(rank, 8, world))
+    from mask_bev_amd.ddp import RangeReady
     for _ in range(2):
         early = []
-        hook = enc[2].bias.register_post_accumulate_grad_hook(lambda p: early.extend(red.start_ranges(arena, [first_enc])))
+        # the range holds enc[2]'s weight AND bias: it goes on the wire when both have accumulated (RangeReady), not from
+        # the bias's hook alone (autograd promises no order between a layer's parameters: that form failed 1 run in 8)
+        guard = RangeReady(list(enc[2].parameters()), lambda: early.extend(red.start_ranges(arena, [first_enc]))).arm()
+        red.debug_pending = [(guard, first_enc)]
         ((m(x_all[idx]) - y_all[idx]) ** 2).mean().backward()
-        hook.remove()
-        assert early, 'the hook did not fire'
+        guard.remove()
+        red.debug_pending = None
+        assert early and guard.fired and not guard.pending(), 'the range was not launched from inside backward'
         handles = red.start_ranges(arena, [arena.segments['head'], last], chunk_mb=0.0005)
         handles += red.start_ranges(arena, [(a, last[0]), (last[1], b)])
         handles += early + red.start_ranges(arena, [(ea, first_enc[0]), (first_enc[1], eb)])
@@ -259,6 +264,52 @@ def test_staged_range_allreduce_world2_matches_single_process():
     from mask_bev_amd.arena import ParameterArena
     want = ParameterArena([('encoder', enc), ('backbone', bb), ('head', head)], shadow_dtype=None).param
     assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-6)
+
+
+def test_range_ready_fires_once_when_every_parameter_has_announced():
+    """RangeReady: the callback runs exactly once per armed pass, only after the LAST parameter of the range announced
+    (whatever the order, repeated announcements counted once), and `start_ranges`' debug check refuses a range whose
+    guard still waits."""
+    from mask_bev_amd.ddp import RangeReady
+    lin = nn.Linear(4, 3)
+    fired = []
+    guard = RangeReady(list(lin.parameters()), lambda: fired.append(len(guard.pending()))).arm()
+    for first, second in ((lin.bias, lin.weight), (lin.weight, lin.bias)):
+        guard.arm()
+        fired.clear()
+        guard._announce(first)
+        guard._announce(first)                      # announced twice (K3's backward does): still one parameter
+        assert not fired and guard.pending() == [second] and not guard.fired
+        guard._announce(second)
+        guard._announce(second)
+        assert fired == [0] and guard.fired
+    guard.arm()
+    fired.clear()
+    lin(torch.randn(5, 4)).sum().backward()         # through autograd's own post-accumulate hooks
+    assert fired == [0]
+    guard.remove()
+
+    class _Reducer:                                  # start_ranges' debug check, without a process group
+        debug_pending = None
+        grad_dtype = None
+        from mask_bev_amd.ddp import GradientAllReducer as _G
+        start_ranges = _G.start_ranges
+
+        def _reduce_chunk(self, arena, lo, hi):
+            return (lo, hi)
+
+    red = _Reducer()
+    guard = RangeReady(list(lin.parameters()), lambda: None).arm()
+    red.debug_pending = [(guard, (10, 20))]
+    assert red.start_ranges(None, [(0, 10), (20, 30)]) == [(0, 10), (20, 30)]          # disjoint: fine
+    with pytest.raises(RuntimeError):
+        red.start_ranges(None, [(5, 12)])
+    guard._announce(lin.weight)
+    with pytest.raises(RuntimeError):
+        red.start_ranges(None, [(10, 20)])
+    guard._announce(lin.bias)
+    assert red.start_ranges(None, [(10, 20)]) == [(10, 20)]
+    guard.remove()
 
 
 def test_arena_range_of_rejects_interleaved_parameters():

@@ -91,7 +91,8 @@ def _rank(rank, world, port, out_dir):
         scales.append(float(seen['grad_scale']))
     checksum = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().cpu()
     flat = arena.param.detach().cpu().clone()
-    torch.save(dict(ok_sum=ok_sum, ok_cov=ok_cov, scales=scales, checksum=checksum, params=flat,
+    buffers = torch.cat([b.detach().float().reshape(-1).cpu() for b in m.buffers() if b.is_floating_point()])
+    torch.save(dict(ok_sum=ok_sum, ok_cov=ok_cov, scales=scales, checksum=checksum, params=flat, buffers=buffers,
                     grad_norm=float(seen['reduced'].norm())), os.path.join(out_dir, f'rank{rank}.pt'))
     g.close()
     dist.destroy_process_group()
@@ -110,3 +111,7 @@ def test_two_rank_graph_step_reduces_the_arena(tmp_path):
         assert r['grad_norm'] > 0
     assert float(r0['checksum']) == float(r1['checksum'])          # replica_param_checksum_spread == 0
     assert torch.equal(r0['params'], r1['params'])
+    # the floating-point buffers (BatchNorm running statistics) are rank 0's on every rank when a step ends — the
+    # asynchronous broadcast behind the encoder forward (graph.py); the ranks saw different scans, so without it they differ
+    assert r0['buffers'].numel() > 0 and torch.equal(r0['buffers'], r1['buffers'])
+    assert float(r0['buffers'].abs().sum()) > 0

@@ -14,6 +14,48 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
 
 
+class _Teacher:
+    """Teacher forcing for the 16-bit parity tests, from OUTSIDE the product (no test hook on the hot
+    path): wraps `ops.mask_logits` and `ops.hungarian` for the duration of a `with` block.  The model has two kinds of
+    DISCONTINUITIES between its layers — the next layer's attention mask `sigmoid(logit) < 0.5` and the Hungarian
+    assignment — and a 16-bit run can only be compared with the fp32 oracle at rounding level when both take the
+    oracle's decisions.  `blocked` = list of (B, 1, Q, L) bool masks used instead of the computed ones, in call order
+    (`blocked_flips` collects how many bits differed); `assignment` = (N, R) int32 taken instead of K9's result (kept in
+    `assignment_raw`); `replace=False` only records the differences."""
+
+    def __init__(self, blocked=None, assignment=None, replace=True):
+        self.blocked, self.assignment, self.replace = blocked, assignment, replace
+        self.blocked_flips, self.assignment_raw, self._i = [], None, 0
+
+    def __enter__(self):
+        from mask_bev_amd import ops
+        self._ops, self._ml, self._hu = ops, ops.mask_logits, ops.hungarian
+
+        def mask_logits(*a, **k):
+            logits, blocked = self._ml(*a, **k)
+            i, self._i = self._i, self._i + 1
+            if self.blocked is not None and i < len(self.blocked) and self.blocked[i].shape == blocked.shape:
+                self.blocked_flips.append((self.blocked[i] != blocked).sum())
+                if self.replace:
+                    blocked = self.blocked[i]
+            return logits, blocked
+
+        def hungarian(*a, **k):
+            out = self._hu(*a, **k)
+            if self.assignment is not None and self.assignment.shape == out.shape:
+                self.assignment_raw = out.clone()
+                if self.replace:
+                    out.copy_(self.assignment)
+            return out
+
+        ops.mask_logits, ops.hungarian = mask_logits, hungarian
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.mask_logits, self._ops.hungarian = self._ml, self._hu
+        return False
+
+
 def _build(kw, device, seed=0):
     from mask_bev_amd.mask_bev_module import MaskBevModule
     cfg = O.make_cfg(**kw)
@@ -192,6 +234,39 @@ def test_loss_and_gradients_match_oracle(device):
     assert checked == 11
 
 
+def test_targets_that_arrive_after_forward_or_as_lists_are_ordered_by_the_callers_stream(device):
+    """the loss's target preparation forks where the head's forward began — legal only for targets
+    that were complete before it (`announce_targets`: `_step` and the HIP-graph step).  Targets handed over as LISTS
+    (the reference's interface: `torch.stack` inside `loss()`), or produced on the caller's stream AFTER `forward()`
+    behind a long-running kernel, must not be read early: the loss equals the one computed with resident tensors."""
+    kw = tiny_kwargs()
+    m, cfg, sd = _build(kw, device, seed=7)
+    head = m._panoptic_head._panoptic_head
+    head.num_points, head.point_seed = 256, 11
+    assert switches.get('early_targets')
+    scans = [s.to(device) for s in random_scans(kw, [3000, 2000], seed=2)]
+    labels, gt = random_gt(kw, 2, 3, seed=4)
+    labels_d, gt_d = labels.to(device), gt.to(device)
+    m.train()
+    want = float(m.training_step((scans, (labels_d, gt_d)), 1).detach())          # announced: the early fork is taken
+    # (a) lists of per-image tensors
+    cls, masks, _ = m(scans)
+    got = float(m.loss(m.compute_loss(cls, masks, list(labels_d.unbind(0)), list(gt_d.unbind(0)))).detach())
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+    # (b) targets written on the main stream after forward(), behind a spin: a side stream forked at the head's start
+    # would read the stale (all-zero / wrong-label) buffers
+    stale_l, stale_g = torch.zeros_like(labels_d), torch.ones_like(gt_d)
+    cls, masks, _ = m(scans)
+    torch.cuda._sleep(200_000_000)                                                 # ~ 0.1 s of busy stream
+    stale_l.copy_(labels_d)
+    stale_g.copy_(gt_d)
+    got = float(m.loss(m.compute_loss(cls, masks, stale_l, stale_g)).detach())
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+    # (c) the module's own step with list targets in the batch
+    got = float(m.training_step((scans, (list(labels_d.unbind(0)), list(gt_d.unbind(0)))), 1).detach())
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+
+
 @pytest.mark.parametrize('n_gt', [5, 8, 12])
 def test_loss_on_given_logits_any_gt_count(device, n_gt):
     """Product loss (K8 sampling, K9 matcher, layer-batched) vs oracle loss on the SAME logits, with fewer / equal /
@@ -269,15 +344,11 @@ def test_16bit_whole_model_against_fp32_oracle(device, capsys, dtype):
     cls_ref, masks_ref, loss_ref, blocked_ref, _ = _oracle_with_decisions(cfg, sd_g, scans, labels, gt, 11)
     loss_ref.backward()
     from mask_bev_amd import ops
-    ops.TEACHER.clear()
-    ops.TEACHER.update(blocked=[t.to(device) for t in blocked_ref], replace=False)     # count the flips, change nothing
-    try:
+    with _Teacher(blocked=[t.to(device) for t in blocked_ref], replace=False) as teacher:     # count the flips, change nothing
         with torch.no_grad():
             cls, masks, _ = m(dscans)
         torch.cuda.synchronize()
-        flips = [int(x) for x in ops.TEACHER.get('blocked_flips', [])]
-    finally:
-        ops.TEACHER.clear()
+        flips = [int(x) for x in teacher.blocked_flips]
     loss = m.training_step((dscans, (labels.to(device), gt.to(device))), 1)
     m.scale_loss(loss).backward()
     errs = {'attention-mask bits that differ from the oracle\'s, per decoder layer': flips}
@@ -370,7 +441,7 @@ TEACHER_TOL = {'bf16': dict(final=2.5e-2, layer_mask=3e-2, layer_cls=8e-2, loss=
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_16bit_whole_model_teacher_forced(device, capsys, dtype):
-    """The 16-bit product with the oracle's DECISIONS injected (ops.TEACHER: the ten attention masks and the Hungarian
+    """The 16-bit product with the oracle's DECISIONS injected (`_Teacher` above: the ten attention masks and the Hungarian
     assignment of the fp32 oracle, same weights / inputs / sampling points): every decoder output, the loss and the
     gradients then differ from the oracle by operand rounding only — the free-running test above carries flips of
     `sigmoid(logit) < 0.5`, of ReLU gates downstream of them and of the assignment on top.  Also reports how many mask
@@ -399,24 +470,20 @@ def test_16bit_whole_model_teacher_forced(device, capsys, dtype):
     head = m._panoptic_head._panoptic_head
     head.num_points, head.point_seed = 256, 11
     dscans = [s.to(device) for s in scans]
-    ops.TEACHER.clear()
-    ops.TEACHER.update(blocked=[t.to(device) for t in blocked], assignment=assignment.to(device), replace=True)
-    try:
+    with _Teacher(blocked=[t.to(device) for t in blocked], assignment=assignment.to(device), replace=True) as teacher:
         cls, masks, _ = m(dscans)
         loss = m.loss(m.compute_loss(cls, masks, labels.to(device), gt.to(device)))
         m.scale_loss(loss).backward()
         ops.flush_deferred_grads()
         torch.cuda.synchronize()
-        mask_flips = [int(x) for x in ops.TEACHER.get('blocked_flips', [])]
+        mask_flips = [int(x) for x in teacher.blocked_flips]
         # assignments that differ in a REAL ground-truth column (the padded all-zero columns are interchangeable: K9 hands
         # them out in ascending order, scipy in its own — same loss)
-        raw = ops.TEACHER['assignment_raw'].cpu().view(-1, labels.shape[0], assignment.shape[1])
+        raw = teacher.assignment_raw.cpu().view(-1, labels.shape[0], assignment.shape[1])
         real = ((labels != 0) | gt.flatten(2).any(-1))                                     # (B, G)
         want = assignment.view_as(raw)
         is_real = lambda a: torch.gather(real.unsqueeze(0).expand(a.shape[0], -1, -1), 2, a.clamp(min=0).long()) & (a >= 0)
         assign_flips = int(((raw != want) & (is_real(raw) | is_real(want))).sum())
-    finally:
-        ops.TEACHER.clear()
     assert len(mask_flips) == 9 and len(blocked) == 10      # (the tenth mask, behind the last layer, has no consumer)
     errs = dict(final=_rel(masks[-1].float().cpu(), masks_ref[-1].detach()),
                 layer_mask=max(_rel(masks[i].float().cpu(), masks_ref[i].detach()) for i in range(10)),
