@@ -914,6 +914,45 @@ int mbv_copy_group(const void* const* src, void* const* dst, const int64_t* byte
 int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t* rows, const int32_t* cols, int32_t n,
                         int32_t elem_size, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K20 — f32 GEMMs on the 16-bit matrix pipe (csrc/gemm_f32s.hip): every f32 operand element is split at staging time into
+ * an IEEE-half pair  x 2^e = hi + lo  (22 significant bits) and the product is hi.hi + hi.lo + lo.hi with f32
+ * accumulation (error <= 2^-22 sum|a||b| + K 2^-37 max|a| max|b|: the level of an f32 dot product; the dropped lo.lo
+ * term is 2^-22 relative).  Replaces, in the reference-precision (fp32) step, the f32 library GEMMs behind nn.Linear
+ * forward / backward of the token-major layers: Swin qkv / proj / FFN / patch merging
+ * (/root/reference: mask_bev/models/networks/swin/swin.py:89-116, 347-355, 611-616) and the pixel decoder's Linears
+ * (mask_bev/models/head/mask_bev_panoptic_head.py:119-146) — `precision=32` in train_mask_bev.py:96.
+ * All matrices f32, row-major, ld* in elements (multiples of 4), pointers 16-byte aligned, n and k multiples of 8.
+ * amax_*: device words holding the BITS of max|operand| (mbv_f32_absmax_group) from which the kernel derives the power
+ * of two that puts the operand's largest magnitude in [2^13, 2^14); NULL = unscaled (operands whose magnitudes lie
+ * within [2^-3, 2^15] then keep full accuracy, smaller elements lose one bit per binade).  `act`: 0 none, 1 ReLU,
+ * 2 GELU (erf form); out_pre (optional) receives the pre-activation.  Batched: `batch` products with element strides. */
+int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
+
+/* max|x| of `count` f32 tensors (rows[i], cols[i]) with row stride ld[i] (cols % 4 == 0), as the BITS of the maximum,
+ * combined into *out[i] by an integer atomic max: the word must hold 0 (or an earlier partial maximum of the same tensor)
+ * when the launch starts.  Every array argument is a HOST array of length count; one launch per 64 tensors. */
+int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ld,
+                         uint32_t* const* out, int32_t count, void* stream);
+
+/* out (m, n) = act(x (m, k) . w (n, k)^T + bias)                                   (nn.Linear forward) */
+int mbv_gemm32s_nt(const float* x, const float* w, const float* bias, float* out, float* out_pre, int64_t m, int64_t n,
+                   int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, const uint32_t* amax_x, const uint32_t* amax_w,
+                   int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w, int64_t stride_o, void* stream);
+
+/* out (m, k) = g (m, n) . w (n, k)                                                 (nn.Linear data gradient) */
+int mbv_gemm32s_nn(const float* g, const float* w, float* out, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw,
+                   int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, int32_t batch, int64_t stride_g,
+                   int64_t stride_w, int64_t stride_o, void* stream);
+
+/* dw (n, k) contiguous += g (m, n)^T . x (m, k)                                     (nn.Linear weight gradient)
+ * The token sum is cut into parts that are stored to `workspace` (mbv_gemm32s_tn_workspace_bytes) and added into dw by
+ * their owner thread: no atomics, bit-reproducible. */
+size_t mbv_gemm32s_tn_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int mbv_gemm32s_tn_acc(const float* g, const float* x, float* dw, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldx,
+                       const uint32_t* amax_g, const uint32_t* amax_x, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,536 @@
+// K20 — f32 GEMMs on the 16-bit matrix pipe: every f32 operand element is split, while its tile is staged, into an
+// IEEE-half PAIR  x * 2^e = hi + lo  (hi = half(x 2^e), lo = half(x 2^e - hi): 22 significant bits) and the product is
+// formed as  hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_f16 with f32 accumulation — three matrix instructions at 16x the
+// rate of v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md § Matrix cores: the exact-f32 MFMA runs at the f32 VECTOR rate,
+// 157 TFLOP/s, and the library's f32 GEMMs already sit at 0.72 of it — VERDICT r04 #3).  The dropped lo.lo term is 2^-22
+// relative.  It serves the reference-precision (fp32) step's token-major Linears — the Swin qkv / proj / fc1 / fc2 / patch
+// merging projections (/root/reference: mask_bev/models/networks/swin/swin.py:89-116, 347-355, 611-616), the pixel
+// decoder's Linears (mask_bev/models/head/mask_bev_panoptic_head.py:119-146) — in the three layouts of K17 (gemm.hip):
+//
+//   NT  C[m][n] = sum_k X[m][k] W[n][k]          forward Linear
+//   NN  C[m][k] = sum_n G[m][n] W[n][k]          data gradient
+//   TN  C[n][k] = sum_m G[m][n] X[m][k]          weight gradient (split over m: parts stored, owner adds — no atomics)
+//
+// Range: half has 5 exponent bits, so each operand is scaled by a power of two 2^e that puts its largest magnitude in
+// [2^13, 2^14) — PER TENSOR, from one device word holding the bits of max|x| (mbv_f32_absmax: one streaming pass, an
+// integer atomic max per workgroup; weights: once per optimizer step).  An element 2^-j of the maximum keeps 11 + 11 bits
+// for j <= 18 and loses one bit per binade below that (lo becomes subnormal; 2^-24 absolute on the scaled values, i.e.
+// 2^-38 of the operand's maximum): the error of a product row is <= 2^-22 sum|a||b| + K 2^-37 max|a| max|b|.  The scales
+// are exact (powers of two) and are divided out of the f32 accumulators in the epilogue.
+//
+// Structure: K17's 128 x 128 x 32 block (4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 MFMA tiles), but the operands arrive
+// through REGISTERS (buffer_load_dwordx4 with the descriptor's range check: ragged edges read as zeros) because they have
+// to be split on the way: one register set, step kt + 1 is split and written to the other LDS stage behind step kt's
+// matrix instructions, step kt + 2 is requested right after (cdna_hip_programming.md §5, T14 as G15 writes it); the LDS
+// images are K17's swizzled 16-bit images — one for the hi halves, one for the lo halves of each operand — so the
+// fragment reads (ds_read_b128 rows / ds_read_b64_tr_b16 transposed) are K17's.  Each element is split ONCE per workgroup
+// (6 VALU instructions per pair: v_pk_mul, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_fma, v_cvt_pk_f16_f32).
+
+#include "common.hpp"
+#include "gemm_tiles.hpp"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KB32 = 32;                          // K-step
+constexpr int IMG32 = 128 * KB32 * 2;             // one 16-bit image of a 128-wide operand tile: 8 KB
+constexpr int STAGE32 = 4 * IMG32;                // A hi, A lo, B hi, B lo
+constexpr int LDS32 = 2 * STAGE32;                // two stages: 64 KB -> two workgroups per CU
+constexpr int NLD = 4;                            // 16-byte loads per thread and operand tile (128 x 32 f32 / 256 threads)
+
+enum { EPI32_NONE = 0, EPI32_RELU = 1, EPI32_GELU = 2 };
+
+struct Gemm32Args {
+  const float* a;
+  const float* b;
+  float* c;             // (gm, gn) row-major f32
+  float* c2;            // EPI32_RELU / EPI32_GELU: optional pre-activation output
+  const float* bias;    // optional, (gn)
+  const unsigned* amax_a;   // device word: bits of max|a| over the operand (NULL: scale 1)
+  const unsigned* amax_b;
+  int gm, gn, gk;
+  int lda, ldb, ldc;
+  long long sa, sb, sc;     // batch strides (elements)
+  long long ssplit;         // splits > 1: element stride between the partial results of the K parts
+  unsigned a_bytes, b_bytes;
+  int ntm, ntn, splits, ksteps;
+  int acc_out;              // splits == 1: the product is ADDED to c (read-modify-write by the owning workgroup)
+};
+
+// 2^e with max * 2^e in [2^13, 2^14) from the bits of max|x| (exact; 1 for an all-zero operand), and its inverse.
+__device__ __forceinline__ float pow2_scale(const unsigned* amax, float& inv) {
+  inv = 1.f;
+  if (!amax) return 1.f;
+  const unsigned bits = __builtin_nontemporal_load(amax) & 0x7fffffffu;
+  if (bits == 0u) return 1.f;
+  int e = 267 - (int)(bits >> 23);                // biased exponent of the scale: 127 + 13 - (exponent(max) - 127)
+  e = e < 1 ? 1 : (e > 253 ? 253 : e);            // both the scale and its inverse stay normal numbers
+  inv = __uint_as_float((unsigned)(254 - e) << 23);
+  return __uint_as_float((unsigned)e << 23);
+}
+
+template <bool KS>
+__device__ __forceinline__ unsigned load_offset(int i, int tid, int x0, int x_total, int ld_bytes, int k0, int k_end) {
+  const int q = tid + 256 * i;
+  if (KS) {                                       // [k rows][128 cols] f32: 32 float4 per k row, 8 rows per pass
+    const int gk = k0 + (q >> 5), gx = x0 + 4 * (q & 31);
+    return (gk < k_end && gx < x_total) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gx * 4u : OOB;
+  }
+  const int gx = x0 + (q >> 3), gk = k0 + 4 * (q & 7);      // [128 rows][32 k] f32: 8 float4 per row, 32 rows per pass
+  return (gx < x_total && gk < k_end) ? (unsigned)gx * (unsigned)ld_bytes + (unsigned)gk * 4u : OOB;
+}
+
+// where this thread's 4 halves of load i go in K17's 16-bit image (gemm_tiles.hpp: kc_lane<32> / ks_lane swizzles)
+template <bool KS>
+__device__ __forceinline__ unsigned image_offset(int i, int tid) {
+  const int q = tid + 256 * i;
+  if (KS) {
+    const int r = q >> 5, cq = q & 31;
+    return (unsigned)(r * 256 + ((((cq >> 1) ^ ks_swz(r))) << 4) + (cq & 1) * 8);
+  }
+  const int r = q >> 3, kq = q & 7;
+  return (unsigned)(r * 64 + ((((kq >> 1) ^ ((r >> 2) & 3))) << 4) + (kq & 1) * 8);
+}
+
+__device__ __forceinline__ void split4(const u32x4 raw, const float s, uint2& hi, uint2& lo) {
+  const f32x4 f = __builtin_bit_cast(f32x4, raw) * s;
+  const f32x2 f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
+  const f16x2 h01 = __builtin_convertvector(f01, f16x2), h23 = __builtin_convertvector(f23, f16x2);
+  const f32x2 r01 = f01 - __builtin_convertvector(h01, f32x2), r23 = f23 - __builtin_convertvector(h23, f32x2);
+  const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+  lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+
+__device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool A_KS, bool B_KS, int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles = p.ntm * p.ntn;
+  const int z = bid / tiles, t = bid - z * tiles;
+  const int tile_m = t / p.ntn, tile_n = t - tile_m * p.ntn;
+  const int bz = z / p.splits, sp = z - bz * p.splits;
+  const int k_begin = sp * p.ksteps * KB32;
+  int k_end = k_begin + p.ksteps * KB32;
+  if (k_end > p.gk) k_end = p.gk;
+  const int nk = (k_end - k_begin + KB32 - 1) / KB32;
+  if (nk <= 0) return;
+
+  float inv_a, inv_b;
+  const float sca = pow2_scale(p.amax_a, inv_a), scb = pow2_scale(p.amax_b, inv_b);
+
+  const float* abase = p.a + (size_t)bz * (size_t)p.sa;
+  const float* bbase = p.b + (size_t)bz * (size_t)p.sb;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bbase), 0, (int)p.b_bytes, 0x00020000);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bool ragged = ((k_end - k_begin) & (KB32 - 1)) != 0;
+  const unsigned stepa = A_KS ? (unsigned)(KB32 * 4) * (unsigned)p.lda : (unsigned)(KB32 * 4);
+  const unsigned stepb = B_KS ? (unsigned)(KB32 * 4) * (unsigned)p.ldb : (unsigned)(KB32 * 4);
+  unsigned offa[NLD], offb[NLD], imga[NLD], imgb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    offa[i] = load_offset<A_KS>(i, tid, m0, p.gm, p.lda * 4, k_begin, k_begin + KB32);
+    offb[i] = load_offset<B_KS>(i, tid, n0, p.gn, p.ldb * 4, k_begin, k_begin + KB32);
+    imga[i] = image_offset<A_KS>(i, tid);
+    imgb[i] = image_offset<B_KS>(i, tid);
+  }
+
+  u32x4 rawa[NLD], rawb[NLD];
+  auto request = [&](int kt) {                     // the f32 tiles of K-step kt -> registers
+    const bool tail = ragged && kt == nk - 1;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      unsigned va = offa[i], vb = offb[i], sa = (unsigned)kt * stepa, sb = (unsigned)kt * stepb;
+      if (tail) {
+        va = load_offset<A_KS>(i, tid, m0, p.gm, p.lda * 4, k_begin + kt * KB32, k_end);
+        vb = load_offset<B_KS>(i, tid, n0, p.gn, p.ldb * 4, k_begin + kt * KB32, k_end);
+        sa = sb = 0u;
+      }
+      rawa[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)va, (int)sa, 0);
+      rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)vb, (int)sb, 0);
+    }
+  };
+  auto split_store = [&](int slot) {               // registers -> hi / lo images of stage `slot`
+    char* st = smem + slot * STAGE32;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      uint2 hi, lo;
+      split4(rawa[i], sca, hi, lo);
+      *reinterpret_cast<uint2*>(st + imga[i]) = hi;
+      *reinterpret_cast<uint2*>(st + IMG32 + imga[i]) = lo;
+      split4(rawb[i], scb, hi, lo);
+      *reinterpret_cast<uint2*>(st + 2 * IMG32 + imgb[i]) = hi;
+      *reinterpret_cast<uint2*>(st + 3 * IMG32 + imgb[i]) = lo;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // Order of a K-step: (1) step kt + 1's f32 tiles — requested a whole step ago — are split into the other stage (last read
+  // in step kt - 1, behind the barrier), (2) step kt + 2 is requested into the freed registers, (3) this step's fragments and
+  // matrix instructions, (4) barrier.  The loads so have a full step (matrix instructions + split) to arrive, and one
+  // wave's split runs beside its SIMD partner's matrix instructions.
+  request(0);
+  split_store(0);
+  if (nk > 1) request(1);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      split_store((kt + 1) & 1);
+      if (kt + 2 < nk) request(kt + 2);
+    }
+    const char* st = smem + (kt & 1) * STAGE32;
+#pragma unroll
+    for (int ks = 0; ks < KB32 / 16; ++ks) {
+      uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int x = 32 * (wm * TM + i);
+        ah[i] = A_KS ? frag_ks(st, x, ks, lane) : frag_kc<KB32>(st, x, ks, lane);
+        al[i] = A_KS ? frag_ks(st + IMG32, x, ks, lane) : frag_kc<KB32>(st + IMG32, x, ks, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int x = 32 * (wn * TN + j);
+        bh[j] = B_KS ? frag_ks(st + 2 * IMG32, x, ks, lane) : frag_kc<KB32>(st + 2 * IMG32, x, ks, lane);
+        bl[j] = B_KS ? frag_ks(st + 3 * IMG32, x, ks, lane) : frag_kc<KB32>(st + 3 * IMG32, x, ks, lane);
+      }
+      // C^T accumulators (a lane holds 4 consecutive columns of C): the small cross terms first, then hi . hi
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = mma16(bl[j], ah[i], acc[i][j]);
+          acc[i][j] = mma16(bh[j], al[i], acc[i][j]);
+          acc[i][j] = mma16(bh[j], ah[i], acc[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[i][j][e] = C[m = 64 wm + 32 i + r][n = 64 wn + 32 j + acc_row(e, h)] (K17's STORE form, f32) ----
+  const int r = lane & 31, h = lane >> 5;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
+  const int prow = lane >> 3, cg = lane & 7;
+  const int gn = n0 + 64 * wn + 8 * cg;
+  const bool col_ok = gn < p.gn;                    // gn % 8 == 0 is required: a column group is all in or all out
+  const size_t cbase = (size_t)bz * (size_t)p.sc + (size_t)sp * (size_t)p.ssplit;
+  const int mrow0 = m0 + 32 * TM * wm + prow;
+  const float inv = inv_a * inv_b;                  // each factor is a normal power of two; the product may be subnormal
+  const bool two_step = !(inv >= 1.1754944e-38f);   // then scale in two exact steps
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (p.bias && col_ok) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * g]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+        *reinterpret_cast<f32x4*>(stg + r * STG_LD + 32 * j + 8 * g + 4 * h) = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = 8 * ps + prow;
+      const int gm = mrow0 + 32 * i + 8 * ps;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * STG_LD + 8 * cg);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * STG_LD + 8 * cg + 4);
+      if (gm >= p.gm || !col_ok) continue;
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (two_step ? (v[e] * inv_a) * inv_b : v[e] * inv) + bias8[e];
+      const size_t o = cbase + (size_t)gm * p.ldc + gn;
+      if (EPI != EPI32_NONE) {
+        if (p.c2) {
+          *reinterpret_cast<float4*>(p.c2 + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(p.c2 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (EPI == EPI32_RELU) {
+            v[e] = v[e] > 0.f ? v[e] : 0.f;
+          } else {
+            float dens;
+            v[e] *= gelu_cdf_parts(v[e], dens);
+          }
+        }
+      }
+      if (p.acc_out) {
+        const float4 d0 = *reinterpret_cast<const float4*>(p.c + o), d1 = *reinterpret_cast<const float4*>(p.c + o + 4);
+        v[0] += d0.x; v[1] += d0.y; v[2] += d0.z; v[3] += d0.w;
+        v[4] += d1.x; v[5] += d1.y; v[6] += d1.z; v[7] += d1.w;
+      }
+      *reinterpret_cast<float4*>(p.c + o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(p.c + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
+// out (n) += sum of the `parts` partial results part (parts, n): a thread owns 4 consecutive elements (owner adds: no
+// atomics, bit-reproducible)
+__global__ void __launch_bounds__(256) k_add_parts32(const float* __restrict__ part, int parts, long long n,
+                                                     float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < parts; p += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = p + u < parts ? *reinterpret_cast<const float4*>(part + (long long)(p + u) * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  float4 o = *reinterpret_cast<const float4*>(out + i);
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *reinterpret_cast<float4*>(out + i) = o;
+}
+
+// ---- max|x| of f32 tensors as the BITS of the maximum (non-negative floats order like integers) -------------------------
+constexpr int kAbsmaxGroup = 64;
+struct AbsmaxEntry {
+  const float* x;
+  unsigned* out;
+  long long rows, cols, ld;       // cols % 4 == 0, 16-byte aligned rows
+  int block_begin, blocks;
+};
+struct AbsmaxArgs {
+  AbsmaxEntry e[kAbsmaxGroup];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) k_absmax_group(const AbsmaxArgs a) {
+  __shared__ unsigned red[4];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.e[i + 1].block_begin) ++i;
+  const AbsmaxEntry& e = a.e[i];
+  const long long c4 = e.cols >> 2, total = e.rows * c4;
+  const long long stride = (long long)e.blocks * 256;
+  unsigned m = 0u;
+  for (long long q = (long long)(blockIdx.x - e.block_begin) * 256 + threadIdx.x; q < total; q += 4 * stride) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long qq = q + u * stride;
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (qq < total) {
+        const long long row = qq / c4, col = qq - row * c4;
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(e.x + row * e.ld + 4 * col));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4 w = v[u] & 0x7fffffffu;
+      const unsigned m0 = w[0] > w[1] ? w[0] : w[1], m1 = w[2] > w[3] ? w[2] : w[3];
+      const unsigned mm = m0 > m1 ? m0 : m1;
+      m = m > mm ? m : mm;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m, s, 64);
+    m = m > o ? m : o;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a01 = red[0] > red[1] ? red[0] : red[1], a23 = red[2] > red[3] ? red[2] : red[3];
+    const unsigned mm = a01 > a23 ? a01 : a23;
+    if (mm) atomicMax(e.out, mm);
+  }
+}
+
+}  // namespace
+
+static bool fits32(long long rows, long long ld) { return rows * ld * 4 < 0x7fff0000LL; }
+
+template <bool AKS, bool BKS>
+static int gemm32s_launch(int epi, const Gemm32Args& a, int batch, hipStream_t st) {
+  const long long nblk = (long long)a.ntm * a.ntn * a.splits * batch;
+  if (nblk <= 0) return MBV_OK;
+  if (nblk > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+#define MBV_G32_LAUNCH(E)                                                                                                \
+  do {                                                                                                                   \
+    static bool done = false;       /* idempotent attribute of the code object, not library state */                     \
+    if (!done) {                                                                                                         \
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm32s<AKS, BKS, E>),                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));                             \
+      done = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((k_gemm32s<AKS, BKS, E>), dim3((unsigned)nblk), dim3(256), LDS32, st, a);                          \
+  } while (0)
+  if (epi == EPI32_RELU) MBV_G32_LAUNCH(EPI32_RELU);
+  else if (epi == EPI32_GELU) MBV_G32_LAUNCH(EPI32_GELU);
+  else MBV_G32_LAUNCH(EPI32_NONE);
+#undef MBV_G32_LAUNCH
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64_t k) {
+  if (layout < 0 || layout > 2 || m <= 0 || n <= 0 || k <= 0) return 0;
+  if ((n & 7) || (k & 7)) return 0;
+  return fits32(m, n > k ? n : k) ? 1 : 0;
+}
+
+// max|x| of `count` f32 tensors (rows[i], cols[i]) with row stride ld[i] (cols % 4 == 0, 16-byte aligned rows), as the BITS
+// of the maximum, combined into out[i] by an integer atomic max: out[i] must hold 0 (or an earlier partial maximum) when
+// the launch starts.  Every array argument is a HOST array of length count; one launch per 64 tensors.
+extern "C" int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ld,
+                                    uint32_t* const* out, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && (!x || !rows || !cols || !ld || !out))) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < count; base += kAbsmaxGroup) {
+    const int cnt = count - base < kAbsmaxGroup ? count - base : kAbsmaxGroup;
+    AbsmaxArgs a;
+    a.n = 0;
+    long long blocks = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      if (rows[i] < 0 || cols[i] < 0 || !out[i]) return MBV_ERR_BAD_ARG;
+      if (rows[i] == 0 || cols[i] == 0) continue;
+      if (!x[i] || (cols[i] & 3) || (ld[i] & 3) || ld[i] < cols[i] || (reinterpret_cast<size_t>(x[i]) & 15)) return MBV_ERR_UNSUPPORTED;
+      AbsmaxEntry& e = a.e[a.n++];
+      e.x = x[i]; e.out = out[i]; e.rows = rows[i]; e.cols = cols[i]; e.ld = ld[i];
+      const long long q = rows[i] * (cols[i] >> 2);
+      long long nb = (q + 256 * 16 - 1) / (256 * 16);       // 16 float4 per thread
+      if (nb > 2048) nb = 2048;
+      if (nb < 1) nb = 1;
+      e.block_begin = (int)blocks; e.blocks = (int)nb;
+      blocks += nb;
+    }
+    if (a.n == 0) continue;
+    hipLaunchKernelGGL(k_absmax_group, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+  }
+  return MBV_OK;
+}
+
+static int gemm32s_common(int layout, const float* a_op, const float* b_op, float* out, float* out_pre, const float* bias,
+                          const uint32_t* amax_a, const uint32_t* amax_b, int64_t gm, int64_t gn, int64_t gk, int64_t lda,
+                          int64_t ldb, int64_t ldc, int64_t a_rows, int64_t a_cols, int64_t b_rows, int64_t b_cols,
+                          int32_t act, int32_t batch, int64_t sa, int64_t sb, int64_t sc, hipStream_t st) {
+  Gemm32Args a = {};
+  a.a = a_op; a.b = b_op; a.c = out; a.c2 = out_pre; a.bias = bias; a.amax_a = amax_a; a.amax_b = amax_b;
+  a.gm = (int)gm; a.gn = (int)gn; a.gk = (int)gk;
+  a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc;
+  a.sa = sa; a.sb = sb; a.sc = sc;
+  a.a_bytes = (unsigned)(((a_rows - 1) * lda + a_cols) * 4); a.b_bytes = (unsigned)(((b_rows - 1) * ldb + b_cols) * 4);
+  a.ntm = (int)((gm + 127) / 128); a.ntn = (int)((gn + 127) / 128); a.splits = 1; a.ksteps = (int)((gk + KB32 - 1) / KB32);
+  if (layout == 0) return gemm32s_launch<false, false>(act, a, batch, st);
+  return gemm32s_launch<false, true>(act, a, batch, st);
+}
+
+// out (m, n) f32 = act(x (m, k) . w (n, k)^T + bias); out_pre (optional, act != 0) = the pre-activation.
+// amax_x / amax_w: device words holding the bits of max|x| / max|w| (mbv_f32_absmax_group), NULL = no scaling (operand
+// magnitudes within [2^-14, 2^15) keep full accuracy unscaled).
+extern "C" int mbv_gemm32s_nt(const float* x, const float* w, const float* bias, float* out, float* out_pre, int64_t m,
+                              int64_t n, int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, const uint32_t* amax_x,
+                              const uint32_t* amax_w, int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w,
+                              int64_t stride_o, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !x || !w || !out) return MBV_ERR_BAD_ARG;
+  if (act < 0 || act > 2) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldx & 3) || (ldw & 3) || (ldo & 3) || ldx < k || ldw < k || ldo < n) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out) |
+       reinterpret_cast<size_t>(out_pre) | reinterpret_cast<size_t>(bias)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  if (!fits32(m, ldx) || !fits32(n, ldw)) return MBV_ERR_UNSUPPORTED;
+  if (m == 0 || batch == 0) return MBV_OK;
+  return gemm32s_common(0, x, w, out, out_pre, bias, amax_x, amax_w, m, n, k, ldx, ldw, ldo, m, k, n, k, act, batch,
+                        stride_x, stride_w, stride_o, (hipStream_t)stream);
+}
+
+// out (m, k) f32 = g (m, n) . w (n, k)
+extern "C" int mbv_gemm32s_nn(const float* g, const float* w, float* out, int64_t m, int64_t n, int64_t k, int64_t ldg,
+                              int64_t ldw, int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, int32_t batch,
+                              int64_t stride_g, int64_t stride_w, int64_t stride_o, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !w || !out) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldg & 3) || (ldw & 3) || (ldo & 3) || ldg < n || ldw < k || ldo < k) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out)) & 15) return MBV_ERR_UNSUPPORTED;
+  if (!fits32(m, ldg) || !fits32(n, ldw)) return MBV_ERR_UNSUPPORTED;
+  if (m == 0 || batch == 0) return MBV_OK;
+  return gemm32s_common(1, g, w, out, nullptr, nullptr, amax_g, amax_w, m, k, n, ldg, ldw, ldo, m, n, n, k, 0, batch,
+                        stride_g, stride_w, stride_o, (hipStream_t)stream);
+}
+
+static void tn32_split(int64_t m, int64_t n, int64_t k, int& splits, int& ksteps) {
+  const int total_steps = (int)((m + KB32 - 1) / KB32);
+  const long long tiles = ((n + 127) / 128) * ((k + 127) / 128);
+  long long s = (512 + tiles - 1) / tiles;            // about two workgroups per CU
+  const long long cap = (m + 1023) / 1024;            // at least 1024 tokens deep
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  ksteps = (int)((total_steps + s - 1) / s);
+  splits = (total_steps + ksteps - 1) / ksteps;
+}
+
+extern "C" size_t mbv_gemm32s_tn_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  int splits, ksteps;
+  tn32_split(m, n, k, splits, ksteps);
+  return splits > 1 ? (size_t)splits * (size_t)n * (size_t)k * 4 : 0;
+}
+
+// dw (n, k) f32, contiguous  +=  g (m, n)^T . x (m, k): the token sum is cut into parts that are STORED to the workspace and
+// added into dw by their owner (no atomics; bit-reproducible); a single part adds its tile to dw in place.
+extern "C" int mbv_gemm32s_tn_acc(const float* g, const float* x, float* dw, int64_t m, int64_t n, int64_t k, int64_t ldg,
+                                  int64_t ldx, const uint32_t* amax_g, const uint32_t* amax_x, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || !g || !x || !dw) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldg & 3) || (ldx & 3) || ldg < n || ldx < k) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dw) |
+       reinterpret_cast<size_t>(workspace)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  if (!fits32(m, ldg) || !fits32(m, ldx) || n * k >= 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+  if (m == 0) return MBV_OK;
+  Gemm32Args a = {};
+  a.a = g; a.b = x; a.amax_a = amax_g; a.amax_b = amax_x;
+  a.gm = (int)n; a.gn = (int)k; a.gk = (int)m;
+  a.lda = (int)ldg; a.ldb = (int)ldx; a.ldc = (int)k;
+  a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 4); a.b_bytes = (unsigned)(((m - 1) * ldx + k) * 4);
+  a.ntm = (int)((n + 127) / 128); a.ntn = (int)((k + 127) / 128);
+  tn32_split(m, n, k, a.splits, a.ksteps);
+  if (a.splits == 1) {
+    a.c = dw; a.acc_out = 1;
+    return gemm32s_launch<true, true>(EPI32_NONE, a, 1, (hipStream_t)stream);
+  }
+  if (!workspace || workspace_bytes < (size_t)a.splits * (size_t)n * (size_t)k * 4) return MBV_ERR_WORKSPACE;
+  a.c = reinterpret_cast<float*>(workspace);
+  a.ssplit = n * k;
+  const int rc = gemm32s_launch<true, true>(EPI32_NONE, a, 1, (hipStream_t)stream);
+  if (rc != MBV_OK) return rc;
+  const long long total = n * k;
+  hipLaunchKernelGGL(k_add_parts32, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float*>(workspace), a.splits, total, dw);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}

@@ -1179,6 +1179,122 @@ def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype]
 
 
 # --------------------------------------------------------------------------------------
+# K20 f32 GEMMs from IEEE-half pairs on the 16-bit matrix pipe (csrc/gemm_f32s.hip) — the fp32 compute mode's Linears
+# --------------------------------------------------------------------------------------
+class _AmaxPool:
+    """Device words for `mbv_f32_absmax_group` results (the BITS of max|x|, combined by an integer atomic max, so a word
+    must be zero before its tensor's launch).  Words are handed out one after the other from zero-filled blocks of 1024
+    (one fill launch per block instead of one per tensor).  A block never spans the start of a stream capture: a block
+    filled eagerly would not be zeroed again by the replay, and a word would then hold the maximum over ALL replays."""
+
+    def __init__(self):
+        self.block, self.used, self.capturing = None, 0, False
+
+    def take(self, device, n: int = 1) -> torch.Tensor:
+        cap = torch.cuda.is_current_stream_capturing()
+        if (self.block is None or self.used + n > self.block.numel() or cap != self.capturing
+                or self.block.device != device):
+            self.block = torch.zeros(1024, dtype=torch.int32, device=device)
+            self.used, self.capturing = 0, cap
+        out = self.block[self.used:self.used + n]
+        self.used += n
+        return out
+
+
+_AMAX_POOLS: dict = {}
+
+
+def f32_absmax(tensors) -> torch.Tensor:
+    """(len(tensors),) int32 device words: the bits of max|t| of each f32 matrix (rows may be strided), one launch."""
+    lib = _lib.load()
+    n = len(tensors)
+    dev = tensors[0].device
+    for t in tensors:
+        if (not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[1] % 4
+                or t.stride(0) % 4 or t.data_ptr() % 16):
+            raise MaskBevHipError('f32_absmax: f32 matrices with contiguous, 16-byte aligned rows (cols % 4 == 0) only')
+    # one pool per (device, thread, stream): a block is zero-filled on the stream that is current when it is made, and a
+    # word handed to a launch on another stream could be read before that fill ran
+    import threading
+    pool = _AMAX_POOLS.setdefault((dev, threading.get_ident(), torch.cuda.current_stream(dev).cuda_stream), _AmaxPool())
+    out = pool.take(dev, n)
+    PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    check(lib.mbv_f32_absmax_group(PA(*[t.data_ptr() for t in tensors]), LA(*[t.shape[0] for t in tensors]),
+                                   LA(*[t.shape[1] for t in tensors]), LA(*[t.stride(0) for t in tensors]),
+                                   PA(*[out.data_ptr() + 4 * i for i in range(n)]), n, _stream()), 'mbv_f32_absmax_group')
+    return out
+
+
+def _gemm32s_ok(*ts: torch.Tensor) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+               and t.shape[1] % 8 == 0 and t.data_ptr() % 16 == 0 and t.shape[0] * t.stride(0) * 4 < 0x7fff0000 for t in ts)
+
+
+def gemm32s_wants(tokens: int) -> bool:
+    return bool(switches.get('gemm32s')) and tokens >= int(switches.get('gemm32s_min'))
+
+
+def _amax_ptr(amax: Optional[torch.Tensor], i: int):
+    return ctypes.c_void_p(0) if amax is None else ctypes.c_void_p(amax.data_ptr() + 4 * i)
+
+
+def gemm32s_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+               amax: Optional[torch.Tensor] = None, want_pre: bool = False):
+    """``act(x (M, K) @ w (N, K)^T + bias)`` in f32 on K20.  ``amax`` = ``f32_absmax([x, w])`` (computed here when None)."""
+    lib = _lib.load()
+    if not _gemm32s_ok(x, w) or x.shape[1] != w.shape[1] or w.shape[0] % 8:
+        raise MaskBevHipError('gemm32s_nt: unsupported operands')
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16):
+        raise MaskBevHipError('gemm32s_nt: bias must be contiguous f32, 16-byte aligned')
+    if amax is None:
+        amax = f32_absmax([x, w])
+    m, k = x.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    pre = torch.empty((m, n), dtype=torch.float32, device=x.device) if (want_pre and _ACT[act]) else None
+    check(lib.mbv_gemm32s_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pre), m, n, k, x.stride(0), w.stride(0), n,
+                             _amax_ptr(amax, 0), _amax_ptr(amax, 1), _ACT[act], 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nt')
+    return (out, pre) if want_pre else out
+
+
+def gemm32s_nn(g: torch.Tensor, w: torch.Tensor, amax_g: Optional[torch.Tensor] = None,
+               amax_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``g (M, N) @ w (N, K)`` in f32 on K20 (the data gradient of a Linear); amax_* = one-word tensors."""
+    lib = _lib.load()
+    if not _gemm32s_ok(g, w) or g.shape[1] != w.shape[0]:
+        raise MaskBevHipError('gemm32s_nn: unsupported operands')
+    if amax_g is None:
+        amax_g = f32_absmax([g])
+    if amax_w is None:
+        amax_w = f32_absmax([w])
+    m, n = g.shape
+    k = w.shape[1]
+    out = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    check(lib.mbv_gemm32s_nn(_ptr(g), _ptr(w), _ptr(out), m, n, k, g.stride(0), w.stride(0), k, _amax_ptr(amax_g, 0),
+                             _amax_ptr(amax_w, 0), 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nn')
+    return out
+
+
+def gemm32s_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, amax_g: Optional[torch.Tensor] = None,
+                   amax_x: Optional[torch.Tensor] = None) -> None:
+    """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` on K20 (the weight gradient; token sum in parts, owner adds)."""
+    lib = _lib.load()
+    if (not _gemm32s_ok(g, x) or g.shape[0] != x.shape[0] or acc.dtype != torch.float32 or not acc.is_contiguous()
+            or tuple(acc.shape) != (g.shape[1], x.shape[1]) or acc.data_ptr() % 16):
+        raise MaskBevHipError('gemm32s_tn_acc: unsupported operands')
+    if amax_g is None:
+        amax_g = f32_absmax([g])
+    if amax_x is None:
+        amax_x = f32_absmax([x])
+    m, n = g.shape
+    k = x.shape[1]
+    nbytes = lib.mbv_gemm32s_tn_workspace_bytes(m, n, k)
+    ws = _workspace(nbytes, g.device) if nbytes else None
+    check(lib.mbv_gemm32s_tn_acc(_ptr(g), _ptr(x), _ptr(acc), m, n, k, g.stride(0), x.stride(0), _amax_ptr(amax_g, 0),
+                                 _amax_ptr(amax_x, 0), _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_acc')
+
+
+# --------------------------------------------------------------------------------------
 # Linear layers: library GEMMs, with a split-K weight gradient for token-major activations
 # --------------------------------------------------------------------------------------
 def _wgrad_splits(tokens: int) -> int:
@@ -1451,12 +1567,16 @@ flush_small_wgrads = flush_deferred_grads
 
 
 def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc: Optional[torch.Tensor] = None,
-                persistent: bool = False) -> bool:
+                persistent: bool = False, amax=None) -> bool:
     """acc (out, in) f32 += g2^T x2, f32 accumulation inside the GEMM (no bf16 round trip, no separate add).
     Returns True when ``bias_acc`` (out,) f32 += column sums of g2 was done by the same launch.
     ``persistent``: ``acc`` / ``bias_acc`` are arena gradients nobody reads before the backward pass ends — the
     small-token form may then be deferred to the grouped launch at the end of the pass."""
     t = g2.shape[0]
+    if (amax is not None and acc.is_contiguous() and acc.data_ptr() % 16 == 0 and _gemm32s_ok(g2, x2)
+            and g2.shape[1] % 8 == 0):
+        gemm32s_tn_acc(acc, g2, x2, amax[0], amax[1])        # fp32 compute: K20, token sum in parts, owner adds
+        return False
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
             and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):
         per_layer = _k17_wants('wgrad', t) and (x2.shape[1] <= switches.get('tn_max_in') or gemm16_policy() == 'all')   # 2048-wide patch rows: the library wins (77 vs 95 us)
@@ -1518,8 +1638,19 @@ class _Linear(torch.autograd.Function):
             w = w[rows[0]:rows[1]]
             b = None if b is None else b[rows[0]:rows[1]]
         x2k = x.reshape(-1, x.shape[-1]) if x.is_cuda and x.dtype in _GEMM16_DT else None
+        ctx.amax = None
+        x32 = None
+        if x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() >= 2:
+            x32 = x.reshape(-1, x.shape[-1])
+            if not (gemm32s_wants(x32.shape[0]) and _gemm32s_ok(x32, w) and w.shape[0] % 8 == 0
+                    and (b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.data_ptr() % 16 == 0))):
+                x32 = None
         with torch.autocast('cuda', enabled=False):
-            if (x2k is not None and gemm16_policy() == 'all' and _gemm16_ok(x2k, w)
+            if x32 is not None:
+                # fp32 compute: K20 — f32 products from IEEE-half pairs on the 16-bit matrix pipe (csrc/gemm_f32s.hip)
+                ctx.amax = f32_absmax([x32, w])
+                y = gemm32s_nt(x32, w, b, amax=ctx.amax).view(x.shape[:-1] + (w.shape[0],))
+            elif (x2k is not None and gemm16_policy() == 'all' and _gemm16_ok(x2k, w)
                     and (bias is None or bias.dtype == torch.float32)):
                 bf = None if bias is None else (bias if rows is None else bias[rows[0]:rows[1]])
                 y = gemm16_nt(x2k, w, bf, out_dtype=torch.float32 if f32_out else None)
@@ -1548,8 +1679,16 @@ class _Linear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
+        amax_g = None
+        if ctx.amax is not None:
+            if not g2.is_contiguous():
+                g2 = g2.contiguous()
+            if _gemm32s_ok(g2, w) and _gemm32s_ok(x2):
+                amax_g = f32_absmax([g2])
         if ctx.needs_input_grad[0]:
-            if gemm16_policy() == 'all' and g2.is_cuda and _gemm16_ok(g2, w):
+            if amax_g is not None:
+                gx = gemm32s_nn(g2, w, amax_g, ctx.amax[1:2]).view_as(x)
+            elif gemm16_policy() == 'all' and g2.is_cuda and _gemm16_ok(g2, w):
                 gx = gemm16_nn(g2, w).view_as(x)
             elif ctx.gx_f32:         # an f32 input was cast for the GEMM: its gradient leaves the GEMM as f32 (no cast pass)
                 gx = torch.mm(g2, w, out_dtype=torch.float32).view_as(x)
@@ -1566,10 +1705,14 @@ class _Linear(torch.autograd.Function):
                 bacc = None
                 if bias_direct:
                     bacc = bias.grad if rows is None else bias.grad[rows[0]:rows[1]]
-                bias_done = _wgrad_into(acc, g2, x2, bacc, persistent=True) or bias_done    # straight into the arena
+                bias_done = _wgrad_into(acc, g2, x2, bacc, persistent=True,                  # straight into the arena
+                                        amax=None if amax_g is None else (amax_g, ctx.amax[0:1])) or bias_done
                 _fire_grad_hooks(weight)
                 if bias_done:
                     _fire_grad_hooks(bias)
+            elif amax_g is not None and weight.dtype == torch.float32 and weight.is_contiguous():
+                gw = torch.zeros_like(weight)
+                gemm32s_tn_acc(gw if rows is None else gw[rows[0]:rows[1]], g2, x2, amax_g, ctx.amax[0:1])
             elif rows is None:
                 gw = _wgrad(g2, x2).to(weight.dtype)
             else:

@@ -1,0 +1,199 @@
+"""K20 (csrc/gemm_f32s.hip): f32 GEMMs formed on the 16-bit matrix pipe from IEEE-half PAIRS of the scaled operands
+(hi.hi + hi.lo + lo.hi, f32 accumulation), against the float64 product of the same f32 operands.
+
+Bar: max-norm error <= 2e-6 of max|ref| — the level `test_skinny_gemm_f32_equals_float64_product` holds the
+exact-f32 MFMA kernel to — on every layout (NT forward, NN data gradient, TN weight gradient), ragged edges, operand
+magnitudes from 1e-9 to 1e+6 (the per-tensor power-of-two scales from `mbv_f32_absmax_group`), and next to the library's own
+f32 GEMM on the same operands (the split product must not be worse than 4x the f32 GEMM's error)."""
+import pytest
+import torch
+from mask_bev_amd import switches
+
+gpu = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda', 0)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(_dev())
+
+
+def _err(out, ref):
+    return float((out.double() - ref).abs().max() / ref.abs().max().clamp(min=1e-300))
+
+
+@gpu
+def test_absmax_words_are_the_bits_of_the_maximum():
+    from mask_bev_amd import ops
+    a = _rand((1000, 192), 1, 3.0)
+    wide = _rand((257, 512), 2, 1e-5)
+    b = wide[:, 128:328]                                   # strided rows, offset start (200 columns, 16-byte aligned)
+    z = torch.zeros(64, 8, device=_dev())
+    big = _rand((65536, 96), 3, 100.0)
+    words = ops.f32_absmax([a, b, z, big])
+    want = torch.stack([t.abs().max() for t in (a, b, z, big)]).view(torch.int32)
+    assert torch.equal(words.cpu(), want.cpu())
+    # a second launch into the same words keeps the larger of the two (integer max): the grouped-weights use
+    from mask_bev_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    small = (a * 0.5).contiguous()
+    PA, LA = ctypes.c_void_p * 1, ctypes.c_int64 * 1
+    ops.check(lib.mbv_f32_absmax_group(PA(small.data_ptr()), LA(1000), LA(192), LA(192), PA(words.data_ptr()), 1,
+                                       ops._stream()), 'mbv_f32_absmax_group')
+    assert int(words[0]) == int(want[0])
+
+
+SHAPES = [  # (M, N, K)
+    (256, 128, 64), (128, 192, 192), (1000, 576, 192), (131, 200, 72), (4096, 768, 3072), (777, 96, 256), (33, 8, 8),
+    (8192, 192, 2048), (5000, 1024, 40)]
+
+
+@gpu
+@pytest.mark.parametrize('m,n,k', SHAPES)
+@pytest.mark.parametrize('sx,sw', [(1.0, 0.05), (3e-7, 40.0), (2e5, 1e-6)])
+def test_nt_equals_float64_product(m, n, k, sx, sw):
+    from mask_bev_amd import ops
+    x, w = _rand((m, k), m + k, sx), _rand((n, k), n + k + 1, sw)
+    bias = _rand((n,), 5, sx * sw * k ** 0.5)
+    ref = x.double() @ w.double().t() + bias.double()
+    out = ops.gemm32s_nt(x, w, bias)
+    assert torch.isfinite(out).all()
+    e = _err(out, ref)
+    lib_e = _err(torch.addmm(bias, x, w.t()), ref)
+    assert e <= 2e-6, (e, lib_e)
+    assert e <= max(4 * lib_e, 5e-7), (e, lib_e)
+
+
+@gpu
+def test_nt_activation_epilogues_and_strided_operands():
+    from mask_bev_amd import ops
+    m, n, k = 3000, 768, 192
+    xw = _rand((m, 2 * k), 1)
+    x = xw[:, k:]                                          # row stride 2k, offset start
+    wfull = _rand((n + 16, k), 2, 0.1)
+    w = wfull[8:8 + n]                                     # a row block of a packed weight (the `rows=` use of ops.linear)
+    bias = _rand((n,), 3)
+    pre_ref = x.double() @ w.double().t() + bias.double()
+    for act, fn in (('relu', torch.relu), ('gelu', torch.nn.functional.gelu)):
+        out, pre = ops.gemm32s_nt(x, w, bias, act=act, want_pre=True)
+        assert _err(pre, pre_ref) <= 2e-6
+        assert _err(out, fn(pre_ref)) <= 4e-6             # (the erf of the GELU epilogue is Abramowitz-Stegun 7.1.26: 1.5e-7)
+    out = ops.gemm32s_nt(x, w, None)
+    assert _err(out, pre_ref - bias.double()) <= 2e-6
+
+
+@gpu
+@pytest.mark.parametrize('m,n,k', SHAPES)
+@pytest.mark.parametrize('sg,sw', [(1.0, 0.05), (1e-8, 0.3)])
+def test_nn_equals_float64_product(m, n, k, sg, sw):
+    """data gradient: g (M, N) . w (N, K) — w read with the transposing LDS reads from its hi / lo images"""
+    from mask_bev_amd import ops
+    g, w = _rand((m, n), m + n, sg), _rand((n, k), n + k + 2, sw)
+    ref = g.double() @ w.double()
+    out = ops.gemm32s_nn(g, w)
+    assert torch.isfinite(out).all()
+    e, lib_e = _err(out, ref), _err(g @ w, ref)
+    assert e <= 2e-6 and e <= max(4 * lib_e, 5e-7), (e, lib_e)
+
+
+@gpu
+@pytest.mark.parametrize('m,n,k', [(512, 128, 64), (4096, 192, 192), (65536, 576, 192), (16384, 768, 3072), (1000, 200, 72),
+                                   (8191, 96, 384), (40000, 8, 8)])
+@pytest.mark.parametrize('sg', [1.0, 1e-7])
+def test_tn_accumulates_the_weight_gradient(m, n, k, sg):
+    """acc (N, K) += g (M, N)^T . x (M, K): one part adds in place, several parts are stored and added by their owner —
+    either way onto what acc already held, and bit-reproducibly."""
+    from mask_bev_amd import ops
+    g, x = _rand((m, n), m + n, sg), _rand((m, k), m + k + 3)
+    start = _rand((n, k), 9, sg * m ** 0.5)
+    ref = start.double() + g.double().t() @ x.double()
+    acc = start.clone()
+    ops.gemm32s_tn_acc(acc, g, x)
+    assert torch.isfinite(acc).all()
+    e, lib_e = _err(acc, ref), _err(torch.addmm(start, g.t(), x), ref)
+    assert e <= 2e-6 and e <= max(4 * lib_e, 5e-7), (e, lib_e)
+    again = start.clone()
+    ops.gemm32s_tn_acc(again, g, x)
+    assert torch.equal(acc, again)
+
+
+@gpu
+def test_rows_far_below_the_operand_maximum_keep_their_relative_accuracy_down_to_2_pow_minus_18():
+    """Per-TENSOR scales: an element 2^-j of the operand's maximum keeps all 22 bits for j <= 18 (csrc/gemm_f32s.hip).  Token
+    rows 1e-5 of the largest row (padded / background tokens next to object tokens) are still right to 1e-6 of THEIR OWN
+    scale; rows 1e-9 of it only in absolute terms — stated, not hidden."""
+    from mask_bev_amd import ops
+    m, n, k = 2048, 192, 192
+    x, w = _rand((m, k), 1), _rand((n, k), 2, 0.1)
+    x[1::2] *= 1e-5
+    x[3::8] *= 1e-4                                        # these rows: 1e-9 of the maximum
+    ref = x.double() @ w.double().t()
+    out = ops.gemm32s_nt(x, w)
+    big, small, tiny = ref[0::2], ref[1::8], ref[3::8]
+    assert _err(out[0::2], big) <= 2e-6
+    assert _err(out[1::8], small) <= 2e-6                   # 1e-5 of the maximum: full accuracy relative to themselves
+    assert float((out[3::8].double() - tiny).abs().max()) <= 2e-6 * float(small.abs().max())
+    assert _err(out[3::8], tiny) <= 2e-2                    # still the right numbers, with fewer bits
+
+
+@gpu
+def test_unscaled_mode_and_nonfinite_inputs():
+    from mask_bev_amd import ops, _lib
+    lib = _lib.load()
+    m, n, k = 512, 128, 96
+    x, w = _rand((m, k), 1), _rand((n, k), 2)
+    out = torch.empty(m, n, device=_dev())
+    ops.check(lib.mbv_gemm32s_nt(ops._ptr(x), ops._ptr(w), None, ops._ptr(out), None, m, n, k, k, k, n, None, None, 0, 1, 0,
+                                 0, 0, ops._stream()), 'mbv_gemm32s_nt')
+    assert _err(out, x.double() @ w.double().t()) <= 2e-6  # O(1) operands need no scale
+    x[7, 5] = float('inf')
+    w[3, 9] = float('nan')
+    out = ops.gemm32s_nt(x, w)
+    assert not torch.isfinite(out[7]).any() and not torch.isfinite(out[:, 3]).any()
+    ok = torch.ones(m, dtype=torch.bool)
+    ok[7] = False
+    # (an infinite maximum makes the scale 2^-115: the finite rows flush to zero instead of being right — the output of a
+    # GEMM with a non-finite operand is only required to SHOW it)
+    assert lib.mbv_gemm32s_supported(0, 512, 128, 96) == 1 and lib.mbv_gemm32s_supported(0, 512, 100, 96) == 0
+
+
+@gpu
+@pytest.mark.parametrize('arena', [False, True])
+def test_fp32_linear_takes_k20_and_matches_float64(arena):
+    """ops.linear in fp32 compute with >= gemm32s_min tokens: forward, data gradient, weight and bias gradients against
+    float64 — plain parameters (autograd's .grad) and arena parameters (accumulated in place)."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.arena import ParameterArena
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(192, 576).to(_dev())
+    x = _rand((4, 1024, 192), 4).requires_grad_()
+    gy = _rand((4, 1024, 576), 5, 1e-4)
+    if arena:
+        ParameterArena([('l', lin)], shadow_dtype=None)
+    calls = []
+    orig = ops.gemm32s_nt
+    ops.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = ops.linear(x, lin.weight, lin.bias)
+    finally:
+        ops.gemm32s_nt = orig
+    assert calls, 'the f32 Linear did not take K20'
+    y.backward(gy)
+    ops.flush_deferred_grads()
+    xd, wd, bd, gd = x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double(), gy.double()
+    assert _err(y.detach(), xd @ wd.t() + bd) <= 2e-6
+    assert _err(x.grad, gd @ wd) <= 2e-6
+    assert _err(lin.weight.grad, gd.flatten(0, 1).t() @ xd.flatten(0, 1)) <= 2e-6
+    assert _err(lin.bias.grad, gd.flatten(0, 1).sum(0)) <= 2e-6
+    with switches.override(gemm32s=False):
+        calls.clear()
+        ops.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            y2 = ops.linear(x.detach(), lin.weight, lin.bias)
+        finally:
+            ops.gemm32s_nt = orig
+        assert not calls and _err(y2.detach(), y.detach().double()) <= 4e-6
