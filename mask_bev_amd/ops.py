@@ -846,9 +846,12 @@ class _MSDAQuerySide(torch.autograd.Function):
             else:
                 xb = x.to(dt)
                 torch.add(x, pos, out=qb)                 # the sum, stored in the compute dtype by the same launch
-                value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
+                if dt == torch.float32:
+                    value = mm32_nt(xb.reshape(b * n, e), wvc, bv.contiguous()).view(b, n, e)
+                else:
+                    value = torch.nn.functional.linear(xb, wvc, _compute_copy(bv, dt)).float().contiguous()
             # [offsets | logits] = q . [Wo; Wa]^T without the biases: K16 adds them in f32 on load
-            ol = torch.mm(qb.view(b * n, e), wcat[e:].t())
+            ol = mm32_nt(qb.view(b * n, e), wcat[e:]) if dt == torch.float32 else torch.mm(qb.view(b * n, e), wcat[e:].t())
         host = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
         ref32 = ref.to(torch.float32).contiguous()
         loc = torch.empty((b, n, heads, levels, points, 2), dtype=torch.float32, device=x.device)
@@ -910,7 +913,7 @@ class _MSDAQuerySide(torch.autograd.Function):
         od = {} if dt == torch.float32 else dict(out_dtype=torch.float32)
         gx = gpos = None
         if ctx.needs_input_grad[0]:
-            gx = torch.mm(g, wcat, **od).view(b, n, e).to(x_dtype)
+            gx = (mm32_nn(g, wcat) if dt == torch.float32 else torch.mm(g, wcat, **od)).view(b, n, e).to(x_dtype)
         if ctx.needs_input_grad[1]:                                       # pos is broadcast over the batch
             # (a 16-bit sum accumulates in f32 and rounds once on the way out: the same value as an f32 sum + cast, one launch)
             share, share_index = ctx.share
@@ -1294,6 +1297,24 @@ def gemm32s_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, amax_g: 
                                  _amax_ptr(amax_x, 0), _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_acc')
 
 
+def mm32_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x (M, K) @ w (N, K)^T (+ bias)`` for f32 operands: K20 when the product is large enough and its operands fit
+    (``switches.gemm32s``), else the library's f32 GEMM — the fp32 compute mode's stand-in for ``torch.mm`` / ``addmm``."""
+    if (x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_cuda and x.dim() == 2 and gemm32s_wants(x.shape[0])
+            and _gemm32s_ok(x, w) and w.shape[0] % 8 == 0
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
+        return gemm32s_nt(x, w, bias)
+    return torch.mm(x, w.t()) if bias is None else torch.addmm(bias, x, w.t())
+
+
+def mm32_nn(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``g (M, N) @ w (N, K)`` for f32 operands: K20 or the library (see :func:`mm32_nt`)."""
+    if (g.dtype == torch.float32 and w.dtype == torch.float32 and g.is_cuda and g.dim() == 2 and gemm32s_wants(g.shape[0])
+            and _gemm32s_ok(g, w)):
+        return gemm32s_nn(g, w)
+    return torch.mm(g, w)
+
+
 # --------------------------------------------------------------------------------------
 # Linear layers: library GEMMs, with a split-K weight gradient for token-major activations
 # --------------------------------------------------------------------------------------
@@ -1573,9 +1594,10 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     ``persistent``: ``acc`` / ``bias_acc`` are arena gradients nobody reads before the backward pass ends — the
     small-token form may then be deferred to the grouped launch at the end of the pass."""
     t = g2.shape[0]
-    if (amax is not None and acc.is_contiguous() and acc.data_ptr() % 16 == 0 and _gemm32s_ok(g2, x2)
-            and g2.shape[1] % 8 == 0):
-        gemm32s_tn_acc(acc, g2, x2, amax[0], amax[1])        # fp32 compute: K20, token sum in parts, owner adds
+    if ((amax is not None or (g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.is_cuda and gemm32s_wants(t)))
+            and acc.dtype == torch.float32 and acc.is_contiguous() and acc.data_ptr() % 16 == 0 and _gemm32s_ok(g2, x2)):
+        # fp32 compute: K20, token sum in parts, owner adds (the absmax words come from the layer's forward when it has them)
+        gemm32s_tn_acc(acc, g2, x2, None if amax is None else amax[0], None if amax is None else amax[1])
         return False
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0
             and gemm16_policy() != 'none' and _gemm16_ok(g2, x2)):

@@ -41,7 +41,7 @@ _DEFAULTS: Dict[str, Any] = {
     'tn_max_in': 1536,            # widest input of a Linear whose weight gradient K17 takes
     'k17_fused_min': 4096,        # fewest tokens of an FFN that takes the fused K17 pair
     'gemm32s': True,              # fp32 compute: token-major Linears on K20 (f32 products from IEEE-half pairs on the 16-bit MFMA)
-    'gemm32s_min': 2048,          # fewest tokens of an f32 Linear that takes K20 (below: the library's f32 GEMM)
+    'gemm32s_min': 1024,          # fewest tokens of an f32 Linear that takes K20 (below: the library's f32 GEMM; measured: scratch/bench_gemm32s.py)
     'k7_f32_library': True,       # fp32 mask logits through the library's batched GEMM instead of K7's exact-f32 kernel
     'stage_out_lowp': True,       # backbone stage outputs stored in the autocast dtype by their LayerNorm launch
     'pos_fused': True,            # absolute position embedding added inside the first block's K12 launch

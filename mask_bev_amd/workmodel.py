@@ -369,6 +369,17 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_wgrad_small_f32_group': lambda a: _wgrad_group(a),
     'mbv_colsum_accum_group': lambda a: _colsum_group(a),
     'mbv_gemm16_tn_group': lambda a: _tn_group(a),
+    # K20 (f32 products from IEEE-half pairs): the ALGORITHMIC flops of the f32 product, 2 m n k, against the 16-bit MFMA peak
+    # (the kernel issues three matrix instructions per product term: a frac of 1/3 would be the pipe's own ceiling)
+    'mbv_gemm32s_nt': lambda a: ('k_gemm32s<NT>', 'mfma', ((_i(a[5]) * _i(a[7]) + _i(a[6]) * _i(a[7])) * 4.0
+                                                          + _i(a[5]) * _i(a[6]) * 4.0 * (2 if a[4] is not None and _i(a[4]) else 1))
+                                 * max(1, _i(a[14])), 2.0 * _i(a[5]) * _i(a[6]) * _i(a[7]) * max(1, _i(a[14]))),
+    'mbv_gemm32s_nn': lambda a: ('k_gemm32s<NN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[4]) * _i(a[5]) + _i(a[3]) * _i(a[5])) * 4.0
+                                 * max(1, _i(a[11])), 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * max(1, _i(a[11]))),
+    'mbv_gemm32s_tn_acc': lambda a: ('k_gemm32s<TN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[3]) * _i(a[5])) * 4.0
+                                     + _i(a[4]) * _i(a[5]) * 4.0 * 2, 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
+    'mbv_f32_absmax_group': lambda a: ('k_absmax_group', 'hbm',
+                                       4.0 * sum(int(a[1][i]) * int(a[2][i]) for i in range(_i(a[5]))), 0.0),
     'mbv_upsample_bilinear_bwd': lambda a: ('k_upsample_bilinear_bwd', 'hbm',
                                             _i(a[2]) * (_i(a[3]) * _i(a[4]) * _sz(a[1]) + _i(a[5]) * _i(a[6]) * _sz(a[8])), 0.0),
     'mbv_groupnorm_fwd': lambda a: _groupnorm(a, False),
