@@ -58,7 +58,25 @@ struct Gemm32Args {
   unsigned a_bytes, b_bytes;
   int ntm, ntn, splits, ksteps;
   int acc_out;              // splits == 1: the product is ADDED to c (read-modify-write by the owning workgroup)
+  int pc, ph, pw;           // GATHER modes: the (B, pc, ph, pw) NCHW image behind the 4 x 4 patch rows
 };
+
+// The rows of a non-overlapping 4 x 4 patch projection (mmdet PatchEmbed: Conv2d(C, E, 4, stride 4) on an NCHW image,
+// /root/reference: mask_bev/models/networks/swin/swin.py:579-586) are never materialised: element (token, k') of the
+// (B * H/4 * W/4, 16 C) row matrix, k' = c * 16 + dy * 4 + dx — the flattening of the (E, C, 4, 4) weight — IS image element
+// (b, c, 4 oy + dy, 4 ox + dx).  Four consecutive k' (dx = 0 .. 3) are 16 contiguous bytes, so a 16-byte operand piece of
+// the GEMM loaders is one aligned load from the image, and 16-byte pieces of consecutive tokens of an image row are
+// contiguous (the thread maps below give consecutive lanes consecutive tokens).
+//   GATHER 1: NT  out (tokens, E) = rows . W^T          — A is the gathered row matrix
+//   GATHER 2: NN  d image = (d out (tokens, E) . W) scattered back to NCHW — C is the scattered row matrix
+//   GATHER 3: TN  dW (E, 16 C) += d out^T . rows        — B is the gathered row matrix (contraction over tokens)
+__device__ __forceinline__ unsigned patch_elem(const Gemm32Args& p, int token, int kp) {
+  const int tw = p.pw >> 2, th = p.ph >> 2;
+  const int b = token / (th * tw), rem = token - b * th * tw;
+  const int oy = rem / tw, ox = rem - oy * tw;
+  const int c = kp >> 4, dy = (kp >> 2) & 3;
+  return (unsigned)(((b * p.pc + c) * p.ph + 4 * oy + dy) * p.pw + 4 * ox + (kp & 3));
+}
 
 // 2^e with max * 2^e in [2^13, 2^14) from the bits of max|x| (exact; 1 for an all-zero operand), and its inverse.
 __device__ __forceinline__ float pow2_scale(const unsigned* amax, float& inv) {
@@ -109,7 +127,7 @@ __device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <bool A_KS, bool B_KS, int EPI>
+template <bool A_KS, bool B_KS, int EPI, int GATHER = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
@@ -138,15 +156,37 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool ragged = ((k_end - k_begin) & (KB32 - 1)) != 0;
-  const unsigned stepa = A_KS ? (unsigned)(KB32 * 4) * (unsigned)p.lda : (unsigned)(KB32 * 4);
-  const unsigned stepb = B_KS ? (unsigned)(KB32 * 4) * (unsigned)p.ldb : (unsigned)(KB32 * 4);
+  // (GATHER 1: a K-step of 32 k' is two channels of the image; GATHER 3's token steps are not uniform in the image: its
+  // offsets are formed per step)
+  const unsigned stepa = GATHER == 1 ? (unsigned)(2 * 4) * (unsigned)p.ph * (unsigned)p.pw
+                                     : (A_KS ? (unsigned)(KB32 * 4) * (unsigned)p.lda : (unsigned)(KB32 * 4));
+  const unsigned stepb = GATHER == 3 ? 0u : (B_KS ? (unsigned)(KB32 * 4) * (unsigned)p.ldb : (unsigned)(KB32 * 4));
+  // operand-piece offsets of K-step (k0 .. kend) for this thread's load i
+  auto a_offset = [&](int i, int k0, int kend) -> unsigned {
+    if (GATHER == 1) {                             // lane = token (contiguous 16-byte pieces), 8 k' quads per tile row
+      const int q = tid + 256 * i, token = m0 + (q & 127), kp = k0 + 4 * (q >> 7);
+      return (token < p.gm && kp < kend) ? patch_elem(p, token, kp) * 4u : OOB;
+    }
+    return load_offset<A_KS>(i, tid, m0, p.gm, p.lda * 4, k0, kend);
+  };
+  auto b_offset = [&](int i, int k0, int kend) -> unsigned {
+    if (GATHER == 3) {                             // [32 tokens][128 k'] tile: lane = token, 32 k' quads
+      const int q = tid + 256 * i, token = k0 + (q & 31), kp = n0 + 4 * (q >> 5);
+      return (token < kend && kp < p.gn) ? patch_elem(p, token, kp) * 4u : OOB;
+    }
+    return load_offset<B_KS>(i, tid, n0, p.gn, p.ldb * 4, k0, kend);
+  };
   unsigned offa[NLD], offb[NLD], imga[NLD], imgb[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    offa[i] = load_offset<A_KS>(i, tid, m0, p.gm, p.lda * 4, k_begin, k_begin + KB32);
-    offb[i] = load_offset<B_KS>(i, tid, n0, p.gn, p.ldb * 4, k_begin, k_begin + KB32);
-    imga[i] = image_offset<A_KS>(i, tid);
-    imgb[i] = image_offset<B_KS>(i, tid);
+    offa[i] = a_offset(i, k_begin, k_begin + KB32);
+    offb[i] = b_offset(i, k_begin, k_begin + KB32);
+    const int q = tid + 256 * i;
+    // (row, 16-byte piece) of this load in the 16-bit images: the gather maps give consecutive lanes consecutive rows
+    imga[i] = GATHER == 1 ? (unsigned)((q & 127) * 64 + (((((q >> 7) >> 1) ^ (((q & 127) >> 2) & 3))) << 4) + ((q >> 7) & 1) * 8)
+                          : image_offset<A_KS>(i, tid);
+    imgb[i] = GATHER == 3 ? (unsigned)((q & 31) * 256 + (((((q >> 5) >> 1) ^ ks_swz(q & 31))) << 4) + ((q >> 5) & 1) * 8)
+                          : image_offset<B_KS>(i, tid);
   }
 
   u32x4 rawa[NLD], rawb[NLD];
@@ -155,9 +195,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
     for (int i = 0; i < NLD; ++i) {
       unsigned va = offa[i], vb = offb[i], sa = (unsigned)kt * stepa, sb = (unsigned)kt * stepb;
       if (tail) {
-        va = load_offset<A_KS>(i, tid, m0, p.gm, p.lda * 4, k_begin + kt * KB32, k_end);
-        vb = load_offset<B_KS>(i, tid, n0, p.gn, p.ldb * 4, k_begin + kt * KB32, k_end);
+        va = a_offset(i, k_begin + kt * KB32, k_end);
+        vb = b_offset(i, k_begin + kt * KB32, k_end);
         sa = sb = 0u;
+      } else if (GATHER == 3) {
+        vb = b_offset(i, k_begin + kt * KB32, k_end);
       }
       rawa[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)va, (int)sa, 0);
       rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)vb, (int)sb, 0);
@@ -252,7 +294,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
         split4(rawb[g - NLD], scb, hi, lo);
         *reinterpret_cast<uint2*>(nst + 2 * IMG32 + imgb[g - NLD]) = hi;
         *reinterpret_cast<uint2*>(nst + 3 * IMG32 + imgb[g - NLD]) = lo;
-        rawb[g - NLD] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)offb[g - NLD], (int)sb2, 0);
+        const unsigned vb2 = GATHER == 3 ? b_offset(g - NLD, k_begin + (kt + 2) * KB32, k_end) : offb[g - NLD];
+        rawb[g - NLD] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)vb2, (int)sb2, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -309,6 +352,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (two_step ? (v[e] * inv_a) * inv_b : v[e] * inv) + bias8[e];
+      if (GATHER == 2) {                            // the row matrix element (token gm, k' gn ..) scattered to the NCHW image
+        float* d0 = p.c + patch_elem(p, gm, gn);
+        float* d1 = p.c + patch_elem(p, gm, gn + 4);
+        *reinterpret_cast<float4*>(d0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d1) = make_float4(v[4], v[5], v[6], v[7]);
+        continue;
+      }
       const size_t o = cbase + (size_t)gm * p.ldc + gn;
       if (EPI != EPI32_NONE) {
         if (p.c2) {
@@ -414,7 +464,7 @@ __global__ void __launch_bounds__(256) k_absmax_group(const AbsmaxArgs a) {
 
 static bool fits32(long long rows, long long ld) { return rows * ld * 4 < 0x7fff0000LL; }
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, int G = 0>
 static int gemm32s_launch(int epi, const Gemm32Args& a, int batch, hipStream_t st) {
   const long long nblk = (long long)a.ntm * a.ntn * a.splits * batch;
   if (nblk <= 0) return MBV_OK;
@@ -423,15 +473,20 @@ static int gemm32s_launch(int epi, const Gemm32Args& a, int batch, hipStream_t s
   do {                                                                                                                   \
     static bool done = false;       /* idempotent attribute of the code object, not library state */                     \
     if (!done) {                                                                                                         \
-      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm32s<AKS, BKS, E>),                          \
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm32s<AKS, BKS, E, G>),                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));                             \
       done = true;                                                                                                       \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_gemm32s<AKS, BKS, E>), dim3((unsigned)nblk), dim3(256), LDS32, st, a);                          \
+    hipLaunchKernelGGL((k_gemm32s<AKS, BKS, E, G>), dim3((unsigned)nblk), dim3(256), LDS32, st, a);                       \
   } while (0)
-  if (epi == EPI32_RELU) MBV_G32_LAUNCH(EPI32_RELU);
-  else if (epi == EPI32_GELU) MBV_G32_LAUNCH(EPI32_GELU);
-  else MBV_G32_LAUNCH(EPI32_NONE);
+  if constexpr (G == 0 && !AKS && !BKS) {          // the activation epilogues exist for the forward form only
+    if (epi == EPI32_RELU) MBV_G32_LAUNCH(EPI32_RELU);
+    else if (epi == EPI32_GELU) MBV_G32_LAUNCH(EPI32_GELU);
+    else MBV_G32_LAUNCH(EPI32_NONE);
+  } else {
+    if (epi != EPI32_NONE) return MBV_ERR_UNSUPPORTED;
+    MBV_G32_LAUNCH(EPI32_NONE);
+  }
 #undef MBV_G32_LAUNCH
   MBV_CHECK_LAUNCH();
   return MBV_OK;
@@ -571,6 +626,96 @@ extern "C" int mbv_gemm32s_tn_acc(const float* g, const float* x, float* dw, int
   const long long total = n * k;
   hipLaunchKernelGGL(k_add_parts32, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float*>(workspace), a.splits, total, dw);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// ---- the 4 x 4 non-overlapping patch projection on an NCHW f32 image, without materialising its rows -------------------
+static bool patch_ok(int64_t batch, int64_t c, int64_t h, int64_t w, int64_t e) {
+  return batch > 0 && c > 0 && h > 0 && w > 0 && e > 0 && (h & 3) == 0 && (w & 127) == 0 && (e & 7) == 0 && (c & 1) == 0 &&
+         batch * c * h * w * 4 < 0x7fff0000LL && (w >> 2) % 32 == 0;
+}
+
+extern "C" int mbv_patch_embed32_supported(int64_t batch, int64_t channels, int64_t h, int64_t w, int64_t embed) {
+  return patch_ok(batch, channels, h, w, embed) ? 1 : 0;
+}
+
+// out (B * h/4 * w/4, E) = rows(image) . weight (E, 16 C)^T + bias
+extern "C" int mbv_patch_embed32_fwd(const float* image, const float* weight, const float* bias, float* out, int64_t batch,
+                                     int64_t channels, int64_t h, int64_t w, int64_t embed, const uint32_t* amax_image,
+                                     const uint32_t* amax_w, void* stream) {
+  if (!image || !weight || !out) return MBV_ERR_BAD_ARG;
+  if (!patch_ok(batch, channels, h, w, embed)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(image) | reinterpret_cast<size_t>(weight) | reinterpret_cast<size_t>(out) |
+       reinterpret_cast<size_t>(bias)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t m = batch * (h / 4) * (w / 4), k = 16 * channels;
+  Gemm32Args a = {};
+  a.a = image; a.b = weight; a.c = out; a.bias = bias; a.amax_a = amax_image; a.amax_b = amax_w;
+  a.gm = (int)m; a.gn = (int)embed; a.gk = (int)k;
+  a.lda = (int)k; a.ldb = (int)k; a.ldc = (int)embed;
+  a.a_bytes = (unsigned)(batch * channels * h * w * 4); a.b_bytes = (unsigned)(embed * k * 4);
+  a.ntm = (int)((m + 127) / 128); a.ntn = (int)((embed + 127) / 128); a.splits = 1; a.ksteps = (int)(k / KB32);
+  a.pc = (int)channels; a.ph = (int)h; a.pw = (int)w;
+  return gemm32s_launch<false, false, 1>(EPI32_NONE, a, 1, (hipStream_t)stream);
+}
+
+// d image (B, C, h, w) = (d out (tokens, E) . weight (E, 16 C)) scattered back (every image element is written)
+extern "C" int mbv_patch_embed32_bwd_image(const float* d_out, const float* weight, float* d_image, int64_t batch,
+                                           int64_t channels, int64_t h, int64_t w, int64_t embed, const uint32_t* amax_g,
+                                           const uint32_t* amax_w, void* stream) {
+  if (!d_out || !weight || !d_image) return MBV_ERR_BAD_ARG;
+  if (!patch_ok(batch, channels, h, w, embed)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(d_out) | reinterpret_cast<size_t>(weight) | reinterpret_cast<size_t>(d_image)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t m = batch * (h / 4) * (w / 4), k = 16 * channels;
+  Gemm32Args a = {};
+  a.a = d_out; a.b = weight; a.c = d_image; a.amax_a = amax_g; a.amax_b = amax_w;
+  a.gm = (int)m; a.gn = (int)k; a.gk = (int)embed;
+  a.lda = (int)embed; a.ldb = (int)k; a.ldc = (int)k;
+  a.a_bytes = (unsigned)(m * embed * 4); a.b_bytes = (unsigned)(embed * k * 4);
+  a.ntm = (int)((m + 127) / 128); a.ntn = (int)((k + 127) / 128); a.splits = 1; a.ksteps = (int)((embed + KB32 - 1) / KB32);
+  a.pc = (int)channels; a.ph = (int)h; a.pw = (int)w;
+  return gemm32s_launch<false, true, 2>(EPI32_NONE, a, 1, (hipStream_t)stream);
+}
+
+extern "C" size_t mbv_patch_embed32_bwd_weight_workspace_bytes(int64_t batch, int64_t channels, int64_t h, int64_t w,
+                                                               int64_t embed) {
+  if (!patch_ok(batch, channels, h, w, embed)) return 0;
+  return mbv_gemm32s_tn_workspace_bytes(batch * (h / 4) * (w / 4), embed, 16 * channels);
+}
+
+// d weight (E, 16 C) f32, contiguous += d out (tokens, E)^T . rows(image)
+extern "C" int mbv_patch_embed32_bwd_weight(const float* d_out, const float* image, float* d_weight, int64_t batch,
+                                            int64_t channels, int64_t h, int64_t w, int64_t embed, const uint32_t* amax_g,
+                                            const uint32_t* amax_image, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  if (!d_out || !image || !d_weight) return MBV_ERR_BAD_ARG;
+  if (!patch_ok(batch, channels, h, w, embed)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(d_out) | reinterpret_cast<size_t>(image) | reinterpret_cast<size_t>(d_weight) |
+       reinterpret_cast<size_t>(workspace)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t m = batch * (h / 4) * (w / 4), k = 16 * channels;
+  Gemm32Args a = {};
+  a.a = d_out; a.b = image; a.amax_a = amax_g; a.amax_b = amax_image;
+  a.gm = (int)embed; a.gn = (int)k; a.gk = (int)m;
+  a.lda = (int)embed; a.ldb = (int)k; a.ldc = (int)k;
+  a.a_bytes = (unsigned)(m * embed * 4); a.b_bytes = (unsigned)(batch * channels * h * w * 4);
+  a.ntm = (int)((embed + 127) / 128); a.ntn = (int)((k + 127) / 128);
+  tn32_split(m, embed, k, a.splits, a.ksteps);
+  a.pc = (int)channels; a.ph = (int)h; a.pw = (int)w;
+  if (a.splits == 1) {
+    a.c = d_weight; a.acc_out = 1;
+    return gemm32s_launch<true, true, 3>(EPI32_NONE, a, 1, (hipStream_t)stream);
+  }
+  if (!workspace || workspace_bytes < (size_t)a.splits * (size_t)embed * (size_t)k * 4) return MBV_ERR_WORKSPACE;
+  a.c = reinterpret_cast<float*>(workspace);
+  a.ssplit = embed * k;
+  const int rc = gemm32s_launch<true, true, 3>(EPI32_NONE, a, 1, (hipStream_t)stream);
+  if (rc != MBV_OK) return rc;
+  const long long total = embed * k;
+  hipLaunchKernelGGL(k_add_parts32, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float*>(workspace), a.splits, total, d_weight);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

@@ -133,7 +133,11 @@ class PatchEmbed(nn.Module):
             w = self.projection.weight                                   # (E, C, p, p) → (E, p, C, p)
             w2 = w.permute(0, 2, 1, 3).reshape(w.shape[0], -1)
             return self.norm(ops.linear(x.rows, w2, self.projection.bias))
-        x = self.projection(corner_pad(x, self.patch, self.patch))
+        x = corner_pad(x, self.patch, self.patch)
+        if self.patch == 4 and ops.patch_embed32_ok(x, self.projection.weight, self.projection.bias):
+            # fp32 compute: the projection as K20 products that gather the NCHW image (no MIOpen convolution, tokens out)
+            return self.norm(ops.patch_embed32(x, self.projection.weight, self.projection.bias))
+        x = self.projection(x)
         return self.norm(x.permute(0, 2, 3, 1))
 
 

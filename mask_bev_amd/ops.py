@@ -1297,6 +1297,80 @@ def gemm32s_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, amax_g: 
                                  _amax_ptr(amax_x, 0), _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_acc')
 
 
+class _PatchEmbed32(torch.autograd.Function):
+    """The backbone's 4 x 4 patch projection on the f32 NCHW pseudo-image as K20 products that gather / scatter the image
+    directly (csrc/gemm_f32s.hip, GATHER modes): (B, C, H, W) -> tokens (B, H/4, W/4, E)."""
+
+    @staticmethod
+    def forward(ctx, image, weight, bias):
+        lib = _lib.load()
+        b, c, h, w = image.shape
+        e = weight.shape[0]
+        image = image.contiguous()
+        w2 = weight.reshape(e, -1)
+        amax = f32_absmax([image.view(b * c * h, w), w2])
+        out = torch.empty((b, h // 4, w // 4, e), dtype=torch.float32, device=image.device)
+        check(lib.mbv_patch_embed32_fwd(_ptr(image), _ptr(w2), _ptr(bias), _ptr(out), b, c, h, w, e, _amax_ptr(amax, 0),
+                                        _amax_ptr(amax, 1), _stream()), 'mbv_patch_embed32_fwd')
+        ctx.save_for_backward(image, weight)
+        ctx.amax, ctx.bias = amax, bias
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        image, weight = ctx.saved_tensors
+        bias = ctx.bias
+        b, c, h, w = image.shape
+        e = weight.shape[0]
+        g = g.contiguous()
+        g2 = g.view(-1, e)
+        amax_g = f32_absmax([g2])
+        w2 = weight.reshape(e, -1)
+        gi = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gi = torch.empty_like(image)
+            check(lib.mbv_patch_embed32_bwd_image(_ptr(g2), _ptr(w2), _ptr(gi), b, c, h, w, e, _amax_ptr(amax_g, 0),
+                                                  _amax_ptr(ctx.amax, 1), _stream()), 'mbv_patch_embed32_bwd_image')
+        if ctx.needs_input_grad[1]:
+            direct = (getattr(weight, '_mbv_arena', False) and weight.grad is not None
+                      and weight.grad.dtype == torch.float32 and weight.grad.is_contiguous())
+            acc = weight.grad if direct else torch.zeros_like(weight)
+            nbytes = lib.mbv_patch_embed32_bwd_weight_workspace_bytes(b, c, h, w, e)
+            ws = _workspace(nbytes, g.device) if nbytes else None
+            check(lib.mbv_patch_embed32_bwd_weight(_ptr(g2), _ptr(image), _ptr(acc), b, c, h, w, e, _amax_ptr(amax_g, 0),
+                                                   _amax_ptr(ctx.amax, 0), _ptr(ws), int(nbytes), _stream()),
+                  'mbv_patch_embed32_bwd_weight')
+            if direct:
+                _fire_grad_hooks(weight)
+            else:
+                gw = acc
+        if bias is not None and ctx.needs_input_grad[2]:
+            if (getattr(bias, '_mbv_arena', False) and bias.grad is not None and bias.grad.dtype == torch.float32):
+                colsum_accum(g2, bias.grad, persistent=True)
+                _fire_grad_hooks(bias)
+            else:
+                gb = g2.sum(0)
+        return gi, gw, gb
+
+
+def patch_embed32_ok(image: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    """fp32 compute, a 4 x 4 stride-4 projection, shapes K20's gather modes take (include/maskbev_hip.h)."""
+    if not (switches.get('gemm32s') and image.is_cuda and image.dtype == torch.float32 and weight.dtype == torch.float32
+            and image.dim() == 4 and weight.dim() == 4 and tuple(weight.shape[2:]) == (4, 4)
+            and weight.shape[1] == image.shape[1] and not torch.is_autocast_enabled('cuda')):
+        return False
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16):
+        return False
+    b, c, h, w = image.shape
+    return bool(weight.is_contiguous() and weight.data_ptr() % 16 == 0
+                and _lib.load().mbv_patch_embed32_supported(b, c, h, w, weight.shape[0]))
+
+
+def patch_embed32(image: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _PatchEmbed32.apply(image, weight, bias)
+
+
 def mm32_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x (M, K) @ w (N, K)^T (+ bias)`` for f32 operands: K20 when the product is large enough and its operands fit
     (``switches.gemm32s``), else the library's f32 GEMM — the fp32 compute mode's stand-in for ``torch.mm`` / ``addmm``."""

@@ -378,6 +378,16 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                  * max(1, _i(a[11])), 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * max(1, _i(a[11]))),
     'mbv_gemm32s_tn_acc': lambda a: ('k_gemm32s<TN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[3]) * _i(a[5])) * 4.0
                                      + _i(a[4]) * _i(a[5]) * 4.0 * 2, 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
+    # the patch projection on K20's gather modes: (image, weight, bias, out, batch, C, h, w, E, ...): tokens x E x 16 C
+    'mbv_patch_embed32_fwd': lambda a: ('k_gemm32s<NT,patch>', 'mfma',
+                                        (_i(a[4]) * _i(a[5]) * _i(a[6]) * _i(a[7]) + _i(a[4]) * _i(a[6]) * _i(a[7]) // 16 * _i(a[8])) * 4.0,
+                                        2.0 * _i(a[4]) * (_i(a[6]) // 4) * (_i(a[7]) // 4) * _i(a[8]) * 16 * _i(a[5])),
+    'mbv_patch_embed32_bwd_image': lambda a: ('k_gemm32s<NN,patch>', 'mfma',
+                                              (_i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]) + _i(a[3]) * _i(a[5]) * _i(a[6]) // 16 * _i(a[7])) * 4.0,
+                                              2.0 * _i(a[3]) * (_i(a[5]) // 4) * (_i(a[6]) // 4) * _i(a[7]) * 16 * _i(a[4])),
+    'mbv_patch_embed32_bwd_weight': lambda a: ('k_gemm32s<TN,patch>', 'mfma',
+                                               (_i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]) + _i(a[3]) * _i(a[5]) * _i(a[6]) // 16 * _i(a[7])) * 4.0,
+                                               2.0 * _i(a[3]) * (_i(a[5]) // 4) * (_i(a[6]) // 4) * _i(a[7]) * 16 * _i(a[4])),
     'mbv_f32_absmax_group': lambda a: ('k_absmax_group', 'hbm',
                                        4.0 * sum(int(a[1][i]) * int(a[2][i]) for i in range(_i(a[5]))), 0.0),
     'mbv_upsample_bilinear_bwd': lambda a: ('k_upsample_bilinear_bwd', 'hbm',

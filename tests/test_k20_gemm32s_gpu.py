@@ -197,3 +197,41 @@ def test_fp32_linear_takes_k20_and_matches_float64(arena):
         finally:
             ops.gemm32s_nt = orig
         assert not calls and _err(y2.detach(), y.detach().double()) <= 4e-6
+
+
+@gpu
+@pytest.mark.parametrize('b,c,h,w,e', [(2, 8, 16, 128, 24), (4, 128, 64, 256, 192), (1, 32, 256, 128, 96)])
+@pytest.mark.parametrize('arena', [False, True])
+def test_patch_projection_gathers_the_nchw_image(b, c, h, w, e, arena):
+    """K20's GATHER modes: the 4 x 4 stride-4 Conv2d of mmdet's PatchEmbed on the f32 pseudo-image — forward tokens, image
+    gradient (scattered back to NCHW, every element written) and weight / bias gradients against float64 convolution."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.arena import ParameterArena
+    torch.manual_seed(b + c + e)
+    conv = torch.nn.Conv2d(c, e, 4, stride=4).to(_dev())
+    x = _rand((b, c, h, w), 3, 2.0).requires_grad_()
+    gy = _rand((b, h // 4, w // 4, e), 4, 1e-3)
+    if arena:
+        ParameterArena([('c', conv)], shadow_dtype=None)
+    assert ops.patch_embed32_ok(x, conv.weight, conv.bias)
+    y = ops.patch_embed32(x, conv.weight, conv.bias)
+    y.backward(gy)
+    ops.flush_deferred_grads()
+    xd = x.detach().double().requires_grad_()
+    wd, bd = conv.weight.detach().double().requires_grad_(), conv.bias.detach().double().requires_grad_()
+    ref = torch.nn.functional.conv2d(xd, wd, bd, stride=4).permute(0, 2, 3, 1)
+    ref.backward(gy.double())
+    assert y.shape == ref.shape and _err(y.detach(), ref.detach()) <= 2e-6
+    assert _err(x.grad, xd.grad) <= 2e-6
+    assert _err(conv.weight.grad, wd.grad) <= 2e-6
+    assert _err(conv.bias.grad, bd.grad) <= 2e-6
+
+
+@gpu
+def test_patch_projection_refuses_what_it_cannot_gather():
+    from mask_bev_amd import ops
+    conv = torch.nn.Conv2d(8, 24, 4, stride=4).to(_dev())
+    assert not ops.patch_embed32_ok(_rand((1, 8, 16, 96), 1), conv.weight, conv.bias)          # token rows of 24: not 32-aligned
+    assert not ops.patch_embed32_ok(_rand((1, 8, 16, 128), 1).half(), conv.weight, conv.bias)
+    conv2 = torch.nn.Conv2d(8, 24, 2, stride=2).to(_dev())
+    assert not ops.patch_embed32_ok(_rand((1, 8, 16, 128), 1), conv2.weight, conv2.bias)
