@@ -923,27 +923,31 @@ int mbv_transpose_group(const void* const* src, void* const* dst, const int32_t*
  * (/root/reference: mask_bev/models/networks/swin/swin.py:89-116, 347-355, 611-616) and the pixel decoder's Linears
  * (mask_bev/models/head/mask_bev_panoptic_head.py:119-146) — `precision=32` in train_mask_bev.py:96.
  * All matrices f32, row-major, ld* in elements (multiples of 4), pointers 16-byte aligned, n and k multiples of 8.
- * amax_*: device words holding the BITS of max|operand| (mbv_f32_absmax_group) from which the kernel derives the power
- * of two that puts the operand's largest magnitude in [2^13, 2^14); NULL = unscaled (operands whose magnitudes lie
+ * amax_*: absmax RECORDS — 64 consecutive device words (256 bytes) whose maximum is the BITS of max|operand| or of an upper
+ * bound of it (mbv_f32_absmax_group, or a K20 product that max-combined its outputs into the record: amax_out here; 64 slots, and a
+ * workgroup adds only when its maximum exceeds what its slot already holds: a few atomics per launch) —
+ * from which the kernel derives the power of two that puts the operand's largest magnitude in [2^13, 2^14); a bound up
+ * to 2^4 too large costs nothing (the full-accuracy window is 18 binades deep); NULL = unscaled (operands whose magnitudes lie
  * within [2^-3, 2^15] then keep full accuracy, smaller elements lose one bit per binade).  `act`: 0 none, 1 ReLU,
  * 2 GELU (erf form); out_pre (optional) receives the pre-activation.  Batched: `batch` products with element strides. */
 int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
 
 /* max|x| of `count` f32 tensors (rows[i], cols[i]) with row stride ld[i] (cols % 4 == 0), as the BITS of the maximum,
- * combined into *out[i] by an integer atomic max: the word must hold 0 (or an earlier partial maximum of the same tensor)
- * when the launch starts.  Every array argument is a HOST array of length count; one launch per 64 tensors. */
+ * max-combined into the 64-word record at out[i] (slot = workgroup mod 64): the record must hold zeros (or earlier partial
+ * maxima of the same tensor) when the launch starts.  Every array argument is a HOST array of length count; one launch per 64 tensors. */
 int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ld,
                          uint32_t* const* out, int32_t count, void* stream);
 
 /* out (m, n) = act(x (m, k) . w (n, k)^T + bias)                                   (nn.Linear forward) */
 int mbv_gemm32s_nt(const float* x, const float* w, const float* bias, float* out, float* out_pre, int64_t m, int64_t n,
                    int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, const uint32_t* amax_x, const uint32_t* amax_w,
-                   int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w, int64_t stride_o, void* stream);
+                   uint32_t* amax_out, int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w, int64_t stride_o,
+                   void* stream);
 
 /* out (m, k) = g (m, n) . w (n, k)                                                 (nn.Linear data gradient) */
 int mbv_gemm32s_nn(const float* g, const float* w, float* out, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw,
-                   int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, int32_t batch, int64_t stride_g,
-                   int64_t stride_w, int64_t stride_o, void* stream);
+                   int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, uint32_t* amax_out, int32_t batch,
+                   int64_t stride_g, int64_t stride_w, int64_t stride_o, void* stream);
 
 /* dw (n, k) contiguous += g (m, n)^T . x (m, k)                                     (nn.Linear weight gradient)
  * The token sum is cut into parts that are stored to `workspace` (mbv_gemm32s_tn_workspace_bytes) and added into dw by
@@ -970,6 +974,7 @@ size_t mbv_patch_embed32_bwd_weight_workspace_bytes(int64_t batch, int64_t chann
 int mbv_patch_embed32_bwd_weight(const float* d_out, const float* image, float* d_weight, int64_t batch, int64_t channels,
                                  int64_t h, int64_t w, int64_t embed, const uint32_t* amax_g, const uint32_t* amax_image,
                                  void* workspace, size_t workspace_bytes, void* stream);
+
 
 #ifdef __cplusplus
 }

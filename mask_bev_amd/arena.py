@@ -109,6 +109,7 @@ class ParameterArena:
 
     def refresh_shadow(self):
         """Re-derive the 16-bit shadow from the f32 parameters (after load_state_dict / broadcast / manual edits)."""
+        ops.note_parameters_changed()
         if self.shadow is None or self.numel == 0:
             return
         if self.device.type != 'cuda':
@@ -237,6 +238,7 @@ class FlatAdam(torch.optim.Optimizer):
         ar = self.arena
         if ar.device.type != 'cuda':
             raise _lib.MaskBevHipError('FlatAdam runs on the MI355X only (mbv_adamw_step)')
+        ops.note_parameters_changed()          # cached per-weight records (K20's absmax words) die with this update
         lib = _lib.load()
         self.steps += 1
         stream = torch.cuda.current_stream(ar.device).cuda_stream

@@ -49,8 +49,9 @@ struct Gemm32Args {
   float* c;             // (gm, gn) row-major f32
   float* c2;            // EPI32_RELU / EPI32_GELU: optional pre-activation output
   const float* bias;    // optional, (gn)
-  const unsigned* amax_a;   // device word: bits of max|a| over the operand (NULL: scale 1)
+  const unsigned* amax_a;   // kAmaxSlots device words whose maximum is the bits of (a bound of) max|a| (NULL: scale 1)
   const unsigned* amax_b;
+  unsigned* amax_out;       // optional: the bits of max|stored c| are max-combined into these kAmaxSlots words
   int gm, gn, gk;
   int lda, ldb, ldc;
   long long sa, sb, sc;     // batch strides (elements)
@@ -78,11 +79,20 @@ __device__ __forceinline__ unsigned patch_elem(const Gemm32Args& p, int token, i
   return (unsigned)(((b * p.pc + c) * p.ph + 4 * oy + dy) * p.pw + 4 * ox + (kp & 3));
 }
 
+// An absmax "word" is kAmaxSlots words (256 bytes): producers max-combine into slot (workgroup id mod kAmaxSlots) — tens
+// of thousands of atomics on ONE address would serialise — and the consumer takes the maximum of the slots.
+constexpr int kAmaxSlots = 64;
+
 // 2^e with max * 2^e in [2^13, 2^14) from the bits of max|x| (exact; 1 for an all-zero operand), and its inverse.
 __device__ __forceinline__ float pow2_scale(const unsigned* amax, float& inv) {
   inv = 1.f;
   if (!amax) return 1.f;
-  const unsigned bits = __builtin_nontemporal_load(amax) & 0x7fffffffu;
+  unsigned bits = 0u;                             // (a uniform address: scalar loads and scalar max)
+#pragma unroll
+  for (int i = 0; i < kAmaxSlots; ++i) {
+    const unsigned w = amax[i] & 0x7fffffffu;
+    bits = bits > w ? bits : w;
+  }
   if (bits == 0u) return 1.f;
   int e = 267 - (int)(bits >> 23);                // biased exponent of the scale: 127 + 13 - (exponent(max) - 127)
   e = e < 1 ? 1 : (e > 253 ? 253 : e);            // both the scale and its inverse stay normal numbers
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
   const int mrow0 = m0 + 32 * TM * wm + prow;
   const float inv = inv_a * inv_b;                  // each factor is a normal power of two; the product may be subnormal
   const bool two_step = !(inv >= 1.1754944e-38f);   // then scale in two exact steps
+  unsigned out_max = 0u;                            // bits of the largest magnitude this thread stores (amax_out)
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -380,9 +391,25 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
         v[0] += d0.x; v[1] += d0.y; v[2] += d0.z; v[3] += d0.w;
         v[4] += d1.x; v[5] += d1.y; v[6] += d1.z; v[7] += d1.w;
       }
+      if (p.amax_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned w = __float_as_uint(v[e]) & 0x7fffffffu;
+          out_max = out_max > w ? out_max : w;
+        }
+      }
       *reinterpret_cast<float4*>(p.c + o) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(p.c + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
+  }
+  if (p.amax_out) {                                 // one max-combine per wave, skipped when the slot already holds more
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      const unsigned o2 = (unsigned)__shfl_xor((int)out_max, sft, 64);
+      out_max = out_max > o2 ? out_max : o2;
+    }
+    unsigned* slot = p.amax_out + (bid & (kAmaxSlots - 1));
+    if (lane == 0 && out_max > __builtin_nontemporal_load(slot)) atomicMax(slot, out_max);
   }
 }
 
@@ -456,7 +483,7 @@ __global__ void __launch_bounds__(256) k_absmax_group(const AbsmaxArgs a) {
   if (threadIdx.x == 0) {
     const unsigned a01 = red[0] > red[1] ? red[0] : red[1], a23 = red[2] > red[3] ? red[2] : red[3];
     const unsigned mm = a01 > a23 ? a01 : a23;
-    if (mm) atomicMax(e.out, mm);
+    if (mm) atomicMax(e.out + (blockIdx.x & (kAmaxSlots - 1)), mm);
   }
 }
 
@@ -499,8 +526,8 @@ extern "C" int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64
 }
 
 // max|x| of `count` f32 tensors (rows[i], cols[i]) with row stride ld[i] (cols % 4 == 0, 16-byte aligned rows), as the BITS
-// of the maximum, combined into out[i] by an integer atomic max: out[i] must hold 0 (or an earlier partial maximum) when
-// the launch starts.  Every array argument is a HOST array of length count; one launch per 64 tensors.
+// of the maximum, max-combined into the kAmaxSlots (64) words at out[i]: they must hold 0 (or earlier partial maxima) when
+// the launch starts; the maximum over the 64 words is the result.  Every array argument is a HOST array of length count; one launch per 64 tensors.
 extern "C" int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ld,
                                     uint32_t* const* out, int32_t count, void* stream) {
   if (count < 0 || (count > 0 && (!x || !rows || !cols || !ld || !out))) return MBV_ERR_BAD_ARG;
@@ -531,11 +558,13 @@ extern "C" int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, 
 }
 
 static int gemm32s_common(int layout, const float* a_op, const float* b_op, float* out, float* out_pre, const float* bias,
-                          const uint32_t* amax_a, const uint32_t* amax_b, int64_t gm, int64_t gn, int64_t gk, int64_t lda,
+                          const uint32_t* amax_a, const uint32_t* amax_b, uint32_t* amax_out, int64_t gm, int64_t gn,
+                          int64_t gk, int64_t lda,
                           int64_t ldb, int64_t ldc, int64_t a_rows, int64_t a_cols, int64_t b_rows, int64_t b_cols,
                           int32_t act, int32_t batch, int64_t sa, int64_t sb, int64_t sc, hipStream_t st) {
   Gemm32Args a = {};
   a.a = a_op; a.b = b_op; a.c = out; a.c2 = out_pre; a.bias = bias; a.amax_a = amax_a; a.amax_b = amax_b;
+  a.amax_out = amax_out;
   a.gm = (int)gm; a.gn = (int)gn; a.gk = (int)gk;
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc;
   a.sa = sa; a.sb = sb; a.sc = sc;
@@ -550,8 +579,8 @@ static int gemm32s_common(int layout, const float* a_op, const float* b_op, floa
 // magnitudes within [2^-14, 2^15) keep full accuracy unscaled).
 extern "C" int mbv_gemm32s_nt(const float* x, const float* w, const float* bias, float* out, float* out_pre, int64_t m,
                               int64_t n, int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, const uint32_t* amax_x,
-                              const uint32_t* amax_w, int32_t act, int32_t batch, int64_t stride_x, int64_t stride_w,
-                              int64_t stride_o, void* stream) {
+                              const uint32_t* amax_w, uint32_t* amax_out, int32_t act, int32_t batch, int64_t stride_x,
+                              int64_t stride_w, int64_t stride_o, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !x || !w || !out) return MBV_ERR_BAD_ARG;
   if (act < 0 || act > 2) return MBV_ERR_BAD_ARG;
   if ((n & 7) || (k & 7) || (ldx & 3) || (ldw & 3) || (ldo & 3) || ldx < k || ldw < k || ldo < n) return MBV_ERR_UNSUPPORTED;
@@ -560,21 +589,21 @@ extern "C" int mbv_gemm32s_nt(const float* x, const float* w, const float* bias,
     return MBV_ERR_UNSUPPORTED;
   if (!fits32(m, ldx) || !fits32(n, ldw)) return MBV_ERR_UNSUPPORTED;
   if (m == 0 || batch == 0) return MBV_OK;
-  return gemm32s_common(0, x, w, out, out_pre, bias, amax_x, amax_w, m, n, k, ldx, ldw, ldo, m, k, n, k, act, batch,
+  return gemm32s_common(0, x, w, out, out_pre, bias, amax_x, amax_w, amax_out, m, n, k, ldx, ldw, ldo, m, k, n, k, act, batch,
                         stride_x, stride_w, stride_o, (hipStream_t)stream);
 }
 
 // out (m, k) f32 = g (m, n) . w (n, k)
 extern "C" int mbv_gemm32s_nn(const float* g, const float* w, float* out, int64_t m, int64_t n, int64_t k, int64_t ldg,
-                              int64_t ldw, int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, int32_t batch,
-                              int64_t stride_g, int64_t stride_w, int64_t stride_o, void* stream) {
+                              int64_t ldw, int64_t ldo, const uint32_t* amax_g, const uint32_t* amax_w, uint32_t* amax_out,
+                              int32_t batch, int64_t stride_g, int64_t stride_w, int64_t stride_o, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || batch < 0 || !g || !w || !out) return MBV_ERR_BAD_ARG;
   if ((n & 7) || (k & 7) || (ldg & 3) || (ldw & 3) || (ldo & 3) || ldg < n || ldw < k || ldo < k) return MBV_ERR_UNSUPPORTED;
   if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out)) & 15) return MBV_ERR_UNSUPPORTED;
   if (!fits32(m, ldg) || !fits32(n, ldw)) return MBV_ERR_UNSUPPORTED;
   if (m == 0 || batch == 0) return MBV_OK;
-  return gemm32s_common(1, g, w, out, nullptr, nullptr, amax_g, amax_w, m, k, n, ldg, ldw, ldo, m, n, n, k, 0, batch,
-                        stride_g, stride_w, stride_o, (hipStream_t)stream);
+  return gemm32s_common(1, g, w, out, nullptr, nullptr, amax_g, amax_w, amax_out, m, k, n, ldg, ldw, ldo, m, n, n, k, 0,
+                        batch, stride_g, stride_w, stride_o, (hipStream_t)stream);
 }
 
 static void tn32_split(int64_t m, int64_t n, int64_t k, int& splits, int& ksteps) {

@@ -600,7 +600,10 @@ def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, bias_table: torc
     Returns (B, H, W, C) (before the output projection), same dtype as qkv (f32 or bf16).
     ``full_bias_grad``: the gradient returned for ``qkv_bias`` is the WHOLE bias gradient of the qkv projection
     (column sums of d(qkv) over all tokens) — run that Linear with ``skip_bias_grad=True``."""
-    return _WindowAttention.apply(qkv, qkv_bias, bias_table, num_heads, ws, shift, full_bias_grad)
+    out = _WindowAttention.apply(qkv, qkv_bias, bias_table, num_heads, ws, shift, full_bias_grad)
+    # every output element is a convex combination of v elements: the absmax record of qkv bounds the attention output
+    amax_hint_set(out, amax_hint_get(qkv))
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -1184,20 +1187,24 @@ def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype]
 # --------------------------------------------------------------------------------------
 # K20 f32 GEMMs from IEEE-half pairs on the 16-bit matrix pipe (csrc/gemm_f32s.hip) — the fp32 compute mode's Linears
 # --------------------------------------------------------------------------------------
+AMAX_SLOTS = 64          # words per absmax record (csrc/gemm_f32s.hip kAmaxSlots)
+
+
 class _AmaxPool:
-    """Device words for `mbv_f32_absmax_group` results (the BITS of max|x|, combined by an integer atomic max, so a word
-    must be zero before its tensor's launch).  Words are handed out one after the other from zero-filled blocks of 1024
-    (one fill launch per block instead of one per tensor).  A block never spans the start of a stream capture: a block
-    filled eagerly would not be zeroed again by the replay, and a word would then hold the maximum over ALL replays."""
+    """Absmax records for K20 (csrc/gemm_f32s.hip): 64 device words each, whose maximum is the BITS of max|x| (or of a bound
+    of it), max-combined by `mbv_f32_absmax_group` or by a producer kernel — so a record must be zero before its tensor's
+    launch.  Records are handed out one after the other from zero-filled blocks of 256 (one fill launch per block instead
+    of one per tensor).  A block never spans the start of a stream capture: a block filled eagerly would not be zeroed
+    again by the replay, and a record would then hold the maximum over ALL replays."""
 
     def __init__(self):
         self.block, self.used, self.capturing = None, 0, False
 
     def take(self, device, n: int = 1) -> torch.Tensor:
         cap = torch.cuda.is_current_stream_capturing()
-        if (self.block is None or self.used + n > self.block.numel() or cap != self.capturing
+        if (self.block is None or self.used + n > self.block.shape[0] or cap != self.capturing
                 or self.block.device != device):
-            self.block = torch.zeros(1024, dtype=torch.int32, device=device)
+            self.block = torch.zeros((256, AMAX_SLOTS), dtype=torch.int32, device=device)
             self.used, self.capturing = 0, cap
         out = self.block[self.used:self.used + n]
         self.used += n
@@ -1207,8 +1214,17 @@ class _AmaxPool:
 _AMAX_POOLS: dict = {}
 
 
+def amax_record(device, n: int = 1) -> torch.Tensor:
+    """(n, 64) int32 zeroed absmax records on the current stream (see :class:`_AmaxPool`)."""
+    # one pool per (device, thread, stream): a block is zero-filled on the stream that is current when it is made, and a
+    # record handed to a launch on another stream could be read before that fill ran
+    import threading
+    pool = _AMAX_POOLS.setdefault((device, threading.get_ident(), torch.cuda.current_stream(device).cuda_stream), _AmaxPool())
+    return pool.take(device, n)
+
+
 def f32_absmax(tensors) -> torch.Tensor:
-    """(len(tensors),) int32 device words: the bits of max|t| of each f32 matrix (rows may be strided), one launch."""
+    """(len(tensors), 64) int32 absmax records of the f32 matrices (rows may be strided), one launch."""
     lib = _lib.load()
     n = len(tensors)
     dev = tensors[0].device
@@ -1216,16 +1232,92 @@ def f32_absmax(tensors) -> torch.Tensor:
         if (not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[1] % 4
                 or t.stride(0) % 4 or t.data_ptr() % 16):
             raise MaskBevHipError('f32_absmax: f32 matrices with contiguous, 16-byte aligned rows (cols % 4 == 0) only')
-    # one pool per (device, thread, stream): a block is zero-filled on the stream that is current when it is made, and a
-    # word handed to a launch on another stream could be read before that fill ran
-    import threading
-    pool = _AMAX_POOLS.setdefault((dev, threading.get_ident(), torch.cuda.current_stream(dev).cuda_stream), _AmaxPool())
-    out = pool.take(dev, n)
+    out = amax_record(dev, n)
     PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
     check(lib.mbv_f32_absmax_group(PA(*[t.data_ptr() for t in tensors]), LA(*[t.shape[0] for t in tensors]),
                                    LA(*[t.shape[1] for t in tensors]), LA(*[t.stride(0) for t in tensors]),
-                                   PA(*[out.data_ptr() + 4 * i for i in range(n)]), n, _stream()), 'mbv_f32_absmax_group')
+                                   PA(*[out.data_ptr() + 4 * AMAX_SLOTS * i for i in range(n)]), n, _stream()),
+          'mbv_f32_absmax_group')
     return out
+
+
+# Absmax HINTS: K20's epilogue can max-combine the values it stores into a record while they are in its registers, and the
+# wrappers carry that record — or a bound derived from it: |gelu(z)| <= |z|, a window-attention output is a convex combination
+# of v rows, |act'| <= 1.13 — to the next K20 product that reads the tensor (fc2's input behind fc1 + GELU, proj's input
+# behind qkv + attention, fc1's output gradient behind fc2's data gradient) — found by the tensor's address, valid only while the very tensor object is alive and unmodified
+# (weak reference + version).  A consumer without a valid hint runs the absmax pass: a missed hint costs time, never accuracy.
+_AMAX_HINTS: dict = {}
+_LAST_HINT = [0, None]
+
+
+def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor]) -> None:
+    if rec is None or not torch.is_tensor(t) or not t.is_cuda:
+        return
+    import weakref
+    if len(_AMAX_HINTS) > 512:
+        for k in [k for k, (ref, _, _) in _AMAX_HINTS.items() if ref() is None]:
+            del _AMAX_HINTS[k]
+        if len(_AMAX_HINTS) > 512:
+            _AMAX_HINTS.clear()
+    _AMAX_HINTS[t.data_ptr()] = (weakref.ref(t), t._version, rec)
+    _LAST_HINT[0], _LAST_HINT[1] = t.data_ptr(), rec
+
+
+def amax_hint_refresh(t) -> None:
+    """After ``Function.apply``: the tensor object the caller holds may be a new wrapper of the one the forward hinted."""
+    if torch.is_tensor(t) and t.is_cuda and _LAST_HINT[0] == t.data_ptr() and _LAST_HINT[1] is not None \
+            and amax_hint_get(t) is None:
+        amax_hint_set(t, _LAST_HINT[1])
+
+
+def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
+    e = _AMAX_HINTS.get(t.data_ptr())
+    if e is None:
+        return None
+    ref, version, rec = e
+    src = ref()
+    if (src is None or src.data_ptr() != t.data_ptr() or src.numel() != t.numel() or src._version != version
+            or rec.device != t.device):
+        return None
+    return rec
+
+
+def _hinted_view(t: torch.Tensor, shape) -> torch.Tensor:
+    """``t.view(shape)`` that keeps ``t``'s absmax hint (a view is another tensor object at the same address)."""
+    v = t.view(shape)
+    if v is not t:
+        amax_hint_set(v, amax_hint_get(t))
+    return v
+
+
+def amax_hint_wanted(rows: int) -> bool:
+    """Whether a producer of an f32 activation with this many rows should emit an absmax record (K20 will read it)."""
+    return gemm32s_wants(rows)
+
+
+# the absmax record of a WEIGHT is good until the parameters change: keyed by the optimizer epoch (FlatAdam / arena bump it),
+# the tensor's version (torch optimizers and copy_ bump that) and whether a stream capture is running (a record computed
+# eagerly would go stale inside a replayed graph: within a capture the first use computes it, as a captured launch)
+PARAM_EPOCH = [0]
+_WEIGHT_AMAX: dict = {}
+
+
+def note_parameters_changed() -> None:
+    PARAM_EPOCH[0] += 1
+    _WEIGHT_AMAX.clear()
+
+
+def weight_amax(w: torch.Tensor) -> torch.Tensor:
+    key = (w.data_ptr(), tuple(w.shape), w.stride(0))
+    tag = (PARAM_EPOCH[0], w._version, torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream(w.device).cuda_stream)
+    e = _WEIGHT_AMAX.get(key)
+    if e is not None and e[0] == tag:
+        return e[1]
+    rec = f32_absmax([w])
+    if len(_WEIGHT_AMAX) > 2048:
+        _WEIGHT_AMAX.clear()
+    _WEIGHT_AMAX[key] = (tag, rec)
+    return rec
 
 
 def _gemm32s_ok(*ts: torch.Tensor) -> bool:
@@ -1237,13 +1329,19 @@ def gemm32s_wants(tokens: int) -> bool:
     return bool(switches.get('gemm32s')) and tokens >= int(switches.get('gemm32s_min'))
 
 
-def _amax_ptr(amax: Optional[torch.Tensor], i: int):
-    return ctypes.c_void_p(0) if amax is None else ctypes.c_void_p(amax.data_ptr() + 4 * i)
+def _amax_ptr(amax, i: int):
+    """Pointer to record i of ``amax``: an (n, 64) tensor of records, or a tuple of one-record tensors."""
+    if amax is None:
+        return ctypes.c_void_p(0)
+    if isinstance(amax, (tuple, list)):
+        return ctypes.c_void_p(0 if amax[i] is None else amax[i].data_ptr())
+    return ctypes.c_void_p(amax.data_ptr() + 4 * AMAX_SLOTS * i)
 
 
 def gemm32s_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
-               amax: Optional[torch.Tensor] = None, want_pre: bool = False):
-    """``act(x (M, K) @ w (N, K)^T + bias)`` in f32 on K20.  ``amax`` = ``f32_absmax([x, w])`` (computed here when None)."""
+               amax: Optional[torch.Tensor] = None, want_pre: bool = False, hint_out: bool = False):
+    """``act(x (M, K) @ w (N, K)^T + bias)`` in f32 on K20.  ``amax`` = ``f32_absmax([x, w])`` (computed here when None).
+    ``hint_out``: the epilogue max-combines |out| into an absmax record left as a hint for the next K20 product."""
     lib = _lib.load()
     if not _gemm32s_ok(x, w) or x.shape[1] != w.shape[1] or w.shape[0] % 8:
         raise MaskBevHipError('gemm32s_nt: unsupported operands')
@@ -1255,13 +1353,16 @@ def gemm32s_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     n = w.shape[0]
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     pre = torch.empty((m, n), dtype=torch.float32, device=x.device) if (want_pre and _ACT[act]) else None
+    rec = amax_record(x.device) if hint_out else None
     check(lib.mbv_gemm32s_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pre), m, n, k, x.stride(0), w.stride(0), n,
-                             _amax_ptr(amax, 0), _amax_ptr(amax, 1), _ACT[act], 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nt')
+                             _amax_ptr(amax, 0), _amax_ptr(amax, 1), _ptr(rec), _ACT[act], 1, 0, 0, 0, _stream()),
+          'mbv_gemm32s_nt')
+    amax_hint_set(out, rec)
     return (out, pre) if want_pre else out
 
 
 def gemm32s_nn(g: torch.Tensor, w: torch.Tensor, amax_g: Optional[torch.Tensor] = None,
-               amax_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+               amax_w: Optional[torch.Tensor] = None, hint_out: bool = False) -> torch.Tensor:
     """``g (M, N) @ w (N, K)`` in f32 on K20 (the data gradient of a Linear); amax_* = one-word tensors."""
     lib = _lib.load()
     if not _gemm32s_ok(g, w) or g.shape[1] != w.shape[0]:
@@ -1273,8 +1374,10 @@ def gemm32s_nn(g: torch.Tensor, w: torch.Tensor, amax_g: Optional[torch.Tensor] 
     m, n = g.shape
     k = w.shape[1]
     out = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    rec = amax_record(g.device) if hint_out else None
     check(lib.mbv_gemm32s_nn(_ptr(g), _ptr(w), _ptr(out), m, n, k, g.stride(0), w.stride(0), k, _amax_ptr(amax_g, 0),
-                             _amax_ptr(amax_w, 0), 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nn')
+                             _amax_ptr(amax_w, 0), _ptr(rec), 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nn')
+    amax_hint_set(out, rec)
     return out
 
 
@@ -1743,9 +1846,19 @@ class _Linear(torch.autograd.Function):
                 x32 = None
         with torch.autocast('cuda', enabled=False):
             if x32 is not None:
-                # fp32 compute: K20 — f32 products from IEEE-half pairs on the 16-bit matrix pipe (csrc/gemm_f32s.hip)
-                ctx.amax = f32_absmax([x32, w])
-                y = gemm32s_nt(x32, w, b, amax=ctx.amax).view(x.shape[:-1] + (w.shape[0],))
+                # fp32 compute: K20 — f32 products from IEEE-half pairs on the 16-bit matrix pipe (csrc/gemm_f32s.hip).  The
+                # operand scales: x's absmax record from its producer when it left one (K12, K20), else one pass over x;
+                # the weight's once per parameter update
+                hints = bool(switches.get('amax_hints'))
+                hx = amax_hint_get(x32) if hints else None
+                if hx is not None:
+                    ctx.amax = (hx, weight_amax(w))
+                else:
+                    both = f32_absmax([x32, w])
+                    ctx.amax = (both[0:1], both[1:2])
+                y2 = gemm32s_nt(x32, w, b, amax=ctx.amax, hint_out=hints)
+                y = y2.view(x.shape[:-1] + (w.shape[0],))
+                amax_hint_set(y, amax_hint_get(y2))
             elif (x2k is not None and gemm16_policy() == 'all' and _gemm16_ok(x2k, w)
                     and (bias is None or bias.dtype == torch.float32)):
                 bf = None if bias is None else (bias if rows is None else bias[rows[0]:rows[1]])
@@ -1780,10 +1893,13 @@ class _Linear(torch.autograd.Function):
             if not g2.is_contiguous():
                 g2 = g2.contiguous()
             if _gemm32s_ok(g2, w) and _gemm32s_ok(x2):
-                amax_g = f32_absmax([g2])
+                amax_g = amax_hint_get(g2) if switches.get('amax_hints') else None
+                if amax_g is None:
+                    amax_g = f32_absmax([g2])
         if ctx.needs_input_grad[0]:
             if amax_g is not None:
-                gx = gemm32s_nn(g2, w, amax_g, ctx.amax[1:2]).view_as(x)
+                gx = gemm32s_nn(g2, w, amax_g, ctx.amax[1], hint_out=bool(switches.get('amax_hints')))
+                gx = _hinted_view(gx, x.shape)
             elif gemm16_policy() == 'all' and g2.is_cuda and _gemm16_ok(g2, w):
                 gx = gemm16_nn(g2, w).view_as(x)
             elif ctx.gx_f32:         # an f32 input was cast for the GEMM: its gradient leaves the GEMM as f32 (no cast pass)
@@ -1802,13 +1918,13 @@ class _Linear(torch.autograd.Function):
                 if bias_direct:
                     bacc = bias.grad if rows is None else bias.grad[rows[0]:rows[1]]
                 bias_done = _wgrad_into(acc, g2, x2, bacc, persistent=True,                  # straight into the arena
-                                        amax=None if amax_g is None else (amax_g, ctx.amax[0:1])) or bias_done
+                                        amax=None if amax_g is None else (amax_g, ctx.amax[0])) or bias_done
                 _fire_grad_hooks(weight)
                 if bias_done:
                     _fire_grad_hooks(bias)
             elif amax_g is not None and weight.dtype == torch.float32 and weight.is_contiguous():
                 gw = torch.zeros_like(weight)
-                gemm32s_tn_acc(gw if rows is None else gw[rows[0]:rows[1]], g2, x2, amax_g, ctx.amax[0:1])
+                gemm32s_tn_acc(gw if rows is None else gw[rows[0]:rows[1]], g2, x2, amax_g, ctx.amax[0])
             elif rows is None:
                 gw = _wgrad(g2, x2).to(weight.dtype)
             else:
@@ -1833,7 +1949,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     without materialising slices or zero-padded slice gradients.  Parameters that live in a
     :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
     direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
-    return _Linear.apply(x, weight, bias, rows, f32_out, skip_bias_grad)
+    y = _Linear.apply(x, weight, bias, rows, f32_out, skip_bias_grad)
+    amax_hint_refresh(y)
+    return y
 
 
 class _FFN(torch.autograd.Function):
@@ -2825,7 +2943,9 @@ class _BiasAct(torch.autograd.Function):
     def forward(ctx, z, bias, kind):
         ctx.bias, ctx.kind = bias, kind
         ctx.save_for_backward(z)
-        return torch.nn.functional.gelu(z) if kind == 1 else torch.relu(z)
+        out = torch.nn.functional.gelu(z) if kind == 1 else torch.relu(z)
+        amax_hint_set(out, amax_hint_get(z))             # |gelu(z)|, |relu(z)| <= |z|: z's absmax record bounds the output
+        return out
 
     @staticmethod
     def backward(ctx, ga):
@@ -2839,6 +2959,10 @@ class _BiasAct(torch.autograd.Function):
         check(lib.mbv_act_bwd_colsum(_ptr(ga), _ptr(zc), _dt_flag(zc.dtype), ctx.kind, zc.numel() // n, n,
                                      _ptr(gz), _ptr(None if bias is None else bias.grad), _stream()),
               'mbv_act_bwd_colsum')
+        hg = amax_hint_get(ga) if gz.dtype == torch.float32 else None
+        if hg is not None:
+            # |act'| <= 1.13 (GELU) / 1 (ReLU): twice ga's bound bounds gz — one more binade in the record (64 words, one tiny launch)
+            amax_hint_set(gz, hg + (1 << 23))
         if bias is not None:
             _fire_grad_hooks(bias)
         return gz, None, None
@@ -2853,8 +2977,13 @@ def bias_act(z: torch.Tensor, bias: Optional[torch.Tensor], kind: str) -> torch.
     if not ok:
         if bias is not None and z.requires_grad:
             z = accumulate_bias_grad(z, bias)          # the deferred bias gradient must not be lost: dz reaches it here
-        return torch.nn.functional.gelu(z) if k == 1 else torch.relu(z)
-    return _BiasAct.apply(z, bias, k)
+        out = torch.nn.functional.gelu(z) if k == 1 else torch.relu(z)
+        amax_hint_set(out, amax_hint_get(z))
+        return out
+    _LAST_HINT[1] = None
+    out = _BiasAct.apply(z, bias, k)
+    amax_hint_refresh(out)
+    return out
 
 
 class _AccumulateBiasGrad(torch.autograd.Function):

@@ -373,9 +373,9 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     # (the kernel issues three matrix instructions per product term: a frac of 1/3 would be the pipe's own ceiling)
     'mbv_gemm32s_nt': lambda a: ('k_gemm32s<NT>', 'mfma', ((_i(a[5]) * _i(a[7]) + _i(a[6]) * _i(a[7])) * 4.0
                                                           + _i(a[5]) * _i(a[6]) * 4.0 * (2 if a[4] is not None and _i(a[4]) else 1))
-                                 * max(1, _i(a[14])), 2.0 * _i(a[5]) * _i(a[6]) * _i(a[7]) * max(1, _i(a[14]))),
+                                 * max(1, _i(a[15])), 2.0 * _i(a[5]) * _i(a[6]) * _i(a[7]) * max(1, _i(a[15]))),
     'mbv_gemm32s_nn': lambda a: ('k_gemm32s<NN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[4]) * _i(a[5]) + _i(a[3]) * _i(a[5])) * 4.0
-                                 * max(1, _i(a[11])), 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * max(1, _i(a[11]))),
+                                 * max(1, _i(a[12])), 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * max(1, _i(a[12]))),
     'mbv_gemm32s_tn_acc': lambda a: ('k_gemm32s<TN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[3]) * _i(a[5])) * 4.0
                                      + _i(a[4]) * _i(a[5]) * 4.0 * 2, 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
     # the patch projection on K20's gather modes: (image, weight, bias, out, batch, C, h, w, E, ...): tokens x E x 16 C

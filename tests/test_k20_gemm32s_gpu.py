@@ -34,8 +34,9 @@ def test_absmax_words_are_the_bits_of_the_maximum():
     z = torch.zeros(64, 8, device=_dev())
     big = _rand((65536, 96), 3, 100.0)
     words = ops.f32_absmax([a, b, z, big])
+    assert tuple(words.shape) == (4, ops.AMAX_SLOTS)        # a record = 64 words whose maximum is the result
     want = torch.stack([t.abs().max() for t in (a, b, z, big)]).view(torch.int32)
-    assert torch.equal(words.cpu(), want.cpu())
+    assert torch.equal(words.max(1).values.cpu(), want.cpu())
     # a second launch into the same words keeps the larger of the two (integer max): the grouped-weights use
     from mask_bev_amd import _lib
     import ctypes
@@ -44,7 +45,7 @@ def test_absmax_words_are_the_bits_of_the_maximum():
     PA, LA = ctypes.c_void_p * 1, ctypes.c_int64 * 1
     ops.check(lib.mbv_f32_absmax_group(PA(small.data_ptr()), LA(1000), LA(192), LA(192), PA(words.data_ptr()), 1,
                                        ops._stream()), 'mbv_f32_absmax_group')
-    assert int(words[0]) == int(want[0])
+    assert int(words[0].max()) == int(want[0])
 
 
 SHAPES = [  # (M, N, K)
@@ -147,8 +148,8 @@ def test_unscaled_mode_and_nonfinite_inputs():
     m, n, k = 512, 128, 96
     x, w = _rand((m, k), 1), _rand((n, k), 2)
     out = torch.empty(m, n, device=_dev())
-    ops.check(lib.mbv_gemm32s_nt(ops._ptr(x), ops._ptr(w), None, ops._ptr(out), None, m, n, k, k, k, n, None, None, 0, 1, 0,
-                                 0, 0, ops._stream()), 'mbv_gemm32s_nt')
+    ops.check(lib.mbv_gemm32s_nt(ops._ptr(x), ops._ptr(w), None, ops._ptr(out), None, m, n, k, k, k, n, None, None, None, 0, 1,
+                                 0, 0, 0, ops._stream()), 'mbv_gemm32s_nt')
     assert _err(out, x.double() @ w.double().t()) <= 2e-6  # O(1) operands need no scale
     x[7, 5] = float('inf')
     w[3, 9] = float('nan')
@@ -235,3 +236,51 @@ def test_patch_projection_refuses_what_it_cannot_gather():
     assert not ops.patch_embed32_ok(_rand((1, 8, 16, 128), 1).half(), conv.weight, conv.bias)
     conv2 = torch.nn.Conv2d(8, 24, 2, stride=2).to(_dev())
     assert not ops.patch_embed32_ok(_rand((1, 8, 16, 128), 1), conv2.weight, conv2.bias)
+
+
+@gpu
+def test_producers_leave_absmax_records_and_consumers_use_them():
+    """The absmax HINTS (ops.amax_hint_*): K20's epilogue and the activation / attention wrappers leave a 64-word
+    record whose maximum is (a bound of) max|tensor|; a Linear that finds one skips the absmax pass over its operand — same
+    results to the last bit as with the pass (a record bounds the same binade unless it is a looser bound, which only moves
+    the scale)."""
+    from mask_bev_amd import ops, _lib
+    x, w = _rand((4096, 192), 1, 2.0), _rand((576, 192), 2, 0.05)
+    out = ops.gemm32s_nt(x, w, None, hint_out=True)
+    rec = ops.amax_hint_get(out)
+    assert rec is not None and int(rec.max()) == int(out.abs().max().view(torch.int32))
+    assert ops.amax_hint_get(out.view(4, 1024, 576)) is rec              # a view of the same elements, while `out` lives
+    assert ops.amax_hint_get(out[:2048]) is None                         # other extent: not the tensor the record describes
+    out.add_(1.0)
+    assert ops.amax_hint_get(out) is None                                # modified in place: the record no longer describes it
+    # a Linear behind a hinted tensor runs no absmax pass over it
+    lin = torch.nn.Linear(192, 576).to(_dev())
+    lib = _lib.load()
+    calls = []
+    lib.hook = lambda name, fn, args: (calls.append(name), fn(*args))[1]
+    ctx = switches.override(amax_hints=True)
+    ctx.__enter__()
+    try:
+        h = ops.gemm32s_nt(x, w[:192].contiguous(), None, hint_out=True)      # (4096, 192) with a record
+        calls.clear()
+        y1 = ops.linear(h, lin.weight, lin.bias)
+        first = list(calls)
+        calls.clear()
+        y2 = ops.linear(h, lin.weight, lin.bias)                              # the weight's record is cached until parameters change
+        second = list(calls)
+    finally:
+        lib.hook = None
+        ctx.__exit__(None, None, None)
+    assert first.count('mbv_f32_absmax_group') == 1 and second.count('mbv_f32_absmax_group') == 0, (first, second)
+    with switches.override(amax_hints=False):
+        y3 = ops.linear(h, lin.weight, lin.bias)
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+    ops.note_parameters_changed()
+    calls = []
+    lib.hook = lambda name, fn, args: (calls.append(name), fn(*args))[1]
+    try:
+        with switches.override(amax_hints=True):
+            ops.linear(h, lin.weight, lin.bias)
+    finally:
+        lib.hook = None
+    assert calls.count('mbv_f32_absmax_group') == 1                      # the weight's record again, after an update
