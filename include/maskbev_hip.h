@@ -976,6 +976,16 @@ int mbv_patch_embed32_bwd_weight(const float* d_out, const float* image, float* 
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 
+/* The weight gradients of `count` few-row f32 Linears (m[i] <= 8192 tokens: the decoder's 400 query rows) in ONE K20 launch per
+ * 48 of them:  dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i]).  A 256 x 256 ... 2048 x 256
+ * output alone is 4 ... 32 tiles; the tiles of all layers together fill the chip once.  Each tile is added to dw in place by its
+ * owner workgroup (no parts, no atomics, bit-reproducible).  amax_g[i] / amax_x[i]: absmax records of the operands (NULL
+ * array or entry = unscaled).  Replaces, in fp32 compute, the exact-f32 MFMA form (mbv_wgrad_small_f32_group: 1.8 ms per step at
+ * the f32 matrix rate and an atomic per element) for shapes with n, k multiples of 8.  HOST arrays of length count. */
+int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* const* dw, const int64_t* m, const int64_t* n,
+                         const int64_t* k, const int64_t* ldg, const int64_t* ldx, const uint32_t* const* amax_g,
+                         const uint32_t* const* amax_x, int32_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

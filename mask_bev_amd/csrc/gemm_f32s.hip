@@ -137,11 +137,10 @@ __device__ __forceinline__ f32x16 mma16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// One workgroup's share of a product: work item `bid` of its (batch, split, tile_m, tile_n) index.
 template <bool A_KS, bool B_KS, int EPI, int GATHER = 0>
-__global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid, char* smem) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -413,6 +412,48 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
   }
 }
 
+template <bool A_KS, bool B_KS, int EPI, int GATHER = 0>
+__global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32s_body<A_KS, B_KS, EPI, GATHER>(p, xcd_contiguous(blockIdx.x, gridDim.x), smem);
+}
+
+// ---- grouped weight gradients: up to kTn32Group products dw_i (n_i, k_i) += g_i (m_i, n_i)^T x_i (m_i, k_i) in ONE launch ------
+// The fp32 step's few-row Linears (the decoder's 400 query rows x 9 layers, /root/reference: mask_bev/models/networks/
+// mask2former_head/mask2former_head.py:535-560) each give a handful of 128 x 128 tiles: alone they cannot fill the chip,
+// together (collected during the backward pass, issued at its end like K17's group) they are one launch.  Every entry is ONE
+// token range (m_i <= 8192): its owner workgroup adds the tile to dw in place — no parts, no atomics.
+constexpr int kTn32Group = 48;
+struct Tn32Entry {
+  const float* g; const float* x; float* dw;
+  const unsigned* amax_g; const unsigned* amax_x;
+  int m, n, k, ldg, ldx, ntn, item_begin;
+};
+struct Tn32GroupArgs {
+  Tn32Entry e[kTn32Group];
+  int n;
+};
+
+__global__ void __launch_bounds__(256, 2) k_gemm32s_tn_group(const Tn32GroupArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+  int i = 0;
+  while (i + 1 < a.n && item >= a.e[i + 1].item_begin) ++i;     // block-uniform: a scalar loop over <= 48 entries
+  const Tn32Entry& e = a.e[i];
+  Gemm32Args p;
+  p.a = e.g; p.b = e.x; p.c = e.dw; p.c2 = nullptr; p.bias = nullptr;
+  p.amax_a = e.amax_g; p.amax_b = e.amax_x; p.amax_out = nullptr;
+  p.gm = e.n; p.gn = e.k; p.gk = e.m;
+  p.lda = e.ldg; p.ldb = e.ldx; p.ldc = e.k;
+  p.sa = 0; p.sb = 0; p.sc = 0; p.ssplit = 0;
+  p.a_bytes = (unsigned)(((long long)(e.m - 1) * e.ldg + e.n) * 4);
+  p.b_bytes = (unsigned)(((long long)(e.m - 1) * e.ldx + e.k) * 4);
+  p.ntm = (e.n + 127) / 128; p.ntn = e.ntn; p.splits = 1; p.ksteps = (e.m + KB32 - 1) / KB32;
+  p.acc_out = 1;
+  p.pc = 0; p.ph = 0; p.pw = 0;
+  gemm32s_body<true, true, EPI32_NONE, 0>(p, item - e.item_begin, smem);
+}
+
 // out (n) += sum of the `parts` partial results part (parts, n): a thread owns 4 consecutive elements (owner adds: no
 // atomics, bit-reproducible)
 __global__ void __launch_bounds__(256) k_add_parts32(const float* __restrict__ part, int parts, long long n,
@@ -606,14 +647,23 @@ extern "C" int mbv_gemm32s_nn(const float* g, const float* w, float* out, int64_
                         batch, stride_g, stride_w, stride_o, (hipStream_t)stream);
 }
 
+// Token ranges of a weight gradient: the chip holds 512 of these workgroups at a time (two per CU), and a launch of 516 takes
+// as long as one of 1024 — so the split is the one that minimises (rounds of 512) / (ranges), at least 1024 tokens deep
+// (43 ranges x 12 tiles = 516 workgroups measured 115 us at 65 536 x 768 x 192; 42 x 12 = 504 fit one round: 92 us).
 static void tn32_split(int64_t m, int64_t n, int64_t k, int& splits, int& ksteps) {
   const int total_steps = (int)((m + KB32 - 1) / KB32);
   const long long tiles = ((n + 127) / 128) * ((k + 127) / 128);
-  long long s = (512 + tiles - 1) / tiles;            // about two workgroups per CU
-  const long long cap = (m + 1023) / 1024;            // at least 1024 tokens deep
-  if (s > cap) s = cap;
-  if (s < 1) s = 1;
-  ksteps = (int)((total_steps + s - 1) / s);
+  long long cap = (m + 1023) / 1024;
+  if (cap > 256) cap = 256;
+  if (cap < 1) cap = 1;
+  long long best = 1;
+  double best_cost = 1e30;
+  for (long long s = 1; s <= cap; ++s) {
+    const long long rounds = (tiles * s + 511) / 512;
+    const double cost = (double)rounds / (double)s;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = s; }
+  }
+  ksteps = (int)((total_steps + best - 1) / best);
   splits = (total_steps + ksteps - 1) / ksteps;
 }
 
@@ -746,5 +796,52 @@ extern "C" int mbv_patch_embed32_bwd_weight(const float* d_out, const float* ima
   hipLaunchKernelGGL(k_add_parts32, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float*>(workspace), a.splits, total, d_weight);
   MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+// dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])  for i < count in one launch per 48 products;
+// every entry is one token range (m[i] <= 8192: the few-row Linears), its tiles are added to dw in place by their owner
+// workgroups.  amax_g[i] / amax_x[i]: absmax records (NULL entries = unscaled).  Array arguments are HOST arrays of length count.
+extern "C" int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* const* dw, const int64_t* m,
+                                    const int64_t* n, const int64_t* k, const int64_t* ldg, const int64_t* ldx,
+                                    const uint32_t* const* amax_g, const uint32_t* const* amax_x, int32_t count,
+                                    void* stream) {
+  if (count < 0 || (count > 0 && (!g || !x || !dw || !m || !n || !k || !ldg || !ldx))) return MBV_ERR_BAD_ARG;
+  for (int i = 0; i < count; ++i) {
+    if (m[i] < 0) return MBV_ERR_BAD_ARG;
+    if (m[i] == 0) continue;
+    if (m[i] > 8192 || n[i] <= 0 || k[i] <= 0 || !g[i] || !x[i] || !dw[i]) return MBV_ERR_BAD_ARG;
+    if ((n[i] & 7) || (k[i] & 7) || (ldg[i] & 3) || (ldx[i] & 3) || ldg[i] < n[i] || ldx[i] < k[i]) return MBV_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<size_t>(g[i]) | reinterpret_cast<size_t>(x[i]) | reinterpret_cast<size_t>(dw[i])) & 15)
+      return MBV_ERR_UNSUPPORTED;
+    if (!fits32(m[i], ldg[i]) || !fits32(m[i], ldx[i]) || n[i] * k[i] >= 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+  }
+  static bool attr = false;
+  if (!attr) {
+    MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm32s_tn_group),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));
+    attr = true;
+  }
+  for (int base = 0; base < count; base += kTn32Group) {
+    const int cnt = count - base < kTn32Group ? count - base : kTn32Group;
+    Tn32GroupArgs a;
+    a.n = 0;
+    long long items = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const int i = base + j;
+      if (m[i] == 0) continue;
+      Tn32Entry& e = a.e[a.n++];
+      e.g = g[i]; e.x = x[i]; e.dw = dw[i];
+      e.amax_g = amax_g ? amax_g[i] : nullptr; e.amax_x = amax_x ? amax_x[i] : nullptr;
+      e.m = (int)m[i]; e.n = (int)n[i]; e.k = (int)k[i]; e.ldg = (int)ldg[i]; e.ldx = (int)ldx[i];
+      e.ntn = (int)((k[i] + 127) / 128);
+      e.item_begin = (int)items;
+      items += (long long)((n[i] + 127) / 128) * e.ntn;
+    }
+    if (a.n == 0) continue;
+    if (items > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gemm32s_tn_group, dim3((unsigned)items), dim3(256), LDS32, (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+  }
   return MBV_OK;
 }

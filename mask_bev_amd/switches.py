@@ -46,6 +46,7 @@ _DEFAULTS: Dict[str, Any] = {
     # is also what brings x into the memory-side cache, and K20 (one K-step of loads in flight) runs its NT / NN launches at
     # 53 us behind it against 74 us cold; the 1.1 ms of passes saved cost 1.7 ms of GEMM time
     'amax_hints': False,
+    'tn32_group': True,           # fp32 compute: the few-row weight gradients of a backward pass as one grouped K20 launch
     'gemm32s_min': 1024,          # fewest tokens of an f32 Linear that takes K20 (below: the library's f32 GEMM; measured: scratch/bench_gemm32s.py)
     'k7_f32_library': True,       # fp32 mask logits through the library's batched GEMM instead of K7's exact-f32 kernel
     'stage_out_lowp': True,       # backbone stage outputs stored in the autocast dtype by their LayerNorm launch

@@ -388,6 +388,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_patch_embed32_bwd_weight': lambda a: ('k_gemm32s<TN,patch>', 'mfma',
                                                (_i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]) + _i(a[3]) * _i(a[5]) * _i(a[6]) // 16 * _i(a[7])) * 4.0,
                                                2.0 * _i(a[3]) * (_i(a[5]) // 4) * (_i(a[6]) // 4) * _i(a[7]) * 16 * _i(a[4])),
+    'mbv_gemm32s_tn_group': lambda a: ('k_gemm32s_tn_group', 'mfma',
+                                       sum((int(a[3][i]) * (int(a[4][i]) + int(a[5][i])) + 2 * int(a[4][i]) * int(a[5][i])) * 4.0
+                                           for i in range(_i(a[10]))),
+                                       sum(2.0 * int(a[3][i]) * int(a[4][i]) * int(a[5][i]) for i in range(_i(a[10])))),
     'mbv_f32_absmax_group': lambda a: ('k_absmax_group', 'hbm',
                                        4.0 * sum(int(a[1][i]) * int(a[2][i]) for i in range(_i(a[5]))), 0.0),
     'mbv_upsample_bilinear_bwd': lambda a: ('k_upsample_bilinear_bwd', 'hbm',

@@ -1,7 +1,7 @@
 #!/bin/bash
-# gpurun helper: A/B of path selectors on the fp32 step.  usage: bash scratch/ab32_cmd.sh "" "name=value" ...
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for cfg in "$@"; do
-  echo "== fp32 $cfg"
-  timeout 600 python bench.py --dtype fp32 $(for kv in $cfg; do echo --switch $kv; done) --steps ${AB_STEPS:-30} --warmup 4 --no-kernel-profile --no-cpu-baseline --no-fp32 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],2), round(d['ms_per_step'],3), d['config'].get('final_loss'))"
-done 2>&1 | tee -a gpurun_out/ab.log
+# gpurun helper: same-box A/B of fp32 switches: bash scratch/ab32_cmd.sh "name=a" "name=b" ...  (each twice, interleaved)
+for rep in 1 2; do
+for sw in "$@"; do
+  timeout 600 python3 bench.py --dtype fp32 --steps 40 --no-cpu-baseline --no-fp32 --no-kernel-profile --switch $sw 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw', round(d['value'],2), round(d['ms_per_step'],2))"
+done
+done

@@ -284,3 +284,26 @@ def test_producers_leave_absmax_records_and_consumers_use_them():
     finally:
         lib.hook = None
     assert calls.count('mbv_f32_absmax_group') == 1                      # the weight's record again, after an update
+
+
+@gpu
+def test_grouped_few_row_weight_gradients():
+    """mbv_gemm32s_tn_group: the weight gradients of many few-row Linears (the decoder's 400 rows) in one launch, each tile
+    added in place by its owner — against float64, on top of what the destinations held, bit-reproducibly; and through the
+    end-of-pass flush of a backward pass (ops.flush_deferred_grads takes the f32 few-row products there)."""
+    from mask_bev_amd import ops
+    shapes = [(400, 256, 256), (400, 2048, 256), (400, 256, 2048), (100, 256, 264), (4000, 256, 256), (37, 8, 8)] * 9
+    items, refs = [], []
+    for i, (m, n, k) in enumerate(shapes):
+        g, x = _rand((m, n), 100 + i, 10.0 ** (-(i % 5))), _rand((m, k), 200 + i)
+        acc = _rand((n, k), 300 + i, 0.1)
+        refs.append(acc.double() + g.double().t() @ x.double())
+        items.append((g, x, acc))
+    starts = [a.clone() for _, _, a in items]
+    ops.gemm32s_tn_group(items)
+    for (g, x, acc), ref, s0 in zip(items, refs, starts):
+        e, lib_e = _err(acc, ref), _err(torch.addmm(s0, g.t(), x), ref)
+        assert e <= max(2e-6, 2 * lib_e), (tuple(g.shape), e, lib_e)      # (a 4 000-term f32 sum: the library's own error is 1-2e-6)
+    again = [(g, x, s0) for (g, x, _), s0 in zip(items, starts)]
+    ops.gemm32s_tn_group(again)
+    assert all(torch.equal(a, b) for (_, _, a), (_, _, b) in zip(items, again))
