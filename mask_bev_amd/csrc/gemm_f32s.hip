@@ -401,14 +401,25 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
       *reinterpret_cast<float4*>(p.c + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
   }
-  if (p.amax_out) {                                 // one max-combine per wave, skipped when the slot already holds more
+  if (p.amax_out) {
+    // ONE fire-and-forget max-combine per workgroup (the waves' maxima meet in LDS).  A read of the slot in front of the
+    // atomic ("skip when it already holds more") made every wave wait for its own stores to be acknowledged — up to + 29 us
+    // per launch (65 536 x 768 -> 192); a no-return atomic costs the workgroup nothing and <= 3 072 of them per launch
+    // trickle in as the workgroups finish.
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
       const unsigned o2 = (unsigned)__shfl_xor((int)out_max, sft, 64);
       out_max = out_max > o2 ? out_max : o2;
     }
-    unsigned* slot = p.amax_out + (bid & (kAmaxSlots - 1));
-    if (lane == 0 && out_max > __builtin_nontemporal_load(slot)) atomicMax(slot, out_max);
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    __syncthreads();                                // the staging tiles above are done with
+    if (lane == 0) red[wave] = out_max;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+      const unsigned m = m01 > m23 ? m01 : m23;
+      if (m) atomicMax(p.amax_out + (bid & (kAmaxSlots - 1)), m);
+    }
   }
 }
 

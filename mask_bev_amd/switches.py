@@ -41,11 +41,9 @@ _DEFAULTS: Dict[str, Any] = {
     'tn_max_in': 1536,            # widest input of a Linear whose weight gradient K17 takes
     'k17_fused_min': 4096,        # fewest tokens of an FFN that takes the fused K17 pair
     'gemm32s': True,              # fp32 compute: token-major Linears on K20 (f32 products from IEEE-half pairs on the 16-bit MFMA)
-    # K20's operand scales from absmax records / bounds a producing K20 product leaves, instead of a pass over the tensor.
-    # OFF: measured slower in the fp32 step (87.4 against 92.0 scans/s on one box) — the pass over x right in front of the GEMM
-    # is also what brings x into the memory-side cache, and K20 (one K-step of loads in flight) runs its NT / NN launches at
-    # 53 us behind it against 74 us cold; the 1.1 ms of passes saved cost 1.7 ms of GEMM time
-    'amax_hints': False,
+    # K20's operand scales from absmax records / bounds a producing K20 product leaves (its epilogue max-combines what it stores:
+    # one no-return atomic per workgroup), instead of a pass over the tensor: 92.6 / 92.9 -> 93.6 / 95.1 scans/s (fp32, one box)
+    'amax_hints': True,
     'tn32_group': True,           # fp32 compute: the few-row weight gradients of a backward pass as one grouped K20 launch
     'gemm32s_min': 1024,          # fewest tokens of an f32 Linear that takes K20 (below: the library's f32 GEMM; measured: scratch/bench_gemm32s.py)
     'k7_f32_library': True,       # fp32 mask logits through the library's batched GEMM instead of K7's exact-f32 kernel
