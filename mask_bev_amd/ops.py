@@ -172,14 +172,16 @@ def voxelize(point_clouds: Sequence[torch.Tensor], geom: VoxelGeometry, max_poin
                                                  and (p.shape[0] * dim * 4) % 16 == 0 for p in point_clouds)):
         # the scans of a batch behind one another in ONE grouped-copy launch (ATen's batched cat: 70 us for 4 x 120 k points)
         points = torch.empty((n, dim), dtype=torch.float32, device=dev)
-        k = len(point_clouds)
-        nb = [l * dim * 4 for l in lens]
-        dst, off = [], 0
-        for b_ in nb:
-            dst.append(points.data_ptr() + off)
-            off += b_
-        check(lib.mbv_copy_group((ctypes.c_void_p * k)(*[p.data_ptr() for p in point_clouds]), (ctypes.c_void_p * k)(*dst),
-                                 (ctypes.c_int64 * k)(*nb), k, _stream()), 'mbv_copy_group')
+        src, dst, nb, off = [], [], [], 0
+        for p, l in zip(point_clouds, lens):
+            if l > 0:                                   # (an empty scan has nothing to copy — and no address to copy from)
+                src.append(p.data_ptr())
+                dst.append(points.data_ptr() + off)
+                nb.append(l * dim * 4)
+            off += l * dim * 4
+        k = len(src)
+        check(lib.mbv_copy_group((ctypes.c_void_p * k)(*src), (ctypes.c_void_p * k)(*dst), (ctypes.c_int64 * k)(*nb), k,
+                                 _stream()), 'mbv_copy_group')
     else:
         points = torch.cat([p.reshape(-1, dim) for p in point_clouds], 0).to(torch.float32).contiguous()
     batch = len(point_clouds)
