@@ -986,6 +986,16 @@ int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* co
                          const int64_t* k, const int64_t* ldg, const int64_t* ldx, const uint32_t* const* amax_g,
                          const uint32_t* const* amax_x, int32_t count, void* stream);
 
+/* The fp32 FFN's backward in one K20 launch: out (m, k) = act'(pre (m, k)) * (g (m, n) . w (n, k)) — the data gradient of the
+ * output layer times the activation's derivative (act: 1 ReLU, 2 erf-GELU) — and, into `parts`
+ * ((mbv_gemm32s_nn_part_rows(m, 1), k) f32, every element written), the partial column sums of `out`: their sum over the rows is
+ * the bias gradient of the input layer.  Replaces the f32 library GEMM + mbv_act_bwd_colsum pass of mmcv FFN's backward
+ * (/root/reference: mask_bev/models/networks/swin/swin.py:347-355). */
+int64_t mbv_gemm32s_nn_part_rows(int64_t m, int32_t batch);
+int mbv_gemm32s_nn_act(const float* g, const float* w, float* out, const float* pre, float* parts, size_t parts_bytes,
+                       int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo, int64_t ldpre,
+                       const uint32_t* amax_g, const uint32_t* amax_w, uint32_t* amax_out, int32_t act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 
 class MaskBevHipError(RuntimeError):
@@ -151,6 +151,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gemm32s_nt': (ctypes.c_int, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _P, _P, _I, _I, _L, _L, _L, _P]),
     'mbv_gemm32s_nn': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _L, _P, _P, _P, _I, _L, _L, _L, _P]),
     'mbv_gemm32s_tn_workspace_bytes': (c_size_t, [_L, _L, _L]),
+    'mbv_gemm32s_nn_part_rows': (ctypes.c_int64, [_L, _I]),
+    'mbv_gemm32s_nn_act': (ctypes.c_int, [_P, _P, _P, _P, _P, c_size_t, _L, _L, _L, _L, _L, _L, _L, _P, _P, _P, _I, _P]),
     'mbv_gemm32s_tn_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_patch_embed32_supported': (ctypes.c_int, [_L, _L, _L, _L, _L]),
     'mbv_patch_embed32_fwd': (ctypes.c_int, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P]),

@@ -41,7 +41,7 @@ constexpr int STAGE32 = 4 * IMG32;                // A hi, A lo, B hi, B lo
 constexpr int LDS32 = 2 * STAGE32;                // two stages: 64 KB -> two workgroups per CU
 constexpr int NLD = 4;                            // 16-byte loads per thread and operand tile (128 x 32 f32 / 256 threads)
 
-enum { EPI32_NONE = 0, EPI32_RELU = 1, EPI32_GELU = 2 };
+enum { EPI32_NONE = 0, EPI32_RELU = 1, EPI32_GELU = 2, EPI32_DRELU = 3, EPI32_DGELU = 4 };
 
 struct Gemm32Args {
   const float* a;
@@ -52,6 +52,10 @@ struct Gemm32Args {
   const unsigned* amax_a;   // kAmaxSlots device words whose maximum is the bits of (a bound of) max|a| (NULL: scale 1)
   const unsigned* amax_b;
   unsigned* amax_out;       // optional: the bits of max|stored c| are max-combined into these kAmaxSlots words
+  const float* aux;         // EPI32_DRELU / EPI32_DGELU: the saved pre-activation (gm, gn) f32, row stride ldx
+  float* colsum_rows;       // EPI32_D*: (2 ntm, gn) f32 — the column sums of the stored values per 64-row wave row (the bias
+                            // gradient of the layer in front, reduced by the caller: no atomics)
+  int ldx;
   int gm, gn, gk;
   int lda, ldb, ldc;
   long long sa, sb, sc;     // batch strides (elements)
@@ -331,9 +335,9 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
   const float inv = inv_a * inv_b;                  // each factor is a normal power of two; the product may be subnormal
   const bool two_step = !(inv >= 1.1754944e-38f);   // then scale in two exact steps
   unsigned out_max = 0u;                            // bits of the largest magnitude this thread stores (amax_out)
-  float bias8[8];
+  float bias8[8], csum[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; csum[e] = 0.f; }
   if (p.bias && col_ok) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
     const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
@@ -370,7 +374,22 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
         continue;
       }
       const size_t o = cbase + (size_t)gm * p.ldc + gn;
-      if (EPI != EPI32_NONE) {
+      if (EPI == EPI32_DRELU || EPI == EPI32_DGELU) {     // d(pre-activation) = product * act'(pre), and its column sums
+        const float* ax = p.aux + cbase + (size_t)gm * p.ldx + gn;
+        const float4 z0 = *reinterpret_cast<const float4*>(ax), z1 = *reinterpret_cast<const float4*>(ax + 4);
+        const float z[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (EPI == EPI32_DRELU) {
+            v[e] = z[e] > 0.f ? v[e] : 0.f;
+          } else {
+            float dens;
+            const float cdf = gelu_cdf_parts(z[e], dens);
+            v[e] *= cdf + z[e] * dens;
+          }
+          csum[e] += v[e];
+        }
+      } else if (EPI != EPI32_NONE) {
         if (p.c2) {
           *reinterpret_cast<float4*>(p.c2 + o) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(p.c2 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -399,6 +418,22 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
       }
       *reinterpret_cast<float4*>(p.c + o) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(p.c + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+  if ((EPI == EPI32_DRELU || EPI == EPI32_DGELU) && p.colsum_rows) {
+    // one partial row per (tile_m, wave row): the lanes that own a column group meet by shuffles (lane = 8 prow + cg)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sm = csum[e];
+      sm += __shfl_xor(sm, 8, 64);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      csum[e] = sm;
+    }
+    if (prow == 0 && col_ok) {
+      float* d = p.colsum_rows + ((size_t)bz * 2 * p.ntm + 2 * tile_m + wm) * (size_t)p.gn + gn;
+      *reinterpret_cast<float4*>(d) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
     }
   }
   if (p.amax_out) {
@@ -561,6 +596,11 @@ static int gemm32s_launch(int epi, const Gemm32Args& a, int batch, hipStream_t s
   if constexpr (G == 0 && !AKS && !BKS) {          // the activation epilogues exist for the forward form only
     if (epi == EPI32_RELU) MBV_G32_LAUNCH(EPI32_RELU);
     else if (epi == EPI32_GELU) MBV_G32_LAUNCH(EPI32_GELU);
+    else MBV_G32_LAUNCH(EPI32_NONE);
+  } else if constexpr (G == 0 && !AKS && BKS) {    // the data-gradient form: optionally times the activation's derivative
+    if (epi == EPI32_DRELU) MBV_G32_LAUNCH(EPI32_DRELU);
+    else if (epi == EPI32_DGELU) MBV_G32_LAUNCH(EPI32_DGELU);
+    else if (epi != EPI32_NONE) return MBV_ERR_UNSUPPORTED;
     else MBV_G32_LAUNCH(EPI32_NONE);
   } else {
     if (epi != EPI32_NONE) return MBV_ERR_UNSUPPORTED;
@@ -855,4 +895,37 @@ extern "C" int mbv_gemm32s_tn_group(const float* const* g, const float* const* x
     MBV_CHECK_LAUNCH();
   }
   return MBV_OK;
+}
+
+// Partial column-sum rows an mbv_gemm32s_nn_act of this shape leaves: one per 64 output rows of a 128-row tile.
+extern "C" int64_t mbv_gemm32s_nn_part_rows(int64_t m, int32_t batch) {
+  if (m <= 0 || batch <= 0) return 0;
+  return 2 * ((m + 127) / 128) * batch;
+}
+
+// out (m, k) f32 = act'(pre (m, k)) * (g (m, n) . w (n, k));  parts (mbv_gemm32s_nn_part_rows(m, 1), k) f32 (every element
+// written): partial column sums of out — their sum over the rows is the bias gradient of the layer that produced `pre`.
+// act: 1 ReLU, 2 GELU (erf).  The fp32 FFN's backward: the data gradient of fc2 times the activation's derivative in one launch.
+extern "C" int mbv_gemm32s_nn_act(const float* g, const float* w, float* out, const float* pre, float* parts,
+                                  size_t parts_bytes, int64_t m, int64_t n, int64_t k, int64_t ldg, int64_t ldw, int64_t ldo,
+                                  int64_t ldpre, const uint32_t* amax_g, const uint32_t* amax_w, uint32_t* amax_out,
+                                  int32_t act, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0 || !g || !w || !out || !pre) return MBV_ERR_BAD_ARG;
+  if (act < 1 || act > 2) return MBV_ERR_BAD_ARG;
+  if ((n & 7) || (k & 7) || (ldg & 3) || (ldw & 3) || (ldo & 3) || (ldpre & 3) || ldg < n || ldw < k || ldo < k || ldpre < k)
+    return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(out) |
+       reinterpret_cast<size_t>(pre) | reinterpret_cast<size_t>(parts)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  if (!fits32(m, ldg) || !fits32(n, ldw) || !fits32(m, ldpre)) return MBV_ERR_UNSUPPORTED;
+  if (parts && parts_bytes < (size_t)mbv_gemm32s_nn_part_rows(m, 1) * (size_t)k * 4) return MBV_ERR_WORKSPACE;
+  if (m == 0) return MBV_OK;
+  Gemm32Args a = {};
+  a.a = g; a.b = w; a.c = out; a.amax_a = amax_g; a.amax_b = amax_w; a.amax_out = amax_out;
+  a.aux = pre; a.ldx = (int)ldpre; a.colsum_rows = parts;
+  a.gm = (int)m; a.gn = (int)k; a.gk = (int)n;
+  a.lda = (int)ldg; a.ldb = (int)ldw; a.ldc = (int)ldo;
+  a.a_bytes = (unsigned)(((m - 1) * ldg + n) * 4); a.b_bytes = (unsigned)(((n - 1) * ldw + k) * 4);
+  a.ntm = (int)((m + 127) / 128); a.ntn = (int)((k + 127) / 128); a.splits = 1; a.ksteps = (int)((n + KB32 - 1) / KB32);
+  return gemm32s_launch<false, true>(act == 1 ? EPI32_DRELU : EPI32_DGELU, a, 1, (hipStream_t)stream);
 }

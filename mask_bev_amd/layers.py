@@ -93,6 +93,11 @@ class FFN(nn.Module):
             y = ops.ffn(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, kind,
                         defer_out_bias=defer_out_bias and not add_identity)
             return y if not add_identity else (x if identity is None else identity) + y
+        if ops.ffn32_ok(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+            # fp32 compute, K20: the same two fusions on f32 products formed from IEEE-half pairs
+            y = ops.ffn32(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, kind,
+                          defer_out_bias=defer_out_bias and not add_identity)
+            return y if not add_identity else (x if identity is None else identity) + y
         if not add_identity:
             return self.layers[1](self._hidden(x), skip_bias_grad=defer_out_bias)
         return (x if identity is None else identity) + self.layers[1](self._hidden(x))

@@ -2069,6 +2069,99 @@ class _FFN(torch.autograd.Function):
         return gx, None, None, None, None, None, None
 
 
+class _FFN32(torch.autograd.Function):
+    """``fc2(act(fc1(x)))`` of an mmcv FFN in fp32 compute on K20 (csrc/gemm_f32s.hip): forward, fc1 + bias + activation in one
+    launch (stores the activation and the pre-activation, leaves the activation's absmax record for fc2); backward, the data
+    gradient of fc2 times the activation's derivative with the partial column sums of the result (= d bias of fc1) in one
+    launch — no activation kernels, no pass over the hidden gradient — then the two weight gradients and fc1's data gradient.
+    /root/reference: mask_bev/models/networks/swin/swin.py:347-355."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, kind, defer_out_bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        hx = amax_hint_get(x2) if switches.get('amax_hints') else None
+        if hx is None:
+            both = f32_absmax([x2, w1])
+            ax, aw1 = both[0:1], both[1:2]
+        else:
+            ax, aw1 = hx, weight_amax(w1)
+        a, h = gemm32s_nt(x2, w1, b1, act=kind, amax=(ax, aw1), want_pre=True, hint_out=True)
+        aa = amax_hint_get(a)
+        aw2 = weight_amax(w2)
+        out = gemm32s_nt(a, w2, b2, amax=(aa, aw2), hint_out=bool(switches.get('amax_hints')))
+        ctx.save_for_backward(x2, h, a)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.amax = (ax, aw1, aa, aw2)
+        ctx.kind, ctx.defer_out_bias, ctx.xshape = kind, defer_out_bias, x.shape
+        y = out.view(x.shape[:-1] + (w2.shape[0],))
+        amax_hint_set(y, amax_hint_get(out))
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        x2, h, a = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        ax, aw1, aa, aw2 = ctx.amax
+        g2 = gout.reshape(-1, gout.shape[-1])
+        if g2.dtype != torch.float32:
+            g2 = g2.float()
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        ag = amax_hint_get(g2) if switches.get('amax_hints') else None
+        if ag is None:
+            ag = f32_absmax([g2])
+        t, f = h.shape
+        # d hidden = (g . W2) * act'(pre), its partial column sums -> d b1, its absmax record for the products below
+        dh = torch.empty_like(h)
+        rows = lib.mbv_gemm32s_nn_part_rows(t, 1)
+        parts = torch.empty((rows, f), dtype=torch.float32, device=h.device)
+        adh = amax_record(h.device)
+        check(lib.mbv_gemm32s_nn_act(_ptr(g2), _ptr(w2), _ptr(dh), _ptr(h), _ptr(parts), parts.numel() * 4, t, w2.shape[0], f,
+                                     g2.stride(0), w2.stride(0), f, f, _ptr(ag), _ptr(aw2), _ptr(adh), _ACT[ctx.kind],
+                                     _stream()), 'mbv_gemm32s_nn_act')
+        if not _defer_colsum(parts, b1.grad, rows, f, f):
+            _colsum_now(parts, b1.grad, rows, f, f)
+        _fire_grad_hooks(b1)
+        _wgrad_into(w2.grad, g2, a, persistent=True, amax=(ag, aa))
+        _fire_grad_hooks(w2)
+        if not ctx.defer_out_bias:
+            colsum_accum(g2, b2.grad, persistent=True)
+            _fire_grad_hooks(b2)
+        _wgrad_into(w1.grad, dh, x2, persistent=True, amax=(adh, ax))
+        _fire_grad_hooks(w1)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx2 = gemm32s_nn(dh, w1, adh, aw1, hint_out=bool(switches.get('amax_hints')))
+            gx = _hinted_view(gx2, ctx.xshape)
+        return gx, None, None, None, None, None, None
+
+
+def ffn32_ok(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b) -> bool:
+    """The K20 FFN applies: fp32 compute (no autocast) on the device, arena-resident f32 parameters with f32 gradients, a token
+    count K20 takes, shapes in 8-element chunks."""
+    if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and torch.is_grad_enabled()
+            and switches.get('gemm32s') and switches.get('ffn32')):
+        return False
+    rows = x.numel() // max(1, x.shape[-1])
+    if not gemm32s_wants(rows) or x.shape[-1] % 8:
+        return False
+    for p in (fc1_w, fc1_b, fc2_w, fc2_b):
+        if (p is None or p.dtype != torch.float32 or not getattr(p, '_mbv_arena', False) or p.grad is None
+                or p.grad.dtype != torch.float32 or not p.is_contiguous() or p.data_ptr() % 16
+                or not p.grad.is_contiguous()):
+            return False
+    return fc1_w.shape[0] % 8 == 0 and fc1_w.shape[1] % 8 == 0 and fc2_w.shape[0] % 8 == 0
+
+
+def ffn32(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b, kind: str, defer_out_bias: bool = False) -> torch.Tensor:
+    y = _FFN32.apply(x, fc1_w, fc1_b, fc2_w, fc2_b, kind, defer_out_bias)
+    amax_hint_refresh(y)
+    return y
+
+
 def ffn_fused_ok(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b) -> bool:
     """The fused FFN (K17 epilogues) applies: 16-bit autocast on a ROCm device, arena-resident parameters with f32
     gradients, token count in K17's range, 16-byte-chunk shapes."""

@@ -307,3 +307,31 @@ def test_grouped_few_row_weight_gradients():
     again = [(g, x, s0) for (g, x, _), s0 in zip(items, starts)]
     ops.gemm32s_tn_group(again)
     assert all(torch.equal(a, b) for (_, _, a), (_, _, b) in zip(items, again))
+
+
+@gpu
+@pytest.mark.parametrize('kind', ['gelu', 'relu'])
+@pytest.mark.parametrize('rows,c,f', [(4096, 192, 768), (2100, 256, 1024)])
+def test_fp32_ffn_on_k20_matches_float64(kind, rows, c, f):
+    """ops.ffn32 (K20: fc1 + bias + activation in one launch; dgrad(fc2) x act' + the partial column sums of d b1 in one) against
+    the float64 FFN: output, input gradient, the four parameter gradients (accumulated into the arena in place)."""
+    from mask_bev_amd import ops
+    from mask_bev_amd.arena import ParameterArena
+    torch.manual_seed(rows + f)
+    fc1, fc2 = torch.nn.Linear(c, f).to(_dev()), torch.nn.Linear(f, c).to(_dev())
+    ParameterArena([('ffn', torch.nn.ModuleList([fc1, fc2]))], shadow_dtype=None)
+    x = _rand((rows, c), 5).requires_grad_()
+    gy = _rand((rows, c), 6, 1e-3)
+    assert ops.ffn32_ok(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    y = ops.ffn32(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, kind)
+    y.backward(gy)
+    ops.flush_deferred_grads()
+    act = torch.nn.functional.gelu if kind == 'gelu' else torch.relu
+    xd = x.detach().double().requires_grad_()
+    ps = [p.detach().double().requires_grad_() for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    ref = torch.nn.functional.linear(act(torch.nn.functional.linear(xd, ps[0], ps[1])), ps[2], ps[3])
+    ref.backward(gy.double())
+    assert _err(y.detach(), ref.detach()) <= 4e-6
+    assert _err(x.grad, xd.grad) <= (4e-6 if kind == 'gelu' else 2e-5)      # (ReLU: an input within rounding of the kink flips its gate)
+    for p, r in zip((fc1.weight, fc1.bias, fc2.weight, fc2.bias), ps):
+        assert _err(p.grad, r.grad) <= (6e-6 if kind == 'gelu' else 3e-5), float(_err(p.grad, r.grad))
