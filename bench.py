@@ -21,7 +21,7 @@ Extra objects on the line:
                 instrumented family of both dtypes (`roofline_all`) goes to `--detail-out` (gpurun_out/bench_detail.json).
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample:
                 1 warm-up + 3 iterations, forward and forward+backward, at 6 threads (the reference's setting).
-  fp32          the same step in fp32 — the precision the reference trains in — timed the same way (20 steps).
+  fp32          the same step in fp32 — the precision the reference trains in — timed the same way (50 steps).
 """
 from __future__ import annotations
 
@@ -552,7 +552,7 @@ def main():
     fp32_line = None
     if world == 1 and args.dtype != 'fp32' and not args.no_fp32 and not args.no_graph and not args.no_arena:
         try:
-            fp32_line = time_other_dtype(args, 'fp32', device, pool, min(args.steps, 20), min(args.warmup, 3))
+            fp32_line = time_other_dtype(args, 'fp32', device, pool, min(args.steps, 50), min(args.warmup, 5))
         except Exception as e:      # the secondary figure must never take the headline number down with it
             fp32_line = dict(value=None, error=f'{type(e).__name__}: {e}')
     replica_spread = None
