@@ -376,6 +376,10 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                  * max(1, _i(a[15])), 2.0 * _i(a[5]) * _i(a[6]) * _i(a[7]) * max(1, _i(a[15]))),
     'mbv_gemm32s_nn': lambda a: ('k_gemm32s<NN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[4]) * _i(a[5]) + _i(a[3]) * _i(a[5])) * 4.0
                                  * max(1, _i(a[12])), 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5]) * max(1, _i(a[12]))),
+    # the same product with the activation's derivative in the epilogue: one more read of the output-shaped pre-activation
+    'mbv_gemm32s_nn_act': lambda a: ('k_gemm32s<NN,dact>', 'mfma',
+                                     (_i(a[6]) * _i(a[7]) + _i(a[7]) * _i(a[8]) + 2 * _i(a[6]) * _i(a[8])) * 4.0,
+                                     2.0 * _i(a[6]) * _i(a[7]) * _i(a[8])),
     'mbv_gemm32s_tn_acc': lambda a: ('k_gemm32s<TN>', 'mfma', (_i(a[3]) * _i(a[4]) + _i(a[3]) * _i(a[5])) * 4.0
                                      + _i(a[4]) * _i(a[5]) * 4.0 * 2, 2.0 * _i(a[3]) * _i(a[4]) * _i(a[5])),
     # the patch projection on K20's gather modes: (image, weight, bias, out, batch, C, h, w, E, ...): tokens x E x 16 C

@@ -17,6 +17,16 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_gn_bwd', r'k_gn_bwd_dx', [r'k_gn_bwd_sums']),
     ('k_gemm16<NN>', r'k_gemm16I.*Lb0ELb1ELi0E', [r'k_sum_rows']),
     ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0E', []),
+    # K20 (fp32 runs): template arguments <A_KS, B_KS, EPI, GATHER>
+    ('k_gemm32s<NT>', r'k_gemm32sILb0ELb0ELi[012]ELi0E', []),
+    ('k_gemm32s<NT,patch>', r'k_gemm32sILb0ELb0ELi0ELi1E', []),
+    ('k_gemm32s<NN>', r'k_gemm32sILb0ELb1ELi0ELi0E', []),
+    ('k_gemm32s<NN,dact>', r'k_gemm32sILb0ELb1ELi[34]ELi0E', []),
+    ('k_gemm32s<NN,patch>', r'k_gemm32sILb0ELb1ELi0ELi2E', []),
+    ('k_gemm32s<TN>', r'k_gemm32sILb1ELb1ELi0ELi0E', [r'k_add_parts32']),
+    ('k_gemm32s<TN,patch>', r'k_gemm32sILb1ELb1ELi0ELi3E', []),
+    ('k_gemm32s_tn_group', r'k_gemm32s_tn_group', []),
+    ('k_absmax_group', r'k_absmax_group', []),
     ('k_adamw', r'k_adamw', []),
     ('k_sample_select', r'k_sample_select', []),
     ('k_window_attn_bwd', r'k_window_attn_bwd', []),
@@ -74,7 +84,7 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
 # End-of-backward group launches: the graph step flushes them once per captured graph (two calls per step), the eager
 # step bench.py instruments once per step — their traffic is recorded PER STEP (listed under "_per_step") and bench.py
 # divides by the calls per step it measured.
-PER_STEP = ['k_gemm16_tn_group', 'k_wgrad_small_group', 'k_colsum_group']
+PER_STEP = ['k_gemm16_tn_group', 'k_gemm32s_tn_group', 'k_wgrad_small_group', 'k_colsum_group']
 
 
 def load(path, counter):
