@@ -976,15 +976,20 @@ int mbv_patch_embed32_bwd_weight(const float* d_out, const float* image, float* 
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 
-/* The weight gradients of `count` few-row f32 Linears (m[i] <= 8192 tokens: the decoder's 400 query rows) in ONE K20 launch per
- * 48 of them:  dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i]).  A 256 x 256 ... 2048 x 256
- * output alone is 4 ... 32 tiles; the tiles of all layers together fill the chip once.  Each tile is added to dw in place by its
- * owner workgroup (no parts, no atomics, bit-reproducible).  amax_g[i] / amax_x[i]: absmax records of the operands (NULL
- * array or entry = unscaled).  Replaces, in fp32 compute, the exact-f32 MFMA form (mbv_wgrad_small_f32_group: 1.8 ms per step at
- * the f32 matrix rate and an atomic per element) for shapes with n, k multiples of 8.  HOST arrays of length count. */
+/* The weight gradients of `count` f32 Linears in ONE K20 launch (+ one parts-add launch) per 48 of them:
+ * dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i]);  the dw[i] of one call must not overlap.
+ * A weight gradient is nobody's input: the Linears of a backward pass hand theirs over and the pass issues them together at its
+ * end (fp32 compute; the 16-bit modes' mbv_gemm16_tn_group).  Few-row products (the decoder's 400 query rows: a 256 x 256 ...
+ * 2048 x 256 output is 4 ... 32 tiles) fill the chip together; token-major ones (1 024 - 65 536 tokens) are cut into ranges of
+ * ~ 4 096 tokens instead of the ~ 40 slivers each needs alone.  One range: the tile is added to dw in place by its owner
+ * workgroup; several: partial tiles go to `workspace` (mbv_gemm32s_tn_group_workspace_bytes; 16-byte aligned) and are added by
+ * their owner — no atomics, bit-reproducible.  amax_g[i] / amax_x[i]: absmax records of the operands (NULL array or entry =
+ * unscaled).  Replaces, in fp32 compute, mbv_wgrad_small_f32_group (exact-f32 MFMA + atomics) for shapes with n, k multiples
+ * of 8, and the per-layer mbv_gemm32s_tn_acc launches.  HOST arrays of length count. */
+size_t mbv_gemm32s_tn_group_workspace_bytes(const int64_t* m, const int64_t* n, const int64_t* k, int32_t count);
 int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* const* dw, const int64_t* m, const int64_t* n,
                          const int64_t* k, const int64_t* ldg, const int64_t* ldx, const uint32_t* const* amax_g,
-                         const uint32_t* const* amax_x, int32_t count, void* stream);
+                         const uint32_t* const* amax_x, int32_t count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The fp32 FFN's backward in one K20 launch: out (m, k) = act'(pre (m, k)) * (g (m, n) . w (n, k)) — the data gradient of the
  * output layer times the activation's derivative (act: 1 ReLU, 2 erf-GELU) — and, into `parts`

@@ -465,15 +465,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s(const Gemm32Args p) {
 }
 
 // ---- grouped weight gradients: up to kTn32Group products dw_i (n_i, k_i) += g_i (m_i, n_i)^T x_i (m_i, k_i) in ONE launch ------
-// The fp32 step's few-row Linears (the decoder's 400 query rows x 9 layers, /root/reference: mask_bev/models/networks/
-// mask2former_head/mask2former_head.py:535-560) each give a handful of 128 x 128 tiles: alone they cannot fill the chip,
-// together (collected during the backward pass, issued at its end like K17's group) they are one launch.  Every entry is ONE
-// token range (m_i <= 8192): its owner workgroup adds the tile to dw in place — no parts, no atomics.
+// A weight gradient is nobody's input, so the fp32 step's Linears hand theirs over during the backward pass and the pass
+// issues them together at its end (as K17's group does for the 16-bit modes): the few-row ones (the decoder's 400 query rows
+// x 9 layers, /root/reference: mask_bev/models/networks/mask2former_head/mask2former_head.py:535-560) are a handful of
+// 128 x 128 tiles each, the token-major ones (Swin / pixel decoder: 1 024 - 65 536 tokens) alone fill the chip only by cutting
+// their token sum into ~ 40 slivers with a round trip of partial tiles each.  Work item = (entry, token range, tile); every
+// entry is cut into ranges of about kTn32Depth tokens, so the items are about equally long.  One range: the owner adds its
+// tile to dw in place; several: partial tiles go to the workspace and k_add_parts32_group folds them into dw (no atomics).
 constexpr int kTn32Group = 48;
+constexpr int kTn32Depth = 4096;
 struct Tn32Entry {
-  const float* g; const float* x; float* dw;
+  const float* g; const float* x; float* out;     // out: dw (splits == 1) or this entry's parts in the workspace
   const unsigned* amax_g; const unsigned* amax_x;
-  int m, n, k, ldg, ldx, ntn, item_begin;
+  int m, n, k, ldg, ldx, ntn, splits, ksteps, item_begin;
 };
 struct Tn32GroupArgs {
   Tn32Entry e[kTn32Group];
@@ -487,15 +491,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm32s_tn_group(const Tn32GroupArgs
   while (i + 1 < a.n && item >= a.e[i + 1].item_begin) ++i;     // block-uniform: a scalar loop over <= 48 entries
   const Tn32Entry& e = a.e[i];
   Gemm32Args p;
-  p.a = e.g; p.b = e.x; p.c = e.dw; p.c2 = nullptr; p.bias = nullptr;
+  p.a = e.g; p.b = e.x; p.c = e.out; p.c2 = nullptr; p.bias = nullptr;
   p.amax_a = e.amax_g; p.amax_b = e.amax_x; p.amax_out = nullptr;
   p.gm = e.n; p.gn = e.k; p.gk = e.m;
   p.lda = e.ldg; p.ldb = e.ldx; p.ldc = e.k;
-  p.sa = 0; p.sb = 0; p.sc = 0; p.ssplit = 0;
+  p.sa = 0; p.sb = 0; p.sc = 0; p.ssplit = (long long)e.n * e.k;
   p.a_bytes = (unsigned)(((long long)(e.m - 1) * e.ldg + e.n) * 4);
   p.b_bytes = (unsigned)(((long long)(e.m - 1) * e.ldx + e.k) * 4);
-  p.ntm = (e.n + 127) / 128; p.ntn = e.ntn; p.splits = 1; p.ksteps = (e.m + KB32 - 1) / KB32;
-  p.acc_out = 1;
+  p.ntm = (e.n + 127) / 128; p.ntn = e.ntn; p.splits = e.splits; p.ksteps = e.ksteps;
+  p.acc_out = e.splits == 1;
   p.pc = 0; p.ph = 0; p.pw = 0;
   gemm32s_body<true, true, EPI32_NONE, 0>(p, item - e.item_begin, smem);
 }
@@ -518,6 +522,38 @@ __global__ void __launch_bounds__(256) k_add_parts32(const float* __restrict__ p
   float4 o = *reinterpret_cast<const float4*>(out + i);
   o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
   *reinterpret_cast<float4*>(out + i) = o;
+}
+
+constexpr int kParts32Group = 96;
+struct Parts32Entry {
+  const float* part; float* out;
+  long long n;                 // elements of out (a multiple of 4)
+  int parts, block_begin;
+};
+struct Parts32GroupArgs {
+  Parts32Entry e[kParts32Group];
+  int n;
+};
+
+// out_i (n_i) += sum of its parts (parts_i, n_i), for up to kParts32Group outputs; a thread owns 4 consecutive elements
+__global__ void __launch_bounds__(256) k_add_parts32_group(const Parts32GroupArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.e[i + 1].block_begin) ++i;
+  const Parts32Entry& e = a.e[i];
+  const long long j = ((long long)(blockIdx.x - e.block_begin) * 256 + threadIdx.x) * 4;
+  if (j >= e.n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < e.parts; p += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = p + u < e.parts ? *reinterpret_cast<const float4*>(e.part + (long long)(p + u) * e.n + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  float4 o = *reinterpret_cast<const float4*>(e.out + j);
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *reinterpret_cast<float4*>(e.out + j) = o;
 }
 
 // ---- max|x| of f32 tensors as the BITS of the maximum (non-negative floats order like integers) -------------------------
@@ -850,49 +886,86 @@ extern "C" int mbv_patch_embed32_bwd_weight(const float* d_out, const float* ima
   return MBV_OK;
 }
 
-// dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])  for i < count in one launch per 48 products;
-// every entry is one token range (m[i] <= 8192: the few-row Linears), its tiles are added to dw in place by their owner
-// workgroups.  amax_g[i] / amax_x[i]: absmax records (NULL entries = unscaled).  Array arguments are HOST arrays of length count.
+static void tn32_group_split(int64_t m, int& splits, int& ksteps) {
+  const int total_steps = (int)((m + KB32 - 1) / KB32);
+  int s = (int)((m + kTn32Depth - 1) / kTn32Depth);
+  if (s < 1) s = 1;
+  ksteps = (total_steps + s - 1) / s;
+  splits = (total_steps + ksteps - 1) / ksteps;
+}
+
+extern "C" size_t mbv_gemm32s_tn_group_workspace_bytes(const int64_t* m, const int64_t* n, const int64_t* k, int32_t count) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (m[i] <= 0 || n[i] <= 0 || k[i] <= 0) continue;
+    int splits, ksteps;
+    tn32_group_split(m[i], splits, ksteps);
+    if (splits > 1) total += (size_t)splits * (size_t)n[i] * (size_t)k[i] * 4;
+  }
+  return total;
+}
+
+// dw[i] (n[i], k[i]) f32, contiguous  +=  g[i] (m[i], n[i])^T . x[i] (m[i], k[i])  for i < count, in one launch (+ one parts-add
+// launch) per 48 products; the dw[i] of one call must not overlap.  amax_g[i] / amax_x[i]: absmax records (NULL entries =
+// unscaled).  Array arguments are HOST arrays of length count; workspace: mbv_gemm32s_tn_group_workspace_bytes, 16-byte aligned.
 extern "C" int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* const* dw, const int64_t* m,
                                     const int64_t* n, const int64_t* k, const int64_t* ldg, const int64_t* ldx,
                                     const uint32_t* const* amax_g, const uint32_t* const* amax_x, int32_t count,
-                                    void* stream) {
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (count < 0 || (count > 0 && (!g || !x || !dw || !m || !n || !k || !ldg || !ldx))) return MBV_ERR_BAD_ARG;
   for (int i = 0; i < count; ++i) {
     if (m[i] < 0) return MBV_ERR_BAD_ARG;
     if (m[i] == 0) continue;
-    if (m[i] > 8192 || n[i] <= 0 || k[i] <= 0 || !g[i] || !x[i] || !dw[i]) return MBV_ERR_BAD_ARG;
+    if (n[i] <= 0 || k[i] <= 0 || !g[i] || !x[i] || !dw[i]) return MBV_ERR_BAD_ARG;
     if ((n[i] & 7) || (k[i] & 7) || (ldg[i] & 3) || (ldx[i] & 3) || ldg[i] < n[i] || ldx[i] < k[i]) return MBV_ERR_UNSUPPORTED;
     if ((reinterpret_cast<size_t>(g[i]) | reinterpret_cast<size_t>(x[i]) | reinterpret_cast<size_t>(dw[i])) & 15)
       return MBV_ERR_UNSUPPORTED;
     if (!fits32(m[i], ldg[i]) || !fits32(m[i], ldx[i]) || n[i] * k[i] >= 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
   }
+  if (mbv_gemm32s_tn_group_workspace_bytes(m, n, k, count) > workspace_bytes) return MBV_ERR_WORKSPACE;
+  if (workspace_bytes && (!workspace || (reinterpret_cast<size_t>(workspace) & 15))) return MBV_ERR_WORKSPACE;
   static bool attr = false;
   if (!attr) {
     MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm32s_tn_group),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS32));
     attr = true;
   }
+  float* ws = reinterpret_cast<float*>(workspace);
   for (int base = 0; base < count; base += kTn32Group) {
     const int cnt = count - base < kTn32Group ? count - base : kTn32Group;
     Tn32GroupArgs a;
-    a.n = 0;
-    long long items = 0;
+    Parts32GroupArgs pa;
+    a.n = 0; pa.n = 0;
+    long long items = 0, pblocks = 0;
     for (int j = 0; j < cnt; ++j) {
       const int i = base + j;
       if (m[i] == 0) continue;
       Tn32Entry& e = a.e[a.n++];
-      e.g = g[i]; e.x = x[i]; e.dw = dw[i];
+      e.g = g[i]; e.x = x[i];
       e.amax_g = amax_g ? amax_g[i] : nullptr; e.amax_x = amax_x ? amax_x[i] : nullptr;
       e.m = (int)m[i]; e.n = (int)n[i]; e.k = (int)k[i]; e.ldg = (int)ldg[i]; e.ldx = (int)ldx[i];
       e.ntn = (int)((k[i] + 127) / 128);
+      tn32_group_split(m[i], e.splits, e.ksteps);
       e.item_begin = (int)items;
-      items += (long long)((n[i] + 127) / 128) * e.ntn;
+      items += (long long)((n[i] + 127) / 128) * e.ntn * e.splits;
+      if (e.splits == 1) {
+        e.out = dw[i];
+      } else {
+        e.out = ws;
+        Parts32Entry& q = pa.e[pa.n++];
+        q.part = ws; q.out = dw[i]; q.n = n[i] * k[i]; q.parts = e.splits; q.block_begin = (int)pblocks;
+        pblocks += (q.n / 4 + 255) / 256;
+        ws += (size_t)e.splits * (size_t)q.n;
+      }
     }
     if (a.n == 0) continue;
-    if (items > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
+    if (items > 0x7fffffffLL || pblocks > 0x7fffffffLL) return MBV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_gemm32s_tn_group, dim3((unsigned)items), dim3(256), LDS32, (hipStream_t)stream, a);
     MBV_CHECK_LAUNCH();
+    if (pa.n) {
+      hipLaunchKernelGGL(k_add_parts32_group, dim3((unsigned)pblocks), dim3(256), 0, (hipStream_t)stream, pa);
+      MBV_CHECK_LAUNCH();
+    }
   }
   return MBV_OK;
 }

@@ -1491,28 +1491,35 @@ def patch_embed32(image: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
 
 
 def gemm32s_tn_group(items) -> None:
-    """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` for every ``(g, x, acc)`` of ``items`` (f32, M <= 8192) in one K20 launch per
-    48, behind one absmax launch per 32 products (the records of all g and x)."""
+    """``acc (N, K) f32 += g (M, N)^T @ x (M, K)`` for every ``(g, x, acc[, amax_g, amax_x])`` of ``items`` (f32, pairwise
+    disjoint ``acc``) in one K20 launch (+ one parts-add launch) per 48; the operands that come without an absmax record get
+    theirs from one absmax launch per 64 of them."""
     if not items:
         return
     lib = _lib.load()
     n = len(items)
-    for g, x, acc in items:
-        if (not _gemm32s_ok(g, x) or g.shape[0] != x.shape[0] or g.shape[0] > 8192 or acc.dtype != torch.float32
+    items = [tuple(it) + (None, None) if len(it) == 3 else tuple(it) for it in items]
+    for g, x, acc, _, _ in items:
+        if (not _gemm32s_ok(g, x) or g.shape[0] != x.shape[0] or acc.dtype != torch.float32
                 or not acc.is_contiguous() or tuple(acc.shape) != (g.shape[1], x.shape[1]) or acc.data_ptr() % 16):
             raise MaskBevHipError('gemm32s_tn_group: unsupported operands')
-    recs = []
-    for i in range(0, n, 32):
-        chunk = items[i:i + 32]
-        recs.append(f32_absmax([t for g, x, _ in chunk for t in (g, x)]))
+    need = [(i, j) for i, it in enumerate(items) for j in (0, 1) if it[3 + j] is None]
+    recs = {}
+    for c in range(0, len(need), 64):
+        chunk = need[c:c + 64]
+        r = f32_absmax([items[i][j] for i, j in chunk])
+        for q, key in enumerate(chunk):
+            recs[key] = r[q:q + 1]
+    amax = [[it[3 + j] if it[3 + j] is not None else recs[(i, j)] for j in (0, 1)] for i, it in enumerate(items)]
     PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
-    ag = PA(*[recs[i // 32].data_ptr() + 4 * AMAX_SLOTS * (2 * (i % 32)) for i in range(n)])
-    ax = PA(*[recs[i // 32].data_ptr() + 4 * AMAX_SLOTS * (2 * (i % 32) + 1) for i in range(n)])
-    check(lib.mbv_gemm32s_tn_group(PA(*[g.data_ptr() for g, _, _ in items]), PA(*[x.data_ptr() for _, x, _ in items]),
-                                   PA(*[a.data_ptr() for _, _, a in items]), LA(*[g.shape[0] for g, _, _ in items]),
-                                   LA(*[g.shape[1] for g, _, _ in items]), LA(*[x.shape[1] for _, x, _ in items]),
-                                   LA(*[g.stride(0) for g, _, _ in items]), LA(*[x.stride(0) for _, x, _ in items]),
-                                   ag, ax, n, _stream()), 'mbv_gemm32s_tn_group')
+    m, nn, k = LA(*[it[0].shape[0] for it in items]), LA(*[it[0].shape[1] for it in items]), LA(*[it[1].shape[1] for it in items])
+    nbytes = lib.mbv_gemm32s_tn_group_workspace_bytes(m, nn, k, n)
+    ws = _workspace(nbytes, items[0][0].device) if nbytes else None
+    check(lib.mbv_gemm32s_tn_group(PA(*[it[0].data_ptr() for it in items]), PA(*[it[1].data_ptr() for it in items]),
+                                   PA(*[it[2].data_ptr() for it in items]), m, nn, k,
+                                   LA(*[it[0].stride(0) for it in items]), LA(*[it[1].stride(0) for it in items]),
+                                   PA(*[_amax_ptr(a[0], 0).value for a in amax]), PA(*[_amax_ptr(a[1], 0).value for a in amax]),
+                                   n, _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_group')
 
 
 def mm32_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1627,7 +1634,7 @@ def _pending_lists():
         if len(_PENDING) >= _PENDING_MAX:
             for old in sorted(_PENDING)[:len(_PENDING) - _PENDING_MAX + 1]:
                 del _PENDING[old]
-        lists = _PENDING[tid] = ([], [], [])
+        lists = _PENDING[tid] = ([], [], [], [])
     return lists
 
 
@@ -1657,6 +1664,18 @@ def _defer_tn_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor) -> bo
     if lists is None:
         return False
     lists[2].append((g2, x2, acc, torch.cuda.current_stream()))
+    return True
+
+
+def _defer_tn32_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor, amax) -> bool:
+    """fp32 compute: a token-major K20 weight gradient joins the pass's grouped launch (``switches.tn32_group``)."""
+    if not switches.get('tn32_group'):
+        return False
+    lists = _pending_lists()
+    if lists is None:
+        return False
+    lists[3].append((g2, x2, acc, None if amax is None else amax[0], None if amax is None else amax[1],
+                     torch.cuda.current_stream()))
     return True
 
 
@@ -1757,19 +1776,20 @@ def flush_deferred_grads(task_id: Optional[int] = None) -> None:
     if task_id is not None:          # passes nested INSIDE this one have ended: what they left (they raised) is dropped
         for t in [t for t in _PENDING if t > task_id]:
             del _PENDING[t]
-    wg, cs, tn = [], [], []
+    wg, cs, tn, tn32 = [], [], [], []
     for t in tids:
         lists = _PENDING.pop(t, None)
         if lists is not None:
             wg += lists[0]
             cs += lists[1]
             tn += lists[2]
-    if not wg and not cs and not tn:
+            tn32 += lists[3]
+    if not wg and not cs and not tn and not tn32:
         return
     lib = _lib.load()
     cur = torch.cuda.current_stream()
     wg_all = list(wg)
-    for st in {it[-1] for it in wg + cs + tn}:
+    for st in {it[-1] for it in wg + cs + tn + tn32}:
         if st != cur:
             cur.wait_stream(st)
     if tn and _TN_SINK is not None:
@@ -1789,10 +1809,14 @@ def flush_deferred_grads(task_id: Optional[int] = None) -> None:
         if k20:
             ids = {id(it) for it in k20}
             wg = [it for it in wg if id(it) not in ids]
-            gemm32s_tn_group([(it[0], it[1], it[2]) for it in k20])
+            tn32 = tn32 + [(it[0], it[1], it[2], None, None, it[-1]) for it in k20]
             for it in k20:
                 if it[3] is not None:
                     cs.append((it[0], it[3], it[0].shape[0], it[0].shape[1], it[0].stride(0), 0, it[-1]))
+    if tn32:
+        # deepest token sums first (their work items are the longest of a launch); a weight used twice meets itself in the next launch
+        for wave in _distinct_destination_waves(sorted(tn32, key=lambda it: -it[0].shape[0])):
+            gemm32s_tn_group([it[:5] for it in wave])
     if wg:
         n = len(wg)
         PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
@@ -1808,7 +1832,7 @@ def flush_deferred_grads(task_id: Optional[int] = None) -> None:
             PA(*[it[0].data_ptr() + it[5] * it[0].element_size() for it in cs]), IA(*[_dt_flag(it[0].dtype) for it in cs]),
             LA(*[it[2] for it in cs]), IA(*[it[3] for it in cs]), LA(*[it[4] for it in cs]),
             PA(*[it[1].data_ptr() for it in cs]), n, _stream()), 'mbv_colsum_accum_group')
-    for it in wg_all + tn:            # the producers' memory may be reused by later work on their own streams
+    for it in wg_all + tn + tn32:     # the producers' memory may be reused by later work on their own streams
         if it[-1] != cur:
             it[0].record_stream(cur)
             it[1].record_stream(cur)
@@ -1829,7 +1853,10 @@ def _wgrad_into(acc: torch.Tensor, g2: torch.Tensor, x2: torch.Tensor, bias_acc:
     t = g2.shape[0]
     if ((amax is not None or (g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.is_cuda and gemm32s_wants(t)))
             and acc.dtype == torch.float32 and acc.is_contiguous() and acc.data_ptr() % 16 == 0 and _gemm32s_ok(g2, x2)):
-        # fp32 compute: K20, token sum in parts, owner adds (the absmax words come from the layer's forward when it has them)
+        # fp32 compute: K20, token sum in parts, owner adds (the absmax words come from the layer's forward when it has them);
+        # an arena gradient joins the pass's grouped launch
+        if persistent and _defer_tn32_wgrad(g2, x2, acc, amax):
+            return False
         gemm32s_tn_acc(acc, g2, x2, None if amax is None else amax[0], None if amax is None else amax[1])
         return False
     if (g2.dtype in _GEMM16_DT and x2.dtype == g2.dtype and acc.stride(-1) == 1 and acc.data_ptr() % 16 == 0

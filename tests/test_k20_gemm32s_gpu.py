@@ -310,6 +310,37 @@ def test_grouped_few_row_weight_gradients():
 
 
 @gpu
+def test_grouped_token_major_weight_gradients():
+    """The same launch with token-major products (their token sums cut into ranges of ~ 4 096, partial tiles added by their
+    owner), few-row ones beside them, operands with and without their own absmax records, a ragged last range, strided rows:
+    float64, bit-reproducible, and equal to what the per-layer entry point gives up to the order of the range sums."""
+    from mask_bev_amd import ops
+    shapes = [(65536, 192, 192), (16384, 384, 1536), (20001, 264, 136), (4096, 768, 768), (400, 256, 256), (9000, 8, 2048),
+              (4097, 128, 128)]
+    items, refs = [], []
+    for i, (m, n, k) in enumerate(shapes):
+        gfull, x = _rand((m, n + 8), 400 + i, 10.0 ** (-(i % 4))), _rand((m, k), 500 + i)
+        g = gfull[:, 4:4 + n] if i % 2 else gfull[:, :n].contiguous()            # (odd entries: strided rows, 16-byte aligned)
+        acc = _rand((n, k), 600 + i, 0.1)
+        refs.append(acc.double() + g.double().t() @ x.double())
+        rec = ops.f32_absmax([g, x]) if i % 3 == 0 else None
+        items.append((g, x, acc) if rec is None else (g, x, acc, rec[0:1], rec[1:2]))
+    starts = [it[2].clone() for it in items]
+    ops.gemm32s_tn_group(items)
+    for it, ref, s0 in zip(items, refs, starts):
+        g, x, acc = it[:3]
+        e, lib_e = _err(acc, ref), _err(torch.addmm(s0, g.t(), x), ref)
+        assert e <= max(2e-6, 2 * lib_e), (tuple(g.shape), e, lib_e)
+    again = [(it[0], it[1], s0.clone()) + tuple(it[3:]) for it, s0 in zip(items, starts)]
+    ops.gemm32s_tn_group(again)
+    assert all(torch.equal(a[2], b[2]) for a, b in zip(items, again))
+    for it, s0, ref in zip(items[:3], starts, refs):
+        one = s0.clone()
+        ops.gemm32s_tn_acc(one, it[0], it[1])
+        assert _err(one, ref) <= 2e-6 and _err(one, it[2].double()) <= 2e-6
+
+
+@gpu
 @pytest.mark.parametrize('kind', ['gelu', 'relu'])
 @pytest.mark.parametrize('rows,c,f', [(4096, 192, 768), (2100, 256, 1024)])
 def test_fp32_ffn_on_k20_matches_float64(kind, rows, c, f):
