@@ -343,6 +343,24 @@ int mbv_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bia
                         void* grad_qkv, float* grad_table, float* grad_qkv_bias, int32_t full_bias_grad,
                         int32_t accumulate, void* stream);
 
+/* K4 on f32 tensors in the SPLIT mode (fp32 compute; same tensors, results and reference lines as mbv_window_attn_fwd / _bwd with
+ * is_bf16 = 0): every f32 operand element is split into an IEEE-half pair while its tile is staged (x 2^e = hi + lo: 22
+ * significant bits) and every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with f32 accumulation — K20's arithmetic
+ * (mbv_gemm32s_*) inside the attention — instead of v_mfma_f32_32x32x2_f32 at the f32 vector rate out of word-wise LDS images.
+ * amax_qkv / amax_grad_out: absmax records of the tensors (64 words each, mbv_f32_absmax_group or a producing kernel's epilogue;
+ * NULL = unscaled); amax_grad_qkv (optional): the record of what the backward stores, max-combined by one atomic per workgroup.
+ * Requires head dims 16 / 32 / 64, C % 4 == 0, 16-byte aligned tensors (mbv_window_attn_split_supported; else
+ * MBV_ERR_UNSUPPORTED and the caller keeps the exact-f32 form).  Accuracy: <= 2e-6 of the result's maximum (tests). */
+int mbv_window_attn_split_supported(int32_t C, int32_t heads, int32_t ws);
+int mbv_window_attn_split_fwd(const float* qkv, const float* qkv_bias, const float* bias_table, int32_t batch, int32_t H,
+                              int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift, const uint32_t* amax_qkv,
+                              float* out, float* lse, void* stream);
+int mbv_window_attn_split_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* out,
+                              const float* grad_out, const float* lse, int32_t batch, int32_t H, int32_t W, int32_t C,
+                              int32_t heads, int32_t ws, int32_t shift, const uint32_t* amax_qkv,
+                              const uint32_t* amax_grad_out, float* grad_qkv, float* grad_table, float* grad_qkv_bias,
+                              int32_t full_bias_grad, int32_t accumulate, uint32_t* amax_grad_qkv, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K8 — indexed bilinear point sampling of mask maps (loss and Hungarian targets).
  * Replaces: mmcv point_sample (= F.grid_sample, align_corners=False, zeros) at

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 
 class MaskBevHipError(RuntimeError):
@@ -155,6 +155,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gemm32s_nn_act': (ctypes.c_int, [_P, _P, _P, _P, _P, c_size_t, _L, _L, _L, _L, _L, _L, _L, _P, _P, _P, _I, _P]),
     'mbv_gemm32s_tn_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, c_size_t, _P]),
     'mbv_gemm32s_tn_group_workspace_bytes': (c_size_t, [_P, _P, _P, _I]),
+    'mbv_window_attn_split_supported': (ctypes.c_int, [_I, _I, _I]),
+    'mbv_window_attn_split_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'mbv_window_attn_split_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I,
+                                                 _P, _P]),
     'mbv_patch_embed32_supported': (ctypes.c_int, [_L, _L, _L, _L, _L]),
     'mbv_patch_embed32_fwd': (ctypes.c_int, [_P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P]),
     'mbv_patch_embed32_bwd_image': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P]),

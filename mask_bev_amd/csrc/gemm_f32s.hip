@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "gemm_tiles.hpp"
+#include "amax.hpp"
 
 namespace {
 
@@ -81,27 +82,6 @@ __device__ __forceinline__ unsigned patch_elem(const Gemm32Args& p, int token, i
   const int oy = rem / tw, ox = rem - oy * tw;
   const int c = kp >> 4, dy = (kp >> 2) & 3;
   return (unsigned)(((b * p.pc + c) * p.ph + 4 * oy + dy) * p.pw + 4 * ox + (kp & 3));
-}
-
-// An absmax "word" is kAmaxSlots words (256 bytes): producers max-combine into slot (workgroup id mod kAmaxSlots) — tens
-// of thousands of atomics on ONE address would serialise — and the consumer takes the maximum of the slots.
-constexpr int kAmaxSlots = 64;
-
-// 2^e with max * 2^e in [2^13, 2^14) from the bits of max|x| (exact; 1 for an all-zero operand), and its inverse.
-__device__ __forceinline__ float pow2_scale(const unsigned* amax, float& inv) {
-  inv = 1.f;
-  if (!amax) return 1.f;
-  unsigned bits = 0u;                             // (a uniform address: scalar loads and scalar max)
-#pragma unroll
-  for (int i = 0; i < kAmaxSlots; ++i) {
-    const unsigned w = amax[i] & 0x7fffffffu;
-    bits = bits > w ? bits : w;
-  }
-  if (bits == 0u) return 1.f;
-  int e = 267 - (int)(bits >> 23);                // biased exponent of the scale: 127 + 13 - (exponent(max) - 127)
-  e = e < 1 ? 1 : (e > 253 ? 253 : e);            // both the scale and its inverse stay normal numbers
-  inv = __uint_as_float((unsigned)(254 - e) << 23);
-  return __uint_as_float((unsigned)e << 23);
 }
 
 template <bool KS>

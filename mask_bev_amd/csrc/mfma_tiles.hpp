@@ -134,6 +134,60 @@ __device__ __forceinline__ void mma_acc_tr(const f32x16& x, const lo16_t* __rest
   }
 }
 
+#ifdef MBV_H16
+// ---- f32 operands as IEEE-half pairs (the split mode of K4; K20's arithmetic, csrc/gemm_f32s.hip) -------------------------
+// An operand x * 2^e = hi + lo (hi = half(x 2^e), lo = half(x 2^e - hi): 22 significant bits) lives in TWO swizzled images;
+// a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 (the small terms first).
+template <int D>
+__device__ __forceinline__ void mma_rows_split(const lo16_t* __restrict__ a_hi, const lo16_t* __restrict__ a_lo, int a0,
+                                               const lo16_t* __restrict__ b_hi, const lo16_t* __restrict__ b_lo, int b0,
+                                               f32x16& acc) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const int oa = Swz<D>::chunk_off(a0 + r, 2 * ks + h), ob = Swz<D>::chunk_off(b0 + r, 2 * ks + h);
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + oa), al = *reinterpret_cast<const bf16x8*>(a_lo + oa);
+    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + ob), bl = *reinterpret_cast<const bf16x8*>(b_lo + ob);
+    acc = mfma16(ah, bl, acc);
+    acc = mfma16(al, bh, acc);
+    acc = mfma16(ah, bh, acc);
+  }
+}
+
+// out += (X sx)^T . M  with X an accumulator tile (split in registers at the power-of-two scale sx) and M = m_hi + m_lo
+template <int D>
+__device__ __forceinline__ void mma_acc_tr_split(const f32x16& x, float sx, const lo16_t* __restrict__ m_hi,
+                                                 const lo16_t* __restrict__ m_lo, int k0, int cb, f32x16& out) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* tr_ptr;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  const int c = 4 * cb + 2 * ((lane >> 4) & 1) + (p >> 1);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 ah, al;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float y = x[8 * s + j] * sx;
+      ah[j] = (lo16_t)y;
+      al[j] = (lo16_t)(y - (float)ah[j]);
+    }
+    const int row0 = k0 + 16 * s + 4 * h + q;
+    const int o0 = Swz<D>::chunk_off(row0, c) + 4 * (p & 1), o1 = Swz<D>::chunk_off(row0 + 8, c) + 4 * (p & 1);
+    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(m_hi + o0));
+    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(m_hi + o1));
+    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(m_lo + o0));
+    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(m_lo + o1));
+    const bf16x8 th = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+    const bf16x8 tl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+    out = mfma16(ah, tl, out);
+    out = mfma16(al, th, out);
+    out = mfma16(ah, th, out);
+  }
+}
+#endif
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll

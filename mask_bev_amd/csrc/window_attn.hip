@@ -21,6 +21,9 @@
 // gradient to a (3C) bias-gradient buffer; the relative-position-bias gradient is reduced in LDS per
 // workgroup and then added to the table gradient with one atomic per entry.
 #include "mfma_tiles.hpp"
+#ifdef MBV_H16
+#include "amax.hpp"
+#endif
 
 namespace {
 
@@ -650,6 +653,401 @@ int launch_bwd(const WinGeom& g, int D, const void* qkv, const float* qkv_bias, 
   return MBV_OK;
 }
 
+#ifdef MBV_H16
+// ---------------------------------------------------------------------------------------------
+// f32 tensors on the 16-bit matrix pipe ("split" mode; fp32 compute)
+// ---------------------------------------------------------------------------------------------
+// The exact-f32 form above multiplies with v_mfma_f32_32x32x2_f32 (the f32 vector rate) out of padded-row f32 images that
+// it fills and reads one word at a time.  Here every f32 operand element is split while its tile is staged — x 2^e = hi + lo,
+// two IEEE halves, 22 significant bits (K20's arithmetic: csrc/gemm_f32s.hip) — into a PAIR of the 16-bit path's swizzled
+// images, and every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with f32 accumulation: three instructions at
+// 16x the f32 rate, 16-byte staging and fragment reads, the transposing LDS read for the X^T . M products.  Ranges: one
+// power-of-two scale per TENSOR from its absmax record (amax.hpp: qkv, dO); the register operands take static bounds —
+// probabilities <= 1 (2^13), |dS| <= 2 D max|v| max|dO| / sqrt(D) — every scale is divided out exactly where a result is used.
+struct SplitScales {
+  float s_q, inv_q, s_d, inv_d, s_ds, inv_ds;
+};
+constexpr float kProbScale = 8192.f, kProbInv = 1.f / 8192.f;
+
+__device__ __forceinline__ void split_pack(const float (&x)[8], float s, Pack8& hi, Pack8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float y = x[j] * s;
+    hi.h[j] = (lo16_t)y;
+    lo.h[j] = (lo16_t)(y - (float)hi.h[j]);
+  }
+}
+
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <int D>
+__device__ __forceinline__ void put_split(lo16_t* hi_img, lo16_t* lo_img, int t, int c8, const float (&v)[8], float s) {
+  Pack8 hi, lo;
+  split_pack(v, s, hi, lo);
+  put_row<D>(hi_img, t, c8, hi);
+  put_row<D>(lo_img, t, c8, lo);
+}
+
+// q, k, v (and dO, with delta = sum_d dO O) of one (window, head): every 16-byte load of an item is issued before the first
+// use; padded tokens take the qkv bias (dO: zero).  C % 4 == 0, 16-byte aligned tensors (head columns are multiples of 8).
+template <int D, bool BWD>
+__device__ __forceinline__ void stage_split(const WinGeom& g, const BlockId& id, const int* __restrict__ pix_lds,
+                                            const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                            const float* __restrict__ out, const float* __restrict__ grad_out, int col,
+                                            float s_q, float s_d, lo16_t* q_img, lo16_t* k_img, lo16_t* v_img,
+                                            lo16_t* do_img, double* delta_s) {
+  constexpr int CH = D / 8, IMG = Swz<D>::IMG;
+  const int C3 = 3 * g.C;
+  for (int idx = threadIdx.x; idx < NPAD * CH; idx += blockDim.x) {
+    const int t = idx / CH, c8 = (idx - t * CH) * 8;
+    float q[8], k[8], v[8], d[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = k[j] = v[j] = d[j] = o[j] = 0.f;
+    bool real = false;
+    if (t < g.N) {
+      const int pix = pix_lds[t];
+      if (pix >= 0) {
+        real = true;
+        const int64_t row = (int64_t)id.b * g.H * g.W + pix;
+        const float* p = qkv + row * C3 + col + c8;
+        load8(p, q);
+        load8(p + g.C, k);
+        load8(p + 2 * g.C, v);
+        if (BWD) {
+          load8(grad_out + row * g.C + col + c8, d);
+          load8(out + row * g.C + col + c8, o);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          q[j] = qkv_bias[col + c8 + j];
+          k[j] = qkv_bias[g.C + col + c8 + j];
+          v[j] = qkv_bias[2 * g.C + col + c8 + j];
+        }
+      }
+    }
+    put_split<D>(q_img, q_img + IMG, t, c8, q, s_q);
+    put_split<D>(k_img, k_img + IMG, t, c8, k, s_q);
+    put_split<D>(v_img, v_img + IMG, t, c8, v, s_q);
+    if (BWD) {
+      put_split<D>(do_img, do_img + IMG, t, c8, d, s_d);
+      if (real) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += o[j] * d[j];
+        atomicAdd(&delta_s[t], (double)acc);
+      }
+    }
+  }
+}
+
+// the maximum of the bits of |stored values| of a workgroup -> ONE no-return atomic into its slot of the record
+__device__ __forceinline__ void publish_absmax(unsigned mine, unsigned* red /* >= 16 words of LDS */, unsigned* record) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const unsigned o2 = (unsigned)__shfl_xor((int)mine, sft, 64);
+    mine = mine > o2 ? mine : o2;
+  }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned m = 0u;
+    for (int i = 0; i < nw; ++i) m = m > red[i] ? m : red[i];
+    if (m) atomicMax(record + (blockIdx.x & (kAmaxSlots - 1)), m);
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_window_attn_split_fwd(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                               const float* __restrict__ bias_table, WinGeom g, float scale,
+                                                               const unsigned* __restrict__ amax_qkv,
+                                                               float* __restrict__ out, float* __restrict__ lse) {
+  constexpr int IMG = Swz<D>::IMG;
+  __shared__ __attribute__((aligned(16))) lo16_t k_img[2 * IMG];      // hi image, lo image
+  __shared__ __attribute__((aligned(16))) lo16_t q_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t v_img[2 * IMG];
+  __shared__ float tbl[21 * 21];
+  __shared__ int kinfo[NPAD];
+  __shared__ int pix[NPAD];
+  const BlockId id = decode_block(g);
+  const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tbl[i] = bias_table[i * g.heads + id.head] * kLog2e;
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    if (t < g.N) {
+      kinfo[t] = token_info(g, id, t);
+      pix[t] = token_pixel(g, id.wy, id.wx, t);
+    } else {
+      kinfo[t] = 0;
+      pix[t] = -1;
+    }
+  }
+  float inv_q;
+  const float s_q = pow2_scale(amax_qkv, inv_q);
+  __syncthreads();
+  const int col = id.head * D;
+  stage_split<D, false>(g, id, pix, qkv, qkv_bias, nullptr, nullptr, col, s_q, 1.f, q_img, k_img, v_img, nullptr, nullptr);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nblk = (g.N + 31) / 32;
+  if (wave >= nblk) return;
+  const int q = 32 * wave + r;
+  f32x16 s[NBLK];
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    s[kb] = zero16();
+    if (kb < nblk) mma_rows_split<D>(k_img, k_img + IMG, 32 * kb, q_img, q_img + IMG, 32 * wave, s[kb]);
+  }
+  const float sl2 = scale * kLog2e * inv_q * inv_q;            // the operands' scales leave with the softmax scale
+  const int idx0 = (g.ws - 1) * 2 * g.ws;
+  const int qi = kinfo[q];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 32 * kb + acc_row(i, h);
+      float v = fmaf(s[kb][i], sl2, bias_mask2(tbl, qi, kinfo[k], idx0, nullptr));
+      v = (q < g.N) ? v : 0.f;
+      v = (kb < nblk && k < g.N) ? v : -INFINITY;
+      s[kb][i] = v;
+      m = fmaxf(m, v);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __builtin_amdgcn_exp2f(s[kb][i] - m);
+      s[kb][i] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[kb][i] *= inv;
+  if (h == 0 && q < g.N) lse[(int64_t)blockIdx.x * NPAD + q] = (m + __log2f(sum)) * kLn2;
+
+  constexpr int NCB = (D + 31) / 32;
+  f32x16 o[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    o[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb)
+      if (kb < nblk) mma_acc_tr_split<D>(s[kb], kProbScale, v_img, v_img + IMG, 32 * kb, cb, o[cb]);
+  }
+  const float o_inv = kProbInv * inv_q;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int dcol = r + 32 * cb;
+    if (dcol >= D) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = 32 * wave + acc_row(i, h);
+      if (qq < g.N) {
+        const int px = pix[qq];
+        if (px >= 0) out[((int64_t)id.b * g.H * g.W + px) * g.C + col + dcol] = o[cb][i] * o_inv;
+      }
+    }
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(512, (D <= 32 ? 4 : 2)) k_window_attn_split_bwd(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+    const float* __restrict__ out, const float* __restrict__ grad_out, const float* __restrict__ lse, WinGeom g, float scale,
+    const unsigned* __restrict__ amax_qkv, const unsigned* __restrict__ amax_do, float* __restrict__ grad_qkv,
+    float* __restrict__ grad_table, float* __restrict__ grad_pad, int full_bias, unsigned* __restrict__ amax_out) {
+  constexpr int IMG = Swz<D>::IMG;
+  __shared__ __attribute__((aligned(16))) lo16_t q_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t k_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t v_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t do_img[2 * IMG];
+  __shared__ float tbl[21 * 21];
+  __shared__ double dtbl[21 * 21];
+  __shared__ int kinfo[NPAD];
+  __shared__ int pix[NPAD];
+  __shared__ float lse_s[NPAD];
+  __shared__ double delta_s[NPAD];
+  __shared__ float2 ld_s[NPAD];
+  __shared__ double colacc[3 * D];
+  __shared__ unsigned red[16];
+  const BlockId id = decode_block(g);
+  const int tsz = (2 * g.ws - 1) * (2 * g.ws - 1);
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) {
+    tbl[i] = bias_table[i * g.heads + id.head] * kLog2e;
+    dtbl[i] = 0.0;
+  }
+  for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) colacc[i] = 0.0;
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    if (t < g.N) {
+      kinfo[t] = token_info(g, id, t);
+      pix[t] = token_pixel(g, id.wy, id.wx, t);
+      lse_s[t] = lse[(int64_t)blockIdx.x * NPAD + t];
+    } else {
+      kinfo[t] = 0;
+      pix[t] = -1;
+      lse_s[t] = 0.f;
+    }
+    delta_s[t] = 0.0;
+  }
+  // scales: the tensors' (their maxima in [2^13, 2^14)) and the bound of |dS| / sqrt(D): 2 D max|v| max|dO| / sqrt(D) <
+  // 2^(3 + log2 D) 2^e(v) 2^e(dO) with max < 2^(e + 1), i.e. scale exponent 13 - (3 + log2 D + e_v + e_d)
+  const int eq = pow2_scale_exp(amax_qkv), ed = pow2_scale_exp(amax_do);      // biased: scale = 2^(e - 127), e = 140 - e_max
+  constexpr int LOG2D = D == 16 ? 4 : (D == 32 ? 5 : 6);
+  const int eds = eq + ed - 127 - 13 - 3 - LOG2D;
+  SplitScales sc;
+  sc.s_q = pow2_from_exp(eq); sc.inv_q = pow2_from_exp(254 - eq);
+  sc.s_d = pow2_from_exp(ed); sc.inv_d = pow2_from_exp(254 - ed);
+  const int eds_c = eds < 1 ? 1 : (eds > 253 ? 253 : eds);
+  sc.s_ds = pow2_from_exp(eds_c); sc.inv_ds = pow2_from_exp(254 - eds_c);
+  __syncthreads();
+  const int C3 = 3 * g.C, col = id.head * D;
+  stage_split<D, true>(g, id, pix, qkv, qkv_bias, out, grad_out, col, sc.s_q, sc.s_d, q_img, k_img, v_img, do_img, delta_s);
+  __syncthreads();
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) ld_s[t] = make_float2(lse_s[t] * kLog2e, (float)delta_s[t]);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = threadIdx.x >> 8;
+  const int r = lane & 31, h = lane >> 5;
+  const int nblk = (g.N + 31) / 32;
+  constexpr int NCB = (D + 31) / 32;
+  const int64_t row0 = (int64_t)id.b * g.H * g.W;
+  const float sl2 = scale * kLog2e * sc.inv_q * sc.inv_q;
+  const float dp_inv = sc.inv_q * sc.inv_d;
+  const int idx0 = (g.ws - 1) * 2 * g.ws;
+  unsigned out_max = 0u;
+
+  if (wave < nblk && part == 0) {
+    // ---- part 1: lane = query.  dS^T tiles, relative-position-bias gradient, dQ
+    const int q = 32 * wave + r;
+    const float my_lse2 = ld_s[q].x, my_delta = ld_s[q].y;
+    const int qi = kinfo[q];
+    f32x16 dq[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      if (kb >= nblk) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows_split<D>(k_img, k_img + IMG, 32 * kb, q_img, q_img + IMG, 32 * wave, s);
+      mma_rows_split<D>(v_img, v_img + IMG, 32 * kb, do_img, do_img + IMG, 32 * wave, dp);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = 32 * kb + acc_row(i, h);
+        int idx;
+        const float bm = bias_mask2(tbl, qi, kinfo[k], idx0, &idx);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, bm - my_lse2));
+        const bool valid = q < g.N && k < g.N;
+        const float ds = valid ? p * (dp[i] * dp_inv - my_delta) : 0.f;
+        if (valid) atomicAdd(&dtbl[idx], (double)ds);
+        s[i] = ds * scale;                       // dQ = scale * dS K
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) mma_acc_tr_split<D>(s, sc.s_ds, k_img, k_img + IMG, 32 * kb, cb, dq[cb]);
+    }
+    const float dq_inv = sc.inv_ds * sc.inv_q;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+      float csum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (qq >= g.N) continue;
+        const int px = pix[qq];
+        const float v = dq[cb][i] * dq_inv;
+        if (px >= 0) {
+          grad_qkv[(row0 + px) * C3 + col + dcol] = v;
+          const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+          out_max = out_max > b ? out_max : b;
+        }
+        if (px < 0 || full_bias) csum += v;
+      }
+      csum += __shfl_xor(csum, 32, 64);
+      if (h == 0 && csum != 0.f) atomicAdd(&colacc[dcol], (double)csum);
+    }
+  }
+  if (wave < nblk && part == 1) {
+    // ---- part 2: wave = key block.  dK, dV
+    const int kb = wave;
+    f32x16 dk[NCB], dv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
+    const int k = 32 * kb + r;
+    const int ki = kinfo[k];
+#pragma unroll
+    for (int qb = 0; qb < NBLK; ++qb) {
+      if (qb >= nblk) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows_split<D>(q_img, q_img + IMG, 32 * qb, k_img, k_img + IMG, 32 * kb, s);
+      mma_rows_split<D>(do_img, do_img + IMG, 32 * qb, v_img, v_img + IMG, 32 * kb, dp);
+      f32x16 ds;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * qb + acc_row(i, h);
+        const float2 ld = ld_s[qq];
+        float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, bias_mask2(tbl, kinfo[qq], ki, idx0, nullptr) - ld.x));
+        p = (qq < g.N && k < g.N) ? p : 0.f;
+        s[i] = p;
+        ds[i] = p * (dp[i] * dp_inv - ld.y) * scale;
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        mma_acc_tr_split<D>(s, kProbScale, do_img, do_img + IMG, 32 * qb, cb, dv[cb]);      // dV = P^T dO
+        mma_acc_tr_split<D>(ds, sc.s_ds, q_img, q_img + IMG, 32 * qb, cb, dk[cb]);          // dK = scale dS^T Q
+      }
+    }
+    const float dv_inv = kProbInv * sc.inv_d, dk_inv = sc.inv_ds * sc.inv_q;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+      float ksum = 0.f, vsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * kb + acc_row(i, h);
+        if (kk >= g.N) continue;
+        const int px = pix[kk];
+        const float vk = dk[cb][i] * dk_inv, vv = dv[cb][i] * dv_inv;
+        if (px >= 0) {
+          grad_qkv[(row0 + px) * C3 + g.C + col + dcol] = vk;
+          grad_qkv[(row0 + px) * C3 + 2 * g.C + col + dcol] = vv;
+          const unsigned b1 = __float_as_uint(vk) & 0x7fffffffu, b2 = __float_as_uint(vv) & 0x7fffffffu;
+          const unsigned b = b1 > b2 ? b1 : b2;
+          out_max = out_max > b ? out_max : b;
+        }
+        if (px < 0 || full_bias) { ksum += vk; vsum += vv; }
+      }
+      ksum += __shfl_xor(ksum, 32, 64);
+      vsum += __shfl_xor(vsum, 32, 64);
+      if (h == 0 && ksum != 0.f) atomicAdd(&colacc[D + dcol], (double)ksum);
+      if (h == 0 && vsum != 0.f) atomicAdd(&colacc[2 * D + dcol], (double)vsum);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) atomicAdd(&grad_table[i * g.heads + id.head], (float)dtbl[i]);
+  for (int i = threadIdx.x; i < 3 * D; i += blockDim.x) {
+    const double v = colacc[i];
+    if (v != 0.0) atomicAdd(&grad_pad[(i / D) * g.C + col + (i % D)], (float)v);
+  }
+  if (amax_out) publish_absmax(out_max, red, amax_out);
+}
+#endif
+
 }  // namespace
 
 #ifndef MBV_H16
@@ -715,3 +1113,71 @@ MBV_ENTRY int MBV_SYM(mbv_window_attn_bwd)(const void* qkv, const float* qkv_bia
                  : launch_bwd<false, float>(g, D, qkv, qkv_bias, bias_table, out, grad_out, lse, grad_qkv, grad_table,
                                             grad_qkv_bias, full_bias_grad, stream);
 }
+
+#ifdef MBV_H16
+// ---- K4 on f32 tensors in the split mode (see k_window_attn_split_fwd) ----------------------------------------------------
+extern "C" int mbv_window_attn_split_supported(int32_t C, int32_t heads, int32_t ws) {
+  if (C <= 0 || heads <= 0 || C % heads || ws <= 0 || ws > 11) return 0;
+  const int D = C / heads;
+  return (D == 16 || D == 32 || D == 64) ? 1 : 0;
+}
+
+extern "C" int mbv_window_attn_split_fwd(const float* qkv, const float* qkv_bias, const float* bias_table, int32_t batch,
+                                         int32_t H, int32_t W, int32_t C, int32_t heads, int32_t ws, int32_t shift,
+                                         const uint32_t* amax_qkv, float* out, float* lse, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g;
+  if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
+  if (!mbv_window_attn_split_supported(C, heads, ws) || g.N > NPAD) return MBV_ERR_UNSUPPORTED;
+  if (!qkv || !qkv_bias || !bias_table || !out || !lse) return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(out)) & 15) return MBV_ERR_UNSUPPORTED;
+  const int D = C / heads;
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(256);
+  switch (D) {
+    case 16: hipLaunchKernelGGL((k_window_attn_split_fwd<16>), grid, block, 0, stream, qkv, qkv_bias, bias_table, g, scale, amax_qkv, out, lse); break;
+    case 32: hipLaunchKernelGGL((k_window_attn_split_fwd<32>), grid, block, 0, stream, qkv, qkv_bias, bias_table, g, scale, amax_qkv, out, lse); break;
+    default: hipLaunchKernelGGL((k_window_attn_split_fwd<64>), grid, block, 0, stream, qkv, qkv_bias, bias_table, g, scale, amax_qkv, out, lse); break;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_window_attn_split_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* out,
+                                         const float* grad_out, const float* lse, int32_t batch, int32_t H, int32_t W,
+                                         int32_t C, int32_t heads, int32_t ws, int32_t shift, const uint32_t* amax_qkv,
+                                         const uint32_t* amax_grad_out, float* grad_qkv, float* grad_table,
+                                         float* grad_qkv_bias, int32_t full_bias_grad, int32_t accumulate,
+                                         uint32_t* amax_grad_qkv, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g;
+  if (!make_geom(batch, H, W, C, heads, ws, shift, g)) return MBV_ERR_BAD_ARG;
+  if (!mbv_window_attn_split_supported(C, heads, ws) || g.N > NPAD) return MBV_ERR_UNSUPPORTED;
+  if (!qkv || !qkv_bias || !bias_table || !out || !grad_out || !lse || !grad_qkv || !grad_table || !grad_qkv_bias)
+    return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(grad_out)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int D = C / heads;
+  const int tsz = (2 * ws - 1) * (2 * ws - 1);
+  if (accumulate) {
+  } else if (grad_qkv_bias == grad_table + (size_t)tsz * heads) {
+    MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * ((size_t)tsz * heads + 3 * (size_t)C), stream));
+  } else {
+    MBV_CHECK_HIP(mbv_fill_async(grad_table, 0, sizeof(float) * tsz * heads, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_qkv_bias, 0, sizeof(float) * 3 * C, stream));
+  }
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 grid((unsigned)(g.batch * g.nWh * g.nWw * g.heads)), block(512);
+#define MBV_K4S_BWD(DD)                                                                                                      \
+  hipLaunchKernelGGL((k_window_attn_split_bwd<DD>), grid, block, 0, stream, qkv, qkv_bias, bias_table, out, grad_out, lse, g, \
+                     scale, amax_qkv, amax_grad_out, grad_qkv, grad_table, grad_qkv_bias, full_bias_grad, amax_grad_qkv)
+  switch (D) {
+    case 16: MBV_K4S_BWD(16); break;
+    case 32: MBV_K4S_BWD(32); break;
+    default: MBV_K4S_BWD(64); break;
+  }
+#undef MBV_K4S_BWD
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+#endif

@@ -569,9 +569,21 @@ class _WindowAttention(torch.autograd.Function):
         lse = torch.empty((lib.mbv_window_attn_lse_elems(b, h, w, num_heads, ws),), dtype=torch.float32,
                           device=qkv.device)
         is_bf16 = _dt_flag(qkv.dtype)
-        rc = lib.mbv_window_attn_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), is_bf16, b, h, w, c, num_heads, ws, shift,
-                                     _ptr(out), _ptr(lse), _stream())
-        check(rc, 'mbv_window_attn_fwd')
+        ctx.amax_qkv = None
+        if (qkv.dtype == torch.float32 and switches.get('k4_split') and qkv.data_ptr() % 16 == 0 and c % 4 == 0
+                and lib.mbv_window_attn_split_supported(c, num_heads, ws)):
+            # fp32 compute: the products on the 16-bit matrix pipe from IEEE-half pairs (K20's arithmetic inside K4); the
+            # tensor's scale from the record its producer left (the qkv projection's epilogue), else one pass over it
+            q2 = qkv.view(-1, c3)
+            rec = amax_hint_get(qkv) if switches.get('amax_hints') else None
+            ctx.amax_qkv = rec if rec is not None else f32_absmax([q2])
+            check(lib.mbv_window_attn_split_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), b, h, w, c, num_heads, ws, shift,
+                                                _amax_ptr(ctx.amax_qkv, 0), _ptr(out), _ptr(lse), _stream()),
+                  'mbv_window_attn_split_fwd')
+        else:
+            rc = lib.mbv_window_attn_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), is_bf16, b, h, w, c, num_heads, ws, shift,
+                                         _ptr(out), _ptr(lse), _stream())
+            check(rc, 'mbv_window_attn_fwd')
         ctx.save_for_backward(qkv, bias32, table32, out, lse)
         ctx.cfg = (num_heads, ws, shift, qkv_bias.dtype, bias_table.dtype)
         ctx.params = (qkv_bias, bias_table)
@@ -596,10 +608,24 @@ class _WindowAttention(torch.autograd.Function):
             small = torch.empty(table32.numel() + bias32.numel(), dtype=torch.float32, device=qkv.device)
             g_table = small[:table32.numel()].view(table32.shape)
             g_bias = small[table32.numel():]
-        rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
-                                     is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
-                                     _ptr(g_bias), 1 if ctx.full_bias_grad else 0, 1 if direct else 0, _stream())
-        check(rc, 'mbv_window_attn_bwd')
+        if ctx.amax_qkv is not None and grad_out.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+            hints = bool(switches.get('amax_hints'))
+            go2 = grad_out.view(-1, c)
+            rec_do = amax_hint_get(grad_out) if hints else None
+            if rec_do is None:
+                rec_do = f32_absmax([go2])
+            rec_out = amax_record(qkv.device) if hints else None
+            check(lib.mbv_window_attn_split_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
+                                                b, h, w, c, num_heads, ws, shift, _amax_ptr(ctx.amax_qkv, 0),
+                                                _amax_ptr(rec_do, 0), _ptr(g_qkv), _ptr(g_table), _ptr(g_bias),
+                                                1 if ctx.full_bias_grad else 0, 1 if direct else 0, _ptr(rec_out), _stream()),
+                  'mbv_window_attn_split_bwd')
+            amax_hint_set(g_qkv, rec_out)
+        else:
+            rc = lib.mbv_window_attn_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
+                                         is_bf16, b, h, w, c, num_heads, ws, shift, _ptr(g_qkv), _ptr(g_table),
+                                         _ptr(g_bias), 1 if ctx.full_bias_grad else 0, 1 if direct else 0, _stream())
+            check(rc, 'mbv_window_attn_bwd')
         if direct:
             _fire_grad_hooks(pb)
             _fire_grad_hooks(pt)

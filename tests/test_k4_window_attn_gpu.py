@@ -58,9 +58,14 @@ CASES = [
 
 
 @pytest.mark.parametrize('B,H,W,heads,D,ws,shift', CASES)
-@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['f32', 'f32_exact', 'bf16', 'fp16'])
 def test_window_attention_fwd_bwd(device, B, H, W, heads, D, ws, shift, dtype):
-    from mask_bev_amd import ops
+    """'f32': the split mode where the head dimension allows it (IEEE-half pairs on the 16-bit matrix pipe); 'f32_exact':
+    v_mfma_f32_32x32x2_f32 (switches.k4_split off)."""
+    from mask_bev_amd import ops, switches
+    if dtype == 'f32_exact':
+        with switches.override(k4_split=False):
+            return test_window_attention_fwd_bwd(device, B, H, W, heads, D, ws, shift, 'f32')
     g = torch.Generator().manual_seed(H * 31 + W + shift)
     C = heads * D
     qkv = torch.randn(B, H, W, 3 * C, generator=g)
@@ -93,3 +98,43 @@ def test_window_attention_fwd_bwd(device, B, H, W, heads, D, ws, shift, dtype):
     assert float((t_d.grad.cpu() - t_r.grad).abs().max()) / scale < ptol
     scale = float(b_r.grad.abs().max().clamp(min=1.0))
     assert float((b_d.grad.cpu() - b_r.grad).abs().max()) / scale < ptol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,heads,D,ws,shift,gscale', [(2, 23, 17, 3, 32, 10, 5, 1e-6), (1, 20, 20, 2, 64, 10, 0, 1.0),
+                                                        (2, 16, 16, 4, 16, 7, 3, 3e-4), (1, 30, 30, 6, 32, 10, 5, 1e3)])
+def test_split_mode_against_float64(device, B, H, W, heads, D, ws, shift, gscale):
+    """K4's split mode (f32 tensors, products from IEEE-half pairs) against the float64 attention: output and every gradient
+    within 4e-6 of the result's maximum — the exact-f32 MFMA form is held to the same bar beside it — for output gradients of
+    1e-6 ... 1e+3 (the tensors' power-of-two scales come from absmax records), and its absmax record of d(qkv) is exact."""
+    from mask_bev_amd import ops, switches
+    g = torch.Generator().manual_seed(B * 1000 + H + D)
+    C = heads * D
+    qkv = torch.randn(B, H, W, 3 * C, generator=g) * 2.0
+    bias = torch.randn(3 * C, generator=g) * 0.5
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    go = torch.randn(B, H, W, C, generator=g) * gscale
+    q_r, b_r, t_r = (t.double().requires_grad_() for t in (qkv, bias, table))
+    ref = ref_window_attention(q_r, b_r, t_r, heads, ws, shift)
+    ref.backward(go.double())
+
+    def run(split):
+        with switches.override(k4_split=split, amax_hints=True):
+            q_d = qkv.to(device).requires_grad_()
+            b_d, t_d = bias.to(device).requires_grad_(), table.to(device).requires_grad_()
+            mid, seen = q_d * 1.0, []
+            mid.register_hook(lambda gr: seen.append(ops.amax_hint_get(gr)))      # what the qkv projection's backward finds
+            out = ops.window_attention(mid, b_d, t_d, heads, ws, shift)
+            out.backward(go.to(device))
+            return out.detach(), q_d.grad, b_d.grad, t_d.grad, seen[0]
+
+    def err(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+    res = {split: run(split) for split in (True, False)}
+    for split, (out, gq, gb, gt, rec) in res.items():
+        for name, a, b in (('out', out, ref.detach()), ('dqkv', gq, q_r.grad), ('dbias', gb, b_r.grad), ('dtable', gt, t_r.grad)):
+            assert err(a, b) <= 4e-6, (split, name, err(a, b))
+    rec = res[True][4]
+    assert rec is not None and res[False][4] is None
+    assert int(rec.max()) == int(res[True][1].abs().max().view(torch.int32))
