@@ -34,6 +34,21 @@ def _window_attn(a, bwd: bool) -> Work:
     return ('k_window_attn_fwd', 'hbm', t * c * es * (3 + 1), 4.0 * nwin * heads * n * n * d)
 
 
+def _window_attn_split(a, bwd: bool) -> Work:
+    """K4 on f32 tensors in the split mode: the same bytes and ALGORITHMIC flops as the f32 form (the kernel issues three 16-bit
+    matrix instructions per product term)."""
+    if bwd:
+        b, h, w, c, heads, ws = (_i(a[i]) for i in (6, 7, 8, 9, 10, 11))
+    else:
+        b, h, w, c, heads, ws = (_i(a[i]) for i in (3, 4, 5, 6, 7, 8))
+    t = b * h * w
+    nwin = b * ((h + ws - 1) // ws) * ((w + ws - 1) // ws)
+    n, d = ws * ws, c // max(1, heads)
+    if bwd:
+        return ('k_window_attn_bwd', 'hbm', t * c * 4 * (3 + 1 + 1 + 3), 10.0 * nwin * heads * n * n * d)
+    return ('k_window_attn_fwd', 'hbm', t * c * 4 * (3 + 1), 4.0 * nwin * heads * n * n * d)
+
+
 def _msda(a, bwd: bool) -> Work:
     o = 1 if bwd else 0
     b, nv, heads, d, levels, nq, pts = (_i(a[i + o]) for i in (5, 6, 7, 8, 9, 10, 11))
@@ -316,6 +331,8 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                     2.0 * _i(a[11]) * _i(a[3]) * _i(a[4]) * _i(a[5])),
     'mbv_window_attn_fwd': lambda a: _window_attn(a, False),
     'mbv_window_attn_bwd': lambda a: _window_attn(a, True),
+    'mbv_window_attn_split_fwd': lambda a: _window_attn_split(a, False),
+    'mbv_window_attn_split_bwd': lambda a: _window_attn_split(a, True),
     'mbv_ms_deform_attn_fwd': lambda a: _msda(a, False),
     'mbv_ms_deform_attn_bwd': lambda a: _msda(a, True),
     'mbv_ms_deform_attn_fwd_v': lambda a: _msda_typed(a, False),

@@ -29,8 +29,8 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_absmax_group', r'k_absmax_group', []),
     ('k_adamw', r'k_adamw', []),
     ('k_sample_select', r'k_sample_select', []),
-    ('k_window_attn_bwd', r'k_window_attn_bwd', []),
-    ('k_window_attn_fwd', r'k_window_attn_fwd', []),
+    ('k_window_attn_bwd', r'k_window_attn(_split)?_bwd', []),
+    ('k_window_attn_fwd', r'k_window_attn(_split)?_fwd', []),
     ('k_msda_bwd', r'k_msda_bwd_locattn', [r'k_msda_bwd_value<', r'k_msda_bwd_valueI']),
     ('k_msda_bwd_locattn', r'k_msda_bwd_locattn', []),
     ('k_msda_bwd_value_fx', r'k_msda_bwd_value_fx', [r'k_msda_bwd_relayout']),
