@@ -1009,6 +1009,27 @@ int mbv_gemm32s_tn_group(const float* const* g, const float* const* x, float* co
                          const int64_t* k, const int64_t* ldg, const int64_t* ldx, const uint32_t* const* amax_g,
                          const uint32_t* const* amax_x, int32_t count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The pixel decoder's 3 x 3 convolution in-tree (fp32 compute; replaces MIOpen's f32 convolution forward / backward-data /
+ * backward-weight for /root/reference: mask_bev/models/head/mask_bev_panoptic_head.py:119-146 — mmdet
+ * MSDeformAttnPixelDecoder.output_convs: ConvModule(256, 256, 3, padding 1, bias off) + GroupNorm + ReLU on the (B, 256, 128, 128)
+ * map).  The map is turned once into a zero-bordered channels-last ROWS buffer — (mbv_conv_rows(B, H, W), C): G = W + 3 guard
+ * rows, then the (B, H + 2, W + 2) padded positions, then G guard rows; everything but the interior pixels zero — on which the
+ * convolution is ONE token-major K20 product over k = (tap, channel): the row of position m for tap t = 3 dy + dx is row
+ * m + (dy - 1)(W + 2) + (dx - 1) of the same buffer (a scalar offset per K-step, no im2col).
+ *   mbv_conv_pad_rows:   dst rows (cleared by the caller) <- interior pixels of src (B, C, H, W); elem_size 4 (f32) or 2
+ *   mbv_conv_unpad_rows: dst (B, C, H, W) <- interior pixels of the rows buffer src
+ *   mbv_conv3x3_gemm32s: out_rows (rows buffer, cout channels; its interior positions hold the result) from rows (C channels)
+ *                        and wm (cout, 9 C) f32 with wm[co][t C + ci] = weight[co][ci][dy][dx].  The DATA gradient is the same call
+ *                        on the output gradient's rows with wm[ci][t cout + co] = weight[co][ci][2 - dy][2 - dx]; the WEIGHT
+ *                        gradient is nine entries of mbv_gemm32s_tn_group (g = the output gradient's rows, x = rows shifted by
+ *                        the tap).  C % 32 == 0, cout % 8 == 0, 16-byte aligned buffers; amax_*: absmax records (NULL = unscaled). */
+int64_t mbv_conv_rows(int64_t batch, int64_t H, int64_t W);
+int mbv_conv_pad_rows(const void* src, void* dst, int64_t batch, int64_t C, int64_t H, int64_t W, int32_t elem_size, void* stream);
+int mbv_conv_unpad_rows(const void* src, void* dst, int64_t batch, int64_t C, int64_t H, int64_t W, int32_t elem_size,
+                        void* stream);
+int mbv_conv3x3_gemm32s(const float* rows, const float* wm, float* out_rows, int64_t batch, int64_t H, int64_t W, int64_t C,
+                        int64_t cout, const uint32_t* amax_rows, const uint32_t* amax_w, uint32_t* amax_out, void* stream);
+
 /* The fp32 FFN's backward in one K20 launch: out (m, k) = act'(pre (m, k)) * (g (m, n) . w (n, k)) — the data gradient of the
  * output layer times the activation's derivative (act: 1 ReLU, 2 erf-GELU) — and, into `parts`
  * ((mbv_gemm32s_nn_part_rows(m, 1), k) f32, every element written), the partial column sums of `out`: their sum over the rows is

@@ -65,6 +65,7 @@ struct Gemm32Args {
   int ntm, ntn, splits, ksteps;
   int acc_out;              // splits == 1: the product is ADDED to c (read-modify-write by the owning workgroup)
   int pc, ph, pw;           // GATHER modes: the (B, pc, ph, pw) NCHW image behind the 4 x 4 patch rows
+  int tap[9], tap_steps;    // GATHER 4: byte offset added to A's rows for the K-steps of tap t (tap_steps K-steps each)
 };
 
 // The rows of a non-overlapping 4 x 4 patch projection (mmdet PatchEmbed: Conv2d(C, E, 4, stride 4) on an NCHW image,
@@ -76,6 +77,8 @@ struct Gemm32Args {
 //   GATHER 1: NT  out (tokens, E) = rows . W^T          — A is the gathered row matrix
 //   GATHER 2: NN  d image = (d out (tokens, E) . W) scattered back to NCHW — C is the scattered row matrix
 //   GATHER 3: TN  dW (E, 16 C) += d out^T . rows        — B is the gathered row matrix (contraction over tokens)
+//   GATHER 4: NT  a 3 x 3 convolution on a zero-bordered channels-last image as ONE product over k = (tap, channel): the A
+//             row of output position m for tap t is row m + shift_t of the same matrix — a per-K-step scalar offset
 __device__ __forceinline__ unsigned patch_elem(const Gemm32Args& p, int token, int kp) {
   const int tw = p.pw >> 2, th = p.ph >> 2;
   const int b = token / (th * tw), rem = token - b * th * tw;
@@ -187,10 +190,12 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       unsigned va = offa[i], vb = offb[i], sa = (unsigned)kt * stepa, sb = (unsigned)kt * stepb;
+      if (GATHER == 4) sa += (unsigned)p.tap[(k_begin / KB32 + kt) / p.tap_steps];
       if (tail) {
         va = a_offset(i, k_begin + kt * KB32, k_end);
         vb = b_offset(i, k_begin + kt * KB32, k_end);
-        sa = sb = 0u;
+        sa = GATHER == 4 ? (unsigned)p.tap[(k_begin / KB32 + kt) / p.tap_steps] : 0u;
+        sb = 0u;
       } else if (GATHER == 3) {
         vb = b_offset(i, k_begin + kt * KB32, k_end);
       }
@@ -268,7 +273,9 @@ __device__ __forceinline__ void gemm32s_body(const Gemm32Args& p, const int bid,
   for (; kt < n_main; ++kt) {
     read_frags(kt);                                // (in front of the split's LDS stores: the compiler orders LDS accesses)
     char* nst = smem + ((kt + 1) & 1) * STAGE32;
-    const unsigned sa2 = (unsigned)(kt + 2) * stepa, sb2 = (unsigned)(kt + 2) * stepb;
+    unsigned sa2 = (unsigned)(kt + 2) * stepa;
+    const unsigned sb2 = (unsigned)(kt + 2) * stepb;
+    if (GATHER == 4) sa2 += (unsigned)p.tap[(k_begin / KB32 + kt + 2) / p.tap_steps];
     // eight groups of { three matrix instructions (one accumulator's cross terms and hi . hi), the split of ONE 16-byte
     // piece of step kt + 1 and its two LDS stores, the request of that piece of step kt + 2 }, pinned in this order
 #pragma unroll
@@ -948,6 +955,34 @@ extern "C" int mbv_gemm32s_tn_group(const float* const* g, const float* const* x
     }
   }
   return MBV_OK;
+}
+
+// ---- a 3 x 3 convolution (stride 1, padding 1) as one K20 product over k = (tap, channel) ---------------------------------
+// rows / out_rows: zero-bordered channels-last buffers of csrc/conv_pad.hip ((2 G + B (H + 2)(W + 2), C) with G = W + 3 guard
+// rows; mbv_conv_rows).  out_rows[m][co] = sum_t sum_ci rows[m + shift_t][ci] wm[co][t C + ci] for every padded position m
+// (t = 3 dy + dx, shift_t = (dy - 1)(W + 2) + (dx - 1)): the interior positions hold the convolution, the border positions
+// partial sums nobody reads.  The data gradient is the same call on the output gradient's rows with the taps flipped in wm.
+extern "C" int mbv_conv3x3_gemm32s(const float* rows, const float* wm, float* out_rows, int64_t batch, int64_t H, int64_t W,
+                                   int64_t C, int64_t cout, const uint32_t* amax_rows, const uint32_t* amax_w,
+                                   uint32_t* amax_out, void* stream) {
+  if (!rows || !wm || !out_rows || batch <= 0 || H <= 0 || W <= 0 || C <= 0 || cout <= 0) return MBV_ERR_BAD_ARG;
+  if ((C % KB32) || (cout & 7)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(rows) | reinterpret_cast<size_t>(wm) | reinterpret_cast<size_t>(out_rows)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t G = W + 3, mp = batch * (H + 2) * (W + 2), total = mp + 2 * G;
+  if (total * C * 4 >= 0x7fff0000LL || cout * 9 * C * 4 >= 0x7fff0000LL) return MBV_ERR_UNSUPPORTED;
+  Gemm32Args a = {};
+  a.a = rows; a.b = wm; a.c = out_rows + G * cout; a.amax_a = amax_rows; a.amax_b = amax_w; a.amax_out = amax_out;
+  a.gm = (int)mp; a.gn = (int)cout; a.gk = (int)(9 * C);
+  a.lda = (int)C; a.ldb = (int)(9 * C); a.ldc = (int)cout;
+  a.a_bytes = (unsigned)(total * C * 4); a.b_bytes = (unsigned)(cout * 9 * C * 4);
+  a.ntm = (int)((mp + 127) / 128); a.ntn = (int)((cout + 127) / 128); a.splits = 1; a.ksteps = (int)(9 * C / KB32);
+  a.tap_steps = (int)(C / KB32);
+  for (int t = 0; t < 9; ++t) {
+    const int64_t shift = (t / 3 - 1) * (W + 2) + (t % 3 - 1);
+    a.tap[t] = (int)((G + shift - t) * C * 4);          // >= 0: the row of tap t, minus the t C columns k has advanced
+  }
+  return gemm32s_launch<false, false, 4>(EPI32_NONE, a, 1, (hipStream_t)stream);
 }
 
 // Partial column-sum rows an mbv_gemm32s_nn_act of this shape leaves: one per 64 output rows of a 128-row tile.

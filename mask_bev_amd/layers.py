@@ -216,7 +216,12 @@ class ConvGN(nn.Module):
         """``add_upsampled``: a coarser (B, C, h, w) map whose bilinear up-sampling is added to the normalised result
         (the FPN step of the pixel decoder: ``lateral + F.interpolate(previous)``); ``conv_input``: the result only
         feeds convolutions, so under autocast it is stored in the autocast dtype (what they would cast it to)."""
-        y = conv1x1(self.conv, x) if self.conv.kernel_size == (1, 1) and x.is_cuda else self.conv(x)
+        if self.conv.kernel_size == (1, 1) and x.is_cuda:
+            y = conv1x1(self.conv, x)
+        elif ops.conv3x3_32_ok(x, self.conv):
+            y = ops.conv3x3_32(x, self.conv.weight)          # fp32 compute: K20 products instead of MIOpen
+        else:
+            y = self.conv(x)
         if ops.group_norm_supported(y, self.gn.num_groups) and self.gn.weight is not None and \
                 (add_upsampled is None or (y.shape[-1] % 4 == 0 and add_upsampled.dtype in ops._ACT_DTYPES)):
             lo = (conv_input and torch.is_autocast_enabled('cuda')

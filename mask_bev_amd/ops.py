@@ -1548,6 +1548,85 @@ def gemm32s_tn_group(items) -> None:
                                    n, _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_group')
 
 
+class _Conv3x3K20(torch.autograd.Function):
+    """``conv2d(x, weight, padding=1)`` for a 3 x 3 kernel on an f32 (B, C, H, W) map as K20 products on a zero-bordered
+    channels-last ROWS copy of the map (csrc/conv_pad.hip, mbv_conv3x3_gemm32s): forward and data gradient are one product
+    over k = (tap, channel) each, the weight gradient nine entries of the grouped TN launch — no im2col, no MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        b, c, h, w = x.shape
+        cout = weight.shape[0]
+        x = x.contiguous()
+        rows = int(lib.mbv_conv_rows(b, h, w))
+        xp = torch.zeros((rows, c), dtype=torch.float32, device=x.device)
+        check(lib.mbv_conv_pad_rows(_ptr(x), _ptr(xp), b, c, h, w, 4, _stream()), 'mbv_conv_pad_rows')
+        wm = weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous()
+        rec = f32_absmax([xp, wm])
+        outp = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        check(lib.mbv_conv3x3_gemm32s(_ptr(xp), _ptr(wm), _ptr(outp), b, h, w, c, cout, _amax_ptr(rec, 0), _amax_ptr(rec, 1),
+                                      None, _stream()), 'mbv_conv3x3_gemm32s')
+        y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+        check(lib.mbv_conv_unpad_rows(_ptr(outp), _ptr(y), b, cout, h, w, 4, _stream()), 'mbv_conv_unpad_rows')
+        ctx.save_for_backward(xp, weight)
+        ctx.rec_x, ctx.dims = rec[0:1], (b, c, h, w, cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xp, weight = ctx.saved_tensors
+        b, c, h, w, cout = ctx.dims
+        rows = xp.shape[0]
+        guard, mp = w + 3, b * (h + 2) * (w + 2)
+        gy = gy.contiguous()
+        gyp = torch.zeros((rows, cout), dtype=torch.float32, device=gy.device)
+        check(lib.mbv_conv_pad_rows(_ptr(gy), _ptr(gyp), b, cout, h, w, 4, _stream()), 'mbv_conv_pad_rows')
+        gx = gw = None
+        wd = weight.detach()
+        if ctx.needs_input_grad[0]:
+            wflip = wd.flip(2, 3).permute(1, 2, 3, 0).reshape(c, 9 * cout).contiguous()
+            rec = f32_absmax([gyp, wflip])
+            rec_g = rec[0:1]
+            gxp = torch.empty((rows, c), dtype=torch.float32, device=gy.device)
+            check(lib.mbv_conv3x3_gemm32s(_ptr(gyp), _ptr(wflip), _ptr(gxp), b, h, w, cout, c, _amax_ptr(rec, 0),
+                                          _amax_ptr(rec, 1), None, _stream()), 'mbv_conv3x3_gemm32s')
+            gx = torch.empty((b, c, h, w), dtype=torch.float32, device=gy.device)
+            check(lib.mbv_conv_unpad_rows(_ptr(gxp), _ptr(gx), b, c, h, w, 4, _stream()), 'mbv_conv_unpad_rows')
+        else:
+            rec_g = f32_absmax([gyp])
+        if ctx.needs_input_grad[1]:
+            # d weight[co][ci][dy][dx] = sum_m gyp[m][co] xp[m + shift_t][ci]: nine token-major products of the grouped launch
+            dwm = torch.zeros((9, cout, c), dtype=torch.float32, device=gy.device)
+            g2 = gyp[guard:guard + mp]
+            items = []
+            for t in range(9):
+                sh = guard + (t // 3 - 1) * (w + 2) + (t % 3 - 1)
+                items.append((g2, xp[sh:sh + mp], dwm[t], rec_g, ctx.rec_x))
+            gemm32s_tn_group(items)
+            gw = dwm.permute(1, 2, 0).reshape(cout, c, 3, 3)
+            if (getattr(weight, '_mbv_arena', False) and weight.grad is not None and weight.grad.dtype == torch.float32):
+                weight.grad.add_(gw)
+                _fire_grad_hooks(weight)
+                gw = None
+        return gx, gw
+
+
+def conv3x3_32_ok(x: torch.Tensor, conv) -> bool:
+    """fp32 compute, a 3 x 3 stride-1 padding-1 convolution without bias whose channel counts K20 takes."""
+    return bool(switches.get('conv3x3_k20') and switches.get('gemm32s') and x.is_cuda and x.dtype == torch.float32
+                and x.dim() == 4 and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+                and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros'
+                and x.shape[1] % 32 == 0 and conv.weight.shape[0] % 32 == 0
+                and gemm32s_wants(x.shape[0] * x.shape[2] * x.shape[3]))
+
+
+def conv3x3_32(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return _Conv3x3K20.apply(x, weight)
+
+
 def mm32_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x (M, K) @ w (N, K)^T (+ bias)`` for f32 operands: K20 when the product is large enough and its operands fit
     (``switches.gemm32s``), else the library's f32 GEMM — the fp32 compute mode's stand-in for ``torch.mm`` / ``addmm``."""

@@ -409,6 +409,13 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_patch_embed32_bwd_weight': lambda a: ('k_gemm32s<TN,patch>', 'mfma',
                                                (_i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]) + _i(a[3]) * _i(a[5]) * _i(a[6]) // 16 * _i(a[7])) * 4.0,
                                                2.0 * _i(a[3]) * (_i(a[5]) // 4) * (_i(a[6]) // 4) * _i(a[7]) * 16 * _i(a[4])),
+    # the 3 x 3 convolution as a K20 product over (tap, channel): reads the rows buffer and the weights, writes the output rows;
+    # 2 * positions * cout * 9 C flops.  (rows, wm, out_rows, batch, H, W, C, cout, ...)
+    'mbv_conv3x3_gemm32s': lambda a: ('k_gemm32s<NT,conv3x3>', 'mfma',
+                                      (_i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * (_i(a[6]) + _i(a[7])) + 9 * _i(a[6]) * _i(a[7])) * 4.0,
+                                      2.0 * _i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * _i(a[7]) * 9 * _i(a[6])),
+    'mbv_conv_pad_rows': lambda a: ('k_conv_pad_rows', 'hbm', 2.0 * _i(a[2]) * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]), 0.0),
+    'mbv_conv_unpad_rows': lambda a: ('k_conv_pad_rows', 'hbm', 2.0 * _i(a[2]) * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]), 0.0),
     'mbv_gemm32s_tn_group': lambda a: ('k_gemm32s_tn_group', 'mfma',
                                        sum((int(a[3][i]) * (int(a[4][i]) + int(a[5][i])) + 2 * int(a[4][i]) * int(a[5][i])) * 4.0
                                            for i in range(_i(a[10]))),

@@ -20,6 +20,8 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     # K20 (fp32 runs): template arguments <A_KS, B_KS, EPI, GATHER>
     ('k_gemm32s<NT>', r'k_gemm32sILb0ELb0ELi[012]ELi0E', []),
     ('k_gemm32s<NT,patch>', r'k_gemm32sILb0ELb0ELi0ELi1E', []),
+    ('k_gemm32s<NT,conv3x3>', r'k_gemm32sILb0ELb0ELi0ELi4E', []),
+    ('k_conv_pad_rows', r'k_(un)?pad_rows', []),
     ('k_gemm32s<NN>', r'k_gemm32sILb0ELb1ELi0ELi0E', []),
     ('k_gemm32s<NN,dact>', r'k_gemm32sILb0ELb1ELi[34]ELi0E', []),
     ('k_gemm32s<NN,patch>', r'k_gemm32sILb0ELb1ELi0ELi2E', []),

@@ -366,3 +366,30 @@ def test_fp32_ffn_on_k20_matches_float64(kind, rows, c, f):
     assert _err(x.grad, xd.grad) <= (4e-6 if kind == 'gelu' else 2e-5)      # (ReLU: an input within rounding of the kink flips its gate)
     for p, r in zip((fc1.weight, fc1.bias, fc2.weight, fc2.bias), ps):
         assert _err(p.grad, r.grad) <= (6e-6 if kind == 'gelu' else 3e-5), float(_err(p.grad, r.grad))
+
+
+@gpu
+@pytest.mark.parametrize('b,c,cout,h,w', [(2, 32, 64, 24, 23), (1, 64, 32, 33, 37), (4, 256, 256, 32, 32)])
+def test_conv3x3_on_k20_matches_float64(b, c, cout, h, w):
+    """The 3 x 3 convolution as K20 products on the zero-bordered channels-last rows (mbv_conv_pad_rows / mbv_conv3x3_gemm32s /
+    nine grouped TN entries) against the float64 convolution: output, input gradient, weight gradient — and what MIOpen's f32
+    convolution gives beside it."""
+    from mask_bev_amd import ops
+    conv = torch.nn.Conv2d(c, cout, 3, padding=1, bias=False).to(_dev())
+    x = _rand((b, c, h, w), 11).requires_grad_()
+    gy = _rand((b, cout, h, w), 12, 1e-3)
+    assert ops.conv3x3_32_ok(x, conv)
+    y = ops.conv3x3_32(x, conv.weight)
+    y.backward(gy)
+    gx, gw = x.grad.clone(), conv.weight.grad.clone()
+    xd, wd = x.detach().double().requires_grad_(), conv.weight.detach().double().requires_grad_()
+    ref = torch.nn.functional.conv2d(xd, wd, padding=1)
+    ref.backward(gy.double())
+    x.grad = None
+    conv.weight.grad = None
+    lib_y = conv(x)
+    lib_y.backward(gy)
+    for name, mine, r, lib_v in (('y', y.detach(), ref.detach(), lib_y.detach()), ('dx', gx, xd.grad, x.grad),
+                                 ('dw', gw, wd.grad, conv.weight.grad)):
+        e, le = _err(mine, r), _err(lib_v, r)
+        assert e <= max(2e-6, 2 * le), (name, e, le)
