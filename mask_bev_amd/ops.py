@@ -2417,8 +2417,12 @@ class _SharedKVProject(torch.autograd.Function):
             bk = torch.cat([b_[e:2 * e] for b_ in bc], 0)
             bv = torch.cat([b_[2 * e:3 * e] for b_ in bc], 0)
         with torch.autocast('cuda', enabled=False):
-            holder.k_cat = torch.nn.functional.linear(key_in, wk, bk)
-            holder.v_cat = torch.nn.functional.linear(val_in.to(dt), wv, bv)
+            if dt == torch.float32 and key_in.is_cuda:       # fp32 compute: K20 when the token count allows (else the library)
+                holder.k_cat = mm32_nt(key_in.reshape(-1, e), wk, bk).view(key_in.shape[:-1] + (n * e,))
+                holder.v_cat = mm32_nt(val_in.to(dt).reshape(-1, e), wv, bv).view(val_in.shape[:-1] + (n * e,))
+            else:
+                holder.k_cat = torch.nn.functional.linear(key_in, wk, bk)
+                holder.v_cat = torch.nn.functional.linear(val_in.to(dt), wv, bv)
         holder.n, holder.e = n, e
         holder.dk_cat = holder.dv_cat = None
         holder.written = set()
@@ -2442,10 +2446,11 @@ class _SharedKVProject(torch.autograd.Function):
         t = key_in.numel() // e
         dk2, dv2 = dk.view(t, n * e), dv.view(t, n * e)
         key2, val2 = key_in.reshape(t, e), val_in.reshape(t, e).to(dk.dtype)
+        f32 = dk2.dtype == torch.float32 and dk2.is_cuda
         if ctx.needs_input_grad[1]:
-            grads[1] = dk2.mm(wk).view_as(key_in)
+            grads[1] = (mm32_nn(dk2, wk) if f32 else dk2.mm(wk)).view_as(key_in)
         if ctx.needs_input_grad[2]:
-            grads[2] = dv2.mm(wv).view_as(val_in).to(val_in.dtype)
+            grads[2] = (mm32_nn(dv2, wv) if f32 else dv2.mm(wv)).view_as(val_in).to(val_in.dtype)
         # weight / bias gradients.  Arena parameters: every layer's k / v rows take their product straight into the
         # gradient rows (strided column blocks of dk_cat / dv_cat; the 16-bit products and the column sums join the
         # grouped launches at the end of the pass) — per level that was 2 fills, 2 GEMMs + 2 part sums, 2 column sums
