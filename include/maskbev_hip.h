@@ -1029,6 +1029,9 @@ int mbv_conv_unpad_rows(const void* src, void* dst, int64_t batch, int64_t C, in
                         void* stream);
 int mbv_conv3x3_gemm32s(const float* rows, const float* wm, float* out_rows, int64_t batch, int64_t H, int64_t W, int64_t C,
                         int64_t cout, const uint32_t* amax_rows, const uint32_t* amax_w, uint32_t* amax_out, void* stream);
+/* the 16-bit compute modes' form (K17; dtype 0 = bf16, 1 = fp16; out_rows 16-bit or f32): the same buffers and weight layout */
+int mbv_conv3x3_gemm16(const void* rows, const void* wm, void* out_rows, int64_t batch, int64_t H, int64_t W, int64_t C,
+                       int64_t cout, int32_t dtype, int32_t out_f32, void* stream);
 
 /* The fp32 FFN's backward in one K20 launch: out (m, k) = act'(pre (m, k)) * (g (m, n) . w (n, k)) — the data gradient of the
  * output layer times the activation's derivative (act: 1 ReLU, 2 erf-GELU) — and, into `parts`

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 51
+ABI_VERSION = 52
 
 
 class MaskBevHipError(RuntimeError):
@@ -159,6 +159,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_conv_pad_rows': (ctypes.c_int, [_P, _P, _L, _L, _L, _L, _I, _P]),
     'mbv_conv_unpad_rows': (ctypes.c_int, [_P, _P, _L, _L, _L, _L, _I, _P]),
     'mbv_conv3x3_gemm32s': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P, _P]),
+    'mbv_conv3x3_gemm16': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _I, _I, _P]),
     'mbv_window_attn_split_supported': (ctypes.c_int, [_I, _I, _I]),
     'mbv_window_attn_split_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_window_attn_split_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I,

@@ -49,7 +49,8 @@ struct Geo {
   static constexpr int WPS = (BLOCKS * NW + 3) / 4 > 8 ? 8 : (BLOCKS * NW + 3) / 4;               // waves per SIMD
 };
 
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_DRELU = 3, EPI_DGELU = 4 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_DRELU = 3, EPI_DGELU = 4,
+       EPI_CONV = 5 };       // EPI_NONE's epilogue; the A rows of a K-step are shifted by its tap (GemmArgs::tap)
 
 struct GemmArgs {
   const void* a;
@@ -67,6 +68,8 @@ struct GemmArgs {
   int ntm, ntn, splits, ksteps;  // tiles, split-K parts, K-steps of KB per part
   int out_f32;
   int acc_out;          // STORE, f32 output, splits == 1: the product is ADDED to c (read-modify-write, no atomics)
+  int tap_steps;        // != 0: a 3 x 3 convolution on zero-bordered channels-last rows (csrc/conv_pad.hip) as ONE product over
+  int tap[9];           //   k = (tap, channel): the A rows of the K-steps of tap t (tap_steps each) are tap[t] bytes further on
 };
 
 // One workgroup's share of a product: work item `bid` of the (batch, split, tile_m, tile_n) index, tile_n fastest, so
@@ -125,7 +128,10 @@ __device__ __forceinline__ void gemm16_body(const GemmArgs& p, const int bid, ch
       unsigned v = off[j], sof = (unsigned)kt * (is_a ? stepa : stepb);
       if (kt >= nk) { v = OOB; sof = 0u; }
       else if (tail) { v = piece_off(j, k_begin + kt * KB, k_end); sof = 0u; }
-      glds16(is_a ? ra : rb, slot + pi * 1024, v, sof);
+      if constexpr (EPI == EPI_CONV) {
+        if (is_a && kt < nk) sof += (unsigned)p.tap[(k_begin / KB + kt) / p.tap_steps];
+      }
+      glds16(is_a ? ra : rb, slot + pi * 1024, v, __builtin_amdgcn_readfirstlane(sof));
     }
   };
 
@@ -349,6 +355,7 @@ __global__ void __launch_bounds__(256, (Geo<KB, NS, 2, 2, 2>::WPS)) k_gemm16_tn_
   p.ntm = (e.n + 127) / 128; p.ntn = e.ntn; p.splits = e.splits; p.ksteps = e.ksteps;
   p.out_f32 = 1;
   p.acc_out = e.splits == 1;
+  p.tap_steps = 0;
   gemm16_body<KB, NS, 2, 2, 2, true, true, 0, EPI_NONE, T>(p, item - e.item_begin, smem);
 }
 
@@ -470,6 +477,7 @@ static int gemm16_launch_s(int layout, int atomic, int epi, int dtype, const Gem
     if constexpr (TN == 2) {
       if (epi == EPI_RELU) return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_RELU>(dtype, a, n, st);
       if (epi == EPI_GELU) return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_GELU>(dtype, a, n, st);
+      if (epi == EPI_CONV) return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_CONV>(dtype, a, n, st);
       return gemm16_launch_t<WM, TM, TN, false, false, 0, EPI_NONE>(dtype, a, n, st);
     }
     return MBV_ERR_UNSUPPORTED;
@@ -593,6 +601,36 @@ extern "C" int mbv_gemm16_nt_acc(const void* x, const void* w, float* acc, int64
   gemm16_split(a, splits, k, batch);
   a.out_f32 = 1;
   return gemm16_launch(shape, 0, 1, EPI_NONE, dtype, a, batch, (hipStream_t)stream);
+}
+
+// A 3 x 3 convolution (stride 1, padding 1) of 16-bit maps as one K17 product over k = (tap, channel) on the zero-bordered
+// channels-last rows of csrc/conv_pad.hip (see mbv_conv3x3_gemm32s, csrc/gemm_f32s.hip, for the layout and the data-gradient
+// form): out_rows[m][co] = sum_t sum_ci rows[m + shift_t][ci] wm[co][t C + ci].
+extern "C" int mbv_conv3x3_gemm16(const void* rows, const void* wm, void* out_rows, int64_t batch, int64_t H, int64_t W, int64_t C,
+                                  int64_t cout, int32_t dtype, int32_t out_f32, void* stream) {
+  if (!rows || !wm || !out_rows || batch <= 0 || H <= 0 || W <= 0 || C <= 0 || cout <= 0 || dtype < 0 || dtype > 1)
+    return MBV_ERR_BAD_ARG;
+  if ((C % KB) || (cout & 7)) return MBV_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<size_t>(rows) | reinterpret_cast<size_t>(wm) | reinterpret_cast<size_t>(out_rows)) & 15)
+    return MBV_ERR_UNSUPPORTED;
+  const int64_t G = W + 3, mp = batch * (H + 2) * (W + 2), total = mp + 2 * G;
+  if (total * C * 2 >= 0x7fff0000LL || cout * 9 * C * 2 >= 0x7fff0000LL) return MBV_ERR_UNSUPPORTED;
+  const int shape = gemm16_pick_shape(0, mp, cout, 1);
+  const int BM = SHAPE_BM[shape], BN = SHAPE_BN[shape];
+  GemmArgs a = {};
+  a.a = rows; a.b = wm;
+  a.c = reinterpret_cast<char*>(out_rows) + (size_t)G * (size_t)cout * (out_f32 ? 4 : 2);
+  a.gm = (int)mp; a.gn = (int)cout; a.gk = (int)(9 * C);
+  a.lda = (int)C; a.ldb = (int)(9 * C); a.ldc = (int)cout;
+  a.a_bytes = (unsigned)(total * C * 2); a.b_bytes = (unsigned)(cout * 9 * C * 2);
+  a.ntm = (int)((mp + BM - 1) / BM); a.ntn = (int)((cout + BN - 1) / BN); a.splits = 1; a.ksteps = (int)(9 * C / KB);
+  a.out_f32 = out_f32;
+  a.tap_steps = (int)(C / KB);
+  for (int t = 0; t < 9; ++t) {
+    const int64_t shift = (t / 3 - 1) * (W + 2) + (t % 3 - 1);
+    a.tap[t] = (int)((G + shift - t) * C * 2);          // >= 0: the row of tap t, minus the t C columns k has advanced
+  }
+  return gemm16_launch(shape, 0, 0, EPI_CONV, dtype, a, 1, (hipStream_t)stream);
 }
 
 extern "C" size_t mbv_gemm16_nn_workspace_bytes(int64_t m, int64_t k, int32_t batch) {

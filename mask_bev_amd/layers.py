@@ -220,6 +220,8 @@ class ConvGN(nn.Module):
             y = conv1x1(self.conv, x)
         elif ops.conv3x3_32_ok(x, self.conv):
             y = ops.conv3x3_32(x, self.conv.weight)          # fp32 compute: K20 products instead of MIOpen
+        elif ops.conv3x3_16_ok(x, self.conv):
+            y = ops.conv3x3_16(x, self.conv.weight)          # 16-bit compute: K17 products instead of MIOpen
         else:
             y = self.conv(x)
         if ops.group_norm_supported(y, self.gn.num_groups) and self.gn.weight is not None and \

@@ -1613,6 +1613,85 @@ class _Conv3x3K20(torch.autograd.Function):
         return gx, gw
 
 
+class _Conv3x3K17(torch.autograd.Function):
+    """The same convolution for the 16-bit compute modes: 16-bit rows, K17 products (mbv_conv3x3_gemm16; the weight gradient
+    nine entries of mbv_gemm16_tn_group, f32).  ``x`` f32 or 16-bit (cast to ``dt``), the result and d x in ``dt``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dt):
+        lib = _lib.load()
+        b, c, h, w = x.shape
+        cout = weight.shape[0]
+        ctx.x_dtype = x.dtype
+        x = x.to(dt).contiguous()
+        rows = int(lib.mbv_conv_rows(b, h, w))
+        xp = torch.zeros((rows, c), dtype=dt, device=x.device)
+        check(lib.mbv_conv_pad_rows(_ptr(x), _ptr(xp), b, c, h, w, 2, _stream()), 'mbv_conv_pad_rows')
+        wm = _compute_copy(weight, dt).detach().permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous()
+        outp = torch.empty((rows, cout), dtype=dt, device=x.device)
+        check(lib.mbv_conv3x3_gemm16(_ptr(xp), _ptr(wm), _ptr(outp), b, h, w, c, cout, _GEMM16_DT[dt], 0, _stream()),
+              'mbv_conv3x3_gemm16')
+        y = torch.empty((b, cout, h, w), dtype=dt, device=x.device)
+        check(lib.mbv_conv_unpad_rows(_ptr(outp), _ptr(y), b, cout, h, w, 2, _stream()), 'mbv_conv_unpad_rows')
+        ctx.save_for_backward(xp, weight)
+        ctx.dims, ctx.dt = (b, c, h, w, cout), dt
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        xp, weight = ctx.saved_tensors
+        b, c, h, w, cout = ctx.dims
+        dt = ctx.dt
+        rows = xp.shape[0]
+        guard, mp = w + 3, b * (h + 2) * (w + 2)
+        gy = gy.to(dt).contiguous()
+        gyp = torch.zeros((rows, cout), dtype=dt, device=gy.device)
+        check(lib.mbv_conv_pad_rows(_ptr(gy), _ptr(gyp), b, cout, h, w, 2, _stream()), 'mbv_conv_pad_rows')
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wflip = _compute_copy(weight, dt).detach().flip(2, 3).permute(1, 2, 3, 0).reshape(c, 9 * cout).contiguous()
+            gxp = torch.empty((rows, c), dtype=dt, device=gy.device)
+            check(lib.mbv_conv3x3_gemm16(_ptr(gyp), _ptr(wflip), _ptr(gxp), b, h, w, cout, c, _GEMM16_DT[dt], 0, _stream()),
+                  'mbv_conv3x3_gemm16')
+            gx = torch.empty((b, c, h, w), dtype=dt, device=gy.device)
+            check(lib.mbv_conv_unpad_rows(_ptr(gxp), _ptr(gx), b, c, h, w, 2, _stream()), 'mbv_conv_unpad_rows')
+            gx = gx.to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dwm = torch.zeros((9, cout, c), dtype=torch.float32, device=gy.device)
+            g2 = gyp[guard:guard + mp]
+            items = []
+            for t in range(9):
+                sh = guard + (t // 3 - 1) * (w + 2) + (t % 3 - 1)
+                items.append((g2, xp[sh:sh + mp], dwm[t]))
+            gemm16_tn_group(items)
+            gw = dwm.permute(1, 2, 0).reshape(cout, c, 3, 3)
+            if (getattr(weight, '_mbv_arena', False) and weight.grad is not None and weight.grad.dtype == torch.float32):
+                weight.grad.add_(gw)
+                _fire_grad_hooks(weight)
+                gw = None
+            else:
+                gw = gw.to(weight.dtype)
+        return gx, gw, None
+
+
+def conv3x3_16_ok(x: torch.Tensor, conv) -> bool:
+    """A 16-bit compute mode (autocast to bf16 / fp16, or 16-bit tensors), a 3 x 3 stride-1 padding-1 convolution without bias
+    whose channel counts K17 takes."""
+    if not (switches.get('conv3x3_k17') and gemm16_enabled() and x.is_cuda and x.dim() == 4):
+        return False
+    dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    return bool(dt in _GEMM16_DT and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros'
+                and x.shape[1] % 32 == 0 and conv.weight.shape[0] % 32 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 1024)
+
+
+def conv3x3_16(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+    with torch.autocast('cuda', enabled=False):
+        return _Conv3x3K17.apply(x, weight, dt)
+
+
 def conv3x3_32_ok(x: torch.Tensor, conv) -> bool:
     """fp32 compute, a 3 x 3 stride-1 padding-1 convolution without bias whose channel counts K20 takes."""
     return bool(switches.get('conv3x3_k20') and switches.get('gemm32s') and x.is_cuda and x.dtype == torch.float32

@@ -47,6 +47,7 @@ _DEFAULTS: Dict[str, Any] = {
     'ffn32': True,                # fp32 compute: the FFN pair on K20 with the activation / its derivative in the GEMM epilogues
     'k4_split': True,             # fp32 compute: K4's products on the 16-bit matrix pipe from IEEE-half pairs (f32 tensors)
     'conv3x3_k20': True,          # fp32 compute: the pixel decoder's 3 x 3 convolution as K20 products on a zero-bordered channels-last copy (no MIOpen)
+    'conv3x3_k17': True,          # 16-bit compute: the same convolution as K17 products
     'tn32_group': True,           # fp32 compute: the few-row weight gradients of a backward pass as one grouped K20 launch
     'gemm32s_min': 1024,          # fewest tokens of an f32 Linear that takes K20 (below: the library's f32 GEMM; measured: scratch/bench_gemm32s.py)
     'k7_f32_library': True,       # fp32 mask logits through the library's batched GEMM instead of K7's exact-f32 kernel

@@ -414,6 +414,9 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_conv3x3_gemm32s': lambda a: ('k_gemm32s<NT,conv3x3>', 'mfma',
                                       (_i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * (_i(a[6]) + _i(a[7])) + 9 * _i(a[6]) * _i(a[7])) * 4.0,
                                       2.0 * _i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * _i(a[7]) * 9 * _i(a[6])),
+    'mbv_conv3x3_gemm16': lambda a: ('k_gemm16<NT,conv3x3>', 'mfma',
+                                     (_i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * (_i(a[6]) + _i(a[7])) + 9 * _i(a[6]) * _i(a[7])) * 2.0,
+                                     2.0 * _i(a[3]) * (_i(a[4]) + 2) * (_i(a[5]) + 2) * _i(a[7]) * 9 * _i(a[6])),
     'mbv_conv_pad_rows': lambda a: ('k_conv_pad_rows', 'hbm', 2.0 * _i(a[2]) * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]), 0.0),
     'mbv_conv_unpad_rows': lambda a: ('k_conv_pad_rows', 'hbm', 2.0 * _i(a[2]) * _i(a[3]) * _i(a[4]) * _i(a[5]) * _i(a[6]), 0.0),
     'mbv_gemm32s_tn_group': lambda a: ('k_gemm32s_tn_group', 'mfma',

@@ -367,3 +367,34 @@ def test_conv1x1_of_a_channels_last_view(bias, autocast):
     tol = 2e-4 if autocast is None else 2e-2
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + tol * 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('b,c,cout,h,w', [(2, 32, 64, 24, 23), (4, 256, 256, 32, 32)])
+def test_conv3x3_on_k17_matches_float64(dtype, b, c, cout, h, w):
+    """The 3 x 3 convolution of the 16-bit compute modes as K17 products on zero-bordered channels-last rows
+    (mbv_conv3x3_gemm16; the weight gradient as nine grouped TN entries) against the float64 convolution of the same 16-bit
+    operands: output and input gradient within the 16-bit storage rounding, the f32 weight gradient within 1e-3 (bf16 dy)."""
+    from mask_bev_amd import ops
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(c + h)
+    conv = torch.nn.Conv2d(c, cout, 3, padding=1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.to(dtype).float())
+    x = torch.randn(b, c, h, w, generator=g).to(dtype).to(dev).requires_grad_()
+    gy = (torch.randn(b, cout, h, w, generator=g) * 1e-2).to(dtype).to(dev)
+    assert ops.conv3x3_16_ok(x, conv)
+    y = ops.conv3x3_16(x, conv.weight)
+    assert y.dtype == dtype
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(), conv.weight.detach().double().requires_grad_()
+    ref = torch.nn.functional.conv2d(xd, wd, padding=1)
+    ref.backward(gy.double())
+
+    def err(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert err(y.detach(), ref.detach()) <= 1.5 * eps
+    assert err(x.grad, xd.grad) <= 1.5 * eps
+    assert err(conv.weight.grad, wd.grad) <= 1e-3
