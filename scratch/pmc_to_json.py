@@ -16,7 +16,8 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_gn_fwd', r'k_gn_apply', [r'k_gn_stats']),
     ('k_gn_bwd', r'k_gn_bwd_dx', [r'k_gn_bwd_sums']),
     ('k_gemm16<NN>', r'k_gemm16I.*Lb0ELb1ELi0E', [r'k_sum_rows']),
-    ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0E', []),
+    ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0ELi[0-4]E', []),
+    ('k_gemm16<NT,conv3x3>', r'k_gemm16I.*Lb0ELb0ELi0ELi5E', []),
     # K20 (fp32 runs): template arguments <A_KS, B_KS, EPI, GATHER>
     ('k_gemm32s<NT>', r'k_gemm32sILb0ELb0ELi[012]ELi0E', []),
     ('k_gemm32s<NT,patch>', r'k_gemm32sILb0ELb0ELi0ELi1E', []),
