@@ -956,6 +956,13 @@ int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64_t k);
 int mbv_f32_absmax_group(const float* const* x, const int64_t* rows, const int64_t* cols, const int64_t* ld,
                          uint32_t* const* out, int32_t count, void* stream);
 
+/* Absmax BOUNDS of LayerNorm outputs without a pass over them: y = xhat gamma + beta with |xhat| <= sqrt(C - 1), so word 0 of
+ * records[i] (64 words, cleared by the caller once) receives the bits of sqrt(c[i]) max|gamma[i]| + max|beta[i]| (beta[i] may be
+ * NULL) — ~ 3x above the true maximum of a 65 536 x 192 map, well inside the 18 binades a K20 operand keeps at full precision.
+ * One workgroup per LayerNorm, 96 per launch; HOST arrays of length count. */
+int mbv_ln_bound_group(const float* const* gamma, const float* const* beta, const int32_t* c, uint32_t* const* records,
+                       int32_t count, void* stream);
+
 /* out (m, n) = act(x (m, k) . w (n, k)^T + bias)                                   (nn.Linear forward) */
 int mbv_gemm32s_nt(const float* x, const float* w, const float* bias, float* out, float* out_pre, int64_t m, int64_t n,
                    int64_t k, int64_t ldx, int64_t ldw, int64_t ldo, const uint32_t* amax_x, const uint32_t* amax_w,

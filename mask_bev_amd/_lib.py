@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 52
+ABI_VERSION = 53
 
 
 class MaskBevHipError(RuntimeError):
@@ -155,6 +155,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_gemm32s_nn_act': (ctypes.c_int, [_P, _P, _P, _P, _P, c_size_t, _L, _L, _L, _L, _L, _L, _L, _P, _P, _P, _I, _P]),
     'mbv_gemm32s_tn_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, c_size_t, _P]),
     'mbv_gemm32s_tn_group_workspace_bytes': (c_size_t, [_P, _P, _P, _I]),
+    'mbv_ln_bound_group': (ctypes.c_int, [_P, _P, _P, _P, _I, _P]),
     'mbv_conv_rows': (ctypes.c_int64, [_L, _L, _L]),
     'mbv_conv_pad_rows': (ctypes.c_int, [_P, _P, _L, _L, _L, _L, _I, _P]),
     'mbv_conv_unpad_rows': (ctypes.c_int, [_P, _P, _L, _L, _L, _L, _I, _P]),

@@ -640,6 +640,67 @@ extern "C" int mbv_gemm32s_supported(int32_t layout, int64_t m, int64_t n, int64
   return fits32(m, n > k ? n : k) ? 1 : 0;
 }
 
+// ---- absmax BOUNDS of LayerNorm outputs ------------------------------------------------------------------------------------
+// y = xhat * gamma + beta with |xhat| <= sqrt(C - 1): the record of y holds the bits of sqrt(C) max|gamma| + max|beta| — a bound
+// ~ 3x above the true maximum of a 65 536 x 192 map (1.6 of the 18 binades a K20 operand keeps at full precision) that costs
+// two reductions over C elements instead of a pass over the map.  One workgroup per LayerNorm, up to kLnBoundGroup per launch;
+// only word 0 of the record is written (the others stay as the caller zeroed them).
+constexpr int kLnBoundGroup = 96;
+struct LnBoundEntry {
+  const float* gamma; const float* beta; unsigned* out;
+  int c;
+};
+struct LnBoundArgs {
+  LnBoundEntry e[kLnBoundGroup];
+};
+
+namespace {
+__global__ void __launch_bounds__(256) k_ln_bound_group(const LnBoundArgs a) {
+  __shared__ float red[8];
+  const LnBoundEntry& e = a.e[blockIdx.x];
+  float mg = 0.f, mb = 0.f;
+  for (int i = threadIdx.x; i < e.c; i += 256) {
+    mg = fmaxf(mg, fabsf(e.gamma[i]));
+    if (e.beta) mb = fmaxf(mb, fabsf(e.beta[i]));
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    mg = fmaxf(mg, __shfl_xor(mg, sft, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, sft, 64));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wave] = mg; red[4 + wave] = mb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mg = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mb = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float bound = sqrtf((float)e.c) * mg + mb;
+    e.out[0] = __float_as_uint(bound) & 0x7fffffffu;      // (NaN / inf parameters give a NaN / inf bound: the consumer clamps)
+  }
+}
+}  // namespace
+
+// records[i][0] = bits of sqrt(c[i]) max|gamma[i]| + max|beta[i]| (beta[i] may be NULL) for i < count; HOST arrays
+extern "C" int mbv_ln_bound_group(const float* const* gamma, const float* const* beta, const int32_t* c, uint32_t* const* records,
+                                  int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && (!gamma || !c || !records))) return MBV_ERR_BAD_ARG;
+  for (int i = 0; i < count; ++i)
+    if (!gamma[i] || !records[i] || c[i] <= 0) return MBV_ERR_BAD_ARG;
+  for (int base = 0; base < count; base += kLnBoundGroup) {
+    const int cnt = count - base < kLnBoundGroup ? count - base : kLnBoundGroup;
+    LnBoundArgs a;
+    for (int j = 0; j < cnt; ++j) {
+      a.e[j].gamma = gamma[base + j];
+      a.e[j].beta = beta ? beta[base + j] : nullptr;
+      a.e[j].out = records[base + j];
+      a.e[j].c = c[base + j];
+    }
+    hipLaunchKernelGGL(k_ln_bound_group, dim3((unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a);
+    MBV_CHECK_LAUNCH();
+  }
+  return MBV_OK;
+}
+
 // max|x| of `count` f32 tensors (rows[i], cols[i]) with row stride ld[i] (cols % 4 == 0, 16-byte aligned rows), as the BITS
 // of the maximum, max-combined into the kAmaxSlots (64) words at out[i]: they must hold 0 (or earlier partial maxima) when
 // the launch starts; the maximum over the 64 words is the result.  Every array argument is a HOST array of length count; one launch per 64 tensors.

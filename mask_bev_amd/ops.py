@@ -1349,17 +1349,81 @@ def note_parameters_changed() -> None:
     _WEIGHT_AMAX.clear()
 
 
+_WEIGHT_REG: dict = {}          # key -> weak reference: every weight K20 has asked a record for (the grouped refresh's list)
+_LN_REG: dict = {}              # gamma's address -> [gamma ref, beta ref or None, record, tag]
+
+
+def _amax_tag(dev):
+    return (PARAM_EPOCH[0], torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream(dev).cuda_stream)
+
+
 def weight_amax(w: torch.Tensor) -> torch.Tensor:
+    """The absmax record of a weight, good until the parameters change.  A miss refreshes the records of EVERY weight seen so
+    far in one launch per 64 (they all went stale together, with the optimizer step): ~ 30 single launches per step otherwise."""
+    import weakref
     key = (w.data_ptr(), tuple(w.shape), w.stride(0))
-    tag = (PARAM_EPOCH[0], w._version, torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream(w.device).cuda_stream)
+    tag = _amax_tag(w.device)
     e = _WEIGHT_AMAX.get(key)
-    if e is not None and e[0] == tag:
+    if e is not None and e[0] == (tag, w._version):
         return e[1]
-    rec = f32_absmax([w])
-    if len(_WEIGHT_AMAX) > 2048:
+    _WEIGHT_REG[key] = weakref.ref(w)
+    todo = []
+    for k2, ref in list(_WEIGHT_REG.items()):
+        t = ref()
+        if t is None or (t.data_ptr(), tuple(t.shape), t.stride(0)) != k2 or t.device != w.device:
+            if t is None:
+                del _WEIGHT_REG[k2]
+            continue
+        e2 = _WEIGHT_AMAX.get(k2)
+        if e2 is None or e2[0] != (tag, t._version):
+            todo.append((k2, t))
+    if len(_WEIGHT_AMAX) > 4096:
         _WEIGHT_AMAX.clear()
-    _WEIGHT_AMAX[key] = (tag, rec)
-    return rec
+    for c in range(0, len(todo), 64):
+        chunk = todo[c:c + 64]
+        recs = f32_absmax([t for _, t in chunk])
+        for i, (k2, t) in enumerate(chunk):
+            _WEIGHT_AMAX[k2] = ((tag, t._version), recs[i:i + 1])
+    return _WEIGHT_AMAX[key][1]
+
+
+def ln_bound(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The absmax-BOUND record of a LayerNorm's output, sqrt(C) max|weight| + max|bias| (mbv_ln_bound_group), good until the
+    parameters change; a miss refreshes every LayerNorm seen so far in one launch."""
+    import weakref
+    if (not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous()
+            or (bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != weight.numel()))):
+        return None
+    tag = _amax_tag(weight.device)
+    key = weight.data_ptr()
+
+    e = _LN_REG.get(key)
+    if e is not None and e[3] == (tag, weight._version, None if bias is None else bias._version) and e[0]() is weight:
+        return e[2]
+    _LN_REG[key] = [weakref.ref(weight), None if bias is None else weakref.ref(bias), amax_record(weight.device), None]
+    todo = []
+    for k2, e2 in list(_LN_REG.items()):
+        g = e2[0]()
+        b = e2[1]() if e2[1] is not None else None
+        if g is None or g.data_ptr() != k2 or (e2[1] is not None and b is None) or g.device != weight.device:
+            del _LN_REG[k2]
+            continue
+        t2 = (tag, g._version, None if b is None else b._version)
+        if e2[3] != t2:
+            # a record that a captured launch wrote must not be rewritten eagerly (and vice versa): a fresh one per refresh
+            e2[2] = amax_record(g.device)
+            todo.append((e2, g, b, t2))
+    if todo:
+        lib = _lib.load()
+        n = len(todo)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+        check(lib.mbv_ln_bound_group(PA(*[g.data_ptr() for _, g, _, _ in todo]),
+                                     PA(*[(0 if b is None else b.data_ptr()) for _, _, b, _ in todo]),
+                                     IA(*[g.numel() for _, g, _, _ in todo]), PA(*[e2[2].data_ptr() for e2, _, _, _ in todo]),
+                                     n, _stream()), 'mbv_ln_bound_group')
+        for e2, _, _, t2 in todo:
+            e2[3] = t2
+    return _LN_REG[key][2]
 
 
 def _gemm32s_ok(*ts: torch.Tensor) -> bool:
@@ -3396,6 +3460,13 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
     if out_dtype is None:
         out_dtype = torch.float32
     y, s, y2 = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias, fanout, branch_dtype)
+    if (out_dtype == torch.float32 and y.is_cuda and switches.get('amax_hints') and switches.get('ln_bound_hints')
+            and amax_hint_wanted(y.numel() // y.shape[-1])):
+        # fp32 compute: the consuming K20 product takes its scale from the LayerNorm's parameters, not from a pass over y
+        rec = ln_bound(weight, bias)
+        amax_hint_set(y, rec)
+        if fanout and y2 is not None and y2.dtype == torch.float32:
+            amax_hint_set(y2, rec)
     if fanout:
         return y, y2
     return (y, a if s is None else s) if return_sum else y
@@ -3648,7 +3719,11 @@ def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, e
                     out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """(B, H, W, C) f32 → (B, H/2, W/2, 4C): the 2 x 2 neighbourhood concat of patch merging (channel order
     ``c*4 + kh*2 + kw``) and its LayerNorm in one pass (K12 with gather addressing)."""
-    return _MergeLayerNorm.apply(x, weight, bias, eps, out_dtype or torch.float32)
+    y = _MergeLayerNorm.apply(x, weight, bias, eps, out_dtype or torch.float32)
+    if (y.dtype == torch.float32 and y.is_cuda and switches.get('amax_hints') and switches.get('ln_bound_hints')
+            and amax_hint_wanted(y.numel() // y.shape[-1])):
+        amax_hint_set(y, ln_bound(weight, bias))
+    return y
 
 
 @torch.no_grad()

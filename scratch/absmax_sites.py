@@ -1,0 +1,21 @@
+"""Which call sites still run an absmax pass in the fp32 step (after the hints), with the bytes they read (eager step)."""
+import sys, os, collections, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mask_bev_amd import ops
+sites, byts = collections.Counter(), collections.Counter()
+orig = ops.f32_absmax
+def spy(tensors):
+    st = traceback.extract_stack(limit=5)
+    key = ' < '.join(f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in reversed(st[:-1]))[:150]
+    sites[key] += 1
+    byts[key] += sum(t.numel() * 4 for t in tensors)
+    return orig(tensors)
+ops.f32_absmax = spy
+import bench
+sys.argv = ['bench.py', '--dtype', 'fp32', '--steps', '2', '--warmup', '1', '--no-graph', '--no-cpu-baseline', '--no-fp32', '--no-kernel-profile']
+bench.main()
+n = 3
+print('absmax passes per step by call site (launches, MB):')
+for k, v in sorted(byts.items(), key=lambda kv: -kv[1]):
+    print(f'  {sites[k] / n:6.1f}  {v / n / 1e6:8.1f} MB  {k}')

@@ -393,3 +393,44 @@ def test_conv3x3_on_k20_matches_float64(b, c, cout, h, w):
                                  ('dw', gw, wd.grad, conv.weight.grad)):
         e, le = _err(mine, r), _err(lib_v, r)
         assert e <= max(2e-6, 2 * le), (name, e, le)
+
+
+@gpu
+def test_layernorm_output_bound_records():
+    """ops.ln_bound: word 0 of the record is the bits of sqrt(C) max|gamma| + max|beta| — never below the true maximum of the
+    LayerNorm's output, for any input — refreshed (for every LayerNorm seen so far, in one launch) when the parameters change;
+    a K20 Linear that finds it as its input's hint stays within the usual 2e-6 of the float64 product."""
+    import math
+    from mask_bev_amd import ops, switches
+    lns = [torch.nn.LayerNorm(c).to(_dev()) for c in (192, 768, 1536)]
+    for i, ln in enumerate(lns):
+        with torch.no_grad():
+            ln.weight.copy_(_rand((ln.weight.numel(),), 40 + i, 2.0))
+            ln.bias.copy_(_rand((ln.bias.numel(),), 50 + i, 0.3))
+    recs = [ops.ln_bound(ln.weight, ln.bias) for ln in lns]
+    for ln, rec in zip(lns, recs):
+        c = ln.weight.numel()
+        want = math.sqrt(c) * float(ln.weight.abs().max()) + float(ln.bias.abs().max())
+        got = float(rec.max().view(torch.float32))
+        assert abs(got - want) <= 1e-5 * want
+        x = _rand((4096, c), 60, 1.0)
+        x[7] = 0.0
+        x[7, 3] = 1e4                                 # one spike per row: xhat reaches sqrt(C - 1)
+        y = torch.nn.functional.layer_norm(x, (c,), ln.weight, ln.bias)
+        assert float(y.abs().max()) <= got
+    assert ops.ln_bound(lns[0].weight, lns[0].bias) is recs[0]          # cached until the parameters change
+    with torch.no_grad():
+        lns[1].weight.mul_(3.0)
+    ops.note_parameters_changed()
+    r1 = ops.ln_bound(lns[1].weight, lns[1].bias)
+    want = math.sqrt(768) * float(lns[1].weight.abs().max()) + float(lns[1].bias.abs().max())
+    assert abs(float(r1.max().view(torch.float32)) - want) <= 1e-5 * want
+    # through the op: K12's output carries the bound, the Linear behind it uses it
+    with switches.override(amax_hints=True, ln_bound_hints=True):
+        x = _rand((2048, 192), 70)
+        y = ops.add_layernorm(x, None, lns[0].weight, lns[0].bias)
+        assert ops.amax_hint_get(y) is not None
+        w = _rand((576, 192), 71, 0.05)
+        out = ops.linear(y, w, None)
+        ref = y.double() @ w.double().t()
+        assert _err(out, ref) <= 2e-6
