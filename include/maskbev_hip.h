@@ -602,6 +602,14 @@ int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const void* dy2, int
                            int64_t rows, int32_t C, float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma,
                            float* dbeta, int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce,
                            void* stream);
+/* mbv_add_layernorm_bwd2 with amax_dx: an optional absmax record (64 zeroed words, mbv_f32_absmax_group's format) that receives the
+ * bits of max|dx| — one max-combine per block — so that the K20 products of the Linear backward that takes dx as its output
+ * gradient need no pass over it (fp32 compute). */
+int mbv_add_layernorm_bwd3(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
+                           int32_t ds_bf16, const float* s, const float* mean, const float* rstd, const float* gamma,
+                           int64_t rows, int32_t C, float* dx, void* dx_lo, int32_t dx_lo_dtype, float* dgamma, float* dbeta,
+                           int32_t accumulate, float* dbranch_bias, float* partial_ws, int32_t defer_reduce, uint32_t* amax_dx,
+                           void* stream);
 /* 1 = the backward of (rows, C) adds the parameter gradients from inside its one kernel; 0 = it writes per-block
  * partial rows (nblk = mbv_add_layernorm_bwd_blocks, layout [nblk][np][C], np = 3 with dbranch_bias else 2) and reduces
  * them with a second launch — unless defer_reduce != 0 (accumulating callers only), in which case the caller adds

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 53
+ABI_VERSION = 54
 
 
 class MaskBevHipError(RuntimeError):
@@ -100,6 +100,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                              _I, _P]),
     'mbv_add_layernorm_bwd2': (ctypes.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P,
                                               _P, _I, _P]),
+    'mbv_add_layernorm_bwd3': (ctypes.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _I, _P,
+                                              _P, _I, _P, _P]),
     'mbv_add_layernorm_bwd_direct': (ctypes.c_int, [_L, _I]),
     'mbv_merge_layernorm_supported': (ctypes.c_int, [_I, _I, _I]),
     'mbv_merge_layernorm_fwd': (ctypes.c_int, [_P, _L, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),

@@ -150,6 +150,8 @@ struct LnBwdIo {
   int np;                            // 2, or 3 when the column sums of dx are wanted too (the bias gradient of
                                      // the Linear that produced the residual branch: d(branch) = dx)
   MergeGeom mg;                      // mg.on: s is the f32 (B, H, W, C) map of the forward, dx has its layout
+  unsigned* amax_dx;                 // optional absmax record (64 words) of dx: one max-combine per block (fp32 compute: the
+                                     // Linear backward that takes dx as its output gradient runs on K20, csrc/gemm_f32s.hip)
 };
 
 // Wide rows (ITERS >= 4, C > 512) add their column sums to the block's LDS accumulators ROW BY ROW instead of keeping
@@ -168,6 +170,7 @@ __global__ void __launch_bounds__(512, (ITERS == 4 ? 4 : 1)) k_add_ln_bwd(LnBwdI
   float4 dg[ITERS], db[ITERS], dxs[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) dg[i] = db[i] = dxs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dmax = 0.f;
   float4 gam[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
@@ -222,6 +225,7 @@ __global__ void __launch_bounds__(512, (ITERS == 4 ? 4 : 1)) k_add_ln_bwd(LnBwdI
         }
         if (io.mg.on) merge_store(io.dx, io.mg, row, v, d);
         else *reinterpret_cast<float4*>(io.dx + base + 4 * v) = d;
+        dmax = fmaxf(dmax, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
         if (io.dx_lo) store4(io.dx_lo, io.dx_lo_kind, base + 4 * v, d);
         if (ROW_LDS) {
           if (np == 3) {
@@ -250,6 +254,18 @@ __global__ void __launch_bounds__(512, (ITERS == 4 ? 4 : 1)) k_add_ln_bwd(LnBwdI
     }
   }
   __syncthreads();
+  if (io.amax_dx) {                   // the waves' maxima meet in LDS: ONE no-return atomic per block
+    __shared__ float wmax[8];
+    dmax = wave_max(dmax);
+    if (lane == 0) wmax[wave] = dmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = wmax[0];
+      for (int i = 1; i < 8; ++i) m = fmaxf(m, wmax[i]);
+      const unsigned bits = __float_as_uint(m) & 0x7fffffffu;
+      if (bits) atomicMax(io.amax_dx + (blockIdx.x & 63), bits);
+    }
+  }
   if (io.partial) {
     float* prow = io.partial + (long)blockIdx.x * np * C;
     for (int i = threadIdx.x; i < np * C; i += 512) prow[i] = (float)red[i];
@@ -444,11 +460,13 @@ static int add_ln_bwd_launch(LnBwdIo io, int it, int64_t rows, int32_t C, int32_
 
 // dy2 (nullable, dy2_dtype): a second gradient of y, added to dy on load — a post-LN output that feeds both the next
 // residual add and the next branch hands its two gradients over separately instead of through an autograd add launch
-extern "C" int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
+// (bwd3: the same with amax_dx — an optional absmax record, 64 zeroed words, that receives the bits of max|dx|)
+extern "C" int mbv_add_layernorm_bwd3(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
                                       int32_t ds_bf16, const float* s, const float* mean, const float* rstd,
                                       const float* gamma, int64_t rows, int32_t C, float* dx, void* dx_lo,
                                       int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
-                                      float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream) {
+                                      float* dbranch_bias, float* partial_ws, int32_t defer_reduce, uint32_t* amax_dx,
+                                      void* stream) {
   const int it = C <= 2048 ? iters_for(C) : 0;
   if (!it) return MBV_ERR_UNSUPPORTED;
   if (rows < 0) return MBV_ERR_BAD_ARG;
@@ -464,8 +482,17 @@ extern "C" int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const voi
   if (!dy || !s || !mean || !rstd || !gamma || !dx || !partial_ws) return MBV_ERR_BAD_ARG;
   if (dx_lo && dx_lo_dtype != MBV_DT_BF16 && dx_lo_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
   LnBwdIo io{dy, dy_bf16, dy2, dy2_dtype, ds, ds_bf16, s, mean, rstd, gamma, dx, dx_lo, dx_lo_dtype, nullptr,
-             dgamma, dbeta, dbranch_bias, dbranch_bias ? 3 : 2, MergeGeom{}};
+             dgamma, dbeta, dbranch_bias, dbranch_bias ? 3 : 2, MergeGeom{}, amax_dx};
   return add_ln_bwd_launch(io, it, rows, C, accumulate, partial_ws, defer_reduce, st);
+}
+
+extern "C" int mbv_add_layernorm_bwd2(const void* dy, int32_t dy_bf16, const void* dy2, int32_t dy2_dtype, const void* ds,
+                                      int32_t ds_bf16, const float* s, const float* mean, const float* rstd,
+                                      const float* gamma, int64_t rows, int32_t C, float* dx, void* dx_lo,
+                                      int32_t dx_lo_dtype, float* dgamma, float* dbeta, int32_t accumulate,
+                                      float* dbranch_bias, float* partial_ws, int32_t defer_reduce, void* stream) {
+  return mbv_add_layernorm_bwd3(dy, dy_bf16, dy2, dy2_dtype, ds, ds_bf16, s, mean, rstd, gamma, rows, C, dx, dx_lo, dx_lo_dtype,
+                                dgamma, dbeta, accumulate, dbranch_bias, partial_ws, defer_reduce, nullptr, stream);
 }
 
 extern "C" int mbv_add_layernorm_bwd(const void* dy, int32_t dy_bf16, const void* ds, int32_t ds_bf16, const float* s,

@@ -3339,14 +3339,18 @@ class _AddLayerNorm(torch.autograd.Function):
         # end of the backward pass instead of one reduction launch per layer
         np_ = 3 if bb is not None else 2
         defer = bool(direct and not lib.mbv_add_layernorm_bwd_direct(rows, c) and _defer_ok())
-        check(lib.mbv_add_layernorm_bwd2(_ptr(gy), _dt_flag(gy.dtype), _ptr(gy2),
+        # fp32 compute: dx is the output gradient of a Linear backward on K20 — its absmax record from this launch
+        rec = (amax_record(s.device) if (lo is None and switches.get('amax_hints') and switches.get('ln_bound_hints')
+                                         and amax_hint_wanted(rows)) else None)
+        check(lib.mbv_add_layernorm_bwd3(_ptr(gy), _dt_flag(gy.dtype), _ptr(gy2),
                                          (_dt_flag(gy2.dtype) if gy2 is not None else 0), _ptr(gs),
                                          (_dt_flag(gs.dtype) if gs is not None else 0), _ptr(s), _ptr(mean),
                                          _ptr(rstd), _ptr(w), rows, c, _ptr(dx), _ptr(dx_lo),
                                          _dt_flag(lo) if lo is not None else 0, _ptr(dgamma), _ptr(dbeta),
                                          1 if direct else 0, _ptr(None if bb is None else bb.grad), _ptr(ws),
-                                         1 if defer else 0, _stream()),
-              'mbv_add_layernorm_bwd2')
+                                         1 if defer else 0, _ptr(rec), _stream()),
+              'mbv_add_layernorm_bwd3')
+        amax_hint_set(dx, rec)
         if defer:
             for j, dst in enumerate((dgamma, dbeta, None if bb is None else bb.grad)[:np_]):
                 if not _defer_colsum(ws, dst, nblk, c, np_ * c, offset=j * c):

@@ -362,6 +362,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
                                                  (_i(a[1]) + 2.0) * _i(a[2]) * _i(a[3]) * 4.0, 0.0),
     'mbv_add_layernorm_bwd': lambda a: _add_ln(a, True),
     'mbv_add_layernorm_bwd2': lambda a: _add_ln_bwd2(a),
+    'mbv_add_layernorm_bwd3': lambda a: _add_ln_bwd2(a),
     # importance sampling: every row's (H, W) f32 map is read once; the 3x over-sampled candidates never touch HBM
     'mbv_sample_select_uncertain': lambda a: ('k_sample_select', 'hbm',
                                               _i(a[4]) * (_i(a[7]) * _i(a[8]) * 4.0 + _i(a[6]) * 8.0), 0.0),
