@@ -1283,6 +1283,26 @@ def f32_absmax(tensors) -> torch.Tensor:
     return out
 
 
+def operand_amax(tensors, activations=None):
+    """One-record tensors for the f32 matrices ``tensors``.  For the ACTIVATIONS among them (``activations[i]``; default: all)
+    the record a producer — or an earlier product that read the same tensor — left as a hint is taken when there is one, and
+    a record computed here is left as a hint in turn: the data gradient and the weight gradient of a layer read the same
+    output gradient, a forward product and the weight gradient the same input (``switches.amax_hints``; a tensor rewritten
+    through torch bumps its version and loses the hint).  Weights never take part: the optimizer rewrites them through raw
+    pointers (their records are :func:`weight_amax`'s, keyed by the optimizer epoch).  One absmax launch for what is left."""
+    hints = bool(switches.get('amax_hints'))
+    act = [True] * len(tensors) if activations is None else list(activations)
+    recs = [amax_hint_get(t) if (hints and a) else None for t, a in zip(tensors, act)]
+    todo = [i for i, r in enumerate(recs) if r is None]
+    if todo:
+        new = f32_absmax([tensors[i] for i in todo])
+        for j, i in enumerate(todo):
+            recs[i] = new[j:j + 1]
+            if hints and act[i]:
+                amax_hint_set(tensors[i], recs[i])
+    return recs
+
+
 # Absmax HINTS: K20's epilogue can max-combine the values it stores into a record while they are in its registers, and the
 # wrappers carry that record — or a bound derived from it: |gelu(z)| <= |z|, a window-attention output is a convex combination
 # of v rows, |act'| <= 1.13 — to the next K20 product that reads the tensor (fc2's input behind fc1 + GELU, proj's input
@@ -1314,14 +1334,23 @@ def amax_hint_refresh(t) -> None:
 
 def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
     e = _AMAX_HINTS.get(t.data_ptr())
-    if e is None:
-        return None
-    ref, version, rec = e
-    src = ref()
-    if (src is None or src.data_ptr() != t.data_ptr() or src.numel() != t.numel() or src._version != version
-            or rec.device != t.device):
-        return None
-    return rec
+    if e is not None:
+        ref, version, rec = e
+        src = ref()
+        if (src is not None and src.data_ptr() == t.data_ptr() and src.numel() == t.numel() and src._version == version
+                and rec.device == t.device):
+            return rec
+    # a slice (column block, row range) of a hinted tensor: the whole tensor's record bounds it
+    base = t._base
+    if base is not None and base is not t and base.dtype == t.dtype:
+        e = _AMAX_HINTS.get(base.data_ptr())
+        if e is not None:
+            ref, version, rec = e
+            src = ref()
+            if (src is not None and src.data_ptr() == base.data_ptr() and src.numel() == base.numel()
+                    and src._version == version and rec.device == t.device):
+                return rec
+    return None
 
 
 def _hinted_view(t: torch.Tensor, shape) -> torch.Tensor:
@@ -1454,7 +1483,7 @@ def gemm32s_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16):
         raise MaskBevHipError('gemm32s_nt: bias must be contiguous f32, 16-byte aligned')
     if amax is None:
-        amax = f32_absmax([x, w])
+        amax = tuple(operand_amax([x, w], (True, False)))
     m, k = x.shape
     n = w.shape[0]
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
@@ -1473,10 +1502,10 @@ def gemm32s_nn(g: torch.Tensor, w: torch.Tensor, amax_g: Optional[torch.Tensor] 
     lib = _lib.load()
     if not _gemm32s_ok(g, w) or g.shape[1] != w.shape[0]:
         raise MaskBevHipError('gemm32s_nn: unsupported operands')
-    if amax_g is None:
-        amax_g = f32_absmax([g])
-    if amax_w is None:
-        amax_w = f32_absmax([w])
+    if amax_g is None or amax_w is None:
+        both = operand_amax([g, w], (True, False))
+        amax_g = both[0] if amax_g is None else amax_g
+        amax_w = both[1] if amax_w is None else amax_w
     m, n = g.shape
     k = w.shape[1]
     out = torch.empty((m, k), dtype=torch.float32, device=g.device)
@@ -1494,10 +1523,10 @@ def gemm32s_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, amax_g: 
     if (not _gemm32s_ok(g, x) or g.shape[0] != x.shape[0] or acc.dtype != torch.float32 or not acc.is_contiguous()
             or tuple(acc.shape) != (g.shape[1], x.shape[1]) or acc.data_ptr() % 16):
         raise MaskBevHipError('gemm32s_tn_acc: unsupported operands')
-    if amax_g is None:
-        amax_g = f32_absmax([g])
-    if amax_x is None:
-        amax_x = f32_absmax([x])
+    if amax_g is None or amax_x is None:
+        both = operand_amax([g, x])
+        amax_g = both[0] if amax_g is None else amax_g
+        amax_x = both[1] if amax_x is None else amax_x
     m, n = g.shape
     k = x.shape[1]
     nbytes = lib.mbv_gemm32s_tn_workspace_bytes(m, n, k)
@@ -1595,6 +1624,12 @@ def gemm32s_tn_group(items) -> None:
             raise MaskBevHipError('gemm32s_tn_group: unsupported operands')
     need = [(i, j) for i, it in enumerate(items) for j in (0, 1) if it[3 + j] is None]
     recs = {}
+    if switches.get('amax_hints'):                       # an earlier product of the pass read the same tensor
+        for key in list(need):
+            r = amax_hint_get(items[key[0]][key[1]])
+            if r is not None:
+                recs[key] = r
+                need.remove(key)
     for c in range(0, len(need), 64):
         chunk = need[c:c + 64]
         r = f32_absmax([items[i][j] for i, j in chunk])

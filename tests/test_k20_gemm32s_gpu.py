@@ -250,7 +250,8 @@ def test_producers_leave_absmax_records_and_consumers_use_them():
     rec = ops.amax_hint_get(out)
     assert rec is not None and int(rec.max()) == int(out.abs().max().view(torch.int32))
     assert ops.amax_hint_get(out.view(4, 1024, 576)) is rec              # a view of the same elements, while `out` lives
-    assert ops.amax_hint_get(out[:2048]) is None                         # other extent: not the tensor the record describes
+    assert ops.amax_hint_get(out[:2048]) is rec                          # a slice of it: the whole tensor's record bounds it
+    assert ops.amax_hint_get(out[:2048].clone()) is None                 # another tensor
     out.add_(1.0)
     assert ops.amax_hint_get(out) is None                                # modified in place: the record no longer describes it
     # a Linear behind a hinted tensor runs no absmax pass over it
