@@ -1395,13 +1395,15 @@ def weight_amax(w: torch.Tensor) -> torch.Tensor:
     e = _WEIGHT_AMAX.get(key)
     if e is not None and e[0] == (tag, w._version):
         return e[1]
-    _WEIGHT_REG[key] = weakref.ref(w)
+    # (the list is per stream: a weight used on a side stream is refreshed by that stream's first miss, not by every stream's)
+    reg = _WEIGHT_REG.setdefault(tag[2], {})
+    reg[key] = weakref.ref(w)
     todo = []
-    for k2, ref in list(_WEIGHT_REG.items()):
+    for k2, ref in list(reg.items()):
         t = ref()
         if t is None or (t.data_ptr(), tuple(t.shape), t.stride(0)) != k2 or t.device != w.device:
             if t is None:
-                del _WEIGHT_REG[k2]
+                del reg[k2]
             continue
         e2 = _WEIGHT_AMAX.get(k2)
         if e2 is None or e2[0] != (tag, t._version):
