@@ -3502,7 +3502,7 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], weight: torch.Tens
         out_dtype = torch.float32
     y, s, y2 = _AddLayerNorm.apply(a, b, weight, bias, eps, out_dtype, branch_bias, fanout, branch_dtype)
     if (out_dtype == torch.float32 and y.is_cuda and switches.get('amax_hints') and switches.get('ln_bound_hints')
-            and amax_hint_wanted(y.numel() // y.shape[-1])):
+            and not torch.is_autocast_enabled('cuda') and amax_hint_wanted(y.numel() // y.shape[-1])):
         # fp32 compute: the consuming K20 product takes its scale from the LayerNorm's parameters, not from a pass over y
         rec = ln_bound(weight, bias)
         amax_hint_set(y, rec)
@@ -3762,7 +3762,7 @@ def merge_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, e
     ``c*4 + kh*2 + kw``) and its LayerNorm in one pass (K12 with gather addressing)."""
     y = _MergeLayerNorm.apply(x, weight, bias, eps, out_dtype or torch.float32)
     if (y.dtype == torch.float32 and y.is_cuda and switches.get('amax_hints') and switches.get('ln_bound_hints')
-            and amax_hint_wanted(y.numel() // y.shape[-1])):
+            and not torch.is_autocast_enabled('cuda') and amax_hint_wanted(y.numel() // y.shape[-1])):
         amax_hint_set(y, ln_bound(weight, bias))
     return y
 
