@@ -194,6 +194,13 @@ int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_st
                               int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
                               int32_t patch, int32_t patch_dtype, void* out, float* stats, void* workspace,
                               size_t workspace_bytes, void* stream, void* ev_start, void* ev_stop);
+/* ... with amax_out: an optional absmax record (64 zeroed words, mbv_f32_absmax_group's format) of the f32 (B, C, ny, nx) map
+ * (patch == 0), max-combined by one atomic per workgroup: the K20 patch projection behind it (fp32 compute) then needs no pass
+ * over the 0.5 GB map. */
+int mbv_scatter_layernorm_fwd2(const float* feats, const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
+                               const float* weight, const float* bias, int32_t batch, int32_t channels, int32_t ny, int32_t nx,
+                               float eps, int32_t patch, int32_t patch_dtype, void* out, float* stats, void* workspace,
+                               size_t workspace_bytes, uint32_t* amax_out, void* stream, void* ev_start, void* ev_stop);
 
 /* Backward: grad_out (layout per `patch`) → grad_feats (V, C), grad_weight / grad_bias (C, cells).
  * `accumulate` != 0 adds into grad_weight / grad_bias instead of overwriting them. */

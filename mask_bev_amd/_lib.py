@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 54
+ABI_VERSION = 55
 
 
 class MaskBevHipError(RuntimeError):
@@ -41,6 +41,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_scatter_layernorm_patch_supported': (ctypes.c_int, [_I, _I, _I, _I]),
     'mbv_scatter_layernorm_fwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, c_size_t,
                                                  _P, _P, _P]),
+    'mbv_scatter_layernorm_fwd2': (ctypes.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, c_size_t,
+                                                  _P, _P, _P, _P]),
     'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
                                                  c_size_t, _P, _P, _P]),
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),

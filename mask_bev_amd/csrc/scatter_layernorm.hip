@@ -204,8 +204,10 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
                                                   const int32_t* __restrict__ cell_to_pillar,
                                                   const float* __restrict__ weight, const float* __restrict__ bias,
                                                   const float* __restrict__ stats, int batch, int channels, int ny,
-                                                  int nx, int xtiles, void* __restrict__ out_) {
+                                                  int nx, int xtiles, void* __restrict__ out_,
+                                                  unsigned* __restrict__ amax_out /* f32 map only; may be null */) {
   using T = Tile<VEC>;
+  float omax = 0.f;
   __shared__ __attribute__((aligned(16))) float lds[kCT * T::LD];
   constexpr int kTokDw = kCT * 2 + 2;                         // dwords per token in the turn tile (64 data + 2 pad)
   __shared__ __attribute__((aligned(8))) uint32_t olds[PATCH ? 64 * kTokDw : 2];
@@ -293,7 +295,10 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
             float f[VEC], r[VEC];
             load_vec<VEC>(&lds[cl * T::LD + cv], f);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r[e] = (f[e] - mean) * rstd * w[k][e] + bz[k][e];
+            for (int e = 0; e < VEC; ++e) {
+              r[e] = (f[e] - mean) * rstd * w[k][e] + bz[k][e];
+              omax = fmaxf(omax, fabsf(r[e]));
+            }
             store_vec<VEC>(out + (((int64_t)b * channels + c) * ny + y) * nx + xv, r);
           }
         }
@@ -302,6 +307,17 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
     // NCHW: the f32 tile is about to be overwritten by the next scan's rows.  Patch rows: every read of the f32 tile
     // precedes the barrier above, and the turn tile is rewritten only after the next scan's first barrier.
     if constexpr (!PATCH) __syncthreads();
+  }
+  if constexpr (!PATCH) {
+    // fp32 compute: the absmax record of the map for the K20 patch projection behind it — one max-combine per workgroup
+    if (amax_out) {
+      omax = wave_max(omax);
+      if (lane == 0) olds[wave & 1] = 0u;
+      __syncthreads();
+      if (lane == 0) atomicMax(&olds[0], __float_as_uint(omax) & 0x7fffffffu);
+      __syncthreads();
+      if (threadIdx.x == 0 && olds[0]) atomicMax(amax_out + ((blockIdx.x + blockIdx.y * gridDim.x) & 63), olds[0]);
+    }
   }
 }
 
@@ -506,12 +522,31 @@ extern "C" int mbv_scatter_layernorm_patch_supported(int32_t channels, int32_t n
   return patch == 4 && channels > 0 && channels % kCT == 0 && ny > 0 && nx > 0 && ny % 4 == 0 && nx % 4 == 0;
 }
 
+extern "C" int mbv_scatter_layernorm_fwd2(const float* feats, const int32_t* pillar_batch_start,
+                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
+                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
+                                          int32_t patch, int32_t patch_dtype, void* out, float* stats,
+                                          void* workspace, size_t workspace_bytes, uint32_t* amax_out, void* stream_,
+                                          void* ev_start, void* ev_stop);
+
 extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pillar_batch_start,
                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
                                          int32_t patch, int32_t patch_dtype, void* out, float* stats,
                                          void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
                                          void* ev_stop) {
+  return mbv_scatter_layernorm_fwd2(feats, pillar_batch_start, cell_to_pillar, weight, bias, batch, channels, ny, nx, eps, patch,
+                                    patch_dtype, out, stats, workspace, workspace_bytes, nullptr, stream_, ev_start, ev_stop);
+}
+
+// ... with amax_out: an optional absmax record (64 zeroed words) of the f32 (B, C, ny, nx) map (patch == 0), max-combined by one
+// atomic per workgroup — the K20 patch projection behind it (fp32 compute) then needs no pass over the 0.5 GB map
+extern "C" int mbv_scatter_layernorm_fwd2(const float* feats, const int32_t* pillar_batch_start,
+                                          const int32_t* cell_to_pillar, const float* weight, const float* bias,
+                                          int32_t batch, int32_t channels, int32_t ny, int32_t nx, float eps,
+                                          int32_t patch, int32_t patch_dtype, void* out, float* stats,
+                                          void* workspace, size_t workspace_bytes, uint32_t* amax_out, void* stream_,
+                                          void* ev_start, void* ev_stop) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
@@ -532,18 +567,18 @@ extern "C" int mbv_scatter_layernorm_fwd(const float* feats, const int32_t* pill
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
     if (patch_dtype == MBV_DT_F16)
       hipLaunchKernelGGL((k_ln_apply<4, MBV_DT_F16>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats,
-                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out, amax_out);
     else
       hipLaunchKernelGGL((k_ln_apply<4, MBV_DT_BF16>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats,
-                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+                         cell_to_pillar, weight, bias, stats, batch, channels, ny, nx, xtiles, out, amax_out);
   } else if (nx % 4 == 0) {
     const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
     hipLaunchKernelGGL((k_ln_apply<4, 0>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
-                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+                       weight, bias, stats, batch, channels, ny, nx, xtiles, out, amax_out);
   } else {
     const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
     hipLaunchKernelGGL((k_ln_apply<1, 0>), dim3(xtiles * ny, ctiles), dim3(256), 0, stream, feats, cell_to_pillar,
-                       weight, bias, stats, batch, channels, ny, nx, xtiles, out);
+                       weight, bias, stats, batch, channels, ny, nx, xtiles, out, amax_out);
   }
   MBV_CHECK_LAUNCH();
   if (ev_stop) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_stop), stream));

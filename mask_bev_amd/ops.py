@@ -469,6 +469,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
             shape, dt = (batch, ny // patch, nx // patch, patch * patch * c), patch_dtype
         else:
             shape, dt = (batch, c, ny, nx), torch.float32
+        owned = out is not None
         if out is None:
             out = torch.empty(shape, dtype=dt, device=dev)
         else:                      # caller-owned destination (the static input buffer of a captured graph)
@@ -477,11 +478,17 @@ class _ScatterLayerNorm(torch.autograd.Function):
             ctx.mark_dirty(out)
         stats = torch.empty((batch, 2), dtype=torch.float32, device=dev)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
-        rc = lib.mbv_scatter_layernorm_fwd(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
-                                           _ptr(bias), batch, c, ny, nx, float(eps), int(patch),
-                                           _dt_flag(dt) if patch else 0, _ptr(out), _ptr(stats), _ptr(ws), ws.numel(),
-                                           _stream(), *TIMER.events('k_ln_apply')[2:])
-        check(rc, 'mbv_scatter_layernorm_fwd')
+        # fp32 compute: the f32 map feeds the K20 patch projection — its absmax record from this launch (no pass over 0.5 GB)
+        rec = None
+        if not patch and switches.get('amax_hints') and switches.get('ln_bound_hints') and switches.get('gemm32s'):
+            # (a caller-owned map — read by a captured graph — gets ONE persistent record, cleared and rewritten every step)
+            rec = static_amax_record(out) if owned else amax_record(dev)
+        rc = lib.mbv_scatter_layernorm_fwd2(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
+                                            _ptr(bias), batch, c, ny, nx, float(eps), int(patch),
+                                            _dt_flag(dt) if patch else 0, _ptr(out), _ptr(stats), _ptr(ws), ws.numel(),
+                                            _ptr(rec), _stream(), *TIMER.events('k_ln_apply')[2:])
+        check(rc, 'mbv_scatter_layernorm_fwd2')
+        amax_hint_set(out, rec, static=owned)
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
         ctx.params = (weight, bias)
@@ -546,6 +553,7 @@ def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
     patch_dtype = out.dtype if (out is not None and patch) else lo_dtype()
     out = _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
                                   p.pillar_batch_start, batch, ny, nx, eps, patch, out, patch_dtype)
+    amax_hint_refresh(out)           # (mark_dirty bumped a caller-owned buffer's version behind the forward's hint)
     return PatchTokens(out, int(weight.shape[0]), patch) if patch else out
 
 
@@ -1308,47 +1316,68 @@ def operand_amax(tensors, activations=None):
 # of v rows, |act'| <= 1.13 — to the next K20 product that reads the tensor (fc2's input behind fc1 + GELU, proj's input
 # behind qkv + attention, fc1's output gradient behind fc2's data gradient) — found by the tensor's address, valid only while the very tensor object is alive and unmodified
 # (weak reference + version).  A consumer without a valid hint runs the absmax pass: a missed hint costs time, never accuracy.
+# A record made OUTSIDE a stream capture must not be baked into a captured launch (the replay would read the address of that one
+# eager step's record for ever) and vice versa: a hint is valid only in the capture state it was made in — unless its record is
+# STATIC (one persistent record per caller-owned buffer, rewritten by the producer every step: the eager encoder's map that a
+# captured graph reads).
 _AMAX_HINTS: dict = {}
-_LAST_HINT = [0, None]
+_LAST_HINT = [0, None, False]
+_STATIC_RECS: dict = {}
 
 
-def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor]) -> None:
+def static_amax_record(buf: torch.Tensor) -> torch.Tensor:
+    """The persistent (1, 64) absmax record of a caller-owned buffer, cleared for the producer's next launch."""
+    key = (buf.data_ptr(), buf.numel())
+    rec = _STATIC_RECS.get(key)
+    if rec is None or rec.device != buf.device:
+        if len(_STATIC_RECS) > 64:
+            _STATIC_RECS.clear()
+        rec = _STATIC_RECS[key] = torch.zeros((1, AMAX_SLOTS), dtype=torch.int32, device=buf.device)
+    else:
+        rec.zero_()
+    return rec
+
+
+def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor], static: bool = False) -> None:
     if rec is None or not torch.is_tensor(t) or not t.is_cuda:
         return
     import weakref
     if len(_AMAX_HINTS) > 512:
-        for k in [k for k, (ref, _, _) in _AMAX_HINTS.items() if ref() is None]:
+        for k in [k for k, e in _AMAX_HINTS.items() if e[0]() is None]:
             del _AMAX_HINTS[k]
         if len(_AMAX_HINTS) > 512:
             _AMAX_HINTS.clear()
-    _AMAX_HINTS[t.data_ptr()] = (weakref.ref(t), t._version, rec)
-    _LAST_HINT[0], _LAST_HINT[1] = t.data_ptr(), rec
+    cap = None if static else torch.cuda.is_current_stream_capturing()
+    _AMAX_HINTS[t.data_ptr()] = (weakref.ref(t), t._version, rec, cap)
+    _LAST_HINT[0], _LAST_HINT[1], _LAST_HINT[2] = t.data_ptr(), rec, static
 
 
 def amax_hint_refresh(t) -> None:
-    """After ``Function.apply``: the tensor object the caller holds may be a new wrapper of the one the forward hinted."""
+    """After ``Function.apply``: the tensor object the caller holds may be a new wrapper of the one the forward hinted (or the
+    same buffer with its version bumped by ``mark_dirty``)."""
     if torch.is_tensor(t) and t.is_cuda and _LAST_HINT[0] == t.data_ptr() and _LAST_HINT[1] is not None \
             and amax_hint_get(t) is None:
-        amax_hint_set(t, _LAST_HINT[1])
+        amax_hint_set(t, _LAST_HINT[1], _LAST_HINT[2])
 
 
 def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
+    capturing = torch.cuda.is_current_stream_capturing() if t.is_cuda else False
     e = _AMAX_HINTS.get(t.data_ptr())
     if e is not None:
-        ref, version, rec = e
+        ref, version, rec, cap = e
         src = ref()
         if (src is not None and src.data_ptr() == t.data_ptr() and src.numel() == t.numel() and src._version == version
-                and rec.device == t.device):
+                and rec.device == t.device and (cap is None or cap == capturing)):
             return rec
     # a slice (column block, row range) of a hinted tensor: the whole tensor's record bounds it
     base = t._base
     if base is not None and base is not t and base.dtype == t.dtype:
         e = _AMAX_HINTS.get(base.data_ptr())
         if e is not None:
-            ref, version, rec = e
+            ref, version, rec, cap = e
             src = ref()
             if (src is not None and src.data_ptr() == base.data_ptr() and src.numel() == base.numel()
-                    and src._version == version and rec.device == t.device):
+                    and src._version == version and rec.device == t.device and (cap is None or cap == capturing)):
                 return rec
     return None
 
@@ -1548,7 +1577,7 @@ class _PatchEmbed32(torch.autograd.Function):
         e = weight.shape[0]
         image = image.contiguous()
         w2 = weight.reshape(e, -1)
-        amax = f32_absmax([image.view(b * c * h, w), w2])
+        amax = tuple(operand_amax([image.view(b * c * h, w), w2], (True, False)))      # (K3 leaves the image's record)
         out = torch.empty((b, h // 4, w // 4, e), dtype=torch.float32, device=image.device)
         check(lib.mbv_patch_embed32_fwd(_ptr(image), _ptr(w2), _ptr(bias), _ptr(out), b, c, h, w, e, _amax_ptr(amax, 0),
                                         _amax_ptr(amax, 1), _stream()), 'mbv_patch_embed32_fwd')
@@ -1959,8 +1988,11 @@ def _defer_tn32_wgrad(g2: torch.Tensor, x2: torch.Tensor, acc: torch.Tensor, ama
     lists = _pending_lists()
     if lists is None:
         return False
-    lists[3].append((g2, x2, acc, None if amax is None else amax[0], None if amax is None else amax[1],
-                     torch.cuda.current_stream()))
+    ag, ax = (None, None) if amax is None else (amax[0], amax[1])
+    if switches.get('amax_hints'):      # resolved NOW: a hint lives as long as the tensor object it was left on, not until the flush
+        ag = amax_hint_get(g2) if ag is None else ag
+        ax = amax_hint_get(x2) if ax is None else ax
+    lists[3].append((g2, x2, acc, ag, ax, torch.cuda.current_stream()))
     return True
 
 

@@ -146,6 +146,32 @@ def test_scatter_layernorm_fwd_bwd(device, nx, ny, C, sizes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('owned', [False, True])
+def test_scatter_layernorm_leaves_the_maps_absmax_record(device, owned):
+    """fp32 compute: K3 leaves the absmax record of its f32 map (one atomic per workgroup) as the hint the K20 patch
+    projection reads — a fresh record for a fresh map, ONE persistent record (cleared and rewritten every call) for a
+    caller-owned buffer that a captured graph reads."""
+    from mask_bev_amd import ops, switches
+    cfg = _cfg(nx=64, ny=64, C=32)
+    scans = _scans(cfg, [3000, 2000], seed=9)
+    pil, _ = _check_voxelize(cfg, scans, device)
+    g = torch.Generator().manual_seed(3)
+    w = (1 + 0.1 * torch.randn(32, 64, 64, generator=g)).to(device)
+    b = (0.1 * torch.randn(32, 64, 64, generator=g)).to(device)
+    buf = torch.empty((2, 32, 64, 64), device=device) if owned else None
+    recs = []
+    with switches.override(amax_hints=True, ln_bound_hints=True, gemm32s=True):
+        for scale in (1.0, 50.0):
+            feats = (torch.randn(pil.num_pillars, 32, generator=g) * scale).to(device)
+            out = ops.scatter_layernorm(feats, w * scale, b, pil, 2, 64, 64, 1e-3, out=buf)
+            rec = ops.amax_hint_get(out)
+            assert rec is not None
+            assert int(rec.max()) == int(out.abs().max().view(torch.int32))
+            recs.append(rec)
+    assert (recs[0].data_ptr() == recs[1].data_ptr()) == owned
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('nx,ny,C,sizes', [(64, 64, 32, [3000, 2000]), (52, 40, 64, [500]), (512, 8, 32, [900, 10, 0]),
                                            (300, 12, 32, [2000, 1500])])
 @pytest.mark.parametrize('lo', [torch.bfloat16, torch.float16])
