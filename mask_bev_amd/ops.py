@@ -1348,6 +1348,9 @@ def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor], static: bool = F
         if len(_AMAX_HINTS) > 512:
             _AMAX_HINTS.clear()
     cap = None if static else torch.cuda.is_current_stream_capturing()
+    base = t._base
+    if base is not None and base.data_ptr() == t.data_ptr() and base.numel() == t.numel() and base.dtype == t.dtype:
+        t = base          # a reshaped view of the whole tensor: the hint lives with the tensor, not with the temporary view object
     _AMAX_HINTS[t.data_ptr()] = (weakref.ref(t), t._version, rec, cap)
     _LAST_HINT[0], _LAST_HINT[1], _LAST_HINT[2] = t.data_ptr(), rec, static
 
