@@ -753,6 +753,20 @@ int mbv_attn_bwd_ld(const void* q, const void* k, const void* v, int32_t ld_kv, 
                     int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
                     void* grad_k, void* grad_v, int32_t ld_grad_kv, int32_t grad_kv_bf16, void* stream);
 
+/* K6 on f32 tensors in the SPLIT mode (fp32 compute; the arguments, results and reference lines of mbv_attn_fwd_ld / _bwd_ld with
+ * is_bf16 = 0, f32 key / value gradients): every f32 operand element of a block's tiles is split into an IEEE-half pair while the
+ * tile is staged and every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 (K20's arithmetic, K4's split mode), with
+ * one power-of-two scale PER TILE found in registers between the loads and the LDS stores.  head_dim 16 / 32 / 64, ld_kv % 4 == 0,
+ * 16-byte aligned tensors (mbv_attn_split_supported; else MBV_ERR_UNSUPPORTED and the caller keeps the exact-f32 form). */
+int mbv_attn_split_supported(int32_t heads, int32_t head_dim, int32_t ld_kv);
+int mbv_attn_split_fwd_ld(const float* q, const float* k, const float* v, int32_t ld_kv, const uint8_t* blocked, int32_t batch,
+                          int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* out, float* lse,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int mbv_attn_split_bwd_ld(const float* q, const float* k, const float* v, int32_t ld_kv, const uint8_t* blocked, const float* out,
+                          const float* grad_out, const float* lse, int32_t batch, int32_t num_queries, int32_t num_keys,
+                          int32_t heads, int32_t head_dim, float* grad_q, float* grad_k, float* grad_v, int32_t ld_grad_kv,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K17 — 16-bit (bf16 / fp16) MFMA GEMMs of the token-major Linear layers, with the element-wise work around them
  * fused into the epilogue.  dtype: 0 = bf16, 1 = fp16 (inputs; accumulation is f32).

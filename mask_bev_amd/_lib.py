@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 55
+ABI_VERSION = 56
 
 
 class MaskBevHipError(RuntimeError):
@@ -165,6 +165,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_conv_unpad_rows': (ctypes.c_int, [_P, _P, _L, _L, _L, _L, _I, _P]),
     'mbv_conv3x3_gemm32s': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _P, _P, _P, _P]),
     'mbv_conv3x3_gemm16': (ctypes.c_int, [_P, _P, _P, _L, _L, _L, _L, _L, _I, _I, _P]),
+    'mbv_attn_split_supported': (ctypes.c_int, [_I, _I, _I]),
+    'mbv_attn_split_fwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, c_size_t, _P]),
+    'mbv_attn_split_bwd_ld': (ctypes.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     'mbv_window_attn_split_supported': (ctypes.c_int, [_I, _I, _I]),
     'mbv_window_attn_split_fwd': (ctypes.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'mbv_window_attn_split_bwd': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I,

@@ -559,6 +559,378 @@ int attn_bwd_launch(const AttnGeom& g, int D, const void* q, const void* k, cons
   return MBV_OK;
 }
 
+#ifdef MBV_H16
+// ---------------------------------------------------------------------------------------------
+// f32 tensors on the 16-bit matrix pipe ("split" mode; fp32 compute) — K4's split mode (csrc/window_attn.hip) for the decoder
+// ---------------------------------------------------------------------------------------------
+// Every f32 operand element of a block's tiles is split into an IEEE-half pair while the tile is staged (x 2^e = hi + lo: 22
+// significant bits; two swizzled images per operand) and every product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16.
+// The power-of-two scales are PER TILE here (the maximum of the 128 x D tile a block stages, found in registers between the
+// loads and the LDS stores: a tile is small and each block's results are rescaled on their own); of the register operands the
+// probabilities take 2^13 (<= 1) and every dS tile the scale of its own maximum (acc_tr_split_scaled).
+union SPack8 {
+  uint4 u;
+  lo16_t h[8];
+};
+constexpr float kProbScale = 8192.f, kProbInv = 1.f / 8192.f;
+
+__device__ __forceinline__ void sload8(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ float smax8(const float (&v)[8]) {
+  return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+               fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+}
+template <int D>
+__device__ __forceinline__ void sput(lo16_t* img, int t, int c, const float (&v)[8], float s) {
+  SPack8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float y = v[j] * s;
+    hi.h[j] = (lo16_t)y;
+    lo.h[j] = (lo16_t)(y - (float)hi.h[j]);
+  }
+  const int o = Swz<D>::chunk_off(t, c);
+  *reinterpret_cast<uint4*>(img + o) = hi.u;
+  *reinterpret_cast<uint4*>(img + Swz<D>::IMG + o) = lo.u;
+}
+// biased exponent e of the scale 2^(e - 127) that puts a maximum with these bits in [2^13, 2^14) (127 for an all-zero tile)
+__device__ __forceinline__ int scale_exp(unsigned bits) {
+  if (bits == 0u) return 127;
+  const int e = 267 - (int)(bits >> 23);
+  return e < 1 ? 1 : (e > 253 ? 253 : e);
+}
+__device__ __forceinline__ float pow2e(int e) {
+  e = e < 1 ? 1 : (e > 254 ? 254 : e);
+  return __uint_as_float((unsigned)e << 23);
+}
+// the maxima of up to four tiles of a block: per-thread values -> per-wave words in LDS -> (after the caller's barrier) maxima
+template <int N>
+__device__ __forceinline__ void publish_tile_max(const float (&m)[N], unsigned* wmax /* [waves][N] */) {
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float v = m[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[wave * N + i] = __float_as_uint(v) & 0x7fffffffu;
+  }
+}
+template <int N>
+__device__ __forceinline__ unsigned tile_max(const unsigned* wmax, int i) {
+  unsigned m = 0u;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) m = m > wmax[w * N + i] ? m : wmax[w * N + i];
+  return m;
+}
+
+// the power-of-two scale (biased exponent) of an accumulator tile that becomes an MFMA operand: its largest magnitude over the wave
+__device__ __forceinline__ int acc_tile_scale_exp(const f32x16& x) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return scale_exp(__builtin_amdgcn_readfirstlane(__float_as_uint(m) & 0x7fffffffu));
+}
+// acc += (X^T . M) with X split at ITS OWN scale (a dS tile: with thousands of keys its elements sit 2^-11 and more below any
+// static bound — measured 2e-5 in dK at L = 4 096 with one bound per block — so every tile takes the scale of its maximum and
+// its product joins the f32 sum outside the matrix instruction)
+template <int D>
+__device__ __forceinline__ void acc_tr_split_scaled(const f32x16& x, const lo16_t* m_hi, const lo16_t* m_lo, int k0, int cb,
+                                                    float m_inv, f32x16& acc) {
+  const int e = acc_tile_scale_exp(x);
+  f32x16 tmp = zero16();
+  mma_acc_tr_split<D>(x, pow2e(e), m_hi, m_lo, k0, cb, tmp);
+  const float inv = pow2e(254 - e) * m_inv;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = fmaf(tmp[i], inv, acc[i]);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_attn_split_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const uint8_t* __restrict__ mask,
+                                                        AttnGeom g, float scale, float* __restrict__ ws_m,
+                                                        float* __restrict__ ws_l, float* __restrict__ ws_o,
+                                                        float* __restrict__ out, float* __restrict__ lse) {
+  constexpr int IMG = Swz<D>::IMG, CH = D / 8, ITEMS = (NPAD * CH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) lo16_t q_img[2 * IMG];      // hi image, lo image
+  __shared__ __attribute__((aligned(16))) lo16_t k_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t v_img[2 * IMG];
+  __shared__ unsigned mbits[NPAD * NBLK];
+  __shared__ unsigned wmax[4 * 3];
+  __shared__ float inv_s[NPAD];
+  const AttnBlock blk = decode(g);
+  const int col = blk.head * D;
+  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.ldkv;
+  float qv[ITEMS][8], kv[ITEMS][8], vv[ITEMS][8];
+  float mx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = threadIdx.x + 256 * it, t = idx / CH, c = idx - t * CH;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[it][j] = kv[it][j] = vv[it][j] = 0.f;
+    if (idx < NPAD * CH) {
+      if (t < blk.nq) sload8(q + qoff + (int64_t)(blk.q0 + t) * g.E + col + 8 * c, qv[it]);
+      if (t < blk.nk) {
+        sload8(k + koff + (int64_t)(blk.k0 + t) * g.ldkv + col + 8 * c, kv[it]);
+        sload8(v + koff + (int64_t)(blk.k0 + t) * g.ldkv + col + 8 * c, vv[it]);
+      }
+    }
+    mx[0] = fmaxf(mx[0], smax8(qv[it])); mx[1] = fmaxf(mx[1], smax8(kv[it])); mx[2] = fmaxf(mx[2], smax8(vv[it]));
+  }
+  publish_tile_max<3>(mx, wmax);
+  stage_mask_bits(mask, g, blk, mbits);
+  __syncthreads();
+  const int eq = scale_exp(tile_max<3>(wmax, 0)), ek = scale_exp(tile_max<3>(wmax, 1)), ev = scale_exp(tile_max<3>(wmax, 2));
+  const float s_q = pow2e(eq), s_k = pow2e(ek), s_v = pow2e(ev);
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = threadIdx.x + 256 * it, t = idx / CH, c = idx - t * CH;
+    if (idx < NPAD * CH) {
+      sput<D>(q_img, t, c, qv[it], s_q);
+      sput<D>(k_img, t, c, kv[it], s_k);
+      sput<D>(v_img, t, c, vv[it], s_v);
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqb = (blk.nq + 31) / 32, nkb = (blk.nk + 31) / 32;
+  if (wave >= nqb) return;
+  const int ql = 32 * wave + r;
+  f32x16 s[NBLK];
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    s[kb] = zero16();
+    if (kb < nkb) mma_rows_split<D>(k_img, k_img + IMG, 32 * kb, q_img, q_img + IMG, 32 * wave, s[kb]);
+  }
+  const float sl2 = scale * kLog2e * pow2e(254 - eq) * pow2e(254 - ek);
+  float m = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const unsigned w = mbits[ql * NBLK + kb] >> (4 * h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool ok = kb < nkb && !((w >> ((i & 3) + 8 * (i >> 2))) & 1u);
+      const float val = ok ? s[kb][i] * sl2 : -INFINITY;
+      s[kb][i] = val;
+      m = fmaxf(m, val);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const float m_use = (m == -INFINITY) ? 0.f : m;
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __builtin_amdgcn_exp2f(s[kb][i] - m_use);
+      s[kb][i] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const int64_t wrow = (int64_t)blk.ws_row * NPAD;
+  const bool single = g.nsplit == 1;
+  if (h == 0) {
+    if (!single) {
+      ws_m[wrow + ql] = m;
+      ws_l[wrow + ql] = sum;
+    } else if (ql < blk.nq) {
+      lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + ql] = (m + __log2f(sum)) * kLn2;
+    }
+  }
+  if (single) {
+    if (h == 0) inv_s[ql] = 1.f / sum;
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave reads back only what it wrote
+  }
+  constexpr int NCB = (D + 31) / 32;
+  const float o_inv = kProbInv * pow2e(254 - ev);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    f32x16 o = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb)
+      if (kb < nkb) mma_acc_tr_split<D>(s[kb], kProbScale, v_img, v_img + IMG, 32 * kb, cb, o);
+    const int dcol = r + 32 * cb;
+    if (dcol < D) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (!single) ws_o[(wrow + qq) * D + dcol] = o[i] * o_inv;
+        else if (qq < blk.nq)
+          out[((int64_t)blk.b * g.Q + blk.q0 + qq) * g.E + blk.head * D + dcol] = o[i] * o_inv * inv_s[qq];
+      }
+    }
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(512, 2) k_attn_split_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ out, const float* __restrict__ grad_out,
+                                                           const float* __restrict__ lse, AttnGeom g, float scale,
+                                                           float* __restrict__ grad_q, float* __restrict__ grad_k,
+                                                           float* __restrict__ grad_v) {
+  constexpr int IMG = Swz<D>::IMG, CH = D / 8, ITEMS = (NPAD * CH + 511) / 512;
+  __shared__ __attribute__((aligned(16))) lo16_t q_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t k_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t v_img[2 * IMG];
+  __shared__ __attribute__((aligned(16))) lo16_t do_img[2 * IMG];
+  __shared__ unsigned mbits[NPAD * NBLK];
+  __shared__ double delta_s[NPAD];
+  __shared__ float2 ld_s[NPAD];
+  __shared__ unsigned wmax[8 * 4];
+  const AttnBlock blk = decode(g);
+  const int col = blk.head * D;
+  const int64_t qoff = (int64_t)blk.b * g.Q * g.E, koff = (int64_t)blk.b * g.L * g.ldkv;
+  const int64_t goff = (int64_t)blk.b * g.L * g.ldg;
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) delta_s[t] = 0.0;
+  __syncthreads();
+  float qv[ITEMS][8], kv[ITEMS][8], vv[ITEMS][8], dv_[ITEMS][8];
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = threadIdx.x + 512 * it, t = idx / CH, c = idx - t * CH;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[it][j] = kv[it][j] = vv[it][j] = dv_[it][j] = 0.f;
+    if (idx < NPAD * CH) {
+      if (t < blk.nq) {
+        const int64_t o = qoff + (int64_t)(blk.q0 + t) * g.E + col + 8 * c;
+        float ov[8];
+        sload8(q + o, qv[it]);
+        sload8(grad_out + o, dv_[it]);
+        sload8(out + o, ov);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += ov[j] * dv_[it][j];
+        atomicAdd(&delta_s[t], (double)acc);          // delta[q] = sum_d dO[q][d] * O[q][d]
+      }
+      if (t < blk.nk) {
+        sload8(k + koff + (int64_t)(blk.k0 + t) * g.ldkv + col + 8 * c, kv[it]);
+        sload8(v + koff + (int64_t)(blk.k0 + t) * g.ldkv + col + 8 * c, vv[it]);
+      }
+    }
+    mx[0] = fmaxf(mx[0], smax8(qv[it])); mx[1] = fmaxf(mx[1], smax8(kv[it]));
+    mx[2] = fmaxf(mx[2], smax8(vv[it])); mx[3] = fmaxf(mx[3], smax8(dv_[it]));
+  }
+  publish_tile_max<4>(mx, wmax);
+  stage_mask_bits(mask, g, blk, mbits);
+  __syncthreads();
+  const int eq = scale_exp(tile_max<4>(wmax, 0)), ek = scale_exp(tile_max<4>(wmax, 1));
+  const int ev = scale_exp(tile_max<4>(wmax, 2)), ed = scale_exp(tile_max<4>(wmax, 3));
+  const float s_q = pow2e(eq), s_k = pow2e(ek), s_v = pow2e(ev), s_d = pow2e(ed);
+  const float inv_q = pow2e(254 - eq), inv_k = pow2e(254 - ek), inv_v = pow2e(254 - ev), inv_d = pow2e(254 - ed);
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = threadIdx.x + 512 * it, t = idx / CH, c = idx - t * CH;
+    if (idx < NPAD * CH) {
+      sput<D>(q_img, t, c, qv[it], s_q);
+      sput<D>(k_img, t, c, kv[it], s_k);
+      sput<D>(v_img, t, c, vv[it], s_v);
+      sput<D>(do_img, t, c, dv_[it], s_d);
+    }
+  }
+  for (int t = threadIdx.x; t < NPAD; t += blockDim.x) {
+    const float l = t < blk.nq ? lse[((int64_t)blk.b * g.heads + blk.head) * g.Q + blk.q0 + t] : 0.f;
+    ld_s[t] = make_float2(l * kLog2e, (float)delta_s[t]);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = threadIdx.x >> 8;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (blk.nq + 31) / 32, nkb = (blk.nk + 31) / 32;
+  constexpr int NCB = (D + 31) / 32;
+  const float sl2 = scale * kLog2e * inv_q * inv_k;
+  const float dp_inv = inv_v * inv_d;
+
+  if (part == 0 && wave < nqb) {   // ---- part 1: lane = query -> dQ partial of this key split
+    const int ql = 32 * wave + r;
+    const float my_lse2 = ld_s[ql].x, my_delta = ld_s[ql].y;
+    f32x16 dq[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dq[cb] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      if (kb >= nkb) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows_split<D>(k_img, k_img + IMG, 32 * kb, q_img, q_img + IMG, 32 * wave, s);
+      mma_rows_split<D>(v_img, v_img + IMG, 32 * kb, do_img, do_img + IMG, 32 * wave, dp);
+      const unsigned w = mbits[ql * NBLK + kb] >> (4 * h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool blocked = (w >> ((i & 3) + 8 * (i >> 2))) & 1u;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -my_lse2));
+        s[i] = blocked ? 0.f : p * (dp[i] * dp_inv - my_delta) * scale;
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc_tr_split_scaled<D>(s, k_img, k_img + IMG, 32 * kb, cb, inv_k, dq[cb]);
+    }
+    const float dq_inv = 1.f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * wave + acc_row(i, h);
+        if (qq < blk.nq) {
+          float* dst = grad_q + qoff + (int64_t)(blk.q0 + qq) * g.E + col + dcol;
+          if (g.nsplit > 1) atomicAdd(dst, dq[cb][i] * dq_inv);
+          else *dst = dq[cb][i] * dq_inv;
+        }
+      }
+    }
+  }
+  if (part == 1 && wave < nkb) {   // ---- part 2: wave = key block -> dK, dV of this split's keys
+    const int kb = wave;
+    f32x16 dk[NCB], dv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { dk[cb] = zero16(); dv[cb] = zero16(); }
+#pragma unroll
+    for (int qb = 0; qb < NBLK; ++qb) {
+      if (qb >= nqb) continue;
+      f32x16 s = zero16(), dp = zero16();
+      mma_rows_split<D>(q_img, q_img + IMG, 32 * qb, k_img, k_img + IMG, 32 * kb, s);
+      mma_rows_split<D>(do_img, do_img + IMG, 32 * qb, v_img, v_img + IMG, 32 * kb, dp);
+      f32x16 ds;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = 32 * qb + acc_row(i, h);
+        const float2 ld = ld_s[qq];
+        const bool blocked = (mbits[qq * NBLK + kb] >> r) & 1u;
+        float p = __builtin_amdgcn_exp2f(fmaf(s[i], sl2, -ld.x));
+        p = blocked ? 0.f : p;
+        s[i] = p;
+        ds[i] = p * (dp[i] * dp_inv - ld.y) * scale;
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        mma_acc_tr_split<D>(s, kProbScale, do_img, do_img + IMG, 32 * qb, cb, dv[cb]);
+        acc_tr_split_scaled<D>(ds, q_img, q_img + IMG, 32 * qb, cb, inv_q, dk[cb]);
+      }
+    }
+    const float dv_inv = kProbInv * inv_d, dk_inv = 1.f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int dcol = r + 32 * cb;
+      if (dcol >= D) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * kb + acc_row(i, h);
+        if (kk < blk.nk) {
+          const int64_t o = goff + (int64_t)(blk.k0 + kk) * g.ldg + col + dcol;
+          const float vk = dk[cb][i] * dk_inv, vv2 = dv[cb][i] * dv_inv;
+          if (g.nsuper > 1) { atomicAdd(grad_k + o, vk); atomicAdd(grad_v + o, vv2); }
+          else { grad_k[o] = vk; grad_v[o] = vv2; }
+        }
+      }
+    }
+  }
+}
+#endif
+
 }  // namespace
 
 #ifndef MBV_H16
@@ -654,5 +1026,72 @@ extern "C" int mbv_attn_bwd(const void* q, const void* k, const void* v, const u
                             float* grad_k, float* grad_v, void* stream_) {
   return mbv_attn_bwd_ld(q, k, v, heads * head_dim, blocked, out, grad_out, lse, is_bf16, batch, num_queries, num_keys,
                          heads, head_dim, grad_q, grad_k, grad_v, heads * head_dim, 0, stream_);
+}
+#endif
+
+#ifdef MBV_H16
+// ---- K6 on f32 tensors in the split mode (see k_attn_split_fwd): the arguments of mbv_attn_fwd_ld / _bwd_ld without the dtype flags
+extern "C" int mbv_attn_split_supported(int32_t heads, int32_t head_dim, int32_t ld_kv) {
+  return (heads > 0 && (head_dim == 16 || head_dim == 32 || head_dim == 64) && ld_kv >= heads * head_dim && (ld_kv & 3) == 0) ? 1 : 0;
+}
+
+extern "C" int mbv_attn_split_fwd_ld(const float* q, const float* k, const float* v, int32_t ld_kv, const uint8_t* blocked,
+                                     int32_t batch, int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim,
+                                     float* out, float* lse, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnGeom g;
+  if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
+  if (!q || !k || !v || !out || !lse) return MBV_ERR_BAD_ARG;
+  if (!mbv_attn_split_supported(heads, head_dim, ld_kv) || !aligned16(q, k, v, out)) return MBV_ERR_UNSUPPORTED;
+  g.ldkv = ld_kv;
+  g.mask_vec = blocked && (num_keys & 15) == 0 && aligned16(blocked);
+  if (!workspace || workspace_bytes < mbv_align_up(attn_ws_floats(g, head_dim) * sizeof(float), 256)) return MBV_ERR_WORKSPACE;
+  float* ws = reinterpret_cast<float*>(workspace);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  const size_t rows = (size_t)g.B * g.heads * g.nsuper * g.nsplit * NPAD;
+  float *ws_m = ws, *ws_l = ws + rows, *ws_o = ws + 2 * rows;
+  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(256);
+  switch (head_dim) {
+    case 16: hipLaunchKernelGGL((k_attn_split_fwd<16>), grid, block, 0, stream, q, k, v, blocked, g, scale, ws_m, ws_l, ws_o, out, lse); break;
+    case 32: hipLaunchKernelGGL((k_attn_split_fwd<32>), grid, block, 0, stream, q, k, v, blocked, g, scale, ws_m, ws_l, ws_o, out, lse); break;
+    default: hipLaunchKernelGGL((k_attn_split_fwd<64>), grid, block, 0, stream, q, k, v, blocked, g, scale, ws_m, ws_l, ws_o, out, lse); break;
+  }
+  MBV_CHECK_LAUNCH();
+  if (g.nsplit == 1) return MBV_OK;
+  const int64_t total = (int64_t)g.B * g.heads * g.Q * head_dim;
+  hipLaunchKernelGGL((k_attn_combine<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ws_m, ws_l, ws_o, g,
+                     head_dim, out, lse);
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
+}
+
+extern "C" int mbv_attn_split_bwd_ld(const float* q, const float* k, const float* v, int32_t ld_kv, const uint8_t* blocked,
+                                     const float* out, const float* grad_out, const float* lse, int32_t batch,
+                                     int32_t num_queries, int32_t num_keys, int32_t heads, int32_t head_dim, float* grad_q,
+                                     float* grad_k, float* grad_v, int32_t ld_grad_kv, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  AttnGeom g;
+  if (!make_attn_geom(batch, num_queries, num_keys, heads, head_dim, g)) return MBV_ERR_BAD_ARG;
+  if (!q || !k || !v || !out || !grad_out || !lse || !grad_q || !grad_k || !grad_v) return MBV_ERR_BAD_ARG;
+  if (ld_grad_kv < g.E) return MBV_ERR_BAD_ARG;
+  if (!mbv_attn_split_supported(heads, head_dim, ld_kv) || !aligned16(q, k, v, out, grad_out)) return MBV_ERR_UNSUPPORTED;
+  if (ld_grad_kv != g.E && g.nsuper > 1) return MBV_ERR_UNSUPPORTED;
+  g.ldkv = ld_kv; g.ldg = ld_grad_kv;
+  g.mask_vec = blocked && (num_keys & 15) == 0 && aligned16(blocked);
+  if (g.nsplit > 1)
+    MBV_CHECK_HIP(mbv_fill_async(grad_q, 0, sizeof(float) * (size_t)batch * num_queries * g.E, stream));
+  if (g.nsuper > 1) {
+    MBV_CHECK_HIP(mbv_fill_async(grad_k, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+    MBV_CHECK_HIP(mbv_fill_async(grad_v, 0, sizeof(float) * (size_t)batch * num_keys * g.E, stream));
+  }
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  const dim3 grid((unsigned)(g.B * g.heads * g.nsuper * g.nsplit)), block(512);
+  switch (head_dim) {
+    case 16: hipLaunchKernelGGL((k_attn_split_bwd<16>), grid, block, 0, stream, q, k, v, blocked, out, grad_out, lse, g, scale, grad_q, grad_k, grad_v); break;
+    case 32: hipLaunchKernelGGL((k_attn_split_bwd<32>), grid, block, 0, stream, q, k, v, blocked, out, grad_out, lse, g, scale, grad_q, grad_k, grad_v); break;
+    default: hipLaunchKernelGGL((k_attn_split_bwd<64>), grid, block, 0, stream, q, k, v, blocked, out, grad_out, lse, g, scale, grad_q, grad_k, grad_v); break;
+  }
+  MBV_CHECK_LAUNCH();
+  return MBV_OK;
 }
 #endif

@@ -2536,6 +2536,14 @@ def ffn(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b, kind: str, defer_out_bias: 
 # --------------------------------------------------------------------------------------
 # K6 decoder multi-head attention
 # --------------------------------------------------------------------------------------
+def _k6_split(dt, heads: int, d: int, ld: int, *tensors) -> bool:
+    """fp32 compute: K6's products on the 16-bit matrix pipe from IEEE-half pairs (``switches.k6_split``) for f32 tensors whose
+    shapes and alignment the split mode takes."""
+    return bool(dt == torch.float32 and switches.get('k6_split')
+                and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+                and _lib.load().mbv_attn_split_supported(heads, d, ld))
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, blocked, num_heads):
@@ -2556,9 +2564,13 @@ class _Attention(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
         ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
-        rc = lib.mbv_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _dt_flag(dt), b, nq, nl,
-                              num_heads, d, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'mbv_attn_fwd')
+        if _k6_split(dt, num_heads, d, e, q, k, v, out):
+            check(lib.mbv_attn_split_fwd_ld(_ptr(q), _ptr(k), _ptr(v), e, _ptr(mask), b, nq, nl, num_heads, d, _ptr(out),
+                                            _ptr(lse), _ptr(ws), ws.numel(), _stream()), 'mbv_attn_split_fwd_ld')
+        else:
+            rc = lib.mbv_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _dt_flag(dt), b, nq, nl,
+                                  num_heads, d, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+            check(rc, 'mbv_attn_fwd')
         ctx.save_for_backward(q, k, v, mask, out, lse)
         ctx.num_heads = num_heads
         return out
@@ -2574,10 +2586,15 @@ class _Attention(torch.autograd.Function):
         g_q = torch.empty((b, nq, e), dtype=torch.float32, device=q.device)
         g_k = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
         g_v = torch.empty((b, nl, e), dtype=torch.float32, device=q.device)
-        rc = lib.mbv_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse),
-                              _dt_flag(q.dtype), b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
-                              _ptr(g_v), _stream())
-        check(rc, 'mbv_attn_bwd')
+        if _k6_split(q.dtype, h, e // h, e, q, k, v, out, grad_out):
+            check(lib.mbv_attn_split_bwd_ld(_ptr(q), _ptr(k), _ptr(v), e, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse),
+                                            b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k), _ptr(g_v), e, _stream()),
+                  'mbv_attn_split_bwd_ld')
+        else:
+            rc = lib.mbv_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse),
+                                  _dt_flag(q.dtype), b, nq, nl, h, e // h, _ptr(g_q), _ptr(g_k),
+                                  _ptr(g_v), _stream())
+            check(rc, 'mbv_attn_bwd')
         dq, dk, dv = ctx.in_dtypes
         return g_q.to(dq), g_k.to(dk), g_v.to(dv), None, None
 
@@ -2836,10 +2853,14 @@ class _AttentionSharedKV(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=q.device)
         ws = _workspace(lib.mbv_attn_workspace_bytes(b, nq, nl, num_heads, d), q.device)
-        rc = lib.mbv_attn_fwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
-                                 ld, _ptr(mask), _dt_flag(dt), b, nq, nl, num_heads, d, _ptr(out),
-                                 _ptr(lse), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'mbv_attn_fwd_ld')
+        kp, vp = ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off)
+        if _k6_split(dt, num_heads, d, ld, q, out) and (k_cat.data_ptr() + off) % 16 == 0 and (v_cat.data_ptr() + off) % 16 == 0:
+            check(lib.mbv_attn_split_fwd_ld(_ptr(q), kp, vp, ld, _ptr(mask), b, nq, nl, num_heads, d, _ptr(out), _ptr(lse),
+                                            _ptr(ws), ws.numel(), _stream()), 'mbv_attn_split_fwd_ld')
+        else:
+            rc = lib.mbv_attn_fwd_ld(_ptr(q), kp, vp, ld, _ptr(mask), _dt_flag(dt), b, nq, nl, num_heads, d, _ptr(out),
+                                     _ptr(lse), _ptr(ws), ws.numel(), _stream())
+            check(rc, 'mbv_attn_fwd_ld')
         ctx.save_for_backward(q, mask, out, lse)
         ctx.holder, ctx.slot, ctx.num_heads = holder, slot, num_heads
         return out
@@ -2860,11 +2881,16 @@ class _AttentionSharedKV(torch.autograd.Function):
         grad_out = grad_out.to(q.dtype).contiguous()
         g_q = torch.empty((b, nq, e), dtype=torch.float32, device=q.device)
         bf = _dt_flag(q.dtype)
-        rc = lib.mbv_attn_bwd_ld(_ptr(q), ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off),
-                                 ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), bf, b, nq, nl, h,
-                                 e // h, _ptr(g_q), ctypes.c_void_p(holder.dk_cat.data_ptr() + off),
-                                 ctypes.c_void_p(holder.dv_cat.data_ptr() + off), ld, bf, _stream())
-        check(rc, 'mbv_attn_bwd_ld')
+        kp, vp = ctypes.c_void_p(k_cat.data_ptr() + off), ctypes.c_void_p(v_cat.data_ptr() + off)
+        dkp, dvp = ctypes.c_void_p(holder.dk_cat.data_ptr() + off), ctypes.c_void_p(holder.dv_cat.data_ptr() + off)
+        if (_k6_split(q.dtype, h, e // h, ld, q, out, grad_out) and (k_cat.data_ptr() + off) % 16 == 0
+                and (v_cat.data_ptr() + off) % 16 == 0 and holder.dk_cat.dtype == torch.float32):
+            check(lib.mbv_attn_split_bwd_ld(_ptr(q), kp, vp, ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), b, nq, nl, h,
+                                            e // h, _ptr(g_q), dkp, dvp, ld, _stream()), 'mbv_attn_split_bwd_ld')
+        else:
+            rc = lib.mbv_attn_bwd_ld(_ptr(q), kp, vp, ld, _ptr(mask), _ptr(out), _ptr(grad_out), _ptr(lse), bf, b, nq, nl, h,
+                                     e // h, _ptr(g_q), dkp, dvp, ld, bf, _stream())
+            check(rc, 'mbv_attn_bwd_ld')
         holder.written.add(slot)
         return g_q.to(ctx.q_dtype), None, None, None, None, None
 

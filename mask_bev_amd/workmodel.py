@@ -168,6 +168,18 @@ def _attn(a, bwd: bool, ld: bool) -> Work:
     return ('k_attn_fwd_split', 'hbm', b * (q * e * es * 2 + 2 * k * e * es + q * k), 4.0 * b * heads * q * k * d)
 
 
+def _attn_split(a, bwd: bool) -> Work:
+    """K6 on f32 tensors in the split mode: the f32 form's bytes and ALGORITHMIC flops.  fwd: (q, k, v, ld, mask, b, Q, L, heads, d,
+    ...); bwd: (q, k, v, ld, mask, out, dout, lse, b, Q, L, heads, d, ...)."""
+    i0 = 8 if bwd else 5
+    b, q, k, heads, d = (_i(a[i0 + j]) for j in range(5))
+    e = heads * d
+    if bwd:
+        return ('k_attn_bwd', 'hbm', b * (2 * q * e * 4 + 2 * k * e * 4 + q * k) + b * (q * e * 4 + 2 * k * e * 4),
+                10.0 * b * heads * q * k * d)
+    return ('k_attn_fwd_split', 'hbm', b * (q * e * 4 * 2 + 2 * k * e * 4 + q * k), 4.0 * b * heads * q * k * d)
+
+
 def _gemm16(a, layout: str) -> Work:
     if layout == 'nt':
         m, n, k, f32 = _i(a[5]), _i(a[6]), _i(a[7]), _i(a[12])
@@ -344,6 +356,8 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_attn_fwd_ld': lambda a: _attn(a, False, True),
     'mbv_attn_bwd': lambda a: _attn(a, True, False),
     'mbv_attn_bwd_ld': lambda a: _attn(a, True, True),
+    'mbv_attn_split_fwd_ld': lambda a: _attn_split(a, False),
+    'mbv_attn_split_bwd_ld': lambda a: _attn_split(a, True),
     'mbv_gemm16_nt': lambda a: _gemm16(a, 'nt'),
     'mbv_gemm16_nn': lambda a: _gemm16(a, 'nn'),
     'mbv_gemm16_nn_parts': lambda a: _gemm16(a, 'nn_parts'),

@@ -41,8 +41,8 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_msda_fwd_v4', r'k_msda_fwd', []),
     ('k_add_ln_bwd', r'k_add_ln_bwd', [r'k_ln_param_reduce']),
     ('k_add_ln_fwd', r'k_add_ln_fwd', []),
-    ('k_attn_bwd', r'k_attn_bwd', []),
-    ('k_attn_fwd_split', r'k_attn_fwd_split', [r'k_attn_fwd_combine', r'k_attn_combine']),
+    ('k_attn_bwd', r'k_attn(_split)?_bwd', []),
+    ('k_attn_fwd_split', r'k_attn_fwd_split|k_attn_split_fwd', [r'k_attn_fwd_combine', r'k_attn_combine']),
     ('k_wgrad_small', r'k_wgrad_small\(', []),
     ('k_wgrad_small_group', r'k_wgrad_small_group', []),
     ('k_colsum_group', r'k_colsum_group', []),

@@ -24,9 +24,14 @@ CASES = [(2, 100, 1024, 8, 32, True), (1, 100, 100, 8, 32, False), (2, 8, 25, 8,
 
 
 @pytest.mark.parametrize('B,Q,L,heads,D,masked', CASES)
-@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['f32', 'f32_exact', 'bf16', 'fp16'])
 def test_attention_fwd_bwd(device, B, Q, L, heads, D, masked, dtype):
-    from mask_bev_amd import ops
+    """'f32': the split mode (IEEE-half pairs on the 16-bit matrix pipe, per-tile scales); 'f32_exact': v_mfma_f32_32x32x2_f32
+    (switches.k6_split off)."""
+    from mask_bev_amd import ops, switches
+    if dtype == 'f32_exact':
+        with switches.override(k6_split=False):
+            return test_attention_fwd_bwd(device, B, Q, L, heads, D, masked, 'f32')
     g = torch.Generator().manual_seed(Q * 7 + L)
     E = heads * D
     q, k, v = (torch.randn(B, n, E, generator=g) for n in (Q, L, L))
@@ -181,3 +186,44 @@ def test_level_inputs_node_on_the_gpu(device, arena):
     assert torch.equal(a, a2.to(dt)) and torch.equal(k, k2.to(dt))
     assert torch.allclose(g_mem, mem.grad, rtol=1e-5, atol=1e-5)
     assert torch.allclose(g_lw, lw2.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Q,L,heads,D,gscale,kmax', [(2, 100, 1024, 8, 32, 1e-6, 1.0), (1, 100, 100, 8, 32, 1.0, 1.0),
+                                                        (2, 100, 4096, 8, 32, 1e3, 1.0), (2, 100, 4096, 8, 32, 1e3, 10.0),
+                                                        (1, 130, 300, 4, 16, 3e-4, 1.0), (1, 60, 200, 2, 64, 1.0, 1.0)])
+def test_split_mode_against_float64(device, B, Q, L, heads, D, gscale, kmax):
+    """K6's split mode (f32 tensors, products from IEEE-half pairs, per-tile power-of-two scales) against the float64 attention,
+    with the exact-f32 MFMA form beside it: output and the three gradients within 4e-6 of the result's maximum — or, where f32
+    arithmetic itself is the limit, within 2x the exact form's own error — for output gradients of 1e-6 ... 1e+3 and keys /
+    values of very different magnitudes per head.  (A query with ONE attendable key has dS = p (dP - delta) = 0 by cancellation:
+    both forms leave ~ 2-4e-5 of noise in dK there.  `kmax` = 10 makes logits of +- 40: a probability's exponent carries its
+    dot product's error, 2^-21 of sum|q_d k_d| for half pairs against 2^-24 for f32 — 8x, inside the same bar.)"""
+    from mask_bev_amd import ops, switches
+    g = torch.Generator().manual_seed(Q + L + D)
+    E = heads * D
+    q = torch.randn(B, Q, E, generator=g)
+    k = torch.randn(B, L, E, generator=g) * torch.logspace(-2, float(torch.log10(torch.tensor(kmax))), heads).repeat_interleave(D)
+    v = torch.randn(B, L, E, generator=g) * torch.logspace(1, -3, heads).repeat_interleave(D)
+    go = torch.randn(B, Q, E, generator=g) * gscale
+    blocked = torch.rand(B, Q, L, generator=g) < 0.5
+    blocked[:, 0] = True
+    blocked[:, 0, L // 2] = False
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = ref_attention(qr, kr, vr, blocked, heads)
+    ref.backward(go.double())
+
+    def err(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max().clamp(min=1e-300))
+
+    errs = {}
+    for split in (False, True):
+        with switches.override(k6_split=split):
+            qd, kd, vd = (t.to(device).requires_grad_() for t in (q, k, v))
+            out = ops.attention(qd, kd, vd, blocked.to(device).unsqueeze(1), heads)
+            out.backward(go.to(device))
+        errs[split] = {name: err(a, b) for name, a, b in (('out', out.detach(), ref.detach()), ('dq', qd.grad, qr.grad),
+                                                           ('dk', kd.grad, kr.grad), ('dv', vd.grad, vr.grad))}
+    for name, e in errs[True].items():
+        bar = max(4e-6, 2.0 * errs[False][name]) * (8.0 if kmax > 1 else 1.0)
+        assert e <= bar, (name, e, errs[False][name])
