@@ -213,9 +213,23 @@ int launch(int wt, const float* x, const float* w, float* y, long m, int c, int 
 
 }  // namespace
 
+// The largest dynamic LDS a launch of this file asks for (kWaves x 32 x (128 + 4) floats = 67 584 B for the <64, 2>, <32, 4> and
+// <8, 4> shapes): more than the 64 KB some devices allow a workgroup (gfx950: 160 KB) — such a device gets "unsupported", and
+// the callers keep the library GEMM, instead of a failed launch.
+static bool skinny_lds_fits() {
+  static int limit = -1;                 // an attribute of the device, queried once
+  if (limit < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+      v = 65536;
+    limit = v;
+  }
+  return (size_t)limit >= (size_t)kWaves * 32 * (128 + 4) * sizeof(float);
+}
+
 extern "C" int mbv_skinny_gemm_f32_supported(int64_t m, int32_t contraction, int32_t out_cols) {
   return m > 0 && contraction >= 1 && contraction <= 128 && out_cols >= 32 && out_cols <= 128 && out_cols % 32 == 0 &&
-         m * (int64_t)(contraction > out_cols ? contraction : out_cols) < 0x7fffffffffLL;
+         m * (int64_t)(contraction > out_cols ? contraction : out_cols) < 0x7fffffffffLL && skinny_lds_fits();
 }
 
 static int skinny_dispatch(const float* x, const float* w, float* y, int64_t m, int32_t c, int32_t n, int32_t ldw,

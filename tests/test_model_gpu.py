@@ -435,8 +435,9 @@ def _oracle_with_decisions(cfg, sd_g, scans, labels, gt, seed):
 #         logits' 1.5-2e-2 is rounding (8 significand bits through 39 layers), the intermediate layers' 5e-2 / 2e-1 were flips.
 #   fp16  2.2e-3, 3.3e-3 / 3.1e-3, 1.2e-4, gradients 6e-4 .. 3.0e-2; free-running flips 1 bit.
 # The 1e-2 / 2e-2 (bf16) and 2e-3 / 4e-3 (fp16) VERDICT r03 proposed for this test are NOT met: rounding alone exceeds them.
-TEACHER_TOL = {'bf16': dict(final=2.5e-2, layer_mask=3e-2, layer_cls=8e-2, loss=2e-3, grad_l2=1.2e-1),
-               'fp16': dict(final=4e-3, layer_mask=6e-3, layer_cls=6e-3, loss=1e-3, grad_l2=5e-2)}
+# (round 5, ADVICE r04: the bounds follow the measured values with a ~ 30 % margin)
+TEACHER_TOL = {'bf16': dict(final=2.0e-2, layer_mask=2.5e-2, layer_cls=6.5e-2, loss=1.5e-3, grad_l2=1.0e-1),
+               'fp16': dict(final=3e-3, layer_mask=4.5e-3, layer_cls=4.5e-3, loss=5e-4, grad_l2=4e-2)}
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
