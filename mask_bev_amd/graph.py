@@ -85,6 +85,9 @@ class GraphedTrainStep:
         self.x_static = torch.zeros_like(self._rows(x)).requires_grad_()
         self._x_in = (ops.PatchTokens(self.x_static, x.channels, x.patch) if isinstance(x, ops.PatchTokens)
                       else self.x_static)
+        if not isinstance(x, ops.PatchTokens) and self.x_static.dtype == torch.float32:
+            # fp32 compute: K3 leaves the map's absmax record for the captured patch projection — one record at a fixed address
+            ops.static_amax_register(self.x_static)
         x = self._rows(x)
         self.labels = labels.clone()
         # dense (B, Q, ny, nx) masks or the bit-packed targets of batch.instance_targets (K14)

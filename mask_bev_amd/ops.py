@@ -481,14 +481,19 @@ class _ScatterLayerNorm(torch.autograd.Function):
         # fp32 compute: the f32 map feeds the K20 patch projection — its absmax record from this launch (no pass over 0.5 GB)
         rec = None
         if not patch and switches.get('amax_hints') and switches.get('ln_bound_hints') and switches.get('gemm32s'):
-            # (a caller-owned map — read by a captured graph — gets ONE persistent record, cleared and rewritten every step)
-            rec = static_amax_record(out) if owned else amax_record(dev)
+            # (a registered caller-owned map — the static input of a captured graph — has ONE persistent record, cleared and
+            # rewritten here every step: static_amax_register)
+            rec = static_amax_record(out) if owned else None
+            if rec is not None:
+                rec.zero_()
+            else:
+                rec = amax_record(dev)
         rc = lib.mbv_scatter_layernorm_fwd2(_ptr(feats), _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(weight),
                                             _ptr(bias), batch, c, ny, nx, float(eps), int(patch),
                                             _dt_flag(dt) if patch else 0, _ptr(out), _ptr(stats), _ptr(ws), ws.numel(),
                                             _ptr(rec), _stream(), *TIMER.events('k_ln_apply')[2:])
         check(rc, 'mbv_scatter_layernorm_fwd2')
-        amax_hint_set(out, rec, static=owned)
+        amax_hint_set(out, rec)
         ctx.save_for_backward(feats, weight, stats, cell_to_pillar, pillar_batch_start)
         ctx.dims = (batch, c, ny, nx)
         ctx.params = (weight, bias)
@@ -1325,17 +1330,26 @@ _LAST_HINT = [0, None, False]
 _STATIC_RECS: dict = {}
 
 
-def static_amax_record(buf: torch.Tensor) -> torch.Tensor:
-    """The persistent (1, 64) absmax record of a caller-owned buffer, cleared for the producer's next launch."""
-    key = (buf.data_ptr(), buf.numel())
-    rec = _STATIC_RECS.get(key)
-    if rec is None or rec.device != buf.device:
-        if len(_STATIC_RECS) > 64:
-            _STATIC_RECS.clear()
-        rec = _STATIC_RECS[key] = torch.zeros((1, AMAX_SLOTS), dtype=torch.int32, device=buf.device)
-    else:
-        rec.zero_()
+def static_amax_register(buf: torch.Tensor) -> torch.Tensor:
+    """Give a long-lived buffer (the static input of a captured graph, graph.py) ONE persistent (1, 64) absmax record: the
+    producer that refills the buffer every step (K3) clears and rewrites it, every K20 product that reads the buffer — under
+    whatever tensor object, inside or outside a capture — finds it by the buffer's address while ``buf`` itself is alive."""
+    import weakref
+    for k in [k for k, (ref, _) in _STATIC_RECS.items() if ref() is None]:
+        del _STATIC_RECS[k]
+    rec = torch.zeros((1, AMAX_SLOTS), dtype=torch.int32, device=buf.device)
+    _STATIC_RECS[(buf.data_ptr(), buf.numel())] = (weakref.ref(buf), rec)
     return rec
+
+
+def static_amax_record(t: torch.Tensor) -> Optional[torch.Tensor]:
+    e = _STATIC_RECS.get((t.data_ptr(), t.numel()))
+    if e is None:
+        return None
+    src = e[0]()
+    if src is None or src.data_ptr() != t.data_ptr() or src.numel() != t.numel() or e[1].device != t.device:
+        return None
+    return e[1]
 
 
 def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor], static: bool = False) -> None:
@@ -1364,6 +1378,10 @@ def amax_hint_refresh(t) -> None:
 
 
 def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
+    if _STATIC_RECS:
+        rec = static_amax_record(t)
+        if rec is not None:
+            return rec
     capturing = torch.cuda.is_current_stream_capturing() if t.is_cuda else False
     e = _AMAX_HINTS.get(t.data_ptr())
     if e is not None:
@@ -1428,7 +1446,11 @@ def weight_amax(w: torch.Tensor) -> torch.Tensor:
     if e is not None and e[0] == (tag, w._version):
         return e[1]
     # (the list is per stream: a weight used on a side stream is refreshed by that stream's first miss, not by every stream's)
-    reg = _WEIGHT_REG.setdefault(tag[2], {})
+    reg = _WEIGHT_REG.get(tag[2])
+    if reg is None:
+        # a stream seen for the first time (the capture stream of a graph): it starts from every weight any stream has used, so
+        # that its first miss is one grouped refresh and not one launch per weight baked into the graph
+        reg = _WEIGHT_REG[tag[2]] = {k2: r for other in list(_WEIGHT_REG.values()) for k2, r in other.items()}
     reg[key] = weakref.ref(w)
     todo = []
     for k2, ref in list(reg.items()):

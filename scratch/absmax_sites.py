@@ -7,7 +7,7 @@ sites, byts = collections.Counter(), collections.Counter()
 orig = ops.f32_absmax
 def spy(tensors):
     st = traceback.extract_stack(limit=5)
-    key = ' < '.join(f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in reversed(st[:-1]))[:150]
+    key = ('CAPTURE ' if torch.cuda.is_current_stream_capturing() else '') + ' < '.join(f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in reversed(st[:-1]))[:150]
     sites[key] += 1
     byts[key] += sum(t.numel() * 4 for t in tensors)
     return orig(tensors)
@@ -24,7 +24,7 @@ def spy_group(items):
     return orig_group(items)
 ops.gemm32s_tn_group = spy_group
 import bench
-sys.argv = ['bench.py', '--dtype', 'fp32', '--steps', '2', '--warmup', '1', '--no-graph', '--no-cpu-baseline', '--no-fp32', '--no-kernel-profile']
+sys.argv = ['bench.py', '--dtype', 'fp32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-fp32', '--no-kernel-profile'] + (['--no-graph'] if os.environ.get('EAGER', '1') == '1' else [])
 bench.main()
 n = 3
 print('absmax passes per step by call site (launches, MB):')
