@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _rank(rank, world, port, out_dir):
+def _rank(rank, world, port, out_dir, compute_dtype='bf16'):
     import torch.distributed as dist
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -29,7 +29,7 @@ def _rank(rank, world, port, out_dir):
     from mask_bev_amd.mask_bev_module import MaskBevModule
     from tests.util_cfg import random_gt, random_scans, tiny_kwargs
     torch.manual_seed(100 + rank)                       # different initial weights: construction must broadcast rank 0's
-    kw = dict(tiny_kwargs(nx=96, ny=96, q=8), compute_dtype='bf16')
+    kw = dict(tiny_kwargs(nx=96, ny=96, q=8), compute_dtype=compute_dtype)
     m = MaskBevModule(**kw).to(dev).train()
     m.log_scalars = False
     m._panoptic_head._panoptic_head.num_points = 1500
@@ -98,10 +98,13 @@ def _rank(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_graph_step_reduces_the_arena(tmp_path):
+@pytest.mark.parametrize('compute_dtype', ['bf16', 'fp32'])
+def test_two_rank_graph_step_reduces_the_arena(tmp_path, compute_dtype):
+    """(fp32: the K20 path — absmax records made inside the capture, the static input map's registered record, the grouped
+    weight gradients — under the same two-rank graph step.)"""
     import torch.multiprocessing as mp
     world, port = 2, str(tmp_path / 'rendezvous')
-    mp.spawn(_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank, args=(world, port, str(tmp_path), compute_dtype), nprocs=world, join=True)
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     for r in (r0, r1):
