@@ -947,7 +947,9 @@ class _MSDAQuerySide(torch.autograd.Function):
         host_b = (ctypes.c_int64 * (2 * levels))(*[int(v) for hw in shapes_host for v in hw])
         g = torch.empty((t, width), dtype=dt, device=dev)                 # [d value | d offsets | d logits]
         dims = (b, n, heads, d, levels, n, points)
-        packed = dt in _LO_DTYPES and width % 2 == 0 and msda_value_packed_ok(dims, host_b)
+        # (fp32 compute: the packed form's 2^-30-of-the-bound fixed point is ~ 1e-6 of a typical sum — `switches.msda_packed_f32`)
+        packed = ((dt in _LO_DTYPES or (dt == torch.float32 and switches.get('msda_packed_f32'))) and width % 2 == 0
+                  and msda_value_packed_ok(dims, host_b))
         if value.dtype in _LO_DTYPES and not packed:
             # the forward stored the value map in 16 bits on the promise of the packed gradient; the f64 form reads the
             # map as f32 — were a switch flipped between the two halves it would read out of bounds

@@ -47,6 +47,7 @@ _DEFAULTS: Dict[str, Any] = {
     'ffn32': True,                # fp32 compute: the FFN pair on K20 with the activation / its derivative in the GEMM epilogues
     'k4_split': True,             # fp32 compute: K4's products on the 16-bit matrix pipe from IEEE-half pairs (f32 tensors)
     'k6_split': True,             # fp32 compute: the decoder attention's products the same way (per-tile scales)
+    'msda_packed_f32': True,      # fp32 compute: K5's value gradient in the packed fixed-point form of the 16-bit modes
     'ln_bound_hints': True,       # fp32 compute: a LayerNorm output's K20 scale from sqrt(C) max|gamma| + max|beta| instead of a pass over it
     'conv3x3_k20': True,          # fp32 compute: the pixel decoder's 3 x 3 convolution as K20 products on a zero-bordered channels-last copy (no MIOpen)
     'conv3x3_k17': True,          # 16-bit compute: the same convolution as K17 products
