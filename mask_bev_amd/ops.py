@@ -1324,11 +1324,10 @@ def operand_amax(tensors, activations=None):
 # behind qkv + attention, fc1's output gradient behind fc2's data gradient) — found by the tensor's address, valid only while the very tensor object is alive and unmodified
 # (weak reference + version).  A consumer without a valid hint runs the absmax pass: a missed hint costs time, never accuracy.
 # A record made OUTSIDE a stream capture must not be baked into a captured launch (the replay would read the address of that one
-# eager step's record for ever) and vice versa: a hint is valid only in the capture state it was made in — unless its record is
-# STATIC (one persistent record per caller-owned buffer, rewritten by the producer every step: the eager encoder's map that a
-# captured graph reads).
+# eager step's record for ever) and vice versa: a hint is valid only in the capture state it was made in.  What crosses that line
+# — the eager encoder's map that a captured graph reads — has a REGISTERED persistent record instead (static_amax_register).
 _AMAX_HINTS: dict = {}
-_LAST_HINT = [0, None, False]
+_LAST_HINT = [0, None]
 _STATIC_RECS: dict = {}
 
 
@@ -1354,7 +1353,7 @@ def static_amax_record(t: torch.Tensor) -> Optional[torch.Tensor]:
     return e[1]
 
 
-def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor], static: bool = False) -> None:
+def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor]) -> None:
     if rec is None or not torch.is_tensor(t) or not t.is_cuda:
         return
     import weakref
@@ -1363,12 +1362,12 @@ def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor], static: bool = F
             del _AMAX_HINTS[k]
         if len(_AMAX_HINTS) > 512:
             _AMAX_HINTS.clear()
-    cap = None if static else torch.cuda.is_current_stream_capturing()
+    cap = torch.cuda.is_current_stream_capturing()
     base = t._base
     if base is not None and base.data_ptr() == t.data_ptr() and base.numel() == t.numel() and base.dtype == t.dtype:
         t = base          # a reshaped view of the whole tensor: the hint lives with the tensor, not with the temporary view object
     _AMAX_HINTS[t.data_ptr()] = (weakref.ref(t), t._version, rec, cap)
-    _LAST_HINT[0], _LAST_HINT[1], _LAST_HINT[2] = t.data_ptr(), rec, static
+    _LAST_HINT[0], _LAST_HINT[1] = t.data_ptr(), rec
 
 
 def amax_hint_refresh(t) -> None:
@@ -1376,7 +1375,7 @@ def amax_hint_refresh(t) -> None:
     same buffer with its version bumped by ``mark_dirty``)."""
     if torch.is_tensor(t) and t.is_cuda and _LAST_HINT[0] == t.data_ptr() and _LAST_HINT[1] is not None \
             and amax_hint_get(t) is None:
-        amax_hint_set(t, _LAST_HINT[1], _LAST_HINT[2])
+        amax_hint_set(t, _LAST_HINT[1])
 
 
 def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
@@ -1390,7 +1389,7 @@ def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
         ref, version, rec, cap = e
         src = ref()
         if (src is not None and src.data_ptr() == t.data_ptr() and src.numel() == t.numel() and src._version == version
-                and rec.device == t.device and (cap is None or cap == capturing)):
+                and rec.device == t.device and cap == capturing):
             return rec
     # a slice (column block, row range) of a hinted tensor: the whole tensor's record bounds it
     base = t._base
@@ -1400,7 +1399,7 @@ def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
             ref, version, rec, cap = e
             src = ref()
             if (src is not None and src.data_ptr() == base.data_ptr() and src.numel() == base.numel()
-                    and src._version == version and rec.device == t.device and (cap is None or cap == capturing)):
+                    and src._version == version and rec.device == t.device and cap == capturing):
                 return rec
     return None
 
