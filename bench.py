@@ -63,6 +63,10 @@ def parse():
                          'MBV_DIST_BACKEND=gloo it runs where no RCCL fabric is available)')
     ap.add_argument('--aten-detail', default=None, metavar='FILE',
                     help='write the per-operator times of the ATen calls of the instrumented step (name, shapes, call site)')
+    ap.add_argument('--force-reducer', action='store_true',
+                    help='N = 1: run the data-parallel step anyway — `init_process_group("nccl", world_size=1)`, the arena '
+                         'reducer and its four-piece exchange around the two graph replays — so that RCCL executes the '
+                         'graph step\'s collectives on the one GPU there is (implies --dry-run-collectives)')
     ap.add_argument('--grad-wire', default='f32', choices=['f32', 'bf16'],
                     help='N > 1: type the gradient all-reduce travels in (bf16 = half the xGMI bytes, sums formed in bf16; '
                          'default f32 = the exact in-place exchange)')
@@ -74,6 +78,15 @@ def parse():
     ap.add_argument('--switch', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set a path selector of mask_bev_amd/switches.py (recorded in config.switches)')
     return ap.parse_args()
+
+
+def free_port() -> int:
+    """A TCP port the kernel just handed out (bound to port 0 and released): not derived from the pid, which collides on
+    a shared box."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
 
 
 def cpu_baseline_worker(state_file: str, workload: str, threads: int, budget_s: float):
@@ -411,6 +424,14 @@ def compact_line(full: dict, detail_path=None) -> dict:
             cb['row'] = {k: r.get(k) for k in ('threads', 'iterations', 'fwd_bwd_s', 'fwd_s', 'fwd_scans_per_s', 'note')}
         line['cpu_baseline'] = cb
     line = _short(line)
+    # unbounded strings (an exception text in fp32.error / roofline.error / cpu_baseline.sample) are cut, never fatal
+    def _clip(node):
+        for k, v in list(node.items()):
+            if isinstance(v, dict):
+                _clip(v)
+            elif isinstance(v, str) and len(v) > 300:
+                node[k] = v[:297] + '...'
+    _clip(line)
     for drop in (('collectives', 'schedule'), ('roofline_top',), ('cpu_baseline', 'row'), ('fp32', 'roofline'),
                  ('roofline_worst',), ('config', 'switches'), ('step_roofline',)):
         if len(json.dumps(line)) < LINE_LIMIT:
@@ -419,7 +440,10 @@ def compact_line(full: dict, detail_path=None) -> dict:
         for k in drop[:-1]:
             node = node.get(k) or {}
         node.pop(drop[-1], None)
-    assert len(json.dumps(line)) < LINE_LIMIT, 'bench line over the limit'
+    if len(json.dumps(line)) >= LINE_LIMIT:      # last resort: the contract keys alone (the full record is in the detail file)
+        line = {k: line.get(k) for k in top + ('config', 'roofline', 'cpu_baseline', 'roofline_detail')}
+        line['config'] = {'workload': (line.get('config') or {}).get('workload')}
+        line['truncated'] = True
     return line
 
 
@@ -452,7 +476,7 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         # launched without torchrun: spawn it as a child and exit with its code
         import subprocess
-        port = 29500 + os.getpid() % 2000
+        port = free_port()
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
@@ -463,7 +487,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     import torch.distributed as dist
-    if world > 1:
+    force = args.force_reducer and world == 1
+    if force:
+        args.dry_run_collectives = True
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        os.environ.update(RANK='0', WORLD_SIZE='1')
+    if world > 1 or force:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('MBV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; gloo only for smoke tests
         if backend == 'nccl':
@@ -484,7 +514,7 @@ def main():
         model.flatten_parameters()      # flat param / grad / bf16-shadow arena + single-launch AdamW (K11)
     opt = model.configure_optimizers()['optimizer']
     reducer = None
-    if world > 1:
+    if world > 1 or force:
         from mask_bev_amd.ddp import GradientAllReducer
         reducer = GradientAllReducer(model, bucket_mb=64.0,
                                      grad_dtype=torch.bfloat16 if args.grad_wire == 'bf16' else None)
@@ -624,7 +654,8 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic' if args.distribution == 'lidar' else 'synthetic (uniform x/y points)',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
-                        step='fwd + Hungarian loss + bwd + AdamW; inputs device-resident', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if world > 1 else None), replica_param_checksum_spread=replica_spread,
+                        step='fwd + Hungarian loss + bwd + AdamW; inputs device-resident', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if (world > 1 or force) else None),
+                        forced_reducer=True if force else None, replica_param_checksum_spread=replica_spread,
                         final_loss=final_loss,
                         switches={k: v for k, v in switches._values.items() if v != switches.defaults()[k]}),
             roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,
@@ -639,7 +670,7 @@ def main():
             t0m = last[0][1]
             total = sum(nb for _, _, nb in last)
             line['collectives'] = dict(
-                backend=os.environ.get('MBV_DIST_BACKEND', 'nccl'), bytes_per_step=total,
+                backend=os.environ.get('MBV_DIST_BACKEND', 'nccl'), world_size=world, bytes_per_step=total,
                 schedule=[dict(mark=name, ms=round((t - t0m) * 1e3, 3), mb=round(nb / 1e6, 2)) for name, t, nb in last],
                 note='host launch times: a piece is launched as soon as the host has issued the work that completes its '
                      'gradients; on the device it waits for that work through stream order (the comm stream waits for '
@@ -652,7 +683,7 @@ def main():
                                             sample=f'failed: {type(e).__name__}: {e}')
         detail_path = write_detail(line, args.detail_out)
         print(json.dumps(compact_line(line, detail_path)), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

@@ -106,7 +106,7 @@ def pytest_sessionfinish(session, exitstatus):
 
 # per-kernel parity first, whole-model next, then captured-graph / launcher / multi-process tests
 _LATE = {'test_model_gpu.py': 1, 'test_guard_gpu.py': 1, 'test_fp16_gpu.py': 2, 'test_graph_gpu.py': 3, 'test_launcher_gpu.py': 4,
-         'test_ddp_graph_gpu.py': 5}
+         'test_ddp_graph_gpu.py': 5, 'test_ddp_rccl_gpu.py': 5}
 
 
 def pytest_collection_modifyitems(session, config, items):
