@@ -682,6 +682,14 @@ def main():
                 line['cpu_baseline'] = dict(value=None, unit='scans/s', cores=os.cpu_count(), kind='port',
                                             sample=f'failed: {type(e).__name__}: {e}')
         detail_path = write_detail(line, args.detail_out)
+        if world > 1 or force:
+            # RCCL prints its version banner through C stdio, which is fully buffered on a pipe: push it out now so that
+            # the JSON line stays the LAST line of stdout
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
         print(json.dumps(compact_line(line, detail_path)), flush=True)
     if world > 1 or force:
         dist.destroy_process_group()
