@@ -85,9 +85,11 @@ class GraphedTrainStep:
         self.x_static = torch.zeros_like(self._rows(x)).requires_grad_()
         self._x_in = (ops.PatchTokens(self.x_static, x.channels, x.patch) if isinstance(x, ops.PatchTokens)
                       else self.x_static)
-        if not isinstance(x, ops.PatchTokens) and self.x_static.dtype == torch.float32:
+        if not isinstance(x, ops.PatchTokens) and self.x_static.dtype == torch.float32 and ops.static_amax_wanted():
             # fp32 compute: K3 leaves the map's absmax record for the captured patch projection — one record at a fixed address
-            ops.static_amax_register(self.x_static)
+            static_rec = ops.static_amax_register(self.x_static)
+        else:
+            static_rec = None
         x = self._rows(x)
         self.labels = labels.clone()
         # dense (B, Q, ny, nx) masks or the bit-packed targets of batch.instance_targets (K14)
@@ -108,6 +110,10 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.x_static.data.copy_(x)
+            if static_rec is not None:
+                # the warm-up passes read the static map through its registered record, which only K3's launch of a real
+                # step writes: give it this copy's maximum (an all-zero record reads as "unscaled")
+                static_rec.copy_(ops.f32_absmax([self.x_static.detach().view(-1, self.x_static.shape[-1])]))
             for _ in range(warmup_iters):
                 self._forward_backward()
         torch.cuda.current_stream().wait_stream(side)
@@ -124,6 +130,7 @@ class GraphedTrainStep:
         # (2) backward of the earlier stages.  Between the two replays a data-parallel step launches the all-reduce
         # of the gradients graph 1 completed (head + last stage = 38 % of the bytes), which then runs on RCCL's
         # stream underneath graph 2; on one GPU the two replays are simply back to back.
+        ops.amax_new_capture()        # records / hints of an earlier captured step in this process are not this step's
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss_static = self._forward_backward_head()

@@ -480,7 +480,7 @@ class _ScatterLayerNorm(torch.autograd.Function):
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
         # fp32 compute: the f32 map feeds the K20 patch projection — its absmax record from this launch (no pass over 0.5 GB)
         rec = None
-        if not patch and switches.get('amax_hints') and switches.get('ln_bound_hints') and switches.get('gemm32s'):
+        if not patch and static_amax_wanted():
             # (a registered caller-owned map — the static input of a captured graph — has ONE persistent record, cleared and
             # rewritten here every step: static_amax_register)
             rec = static_amax_record(out) if owned else None
@@ -556,6 +556,7 @@ def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
     ``patch`` = 4 returns :class:`PatchTokens` (the 16-bit type of the autocast region, or of ``out``) instead of the
     (B, C, ny, nx) f32 map; ``out`` is an optional destination buffer (no grad) of the result's shape and dtype."""
     patch_dtype = out.dtype if (out is not None and patch) else lo_dtype()
+    _LAST_HINT[1] = None             # (a forward that sets no hint must not hand `out` the record of an EARLIER tensor at its address)
     out = _ScatterLayerNorm.apply(feats.float(), weight.float(), bias.float(), p.cell_to_pillar,
                                   p.pillar_batch_start, batch, ny, nx, eps, patch, out, patch_dtype)
     amax_hint_refresh(out)           # (mark_dirty bumped a caller-owned buffer's version behind the forward's hint)
@@ -590,6 +591,7 @@ class _WindowAttention(torch.autograd.Function):
             q2 = qkv.view(-1, c3)
             rec = amax_hint_get(qkv) if switches.get('amax_hints') else None
             ctx.amax_qkv = rec if rec is not None else f32_absmax([q2])
+            AMAX_VERIFY.check(qkv, ctx.amax_qkv, 'window_attn_split_fwd qkv')
             check(lib.mbv_window_attn_split_fwd(_ptr(qkv), _ptr(bias32), _ptr(table32), b, h, w, c, num_heads, ws, shift,
                                                 _amax_ptr(ctx.amax_qkv, 0), _ptr(out), _ptr(lse), _stream()),
                   'mbv_window_attn_split_fwd')
@@ -628,6 +630,8 @@ class _WindowAttention(torch.autograd.Function):
             if rec_do is None:
                 rec_do = f32_absmax([go2])
             rec_out = amax_record(qkv.device) if hints else None
+            AMAX_VERIFY.check(qkv, ctx.amax_qkv, 'window_attn_split_bwd qkv')
+            AMAX_VERIFY.check(grad_out, rec_do, 'window_attn_split_bwd d(out)')
             check(lib.mbv_window_attn_split_bwd(_ptr(qkv), _ptr(bias32), _ptr(table32), _ptr(out), _ptr(grad_out), _ptr(lse),
                                                 b, h, w, c, num_heads, ws, shift, _amax_ptr(ctx.amax_qkv, 0),
                                                 _amax_ptr(rec_do, 0), _ptr(g_qkv), _ptr(g_table), _ptr(g_bias),
@@ -1247,6 +1251,30 @@ def gemm16_tn(g: torch.Tensor, x: torch.Tensor, out_dtype: Optional[torch.dtype]
 AMAX_SLOTS = 64          # words per absmax record (csrc/gemm_f32s.hip kAmaxSlots)
 
 
+# Capture generation: bumped once per captured training step (graph.py, before its first capture).  Records, hints and
+# weight / LayerNorm-bound entries made inside a capture are tagged with it, so that a SECOND captured step of the same
+# process (tests, a re-capture) never takes a record whose zero-fill / refresh launch was captured in the previous graph —
+# the new graph's replays would not re-zero it and it would become a running maximum over all steps.
+CAPTURE_ID = [0]
+
+
+def amax_new_capture() -> int:
+    CAPTURE_ID[0] += 1
+    return CAPTURE_ID[0]
+
+
+def _capture_tag() -> int:
+    """0 outside a stream capture, the capture generation (>= 1) inside one."""
+    return max(1, CAPTURE_ID[0]) if torch.cuda.is_current_stream_capturing() else 0
+
+
+def static_amax_wanted() -> bool:
+    """Whether K3 writes the absmax record of its f32 map (the condition `_ScatterLayerNorm.forward` tests): a static
+    input buffer is registered (static_amax_register) only then — a registered record nobody writes would read as
+    "max|x| = 0" and run the patch projection unscaled."""
+    return bool(switches.get('amax_hints') and switches.get('ln_bound_hints') and switches.get('gemm32s'))
+
+
 class _AmaxPool:
     """Absmax records for K20 (csrc/gemm_f32s.hip): 64 device words each, whose maximum is the BITS of max|x| (or of a bound
     of it), max-combined by `mbv_f32_absmax_group` or by a producer kernel — so a record must be zero before its tensor's
@@ -1258,7 +1286,7 @@ class _AmaxPool:
         self.block, self.used, self.capturing = None, 0, False
 
     def take(self, device, n: int = 1) -> torch.Tensor:
-        cap = torch.cuda.is_current_stream_capturing()
+        cap = _capture_tag()
         if (self.block is None or self.used + n > self.block.shape[0] or cap != self.capturing
                 or self.block.device != device):
             self.block = torch.zeros((256, AMAX_SLOTS), dtype=torch.int32, device=device)
@@ -1296,6 +1324,68 @@ def f32_absmax(tensors) -> torch.Tensor:
                                    PA(*[out.data_ptr() + 4 * AMAX_SLOTS * i for i in range(n)]), n, _stream()),
           'mbv_f32_absmax_group')
     return out
+
+
+class _AmaxVerify:
+    """``switches.amax_verify`` (debug, VERDICT r05 #6a): every absmax record a K20 product is about to consume — a producer's
+    hint, a derived bound, a static / weight / LayerNorm-bound record — is compared with a FRESH max|operand|, taken by a
+    torch reduction right in front of the product on the same stream.  Nothing is read on the host there (the pair
+    (true maximum, record's value) goes into a small device tensor), so the check also runs inside a stream capture and
+    again on every replay of the captured graph; :meth:`report` synchronises and returns the pairs.
+    Invariant under test: record >= max|x| (a smaller one overflows IEEE half once x is scaled by 2^13 / record) and not
+    absurdly larger (every binade of slack is a bit of the 22-bit product lost)."""
+
+    CAPACITY = 8192
+
+    def __init__(self):
+        self.entries, self.fresh, self.cons = [], None, None
+
+    def reset(self):
+        self.entries = []
+
+    def check(self, t: torch.Tensor, rec, what: str) -> None:
+        if rec is None or not switches.get('amax_verify'):
+            return
+        if self.fresh is None or self.fresh.device != t.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise MaskBevHipError('amax_verify: run one eager step first (the result rows are allocated outside the capture)')
+            # persistent result rows, allocated outside any capture: a captured check rewrites ITS rows on every replay, and no
+            # temporary of the check lives in a graph's private pool (the fresh maximum comes from the library's own absmax
+            # kernel straight into its row — no torch reduction, no scratch)
+            self.fresh = torch.zeros((self.CAPACITY, AMAX_SLOTS), dtype=torch.int32, device=t.device)
+            self.cons = torch.zeros((self.CAPACITY, AMAX_SLOTS), dtype=torch.int32, device=t.device)
+        i = len(self.entries)
+        if i >= self.CAPACITY:
+            raise MaskBevHipError('amax_verify: more checks than result rows')
+        with torch.no_grad():
+            t2 = t.detach()
+            if t2.dim() != 2:
+                t2 = t2.reshape(-1, t2.shape[-1])
+            ok = (t2.dtype == torch.float32 and t2.stride(1) == 1 and t2.shape[1] % 4 == 0 and t2.stride(0) % 4 == 0
+                  and t2.data_ptr() % 16 == 0)
+            self.fresh[i].zero_()
+            if ok:
+                PA, LA = ctypes.c_void_p * 1, ctypes.c_int64 * 1
+                check(_lib.load().mbv_f32_absmax_group(PA(t2.data_ptr()), LA(t2.shape[0]), LA(t2.shape[1]), LA(t2.stride(0)),
+                                                       PA(self.fresh.data_ptr() + 4 * AMAX_SLOTS * i), 1, _stream()),
+                      'mbv_f32_absmax_group')
+            else:
+                torch.add(t2.abs().max().float().view(1).view(torch.int32).expand(AMAX_SLOTS), 0, out=self.fresh[i])
+            torch.add(rec.reshape(-1)[:AMAX_SLOTS], 0, out=self.cons[i])      # the record as the product is about to read it
+        self.entries.append((what, tuple(t.shape), bool(torch.cuda.is_current_stream_capturing())))
+
+    def report(self):
+        """[(what, shape, captured, max|x|, record)] after a device synchronisation."""
+        if not self.entries:
+            return []
+        torch.cuda.synchronize()
+        n = len(self.entries)
+        fresh = self.fresh[:n].max(1).values.view(torch.float32).cpu().tolist()
+        cons = self.cons[:n].max(1).values.view(torch.float32).cpu().tolist()
+        return [(w, s, c, f, r) for (w, s, c), f, r in zip(self.entries, fresh, cons)]
+
+
+AMAX_VERIFY = _AmaxVerify()
 
 
 def operand_amax(tensors, activations=None):
@@ -1362,7 +1452,7 @@ def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor]) -> None:
             del _AMAX_HINTS[k]
         if len(_AMAX_HINTS) > 512:
             _AMAX_HINTS.clear()
-    cap = torch.cuda.is_current_stream_capturing()
+    cap = _capture_tag()
     base = t._base
     if base is not None and base.data_ptr() == t.data_ptr() and base.numel() == t.numel() and base.dtype == t.dtype:
         t = base          # a reshaped view of the whole tensor: the hint lives with the tensor, not with the temporary view object
@@ -1372,7 +1462,9 @@ def amax_hint_set(t: torch.Tensor, rec: Optional[torch.Tensor]) -> None:
 
 def amax_hint_refresh(t) -> None:
     """After ``Function.apply``: the tensor object the caller holds may be a new wrapper of the one the forward hinted (or the
-    same buffer with its version bumped by ``mark_dirty``)."""
+    same buffer with its version bumped by ``mark_dirty``).  Callers clear ``_LAST_HINT[1]`` BEFORE the apply: the match is
+    by address, and a forward that sets no hint (library path) would otherwise re-attach the record of an earlier, already
+    freed tensor whose address the caching allocator handed to this output (an f16 overflow, not "time")."""
     if torch.is_tensor(t) and t.is_cuda and _LAST_HINT[0] == t.data_ptr() and _LAST_HINT[1] is not None \
             and amax_hint_get(t) is None:
         amax_hint_set(t, _LAST_HINT[1])
@@ -1383,7 +1475,7 @@ def amax_hint_get(t: torch.Tensor) -> Optional[torch.Tensor]:
         rec = static_amax_record(t)
         if rec is not None:
             return rec
-    capturing = torch.cuda.is_current_stream_capturing() if t.is_cuda else False
+    capturing = _capture_tag() if t.is_cuda else 0
     e = _AMAX_HINTS.get(t.data_ptr())
     if e is not None:
         ref, version, rec, cap = e
@@ -1434,7 +1526,7 @@ _LN_REG: dict = {}              # gamma's address -> [gamma ref, beta ref or Non
 
 
 def _amax_tag(dev):
-    return (PARAM_EPOCH[0], torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream(dev).cuda_stream)
+    return (PARAM_EPOCH[0], _capture_tag(), torch.cuda.current_stream(dev).cuda_stream)
 
 
 def weight_amax(w: torch.Tensor) -> torch.Tensor:
@@ -1546,6 +1638,8 @@ def gemm32s_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     pre = torch.empty((m, n), dtype=torch.float32, device=x.device) if (want_pre and _ACT[act]) else None
     rec = amax_record(x.device) if hint_out else None
+    AMAX_VERIFY.check(x, amax[0], 'gemm32s_nt x')
+    AMAX_VERIFY.check(w, amax[1], 'gemm32s_nt w')
     check(lib.mbv_gemm32s_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pre), m, n, k, x.stride(0), w.stride(0), n,
                              _amax_ptr(amax, 0), _amax_ptr(amax, 1), _ptr(rec), _ACT[act], 1, 0, 0, 0, _stream()),
           'mbv_gemm32s_nt')
@@ -1567,6 +1661,8 @@ def gemm32s_nn(g: torch.Tensor, w: torch.Tensor, amax_g: Optional[torch.Tensor] 
     k = w.shape[1]
     out = torch.empty((m, k), dtype=torch.float32, device=g.device)
     rec = amax_record(g.device) if hint_out else None
+    AMAX_VERIFY.check(g, amax_g, 'gemm32s_nn g')
+    AMAX_VERIFY.check(w, amax_w, 'gemm32s_nn w')
     check(lib.mbv_gemm32s_nn(_ptr(g), _ptr(w), _ptr(out), m, n, k, g.stride(0), w.stride(0), k, _amax_ptr(amax_g, 0),
                              _amax_ptr(amax_w, 0), _ptr(rec), 1, 0, 0, 0, _stream()), 'mbv_gemm32s_nn')
     amax_hint_set(out, rec)
@@ -1588,6 +1684,8 @@ def gemm32s_tn_acc(acc: torch.Tensor, g: torch.Tensor, x: torch.Tensor, amax_g: 
     k = x.shape[1]
     nbytes = lib.mbv_gemm32s_tn_workspace_bytes(m, n, k)
     ws = _workspace(nbytes, g.device) if nbytes else None
+    AMAX_VERIFY.check(g, amax_g, 'gemm32s_tn_acc g')
+    AMAX_VERIFY.check(x, amax_x, 'gemm32s_tn_acc x')
     check(lib.mbv_gemm32s_tn_acc(_ptr(g), _ptr(x), _ptr(acc), m, n, k, g.stride(0), x.stride(0), _amax_ptr(amax_g, 0),
                                  _amax_ptr(amax_x, 0), _ptr(ws), int(nbytes), _stream()), 'mbv_gemm32s_tn_acc')
 
@@ -1605,6 +1703,8 @@ class _PatchEmbed32(torch.autograd.Function):
         w2 = weight.reshape(e, -1)
         amax = tuple(operand_amax([image.view(b * c * h, w), w2], (True, False)))      # (K3 leaves the image's record)
         out = torch.empty((b, h // 4, w // 4, e), dtype=torch.float32, device=image.device)
+        AMAX_VERIFY.check(image, amax[0], 'patch_embed32 image')
+        AMAX_VERIFY.check(w2, amax[1], 'patch_embed32 weight')
         check(lib.mbv_patch_embed32_fwd(_ptr(image), _ptr(w2), _ptr(bias), _ptr(out), b, c, h, w, e, _amax_ptr(amax, 0),
                                         _amax_ptr(amax, 1), _stream()), 'mbv_patch_embed32_fwd')
         ctx.save_for_backward(image, weight)
@@ -1623,6 +1723,9 @@ class _PatchEmbed32(torch.autograd.Function):
         amax_g = f32_absmax([g2])
         w2 = weight.reshape(e, -1)
         gi = gw = gb = None
+        AMAX_VERIFY.check(g2, amax_g, 'patch_embed32_bwd g')
+        AMAX_VERIFY.check(image, ctx.amax[0], 'patch_embed32_bwd image')
+        AMAX_VERIFY.check(w2, ctx.amax[1], 'patch_embed32_bwd weight')
         if ctx.needs_input_grad[0]:
             gi = torch.empty_like(image)
             check(lib.mbv_patch_embed32_bwd_image(_ptr(g2), _ptr(w2), _ptr(gi), b, c, h, w, e, _amax_ptr(amax_g, 0),
@@ -1693,6 +1796,10 @@ def gemm32s_tn_group(items) -> None:
         for q, key in enumerate(chunk):
             recs[key] = r[q:q + 1]
     amax = [[it[3 + j] if it[3 + j] is not None else recs[(i, j)] for j in (0, 1)] for i, it in enumerate(items)]
+    if switches.get('amax_verify'):
+        for i, it in enumerate(items):
+            AMAX_VERIFY.check(it[0], amax[i][0], 'gemm32s_tn_group g')
+            AMAX_VERIFY.check(it[1], amax[i][1], 'gemm32s_tn_group x')
     PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
     m, nn, k = LA(*[it[0].shape[0] for it in items]), LA(*[it[0].shape[1] for it in items]), LA(*[it[1].shape[1] for it in items])
     nbytes = lib.mbv_gemm32s_tn_group_workspace_bytes(m, nn, k, n)
@@ -1721,6 +1828,8 @@ class _Conv3x3K20(torch.autograd.Function):
         wm = weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous()
         rec = f32_absmax([xp, wm])
         outp = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        AMAX_VERIFY.check(xp, rec[0:1], 'conv3x3_gemm32s x')
+        AMAX_VERIFY.check(wm, rec[1:2], 'conv3x3_gemm32s w')
         check(lib.mbv_conv3x3_gemm32s(_ptr(xp), _ptr(wm), _ptr(outp), b, h, w, c, cout, _amax_ptr(rec, 0), _amax_ptr(rec, 1),
                                       None, _stream()), 'mbv_conv3x3_gemm32s')
         y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
@@ -2375,6 +2484,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     without materialising slices or zero-padded slice gradients.  Parameters that live in a
     :class:`~mask_bev_amd.arena.ParameterArena` are read through their bf16 shadow and receive their gradient by
     direct f32 accumulation (the autograd gradient returned for them is ``None``)."""
+    _LAST_HINT[1] = None             # see amax_hint_refresh: only a hint THIS forward sets may be re-attached to y
     y = _Linear.apply(x, weight, bias, rows, f32_out, skip_bias_grad)
     amax_hint_refresh(y)
     return y
@@ -2489,6 +2599,8 @@ class _FFN32(torch.autograd.Function):
         rows = lib.mbv_gemm32s_nn_part_rows(t, 1)
         parts = torch.empty((rows, f), dtype=torch.float32, device=h.device)
         adh = amax_record(h.device)
+        AMAX_VERIFY.check(g2, ag, 'gemm32s_nn_act g')
+        AMAX_VERIFY.check(w2, aw2, 'gemm32s_nn_act w2')
         check(lib.mbv_gemm32s_nn_act(_ptr(g2), _ptr(w2), _ptr(dh), _ptr(h), _ptr(parts), parts.numel() * 4, t, w2.shape[0], f,
                                      g2.stride(0), w2.stride(0), f, f, _ptr(ag), _ptr(aw2), _ptr(adh), _ACT[ctx.kind],
                                      _stream()), 'mbv_gemm32s_nn_act')
@@ -2527,6 +2639,7 @@ def ffn32_ok(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b) -> bool:
 
 
 def ffn32(x: torch.Tensor, fc1_w, fc1_b, fc2_w, fc2_b, kind: str, defer_out_bias: bool = False) -> torch.Tensor:
+    _LAST_HINT[1] = None
     y = _FFN32.apply(x, fc1_w, fc1_b, fc2_w, fc2_b, kind, defer_out_bias)
     amax_hint_refresh(y)
     return y

@@ -44,6 +44,7 @@ _DEFAULTS: Dict[str, Any] = {
     # K20's operand scales from absmax records / bounds a producing K20 product leaves (its epilogue max-combines what it stores:
     # one no-return atomic per workgroup), instead of a pass over the tensor: 92.6 / 92.9 -> 93.6 / 95.1 scans/s (fp32, one box)
     'amax_hints': True,
+    'amax_verify': False,         # debug: every record a K20 product consumes is checked against a fresh absmax of its operand (ops.AMAX_VERIFY)
     'ffn32': True,                # fp32 compute: the FFN pair on K20 with the activation / its derivative in the GEMM epilogues
     'k4_split': True,             # fp32 compute: K4's products on the 16-bit matrix pipe from IEEE-half pairs (f32 tensors)
     'k6_split': True,             # fp32 compute: the decoder attention's products the same way (per-tile scales)

@@ -435,3 +435,83 @@ def test_layernorm_output_bound_records():
         out = ops.linear(y, w, None)
         ref = y.double() @ w.double().t()
         assert _err(out, ref) <= 2e-6
+
+
+@gpu
+def test_a_forward_without_a_hint_does_not_inherit_a_freed_tensors_record():
+    """`linear()` re-attached `_LAST_HINT` by ADDRESS after `Function.apply`.  A forward that sets no
+    hint (library path: fewer rows than gemm32s_min) whose output the caching allocator places at the address of an earlier,
+    freed, hinted tensor must NOT come back carrying that tensor's absmax record — a 1e-4 record on an O(1) activation is an
+    IEEE-half overflow inside the next K20 product."""
+    from mask_bev_amd import ops
+    lin = torch.nn.Linear(192, 1536).to(_dev())
+    xs = _rand((512, 192), 5, 1.0)                           # 512 rows < gemm32s_min: the library's f32 GEMM, no hint
+    hit = 0
+    with switches.override(amax_hints=True):
+        for attempt in range(8):
+            x, w = _rand((4096, 192), 10 + attempt, 1e-4), _rand((192, 192), 20 + attempt, 1.0)
+            h = ops.gemm32s_nt(x, w, None, hint_out=True)    # (4096, 192) f32 = the bytes of a (512, 1536) f32 output
+            assert ops.amax_hint_get(h) is not None
+            addr = h.data_ptr()
+            del h
+            y = ops.linear(xs, lin.weight, lin.bias)
+            if y.data_ptr() == addr:
+                hit += 1
+                assert ops.amax_hint_get(y) is None, 'the output inherited the record of a freed tensor at its address'
+            del y
+    assert hit > 0, 'the allocator never reused the address: the test did not exercise the case'
+
+
+@gpu
+@pytest.mark.parametrize('graphed', [False, True])
+def test_every_consumed_absmax_record_bounds_its_operand_over_a_whole_fp32_step(graphed, capsys):
+    """VERDICT r05 #6a/b: `switches.amax_verify` — every record a K20 product (or K4's split mode) consumes during a whole
+    fp32 training step of the BENCH workload is compared with a fresh max|operand| taken right in front of the product:
+    producer hints, derived bounds (|gelu(z)| <= |z|, convex attention outputs, sqrt(C) max|gamma| + max|beta|), weight
+    records keyed by the optimizer epoch, the registered record of the graph's static input.  Eager step, and the
+    two-graph step (checks captured with the launches: they run again on every replay, here on a DIFFERENT batch than
+    the capture saw, after an optimizer step rewrote the weights through raw pointers).
+    record >= max|x| ALWAYS (a smaller one is an f16 overflow: the accuracy-critical direction).  Looseness only eats the
+    18 binades of headroom under the record inside which an element keeps all 22 product bits: asserted <= 2^8
+    (measured worst: 108x — a row slice of a shared K/V gradient bounded by the whole tensor's record; LayerNorm bounds
+    sqrt(C) max|gamma| + max|beta| sit at 3-12x), i.e. >= 10 binades of full-precision range stay.  The loosest by call
+    site are printed."""
+    from mask_bev_amd import ops, synthetic
+    from mask_bev_amd.graph import GraphedTrainStep
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    torch.manual_seed(0)
+    workload, batch = 'semantic_kitti_512', 2
+    kw = synthetic.module_kwargs(workload, batch, compute_dtype='fp32')
+    m = MaskBevModule(**kw).to(_dev()).train()
+    m.log_scalars = False
+    m.flatten_parameters()
+    opt = m.configure_optimizers()['optimizer']
+    data = [synthetic.make_batch(workload, batch, 0, s, _dev()) for s in range(3)]
+    ops.AMAX_VERIFY.reset()
+    with switches.override(amax_verify=True):
+        if graphed:
+            g = GraphedTrainStep(m, opt, data[0], warmup_iters=1)    # (its eager warm-up pass allocates the result buffer)
+            for s in (1, 2, 0):
+                g.step(data[s])                             # replays re-run the captured checks on new data / new weights
+            rep = [e for e in ops.AMAX_VERIFY.report() if e[2]]      # the captured checks, as the LAST replay left them
+            g.close()
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for s in range(2):
+                    loss = m.training_step(data[s], s)
+                    loss.backward()
+                    opt.step()
+                    del loss
+            torch.cuda.current_stream().wait_stream(side)
+            rep = ops.AMAX_VERIFY.report()
+    ops.AMAX_VERIFY.reset()
+    assert len(rep) > 100, len(rep)
+    low = [(w, s, t, r) for w, s, c, t, r in rep if not (r >= t)]
+    loose = sorted(((r / t, w, s) for w, s, c, t, r in rep if t > 0 and r > t), reverse=True)
+    with capsys.disabled():
+        print(f'\namax_verify ({"graph" if graphed else "eager"}): {len(rep)} consumed records checked, {len(low)} below the truth; '
+              f'loosest: ' + '; '.join(f'{q:.1f}x {w} {s}' for q, w, s in loose[:6]))
+    assert not low, low[:5]
+    assert all(q <= 256.0 for q, _, _ in loose), loose[:5]
