@@ -288,7 +288,7 @@ def kernel_profile(model, opt, batch, steps: int = 2, detail_file=None):
     return out
 
 
-def time_other_dtype(args, dtype, device, pool, steps, warmup):
+def time_other_dtype(args, dtype, device, pool, steps, warmup, exact_f32_steps=0):
     """The same step in another compute dtype, timed the same way (graph replay, inputs resident), as a secondary
     object of the JSON line: fp32 is the precision the reference trains in (/root/reference: train_mask_bev.py:96
     `precision=32`), so the reference-precision rate is measured by the same driver run as the headline one."""
@@ -312,6 +312,38 @@ def time_other_dtype(args, dtype, device, pool, steps, warmup):
     out = dict(value=args.batch * steps / dt, unit='scans/s', ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup,
                dtype=dtype, final_loss=float(loss.detach()))
     g.close()
+    if dtype == 'fp32':
+        from mask_bev_amd import switches
+        split = bool(switches.get('gemm32s'))
+        # which arithmetic this figure is: f32 tensors everywhere; with K20 on, the >= 1024-token
+        # products, every weight gradient, the 3 x 3 convolution, K4 and K6 multiply IEEE-half PAIRS on the 16-bit matrix pipe
+        out['arithmetic'] = ('f32 storage; products from f16 hi/lo pairs (22-bit significand, lo.lo dropped), f32 accumulate '
+                             '(K20 / K4 / K6 split modes)' if split else 'IEEE f32 products (library GEMMs, exact-f32 MFMA)')
+        if split and exact_f32_steps > 0:
+            # the same step with every product in exact f32 (library f32 GEMMs, v_mfma_f32_32x32x2_f32 in K4 / K6), fresh model
+            try:
+                with switches.override(gemm32s=False, k4_split=False, k6_split=False, ffn32=False, conv3x3_k20=False,
+                                       tn32_group=False, msda_packed_f32=False):
+                    torch.manual_seed(420)
+                    m2 = MaskBevModule(**synthetic.module_kwargs(args.workload, args.batch, compute_dtype=dtype)).to(device).train()
+                    m2.log_scalars = False
+                    m2.flatten_parameters()
+                    o2 = m2.configure_optimizers()['optimizer']
+                    g2 = GraphedTrainStep(m2, o2, pool[0])
+                    for i in range(min(warmup, 3)):
+                        g2.step(pool[i % len(pool)])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(exact_f32_steps):
+                        g2.step(pool[i % len(pool)])
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t0
+                    g2.close()
+                    del g2, m2, o2
+                out['exact_f32'] = dict(value=args.batch * exact_f32_steps / dt2, ms_per_step=dt2 / exact_f32_steps * 1e3,
+                                        steps=exact_f32_steps)
+            except Exception as e:
+                out['exact_f32'] = dict(error=f'{type(e).__name__}: {e}'[:200])
     if not args.no_kernel_profile:
         # the same per-family table for this dtype (one instrumented eager step): `roofline` = the family that costs the
         # most time per step (K3's two kernels and the optimizer pass are not bracketed here: ≈ 1.7 ms of the step)
@@ -403,6 +435,7 @@ def compact_line(full: dict, detail_path=None) -> dict:
                                           ms_per_step=w['total_ms_per_step'])
     line['roofline_coverage'] = full.get('roofline_coverage')
     line['roofline_traffic_source'] = full.get('roofline_traffic_source')
+    line['roofline_traffic_measured_in_run'] = False       # `traffic` = the committed PMC passes of the same workload, not this run
     line['roofline_detail'] = detail_path
     sr = full.get('step_roofline')
     if sr:
@@ -412,7 +445,7 @@ def compact_line(full: dict, detail_path=None) -> dict:
     if f32:
         line['fp32'] = {k: (_roofline_object(v) if k == 'roofline' else v) for k, v in f32.items()
                         if k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'roofline',
-                                 'roofline_coverage', 'error')}
+                                 'roofline_coverage', 'error', 'arithmetic', 'exact_f32')}
     if full.get('collectives'):
         line['collectives'] = full['collectives']
     cb = full.get('cpu_baseline')
@@ -582,7 +615,8 @@ def main():
     fp32_line = None
     if world == 1 and args.dtype != 'fp32' and not args.no_fp32 and not args.no_graph and not args.no_arena:
         try:
-            fp32_line = time_other_dtype(args, 'fp32', device, pool, min(args.steps, 50), min(args.warmup, 5))
+            fp32_line = time_other_dtype(args, 'fp32', device, pool, min(args.steps, 50), min(args.warmup, 5),
+                                         exact_f32_steps=min(args.steps, 20))
         except Exception as e:      # the secondary figure must never take the headline number down with it
             fp32_line = dict(value=None, error=f'{type(e).__name__}: {e}')
     replica_spread = None

@@ -515,6 +515,22 @@ int mbv_mask_loss_rows_fwd(const float* logits, const float* targets, int64_t ro
 int mbv_mask_loss_rows_bwd(const float* logits, const float* targets, const float* grad_sums, int64_t rows,
                            int32_t points, float* grad_logits, void* stream);
 
+/* The dice / BCE algebra on K13's row sums, per decoder output — mmdet DiceLoss(naive_dice, eps 1) and
+ * CrossEntropyLoss(use_sigmoid) reduced with their avg_factor as at mask2former_head.py:406-424, for `outputs` decoder outputs of
+ * rows / outputs rows each:  den = S1 + S2 + 1, dice = (2 S0 + 1) / den;
+ *   loss_dice[d] = c_dice * sum_rows(1 - dice),  loss_mask[d] = c_mask * sum_rows(S3)
+ * (c_dice = loss weight / avg_factor, c_mask likewise).  coef (rows, 3) f32 receives the gradient of the two losses with respect
+ * to each row's sums for unit upstream gradients: (-2 c_dice / den, c_dice dice / den, c_mask).  sums 16-byte aligned. */
+int mbv_dice_bce_reduce(const float* sums, int64_t rows, int32_t outputs, float c_dice, float c_mask, float* loss_dice,
+                        float* loss_mask, float* coef, void* stream);
+
+/* mbv_mask_loss_rows_bwd with the per-row gradient of the sums assembled in the kernel from mbv_dice_bce_reduce's `coef` and
+ * the upstream gradients of the row's decoder output: grad_dice / grad_mask (outputs,) f32 with element strides
+ * stride_dice / stride_mask (0 = one broadcast value; NULL = zero gradient). */
+int mbv_mask_loss_rows_bwd_coef(const float* logits, const float* targets, const float* coef, const float* grad_dice,
+                                int32_t stride_dice, const float* grad_mask, int32_t stride_mask, int64_t rows,
+                                int32_t outputs, int32_t points, float* grad_logits, void* stream);
+
 /* Matching-cost terms (mmdet CrossEntropyLossCost(use_sigmoid) + DiceCost on the sampled points,
  * mask2former_head.py:199-205): logits (groups, queries, points) f32 → terms (groups, 3, queries, points) f32 =
  * [softplus(-x), softplus(x), sigmoid(x)] — one batched GEMM against the sampled ground truth then gives all three

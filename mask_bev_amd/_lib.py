@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 56
+ABI_VERSION = 57
 
 
 class MaskBevHipError(RuntimeError):
@@ -91,6 +91,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     'mbv_wgrad_small_f32_group': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'mbv_mask_loss_rows_fwd': (ctypes.c_int, [_P, _P, _L, _I, _P, _P]),
     'mbv_mask_loss_rows_bwd': (ctypes.c_int, [_P, _P, _P, _L, _I, _P, _P]),
+    'mbv_dice_bce_reduce': (ctypes.c_int, [_P, _L, _I, _F, _F, _P, _P, _P, _P]),
+    'mbv_mask_loss_rows_bwd_coef': (ctypes.c_int, [_P, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
     'mbv_sample_select_uncertain': (ctypes.c_int, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _I, _P, _P]),
     'mbv_uniform_points': (ctypes.c_int, [_P, _L, _I, _P, _P]),
     'mbv_add_layernorm_supported': (ctypes.c_int, [_I]),

@@ -677,13 +677,15 @@ class Mask2FormerHead(nn.Module):
         if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream(device).synchronize()
 
-    def _iota(self, n: int, device, div: int = 1, mod: int = 0) -> torch.Tensor:
-        key = (n, div, mod, str(device))
+    def _iota(self, n: int, device, div: int = 1, mod: int = 0, mul: int = 1) -> torch.Tensor:
+        """Cached int32 index vector ((i // div) % mod) * mul, i < n."""
+        key = (n, div, mod, str(device)) if mul == 1 else (n, div, mod, str(device), mul)
         t = self._iota_cache.get(key)
         if t is None:
             t = torch.arange(n, device=device)
             t = t // div if div > 1 else t
             t = t % mod if mod > 0 else t
+            t = t * mul if mul != 1 else t
             t = t.to(torch.int32)
             self._cached_ready(t.device)
             self._iota_cache[key] = t
@@ -863,8 +865,11 @@ class Mask2FormerHead(nn.Module):
             qsel = self._iota(nq, dev).long().view(1, 1, nq).expand(d, b, nq)
         else:
             qsel = torch.sort((~matched).to(torch.uint8), dim=-1, stable=True).indices[..., :m]
-        db = self._iota(d * b, dev).long().view(d, b, 1)
-        pred_index = (db * nq + qsel).flatten().to(torch.int32)                                  # rows of masks_flat
+        if m == nq:
+            pred_index = self._iota(d * b * nq, dev)                                             # every row of masks_flat, in order
+        else:
+            db = self._iota(d * b, dev).long().view(d, b, 1)
+            pred_index = (db * nq + qsel).flatten().to(torch.int32)                              # rows of masks_flat
         rows = self._iota(d * g, dev)
         with torch.no_grad():
             n_unc = int(self.importance_sample_ratio * p)
@@ -880,14 +885,22 @@ class Mask2FormerHead(nn.Module):
         pred = ops.point_sample(masks_flat, pred_index, coords, rows, grad_sink=sink)            # (D*g, P), grads
         if overlap:                                     # join the matcher
             main.wait_stream(side)
-            matched = assigned >= 0
-            safe = assigned.clamp(min=0).long()
         # kept for the metrics path (mask_bev_amd/metrics.py), which the reference feeds by running the matcher again
         self.last_assignment = assigned.detach()
         self.last_gt_packed = gt_flat if isinstance(gt_flat, ops.PackedMasks) else None
+        glue = cls.is_cuda and switches.get('loss_glue')
         with torch.no_grad():
-            bsel = self._iota(b, dev).long().view(1, b, 1)
-            gt_index = (bsel * ng + torch.gather(safe, 2, qsel)).flatten().to(torch.int32)       # rows of gt_flat
+            if m == nq and glue:
+                # every query is matched and `qsel` is the identity: the ground-truth row of (d, b, q) is b * G + assigned —
+                # two launches on the int32 assignment instead of compare / clamp / cast / gather / multiply / add / cast
+                boff = self._iota(d * b * nq, dev, div=nq, mod=b, mul=ng).view(d, b, nq)
+                gt_index = (assigned.clamp(min=0) + boff).flatten()
+            else:
+                if overlap:
+                    matched = assigned >= 0
+                    safe = assigned.clamp(min=0).long()
+                bsel = self._iota(b, dev).long().view(1, b, 1)
+                gt_index = (bsel * ng + torch.gather(safe, 2, qsel)).flatten().to(torch.int32)   # rows of gt_flat
             tgt = self._sample_gt(gt_flat, gt_index, coords, rows)                               # (D*g, P)
 
         # classification loss (class-weighted CE, avg_factor = sum of the class weights of the targets)
@@ -904,10 +917,12 @@ class Mask2FormerHead(nn.Module):
 
         # MaskPseudoSampler: avg_factor = num_pos + num_neg = Q per image; reduce_mean over ranks (:388) is the
         # identity for equal per-rank batches (drop_last=True), see ddp.py
-        num_total_masks = self._const(dev, [float(b * nq)])
-        if self.world_size_fn is not None:
-            num_total_masks = self.world_size_fn(num_total_masks)
-        num_total_masks = num_total_masks.clamp(min=1.0)[0]
+        if self.world_size_fn is None:
+            # avg_factor = B * Q is a host constant (reduce_mean over equal per-rank batches is the identity): the loss
+            # weights over it are plain floats — no device arithmetic, and K13's fused reduce takes them as arguments
+            num_total_masks = max(float(b * nq), 1.0)
+        else:
+            num_total_masks = self.world_size_fn(self._const(dev, [float(b * nq)])).clamp(min=1.0)[0]
 
         if pred.is_cuda and switches.get('loss_node'):
             # K13's row sums (Σ σ·t, Σ σ, Σ t, Σ bce in one pass) and the dice / BCE algebra on them as one autograd node
@@ -927,5 +942,5 @@ class Mask2FormerHead(nn.Module):
             out[f'd{i}.loss_height'] = 0
         # the sum of every entry, taken on the (D,) vectors: 3 reductions instead of 40 scalar adds forward and
         # ≈ 120 slice-gradient kernels backward (MaskBevModule.loss returns it when handed this dict)
-        out.total = loss_cls.sum() + loss_mask.sum() + loss_dice.sum()
+        out.total = torch.cat([loss_cls, loss_mask, loss_dice]).sum()
         return out

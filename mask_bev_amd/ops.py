@@ -3431,20 +3431,47 @@ class _MaskDiceBce(torch.autograd.Function):
         sums = torch.empty((rows, 4), dtype=torch.float32, device=x.device)
         check(lib.mbv_mask_loss_rows_fwd(_ptr(x), _ptr(t), rows, x.shape[1], _ptr(sums), _stream()),
               'mbv_mask_loss_rows_fwd')
+        ctx.consts = (d, c_dice, c_mask)
+        ctx.in_dtype = logits.dtype
+        ctx.fused = not torch.is_tensor(c_dice) and not torch.is_tensor(c_mask)
+        if ctx.fused:
+            # plain-float constants (the usual case: avg_factor = B * Q is a host constant): the algebra on the sums is ONE
+            # launch, which also leaves the per-row gradient coefficients the backward kernel scales on the fly
+            out = torch.empty((2, d), dtype=torch.float32, device=x.device)
+            coef = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
+            check(lib.mbv_dice_bce_reduce(_ptr(sums), rows, d, float(c_dice), float(c_mask), _ptr(out[0]), _ptr(out[1]),
+                                          _ptr(coef), _stream()), 'mbv_dice_bce_reduce')
+            ctx.save_for_backward(x, t, coef)
+            return out[0], out[1]
         den = sums[:, 1] + sums[:, 2] + 1.0
         dice = (2.0 * sums[:, 0] + 1.0) / den
         loss_dice = (1.0 - dice).view(d, rows // d).sum(1) * c_dice
         loss_mask = sums[:, 3].reshape(d, rows // d).sum(1) * c_mask
         ctx.save_for_backward(x, t, den, dice)
-        ctx.consts = (d, c_dice, c_mask)
-        ctx.in_dtype = logits.dtype
         return loss_dice, loss_mask
 
     @staticmethod
     def backward(ctx, g_dice, g_mask):
         lib = _lib.load()
-        x, t, den, dice = ctx.saved_tensors
         d, c_dice, c_mask = ctx.consts
+        if ctx.fused:
+            x, t, coef = ctx.saved_tensors
+            rows = x.shape[0]
+
+            def vec(g):          # (pointer holder, element stride) of an upstream (D,) gradient: expanded scalars stay as they are
+                if g is None:
+                    return None, 0
+                g = g if g.dtype == torch.float32 else g.float()
+                if g.dim() != 1 or g.stride(0) not in (0, 1):
+                    g = g.contiguous().view(-1)
+                return g, int(g.stride(0))
+            gd, sd = vec(g_dice)
+            gm, sm = vec(g_mask)
+            dx = torch.empty_like(x)
+            check(lib.mbv_mask_loss_rows_bwd_coef(_ptr(x), _ptr(t), _ptr(coef), _ptr(gd), sd, _ptr(gm), sm, rows, d, x.shape[1],
+                                                  _ptr(dx), _stream()), 'mbv_mask_loss_rows_bwd_coef')
+            return dx.to(ctx.in_dtype), None, None, None, None
+        x, t, den, dice = ctx.saved_tensors
         rows = x.shape[0]
         g = rows // d
         zero = None

@@ -394,6 +394,7 @@ MODELS: Dict[str, Callable[[tuple], Work]] = {
     'mbv_point_sample_packed_fwd': lambda a: _point_sample(a, 'k_point_sample_packed', 1.0 / 8.0),
     'mbv_mask_loss_rows_fwd': lambda a: ('k_mask_loss_rows_fwd', 'hbm', _i(a[2]) * _i(a[3]) * 8.0, 0.0),
     'mbv_mask_loss_rows_bwd': lambda a: ('k_mask_loss_rows_bwd', 'hbm', _i(a[3]) * _i(a[4]) * 12.0, 0.0),
+    'mbv_mask_loss_rows_bwd_coef': lambda a: ('k_mask_loss_rows_bwd', 'hbm', _i(a[7]) * _i(a[9]) * 12.0, 0.0),
     'mbv_act_bwd_colsum': lambda a: ('k_act_bwd_colsum', 'hbm', _i(a[4]) * _i(a[5]) * 3.0 * (2 if _i(a[2]) else 4), 0.0),
     'mbv_wgrad_small_f32': lambda a: ('k_wgrad_small', 'mfma_f32',
                                       (_i(a[2]) * (_i(a[3]) + _i(a[4])) + 2 * _i(a[3]) * _i(a[4])) * 4.0,

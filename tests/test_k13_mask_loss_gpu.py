@@ -65,6 +65,39 @@ def test_dice_bce_node_equals_the_row_sums_algebra(device):
     assert float((got - x.grad).abs().max()) <= 1e-6 * float(x.grad.abs().max()) + 1e-12
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('upstream', ['vectors', 'broadcast', 'dice_only'])
+def test_fused_dice_bce_reduce_equals_the_tensor_form(device, upstream):
+    """Round 6: with plain-float constants the algebra on the row sums is ONE launch (mbv_dice_bce_reduce) and the backward
+    kernel assembles each row's gradient from its coefficients and the upstream gradients of the row's decoder output
+    (mbv_mask_loss_rows_bwd_coef; a broadcast scalar arrives as a stride-0 view, a missing gradient as NULL) — against the
+    tensor-constant form of the same node (ATen algebra + mbv_mask_loss_rows_bwd), values and d(logits)."""
+    import torch
+    from mask_bev_amd import ops
+    torch.manual_seed(6)
+    d, g, p = 10, 37, 1001
+    x = (torch.randn(d * g, p, device=device) * 3).requires_grad_()
+    t = (torch.rand(d * g, p, device=device) > 0.6).float()
+    c_dice, c_mask = 5.0 / 401.0, 5.0 / (400.0 * p + 1.0)
+
+    def run(cd, cm):
+        x.grad = None
+        ld, lm = ops.mask_dice_bce(x, t, d, cd, cm)
+        if upstream == 'vectors':
+            gd, gm = torch.linspace(-1, 2, d, device=device), torch.linspace(3, -1, d, device=device)
+            torch.autograd.backward([ld, lm], [gd, gm])
+        elif upstream == 'broadcast':
+            torch.cat([ld, lm]).sum().backward()             # the head's `total`: expanded ones reach the node
+        else:
+            (ld * torch.linspace(1, 2, d, device=device)).sum().backward()
+        return ld.detach(), lm.detach(), x.grad.clone()
+
+    ld, lm, gx = run(c_dice, c_mask)
+    ld2, lm2, gx2 = run(torch.tensor(c_dice, device=device), torch.tensor(c_mask, device=device))
+    assert torch.allclose(ld, ld2, rtol=2e-6, atol=1e-7) and torch.allclose(lm, lm2, rtol=2e-6, atol=1e-7)
+    assert float((gx - gx2).abs().max()) <= 2e-6 * float(gx2.abs().max()) + 1e-12
+
+
 def test_match_cost_single_launch_equals_the_torch_form(device):
     """mbv_match_cost (+ the ones row of mbv_match_cost_terms) against the expression it replaces in
     Mask2FormerHead._match_cost: -2 softmax(cls)[label] + 5 BCE + 5 dice on the sampled points (mask2former_head.py:199-210)."""
