@@ -683,7 +683,10 @@ def main():
                              achieved_gbs=bytes_scan * sps / 1e9, hbm_peak_gbs=8000.0,
                              frac_hbm=bytes_scan * sps / 1e9 / 8000.0)
         line = dict(
-            metric='LiDAR scans/sec fwd+bwd, 120k-pt 512x512 BEV 100q', value=args.batch * world * args.steps / dt,
+            # BASELINE.json's metric on its own workload; the other BASELINE configs name their shape in the same form
+            metric=('LiDAR scans/sec fwd+bwd, 120k-pt 512x512 BEV 100q' if args.workload == 'semantic_kitti_512' else
+                    f'LiDAR scans/sec fwd+bwd, {w["points"] // 1000}k-pt {ny}x{nx} BEV {w["num_queries"]}q'),
+            value=args.batch * world * args.steps / dt,
             unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic' if args.distribution == 'lidar' else 'synthetic (uniform x/y points)',
             config=dict(workload=f'{args.workload}: {w["points"]} pts/scan, {ny}x{nx} BEV, {w["num_queries"]} queries',

@@ -700,7 +700,8 @@ int mbv_matched_mask_iou(const float* logits, const int32_t* pred_row, const uin
 int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
                   int32_t* row_to_col, void* stream);
 
-/* The same for matrices (rows = predictions) x (cols = ground-truth slots, rows <= cols <= 128) whose trailing columns
+/* The same for matrices (rows = predictions) x (cols = ground-truth slots, rows <= cols <= 320; above 128 columns the
+ * wide kernel with the real columns' block staged in LDS) whose trailing columns
  * are identical padding — the dataset pads the instance list to num_queries with all-zero masks of label 0
  * (semantic_kitti_transforms.py:66-81), so for a given prediction those columns hold one and the same cost.
  * real_cols (batch) i32 ON THE DEVICE: the number of leading real columns of each problem.  Solves the equivalent

@@ -268,44 +268,76 @@ __device__ __forceinline__ double pick_d(const double (&x)[CPL], int c) {
   return r;
 }
 
+//
+// Padded mode (round 6; `real_cols` != NULL, square caller matrix): the rectangular problem of the K real ground-truth columns
+// against the predictions, exactly as in k_hungarian — K augmenting paths of length <= K instead of `rows` paths through ties
+// (the 200 / 300-query configurations carry 5-40 real instances: 5.6 ms -> 0.2 ms per launch at 200 queries).  Its K x rows
+// matrix (the transposed real columns) is staged in dynamic LDS (`lds_rows` rows of it fit); a problem with more real columns
+// than that is solved in the plain form from global memory.
 template <int CPL>
 __global__ void __launch_bounds__(64) k_hungarian_wide(const float* __restrict__ cost_all, int rows, int cols,
-                                                       int transposed_out, int32_t* __restrict__ out_all, int out_len) {
+                                                       int transposed_out, int32_t* __restrict__ out_all, int out_len,
+                                                       const int32_t* __restrict__ real_cols, int lds_rows) {
   constexpr int MAXD = 64 * CPL;
+  extern __shared__ float a_pad[];        // padded mode: (K, predictions) f32, row stride `cols`
   __shared__ double u_row[MAXD];
   __shared__ int row_matched[MAXD];
   const int lane = threadIdx.x;
   const float* cost = cost_all + (int64_t)blockIdx.x * rows * cols;
   int32_t* out = out_all + (int64_t)blockIdx.x * out_len;
   const double INF = 1e300;
+  const int n_pred = rows, n_gt = cols;
+  bool padded = false;
+  if (real_cols) {
+    int k = real_cols[blockIdx.x];
+    k = k < 0 ? 0 : (k > n_gt ? n_gt : k);
+    if (k < n_gt && n_gt == n_pred && k <= lds_rows) {
+      padded = true;
+      // a_pad[g][q] = cost[q][g]: consecutive lanes read the consecutive real columns of a prediction's row
+#pragma unroll 8
+      for (int e = lane; e < n_pred * k; e += 64) {
+        const int q = e / k, g = e - q * k;
+        a_pad[g * n_pred + q] = cost[(int64_t)q * n_gt + g];
+      }
+      rows = k;
+      cols = n_pred;
+      transposed_out = 1;
+    }
+  }
+  const float* amat = padded ? a_pad : cost;
   int jc[CPL];
   bool has[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) { jc[c] = lane + 1 + 64 * c; has[c] = jc[c] <= cols; }
-  // row reduction (coalesced: the lanes of the wave read one row)
-  for (int i = 0; i < rows; ++i) {
-    float m = INFINITY;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-      if (has[c]) m = fminf(m, cost[(int64_t)i * cols + jc[c] - 1]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) { u_row[i] = (double)m; row_matched[i] = 0; }
-  }
-  __syncthreads();
   double v[CPL], uu[CPL], minv[CPL];
   int p[CPL], way[CPL];
   bool used[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) { v[c] = 0.0; uu[c] = 0.0; p[c] = 0; }
-  if (rows == cols) {                     // column reduction (square problems only, see k_hungarian)
+  for (int c = 0; c < CPL; ++c) {         // padded: the opt-out cost of prediction q is the start value of its dual
+    v[c] = (padded && has[c]) ? (double)cost[(int64_t)(jc[c] - 1) * n_gt + n_gt - 1] : 0.0;
+    uu[c] = 0.0;
+    p[c] = 0;
+  }
+  __syncthreads();                        // a_pad staged
+  // row reduction (coalesced: the lanes of the wave read one row)
+  for (int i = 0; i < rows; ++i) {
+    double m = INF;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      if (has[c]) m = fmin(m, (double)amat[(int64_t)i * cols + jc[c] - 1] - v[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+    if (lane == 0) { u_row[i] = m; row_matched[i] = 0; }
+  }
+  __syncthreads();
+  if (rows == cols && !padded) {          // column reduction (square problems only, see k_hungarian)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) v[c] = INF;
     for (int i = 0; i < rows; ++i) {
       const double ui = u_row[i];
 #pragma unroll
       for (int c = 0; c < CPL; ++c)
-        if (has[c]) v[c] = fmin(v[c], (double)cost[(int64_t)i * cols + jc[c] - 1] - ui);
+        if (has[c]) v[c] = fmin(v[c], (double)amat[(int64_t)i * cols + jc[c] - 1] - ui);
     }
   }
   for (int i = 0; i < rows; ++i) {        // greedy matching on zero reduced costs
@@ -313,7 +345,7 @@ __global__ void __launch_bounds__(64) k_hungarian_wide(const float* __restrict__
     unsigned cand = 0xffffffffu;
 #pragma unroll
     for (int c = CPL - 1; c >= 0; --c)
-      if (has[c] && p[c] == 0 && ((double)cost[(int64_t)i * cols + jc[c] - 1] - ui) - v[c] == 0.0) cand = (unsigned)jc[c];
+      if (has[c] && p[c] == 0 && ((double)amat[(int64_t)i * cols + jc[c] - 1] - ui) - v[c] == 0.0) cand = (unsigned)jc[c];
     const unsigned j = wave_min_u32(cand);
     if (j != 0xffffffffu) {
 #pragma unroll
@@ -343,7 +375,7 @@ __global__ void __launch_bounds__(64) k_hungarian_wide(const float* __restrict__
         i0 = __builtin_amdgcn_readlane(pick_i<CPL>(p, cc), owner);
         ui0 = readlane_f64(pick_d<CPL>(uu, cc), owner);
       }
-      const float* arow = cost + (int64_t)(i0 - 1) * cols;
+      const float* arow = amat + (int64_t)(i0 - 1) * cols;
       double best = INF;
       int bestj = 0x7fffffff;
       bool best_taken = true;
@@ -395,6 +427,18 @@ __global__ void __launch_bounds__(64) k_hungarian_wide(const float* __restrict__
       j = jp;
     }
   }
+  if (padded) {
+    // out[prediction] = its real instance, or — for the predictions left over — the padded columns in ascending order
+    int before = 0;                       // free predictions in the column sets below c
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const bool fr = has[c] && p[c] == 0;
+      const unsigned long long m = __ballot(fr);
+      if (has[c]) out[jc[c] - 1] = p[c] > 0 ? p[c] - 1 : rows + before + __popcll(m & ((1ull << lane) - 1ull));
+      before += __popcll(m);
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     if (!has[c]) continue;
@@ -429,21 +473,37 @@ extern "C" int mbv_hungarian(const float* cost, int32_t batch, int32_t num_rows,
     // mbv_hungarian_wide_t takes the materialised transpose for num_rows > num_cols
     if (num_rows > num_cols) return MBV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col,
-                       num_rows);
+                       num_rows, (const int32_t*)nullptr, 0);
   }
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
 
 // Square-or-wider problems whose trailing columns are identical padding (see k_hungarian): real_cols (batch) i32 on the
-// device = number of leading real columns of each problem.  num_rows <= num_cols <= 128.
+// device = number of leading real columns of each problem.  num_rows <= num_cols <= 320 (above 128 columns: the wide kernel).
 extern "C" int mbv_hungarian_padded(const float* cost, int32_t batch, int32_t num_rows, int32_t num_cols,
                                     const int32_t* real_cols, int32_t* row_to_col, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch < 0 || num_rows <= 0 || num_cols <= 0 || num_rows > num_cols) return MBV_ERR_BAD_ARG;
-  if (num_cols > kMaxDim) return MBV_ERR_UNSUPPORTED;
+  if (num_cols > 320) return MBV_ERR_UNSUPPORTED;
   if (batch == 0) return MBV_OK;
   if (!cost || !row_to_col || !real_cols) return MBV_ERR_BAD_ARG;
+  if (num_cols > kMaxDim) {
+    // wide problems: the K real columns' transposed block in dynamic LDS (as many rows of it as 128 KB hold)
+    constexpr int kPadBytes = 128 * 1024;
+    static bool attr_done = false;       // idempotent attribute of the code object, not library state
+    if (!attr_done) {
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hungarian_wide<5>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kPadBytes));
+      attr_done = true;
+    }
+    int lds_rows = kPadBytes / (4 * num_rows);
+    lds_rows = lds_rows > num_cols ? num_cols : lds_rows;
+    hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), (size_t)lds_rows * num_rows * 4, stream, cost, num_rows,
+                       num_cols, 0, row_to_col, num_rows, real_cols, num_rows == num_cols ? lds_rows : 0);
+    MBV_CHECK_LAUNCH();
+    return MBV_OK;
+  }
   hipLaunchKernelGGL(k_hungarian, dim3(batch), dim3(64), 0, stream, cost, num_rows, num_cols, 0, row_to_col, num_rows,
                      real_cols);
   MBV_CHECK_LAUNCH();
@@ -458,7 +518,7 @@ extern "C" int mbv_hungarian_wide_t(const float* cost_t, int32_t batch, int32_t 
   if (batch == 0) return MBV_OK;
   if (!cost_t || !row_to_col) return MBV_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_hungarian_wide<5>, dim3(batch), dim3(64), 0, stream, cost_t, num_cols, num_rows, 1, row_to_col,
-                     num_rows);
+                     num_rows, (const int32_t*)nullptr, 0);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }

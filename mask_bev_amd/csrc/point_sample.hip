@@ -102,6 +102,56 @@ __global__ void __launch_bounds__(512) k_point_sample_fwd_lds(const float* __res
   }
 }
 
+// The same for a map larger than one tile (round 6: 256 x 256 logits): workgroup (g, band) stages image rows
+// [y0, y0 + band_rows] of the map — band_rows + 1 rows: the lower taps of its last row — and samples the points whose
+// UPPER tap row, clamped to [0, H - 1], lies in [y0, y0 + band_rows): every point belongs to exactly one band.  The
+// bilinear arithmetic is bil_setup's on the whole map (same weights, same sum order: bit-identical to the gather form).
+__global__ void __launch_bounds__(512) k_point_sample_fwd_bands(const float* __restrict__ src,
+                                                                const int32_t* __restrict__ src_index,
+                                                                const float* __restrict__ coords,
+                                                                const int32_t* __restrict__ coord_index, int P, int H,
+                                                                int W, int bands, int band_rows, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+  const int g = (int)blockIdx.x / bands, band = (int)blockIdx.x - g * bands;
+  const int y0 = band * band_rows;
+  const int y_end = (y0 + band_rows + 1) < H ? (y0 + band_rows + 1) : H;       // rows staged: [y0, y_end)
+  const int lo = y0 * W, hw = (y_end - y0) * W;
+  const float* s = src + (int64_t)src_index[g] * H * W + lo;
+  if ((lo & 3) == 0) {
+    stage_map(tile, s, hw);
+  } else {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = s[i];
+  }
+  __syncthreads();
+  const float2* c = reinterpret_cast<const float2*>(coords + (int64_t)coord_index[g] * P * 2);
+  float* o = out + (int64_t)g * P;
+  for (int p0 = threadIdx.x; p0 < P; p0 += 4 * (int)blockDim.x) {
+    float2 xy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      xy[u] = p < P ? c[p] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      if (p < P) {
+        int yt = (int)floorf(xy[u].y * (float)H - 0.5f);
+        yt = yt < 0 ? 0 : (yt > H - 1 ? H - 1 : yt);
+        if (yt >= y0 && yt < y0 + band_rows) {
+          Bil b;
+          bil_setup(xy[u].x, xy[u].y, H, W, b);
+          float v = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (b.o[j] >= 0) v += b.w[j] * tile[b.o[j] - lo];
+          o[p] = v;
+        }
+      }
+    }
+  }
+}
+
 // binary maps packed 32 pixels / word (bit i of word k = pixel 32 k + i != 0)
 __global__ void __launch_bounds__(256) k_pack_binary(const float* __restrict__ src, int64_t hw, int64_t words_per_map,
                                                      uint32_t* __restrict__ packed) {
@@ -182,18 +232,25 @@ __global__ void __launch_bounds__(512) k_point_sample_packed(const uint32_t* __r
   }
 }
 
+// `bands` > 1 (round 6: maps larger than one LDS tile — the 256 x 256 mask logits of the 1024 x 1024 BEV configuration):
+// workgroup (map g, band) owns `band_rows` image rows of the map, walks ALL the map's points and keeps the taps that fall
+// on its rows.  The walk is repeated per band (coordinates are 8 bytes a point), the adds are not: 12 000 maps x 12 544
+// points were 600 M global f32 atomics (28 ms per step); this form accumulates in LDS like the one-tile case.
 __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __restrict__ grad_out,
                                                                const int32_t* __restrict__ src_index,
                                                                const float* __restrict__ coords,
                                                                const int32_t* __restrict__ coord_index, int P, int H,
                                                                int W, void* __restrict__ grad_src, int out_kind,
-                                                               int perm_outer, int perm_inner, int perm_rows) {
+                                                               int perm_outer, int perm_inner, int perm_rows, int bands,
+                                                               int band_rows) {
   // f64 accumulators: on gfx950 an LDS ds_add_f32 wave instruction takes ≈ 192 cycles (the lanes are serialised),
   // ds_add_f64 / ds_add_u64 ≈ 9-16 (scratch/ubench/lds_atomic.hip) — the f32 form of this kernel ran 1.0 ms, bound
   // by exactly that.  128 KB for a 128 x 128 map; the sum is also order-independent to f32 precision.
   __shared__ double tile[kTileFloats];
-  const int g = blockIdx.x;
-  const int hw = H * W;
+  const int g = (int)blockIdx.x / bands, band = (int)blockIdx.x - g * bands;
+  const int y0 = band * band_rows;
+  const int rows_here = (H - y0) < band_rows ? (H - y0) : band_rows;
+  const int lo = y0 * W, hw = rows_here * W;            // this workgroup's pixels: [lo, lo + hw) of the map
   for (int i = threadIdx.x; i < hw; i += blockDim.x) tile[i] = 0.0;
   __syncthreads();
   const float2* c = reinterpret_cast<const float2*>(coords + (int64_t)coord_index[g] * P * 2);
@@ -213,8 +270,10 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
         Bil b;
         bil_setup(xy[u].x, xy[u].y, H, W, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (b.o[j] >= 0) atomicAdd(&tile[b.o[j]], (double)(b.w[j] * gv[u]));
+        for (int j = 0; j < 4; ++j) {
+          const unsigned o = (unsigned)(b.o[j] - lo);      // (a missing tap, -1, and every pixel outside the band: >= hw)
+          if (b.o[j] >= 0 && o < (unsigned)hw) atomicAdd(&tile[o], (double)(b.w[j] * gv[u]));
+        }
       }
     }
   }
@@ -227,9 +286,10 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
     const int64_t o = on / perm_inner, n = on - o * perm_inner;
     row = (n * perm_outer + o) * perm_rows + r;
   }
+  const int64_t map_hw = (int64_t)H * W;
   if (out_kind == MBV_DT_F32) {
-    float* dst = reinterpret_cast<float*>(grad_src) + row * hw;
-    if ((hw & 3) == 0) {
+    float* dst = reinterpret_cast<float*>(grad_src) + row * map_hw + lo;
+    if ((hw & 3) == 0 && (lo & 3) == 0 && (map_hw & 3) == 0) {
       for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
         *reinterpret_cast<float4*>(dst + i) = make_float4((float)tile[i], (float)tile[i + 1], (float)tile[i + 2], (float)tile[i + 3]);
     } else {
@@ -237,19 +297,29 @@ __global__ void __launch_bounds__(1024) k_point_sample_bwd_lds(const float* __re
     }
     return;
   }
-  unsigned short* dst = reinterpret_cast<unsigned short*>(grad_src) + row * hw;
+  unsigned short* dst = reinterpret_cast<unsigned short*>(grad_src) + row * map_hw + lo;
   auto lo2 = [&](double a, double b2) -> unsigned {
     const float x = (float)a, y = (float)b2;
     if (out_kind == MBV_DT_F16)
       return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)y) << 16);
     return pack_bf16x2(x, y);
   };
-  if ((hw & 3) == 0) {
+  if ((hw & 3) == 0 && (lo & 3) == 0 && (map_hw & 3) == 0) {
     for (int i = threadIdx.x * 4; i < hw; i += blockDim.x * 4)
       *reinterpret_cast<uint2*>(dst + i) = make_uint2(lo2(tile[i], tile[i + 1]), lo2(tile[i + 2], tile[i + 3]));
   } else {
     for (int i = threadIdx.x; i < hw; i += blockDim.x) dst[i] = (unsigned short)(lo2(tile[i], 0.0) & 0xffffu);
   }
+}
+
+// band split of an (H, W) map for the LDS form: rows per workgroup (<= kTileFloats pixels) and the number of bands; 0 when
+// one image row alone exceeds the tile
+static inline int lds_band_rows(int H, int W, int* bands) {
+  if (W > kTileFloats) { *bands = 0; return 0; }
+  int br = kTileFloats / W;
+  br = br > H ? H : br;
+  *bands = (H + br - 1) / br;
+  return br;
 }
 
 __global__ void __launch_bounds__(256) k_point_sample_bwd_atomic(const float* __restrict__ grad_out,
@@ -283,6 +353,13 @@ extern "C" int mbv_point_sample_fwd(const float* src, const int32_t* src_index, 
   if ((int64_t)H * W <= kTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W) {
     hipLaunchKernelGGL(k_point_sample_fwd_lds, dim3(num_rows), dim3(512), 0, stream, src, src_index, coords,
                        coord_index, num_points, H, W, out);
+  } else if (W + W <= kTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W &&
+             (H + kTileFloats / W - 2) / (kTileFloats / W - 1) <= 64) {
+    // a map of several tiles sampled densely (the importance sampling of 256 x 256 logits): row bands through LDS
+    const int band_rows = kTileFloats / W - 1;                 // + 1 staged row for the lower taps
+    const int bands = (H + band_rows - 1) / band_rows;
+    hipLaunchKernelGGL(k_point_sample_fwd_bands, dim3((unsigned)num_rows * (unsigned)bands), dim3(512), 0, stream, src,
+                       src_index, coords, coord_index, num_points, H, W, bands, band_rows, out);
   } else {
     hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
                        src_index, coords, coord_index, num_points, H, W, out);
@@ -341,11 +418,14 @@ extern "C" int mbv_point_sample_bwd_stack(const float* grad_out, const int32_t* 
   if (num_rows <= 0 || num_points <= 0 || H <= 0 || W <= 0 || outer <= 0 || inner <= 0 || rows <= 0) return MBV_ERR_BAD_ARG;
   if (!grad_out || !src_index || !coords || !coord_index || !grad_src) return MBV_ERR_BAD_ARG;
   if (out_dtype != MBV_DT_F32 && out_dtype != MBV_DT_BF16 && out_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
-  // every map of the stack is sampled exactly once (no zero fill), in the LDS-tile form
-  if ((int64_t)num_rows != (int64_t)outer * inner * rows || num_rows > 65535 || (int64_t)H * W > kTileFloats)
+  // every map of the stack is sampled exactly once (no zero fill), in the LDS-tile form (larger maps: in row bands)
+  int bands = 0;
+  const int band_rows = lds_band_rows(H, W, &bands);
+  if ((int64_t)num_rows != (int64_t)outer * inner * rows || num_rows > 65535 || bands == 0 || bands > 64)
     return MBV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3(num_rows), dim3(1024), 0, stream, grad_out, src_index, coords,
-                     coord_index, num_points, H, W, grad_src, out_dtype, outer, inner, rows);
+  hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3((unsigned)num_rows * (unsigned)bands), dim3(1024), 0, stream, grad_out,
+                     src_index, coords, coord_index, num_points, H, W, grad_src, out_dtype, outer, inner, rows, bands,
+                     band_rows);
   MBV_CHECK_LAUNCH();
   return MBV_OK;
 }
@@ -358,15 +438,17 @@ extern "C" int mbv_point_sample_bwd(const float* grad_out, const int32_t* src_in
   if (!grad_src && num_src_maps > 0) return MBV_ERR_BAD_ARG;
   // The LDS form stores every sampled map's whole tile (src_index holds no duplicates): when every map is sampled —
   // num_rows == num_src_maps, the loss with all queries matched — nothing is left for the zero fill (262 MB, 35 us)
-  const bool lds_form = (int64_t)H * W <= kTileFloats;
+  int bands = 0;
+  const int band_rows = lds_band_rows(H, W, &bands);
+  const bool lds_form = bands >= 1 && bands <= 64;      // one LDS tile, or up to 64 row bands of the map
   if (!(lds_form && num_rows == num_src_maps && num_rows > 0))
     MBV_CHECK_HIP(mbv_fill_async(grad_src, 0, sizeof(float) * (size_t)num_src_maps * H * W, stream));
   if (num_rows == 0) return MBV_OK;
   if (!grad_out || !src_index || !coords || !coord_index) return MBV_ERR_BAD_ARG;
   if (num_rows > 65535) return MBV_ERR_UNSUPPORTED;
   if (lds_form) {
-    hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3(num_rows), dim3(1024), 0, stream, grad_out, src_index, coords,
-                       coord_index, num_points, H, W, grad_src, MBV_DT_F32, 0, 0, 0);
+    hipLaunchKernelGGL(k_point_sample_bwd_lds, dim3((unsigned)num_rows * (unsigned)bands), dim3(1024), 0, stream, grad_out,
+                       src_index, coords, coord_index, num_points, H, W, grad_src, MBV_DT_F32, 0, 0, 0, bands, band_rows);
   } else {
     hipLaunchKernelGGL(k_point_sample_bwd_atomic, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream,
                        grad_out, src_index, coords, coord_index, num_points, H, W, grad_src);

@@ -660,7 +660,7 @@ class Mask2FormerHead(nn.Module):
         """Per problem, the count K of real ground-truth columns for K9's padded mode (None: solve the square problem).  The
         dataset pads the instance list to num_queries with all-zero masks of label 0; a column counts as padding only if it
         has label 0 AND an empty mask AND every later column is padding too."""
-        if not (nq == ng <= 128 and isinstance(gt_flat, ops.PackedMasks) and switches.get('k9_padded')):
+        if not (nq == ng <= 320 and isinstance(gt_flat, ops.PackedMasks) and switches.get('k9_padded')):
             return None
         dev = labels_gt.device
         real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                      # (B, G)

@@ -3197,7 +3197,7 @@ class _PointSample(torch.autograd.Function):
         sink = ctx.sink
         if sink is not None:
             o, n, r = sink.dims
-            if g == n_src == o * n * r and g <= 65535 and h * w <= 16384:
+            if g == n_src == o * n * r and g <= 65535 and w <= 16384 and -(-h // max(1, 16384 // w)) <= 64:
                 sink.grad = torch.empty((n, o, r, h * w), dtype=sink.dtype, device=grad_out.device)
                 check(lib.mbv_point_sample_bwd_stack(_ptr(grad_out), _ptr(src_index), _ptr(coords), _ptr(coord_index), g, p,
                                                      h, w, o, n, r, _ptr(sink.grad), _dt_flag(sink.dtype), _stream()),
@@ -3279,14 +3279,14 @@ def hungarian(cost: torch.Tensor, out: Optional[torch.Tensor] = None,
     rows left out when R > C.  No host synchronisation (K9, include/maskbev_hip.h).
     ``real_cols`` (N,) int32 on the device: columns ``real_cols[n]`` … C-1 of problem n are identical padding (the
     dataset's zero-padded instance list) — the equivalent rectangular problem of the real columns is solved instead
-    (R <= C <= 128; same optimum, same real pairs when it is unique)."""
+    (R <= C <= 320; same optimum, same real pairs when it is unique)."""
     lib = _lib.load()
     _need_gpu(cost)
     cost = cost.to(torch.float32).contiguous()
     n, r, c = cost.shape
     if out is None:
         out = torch.empty((n, r), dtype=torch.int32, device=cost.device)
-    if real_cols is not None and r <= c <= 128:
+    if real_cols is not None and r <= c <= 320:
         real_cols = real_cols.to(torch.int32).contiguous()
         if real_cols.numel() != n or not real_cols.is_cuda:
             raise MaskBevHipError('hungarian: real_cols must be a device tensor with one entry per problem')

@@ -40,13 +40,15 @@ def test_hungarian_tied_columns_same_cost(device):
         assert real_ours == real_ref
 
 
-@pytest.mark.parametrize('q,g_slots', [(100, 100), (100, 128), (40, 40), (7, 9)])
+@pytest.mark.parametrize('q,g_slots', [(100, 100), (100, 128), (40, 40), (7, 9), (200, 200), (300, 300), (150, 260), (129, 129)])
 def test_hungarian_padded_columns_equal_the_square_solve(device, q, g_slots):
     """ops.hungarian(real_cols=K): the dataset's zero-padded instance list makes columns K .. G-1 identical, and K9
     solves the rectangular problem of the K real columns instead of the square one (mbv_hungarian_padded).  Against
     scipy on the full matrix: a permutation into G slots, the same optimal cost (f64 sums, rel 1e-9), and — generic
     real costs, unique optimum — exactly scipy's pairs on the real columns; predictions left over take the padded
-    columns in ascending order.  Problems with K = 0, K = G (no padding: the plain solve) and K of every size between."""
+    columns in ascending order.  Problems with K = 0, K = G (no padding: the plain solve) and K of every size between.
+    200 / 300 queries (BASELINE configs[3] / [4]): the wide kernel's padded mode, the real columns' block in LDS — and K
+    beyond what 128 KB of it hold (K = 299 of 300: the plain wide solve from global memory)."""
     from mask_bev_amd import ops
     gen = torch.Generator().manual_seed(q * 7 + g_slots)
     ks = [0, 1, min(q, g_slots) // 3, min(q, g_slots) - 1, min(q, g_slots), 5, 17 % (min(q, g_slots) + 1)]
