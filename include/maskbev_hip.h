@@ -212,6 +212,23 @@ int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch
                               void* workspace, size_t workspace_bytes, void* stream,
                               void* ev_start, void* ev_stop);
 
+/* The same backward with the AdamW update of the two (C, ny, nx) affine parameters fused into it (one GPU, one backward
+ * per optimizer step): their gradients are complete in registers inside this kernel (the batch sum is per thread), so they
+ * never go to memory — no grad_weight / grad_bias traffic, no read of them by mbv_adamw_step, no zero fill.  `weight` and
+ * `bias` (C, cells) f32 are read-modify-written together with their moments exp_avg_* / exp_avg_sq_* and, when given, their
+ * 16-bit shadows (`shadow_dtype` = MBV_DT_BF16 / MBV_DT_F16); the arithmetic is mbv_adamw_step's (torch/optim/adamw.py's
+ * single-tensor order; `step` >= 1 = the optimizer's step count INCLUDING this update; grad_scale 1, no loss scaling).
+ * Replaces: mmdet3d / torch nn.LayerNorm([C, ny, nx]) backward (mask_bev_encoders.py:75,92) + the optimizer step of those
+ * two parameters (mask_bev_module.py:131-166). */
+int mbv_scatter_layernorm_bwd_adamw(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
+                                    const int32_t* pillar_batch_start, const int32_t* cell_to_pillar, float* weight,
+                                    float* bias, const float* stats, int32_t batch, int32_t channels, int32_t ny, int32_t nx,
+                                    int64_t num_pillars, float* grad_feats, float* exp_avg_w, float* exp_avg_sq_w,
+                                    float* exp_avg_b, float* exp_avg_sq_b, void* shadow_w, void* shadow_b,
+                                    int32_t shadow_dtype, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    int64_t step, int32_t decoupled, void* workspace, size_t workspace_bytes, void* stream,
+                                    void* ev_start, void* ev_stop);
+
 /* ------------------------------------------------------------------------------------------------
  * K5 — multi-scale deformable attention of the pixel decoder, forward / backward.
  * Replaces: mmcv MultiScaleDeformableAttention's `ms_deform_attn_forward/backward` CUDA op (or its

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libmaskbev_hip.so')
 
-ABI_VERSION = 57
+ABI_VERSION = 58
 
 
 class MaskBevHipError(RuntimeError):
@@ -45,6 +45,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
                                                   _P, _P, _P, _P]),
     'mbv_scatter_layernorm_bwd': (ctypes.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _I, _P,
                                                  c_size_t, _P, _P, _P]),
+    'mbv_scatter_layernorm_bwd_adamw': (ctypes.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P,
+                                                       _P, _P, _I, _F, _F, _F, _F, _F, _L, _I, _P, c_size_t, _P, _P, _P]),
     'mbv_msda_prepare_supported': (ctypes.c_int, [_I, _I]),
     'mbv_pfn_forward_layout': (ctypes.c_int64, [_L, _L, _P, _I, _P]),
     'mbv_pfn_forward': (ctypes.c_int, [_P, _I, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _I, _P, _L, _P]),

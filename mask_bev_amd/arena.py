@@ -228,6 +228,59 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(arena.param)
         self.exp_avg_sq = torch.zeros_like(arena.param)
         self.steps = 0
+        self._k3 = None              # (weight, bias, offset_w, offset_b) of a LayerNorm whose update K3's backward performs
+        self._k3_applied = False
+
+    # -- K3 backward + AdamW of the (C, ny, nx) LayerNorm affine in one launch (csrc/scatter_layernorm.hip, ADAM) ------------
+    def fuse_layernorm_affine(self, weight: Optional[nn.Parameter], bias: Optional[nn.Parameter] = None) -> bool:
+        """Ask K3's backward to perform the AdamW update of ``weight`` / ``bias`` (the encoder's (C, ny, nx) LayerNorm affine,
+        a third of the model's parameters) itself: their gradients are complete in that kernel's registers, so they never
+        reach the arena — 16 B per parameter of gradient traffic less per step.  The CALLER guarantees one backward pass
+        per ``step()`` (the graph step does); a second pass before ``step()`` raises.  Not with a loss scaler (an overflowed
+        step must skip EVERY update, and the verdict is only known after the whole backward) and not with a gradient
+        all-reduce (``grad_scale`` != 1: the reduced gradient does not exist inside the kernel).  ``None`` disarms.
+        Returns whether the fusion is armed."""
+        if ops.K3_ADAM[0] is self:
+            ops.K3_ADAM[0] = None
+        self._k3, self._k3_applied = None, False
+        if weight is None or bias is None or self.scaler is not None or not self.zero_grad_in_step:
+            return False
+        off = {id(p): o for p, o in self.arena.layout}
+        if id(weight) not in off or id(bias) not in off or weight.shape != bias.shape:
+            return False
+        self._k3 = (weight, bias, off[id(weight)], off[id(bias)])
+        ops.K3_ADAM[0] = self
+        return True
+
+    def claim(self, weight, bias):
+        """Called by K3's backward: the optimizer state of (weight, bias) for the fused update, or None (not the armed
+        parameters / a data-parallel step).  Marks the update as applied for the coming ``step()``."""
+        k3 = self._k3
+        if k3 is None or weight is not k3[0] or bias is not k3[1] or float(self.grad_scale) != 1.0:
+            return None
+        if self._k3_applied:
+            raise _lib.MaskBevHipError('FlatAdam: K3 backward ran twice before step() with the fused LayerNorm-affine update '
+                                       'armed (gradient accumulation needs fuse_layernorm_affine(None))')
+        _, _, ow, ob = k3
+        pg = self._group_of(ow)
+        n = weight.numel()
+        if self._group_of(ob + n - 1) is not pg:
+            return None
+        ar = self.arena
+        self._k3_applied = True
+        return dict(m_w=self.exp_avg.data_ptr() + 4 * ow, v_w=self.exp_avg_sq.data_ptr() + 4 * ow,
+                    m_b=self.exp_avg.data_ptr() + 4 * ob, v_b=self.exp_avg_sq.data_ptr() + 4 * ob,
+                    sh_w=0 if ar.shadow is None else ar.shadow.data_ptr() + 2 * ow,
+                    sh_b=0 if ar.shadow is None else ar.shadow.data_ptr() + 2 * ob, shadow_flag=ar.shadow_flag,
+                    lr=float(pg['lr']), beta1=float(pg['betas'][0]), beta2=float(pg['betas'][1]), eps=float(pg['eps']),
+                    weight_decay=float(pg['weight_decay']), step=self.steps + 1, decoupled=1 if self.decoupled else 0)
+
+    def _group_of(self, offset: int):
+        for pg in self.param_groups:
+            a, b = self.arena.segments[pg['segment']]
+            if a <= offset < b:
+                return pg
+        return None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -252,6 +305,23 @@ class FlatAdam(torch.optim.Optimizer):
                 runs[-1][1] = b
             else:
                 runs.append([a, b, hp])
+        if self._k3_applied:
+            # K3's backward already updated these two parameters (and left their gradient range untouched: zero): cut their
+            # element ranges out of the launches
+            self._k3_applied = False
+            w, bp, ow, ob = self._k3
+            for lo in sorted((ow, ob), reverse=True):
+                hi = lo + _round_up(w.numel(), _ALIGN)
+                cut = []
+                for a, b, hp in runs:
+                    if lo >= b or hi <= a:
+                        cut.append([a, b, hp])
+                    else:
+                        if a < lo:
+                            cut.append([a, lo, hp])
+                        if hi < b:
+                            cut.append([hi, b, hp])
+                runs = cut
         sc = self.scaler
         if sc is not None:
             sc.check(ar.grad)

@@ -8,38 +8,11 @@
 // Reference: torch.optim.AdamW / Adam configured at /root/reference mask_bev/mask_bev_module.py:131-166
 // (single-tensor update order of torch/optim/adamw.py is followed so that results agree to f32 rounding).
 #include "common.hpp"
+#include "adam.hpp"
 
 #include <hip/hip_bf16.h>
 
 namespace {
-
-struct AdamArgs {
-  float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale;
-  int decoupled, zero_grad;
-  int shadow_kind;                 // MBV_DT_BF16 / MBV_DT_F16: storage of the weight shadow
-  const float* loss_scale;         // device scalar (nullable): gradients arrive multiplied by it (fp16 loss scaling)
-  const int* skip;                 // device flag (nullable): non-zero = the gradient held inf / nan, skip the update
-  const int* applied;              // device count of updates APPLIED so far (nullable): the bias corrections then use
-                                   //   t = *applied + 1 — torch.amp.GradScaler skips optimizer.step() on an overflow, so
-                                   //   Adam's step count must not advance there (a host count would)
-};
-
-__device__ __forceinline__ unsigned short shadow_bits(float p, int kind) {
-  return kind == MBV_DT_F16 ? __builtin_bit_cast(unsigned short, (_Float16)p) : f32_to_bf16_rne(p);
-}
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
-  g *= a.grad_scale;
-  if (a.decoupled) {
-    p *= 1.0f - a.lr * a.weight_decay;            // param.mul_(1 - lr * wd)
-  } else if (a.weight_decay != 0.0f) {
-    g += a.weight_decay * p;                      // Adam: L2 term folded into the gradient
-  }
-  m += (g - m) * (1.0f - a.beta1);                // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * a.beta2 + (1.0f - a.beta2) * g * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-  const float denom = sqrtf(v) / a.bias_correction2_sqrt + a.eps;
-  p -= (a.lr / a.bias_correction1) * (m / denom);
-}
 
 // 4 elements per thread per iteration (float4 loads: 16 B/lane, fully coalesced), grid-stride.
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ param, float* __restrict__ grad,

@@ -12,6 +12,7 @@
 //     16 B / lane coalesced access.
 // Algorithmic bytes per batch: 2*C*G*4 (weight + bias) + B*C*G*4 (out) + V*C*4 (+ B*G*4 cell map).
 #include "common.hpp"
+#include "adam.hpp"
 
 namespace {
 
@@ -325,7 +326,18 @@ __global__ void __launch_bounds__(256) k_ln_apply(const float* __restrict__ feat
 // backward, pass 1: grad_weight / grad_bias, per-scan sums of (g*w) and (g*w*xhat), and g*w at the
 // occupied cells scattered back into (pillar, channel) rows.
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int PATCH>
+// ADAM (round 6, one GPU): the AdamW update of the two (C, ny, nx) affine parameters — a third of the model's parameters —
+// happens HERE, where their gradients are complete in registers (the batch sum is per thread): the gradient never goes to
+// memory, so its accumulate read + write, the optimizer pass's read of it and its zero fill (16 B per parameter, 1.07 GB
+// at 128 x 512 x 512) are gone.  `weight` is then read-modify-written; grad_weight / grad_bias are not touched.
+struct LnAdam {
+  float* bias;                      // the LayerNorm bias parameter (the weight is the kernel's `weight`)
+  float *m_w, *v_w, *m_b, *v_b;     // exp_avg / exp_avg_sq of weight and bias
+  unsigned short *sh_w, *sh_b;      // 16-bit shadows (nullable)
+  AdamArgs a;
+};
+
+template <int VEC, int PATCH, bool ADAM = false>
 __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ grad_out_,
                                                       const float* __restrict__ feats,
                                                       const int32_t* __restrict__ cell_to_pillar,
@@ -333,7 +345,8 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
                                                       const float* __restrict__ stats, int batch, int channels,
                                                       int ny, int nx, int xtiles, float* __restrict__ grad_feats,
                                                       float* __restrict__ grad_weight, float* __restrict__ grad_bias,
-                                                      int accumulate, double* __restrict__ sums /* [batch][2] */) {
+                                                      int accumulate, double* __restrict__ sums /* [batch][2] */,
+                                                      const LnAdam ad = LnAdam{}) {
   // 8 waves x 4 channels (126 VGPRs: two workgroups per CU).  Per scan the 4 grad_out vectors of a thread are
   // requested FIRST, so that they are in flight underneath the two dependent round trips of the gather (cell →
   // pillar id → pillar row), and the pillar id of the next scan is prefetched.  The per-scan sums meet in LDS and
@@ -473,6 +486,43 @@ __global__ void __launch_bounds__(512) k_ln_bwd_dense(const void* __restrict__ g
       const int c = c0 + ch0 + k;
       if (c < channels) {
         const int64_t o = ((int64_t)c * ny + y) * nx + xv;
+        if constexpr (ADAM) {
+          float pb[VEC], mw[VEC], vw[VEC], mb[VEC], vb[VEC];
+          load_vec<VEC>(ad.bias + o, pb);
+          load_vec<VEC>(ad.m_w + o, mw);
+          load_vec<VEC>(ad.v_w + o, vw);
+          load_vec<VEC>(ad.m_b + o, mb);
+          load_vec<VEC>(ad.v_b + o, vb);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            adam_one(w[k][e], dw[k][e], mw[e], vw[e], ad.a);
+            adam_one(pb[e], db[k][e], mb[e], vb[e], ad.a);
+          }
+          store_vec<VEC>(const_cast<float*>(weight) + o, w[k]);
+          store_vec<VEC>(ad.bias + o, pb);
+          store_vec<VEC>(ad.m_w + o, mw);
+          store_vec<VEC>(ad.v_w + o, vw);
+          store_vec<VEC>(ad.m_b + o, mb);
+          store_vec<VEC>(ad.v_b + o, vb);
+          if (ad.sh_w) {
+            if constexpr (VEC == 4) {                     // o % 4 == 0: one 8-byte store per parameter run
+              const int kd = ad.a.shadow_kind;
+              *reinterpret_cast<uint2*>(ad.sh_w + o) =
+                  make_uint2((unsigned)shadow_bits(w[k][0], kd) | ((unsigned)shadow_bits(w[k][1], kd) << 16),
+                             (unsigned)shadow_bits(w[k][2], kd) | ((unsigned)shadow_bits(w[k][3], kd) << 16));
+              *reinterpret_cast<uint2*>(ad.sh_b + o) =
+                  make_uint2((unsigned)shadow_bits(pb[0], kd) | ((unsigned)shadow_bits(pb[1], kd) << 16),
+                             (unsigned)shadow_bits(pb[2], kd) | ((unsigned)shadow_bits(pb[3], kd) << 16));
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) {
+                ad.sh_w[o + e] = shadow_bits(w[k][e], ad.a.shadow_kind);
+                ad.sh_b[o + e] = shadow_bits(pb[e], ad.a.shadow_kind);
+              }
+            }
+          }
+          continue;
+        }
         if (accumulate) {
           float a[VEC], bb[VEC];
           load_vec<VEC>(grad_weight + o, a);
@@ -585,46 +635,44 @@ extern "C" int mbv_scatter_layernorm_fwd2(const float* feats, const int32_t* pil
   return MBV_OK;
 }
 
-extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
-                                         const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
-                                         const float* weight, const float* stats, int32_t batch, int32_t channels,
-                                         int32_t ny, int32_t nx, int64_t num_pillars, float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
-                                         void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
-                                         void* ev_stop) {
+static int ln_bwd_launch(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
+                         const int32_t* pillar_batch_start, const int32_t* cell_to_pillar, const float* weight,
+                         const float* stats, int32_t batch, int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
+                         float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream_, void* ev_start, void* ev_stop, const LnAdam* ad) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (batch <= 0 || channels <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0) return MBV_ERR_BAD_ARG;
   if (channels % 4 != 0) return MBV_ERR_UNSUPPORTED;
   if (patch != 0 && !mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch)) return MBV_ERR_UNSUPPORTED;
   if (patch != 0 && patch_dtype != MBV_DT_BF16 && patch_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
-  if (!grad_out || !feats || !pillar_batch_start || !cell_to_pillar || !weight || !stats || !grad_feats ||
-      !grad_weight || !grad_bias)
-    return MBV_ERR_BAD_ARG;
+  if (!grad_out || !feats || !pillar_batch_start || !cell_to_pillar || !weight || !stats || !grad_feats) return MBV_ERR_BAD_ARG;
+  if (!ad && (!grad_weight || !grad_bias)) return MBV_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mbv_scatter_layernorm_workspace_bytes(batch)) return MBV_ERR_WORKSPACE;
   double* sums = reinterpret_cast<double*>(workspace);
   MBV_CHECK_HIP(mbv_fill_async(sums, 0, sizeof(double) * 2 * batch, stream));
   const int ctiles = (channels + kCT - 1) / kCT;
   if (ev_start) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_start), stream));
+#define MBV_LN_BWD(VEC_, PATCH_)                                                                                          \
+  do {                                                                                                                   \
+    const int xtiles = (nx + Tile<VEC_>::XT - 1) / Tile<VEC_>::XT;                                                        \
+    if (ad)                                                                                                              \
+      hipLaunchKernelGGL((k_ln_bwd_dense<VEC_, PATCH_, true>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out,  \
+                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,   \
+                         grad_bias, accumulate, sums, *ad);                                                              \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_ln_bwd_dense<VEC_, PATCH_, false>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, \
+                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,   \
+                         grad_bias, accumulate, sums, LnAdam{});                                                         \
+  } while (0)
   if (patch) {
-    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    if (patch_dtype == MBV_DT_F16)
-      hipLaunchKernelGGL((k_ln_bwd_dense<4, MBV_DT_F16>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out,
-                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
-                         grad_bias, accumulate, sums);
-    else
-      hipLaunchKernelGGL((k_ln_bwd_dense<4, MBV_DT_BF16>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out,
-                         feats, cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
-                         grad_bias, accumulate, sums);
+    if (patch_dtype == MBV_DT_F16) MBV_LN_BWD(4, MBV_DT_F16);
+    else MBV_LN_BWD(4, MBV_DT_BF16);
   } else if (nx % 4 == 0) {
-    const int xtiles = (nx + Tile<4>::XT - 1) / Tile<4>::XT;
-    hipLaunchKernelGGL((k_ln_bwd_dense<4, 0>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
-                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
-                       grad_bias, accumulate, sums);
+    MBV_LN_BWD(4, 0);
   } else {
-    const int xtiles = (nx + Tile<1>::XT - 1) / Tile<1>::XT;
-    hipLaunchKernelGGL((k_ln_bwd_dense<1, 0>), dim3(xtiles * ny, ctiles), dim3(512), 0, stream, grad_out, feats,
-                       cell_to_pillar, weight, stats, batch, channels, ny, nx, xtiles, grad_feats, grad_weight,
-                       grad_bias, accumulate, sums);
+    MBV_LN_BWD(1, 0);
   }
+#undef MBV_LN_BWD
   MBV_CHECK_LAUNCH();
   if (ev_stop) MBV_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_stop), stream));
   if (num_pillars > 0) {
@@ -635,4 +683,45 @@ extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, in
     MBV_CHECK_LAUNCH();
   }
   return MBV_OK;
+}
+
+extern "C" int mbv_scatter_layernorm_bwd(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
+                                         const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
+                                         const float* weight, const float* stats, int32_t batch, int32_t channels,
+                                         int32_t ny, int32_t nx, int64_t num_pillars, float* grad_feats, float* grad_weight, float* grad_bias, int32_t accumulate,
+                                         void* workspace, size_t workspace_bytes, void* stream_, void* ev_start,
+                                         void* ev_stop) {
+  return ln_bwd_launch(grad_out, patch, patch_dtype, feats, pillar_batch_start, cell_to_pillar, weight, stats, batch, channels,
+                       ny, nx, num_pillars, grad_feats, grad_weight, grad_bias, accumulate, workspace, workspace_bytes, stream_,
+                       ev_start, ev_stop, nullptr);
+}
+
+extern "C" int mbv_scatter_layernorm_bwd_adamw(const void* grad_out, int32_t patch, int32_t patch_dtype, const float* feats,
+                                               const int32_t* pillar_batch_start, const int32_t* cell_to_pillar,
+                                               float* weight, float* bias, const float* stats, int32_t batch,
+                                               int32_t channels, int32_t ny, int32_t nx, int64_t num_pillars,
+                                               float* grad_feats, float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b,
+                                               float* exp_avg_sq_b, void* shadow_w, void* shadow_b, int32_t shadow_dtype,
+                                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                                               int64_t step, int32_t decoupled, void* workspace, size_t workspace_bytes,
+                                               void* stream_, void* ev_start, void* ev_stop) {
+  if (!weight || !bias || !exp_avg_w || !exp_avg_sq_w || !exp_avg_b || !exp_avg_sq_b || step < 1) return MBV_ERR_BAD_ARG;
+  if ((shadow_w == nullptr) != (shadow_b == nullptr)) return MBV_ERR_BAD_ARG;
+  if (shadow_w && shadow_dtype != MBV_DT_BF16 && shadow_dtype != MBV_DT_F16) return MBV_ERR_BAD_ARG;
+  if ((reinterpret_cast<size_t>(weight) | reinterpret_cast<size_t>(bias) | reinterpret_cast<size_t>(exp_avg_w) |
+       reinterpret_cast<size_t>(exp_avg_sq_w) | reinterpret_cast<size_t>(exp_avg_b) | reinterpret_cast<size_t>(exp_avg_sq_b)) & 15)
+    return MBV_ERR_BAD_ARG;
+  if (shadow_w && ((reinterpret_cast<size_t>(shadow_w) | reinterpret_cast<size_t>(shadow_b)) & 7)) return MBV_ERR_BAD_ARG;
+  LnAdam ad;
+  ad.bias = bias; ad.m_w = exp_avg_w; ad.v_w = exp_avg_sq_w; ad.m_b = exp_avg_b; ad.v_b = exp_avg_sq_b;
+  ad.sh_w = reinterpret_cast<unsigned short*>(shadow_w); ad.sh_b = reinterpret_cast<unsigned short*>(shadow_b);
+  AdamArgs& a = ad.a;
+  a.shadow_kind = shadow_dtype; a.loss_scale = nullptr; a.skip = nullptr; a.applied = nullptr;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  a.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.grad_scale = 1.0f; a.decoupled = decoupled; a.zero_grad = 0;
+  return ln_bwd_launch(grad_out, patch, patch_dtype, feats, pillar_batch_start, cell_to_pillar, weight, stats, batch, channels,
+                       ny, nx, num_pillars, grad_feats, nullptr, nullptr, 0, workspace, workspace_bytes, stream_, ev_start,
+                       ev_stop, &ad);
 }

@@ -434,7 +434,7 @@ VoxWorkspace carve_voxelize(void* ws, int64_t n, int batch) {
 
 }  // namespace
 
-extern "C" int mbv_abi_version(void) { return 57; }
+extern "C" int mbv_abi_version(void) { return 58; }
 
 extern "C" size_t mbv_voxelize_workspace_bytes(int64_t total_points, int32_t batch, int64_t /*cells_per_scan*/) {
   if (total_points < 0 || batch < 0) return 0;

@@ -104,6 +104,13 @@ class GraphedTrainStep:
             self.masks = ops.pack_binary_masks(masks.flatten(0, 1))
         else:
             self.masks = masks.clone()
+        # One GPU: the AdamW update of the encoder's (C, ny, nx) LayerNorm affine happens inside K3's backward (one backward
+        # per step here by construction); a data-parallel step needs the all-reduced gradient and keeps the plain form
+        self._k3_fused = False
+        if (reducer is None and switches.get('k3_adam') and getattr(module, '_arena', None) is not None
+                and hasattr(optimizer, 'fuse_layernorm_affine')):
+            ln = module._encoder._layer_norm
+            self._k3_fused = optimizer.fuse_layernorm_affine(ln.weight, ln.bias)
         self._graph_params = list(module._backbone.parameters()) + list(module._panoptic_head.parameters())
         # warm-up on a side stream (allocator / library workspaces / autotuning settle before capture)
         side = torch.cuda.Stream(device=dev)
@@ -279,3 +286,6 @@ class GraphedTrainStep:
 
     def close(self):
         self.m._panoptic_head._panoptic_head.overlap_matcher = self._overlap_prev
+        if self._k3_fused:
+            self.opt.fuse_layernorm_affine(None)
+            self._k3_fused = False

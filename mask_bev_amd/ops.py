@@ -518,6 +518,21 @@ class _ScatterLayerNorm(torch.autograd.Function):
             g_w = torch.empty_like(weight)
             g_b = torch.empty_like(weight)
         ws = _workspace(lib.mbv_scatter_layernorm_workspace_bytes(batch), dev)
+        fused = K3_ADAM[0].claim(wp, bp) if (direct and K3_ADAM[0] is not None) else None
+        if fused is not None:
+            # the step driver armed the optimizer for this pass (arena.FlatAdam.fuse_layernorm_affine): the AdamW update of
+            # the two affine parameters happens inside the launch, their gradients never reach the arena
+            rc = lib.mbv_scatter_layernorm_bwd_adamw(
+                _ptr(grad_out), ctx.patch, _dt_flag(ctx.patch_dtype) if ctx.patch else 0, _ptr(feats),
+                _ptr(pillar_batch_start), _ptr(cell_to_pillar), _ptr(wp.data), _ptr(bp.data), _ptr(stats), batch, c, ny, nx,
+                int(feats.shape[0]), _ptr(g_feats), fused['m_w'], fused['v_w'], fused['m_b'], fused['v_b'], fused['sh_w'],
+                fused['sh_b'], fused['shadow_flag'], fused['lr'], fused['beta1'], fused['beta2'], fused['eps'],
+                fused['weight_decay'], fused['step'], fused['decoupled'], _ptr(ws), ws.numel(), _stream(),
+                *TIMER.events('k_ln_bwd_dense')[2:])
+            check(rc, 'mbv_scatter_layernorm_bwd_adamw')
+            _fire_grad_hooks(wp)
+            _fire_grad_hooks(bp)
+            return (g_feats,) + (None,) * 11
         rc = lib.mbv_scatter_layernorm_bwd(_ptr(grad_out), ctx.patch, _dt_flag(ctx.patch_dtype) if ctx.patch else 0,
                                            _ptr(feats), _ptr(pillar_batch_start),
                                            _ptr(cell_to_pillar),
@@ -548,6 +563,11 @@ class PatchTokens:
 
 def patch_layout_supported(channels: int, ny: int, nx: int, patch: int) -> bool:
     return bool(_lib.load().mbv_scatter_layernorm_patch_supported(channels, ny, nx, patch))
+
+
+# The optimizer that asked for the AdamW update of K3's two affine parameters to be fused into K3's backward (one entry:
+# arena.FlatAdam.fuse_layernorm_affine arms it, FlatAdam.step() reads what was applied); None = the ordinary backward.
+K3_ADAM = [None]
 
 
 def scatter_layernorm(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, p: Pillars, batch: int, ny: int,

@@ -31,6 +31,7 @@ _DEFAULTS: Dict[str, Any] = {
     'loss_node': True,            # dice / BCE algebra as one autograd node
     'match_fused': True,          # matcher products on MFMA from half pairs, terms never written (K13c)
     'loss_glue': True,            # matching-cost assembly and the class loss as single launches (K13)
+    'k3_adam': True,              # one GPU, graph step: AdamW of the (C, ny, nx) LayerNorm affine inside K3's backward (their gradients never reach memory)
     'tn_overlap': False,          # early stages' grouped weight gradients beside the encoder backward (measured slower)
     'msda_bwd_overlap': False,    # K5 backward's two parts on two streams (measured slower)
     'wgrad_group': True,          # grouped small-token weight gradients / column sums at the end of a backward pass

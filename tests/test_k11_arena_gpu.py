@@ -341,3 +341,70 @@ def test_grouped_gradient_work_equals_per_layer_launches(device, monkeypatch):
         g1 = grads['1'][n]
         scale = float(g0.abs().max()) + 1e-12
         assert float((g0 - g1).abs().max()) <= 5e-3 * scale + 1e-9, n
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_layernorm_affine_update_inside_k3_backward_is_bit_identical(device, dtype):
+    """Round 6 (mbv_scatter_layernorm_bwd_adamw, FlatAdam.fuse_layernorm_affine): K3's backward performs the AdamW update
+    of the two (C, ny, nx) LayerNorm affine parameters itself — their gradients never reach the arena.  Against the plain
+    form (K3 backward accumulates into the arena gradient, mbv_adamw_step updates everything) from the same initial state,
+    on the same scans and upstream gradients, three steps: parameters, both moments and the 16-bit shadow BIT FOR BIT
+    (one definition of the update arithmetic, csrc/adam.hpp), the gradient range of the two parameters stays zero, a second
+    backward before step() raises, and a data-parallel gradient scale leaves the fusion unused."""
+    from mask_bev_amd import ops
+    from mask_bev_amd._lib import MaskBevHipError
+    from mask_bev_amd.mask_bev_module import MaskBevModule
+    kw = dict(tiny_kwargs(nx=96, ny=96, q=8), compute_dtype=dtype)
+    scans = [[x.to(device) for x in random_scans(kw, [2500, 3000], seed=s)] for s in range(3)]
+
+    def run(fused: bool):
+        torch.manual_seed(3)
+        m = MaskBevModule(**kw).to(device).train()
+        arena = m.flatten_parameters()
+        opt = m.configure_optimizers()['optimizer']
+        ln = m._encoder._layer_norm
+        assert opt.fuse_layernorm_affine(ln.weight if fused else None, ln.bias if fused else None) == fused
+        gen = torch.Generator(device='cpu').manual_seed(11)
+        for s in range(3):
+            with m._autocast():
+                x = m._encoder(scans[s], patch=m._patch_handoff())
+            rows = x.rows if isinstance(x, ops.PatchTokens) else x
+            up = (torch.randn(rows.shape, generator=gen) * 0.1).to(device=device, dtype=rows.dtype)
+            rows.backward(up)
+            if fused:
+                lo, hi = arena.range_of(ln)
+                assert float(arena.grad[lo:hi].abs().max()) == 0.0       # the gradient never reached the arena
+                if s == 0:
+                    with m._autocast():
+                        y = m._encoder(scans[s], patch=m._patch_handoff())
+                    yr = y.rows if isinstance(y, ops.PatchTokens) else y
+                    with pytest.raises(MaskBevHipError, match='twice before step'):
+                        yr.backward(up)
+            opt.step()
+        torch.cuda.synchronize()
+        out = (arena.param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+               None if arena.shadow is None else arena.shadow.clone())
+        opt.fuse_layernorm_affine(None)
+        assert ops.K3_ADAM[0] is None
+        return out
+
+    plain, fused = run(False), run(True)
+    for a, b, name in zip(plain, fused, ('param', 'exp_avg', 'exp_avg_sq', 'shadow')):
+        if a is not None:
+            assert torch.equal(a, b), f'{name}: max |diff| {float((a.float() - b.float()).abs().max()):.3e}'
+    # grad_scale != 1 (a data-parallel step): the claim is refused, the plain path runs
+    torch.manual_seed(3)
+    m = MaskBevModule(**kw).to(device).train()
+    arena = m.flatten_parameters()
+    opt = m.configure_optimizers()['optimizer']
+    ln = m._encoder._layer_norm
+    assert opt.fuse_layernorm_affine(ln.weight, ln.bias)
+    opt.grad_scale = 0.5
+    with m._autocast():
+        x = m._encoder(scans[0], patch=m._patch_handoff())
+    rows = x.rows if isinstance(x, ops.PatchTokens) else x
+    rows.backward(torch.ones_like(rows))
+    lo, hi = arena.range_of(ln)
+    assert float(arena.grad[lo:hi].abs().max()) > 0.0
+    opt.step()
+    opt.fuse_layernorm_affine(None)
