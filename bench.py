@@ -649,7 +649,7 @@ def main():
         # HBM bytes per launch measured with the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
         # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload: profiles/rNN/pmc_hbm_traffic.json
         traffic, traffic_file = {}, None
-        for rnd in ('r05', 'r04', 'r03'):                      # the latest round that holds a PMC pass of this workload
+        for rnd in ('r06', 'r05', 'r04', 'r03'):                      # the latest round that holds a PMC pass of this workload
             traffic_file = os.path.join('profiles', rnd, 'pmc_hbm_traffic.json')
             if os.path.exists(os.path.join(ROOT, traffic_file)):
                 break

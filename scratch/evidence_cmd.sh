@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"; rm -rf gpurun_out/ev; mkdir -p gpurun_out/ev
 bash scratch/pmc_cmd.sh > gpurun_out/ev/pmc.log 2>&1; cp gpurun_out/pmc_hbm_traffic.json gpurun_out/pmc_hbm_traffic.csv gpurun_out/ev/
-mkdir -p profiles/r05; cp gpurun_out/pmc_hbm_traffic.json profiles/r05/pmc_hbm_traffic.json      # the bench line below reads it
+mkdir -p profiles/r06; cp gpurun_out/pmc_hbm_traffic.json profiles/r06/pmc_hbm_traffic.json      # the bench line below reads it
 timeout 900 python3 bench.py --detail-out gpurun_out/ev/bench_detail.json > gpurun_out/ev/bench_default.json 2> gpurun_out/ev/bench_default.err; tail -c 300 gpurun_out/ev/bench_default.json
 bash scratch/prof_cmd.sh > gpurun_out/ev/prof.log 2>&1
 cp gpurun_out/prof_c/seq.txt gpurun_out/ev/kernel_sequence_one_step.txt; cp gpurun_out/prof_c/kernel_stats.csv gpurun_out/ev/kernel_stats.csv; cp gpurun_out/prof_c/agg.txt gpurun_out/ev/kernel_trace_by_step.txt; cp gpurun_out/prof_c/bench.json gpurun_out/ev/bench_under_rocprof.json
@@ -23,3 +23,6 @@ done
 bash scratch/pmc_busy_cmd.sh > gpurun_out/ev/pmc_busy.log 2>&1; cp gpurun_out/pmc_b/pmc_busy.csv gpurun_out/ev/pmc_busy.csv
 python3 scratch/show_bench.py gpurun_out/ev/bench_default.json 12
 head -24 gpurun_out/ev/kernel_trace_by_step.txt
+# round 6: RCCL executes the graph step's exchange at world size 1; BASELINE configs[3] / [4] on one GPU
+timeout 600 python3 bench.py --force-reducer --steps 60 --warmup 5 --no-cpu-baseline --no-fp32 --no-kernel-profile > gpurun_out/ev/bench_force_reducer.json 2> gpurun_out/ev/bench_force_reducer.err
+bash scratch/configs34_cmd.sh > gpurun_out/ev/configs34.log 2>&1; cp gpurun_out/c34/*_bench.json gpurun_out/c34/*_detail.json gpurun_out/c34/*_kernel_trace_by_step.txt gpurun_out/ev/
