@@ -642,10 +642,18 @@ def main():
         n_params = sum(p.numel() for p in model.parameters())
         # bf16 compute: the map leaves K3 (and its gradient comes back) as the backbone's bf16 patch rows
         io = 2.0 if model._patch_handoff() else 4.0
+        # round 6, one GPU: the AdamW update of the two (C, ny, nx) affine parameters runs inside K3's backward — per
+        # parameter it reads param + 2 moments and writes them + the 16-bit shadow (26 B) instead of the gradient round
+        # trip; the optimizer pass proper covers the other parameters, in however many launches it took (the family's
+        # bytes PER LAUNCH = the pass's bytes / launches per step)
+        k3_fused = bool(graphed is not None and getattr(graphed, '_k3_fused', False))
+        adam_launches = max(1.0, len(times.get('k_adamw') or []) / max(1, args.steps))
+        adam_params = n_params - (2 * c * cells if k3_fused else 0)
         algo = {'k_ln_apply': 2 * c * cells * 4.0 + args.batch * c * cells * io,
-                'k_ln_bwd_dense': args.batch * c * cells * io + (c * cells + 2 * c * cells + acc) * 4.0,
+                'k_ln_bwd_dense': (args.batch * c * cells * io + 2 * c * cells * 26.0) if k3_fused else
+                                  (args.batch * c * cells * io + (c * cells + 2 * c * cells + acc) * 4.0),
                 # K11: read param, grad, exp_avg, exp_avg_sq; write param, exp_avg, exp_avg_sq, zeroed grad, bf16 shadow
-                'k_adamw': n_params * (16.0 + 16.0 + 2.0)}
+                'k_adamw': adam_params * (16.0 + 16.0 + 2.0) / adam_launches}
         # HBM bytes per launch measured with the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
         # doubled: the gfx950 correction of MI355X_MICROARCH.md), same workload: profiles/rNN/pmc_hbm_traffic.json
         traffic, traffic_file = {}, None
@@ -693,7 +701,7 @@ def main():
                         scans_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f'dp{world}',
                         step='fwd + Hungarian loss + bwd + AdamW; inputs device-resident', launch='eager' if args.no_graph else 'hip-graph', tuned_gemm_table=tuned, grad_wire=(args.grad_wire if (world > 1 or force) else None),
                         forced_reducer=True if force else None, replica_param_checksum_spread=replica_spread,
-                        final_loss=final_loss,
+                        final_loss=final_loss, k3_adam_fused=k3_fused or None,
                         switches={k: v for k, v in switches._values.items() if v != switches.defaults()[k]}),
             roofline=dominant, roofline_all=ranked, roofline_traffic_source=traffic_file if traffic else None,
             # share of the step the table prices: sum of the families' time per step over the measured step time

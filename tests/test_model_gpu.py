@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
+    """MAX-NORM relative error, max|a - b| / max|b| — the meaning of "within 1e-3" in every whole-model comparison of this
+    file (and of __graft_entry__.smoke): logits near zero are measured against the tensor's scale, not against themselves
+    (an element-wise ratio is unbounded at a logit that crosses zero)."""
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
 
 
@@ -26,6 +29,7 @@ class _Teacher:
     def __init__(self, blocked=None, assignment=None, replace=True):
         self.blocked, self.assignment, self.replace = blocked, assignment, replace
         self.blocked_flips, self.assignment_raw, self._i = [], None, 0
+        self.row_flips = []          # per call: (B, Q) bool — queries whose attention-mask row differs from the oracle's
 
     def __enter__(self):
         from mask_bev_amd import ops
@@ -35,7 +39,10 @@ class _Teacher:
             logits, blocked = self._ml(*a, **k)
             i, self._i = self._i, self._i + 1
             if self.blocked is not None and i < len(self.blocked) and self.blocked[i].shape == blocked.shape:
-                self.blocked_flips.append((self.blocked[i] != blocked).sum())
+                diff = self.blocked[i] != blocked
+                self.blocked_flips.append(diff.sum())
+                q = diff.shape[-2]
+                self.row_flips.append(diff.reshape(diff.shape[0], -1, q, diff.shape[-1]).any(-1).any(1))
                 if self.replace:
                     blocked = self.blocked[i]
             return logits, blocked
@@ -349,6 +356,7 @@ def test_16bit_whole_model_against_fp32_oracle(device, capsys, dtype):
             cls, masks, _ = m(dscans)
         torch.cuda.synchronize()
         flips = [int(x) for x in teacher.blocked_flips]
+        row_flips = [r.cpu() for r in teacher.row_flips]
     loss = m.training_step((dscans, (labels.to(device), gt.to(device))), 1)
     m.scale_loss(loss).backward()
     errs = {'attention-mask bits that differ from the oracle\'s, per decoder layer': flips}
@@ -385,6 +393,27 @@ def test_16bit_whole_model_against_fp32_oracle(device, capsys, dtype):
     layer_bound = TOL['logits_any_layer'] if sum(flips) == 0 else 1.0
     assert errs['mask_logits_worst_layer'] < layer_bound
     assert errs['cls_logits_worst_layer'] < layer_bound
+    # ... and a bound that survives the flips: decoder output i of query (b, q) is compared at
+    # rounding level as long as no attention-mask row of THAT query differed in the calls before it (output i passes through
+    # layers 0 .. i-1, which took the masks of calls 0 .. i-1).  The other queries of its image reach it only through the
+    # self-attention (second order), hence twice the rounding bound; queries that did flip are on another trajectory.
+    if row_flips:
+        dirty = torch.zeros_like(row_flips[0])
+        worst_clean, n_clean = 0.0, 0
+        for i in range(10):
+            clean = ~dirty                                           # (B, Q) for output i
+            if bool(clean.any()):
+                d = (masks[i].float().cpu() - masks_ref[i].detach()).abs().flatten(2).amax(-1)      # (B, Q)
+                worst_clean = max(worst_clean, float(d[clean].max() / masks_ref[i].detach().abs().max()))
+                n_clean += int(clean.sum())
+            if i < len(row_flips):
+                dirty = dirty | row_flips[i].reshape(dirty.shape)
+        with capsys.disabled():
+            print(f'  mask logits of the queries whose mask rows had not flipped yet: worst layer {worst_clean:.4f} '
+                  f'over {n_clean} of {10 * dirty.numel()} (output, query) pairs; {int(dirty.sum())} of {dirty.numel()} queries '
+                  f'flipped somewhere')
+        assert n_clean >= dirty.numel()                              # at least the first output's worth
+        assert worst_clean < 2.0 * TOL['logits_any_layer']
     assert errs['loss'] < TOL['loss']
     assert worst < TOL['grad'] and worst_l2 < TOL['grad_l2']
 
