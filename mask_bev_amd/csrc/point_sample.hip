@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int kTileFloats = 16384;   // 64 KB LDS tile: 128 x 128 mask logits
+constexpr int kBandTileFloats = 35840;   // 140 KB of dynamic LDS for the row bands of a larger map (forward)
 
 __global__ void __launch_bounds__(256) k_point_sample_fwd(const float* __restrict__ src,
                                                           const int32_t* __restrict__ src_index,
@@ -111,7 +112,9 @@ __global__ void __launch_bounds__(512) k_point_sample_fwd_bands(const float* __r
                                                                 const float* __restrict__ coords,
                                                                 const int32_t* __restrict__ coord_index, int P, int H,
                                                                 int W, int bands, int band_rows, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+  // dynamic LDS, up to kBandTileFloats (140 KB): every band walks ALL the map's coordinates (8 bytes a point, 300 KB per
+  // over-sampled row), so FEW bands matter more than two workgroups per CU — 256 x 256 logits are 2 bands, not 5
+  extern __shared__ __attribute__((aligned(16))) float tile[];
   const int g = (int)blockIdx.x / bands, band = (int)blockIdx.x - g * bands;
   const int y0 = band * band_rows;
   const int y_end = (y0 + band_rows + 1) < H ? (y0 + band_rows + 1) : H;       // rows staged: [y0, y_end)
@@ -353,12 +356,20 @@ extern "C" int mbv_point_sample_fwd(const float* src, const int32_t* src_index, 
   if ((int64_t)H * W <= kTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W) {
     hipLaunchKernelGGL(k_point_sample_fwd_lds, dim3(num_rows), dim3(512), 0, stream, src, src_index, coords,
                        coord_index, num_points, H, W, out);
-  } else if (W + W <= kTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W &&
-             (H + kTileFloats / W - 2) / (kTileFloats / W - 1) <= 64) {
+  } else if (W + W <= kBandTileFloats && (int64_t)num_points * 8 >= (int64_t)H * W &&
+             (H + kBandTileFloats / W - 2) / (kBandTileFloats / W - 1) <= 64) {
     // a map of several tiles sampled densely (the importance sampling of 256 x 256 logits): row bands through LDS
-    const int band_rows = kTileFloats / W - 1;                 // + 1 staged row for the lower taps
+    int band_rows = kBandTileFloats / W - 1;                   // + 1 staged row for the lower taps
     const int bands = (H + band_rows - 1) / band_rows;
-    hipLaunchKernelGGL(k_point_sample_fwd_bands, dim3((unsigned)num_rows * (unsigned)bands), dim3(512), 0, stream, src,
+    band_rows = (H + bands - 1) / bands;                       // equal bands (the last one is not a sliver)
+    const size_t lds = (size_t)(band_rows + 1) * W * sizeof(float);
+    static bool attr_done = false;       // idempotent attribute of the code object, not library state
+    if (!attr_done) {
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_sample_fwd_bands),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileFloats * (int)sizeof(float)));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_point_sample_fwd_bands, dim3((unsigned)num_rows * (unsigned)bands), dim3(512), lds, stream, src,
                        src_index, coords, coord_index, num_points, H, W, bands, band_rows, out);
   } else {
     hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
