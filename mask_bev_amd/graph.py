@@ -250,7 +250,7 @@ class GraphedTrainStep:
 
             # the range holds weight AND bias: it goes on the wire when every parameter in it has announced itself
             # (RangeReady), not from one parameter's hook — K3's backward writes both in one launch before it fires the
-            # hooks (ops.py, _ScatterLayerNorm.backward), and this no longer depends on that
+            # hooks (ops_encoder.py, _ScatterLayerNorm.backward), and this no longer depends on that
             guard = RangeReady(list(ln.parameters()), launch_ln).arm()
             try:
                 mark('encoder backward (eager)')

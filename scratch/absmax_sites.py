@@ -2,7 +2,7 @@
 import sys, os, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from mask_bev_amd import ops
+from mask_bev_amd import ops, ops_records, ops_gemm
 sites, byts = collections.Counter(), collections.Counter()
 orig = ops.f32_absmax
 def spy(tensors):
@@ -11,7 +11,9 @@ def spy(tensors):
     sites[key] += 1
     byts[key] += sum(t.numel() * 4 for t in tensors)
     return orig(tensors)
-ops.f32_absmax = spy
+# f32_absmax is resolved inside ops_records (operand_amax) and ops_gemm (the K20 wrappers): spy in both
+ops_records.f32_absmax = spy
+ops_gemm.f32_absmax = spy
 orig_group = ops.gemm32s_tn_group
 seen = collections.Counter()
 def spy_group(items):
@@ -22,7 +24,7 @@ def spy_group(items):
                 t = it[j]
                 seen[('g' if j == 0 else 'x', tuple(t.shape), t.stride(0), t._base is not None)] += 1
     return orig_group(items)
-ops.gemm32s_tn_group = spy_group
+ops_gemm.gemm32s_tn_group = spy_group
 import bench
 sys.argv = ['bench.py', '--dtype', 'fp32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-fp32', '--no-kernel-profile'] + (['--no-graph'] if os.environ.get('EAGER', '1') == '1' else [])
 bench.main()

@@ -3,7 +3,10 @@ import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
+# a step ends with the optimizer pass: one k_adamw launch, or a run of adjacent ones (round 6: the pass is cut around the
+# LayerNorm-affine range that K3's backward updates itself) — the LAST launch of a run is the delimiter
+idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']
+       and (i + 1 >= len(rows) or 'k_adamw' not in rows[i + 1]['Kernel_Name'])]
 a, b = idx[-6], idx[-1]
 seg = rows[a + 1:b + 1]
 n = 5

@@ -3,7 +3,10 @@ start (us from the step's first kernel), gap to the previous kernel's end on any
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']]
+# a step ends with the optimizer pass: one k_adamw launch, or a run of adjacent ones (round 6: the pass is cut around the
+# LayerNorm-affine range that K3's backward updates itself) — the LAST launch of a run is the delimiter
+idx = [i for i, r in enumerate(rows) if 'k_adamw' in r['Kernel_Name']
+       and (i + 1 >= len(rows) or 'k_adamw' not in rows[i + 1]['Kernel_Name'])]
 seg = rows[idx[-2] + 1:idx[-1] + 1]
 t0 = int(seg[0]['Start_Timestamp'])
 end = t0

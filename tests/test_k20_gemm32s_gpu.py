@@ -175,13 +175,14 @@ def test_fp32_linear_takes_k20_and_matches_float64(arena):
     gy = _rand((4, 1024, 576), 5, 1e-4)
     if arena:
         ParameterArena([('l', lin)], shadow_dtype=None)
+    from mask_bev_amd import ops_gemm as G          # (the Linear resolves gemm32s_nt in its own module, not through the `ops` facade)
     calls = []
-    orig = ops.gemm32s_nt
-    ops.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    orig = G.gemm32s_nt
+    G.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
         y = ops.linear(x, lin.weight, lin.bias)
     finally:
-        ops.gemm32s_nt = orig
+        G.gemm32s_nt = orig
     assert calls, 'the f32 Linear did not take K20'
     y.backward(gy)
     ops.flush_deferred_grads()
@@ -192,11 +193,11 @@ def test_fp32_linear_takes_k20_and_matches_float64(arena):
     assert _err(lin.bias.grad, gd.flatten(0, 1).sum(0)) <= 2e-6
     with switches.override(gemm32s=False):
         calls.clear()
-        ops.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        G.gemm32s_nt = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
         try:
             y2 = ops.linear(x.detach(), lin.weight, lin.bias)
         finally:
-            ops.gemm32s_nt = orig
+            G.gemm32s_nt = orig
         assert not calls and _err(y2.detach(), y.detach().double()) <= 4e-6
 
 
