@@ -349,7 +349,21 @@ def time_other_dtype(args, dtype, device, pool, steps, warmup, exact_f32_steps=0
         # most time per step (K3's two kernels and the optimizer pass are not bracketed here: ≈ 1.7 ms of the step)
         try:
             prof = kernel_profile(model, opt, pool[0], steps=1)
-            ranked = rank_profile(prof, {})
+            # measured HBM bytes per launch of this dtype's families, from the committed PMC passes of the same workload
+            traffic = {}
+            if args.workload == 'semantic_kitti_512' and args.batch == 4 and args.distribution == 'lidar':
+                for rnd in ('r06', 'r05'):
+                    tf = os.path.join(ROOT, 'profiles', rnd, f'{dtype}_pmc_hbm_traffic.json')
+                    if os.path.exists(tf):
+                        with open(tf) as fh:
+                            raw = json.load(fh)
+                        traffic = {k: v for k, v in raw.items() if not k.startswith('_')}
+                        for k in raw.get('_per_step', []):
+                            if k in traffic and k in prof and prof[k]['launches_per_step'] > 0:
+                                traffic[k] = traffic[k] / prof[k]['launches_per_step']
+                        out['roofline_traffic_source'] = os.path.join('profiles', rnd, f'{dtype}_pmc_hbm_traffic.json')
+                        break
+            ranked = rank_profile(prof, traffic)
             out['roofline'] = ranked[0] if ranked else None
             out['roofline_all'] = [dict(kernel=r['kernel'], bound=r['bound'], frac=r['frac'],
                                         total_ms_per_step=r['total_ms_per_step'], launches_per_step=r['launches_per_step'])
@@ -445,7 +459,7 @@ def compact_line(full: dict, detail_path=None) -> dict:
     if f32:
         line['fp32'] = {k: (_roofline_object(v) if k == 'roofline' else v) for k, v in f32.items()
                         if k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'roofline',
-                                 'roofline_coverage', 'error', 'arithmetic', 'exact_f32')}
+                                 'roofline_coverage', 'error', 'arithmetic', 'exact_f32', 'roofline_traffic_source')}
     if full.get('collectives'):
         line['collectives'] = full['collectives']
     cb = full.get('cpu_baseline')

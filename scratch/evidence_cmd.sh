@@ -13,7 +13,7 @@ bash scratch/phase_cmd.sh > gpurun_out/ev/phase.log 2>&1; cp gpurun_out/prof_p/p
 # fp32: the precision the reference trains in
 PROF_OUT=prof_f32 bash scratch/prof_cmd.sh --dtype fp32 > gpurun_out/ev/prof_f32.log 2>&1
 cp gpurun_out/prof_f32/kernel_stats.csv gpurun_out/ev/fp32_kernel_stats.csv; cp gpurun_out/prof_f32/agg.txt gpurun_out/ev/fp32_kernel_trace_by_step.txt; cp gpurun_out/prof_f32/bench.json gpurun_out/ev/fp32_bench_under_rocprof.json
-PMC_OUT=fp32_pmc_hbm_traffic bash scratch/pmc_cmd.sh --dtype fp32 > gpurun_out/ev/pmc_f32.log 2>&1; cp gpurun_out/fp32_pmc_hbm_traffic.json gpurun_out/fp32_pmc_hbm_traffic.csv gpurun_out/ev/
+PMC_OUT=fp32_pmc_hbm_traffic bash scratch/pmc_cmd.sh --dtype fp32 > gpurun_out/ev/pmc_f32.log 2>&1; cp gpurun_out/fp32_pmc_hbm_traffic.json gpurun_out/fp32_pmc_hbm_traffic.csv gpurun_out/ev/; cp gpurun_out/fp32_pmc_hbm_traffic.json profiles/r06/fp32_pmc_hbm_traffic.json      # (the next bench line's fp32 object reads it)
 for cfg in "--dtype fp16" "--distribution uniform"; do
   name=$(echo $cfg | awk '{print $2}')
   timeout 600 python3 bench.py $cfg --no-cpu-baseline --no-kernel-profile --no-fp32 > gpurun_out/ev/bench_$name.json 2> gpurun_out/ev/bench_$name.err

@@ -18,16 +18,17 @@ FAMILIES = [   # (bench name, primary kernel regex, regexes of kernels charged t
     ('k_gemm16<NN>', r'k_gemm16I.*Lb0ELb1ELi0E', [r'k_sum_rows']),
     ('k_gemm16<NT>', r'k_gemm16I.*Lb0ELb0ELi0ELi[0-4]E', []),
     ('k_gemm16<NT,conv3x3>', r'k_gemm16I.*Lb0ELb0ELi0ELi5E', []),
-    # K20 (fp32 runs): template arguments <A_KS, B_KS, EPI, GATHER>
-    ('k_gemm32s<NT>', r'k_gemm32sILb0ELb0ELi[012]ELi0E', []),
-    ('k_gemm32s<NT,patch>', r'k_gemm32sILb0ELb0ELi0ELi1E', []),
-    ('k_gemm32s<NT,conv3x3>', r'k_gemm32sILb0ELb0ELi0ELi4E', []),
+    # K20 (fp32 runs): template arguments <A_KS, B_KS, EPI, GATHER> — rocprofv3 prints these kernels demangled (round 6: the
+    # mangled-only patterns matched nothing and the fp32 line's roofline.traffic stayed null)
+    ('k_gemm32s<NT>', r'k_gemm32sILb0ELb0ELi[012]ELi0E|k_gemm32s<false, false, [012], 0>', []),
+    ('k_gemm32s<NT,patch>', r'k_gemm32sILb0ELb0ELi0ELi1E|k_gemm32s<false, false, 0, 1>', []),
+    ('k_gemm32s<NT,conv3x3>', r'k_gemm32sILb0ELb0ELi0ELi4E|k_gemm32s<false, false, 0, 4>', []),
     ('k_conv_pad_rows', r'k_(un)?pad_rows', []),
-    ('k_gemm32s<NN>', r'k_gemm32sILb0ELb1ELi0ELi0E', []),
-    ('k_gemm32s<NN,dact>', r'k_gemm32sILb0ELb1ELi[34]ELi0E', []),
-    ('k_gemm32s<NN,patch>', r'k_gemm32sILb0ELb1ELi0ELi2E', []),
-    ('k_gemm32s<TN>', r'k_gemm32sILb1ELb1ELi0ELi0E', [r'k_add_parts32']),
-    ('k_gemm32s<TN,patch>', r'k_gemm32sILb1ELb1ELi0ELi3E', []),
+    ('k_gemm32s<NN>', r'k_gemm32sILb0ELb1ELi0ELi0E|k_gemm32s<false, true, 0, 0>', []),
+    ('k_gemm32s<NN,dact>', r'k_gemm32sILb0ELb1ELi[34]ELi0E|k_gemm32s<false, true, [34], 0>', []),
+    ('k_gemm32s<NN,patch>', r'k_gemm32sILb0ELb1ELi0ELi2E|k_gemm32s<false, true, 0, 2>', []),
+    ('k_gemm32s<TN>', r'k_gemm32sILb1ELb1ELi0ELi0E|k_gemm32s<true, true, 0, 0>', [r'k_add_parts32']),
+    ('k_gemm32s<TN,patch>', r'k_gemm32sILb1ELb1ELi0ELi3E|k_gemm32s<true, true, 0, 3>', []),
     ('k_gemm32s_tn_group', r'k_gemm32s_tn_group', []),
     ('k_absmax_group', r'k_absmax_group', []),
     ('k_adamw', r'k_adamw', []),
