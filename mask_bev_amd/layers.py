@@ -193,6 +193,10 @@ def conv1x1(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         y = ops.conv1x1_tokens(x.permute(0, 2, 3, 1).reshape(b, h * w, c), conv.weight.view(conv.weight.shape[0], c),
                                conv.bias)
         return y.view(b, -1, h, w)
+    if x.is_cuda:
+        # one node whose bias gradient is a product with a ones block (autograd's own would be a multi-workgroup ATen
+        # reduction of 65 536 elements per channel: not replay-safe inside a captured HIP graph on this stack)
+        return ops.conv1x1_rows(x.flatten(2), conv.weight.view(conv.weight.shape[0], c), conv.bias).view(b, -1, h, w)
     w2 = conv.weight.view(conv.weight.shape[0], c).unsqueeze(0).expand(b, -1, -1)
     x2 = x.flatten(2)
     if conv.bias is None:

@@ -663,7 +663,13 @@ class Mask2FormerHead(nn.Module):
         if not (nq == ng <= 320 and isinstance(gt_flat, ops.PackedMasks) and switches.get('k9_padded')):
             return None
         dev = labels_gt.device
-        real = (labels_gt != 0) | (gt_flat.words.view(b, ng, -1).amax(-1) != 0)                      # (B, G)
+        # "the packed mask holds a set bit" in TWO reduction stages of <= 128 words per output: a one-stage reduction of 8 192
+        # words per mask is split by ATen over several workgroups that meet through a memset-cleared semaphore — not
+        # replay-safe inside a captured HIP graph on this stack (scratch/dbg_graph_reduce.py)
+        words = gt_flat.words.view(b, ng, -1)
+        nw = words.shape[-1]
+        any_bit = (words.view(b, ng, nw // 128, 128).amax(-1).amax(-1) if nw % 128 == 0 and nw > 128 else words.amax(-1))
+        real = (labels_gt != 0) | (any_bit != 0)                                                     # (B, G)
         last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)                # (B,) = K
         return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()
 

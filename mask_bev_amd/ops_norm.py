@@ -298,6 +298,21 @@ def pos_tokens(ape: torch.Tensor, batch: int, h: int, w: int) -> torch.Tensor:
     return _PosTokens.apply(ape, int(batch), int(h), int(w))
 
 
+_ONES: dict = {}
+
+
+def _ones_block(n: int, dtype, device) -> torch.Tensor:
+    """Cached (n, 8) block of ones (a row-sum as a GEMM: eight identical columns keep the product off the GEMV paths)."""
+    key = (int(n), dtype, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise MaskBevHipError('conv1x1_tokens: first use inside a stream capture (run one eager step first)')
+        t = _ONES[key] = torch.ones((n, 8), dtype=dtype, device=device)
+        torch.cuda.current_stream(device).synchronize()      # (read by every stream from here on)
+    return t
+
+
 class _Conv1x1Tokens(torch.autograd.Function):
     """A 1 x 1 convolution of a CHANNELS-LAST map handed over as tokens: ``y (B, Cout, HW) = W (Cout, Cin) · x[b]^T + bias``
     for ``x (B, HW, Cin)`` — the backbone's stage outputs are token-major and the pixel decoder's ConvModules want NCHW,
@@ -335,13 +350,60 @@ class _Conv1x1Tokens(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.bmm(gy, xc, **od).sum(0).to(w_dtype)
         if b_dtype is not None and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2), dtype=torch.float32).to(b_dtype)
+            # bias gradient = sum over (batch, pixels) per channel — as a product with a ones block, NOT `gy.sum((0, 2))`:
+            # ATen reduces 65 536 elements per output in several workgroups that meet through a semaphore which it clears
+            # with a memset, and inside a captured HIP graph that pair replays with STALE results on this stack
+            # (scratch/dbg_graph_reduce.py).  The batch sum behind it is 4 elements per output: one block.
+            ones = _ones_block(gy.shape[2], gy.dtype, gy.device)
+            gb = torch.bmm(gy, ones.unsqueeze(0).expand(b, -1, -1), **od)[:, :, 0].sum(0).to(b_dtype)
         return gx, gw, gb
 
 
 def conv1x1_tokens(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """x (B, HW, Cin) tokens, weight (Cout, Cin) → (B, Cout, HW)."""
     return _Conv1x1Tokens.apply(x, weight, bias)
+
+
+class _Conv1x1Rows(torch.autograd.Function):
+    """The same 1 x 1 convolution for an NCHW-contiguous map, ``y (B, Cout, HW) = W · x[b] + bias`` with x (B, Cin, HW), as ONE
+    node (round 6).  As plain ``torch.baddbmm`` the broadcast bias's gradient was autograd's ``sum`` of the (B, Cout, HW)
+    gradient down to (1, Cout, 1) — 65 536 elements per output at the mask-feature projection: a multi-workgroup ATen reduction,
+    which replays with stale results inside a captured HIP graph on this stack (see `_Conv1x1Tokens.backward`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+        with torch.autocast('cuda', enabled=False):
+            xc = x.to(dt)
+            wc = _compute_copy(weight, dt)
+            b = x.shape[0]
+            w3 = wc.unsqueeze(0).expand(b, -1, -1)
+            y = torch.bmm(w3, xc) if bias is None else torch.baddbmm(_compute_copy(bias, dt).view(1, -1, 1), w3, xc)
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc = ctx.saved_tensors
+        x_dtype, w_dtype, b_dtype = ctx.meta
+        gy = gy.to(xc.dtype).contiguous()
+        b = xc.shape[0]
+        od = {} if xc.dtype == torch.float32 else dict(out_dtype=torch.float32)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.bmm(wc.t().unsqueeze(0).expand(b, -1, -1), gy).to(x_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy, xc.transpose(1, 2), **od).sum(0).to(w_dtype)
+        if b_dtype is not None and ctx.needs_input_grad[2]:
+            ones = _ones_block(gy.shape[2], gy.dtype, gy.device)
+            gb = torch.bmm(gy, ones.unsqueeze(0).expand(b, -1, -1), **od)[:, :, 0].sum(0).to(b_dtype)
+        return gx, gw, gb
+
+
+def conv1x1_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x (B, Cin, HW) (an NCHW map, flattened), weight (Cout, Cin) → (B, Cout, HW)."""
+    return _Conv1x1Rows.apply(x, weight, bias)
 
 
 class _GroupNorm(torch.autograd.Function):
