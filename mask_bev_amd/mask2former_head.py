@@ -668,7 +668,8 @@ class Mask2FormerHead(nn.Module):
         # replay-safe inside a captured HIP graph on this stack (scratch/dbg_graph_reduce.py)
         words = gt_flat.words.view(b, ng, -1)
         nw = words.shape[-1]
-        any_bit = (words.view(b, ng, nw // 128, 128).amax(-1).amax(-1) if nw % 128 == 0 and nw > 128 else words.amax(-1))
+        inner = next((k for k in range(min(256, nw), 15, -1) if nw % k == 0), 0) if nw > 256 else 0     # 512 x 512: 8 192 words = 32 x 256
+        any_bit = words.view(b, ng, nw // inner, inner).amax(-1).amax(-1) if inner else words.amax(-1)
         real = (labels_gt != 0) | (any_bit != 0)                                                     # (B, G)
         last = (real.to(torch.int32) * (self._iota(ng, dev).view(1, ng) + 1)).amax(-1)                # (B,) = K
         return last.to(torch.int32).view(1, b).expand(d, b).reshape(-1).contiguous()

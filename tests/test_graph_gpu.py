@@ -74,18 +74,19 @@ def test_graph_replay_matches_eager(device):
     g.close()
 
 
-def _bench_model(device, batch=2, dtype='bf16'):
+def _bench_model(device, batch=2, dtype='bf16', workload='semantic_kitti_512'):
     from mask_bev_amd import synthetic
     from mask_bev_amd.mask_bev_module import MaskBevModule
     torch.manual_seed(420)
-    m = MaskBevModule(**synthetic.module_kwargs('semantic_kitti_512', batch, compute_dtype=dtype)).to(device).train()
+    m = MaskBevModule(**synthetic.module_kwargs(workload, batch, compute_dtype=dtype)).to(device).train()
     m.log_scalars = False
     arena = m.flatten_parameters()
-    data = [synthetic.make_batch('semantic_kitti_512', batch, 0, s, device) for s in range(3)]
+    data = [synthetic.make_batch(workload, batch, 0, s, device) for s in range(3)]
     return m, arena, data
 
 
-def test_no_multi_workgroup_aten_reduction_inside_the_captured_graphs(device):
+@pytest.mark.parametrize('workload,batch', [('semantic_kitti_512', 2), ('kitti_496x432', 1)])
+def test_no_multi_workgroup_aten_reduction_inside_the_captured_graphs(device, workload, batch):
     """Round 6: on this stack (torch 2.10 + ROCm 7) an ATen reduction that is split over several workgroups per output —
     `x.abs().max()` of a big tensor, a column sum over thousands of rows — replays with STALE results inside a captured HIP
     graph: the workgroups meet through a semaphore that ATen clears with a memset, and the captured memset / kernel pair does
@@ -97,7 +98,7 @@ def test_no_multi_workgroup_aten_reduction_inside_the_captured_graphs(device):
     import collections
     from torch.utils._python_dispatch import TorchDispatchMode
     from mask_bev_amd.graph import GraphedTrainStep
-    m, arena, data = _bench_model(device)
+    m, arena, data = _bench_model(device, batch=batch, workload=workload)
     opt = m.configure_optimizers()['optimizer']
     red = ('sum', 'amax', 'amin', 'max', 'min', 'mean', 'norm', 'prod', 'any', 'all', 'argmax', 'argmin', 'var', 'std',
            'logsumexp', 'count_nonzero')
