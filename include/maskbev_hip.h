@@ -273,8 +273,9 @@ int mbv_ms_deform_attn_bwd_split(int32_t head_dim, int32_t num_levels, const int
  * of the f64 form, all levels in one launch, order-independent (integer) sums.  The scale is taken per block from
  * L1 = sum over queries of (|attention weights| of the level) x (largest |grad_out| of the block's channels), an upper
  * bound of every pixel's sum for any sampling pattern, so the 32-bit halves cannot wrap; addends are rounded to
- * 2^-30 of that bound's power of two.  head_dim == 32, num_points == 4, every level map <= 4096
- * pixels (the limit of the split backward, whose location / weight part the caller runs next), host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
+ * 2^-30 of that bound's power of two.  head_dim == 32, num_points == 4, every level map <= 16 384 pixels (one 128 KB plane of
+ * packed pairs per block in dynamic LDS; the location / weight part the caller runs next is mbv_ms_deform_attn_bwd_locattn,
+ * gathers without a map-size limit), host shapes required.  grad_value is written in `out_dtype` (MBV_DT_F32 / BF16 / F16) with `out_ld` elements between
  * consecutive (batch, value) rows — e.g. straight into the first H*D columns of the 16-bit matrix
  * [d value | d offsets | d logits] whose product with [Wv; Wo; Wa] is d(x).  Every element of that block is written
  * (no zero fill needed).  `_supported` returns 1 when the shape qualifies.  A first launch

@@ -1228,9 +1228,14 @@ extern "C" int mbv_ms_deform_attn_bwd_value_packed_supported(int32_t head_dim, i
                                                              int32_t num_query, const int64_t* spatial_shapes_host) {
   if (!spatial_shapes_host || head_dim != 32 || num_points != 4 || num_levels <= 0 || num_levels > 8) return 0;
   if (num_query <= 0 || num_query > (1 << 18)) return 0;            // >= 12 fractional bits
-  // The caller follows the packed value part with the location / weight part of the split backward (part = 2), which
-  // exists only in the no-global-atomics form: every level map <= 4096 pixels (one 32 KB plane of packed pairs here).
-  return mbv_ms_deform_attn_bwd_split(head_dim, num_levels, spatial_shapes_host);
+  // One u64 plane (two channels) of a level's map per block in dynamic LDS: <= 16 384 pixels (128 KB; round 6 — until then
+  // 4 096, the f64 split form's limit, which sent the 128 x 128 level of the 1024 x 1024 BEV configuration to the banded f64
+  // kernel).  The location / weight part that follows is mbv_ms_deform_attn_bwd_locattn (gathers: no map-size limit).
+  for (int l = 0; l < num_levels; ++l) {
+    const int64_t h = spatial_shapes_host[2 * l], w = spatial_shapes_host[2 * l + 1];
+    if (h <= 0 || w <= 0 || h * w > 16384) return 0;
+  }
+  return 1;
 }
 
 extern "C" size_t mbv_ms_deform_attn_bwd_value_packed_workspace_bytes(int32_t batch, int32_t num_heads, int32_t num_levels,
@@ -1303,6 +1308,18 @@ extern "C" int mbv_ms_deform_attn_bwd_value_packed(const float* grad_out, const 
   }
   A.block_begin[num_levels] = blocks;
   const dim3 grid((unsigned)blocks), block(512);
+  if (max_pix_bytes > 65536) {           // a large level's plane: more than the default dynamic-LDS limit
+    static bool attr_done = false;       // idempotent attribute of the code objects, not library state
+    if (!attr_done) {
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value_fx<MBV_DT_F32>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value_fx<MBV_DT_BF16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      MBV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msda_bwd_value_fx<MBV_DT_F16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      attr_done = true;
+    }
+  }
   if (out_dtype == MBV_DT_F32)
     hipLaunchKernelGGL(k_msda_bwd_value_fx<MBV_DT_F32>, grid, block, (size_t)max_pix_bytes, stream, A);
   else if (out_dtype == MBV_DT_BF16)

@@ -75,14 +75,11 @@ def _msda_backward(lib, g_out, value, shapes_t, level_start, loc, attn, dims, ho
         check(lib.mbv_ms_deform_attn_bwd_value_packed(_ptr(g_out), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt, host,
                                                       _ptr(dst), _dt_flag(dst.dtype), int(ld), _ptr(ws), ws.numel(), _stream()),
               'mbv_ms_deform_attn_bwd_value_packed')
-        if value.dtype in _LO_DTYPES:                    # the 16-bit value map of the 16-bit compute modes
-            check(lib.mbv_ms_deform_attn_bwd_locattn(_ptr(g_out), _ptr(value), _dt_flag(value.dtype), _ptr(shapes_t),
-                                                     _ptr(level_start), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt,
-                                                     _ptr(g_loc), _ptr(g_attn), _stream()), 'mbv_ms_deform_attn_bwd_locattn')
-            return
-        check(lib.mbv_ms_deform_attn_bwd(_ptr(g_out), _ptr(value), _ptr(shapes_t), _ptr(level_start), _ptr(loc),
-                                         _ptr(attn), b, nv, nh, d, nl, nq, npnt, host, _ptr(None), _ptr(g_loc),
-                                         _ptr(g_attn), 2, _stream()), 'mbv_ms_deform_attn_bwd')
+        # d(location), d(weight): gathers from the value map in its own dtype (16-bit in the 16-bit compute modes, f32 in the
+        # fp32 mode) — no limit on a level's size, unlike part 2 of mbv_ms_deform_attn_bwd's split form
+        check(lib.mbv_ms_deform_attn_bwd_locattn(_ptr(g_out), _ptr(value), _dt_flag(value.dtype), _ptr(shapes_t),
+                                                 _ptr(level_start), _ptr(loc), _ptr(attn), b, nv, nh, d, nl, nq, npnt,
+                                                 _ptr(g_loc), _ptr(g_attn), _stream()), 'mbv_ms_deform_attn_bwd_locattn')
         return
     _msda_backward_f64(lib, g_out, value, shapes_t, level_start, loc, attn, dims, host, g_value, g_loc, g_attn)
 
