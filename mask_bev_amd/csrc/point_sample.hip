@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512) k_point_sample_fwd_lds(const float* __res
 // [y0, y0 + band_rows] of the map — band_rows + 1 rows: the lower taps of its last row — and samples the points whose
 // UPPER tap row, clamped to [0, H - 1], lies in [y0, y0 + band_rows): every point belongs to exactly one band.  The
 // bilinear arithmetic is bil_setup's on the whole map (same weights, same sum order: bit-identical to the gather form).
-__global__ void __launch_bounds__(512) k_point_sample_fwd_bands(const float* __restrict__ src,
+__global__ void __launch_bounds__(1024) k_point_sample_fwd_bands(const float* __restrict__ src,
                                                                 const int32_t* __restrict__ src_index,
                                                                 const float* __restrict__ coords,
                                                                 const int32_t* __restrict__ coord_index, int P, int H,
@@ -369,7 +369,7 @@ extern "C" int mbv_point_sample_fwd(const float* src, const int32_t* src_index, 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileFloats * (int)sizeof(float)));
       attr_done = true;
     }
-    hipLaunchKernelGGL(k_point_sample_fwd_bands, dim3((unsigned)num_rows * (unsigned)bands), dim3(512), lds, stream, src,
+    hipLaunchKernelGGL(k_point_sample_fwd_bands, dim3((unsigned)num_rows * (unsigned)bands), dim3(1024), lds, stream, src,
                        src_index, coords, coord_index, num_points, H, W, bands, band_rows, out);
   } else {
     hipLaunchKernelGGL(k_point_sample_fwd, dim3((num_points + 255) / 256, num_rows), dim3(256), 0, stream, src,
