@@ -8,6 +8,7 @@
 #  3. committed table + new rows -> gpurun_out/tune_<workload>/gemm_merged.csv, and a same-box A/B of the two tables
 cd "$GRAFT_REPO_ROOT"; WL=${1:-kitti_496x432}; DT=${2:-bf16}; OUT=gpurun_out/tune_$WL; rm -rf $OUT; mkdir -p $OUT
 cp mask_bev_amd/tuned/gemm_gfx950.csv $OUT/base.csv
+export PYTORCH_TUNABLEOP_ROCBLAS_ENABLED=0   # hipBLASLt solutions or Default only (tests/test_host_cpu.py)
 PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=0 PYTORCH_TUNABLEOP_RECORD_UNTUNED=1 \
 PYTORCH_TUNABLEOP_UNTUNED_FILENAME=$OUT/untuned.csv PYTORCH_TUNABLEOP_FILENAME=$OUT/base.csv \
   timeout 600 python3 bench.py --workload $WL --dtype $DT --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-profile --no-fp32 > $OUT/record.log 2>&1
