@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(1024) k_scan_partials(uint32_t* __restrict__ p
 }
 
 // `in` may alias `out` (in-place scan of the radix histogram): no __restrict__ on them.
-__global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* in, int64_t n,
+__global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* in, int64_t n_in, int64_t n,
                                                              const uint32_t* __restrict__ partials, uint32_t* out) {
   __shared__ uint32_t lds[4];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* in,
   uint32_t s = 0;
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
-    v[j] = (base + j < n) ? in[base + j] : 0u;
+    v[j] = (base + j < n_in) ? in[base + j] : 0u;
     s += v[j];
   }
   uint32_t tot;
@@ -139,14 +139,18 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* in,
   }
 }
 
-int launch_exclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* partials, hipStream_t s) {
+// out[i] = sum of in[0 .. i) for i < n.  `in` holds n_in <= n elements (elements from n_in on count as zero and are never
+// read): the row-start scan has one more output than inputs (row_start[V] = K) and must not read past the caller's array.
+int launch_exclusive_scan(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* partials, hipStream_t s,
+                          int64_t n_in = -1) {
   if (n <= 0) return 0;
+  if (n_in < 0 || n_in > n) n_in = n;
   const int64_t nb = (n + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, n, partials);
+  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, n_in, partials);
   MBV_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, nb);
   MBV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, n, partials, out);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, n_in, n, partials, out);
   MBV_CHECK_LAUNCH();
   return 0;
 }
@@ -512,8 +516,10 @@ extern "C" int mbv_voxelize(const float* points, int32_t point_dim, int64_t tota
     MBV_CHECK_HIP(mbv_fill_async(counts, 0, sizeof(int32_t) * (batch + 2), stream));
   }
   // row_start = exclusive scan of num_points (zero beyond V), K = row_start[V]
+  // (num_points has pillar_capacity entries, row_start one more: the scan's last input does not exist)
   int rc = launch_exclusive_scan(reinterpret_cast<const uint32_t*>(num_points),
-                                 reinterpret_cast<uint32_t*>(row_start), pillar_capacity + 1, w.partials, stream);
+                                 reinterpret_cast<uint32_t*>(row_start), pillar_capacity + 1, w.partials, stream,
+                                 pillar_capacity);
   if (rc) return rc;
   hipLaunchKernelGGL(k_total_rows, dim3(1), dim3(64), 0, stream, row_start, counts, batch);
   MBV_CHECK_LAUNCH();
