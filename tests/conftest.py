@@ -9,6 +9,8 @@ eaten by faulthandler's all-thread dump).  Hence:
   *before* it runs, with a running ``passed=N`` every 25 tests;
 * per-kernel parity tests are collected before whole-model, graph, launcher and multi-process tests, so a
   fault in the latter cannot hide the former's results.
+
+``MBV_TEST_POISON=1`` runs the suite with every uninitialised torch allocation poisoned (see ``pytest_configure``).
 """
 import faulthandler
 import os
@@ -40,6 +42,13 @@ def _scratch_dir():
 @pytest.hookimpl(trylast=True)
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if os.environ.get('MBV_TEST_POISON') == '1':
+        # audit mode (round 6): every `torch.empty` — outputs handed to the library and its workspaces alike — arrives filled
+        # with NaN / the integer maximum instead of whatever the caching allocator last held there, so a kernel that reads
+        # memory it was supposed to write first fails its parity test every time instead of once in a while
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     d = _scratch_dir()
     if d is None:
         return
